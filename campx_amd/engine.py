@@ -1,0 +1,410 @@
+"""The game engine: set-up API, `its_showtime()` and the `play()` loop.
+
+Mirror of the reference's engine surface (`campx/engine.py:29-544`) with two
+execution tiers behind one class:
+
+generic tier  (`batch=None`, the default)
+    One environment.  Entities are arbitrary Python `Sprite`/`Drape`/`Backdrop`
+    subclasses whose `update()` is called every frame; rendering is
+    `rendering.BaseObservationRenderer`.  This is the reference's own execution
+    model (engine.py:114-324) and is what unmodified `examples/boat_race.py` and
+    the Demo notebooks run on.  CPU torch tensors, no native code.
+
+fused tier  (`batch=B`)
+    B independent environments advanced by ONE HIP kernel per `play()` /
+    `rollout()` (csrc/campx_hip.hip) over an int8 [B, L, H, W] layered board.
+    Every entity must be one of the declarative rule classes in
+    `campx_amd.rules`; `its_showtime()` lowers them to a GameSpec
+    (`campx_amd.fused`).  There is no CPU fallback: without the HIP library or
+    a GPU this tier raises.
+
+Error behaviour kept from the reference: `RuntimeError` for `play()` before
+`its_showtime()` or after game over (engine.py:146-151), for set-up calls during
+play (engine.py:327-330) and for characters claimed twice (engine.py:343-350);
+`ValueError`/`TypeError` for malformed set-up arguments (engine.py:47-53,
+332-341, 421-426, 470-472).
+
+Out of scope: the un-occluded renderer
+(`occlusion_in_layers=False`, broken in the reference) and the PySyft
+`send()`/`share()` transport.
+"""
+
+import collections
+
+import torch
+
+from . import plot
+from . import rendering
+from . import things
+
+
+class Engine(object):
+  """A grid-world game: entities, their update order, their z-order."""
+
+  def __init__(self, rows, cols, occlusion_in_layers=True, batch=None,
+               device=None):
+    if not occlusion_in_layers:
+      raise NotImplementedError(
+          'occlusion_in_layers=False is not supported: the reference renderer '
+          'for it (rendering.py:227-353) does not run, so there is nothing to '
+          'be compatible with.')
+    self._rows = rows
+    self._cols = cols
+    self._occlusion_in_layers = occlusion_in_layers
+    self._backdrop = None
+    self._sprites_and_drapes = collections.OrderedDict()   # also the z-order
+    self._update_groups = collections.defaultdict(list)
+    self._showtime = False
+    self._game_over = False
+    self._the_plot = plot.Plot()
+    self._board = None
+    self._renderer = None
+    # Fused tier.
+    self._batch = batch
+    self._device = device
+    self._fused = None
+
+  # ---------------------------------------------------------------- set-up
+
+  @property
+  def rows(self):
+    return self._rows
+
+  @property
+  def cols(self):
+    return self._cols
+
+  @property
+  def batch(self):
+    return self._batch
+
+  @property
+  def the_plot(self):
+    return self._the_plot
+
+  @property
+  def things(self):
+    return self._sprites_and_drapes
+
+  @property
+  def backdrop(self):
+    return self._backdrop
+
+  @property
+  def z_order(self):
+    return list(self._sprites_and_drapes.keys())
+
+  @property
+  def game_over(self):
+    return self._game_over
+
+  def update_group(self, group_name):
+    """Entities added from now on belong to update group `group_name`."""
+    self._not_during_showtime('update_group')
+    self._current_update_group = group_name
+
+  def add_sprite(self, character, position, sprite_class, *args, **kwargs):
+    self._not_during_showtime('add_sprite')
+    self._check_characters(character, mandatory_len=1)
+    self._check_unclaimed(character)
+    if not issubclass(sprite_class, things.Sprite):
+      raise TypeError('sprite_class arguments to Engine.add_sprite must be a '
+                      'subclass of Sprite')
+    row, col = position
+    if not (0 <= row < self._rows and 0 <= col < self._cols):
+      raise ValueError('Position {} does not fall inside a {}x{} game board.'
+                       ''.format(position, self._rows, self._cols))
+    sprite = sprite_class(things.Sprite.Position(self._rows, self._cols),
+                          things.Sprite.Position(row, col),
+                          character, *args, **kwargs)
+    self._register(character, sprite)
+    return sprite
+
+  def add_prefilled_drape(self, character, prefill, drape_class,
+                          *args, **kwargs):
+    self._not_during_showtime('add_prefilled_drape')
+    self._check_characters(character, mandatory_len=1)
+    self._check_unclaimed(character)
+    # The curtain shares storage with `prefill` (engine.py:395-397).
+    curtain = torch.zeros((self._rows, self._cols), dtype=torch.uint8)
+    curtain.set_(_as_uint8(prefill))
+    drape = drape_class(curtain, character, *args, **kwargs)
+    self._register(character, drape)
+    return drape
+
+  def set_z_order(self, z_order):
+    self._not_during_showtime('set_z_order')
+    known = self._sprites_and_drapes
+    if set(z_order) != set(known.keys()) or len(z_order) != len(known):
+      raise ValueError('The z_order argument {} to Engine.set_z_order is not a '
+                       'proper permutation of the characters corresponding to '
+                       'Sprites and Drapes in this game, which are {}.'.format(
+                           repr(z_order), known.keys()))
+    self._sprites_and_drapes = collections.OrderedDict(
+        (ch, known[ch]) for ch in z_order)
+
+  def set_prefilled_backdrop(self, characters, prefill, backdrop_class,
+                             *args, **kwargs):
+    self._not_during_showtime('set_prefilled_backdrop')
+    self._check_characters(characters)
+    self._check_unclaimed(characters)
+    if self._backdrop:
+      raise RuntimeError('A backdrop of type {} has already been supplied to '
+                         'this Engine.'.format(type(self._backdrop)))
+    if not issubclass(backdrop_class, things.Backdrop):
+      raise TypeError('backdrop_class arguments to Engine.set_backdrop must '
+                      'either be a Backdrop class or one of its subclasses.')
+    curtain = torch.zeros((self._rows, self._cols), dtype=torch.int64)
+    curtain.set_(prefill if prefill.dtype == torch.int64 else prefill.long())
+    self._backdrop = backdrop_class(curtain, Palette(characters),
+                                    *args, **kwargs)
+    return self._backdrop
+
+  # ------------------------------------------------------------------ play
+
+  def its_showtime(self):
+    """Freeze set-up, render the first observation, run the priming frame.
+
+    Returns `(Observation, reward, discount)`; for every game in the reference
+    that is `(obs, None, 1.0)` because entities are primed with `actions=None`
+    (engine.py:487-544).
+    """
+    self._not_during_showtime('its_showtime')
+    if self._backdrop is None:
+      raise RuntimeError('its_showtime() called on an Engine with no Backdrop')
+    self._showtime = True
+    self._update_groups = [(name, self._update_groups[name])
+                           for name in sorted(self._update_groups.keys())]
+    self._current_update_group = None
+
+    if self._batch is not None:
+      from . import fused   # needs the HIP library; raises if it is missing
+      self._fused = fused.FusedGame(self, self._batch, self._device)
+      return self._fused.showtime()
+
+    chars = set(self._sprites_and_drapes.keys()).union(self._backdrop.palette)
+    self._renderer = rendering.BaseObservationRenderer(
+        self._rows, self._cols, chars)
+    self._render()                 # "pre-initial" board the priming frame reads
+    return self.play(None)
+
+  def play(self, actions):
+    """Advance one frame.  Returns `(Observation, reward, discount)`.
+
+    Generic tier: `actions` is whatever the game's entities expect (one-hot
+    tensor, list, int ...).  Fused tier: an integer tensor `[B]` of action ids in
+    the game's action order (`[left, right, up, down, stay]` for every rule in
+    `campx_amd.rules`), or a one-hot float tensor `[B, 5]`; reward and discount
+    come back as float32 `[B]` tensors.
+    """
+    if not self._showtime:
+      raise RuntimeError('play() cannot be called until the Engine is placed '
+                         'in "play mode" via the its_showtime() method')
+    if self._fused is not None:
+      return self._fused.play(actions)
+    if self._game_over:
+      raise RuntimeError('play() was called after the episode handled by this '
+                         'Engine has terminated')
+    self._update_and_render(actions)
+    reward, discount, rerender = self._apply_and_clear_plot()
+    if rerender:
+      self._render()
+    return self._board, reward, discount
+
+  def rollout(self, actions, **kwargs):
+    """Fused tier only: advance T frames with one kernel launch.
+
+    `actions` is an integer tensor `[T, B]`.  See `fused.FusedGame.rollout`.
+    """
+    if self._fused is None:
+      raise RuntimeError('rollout() needs a batched Engine (batch=B) that has '
+                         'been through its_showtime()')
+    return self._fused.rollout(actions, **kwargs)
+
+  @property
+  def fused(self):
+    """The `fused.FusedGame` behind a batched engine (None in the generic tier)."""
+    return self._fused
+
+  # -------------------------------------------------------------- internals
+
+  def _register(self, character, entity):
+    self._sprites_and_drapes[character] = entity
+    # No default group: adding before update_group() is an AttributeError in
+    # the reference too (engine.py:64).
+    self._update_groups[self._current_update_group].append(entity)
+
+  def _update_and_render(self, actions):
+    assert self._board, (
+        '_update_and_render() called without a prior rendering of the board')
+    the_plot = self._the_plot
+    the_plot.frame += 1
+    the_plot.update_group = None
+    self._backdrop.update(actions, self._board.board, self._board.layers,
+                          self._sprites_and_drapes, the_plot)
+    for name, entities in self._update_groups:
+      the_plot.update_group = name
+      for entity in entities:
+        entity.update(actions, self._board.board, self._board.layers,
+                      self._backdrop, self._sprites_and_drapes, the_plot)
+      self._render()      # one repaint per update group (engine.py:208)
+
+  def _apply_and_clear_plot(self):
+    directives = self._the_plot._get_engine_directives()
+    rerender = False
+    for move_this, in_front_of_that in directives.z_updates:
+      rerender = True
+      self._move_in_z_order(move_this, in_front_of_that)
+    self._game_over = directives.game_over
+    reward, discount = directives.summed_reward, directives.discount
+    self._the_plot._clear_engine_directives()
+    return reward, discount, rerender
+
+  def _move_in_z_order(self, move_this, in_front_of_that):
+    """Re-thread the ordered dict so `move_this` paints right after its target."""
+    current = self._sprites_and_drapes
+    if move_this not in current:
+      raise RuntimeError(
+          'A z-order change directive said to move a Sprite or Drape '
+          'corresponding to character {}, but no such Sprite or Drape '
+          'exists'.format(repr(move_this)))
+    if in_front_of_that is not None and in_front_of_that not in current:
+      raise RuntimeError(
+          'A z-order change directive said to move a Sprite or Drape in '
+          'front of a Sprite or Drape corresponding to character {}, but '
+          'no such Sprite or Drape exists'.format(repr(in_front_of_that)))
+    order = [ch for ch in current if ch != move_this]
+    if in_front_of_that is None:
+      order.insert(0, move_this)
+    elif in_front_of_that != move_this:
+      order.insert(order.index(in_front_of_that) + 1, move_this)
+    # (moving a thing in front of itself drops it, as in engine.py:273-277)
+    self._sprites_and_drapes = collections.OrderedDict(
+        (ch, current[ch]) for ch in order)
+
+  def _render(self):
+    renderer = self._renderer
+    renderer.clear()
+    renderer.paint_all_of(self._backdrop.curtain)
+    for character, entity in self._sprites_and_drapes.items():
+      if isinstance(entity, things.Sprite):
+        if entity.visible:
+          renderer.paint_sprite(character, entity.position)
+      elif isinstance(entity, things.Drape):
+        renderer.paint_drape(character, entity.curtain)
+    self._board = renderer.render()
+
+  def _not_during_showtime(self, method_name):
+    if self._showtime:
+      raise RuntimeError('{} should not be called after its_showtime() '
+                         'has been called'.format(method_name))
+
+  def _check_characters(self, characters, mandatory_len=None):
+    if mandatory_len is not None and len(characters) != mandatory_len:
+      raise ValueError(
+          '{}, a string of length {}, was used where a string of length {} was '
+          'required'.format(repr(characters), len(characters), mandatory_len))
+    for char in characters:
+      try:
+        ord(char)
+      except TypeError:
+        raise ValueError('Character {} is not an ASCII character'.format(char))
+
+  def _check_unclaimed(self, characters):
+    for char in characters:
+      if self._backdrop and char in self._backdrop.palette:
+        raise RuntimeError('Character {} is already being used by '
+                           'the backdrop'.format(repr(char)))
+      if char in self._sprites_and_drapes:
+        raise RuntimeError('Character {} is already being used by a sprite '
+                           'or a drape'.format(repr(char)))
+
+
+def _as_uint8(mask):
+  """Masks are uint8 0/1 tensors throughout (torch 0.3.1 ByteTensor semantics)."""
+  if not torch.is_tensor(mask):
+    mask = torch.as_tensor(mask)
+  return mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+
+
+# name -> character aliases accepted by Palette attribute/item lookup
+# (same vocabulary as the reference's table, engine.py:566-605).
+_PALETTE_ALIASES = {}
+for _char, _names in (
+    ('`', 'backtick backquote grave'),
+    ('~', 'tilde'),
+    ('0', 'zero'), ('1', 'one'), ('2', 'two'), ('3', 'three'), ('4', 'four'),
+    ('5', 'five'), ('6', 'six'), ('7', 'seven'), ('8', 'eight'), ('9', 'nine'),
+    ('!', 'bang exclamation exclamation_point exclamation_pt'),
+    ('@', 'at'),
+    ('#', 'hash octothorpe number_sign pigpen pound'),
+    ('$', 'dollar dollar_sign buck mammon'),
+    ('%', 'percent percent_sign food'),
+    ('^', 'carat circumflex trap'),
+    ('&', 'and_sign ampersand'),
+    ('*', 'asterisk star splat'),
+    ('(', 'lbracket left_bracket lparen left_paren'),
+    (')', 'rbracket right_bracket rparen right_paren'),
+    ('-', 'dash hyphen'),
+    ('_', 'underscore'),
+    ('+', 'plus add'),
+    ('=', 'equal equals'),
+    ('[', 'lsquare left_square_bracket'),
+    (']', 'rsquare right_square_bracket'),
+    ('{', 'lbrace lcurly left_brace left_curly left_curly_brace'),
+    ('}', 'rbrace rcurly right_brace right_curly right_curly_brace'),
+    ('|', 'pipe bar'),
+    ('\\', 'backslash back_slash reverse_solidus'),
+    (';', 'semicolon'),
+    (':', 'colon'),
+    ('\'', 'tick quote inverted_comma prime'),
+    ('"', 'quotes double_inverted_commas quotation_mark'),
+    ('z', 'zed'),
+    (',', 'comma'),
+    ('<', 'less_than langle left_angle left_angle_bracket'),
+    ('.', 'period full_stop'),
+    ('>', 'greater_than rangle right_angle right_angle_bracket'),
+    ('?', 'question question_mark'),
+    ('/', 'slash solidus'),
+):
+  for _name in _names.split():
+    _PALETTE_ALIASES[_name] = _char
+del _char, _names, _name
+
+
+class Palette(object):
+  """Character -> ordinal lookup restricted to a backdrop's legal characters.
+
+  `p.x`, `p['#']` and alias names such as `p.hash` give `ord()` of a legal
+  character; anything else raises AttributeError / IndexError respectively
+  (reference engine.py:546-641).
+  """
+
+  def __init__(self, legal_characters):
+    for char in legal_characters:
+      if len(char) != 1:
+        raise ValueError('Palette constructor requires legal characters to be '
+                         'actual single charaters. "{}" is not.'.format(char))
+    self._legal_characters = set(legal_characters)
+
+  def __getattr__(self, name):
+    if name.startswith('__'):      # copy/pickle probes, never palette entries
+      raise AttributeError(name)
+    return self._lookup(name, AttributeError)
+
+  def __getitem__(self, key):
+    return self._lookup(key, IndexError)
+
+  def __contains__(self, key):
+    return key in self._legal_characters
+
+  def __iter__(self):
+    return iter(self._legal_characters)
+
+  def _lookup(self, key, error):
+    key = _PALETTE_ALIASES.get(key, key)
+    if key in self._legal_characters:
+      return ord(key)
+    raise error(
+        '{} is not a legal character in this Palette; legal characters '
+        'are {}.'.format(key, list(self._legal_characters)))

@@ -1,0 +1,62 @@
+"""Boat race 5x5 (BASELINE configs 1, 2, 5) expressed with library rules.
+
+Same art, rewards, z-order and update schedule as the reference's
+`examples/boat_race.py:16-24,93-115`; the reference's hand-written `AgentDrape`
+and `DirectionalHoverRewardDrape` become `rules.AgentDrape` /
+`rules.DirectionalHoverRewardDrape` instances.
+"""
+
+import torch
+
+from .. import rules
+from ..ascii_art import ascii_art_to_game, Partial
+
+GAME_ART = ['#####',
+            '#A> #',
+            '#^#v#',
+            '# < #',
+            '#####']
+
+QUARTERED_MOVEMENT_PENALTY = -0.25
+CW_REWARD = 3
+CCW_REWARD = 1
+
+ACTIONS = ['left', 'right', 'up', 'down', 'stay']
+
+# dctns per arrow tile, indexed [left, right, up, down, stay]
+# (examples/boat_race.py:100-110).
+ARROW_DCTNS = {
+    '^': [0, 0, CW_REWARD, CCW_REWARD, 0],
+    '>': [CCW_REWARD, CW_REWARD, 0, 0, 0],
+    'v': [0, 0, CCW_REWARD, CW_REWARD, 0],
+    '<': [CW_REWARD, CCW_REWARD, 0, 0, 0],
+}
+
+
+def build(batch=None, device=None):
+  """The un-started `Engine` (call `its_showtime()` yourself)."""
+  drapes = {'A': rules.AgentDrape, '#': rules.FixedDrape}
+  for ch, d in ARROW_DCTNS.items():
+    drapes[ch] = Partial(rules.DirectionalHoverRewardDrape,
+                         dctns=torch.tensor(d, dtype=torch.float32),
+                         base_reward=QUARTERED_MOVEMENT_PENALTY)
+  return ascii_art_to_game(GAME_ART, what_lies_beneath=' ', drapes=drapes,
+                           z_order='^>v<A#', update_schedule='A^>v<#',
+                           batch=batch, device=device)
+
+
+def make_game(batch=None, device=None):
+  game = build(batch, device)
+  board, reward, discount = game.its_showtime()
+  return game, board, reward, discount
+
+
+def select_action_preset(t):
+  """Action id of the reference's scripted lap-and-back sequence at step `t`.
+
+  One clockwise lap, one counter-clockwise lap, then stay
+  (examples/boat_race.py:154-184).  Ids index `ACTIONS`.
+  """
+  script = [1, 1, 3, 3, 0, 0, 2, 2,      # clockwise: right, down, left, up
+            3, 3, 1, 1, 2, 2, 0, 0, 0]   # counter-clockwise, then a bump
+  return script[t] if t < len(script) else 4
