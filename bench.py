@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec, boat race 5x5, 65 536 environments per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" of this bench = one pass of the hot path over one batch of synthetic
+input = ONE rollout launch: an episode of `--frames` (default 100, the
+reference's episode length, examples/reinforce.py:36) consecutive Engine.play()
+frames for every environment of the rank's shard, rebuilt from the art at the
+start (make_game() per episode, reinforce.py:122), on a committed-seed random
+action stream already resident in HBM.  Every frame's layered board
+[B, L, H, W] int8, reward, discount and done flag are written to HBM
+(trajectory buffers [T, B, ...]), nothing is skipped or cached.
+
+Multi-GPU: environments are independent, so the batch is sharded (weak scaling:
+65 536 per rank) with NO collective on the step path; after each episode the
+ranks all-gather their per-environment episode returns over RCCL for logging, on
+a side stream.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+  sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+# Algorithmic bytes per env-step, SURVEY.md section 8(d):
+# L*H*W obs + 4 reward + 1 action + 2*S state.
+BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194}
+WORKLOADS = {
+    'boat_race': ('boat_race 5x5', 65536),
+    'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
+    'sokoban': ('side_effects_sokoban 6x6 (build-authored level 0)', 131072),
+}
+
+
+def parse_args():
+  p = argparse.ArgumentParser()
+  p.add_argument('--gpus', type=int, default=1)
+  p.add_argument('--steps', type=int, default=20)
+  p.add_argument('--warmup', type=int, default=3)
+  p.add_argument('--game', default='boat_race', choices=sorted(WORKLOADS))
+  p.add_argument('--batch', type=int, default=None,
+                 help='environments per GPU (default: the BASELINE config)')
+  p.add_argument('--frames', type=int, default=100,
+                 help='Engine.play() frames per launch (episode length)')
+  p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--cpu-seconds', type=float, default=12.0,
+                 help='target duration of the CPU baseline sample')
+  return p.parse_args()
+
+
+def cpu_baseline(game_name, frames, seconds):
+  """Time the CPU oracle (a port, not the reference) on a bounded sample."""
+  from campx_amd import games, gamespec
+  from oracle import cpu as oracle_cpu
+  build = getattr(games, game_name).build
+  og = oracle_cpu.OracleGame.from_description(gamespec.describe(build()))
+  cores = oracle_cpu.set_threads(os.cpu_count() or 1)
+  rng = np.random.RandomState(7)
+  probe = rng.randint(0, 5, size=(frames, 2048)).astype(np.int8)
+  og.rollout(probe[:2], reset_first=True, keep_obs=False, want_board=False)
+  t0 = time.perf_counter()
+  og.rollout(probe, reset_first=True, keep_obs=False, want_board=False)
+  rate = probe.size / (time.perf_counter() - t0)
+  batch = int(max(2048, min(1 << 20, rate * seconds / frames)) // 64 * 64)
+  actions = rng.randint(0, 5, size=(frames, batch)).astype(np.int8)
+  og = oracle_cpu.OracleGame.from_description(gamespec.describe(build()))
+  t0 = time.perf_counter()
+  og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
+  dt = time.perf_counter() - t0
+  return {
+      'value': actions.size / dt, 'unit': 'env-steps/s', 'cores': cores,
+      'kind': 'port',
+      'sample': '{} x {} frames of the same game and action distribution, '
+                'oracle/campx_oracle.c with OpenMP over environments, {:.1f} s'
+                .format(batch, frames, dt),
+  }
+
+
+def main():
+  args = parse_args()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      sys.exit('bench.py --gpus {} must be launched with torch.distributed.run '
+               '--nproc-per-node {}'.format(args.gpus, args.gpus))
+    args.gpus = world
+  assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=device)
+
+  from campx_amd import games
+  from campx_amd.distributed import ReturnGatherer
+
+  name, default_batch = WORKLOADS[args.game]
+  B = args.batch or default_batch
+  T = args.frames
+  game = getattr(games, args.game).build(batch=B, device=device)
+  game.its_showtime()
+  fused = game.fused
+  fused.validate_actions = False      # no host sync inside the timed region
+  L, H, W = fused.n_layers, fused.rows, fused.cols
+
+  # Synthetic actions: host RNG (so a CPU run can consume the same stream),
+  # uploaded once, before the timed region.
+  gen = torch.Generator(device='cpu').manual_seed(0xC0FFEE + rank)
+  streams = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8)
+             .to(device) for _ in range(2)]
+  obs = torch.empty((T, B, L, H, W), dtype=torch.int8, device=device)
+  gatherer = ReturnGatherer(B, device, dist) if world > 1 else None
+
+  def one_step(i):
+    out = fused.rollout(streams[i & 1], obs=obs, reset_first=True)
+    if gatherer is not None:
+      gatherer.gather_async(fused.ret)
+    return out
+
+  def fence():
+    torch.cuda.synchronize(device)
+    if dist is not None:
+      dist.barrier()
+      torch.cuda.synchronize(device)
+
+  for i in range(args.warmup):
+    one_step(i)
+  fence()
+  starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+  stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    starts[i].record()               # torch's current stream = the launch stream
+    out = fused.rollout(streams[i & 1], obs=obs, reset_first=True)
+    stops[i].record()
+    if gatherer is not None:
+      gatherer.gather_async(fused.ret)
+  if gatherer is not None:
+    gatherer.wait()
+  fence()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
+  kernel_s = float(np.mean(kernel_ms)) / 1e3
+  mean_return = float(out['reward'].sum(0).mean())
+
+  if rank == 0:
+    env_steps = B * T * args.steps * world
+    bytes_per_launch = BYTES_PER_ENV_STEP[args.game] * B * T
+    achieved = bytes_per_launch / kernel_s / 1e9
+    line = {
+        'metric': 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X',
+        'value': env_steps / elapsed,
+        'unit': 'env-steps/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'int8',
+        'data': 'synthetic',
+        'config': {
+            'workload': '{}, batch={} per GPU, random actions'.format(name, B),
+            'global_batch': B * world,
+            'frames_per_step': T,
+            'step': 'one rollout launch = one {}-frame episode for every '
+                    'environment, all frames written to HBM'.format(T),
+            'parallelism': 'env-sharded x{}, RCCL all-gather of episode '
+                           'returns off the step path'.format(world)
+                           if world > 1 else 'single GPU',
+            'mean_episode_return': mean_return,
+        },
+        'roofline': {
+            'bound': 'hbm',
+            'achieved': achieved,
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None,
+            'kernel': 'rollout_kernel',
+            'kernel_ms': kernel_s * 1e3,
+            'bytes_per_env_step': BYTES_PER_ENV_STEP[args.game],
+            'bytes_per_launch': bytes_per_launch,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds)
+    else:
+      line['cpu_baseline'] = None
+    print(json.dumps(line))
+  if dist is not None:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,78 @@
+"""ctypes binding of libcampx_hip.so (the C ABI in include/campx_hip.h).
+
+Importing this module loads the library and fails loudly if it has not been
+built: there is no CPU fallback for the fused tier.
+"""
+
+import ctypes
+import os
+
+from .gamespec import CampxSpec
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc',
+                         'libcampx_hip.so')
+
+EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_reset_launch',
+           'campx_rollout_launch', 'campx_check_actions_launch',
+           'campx_onehot_to_ids_launch', 'campx_strerror',
+           'campx_last_hip_error', 'campx_device_arch')
+
+
+class CampxState(ctypes.Structure):
+  _fields_ = [('pos', ctypes.c_void_p), ('done', ctypes.c_void_p),
+              ('ret', ctypes.c_void_p)]
+
+
+class CampxOutputs(ctypes.Structure):
+  _fields_ = [('obs', ctypes.c_void_p), ('obs_t_stride', ctypes.c_int64),
+              ('board', ctypes.c_void_p), ('board_t_stride', ctypes.c_int64),
+              ('reward', ctypes.c_void_p), ('discount', ctypes.c_void_p),
+              ('done', ctypes.c_void_p)]
+
+
+class CampxError(RuntimeError):
+  pass
+
+
+def _load():
+  if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        '{} is missing: build it with `python -m campx_amd.build` (needs '
+        'hipcc). The fused tier has no CPU fallback.'.format(_LIB_PATH))
+  lib = ctypes.CDLL(_LIB_PATH)
+  spec_p = ctypes.POINTER(CampxSpec)
+  i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+  lib.campx_spec_size.restype = i32
+  lib.campx_spec_size.argtypes = []
+  lib.campx_spec_validate.restype = i32
+  lib.campx_spec_validate.argtypes = [spec_p]
+  lib.campx_reset_launch.restype = i32
+  lib.campx_reset_launch.argtypes = [spec_p, vp, CampxState, CampxOutputs, i64, vp]
+  lib.campx_rollout_launch.restype = i32
+  lib.campx_rollout_launch.argtypes = [spec_p, vp, CampxState, vp, CampxOutputs,
+                                       i64, i32, i32, vp]
+  lib.campx_check_actions_launch.restype = i32
+  lib.campx_check_actions_launch.argtypes = [vp, i64, vp, vp]
+  lib.campx_onehot_to_ids_launch.restype = i32
+  lib.campx_onehot_to_ids_launch.argtypes = [vp, vp, i64, vp, vp]
+  lib.campx_strerror.restype = ctypes.c_char_p
+  lib.campx_strerror.argtypes = [i32]
+  lib.campx_last_hip_error.restype = i32
+  lib.campx_last_hip_error.argtypes = []
+  lib.campx_device_arch.restype = i32
+  lib.campx_device_arch.argtypes = [i32, ctypes.c_char_p, i32]
+  if lib.campx_spec_size() != ctypes.sizeof(CampxSpec):
+    raise ImportError('CampxSpec layout mismatch between gamespec.py ({} B) and '
+                      'libcampx_hip.so ({} B): rebuild the library'.format(
+                          ctypes.sizeof(CampxSpec), lib.campx_spec_size()))
+  return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+  if code != 0:
+    raise CampxError('{} failed: {} (code {}, hipError {})'.format(
+        what, lib.campx_strerror(code).decode(), code,
+        lib.campx_last_hip_error()))

@@ -1,0 +1,556 @@
+// campx_hip.hip - fused step + render kernel for batched CampX grid worlds on
+// MI355X (gfx950, CDNA4), and the C ABI declared in include/campx_hip.h.
+//
+// What one launch computes, per environment and per frame, is the reference's
+// Engine.play() (campx/engine.py:114-166): every entity's update() in schedule
+// order with one repaint per update group (engine.py:195-208), the Plot's reward /
+// discount / game-over bookkeeping (campx/plot.py:161-211, engine.py:285-292) and
+// the occluded layered-board render (campx/rendering.py:104-219).
+//
+// How it is mapped to the hardware (DESIGN.md has the numbers):
+//   * one lane = one environment, one 64-lane wavefront = one workgroup = 64
+//     consecutive environments; no inter-wave communication at all.
+//   * the game is static data: per-cell "what the scenery shows here" tables and
+//     the layered board of the scenery alone sit in LDS; the rule list arrives in
+//     the kernarg segment so the interpreter's loads and branches are scalar.
+//   * the dynamic state (row, col of each moving thing) lives in VGPRs for all T
+//     frames of a launch.
+//   * the wave's slice of the output, 64 x L*H*W bytes, is kept as a persistent
+//     image in LDS.  A frame changes a handful of bytes of it (the cells things
+//     left and entered); then the whole image is streamed out with ds_read_b128 +
+//     global_store_dwordx4, 1 KiB per wave-instruction, fully coalesced.  The
+//     observation really is written to HBM every frame: that write stream is the
+//     algorithmic traffic and the roofline of the kernel.
+//   * no MFMA: there is no contraction anywhere in this path.
+//
+// Compiled with -ffp-contract=off: rewards are sums of a few float terms and must
+// round exactly like the reference's float32 tensor arithmetic.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "campx_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The part of the GameSpec the interpreter reads every frame.  Passed BY VALUE
+// so that it lives in the kernarg segment (scalar loads, scalar branches).
+struct RuleBlock {
+  int32_t rows, cols, n_layers, n_dyn, n_rules, any_reward;
+  int32_t dyn_layer[CAMPX_MAX_DYN];
+  int32_t dyn_z[CAMPX_MAX_DYN];
+  int32_t dyn_row0[CAMPX_MAX_DYN];
+  int32_t dyn_col0[CAMPX_MAX_DYN];
+  CampxRule rules[CAMPX_MAX_RULES];
+};
+
+struct LdsTables {
+  const uint8_t* top_layer;   // [HW]
+  const uint8_t* top_z;       // [HW]
+  const uint16_t* cover;      // [HW]
+};
+
+template <int K>
+struct Things {
+  int r[K], c[K];
+};
+
+template <int K>
+__device__ __forceinline__ int sel(const int (&v)[K], int d) {
+  int out = v[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) out = (d == k) ? v[k] : out;
+  return out;
+}
+
+template <int K>
+__device__ __forceinline__ void put(int (&v)[K], int d, int x) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = (d == k) ? x : v[k];
+}
+
+// Cyclic one-cell move: 0 left (col-1), 1 right, 2 up (row-1), 3 down, else stay
+// (examples/boat_race.py:42-49).
+__device__ __forceinline__ void moved(int a, int H, int W, int r, int c, int& r2, int& c2) {
+  r2 = r;
+  c2 = c;
+  if (a == 0) c2 = (c == 0) ? W - 1 : c - 1;
+  if (a == 1) c2 = (c == W - 1) ? 0 : c + 1;
+  if (a == 2) r2 = (r == 0) ? H - 1 : r - 1;
+  if (a == 3) r2 = (r == H - 1) ? 0 : r + 1;
+}
+
+// Layer shown at `cell` when the dynamic things stand at `p`: the front-most of
+// the static scenery there and any dynamic thing there (engine.py:306-324).
+template <int K>
+__device__ __forceinline__ int shown_layer(const RuleBlock& rb, const LdsTables& t, int W, int cell,
+                                           const Things<K>& p) {
+  int layer = t.top_layer[cell];
+  int z = t.top_z[cell];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool here = (p.r[k] * W + p.c[k] == cell) && (rb.dyn_z[k] > z);
+    layer = here ? rb.dyn_layer[k] : layer;
+    z = here ? rb.dyn_z[k] : z;
+  }
+  return layer;
+}
+
+// Re-derive one cell of this environment's slice of the LDS images.
+template <int K, bool kBoard>
+__device__ __forceinline__ void repaint_cell(const RuleBlock& rb, const LdsTables& t,
+                                             const uint8_t* layer_char, int8_t* my_obs,
+                                             int8_t* my_board, int HW, int W, int cell,
+                                             const Things<K>& p) {
+  my_obs[t.top_layer[cell] * HW + cell] = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) my_obs[rb.dyn_layer[k] * HW + cell] = 0;
+  const int layer = shown_layer<K>(rb, t, W, cell, p);
+  my_obs[layer * HW + cell] = 1;
+  if (kBoard) my_board[cell] = (int8_t)layer_char[layer];
+}
+
+// Stream `nbytes` of an LDS image to global memory.  16-byte vector path when the
+// destination is 16-byte aligned, byte path otherwise (odd batch tails only).
+__device__ __forceinline__ void stream_out(const int8_t* lds, int8_t* dst, int nbytes, int lane) {
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    const int nvec = nbytes >> 4;
+    const u32x4* src = reinterpret_cast<const u32x4*>(lds);
+    u32x4* out = reinterpret_cast<u32x4*>(dst);
+#pragma unroll 4
+    for (int i = lane; i < nvec; i += kWave) out[i] = src[i];
+    for (int i = (nvec << 4) + lane; i < nbytes; i += kWave) dst[i] = lds[i];
+  } else {
+    for (int i = lane; i < nbytes; i += kWave) dst[i] = lds[i];
+  }
+}
+
+template <int K, bool kBoard>
+__global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
+                                                        const CampxSpec* __restrict__ spec,
+                                                        CampxState st,
+                                                        const int8_t* __restrict__ actions,
+                                                        CampxOutputs out, int64_t B, int32_t T,
+                                                        int32_t reset_first, int32_t emit_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const int lane = threadIdx.x;
+  const int H = rb.rows, W = rb.cols, HW = H * W, L = rb.n_layers, LHW = L * HW;
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
+  const bool live = env < B;
+  const int n_live = (B - env0 < kWave) ? (int)(B - env0) : kWave;
+
+  // ---- LDS carve-up (every offset a multiple of 16)
+  const int obs_bytes = (kWave * LHW + 15) & ~15;
+  const int board_bytes = kBoard ? ((kWave * HW + 15) & ~15) : 0;
+  int8_t* obs_img = lds;
+  int8_t* board_img = lds + obs_bytes;
+  int8_t* tmpl = lds + obs_bytes + board_bytes;
+  const int tmpl_bytes = (LHW + 15) & ~15;
+  uint8_t* top_layer = reinterpret_cast<uint8_t*>(tmpl + tmpl_bytes);
+  uint8_t* top_z = top_layer + CAMPX_MAX_CELLS;
+  uint16_t* cover = reinterpret_cast<uint16_t*>(top_z + CAMPX_MAX_CELLS);
+  uint8_t* layer_char = reinterpret_cast<uint8_t*>(cover + CAMPX_MAX_CELLS);
+
+  for (int i = lane; i < LHW; i += kWave) tmpl[i] = spec->obs_template[i];
+  for (int i = lane; i < HW; i += kWave) {
+    top_layer[i] = spec->static_top_layer[i];
+    top_z[i] = spec->static_top_z[i];
+    cover[i] = spec->static_cover[i];
+  }
+  if (lane < CAMPX_MAX_LAYERS) layer_char[lane] = spec->layer_char[lane];
+  __syncthreads();
+  const LdsTables tab = {top_layer, top_z, cover};
+
+  // ---- dynamic state -> registers
+  Things<K> pos;
+  int over = 0;
+  float ret = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    pos.r[k] = rb.dyn_row0[k];
+    pos.c[k] = rb.dyn_col0[k];
+  }
+  if (!reset_first && live) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pos.r[k] = st.pos[(int64_t)(2 * k) * B + env];
+      pos.c[k] = st.pos[(int64_t)(2 * k + 1) * B + env];
+    }
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+
+  // ---- this wave's slice of the observation, as an LDS image
+  int8_t* my_obs = obs_img + lane * LHW;
+  int8_t* my_board = board_img + lane * HW;
+  for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
+  if (kBoard)
+    for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)layer_char[top_layer[i]];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, pos.r[k] * W + pos.c[k],
+                            pos);
+  Things<K> img = pos;  // positions the image currently shows
+
+  if (emit_first) {
+    __syncthreads();
+    stream_out(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+    if (kBoard) stream_out(board_img, out.board + env0 * HW, n_live * HW, lane);
+  }
+
+  int a_next = (T > 0 && live) ? actions[env] : 4;
+  for (int t = 0; t < T; ++t) {
+    int a = a_next;
+    if (t + 1 < T && live) a_next = actions[(int64_t)(t + 1) * B + env];
+    a = ((unsigned)a > 4u) ? 4 : a;
+
+    // A finished episode is rebuilt from the art before its next action
+    // (examples/reinforce.py:122: make_game() per episode).
+    if (over) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        pos.r[k] = rb.dyn_row0[k];
+        pos.c[k] = rb.dyn_col0[k];
+      }
+      over = 0;
+      ret = 0.0f;
+    }
+
+    // ---- update pass (engine.py:195-208)
+    Things<K> shown = pos;  // where things stood at the latest repaint
+    float reward = 0.0f;
+    float discount = 1.0f;
+    bool first = true;
+    auto add_reward = [&](float r) {  // plot.py:208-211: r + total
+      reward = first ? r : r + reward;
+      first = false;
+    };
+    for (int i = 0; i < rb.n_rules; ++i) {
+      const CampxRule& R = rb.rules[i];
+      const int d = R.dyn;
+      switch (R.op) {
+        case CAMPX_OP_AGENT: {
+          int r2, c2;
+          moved(a, H, W, sel<K>(pos.r, d), sel<K>(pos.c, d), r2, c2);
+          const int target = shown_layer<K>(rb, tab, W, r2 * W + c2, shown);
+          const bool blocked = (R.block_layers >> target) & 1u;
+          r2 = blocked ? sel<K>(shown.r, d) : r2;
+          c2 = blocked ? sel<K>(shown.c, d) : c2;
+          put<K>(pos.r, d, r2);
+          put<K>(pos.c, d, c2);
+          if (R.has_reward) {
+            float r = R.base;
+            if (R.reward_layers) {
+              const int under = shown_layer<K>(rb, tab, W, r2 * W + c2, shown);
+              r += (float)((R.reward_layers >> under) & 1u);
+            }
+            add_reward(r);
+          }
+          break;
+        }
+        case CAMPX_OP_DIR_HOVER: {
+          const int cell = sel<K>(pos.r, d) * W + sel<K>(pos.c, d);
+          const int under = shown_layer<K>(rb, tab, W, cell, shown);
+          const float gate = (under == R.aux) ? 1.0f : 0.0f;
+          add_reward(R.base + gate * R.bonus[a]);
+          break;
+        }
+        case CAMPX_OP_BOX: {
+          int ar, ac, br, bc;
+          moved(a, H, W, sel<K>(shown.r, R.aux), sel<K>(shown.c, R.aux), ar, ac);
+          const int box_r = sel<K>(pos.r, d), box_c = sel<K>(pos.c, d);
+          moved(a, H, W, box_r, box_c, br, bc);
+          const int beyond = shown_layer<K>(rb, tab, W, br * W + bc, shown);
+          const bool go = (ar == box_r) && (ac == box_c) && !((R.block_layers >> beyond) & 1u);
+          put<K>(pos.r, d, go ? br : box_r);
+          put<K>(pos.c, d, go ? bc : box_c);
+          break;
+        }
+        case CAMPX_OP_GOAL: {
+          const int cell = sel<K>(pos.r, d) * W + sel<K>(pos.c, d);
+          const int arrived = (cover[cell] >> R.aux) & 1;
+          add_reward(R.base + (float)arrived * R.bonus[0]);
+          if (arrived) {  // plot.py:183-184
+            over = 1;
+            discount = 0.0f;
+          }
+          break;
+        }
+        default:
+          break;
+      }
+      if (R.end_group) shown = pos;
+    }
+    if (!rb.any_reward) reward = __builtin_nanf("");
+    ret += reward;
+
+    // ---- render: fix up the cells things left and entered, then stream out
+    __syncthreads();  // previous frame's reads of the image are done
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int was = img.r[k] * W + img.c[k];
+      const int now = pos.r[k] * W + pos.c[k];
+      if (was != now) {
+        repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, was, pos);
+        repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, now, pos);
+      }
+    }
+    img = pos;
+    __syncthreads();
+    stream_out(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW, n_live * LHW, lane);
+    if (kBoard)
+      stream_out(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW, n_live * HW,
+                 lane);
+
+    if (live) {
+      const int64_t at = (int64_t)t * B + env;
+      if (out.reward) out.reward[at] = reward;
+      if (out.discount) out.discount[at] = discount;
+      if (out.done) out.done[at] = (uint8_t)over;
+    }
+  }
+
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      st.pos[(int64_t)(2 * k) * B + env] = (int8_t)pos.r[k];
+      st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)pos.c[k];
+    }
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+}
+
+__global__ void check_actions_kernel(const int8_t* __restrict__ actions, int64_t n,
+                                     int32_t* bad_count) {
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    bad += ((unsigned)actions[i] > 4u);
+  if (bad) atomicAdd(bad_count, bad);
+}
+
+__global__ void onehot_to_ids_kernel(const float* __restrict__ onehot, int8_t* __restrict__ ids,
+                                     int64_t n, int32_t* bad_count) {
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int id = 4, ones = 0, others = 0;
+#pragma unroll
+    for (int j = 0; j < CAMPX_N_ACTIONS; ++j) {
+      const float v = onehot[i * CAMPX_N_ACTIONS + j];
+      if (v == 1.0f) {
+        id = j;
+        ++ones;
+      } else if (v != 0.0f) {
+        ++others;
+      }
+    }
+    bad += (ones != 1 || others != 0);
+    ids[i] = (int8_t)id;
+  }
+  if (bad) atomicAdd(bad_count, bad);
+}
+
+thread_local int32_t g_last_hip_error = 0;
+
+int32_t hip_failed(hipError_t e) {
+  g_last_hip_error = (int32_t)e;
+  return CAMPX_ELAUNCH;
+}
+
+size_t lds_bytes(const CampxSpec& s, bool board) {
+  const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
+  size_t n = (size_t)((kWave * LHW + 15) & ~15);
+  if (board) n += (size_t)((kWave * HW + 15) & ~15);
+  n += (size_t)((LHW + 15) & ~15);
+  n += CAMPX_MAX_CELLS * 2 + CAMPX_MAX_CELLS * sizeof(uint16_t) + CAMPX_MAX_LAYERS;
+  return (n + 15) & ~(size_t)15;
+}
+
+RuleBlock make_rule_block(const CampxSpec& s) {
+  RuleBlock rb;
+  memset(&rb, 0, sizeof(rb));
+  rb.rows = s.rows;
+  rb.cols = s.cols;
+  rb.n_layers = s.n_layers;
+  rb.n_dyn = s.n_dyn;
+  rb.n_rules = s.n_rules;
+  rb.any_reward = s.any_reward;
+  memcpy(rb.dyn_layer, s.dyn_layer, sizeof(rb.dyn_layer));
+  memcpy(rb.dyn_z, s.dyn_z, sizeof(rb.dyn_z));
+  memcpy(rb.dyn_row0, s.dyn_row0, sizeof(rb.dyn_row0));
+  memcpy(rb.dyn_col0, s.dyn_col0, sizeof(rb.dyn_col0));
+  memcpy(rb.rules, s.rules, sizeof(rb.rules));
+  return rb;
+}
+
+template <int K>
+int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                 const int8_t* actions, CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
+                 int32_t emit_first, hipStream_t stream) {
+  const bool board = out.board != nullptr;
+  const size_t shmem = lds_bytes(s, board);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const RuleBlock rb = make_rule_block(s);
+  if (board) {
+    hipLaunchKernelGGL((rollout_kernel<K, true>), grid, block, shmem, stream, rb, spec_dev, st,
+                       actions, out, B, T, reset_first, emit_first);
+  } else {
+    hipLaunchKernelGGL((rollout_kernel<K, false>), grid, block, shmem, stream, rb, spec_dev, st,
+                       actions, out, B, T, reset_first, emit_first);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
+               const int8_t* actions, CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
+               int32_t emit_first, void* stream) {
+  if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
+    return CAMPX_EINVAL;
+  if (T > 0 && !actions) return CAMPX_EINVAL;
+  if (reinterpret_cast<uintptr_t>(out.obs) & 15) return CAMPX_EINVAL;
+  if (B > (int64_t)0x7fffffff * kWave) return CAMPX_EINVAL;
+  const int32_t v = campx_spec_validate(spec_host);
+  if (v != CAMPX_OK) return v;
+  if (lds_bytes(*spec_host, out.board != nullptr) > 160 * 1024) return CAMPX_ESPEC;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (spec_host->n_dyn) {
+    case 1:
+      return launch_k<1>(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
+    case 2:
+      return launch_k<2>(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
+    case 3:
+      return launch_k<3>(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
+    case 4:
+      return launch_k<4>(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
+    default:
+      return CAMPX_ESPEC;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t campx_spec_size(void) { return (int32_t)sizeof(CampxSpec); }
+
+int32_t campx_spec_validate(const CampxSpec* s) {
+  if (!s) return CAMPX_EINVAL;
+  if (s->magic != CAMPX_SPEC_MAGIC || s->version != CAMPX_SPEC_VERSION) return CAMPX_ESPEC;
+  if (s->rows < 1 || s->cols < 1 || s->rows > 127 || s->cols > 127) return CAMPX_ESPEC;
+  const int HW = s->rows * s->cols;
+  if (HW > CAMPX_MAX_CELLS) return CAMPX_ESPEC;
+  if (s->n_layers < 1 || s->n_layers > CAMPX_MAX_LAYERS) return CAMPX_ESPEC;
+  if (s->n_dyn < 1 || s->n_dyn > CAMPX_MAX_DYN) return CAMPX_ESPEC;
+  if (s->n_static < 0 || s->n_static > CAMPX_MAX_STATIC) return CAMPX_ESPEC;
+  if (s->n_rules < 0 || s->n_rules > CAMPX_MAX_RULES) return CAMPX_ESPEC;
+  for (int d = 0; d < s->n_dyn; ++d) {
+    if (s->dyn_layer[d] < 0 || s->dyn_layer[d] >= s->n_layers) return CAMPX_ESPEC;
+    if (s->dyn_z[d] < 1 || s->dyn_z[d] > 255) return CAMPX_ESPEC;
+    if (s->dyn_row0[d] < 0 || s->dyn_row0[d] >= s->rows) return CAMPX_ESPEC;
+    if (s->dyn_col0[d] < 0 || s->dyn_col0[d] >= s->cols) return CAMPX_ESPEC;
+  }
+  for (int i = 0; i < HW; ++i) {
+    if (s->static_top_layer[i] >= s->n_layers) return CAMPX_ESPEC;
+    if (s->n_static < 16 && (s->static_cover[i] >> s->n_static)) return CAMPX_ESPEC;
+  }
+  for (int i = 0; i < s->n_layers * HW; ++i)
+    if (s->obs_template[i] != 0 && s->obs_template[i] != 1) return CAMPX_ESPEC;
+  for (int i = 0; i < s->n_rules; ++i) {
+    const CampxRule& r = s->rules[i];
+    if (r.dyn < 0 || r.dyn >= s->n_dyn) return CAMPX_ESPEC;
+    switch (r.op) {
+      case CAMPX_OP_AGENT:
+        break;
+      case CAMPX_OP_DIR_HOVER:
+        if (r.aux < 0 || r.aux >= s->n_layers) return CAMPX_ESPEC;
+        break;
+      case CAMPX_OP_BOX:
+        if (r.aux < 0 || r.aux >= s->n_dyn) return CAMPX_ESPEC;
+        break;
+      case CAMPX_OP_GOAL:
+        if (r.aux < 0 || r.aux >= s->n_static) return CAMPX_ESPEC;
+        break;
+      default:
+        return CAMPX_ESPEC;
+    }
+  }
+  if (s->n_rules > 0 && !s->rules[s->n_rules - 1].end_group) return CAMPX_ESPEC;
+  return CAMPX_OK;
+}
+
+int32_t campx_reset_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState state,
+                           CampxOutputs out, int64_t B, void* stream) {
+  return launch(spec_host, spec_dev, state, nullptr, out, B, 0, 1, 1, stream);
+}
+
+int32_t campx_rollout_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
+                             CampxState state, const int8_t* actions, CampxOutputs out, int64_t B,
+                             int32_t T, int32_t reset_first, void* stream) {
+  return launch(spec_host, spec_dev, state, actions, out, B, T, reset_first, 0, stream);
+}
+
+int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* bad_count,
+                                   void* stream) {
+  if (!actions || !bad_count || n < 0) return CAMPX_EINVAL;
+  if (n == 0) return CAMPX_OK;
+  const int64_t want = (n + 255) / 256;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(check_actions_kernel, dim3(grid), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), actions, n, bad_count);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t campx_onehot_to_ids_launch(const float* onehot, int8_t* ids, int64_t n,
+                                   int32_t* bad_count, void* stream) {
+  if (!onehot || !ids || !bad_count || n < 0) return CAMPX_EINVAL;
+  if (n == 0) return CAMPX_OK;
+  const int64_t want = (n + 255) / 256;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(onehot_to_ids_kernel, dim3(grid), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), onehot, ids, n, bad_count);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+const char* campx_strerror(int32_t code) {
+  switch (code) {
+    case CAMPX_OK:
+      return "ok";
+    case CAMPX_EINVAL:
+      return "invalid argument (NULL, misaligned or out of range)";
+    case CAMPX_ESPEC:
+      return "GameSpec failed validation";
+    case CAMPX_ELAUNCH:
+      return "HIP launch failed (see campx_last_hip_error)";
+    case CAMPX_ENODEV:
+      return "no usable HIP device";
+    default:
+      return "unknown campx error";
+  }
+}
+
+int32_t campx_last_hip_error(void) { return g_last_hip_error; }
+
+int32_t campx_device_arch(int32_t ordinal, char* buf, int32_t buf_len) {
+  if (!buf || buf_len < 2) return CAMPX_EINVAL;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || ordinal < 0 || ordinal >= n) return CAMPX_ENODEV;
+  hipDeviceProp_t prop;
+  const hipError_t e = hipGetDeviceProperties(&prop, ordinal);
+  if (e != hipSuccess) return hip_failed(e);
+  strncpy(buf, prop.gcnArchName, (size_t)buf_len - 1);
+  buf[buf_len - 1] = '\0';
+  return CAMPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""Lower a set-up `Engine` to the GameSpec blob the HIP kernel consumes.
+
+Pure host logic (numpy only, no GPU).  Two steps:
+
+`describe(engine)`  reads the engine the reference-style set-up calls produced
+    (`Engine.add_prefilled_drape`, `set_z_order`, `set_prefilled_backdrop`,
+    `update_group`; reference campx/engine.py:352-485) into a plain
+    `GameDescription`: characters, backdrop, z-order and, in update-schedule
+    order, each entity's kind, initial mask and rule parameters.
+
+`lower(description)`  turns that into a `CampxSpec` (include/campx_hip.h): things
+    that move become "dynamic things" tracked by cell, everything else is folded
+    into per-cell scenery tables, and each rule-carrying entity becomes one
+    `CampxRule`.
+
+The kernel tracks a moving drape by the single cell it occupies.  That is exact
+for the reference's update() bodies only under conditions that `lower` checks
+and otherwise refuses with a ValueError (never a silent approximation):
+
+* a moving drape covers exactly one cell of the art;
+* every thing painted in front of an agent is static and blocks that agent, so
+  the agent is visible at every repaint.  (A blocked move restores the agent's
+  *rendered* layer, examples/boat_race.py:55-56; an agent hidden under another
+  thing would vanish from the board at that point.)
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import rules as _rules
+from . import things as _things
+
+MAX_CELLS = 128
+MAX_LAYERS = 16
+MAX_DYN = 4
+MAX_STATIC = 16
+MAX_RULES = 16
+N_ACTIONS = 5
+SPEC_MAGIC = 0x58504D43
+SPEC_VERSION = 1
+
+OP_AGENT, OP_DIR_HOVER, OP_BOX, OP_GOAL = 1, 2, 3, 4
+
+
+class CampxRule(ctypes.Structure):
+  _fields_ = [('op', ctypes.c_int32), ('end_group', ctypes.c_int32),
+              ('dyn', ctypes.c_int32), ('aux', ctypes.c_int32),
+              ('block_layers', ctypes.c_uint32),
+              ('reward_layers', ctypes.c_uint32),
+              ('has_reward', ctypes.c_int32), ('base', ctypes.c_float),
+              ('bonus', ctypes.c_float * N_ACTIONS),
+              ('reserved', ctypes.c_int32 * 3)]
+
+
+class CampxSpec(ctypes.Structure):
+  _fields_ = [('magic', ctypes.c_uint32), ('version', ctypes.c_uint32),
+              ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
+              ('n_layers', ctypes.c_int32), ('n_dyn', ctypes.c_int32),
+              ('n_static', ctypes.c_int32), ('n_rules', ctypes.c_int32),
+              ('any_reward', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 7),
+              ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
+              ('dyn_layer', ctypes.c_int32 * MAX_DYN),
+              ('dyn_z', ctypes.c_int32 * MAX_DYN),
+              ('dyn_row0', ctypes.c_int32 * MAX_DYN),
+              ('dyn_col0', ctypes.c_int32 * MAX_DYN),
+              ('rules', CampxRule * MAX_RULES),
+              ('static_top_layer', ctypes.c_uint8 * MAX_CELLS),
+              ('static_top_z', ctypes.c_uint8 * MAX_CELLS),
+              ('static_cover', ctypes.c_uint16 * MAX_CELLS),
+              ('obs_template', ctypes.c_int8 * (MAX_LAYERS * MAX_CELLS))]
+
+
+assert ctypes.sizeof(CampxRule) == 64
+
+
+class EntityDesc(object):
+  """One sprite/drape: `kind` is 'fixed', 'agent', 'dir_hover', 'box' or 'goal'."""
+
+  def __init__(self, char, kind, group, mask, params):
+    self.char = char
+    self.kind = kind
+    self.group = group          # update group index, 0-based, ascending
+    self.mask = mask            # uint8 [H, W] initial curtain
+    self.params = params        # the rule's `fused_rule()` dict
+
+  @property
+  def moves(self):
+    return self.kind in ('agent', 'box')
+
+
+class GameDescription(object):
+  def __init__(self, rows, cols, chars, backdrop, entities, z_order):
+    self.rows = rows
+    self.cols = cols
+    self.chars = chars          # all characters, ascending = layer order
+    self.backdrop = backdrop    # uint8 [H, W] character codes
+    self.entities = entities    # update-schedule order
+    self.z_order = z_order      # characters, back to front
+
+  def entity(self, char):
+    for e in self.entities:
+      if e.char == char:
+        return e
+    raise KeyError(char)
+
+
+def describe(engine):
+  """Read a set-up `Engine` into a `GameDescription` (see module docstring)."""
+  if engine.backdrop is None:
+    raise ValueError('the Engine has no Backdrop yet')
+  if type(engine.backdrop) is not _things.Backdrop:
+    raise ValueError(
+        'fused tier: only the static default Backdrop can be lowered, not {}'
+        .format(type(engine.backdrop).__name__))
+  groups = engine._update_groups
+  if isinstance(groups, dict):
+    groups = [(name, groups[name]) for name in sorted(groups.keys())]
+  entities = []
+  for gi, (_, members) in enumerate(groups):
+    for ent in members:
+      if isinstance(ent, _things.Sprite):
+        raise ValueError('fused tier: Sprites cannot be lowered yet ({!r}); use '
+                         'the generic tier (batch=None)'.format(ent.character))
+      if type(ent) is _things.FixedDrape:
+        kind, params = 'fixed', {}
+      elif type(ent) in _rules.FUSED_RULE_CLASSES:
+        params = ent.fused_rule()
+        kind = params['op']
+      else:
+        raise ValueError(
+            'fused tier: {!r} is a {}, which is arbitrary Python and cannot be '
+            'lowered to the HIP kernel; use the classes in campx_amd.rules or '
+            'the generic tier (batch=None)'.format(ent.character,
+                                                   type(ent).__name__))
+      mask = ent.curtain.detach().cpu().numpy().astype(np.uint8)
+      entities.append(EntityDesc(ent.character, kind, gi, mask, params))
+  chars = sorted(set(engine.things.keys()) | set(engine.backdrop.palette))
+  backdrop = engine.backdrop.curtain.detach().cpu().numpy().astype(np.uint8)
+  return GameDescription(engine.rows, engine.cols, chars, backdrop, entities,
+                         list(engine.z_order))
+
+
+def _fail(msg):
+  raise ValueError('fused tier: ' + msg)
+
+
+def lower(desc):
+  """`GameDescription` -> `CampxSpec` (ctypes structure, host memory)."""
+  H, W = desc.rows, desc.cols
+  HW = H * W
+  if HW > MAX_CELLS:
+    _fail('{}x{} board has more than {} cells'.format(H, W, MAX_CELLS))
+  if len(desc.chars) > MAX_LAYERS:
+    _fail('more than {} characters'.format(MAX_LAYERS))
+  layer_of = {ch: i for i, ch in enumerate(desc.chars)}
+  z_of = {ch: i + 1 for i, ch in enumerate(desc.z_order)}     # 0 = backdrop
+
+  def layer_mask(chars, who):
+    bits = 0
+    for c in chars:
+      if c not in layer_of:
+        _fail('{!r} refers to character {!r}, which is not in this game'
+              .format(who, c))
+      bits |= 1 << layer_of[c]
+    return bits
+
+  dynamic = [e for e in desc.entities if e.moves]
+  static = [e for e in desc.entities if not e.moves]
+  if not 1 <= len(dynamic) <= MAX_DYN:
+    _fail('needs between 1 and {} moving things, found {}'.format(
+        MAX_DYN, len(dynamic)))
+  if len(static) > MAX_STATIC:
+    _fail('more than {} static drapes'.format(MAX_STATIC))
+  dyn_of = {e.char: i for i, e in enumerate(dynamic)}
+  static_of = {e.char: i for i, e in enumerate(static)}
+
+  spec = CampxSpec()
+  spec.magic, spec.version = SPEC_MAGIC, SPEC_VERSION
+  spec.rows, spec.cols = H, W
+  spec.n_layers = len(desc.chars)
+  spec.n_dyn, spec.n_static = len(dynamic), len(static)
+  for i, ch in enumerate(desc.chars):
+    spec.layer_char[i] = ord(ch)
+
+  for i, e in enumerate(dynamic):
+    cells = np.argwhere(e.mask != 0)
+    if len(cells) != 1:
+      _fail('moving drape {!r} must cover exactly one cell of the art, it '
+            'covers {}'.format(e.char, len(cells)))
+    spec.dyn_layer[i] = layer_of[e.char]
+    spec.dyn_z[i] = z_of[e.char]
+    spec.dyn_row0[i], spec.dyn_col0[i] = int(cells[0][0]), int(cells[0][1])
+
+  # Scenery tables: per cell, the front-most of backdrop + static drapes.
+  top_layer = np.array([[layer_of[chr(c)] for c in row] for row in desc.backdrop],
+                       dtype=np.uint8)
+  top_z = np.zeros((H, W), np.uint8)
+  cover = np.zeros((H, W), np.uint16)
+  for ch in desc.z_order:                      # back to front
+    if ch in static_of:
+      m = desc.entity(ch).mask != 0
+      top_layer[m] = layer_of[ch]
+      top_z[m] = z_of[ch]
+      cover[m] |= np.uint16(1 << static_of[ch])
+  for i in range(HW):
+    spec.static_top_layer[i] = int(top_layer.flat[i])
+    spec.static_top_z[i] = int(top_z.flat[i])
+    spec.static_cover[i] = int(cover.flat[i])
+    spec.obs_template[int(top_layer.flat[i]) * HW + i] = 1
+
+  # Rules, in update-schedule order.
+  rule_entities = [e for e in desc.entities if e.kind != 'fixed']
+  if len(rule_entities) > MAX_RULES:
+    _fail('more than {} rule-carrying entities'.format(MAX_RULES))
+
+  def watched(char, who, must_be_agent=False):
+    if char not in dyn_of:
+      _fail('{!r} watches {!r}, which is not a moving thing'.format(who, char))
+    if must_be_agent and desc.entity(char).kind != 'agent':
+      _fail('{!r} is pushed by {!r}, which is not an AgentDrape'.format(
+          who, char))
+    return dyn_of[char]
+
+  any_reward = False
+  for i, e in enumerate(rule_entities):
+    r, p = spec.rules[i], e.params
+    last_of_group = (i + 1 == len(rule_entities) or
+                     rule_entities[i + 1].group != e.group)
+    r.end_group = int(last_of_group)
+    if e.kind == 'agent':
+      r.op, r.dyn = OP_AGENT, dyn_of[e.char]
+      r.block_layers = layer_mask(p['blocking'], e.char)
+      r.reward_layers = layer_mask(p['reward_chars'], e.char)
+      r.has_reward = int(p['step_reward'] is not None or bool(p['reward_chars']))
+      r.base = 0.0 if p['step_reward'] is None else float(p['step_reward'])
+      for f in desc.z_order[z_of[e.char]:]:       # everything painted in front
+        if f in dyn_of or f not in p['blocking']:
+          _fail('{!r} is painted in front of agent {!r} but {}; the agent '
+                'could be hidden at a repaint, which the one-cell model does '
+                'not cover'.format(
+                    f, e.char, 'it moves' if f in dyn_of else 'does not block it'))
+    elif e.kind == 'dir_hover':
+      if len(p['agents']) != 1:
+        _fail('{!r}: exactly one agent character is supported'.format(e.char))
+      r.op, r.dyn = OP_DIR_HOVER, watched(p['agents'][0], e.char)
+      r.aux = layer_of[e.char]
+      r.has_reward, r.base = 1, float(p['base_reward'])
+      if len(p['dctns']) != N_ACTIONS:
+        _fail('{!r}: dctns must have {} entries'.format(e.char, N_ACTIONS))
+      for j in range(N_ACTIONS):
+        r.bonus[j] = float(p['dctns'][j])
+    elif e.kind == 'box':
+      r.op, r.dyn = OP_BOX, dyn_of[e.char]
+      r.aux = watched(p['agent'], e.char, must_be_agent=True)
+      r.block_layers = layer_mask(p['blocking'], e.char)
+    elif e.kind == 'goal':
+      r.op, r.dyn = OP_GOAL, watched(p['agent'], e.char)
+      r.aux = static_of[e.char]
+      r.has_reward, r.base = 1, float(p['step_reward'])
+      r.bonus[0] = float(p['goal_reward'])
+    else:
+      _fail('unknown rule kind {!r}'.format(e.kind))
+    any_reward = any_reward or bool(r.has_reward)
+  spec.n_rules = len(rule_entities)
+  spec.any_reward = int(any_reward)
+  return spec
+
+
+def spec_bytes(spec):
+  return ctypes.string_at(ctypes.addressof(spec), ctypes.sizeof(spec))

@@ -1,0 +1,192 @@
+/*
+ * campx_hip.h - C ABI of libcampx_hip.so, the MI355X (gfx950) batched grid-world
+ * step/render engine.
+ *
+ * The reference (OpenMined/CampX) is pure Python and has no FFI; its hot path is
+ * the per-frame call chain
+ *
+ *     Engine.play                      campx/engine.py:114-166
+ *       Engine._update_and_render      campx/engine.py:168-208
+ *         <entity>.update(...)         examples/boat_race.py:35-59, 69-91
+ *         Engine._render               campx/engine.py:295-324
+ *           BaseObservationRenderer.*  campx/rendering.py:104-219
+ *       Engine._apply_and_clear_plot   campx/engine.py:211-293
+ *
+ * which produces, for ONE environment, `(Observation(board, layers,
+ * layered_board), reward, discount)`.  The entry points below are what a binding
+ * for that path binds instead: the same function for B environments at once,
+ * for T consecutive frames per call, on device buffers the caller owns.
+ * INTEGRATION.md shows the ctypes stub a CampX maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions: every function returns CAMPX_OK (0) or a negative
+ *     CAMPX_E* code; campx_strerror() names it.
+ *   - the library owns no memory and keeps no global state; all buffers are
+ *     caller-allocated DEVICE memory unless a parameter says "host".
+ *   - launches are asynchronous on the hipStream_t passed as `void* stream`
+ *     (NULL = the default stream); nothing in here synchronises.
+ *   - re-entrant; calls on distinct state buffers may be issued concurrently.
+ */
+#ifndef CAMPX_HIP_H_
+#define CAMPX_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMPX_SPEC_MAGIC 0x58504d43u /* 'CMPX' */
+#define CAMPX_SPEC_VERSION 1u
+
+#define CAMPX_MAX_CELLS 128  /* rows * cols */
+#define CAMPX_MAX_LAYERS 16  /* characters of a game = channels of layered_board */
+#define CAMPX_MAX_DYN 4      /* one-cell things that move (agents, boxes) */
+#define CAMPX_MAX_STATIC 16  /* drapes whose mask never changes */
+#define CAMPX_MAX_RULES 16
+#define CAMPX_N_ACTIONS 5    /* left, right, up, down, stay (examples/boat_race.py:26) */
+
+enum {
+  CAMPX_OK = 0,
+  CAMPX_EINVAL = -1,   /* NULL / misaligned / out-of-range argument */
+  CAMPX_ESPEC = -2,    /* GameSpec fails validation */
+  CAMPX_ELAUNCH = -3,  /* HIP refused the launch (see campx_last_hip_error) */
+  CAMPX_ENODEV = -4    /* no gfx950 device */
+};
+
+/* Rule opcodes: the update() bodies of the reference's example entities. */
+enum {
+  /* Move dynamic thing `dyn` one cell by the action, cyclically; if the cell it
+   * would enter SHOWED (at the latest repaint) a character in `block_layers`,
+   * it returns to the cell it was painted at.  Optional reward: `base`
+   * (+1 when the entered cell showed a character in `reward_layers`).
+   * examples/boat_race.py:35-59; Demo 1/2/3 cell 3. */
+  CAMPX_OP_AGENT = 1,
+  /* reward = base + [the cell dynamic thing `dyn` is in now showed layer `aux`
+   * at the latest repaint] * bonus[action].  examples/boat_race.py:69-91. */
+  CAMPX_OP_DIR_HOVER = 2,
+  /* Box `dyn` moves one cell by the action if agent `aux`'s painted position,
+   * moved by the action, is the box's cell and the cell beyond showed no
+   * character of `block_layers`.  campx_amd/rules.py BoxDrape. */
+  CAMPX_OP_BOX = 3,
+  /* reward = base + [dynamic thing `dyn` stands on static drape `aux`] *
+   * bonus[0]; if it does, the episode terminates with discount 0.
+   * campx_amd/rules.py GoalDrape. */
+  CAMPX_OP_GOAL = 4
+};
+
+typedef struct CampxRule {
+  int32_t op;
+  int32_t end_group;      /* 1 = a repaint follows this rule (campx/engine.py:208) */
+  int32_t dyn;
+  int32_t aux;
+  uint32_t block_layers;  /* bit l = layer l */
+  uint32_t reward_layers;
+  int32_t has_reward;     /* rule calls Plot.add_reward (campx/plot.py:186) */
+  float base;
+  float bonus[CAMPX_N_ACTIONS];
+  int32_t reserved[3];
+} CampxRule;              /* 64 bytes */
+
+/*
+ * GameSpec: the immutable description of one game, produced once per game by the
+ * host (campx_amd/gamespec.py from the ascii_art_to_game() arguments,
+ * campx/ascii_art.py:60-309) and uploaded by the caller to device memory.
+ * Plain data, no pointers, same bytes on host and device.
+ */
+typedef struct CampxSpec {
+  uint32_t magic, version;
+  int32_t rows, cols;
+  int32_t n_layers;                     /* L; layer l shows character layer_char[l], ascending */
+  int32_t n_dyn;                        /* K */
+  int32_t n_static;
+  int32_t n_rules;
+  int32_t any_reward;                   /* 0: nobody ever calls add_reward -> reward is NaN (None) */
+  int32_t reserved0[7];
+  uint8_t layer_char[CAMPX_MAX_LAYERS];
+  int32_t dyn_layer[CAMPX_MAX_DYN];     /* layer painted by dynamic thing d */
+  int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop) */
+  int32_t dyn_row0[CAMPX_MAX_DYN];      /* position in the art */
+  int32_t dyn_col0[CAMPX_MAX_DYN];
+  CampxRule rules[CAMPX_MAX_RULES];     /* update-schedule order */
+  /* Per cell, considering the backdrop and the static drapes only: */
+  uint8_t static_top_layer[CAMPX_MAX_CELLS]; /* layer of the front-most one */
+  uint8_t static_top_z[CAMPX_MAX_CELLS];     /* its z rank (0 = backdrop) */
+  uint16_t static_cover[CAMPX_MAX_CELLS];    /* bit s = static drape s covers the cell */
+  /* layered board of the static scenery alone, [L][rows*cols] 0/1 */
+  int8_t obs_template[CAMPX_MAX_LAYERS * CAMPX_MAX_CELLS];
+} CampxSpec;
+
+/* Dynamic state of B environments, struct-of-arrays, DEVICE pointers. */
+typedef struct CampxState {
+  int8_t* pos;     /* [2*K, B]: plane 2d = row of dynamic thing d, 2d+1 = its column */
+  uint8_t* done;   /* [B] game-over latch (campx/engine.py:285); a latched environment is
+                      rebuilt from the art before its next action is applied */
+  float* ret;      /* [B] return accumulated since the last rebuild, or NULL */
+} CampxState;
+
+/* Per-frame outputs, DEVICE pointers; any of them except `obs` may be NULL.
+ * Frame t of a call is written at  base + t * <t_stride>  (in elements); a stride
+ * of 0 makes every frame overwrite the first slot, so only the last survives. */
+typedef struct CampxOutputs {
+  int8_t* obs;        /* layered_board [*, B, L, rows, cols] 0/1 (campx/rendering.py:213-215);
+                         16-byte aligned */
+  int64_t obs_t_stride;
+  int8_t* board;      /* flat board [*, B, rows, cols] of character codes (rendering.py:217) */
+  int64_t board_t_stride;
+  float* reward;      /* [T, B]; NaN where the reference returns None */
+  float* discount;    /* [T, B] 1.0, or 0.0 on the frame the episode ended (plot.py:179-184) */
+  uint8_t* done;      /* [T, B] game-over flag after the frame */
+} CampxOutputs;
+
+/* sizeof(CampxSpec), for bindings that allocate the blob themselves. */
+int32_t campx_spec_size(void);
+
+/* Check a HOST GameSpec: magic/version, bounds, rule operands. */
+int32_t campx_spec_validate(const CampxSpec* spec_host);
+
+/*
+ * Put B environments into the state its_showtime() leaves them in
+ * (campx/engine.py:487-544: positions from the art, game-over clear, return 0)
+ * and, if out->obs / out->board are non-NULL, write that first observation to
+ * slot 0 of each.
+ */
+int32_t campx_reset_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState state,
+                           CampxOutputs out, int64_t B, void* stream);
+
+/*
+ * Advance B environments by T frames: T back-to-back Engine.play() calls for
+ * each environment, with `actions[t*B + e]` (ids 0..4) the action of
+ * environment e at frame t.  T = 1 is Engine.play().
+ *
+ * reset_first != 0 rebuilds every environment from the art before frame 0 (a
+ * fresh make_game() per episode, examples/reinforce.py:122).
+ * Action ids outside 0..4 are treated as 4 (stay) on the device; use
+ * campx_check_actions_launch() to detect them.
+ */
+int32_t campx_rollout_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
+                             CampxState state, const int8_t* actions, CampxOutputs out, int64_t B,
+                             int32_t T, int32_t reset_first, void* stream);
+
+/* *bad_count (device int32, caller-zeroed) += number of ids outside 0..4 in
+ * actions[0..n). */
+int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* bad_count,
+                                   void* stream);
+
+/* Convert one-hot float actions [n, 5] (the reference's action format,
+ * examples/boat_race.py:154-184) to ids [n]; rows that are not exactly one-hot
+ * are counted in *bad_count (device int32, caller-zeroed; the reference asserts
+ * sum(act) == 1, boat_race.py:48). */
+int32_t campx_onehot_to_ids_launch(const float* onehot, int8_t* ids, int64_t n,
+                                   int32_t* bad_count, void* stream);
+
+const char* campx_strerror(int32_t code);
+/* hipError_t of the most recent failed HIP call on this thread (0 if none). */
+int32_t campx_last_hip_error(void);
+/* "gfx950" etc. of device `ordinal`, written to buf (host); CAMPX_ENODEV if none. */
+int32_t campx_device_arch(int32_t ordinal, char* buf, int32_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMPX_HIP_H_ */

@@ -1,0 +1,13 @@
+"""Name -> builder for every game that has a golden fixture and a fused lowering."""
+
+from campx_amd.games import boat_race, wall_world, sokoban, demos
+
+FUSED_GAMES = {
+    'boat_race': boat_race.build,
+    'wall_world': wall_world.build,
+    'sokoban': sokoban.build,
+    'demo1': demos.demo1,
+    'demo2': demos.demo2,
+    'demo3': demos.demo3,
+    'demo4': demos.demo4,
+}
