@@ -12,7 +12,8 @@ from .gamespec import CampxSpec
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc',
                          'libcampx_hip.so')
 
-EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_reset_launch',
+EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
+           'campx_reset_launch',
            'campx_rollout_launch', 'campx_check_actions_launch',
            'campx_onehot_to_ids_launch', 'campx_strerror',
            'campx_last_hip_error', 'campx_device_arch')
@@ -46,6 +47,8 @@ def _load():
   lib.campx_spec_size.argtypes = []
   lib.campx_spec_validate.restype = i32
   lib.campx_spec_validate.argtypes = [spec_p]
+  lib.campx_spec_compile.restype = i32
+  lib.campx_spec_compile.argtypes = [spec_p, vp]
   lib.campx_reset_launch.restype = i32
   lib.campx_reset_launch.argtypes = [spec_p, vp, CampxState, CampxOutputs, i64, vp]
   lib.campx_rollout_launch.restype = i32

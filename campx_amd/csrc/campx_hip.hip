@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "campx_hip.h"
@@ -35,6 +36,10 @@
 namespace {
 
 constexpr int kWave = 64;
+// Actions are staged through LDS kChunk frames at a time, so that the frame loop
+// itself issues no global loads: a load in the loop would make every frame wait
+// (vmcnt is in-order) for the previous frames' observation stores to drain.
+constexpr int kChunk = 64;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -75,14 +80,14 @@ __device__ __forceinline__ void put(int (&v)[K], int d, int x) {
 }
 
 // Cyclic one-cell move: 0 left (col-1), 1 right, 2 up (row-1), 3 down, else stay
-// (examples/boat_race.py:42-49).
+// (examples/boat_race.py:42-49).  Branch-free: the action differs per lane.
 __device__ __forceinline__ void moved(int a, int H, int W, int r, int c, int& r2, int& c2) {
-  r2 = r;
-  c2 = c;
-  if (a == 0) c2 = (c == 0) ? W - 1 : c - 1;
-  if (a == 1) c2 = (c == W - 1) ? 0 : c + 1;
-  if (a == 2) r2 = (r == 0) ? H - 1 : r - 1;
-  if (a == 3) r2 = (r == H - 1) ? 0 : r + 1;
+  const int dc = (a == 1) - (a == 0);
+  const int dr = (a == 3) - (a == 2);
+  c2 = c + dc;
+  r2 = r + dr;
+  c2 = (c2 < 0) ? W - 1 : ((c2 == W) ? 0 : c2);
+  r2 = (r2 < 0) ? H - 1 : ((r2 == H) ? 0 : r2);
 }
 
 // Layer shown at `cell` when the dynamic things stand at `p`: the front-most of
@@ -117,20 +122,26 @@ __device__ __forceinline__ void repaint_cell(const RuleBlock& rb, const LdsTable
 
 // Stream `nbytes` of an LDS image to global memory.  16-byte vector path when the
 // destination is 16-byte aligned, byte path otherwise (odd batch tails only).
+template <bool kNT>
 __device__ __forceinline__ void stream_out(const int8_t* lds, int8_t* dst, int nbytes, int lane) {
   if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
     const int nvec = nbytes >> 4;
     const u32x4* src = reinterpret_cast<const u32x4*>(lds);
     u32x4* out = reinterpret_cast<u32x4*>(dst);
 #pragma unroll 4
-    for (int i = lane; i < nvec; i += kWave) out[i] = src[i];
+    for (int i = lane; i < nvec; i += kWave) {
+      if (kNT)
+        __builtin_nontemporal_store(src[i], &out[i]);
+      else
+        out[i] = src[i];
+    }
     for (int i = (nvec << 4) + lane; i < nbytes; i += kWave) dst[i] = lds[i];
   } else {
     for (int i = lane; i < nbytes; i += kWave) dst[i] = lds[i];
   }
 }
 
-template <int K, bool kBoard>
+template <int K, bool kBoard, bool kNT, int kEnvs>
 __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
                                                         const CampxSpec* __restrict__ spec,
                                                         CampxState st,
@@ -140,14 +151,16 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   const int lane = threadIdx.x;
   const int H = rb.rows, W = rb.cols, HW = H * W, L = rb.n_layers, LHW = L * HW;
-  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  // A wave owns kEnvs consecutive environments (lanes >= kEnvs only help stream).
+  const int64_t env0 = (int64_t)blockIdx.x * kEnvs;
   const int64_t env = env0 + lane;
-  const bool live = env < B;
-  const int n_live = (B - env0 < kWave) ? (int)(B - env0) : kWave;
+  const bool mine = lane < kEnvs;
+  const bool live = mine && env < B;
+  const int n_live = (B - env0 < kEnvs) ? (int)(B - env0) : kEnvs;
 
   // ---- LDS carve-up (every offset a multiple of 16)
-  const int obs_bytes = (kWave * LHW + 15) & ~15;
-  const int board_bytes = kBoard ? ((kWave * HW + 15) & ~15) : 0;
+  const int obs_bytes = (kEnvs * LHW + 15) & ~15;
+  const int board_bytes = kBoard ? ((kEnvs * HW + 15) & ~15) : 0;
   int8_t* obs_img = lds;
   int8_t* board_img = lds + obs_bytes;
   int8_t* tmpl = lds + obs_bytes + board_bytes;
@@ -156,6 +169,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   uint8_t* top_z = top_layer + CAMPX_MAX_CELLS;
   uint16_t* cover = reinterpret_cast<uint16_t*>(top_z + CAMPX_MAX_CELLS);
   uint8_t* layer_char = reinterpret_cast<uint8_t*>(cover + CAMPX_MAX_CELLS);
+  int8_t* staged = reinterpret_cast<int8_t*>(layer_char + CAMPX_MAX_LAYERS);  // [kChunk][64]
 
   for (int i = lane; i < LHW; i += kWave) tmpl[i] = spec->obs_template[i];
   for (int i = lane; i < HW; i += kWave) {
@@ -189,25 +203,32 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   // ---- this wave's slice of the observation, as an LDS image
   int8_t* my_obs = obs_img + lane * LHW;
   int8_t* my_board = board_img + lane * HW;
-  for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
-  if (kBoard)
-    for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)layer_char[top_layer[i]];
+  if (mine) {
+    for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
+    if (kBoard)
+      for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)layer_char[top_layer[i]];
 #pragma unroll
-  for (int k = 0; k < K; ++k)
-    repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, pos.r[k] * W + pos.c[k],
-                            pos);
+    for (int k = 0; k < K; ++k)
+      repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W,
+                              pos.r[k] * W + pos.c[k], pos);
+  }
   Things<K> img = pos;  // positions the image currently shows
 
   if (emit_first) {
     __syncthreads();
-    stream_out(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
-    if (kBoard) stream_out(board_img, out.board + env0 * HW, n_live * HW, lane);
+    stream_out<kNT>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+    if (kBoard) stream_out<kNT>(board_img, out.board + env0 * HW, n_live * HW, lane);
   }
 
-  int a_next = (T > 0 && live) ? actions[env] : 4;
   for (int t = 0; t < T; ++t) {
-    int a = a_next;
-    if (t + 1 < T && live) a_next = actions[(int64_t)(t + 1) * B + env];
+    const int in_chunk = t & (kChunk - 1);
+    if (in_chunk == 0) {  // each lane stages its own environment's next actions
+      const int n = (T - t < kChunk) ? T - t : kChunk;
+      if (mine)
+        for (int r = 0; r < n; ++r)
+          staged[r * kEnvs + lane] = live ? actions[(int64_t)(t + r) * B + env] : (int8_t)4;
+    }
+    int a = mine ? staged[in_chunk * kEnvs + lane] : 4;
     a = ((unsigned)a > 4u) ? 4 : a;
 
     // A finished episode is rebuilt from the art before its next action
@@ -296,17 +317,18 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     for (int k = 0; k < K; ++k) {
       const int was = img.r[k] * W + img.c[k];
       const int now = pos.r[k] * W + pos.c[k];
-      if (was != now) {
+      if (mine && was != now) {
         repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, was, pos);
         repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, now, pos);
       }
     }
     img = pos;
     __syncthreads();
-    stream_out(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW, n_live * LHW, lane);
+    stream_out<kNT>(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW, n_live * LHW,
+                    lane);
     if (kBoard)
-      stream_out(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW, n_live * HW,
-                 lane);
+      stream_out<kNT>(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW,
+                      n_live * HW, lane);
 
     if (live) {
       const int64_t at = (int64_t)t * B + env;
@@ -325,6 +347,155 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// One-mover games (K == 1) after campx_spec_compile(): the update pass of a frame
+// is one lookup in the (cell, action) transition table, which was produced by the
+// interpreter kernel above.  Rendering and streaming are unchanged.
+struct MoverParams {
+  int32_t rows, cols, n_layers, dyn_layer, dyn_z, row0, col0;
+};
+
+template <bool kBoard, bool kNT, int kEnvs>
+__global__ __launch_bounds__(kWave) void rollout_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, int32_t emit_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const int lane = threadIdx.x;
+  const int W = mp.cols, HW = mp.rows * mp.cols, LHW = mp.n_layers * HW;
+  const int64_t env0 = (int64_t)blockIdx.x * kEnvs;
+  const int64_t env = env0 + lane;
+  const bool mine = lane < kEnvs;
+  const bool live = mine && env < B;
+  const int n_live = (B - env0 < kEnvs) ? (int)(B - env0) : kEnvs;
+
+  // ---- LDS carve-up (every offset a multiple of 16)
+  const int obs_bytes = (kEnvs * LHW + 15) & ~15;
+  const int board_bytes = kBoard ? ((kEnvs * HW + 15) & ~15) : 0;
+  int8_t* obs_img = lds;
+  int8_t* board_img = lds + obs_bytes;
+  uint2* table = reinterpret_cast<uint2*>(lds + obs_bytes + board_bytes);  // [HW*5] {reward, next|done<<8}
+  uint16_t* paint = reinterpret_cast<uint16_t*>(table + CAMPX_MAX_CELLS * CAMPX_N_ACTIONS);
+  uint8_t* scenery_char = reinterpret_cast<uint8_t*>(paint + CAMPX_MAX_CELLS);
+  int8_t* staged = reinterpret_cast<int8_t*>(scenery_char + CAMPX_MAX_CELLS);  // [kChunk][kEnvs]
+  int8_t* tmpl = staged + kChunk * kWave;
+
+  for (int i = lane; i < HW * CAMPX_N_ACTIONS; i += kWave) {
+    const CampxTransition tr = spec->table[i];
+    table[i] = make_uint2(__float_as_uint(tr.reward), (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8));
+  }
+  for (int i = lane; i < HW; i += kWave) {
+    // paint[cell]: byte offset (inside one environment's slice) of the scenery's own
+    // 1 at that cell; bit 15 set when the scenery there hides the mover.
+    const int layer = spec->static_top_layer[i];
+    const bool hidden = spec->static_top_z[i] > mp.dyn_z;
+    paint[i] = (uint16_t)((layer * HW + i) | (hidden ? 0x8000 : 0));
+    scenery_char[i] = spec->layer_char[layer];
+  }
+  for (int i = lane; i < LHW; i += kWave) tmpl[i] = spec->obs_template[i];
+  const int8_t mover_char = (int8_t)spec->layer_char[mp.dyn_layer];
+  __syncthreads();
+
+  int cell = mp.row0 * W + mp.col0;
+  const int cell0 = cell;
+  int over = 0;
+  float ret = 0.0f;
+  if (!reset_first && live) {
+    cell = (int)st.pos[env] * W + (int)st.pos[B + env];
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+
+  int8_t* my_obs = obs_img + lane * LHW;
+  int8_t* my_board = board_img + lane * HW;
+  const int mover_off = mp.dyn_layer * HW;
+  if (mine) {
+    for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
+    if (kBoard)
+      for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)scenery_char[i];
+    const int p = paint[cell];
+    if (!(p & 0x8000)) {
+      my_obs[p] = 0;
+      my_obs[mover_off + cell] = 1;
+      if (kBoard) my_board[cell] = mover_char;
+    }
+  }
+  int shown_at = cell;  // where the image shows the mover
+
+  if (emit_first) {
+    __syncthreads();
+    stream_out<kNT>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+    if (kBoard) stream_out<kNT>(board_img, out.board + env0 * HW, n_live * HW, lane);
+  }
+
+  for (int t = 0; t < T; ++t) {
+    const int in_chunk = t & (kChunk - 1);
+    if (in_chunk == 0) {
+      const int n = (T - t < kChunk) ? T - t : kChunk;
+      if (mine)
+        for (int r = 0; r < n; ++r)
+          staged[r * kEnvs + lane] = live ? actions[(int64_t)(t + r) * B + env] : (int8_t)4;
+    }
+    int a = mine ? staged[in_chunk * kEnvs + lane] : 4;
+    a = ((unsigned)a > 4u) ? 4 : a;
+    if (over) {  // rebuilt from the art before its next action
+      cell = cell0;
+      ret = 0.0f;
+    }
+    const uint2 tr = table[cell * CAMPX_N_ACTIONS + a];
+    const float reward = __uint_as_float(tr.x);
+    cell = (int)(tr.y & 0xffu);
+    over = (int)((tr.y >> 8) & 1u);
+    ret += reward;
+
+    __syncthreads();  // previous frame's reads of the image are done
+    if (mine && cell != shown_at) {
+      const int was = paint[shown_at], now = paint[cell];
+      if (!(was & 0x8000)) {
+        my_obs[mover_off + shown_at] = 0;
+        my_obs[was] = 1;
+        if (kBoard) my_board[shown_at] = (int8_t)scenery_char[shown_at];
+      }
+      if (!(now & 0x8000)) {
+        my_obs[now] = 0;
+        my_obs[mover_off + cell] = 1;
+        if (kBoard) my_board[cell] = mover_char;
+      }
+      shown_at = cell;
+    }
+    __syncthreads();
+    stream_out<kNT>(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW, n_live * LHW,
+                    lane);
+    if (kBoard)
+      stream_out<kNT>(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW,
+                      n_live * HW, lane);
+    if (live) {
+      const int64_t at = (int64_t)t * B + env;
+      if (out.reward) out.reward[at] = reward;
+      if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
+      if (out.done) out.done[at] = (uint8_t)over;
+    }
+  }
+
+  if (live) {
+    st.pos[env] = (int8_t)(cell / W);
+    st.pos[B + env] = (int8_t)(cell % W);
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+}
+
+size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
+  const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
+  size_t n = (size_t)((envs * LHW + 15) & ~15);
+  if (board) n += (size_t)((envs * HW + 15) & ~15);
+  n += sizeof(uint2) * CAMPX_MAX_CELLS * CAMPX_N_ACTIONS;
+  n += CAMPX_MAX_CELLS * sizeof(uint16_t) + CAMPX_MAX_CELLS;
+  n += (size_t)kChunk * kWave + (size_t)LHW;
+  return (n + 15) & ~(size_t)15;
 }
 
 __global__ void check_actions_kernel(const int8_t* __restrict__ actions, int64_t n,
@@ -360,17 +531,43 @@ __global__ void onehot_to_ids_kernel(const float* __restrict__ onehot, int8_t* _
 
 thread_local int32_t g_last_hip_error = 0;
 
+// Tuning knobs for A/B measurements only (environment variables, read once; not
+// part of the ABI).
+int knob_envs_per_wave() {
+  static const int envs = [] {
+    const char* v = getenv("CAMPX_ENVS_PER_WAVE");
+    const int n = v ? atoi(v) : 64;
+    return (n == 16 || n == 32) ? n : 64;
+  }();
+  return envs;
+}
+bool knob_store_nt() {
+  static const bool nt = [] {
+    const char* v = getenv("CAMPX_STORE_NT");
+    return !v || v[0] != '0';   // non-temporal observation stores by default
+  }();
+  return nt;
+}
+bool knob_no_table() {
+  static const bool off = [] {
+    const char* v = getenv("CAMPX_NO_TABLE");
+    return v && v[0] == '1';
+  }();
+  return off;
+}
+
 int32_t hip_failed(hipError_t e) {
   g_last_hip_error = (int32_t)e;
   return CAMPX_ELAUNCH;
 }
 
-size_t lds_bytes(const CampxSpec& s, bool board) {
+size_t lds_bytes(const CampxSpec& s, bool board, int envs) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
-  size_t n = (size_t)((kWave * LHW + 15) & ~15);
-  if (board) n += (size_t)((kWave * HW + 15) & ~15);
+  size_t n = (size_t)((envs * LHW + 15) & ~15);
+  if (board) n += (size_t)((envs * HW + 15) & ~15);
   n += (size_t)((LHW + 15) & ~15);
   n += CAMPX_MAX_CELLS * 2 + CAMPX_MAX_CELLS * sizeof(uint16_t) + CAMPX_MAX_LAYERS;
+  n += (size_t)kChunk * kWave;
   return (n + 15) & ~(size_t)15;
 }
 
@@ -396,32 +593,81 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                  const int8_t* actions, CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
                  int32_t emit_first, hipStream_t stream) {
   const bool board = out.board != nullptr;
-  const size_t shmem = lds_bytes(s, board);
-  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const int envs = knob_envs_per_wave();
+  const size_t shmem = lds_bytes(s, board, envs);
+  const dim3 grid((unsigned)((B + envs - 1) / envs)), block(kWave);
   const RuleBlock rb = make_rule_block(s);
+  const bool nt = knob_store_nt();
+#define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
+  hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS>), grid, block, shmem, stream, rb, \
+                     spec_dev, st, actions, out, B, T, reset_first, emit_first)
+#define CAMPX_LAUNCH(BOARD, NT)                \
+  do {                                         \
+    if (envs == 16)                            \
+      CAMPX_LAUNCH_E(BOARD, NT, 16);           \
+    else if (envs == 32)                       \
+      CAMPX_LAUNCH_E(BOARD, NT, 32);           \
+    else                                       \
+      CAMPX_LAUNCH_E(BOARD, NT, 64);           \
+  } while (0)
   if (board) {
-    hipLaunchKernelGGL((rollout_kernel<K, true>), grid, block, shmem, stream, rb, spec_dev, st,
-                       actions, out, B, T, reset_first, emit_first);
+    if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);
   } else {
-    hipLaunchKernelGGL((rollout_kernel<K, false>), grid, block, shmem, stream, rb, spec_dev, st,
-                       actions, out, B, T, reset_first, emit_first);
+    if (nt) CAMPX_LAUNCH(false, true); else CAMPX_LAUNCH(false, false);
   }
+#undef CAMPX_LAUNCH
+#undef CAMPX_LAUNCH_E
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                     int32_t reset_first, int32_t emit_first, hipStream_t stream) {
+  const bool board = out.board != nullptr;
+  const int envs = knob_envs_per_wave();
+  const bool nt = knob_store_nt();
+  const size_t shmem = table_lds_bytes(s, board, envs);
+  const dim3 grid((unsigned)((B + envs - 1) / envs)), block(kWave);
+  const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                          s.dyn_row0[0], s.dyn_col0[0]};
+#define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                      \
+  hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS>), grid, block, shmem, stream, mp, \
+                     spec_dev, st, actions, out, B, T, reset_first, emit_first)
+#define CAMPX_LAUNCH(BOARD, NT)                \
+  do {                                         \
+    if (envs == 16)                            \
+      CAMPX_LAUNCH_E(BOARD, NT, 16);           \
+    else if (envs == 32)                       \
+      CAMPX_LAUNCH_E(BOARD, NT, 32);           \
+    else                                       \
+      CAMPX_LAUNCH_E(BOARD, NT, 64);           \
+  } while (0)
+  if (board) {
+    if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);
+  } else {
+    if (nt) CAMPX_LAUNCH(false, true); else CAMPX_LAUNCH(false, false);
+  }
+#undef CAMPX_LAUNCH
+#undef CAMPX_LAUNCH_E
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
 int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
                const int8_t* actions, CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
-               int32_t emit_first, void* stream) {
+               int32_t emit_first, void* stream, bool interpreter_only = false) {
   if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
   if (reinterpret_cast<uintptr_t>(out.obs) & 15) return CAMPX_EINVAL;
-  if (B > (int64_t)0x7fffffff * kWave) return CAMPX_EINVAL;
+  if (B > (int64_t)0x7fffffff * 16) return CAMPX_EINVAL;
   const int32_t v = campx_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
-  if (lds_bytes(*spec_host, out.board != nullptr) > 160 * 1024) return CAMPX_ESPEC;
+  if (lds_bytes(*spec_host, out.board != nullptr, kWave) > 64 * 1024) return CAMPX_ESPEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table())
+    return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {
     case 1:
       return launch_k<1>(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
@@ -485,6 +731,80 @@ int32_t campx_spec_validate(const CampxSpec* s) {
   }
   if (s->n_rules > 0 && !s->rules[s->n_rules - 1].end_group) return CAMPX_ESPEC;
   return CAMPX_OK;
+}
+
+int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
+  const int32_t v = campx_spec_validate(spec);
+  if (v != CAMPX_OK) return v;
+  spec->table_valid = 0;
+  if (spec->n_dyn != 1) return CAMPX_OK;
+  const int W = spec->cols, HW = spec->rows * spec->cols;
+  const int LHW = spec->n_layers * HW, n = HW * CAMPX_N_ACTIONS;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // One scratch allocation: spec | obs | reward | pos | done | actions | done_out
+  const size_t off_obs = (sizeof(CampxSpec) + 255) & ~(size_t)255;
+  const size_t off_reward = (off_obs + (size_t)n * LHW + 255) & ~(size_t)255;
+  const size_t off_pos = off_reward + sizeof(float) * n;
+  const size_t off_done = off_pos + 2 * (size_t)n;
+  const size_t off_act = off_done + n;
+  const size_t off_dout = off_act + n;
+  const size_t total = off_dout + n;
+  char* dev = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), total);
+  if (e != hipSuccess) return hip_failed(e);
+  // host images of pos / actions: pseudo-environment i = (cell i/5, action i%5)
+  int8_t* host = static_cast<int8_t*>(malloc(4 * (size_t)n + sizeof(float) * n));
+  int8_t* h_pos = host;
+  int8_t* h_act = host + 2 * n;
+  uint8_t* h_done = reinterpret_cast<uint8_t*>(host + 3 * n);
+  float* h_reward = reinterpret_cast<float*>(host + 4 * n);
+  for (int i = 0; i < n; ++i) {
+    const int cell = i / CAMPX_N_ACTIONS;
+    h_pos[i] = (int8_t)(cell / W);
+    h_pos[n + i] = (int8_t)(cell % W);
+    h_act[i] = (int8_t)(i % CAMPX_N_ACTIONS);
+  }
+  int32_t rc = CAMPX_OK;
+#define CAMPX_TRY(call)           \
+  do {                            \
+    e = (call);                   \
+    if (e != hipSuccess) {        \
+      rc = hip_failed(e);         \
+      goto done;                  \
+    }                             \
+  } while (0)
+  CAMPX_TRY(hipMemcpyAsync(dev, spec, sizeof(CampxSpec), hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemcpyAsync(dev + off_pos, h_pos, 2 * (size_t)n, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemcpyAsync(dev + off_act, h_act, (size_t)n, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemsetAsync(dev + off_done, 0, (size_t)n, s));
+  {
+    CampxState st = {reinterpret_cast<int8_t*>(dev + off_pos),
+                     reinterpret_cast<uint8_t*>(dev + off_done), nullptr};
+    CampxOutputs out = {reinterpret_cast<int8_t*>(dev + off_obs), 0, nullptr, 0,
+                        reinterpret_cast<float*>(dev + off_reward), nullptr,
+                        reinterpret_cast<uint8_t*>(dev + off_dout)};
+    rc = launch(spec, reinterpret_cast<const CampxSpec*>(dev), st,
+                reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1, 0, 0, stream,
+                /*interpreter_only=*/true);
+    if (rc != CAMPX_OK) goto done;
+  }
+  CAMPX_TRY(hipMemcpyAsync(h_pos, dev + off_pos, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_reward, dev + off_reward, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipStreamSynchronize(s));
+#undef CAMPX_TRY
+  for (int i = 0; i < n; ++i) {
+    CampxTransition& tr = spec->table[i];
+    tr.reward = h_reward[i];
+    tr.next_cell = (uint8_t)((int)h_pos[i] * W + (int)h_pos[n + i]);
+    tr.done = h_done[i];
+    tr.reserved[0] = tr.reserved[1] = 0;
+  }
+  spec->table_valid = 1;
+done:
+  free(host);
+  (void)hipFree(dev);
+  return rc;
 }
 
 int32_t campx_reset_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState state,

@@ -34,6 +34,12 @@ from . import gamespec
 from .rendering import Observation
 
 
+# One-mover games: tabulate the update pass per (cell, action) at showtime
+# (campx_spec_compile) and let the frame loop look it up.  Tests switch this off to
+# exercise the rule interpreter on the same games.
+COMPILE_TABLE = True
+
+
 def _ptr(t):
   return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -59,6 +65,13 @@ class FusedGame(object):
     self.spec = gamespec.lower(self.description)
     _hip.check(_hip.lib.campx_spec_validate(ctypes.byref(self.spec)),
                'campx_spec_validate')
+    if COMPILE_TABLE:
+      with torch.cuda.device(self.device):
+        _hip.check(_hip.lib.campx_spec_compile(
+            ctypes.byref(self.spec),
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+            'campx_spec_compile')
+    self.uses_table = bool(self.spec.table_valid)
     self.chars = list(self.description.chars)
     self.rows, self.cols = engine.rows, engine.cols
     self.n_layers = len(self.chars)

@@ -53,13 +53,19 @@ class CampxRule(ctypes.Structure):
               ('reserved', ctypes.c_int32 * 3)]
 
 
+class CampxTransition(ctypes.Structure):
+  _fields_ = [('reward', ctypes.c_float), ('next_cell', ctypes.c_uint8),
+              ('done', ctypes.c_uint8), ('reserved', ctypes.c_uint8 * 2)]
+
+
 class CampxSpec(ctypes.Structure):
   _fields_ = [('magic', ctypes.c_uint32), ('version', ctypes.c_uint32),
               ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
               ('n_layers', ctypes.c_int32), ('n_dyn', ctypes.c_int32),
               ('n_static', ctypes.c_int32), ('n_rules', ctypes.c_int32),
               ('any_reward', ctypes.c_int32),
-              ('reserved0', ctypes.c_int32 * 7),
+              ('table_valid', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 6),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * MAX_DYN),
               ('dyn_z', ctypes.c_int32 * MAX_DYN),
@@ -69,7 +75,8 @@ class CampxSpec(ctypes.Structure):
               ('static_top_layer', ctypes.c_uint8 * MAX_CELLS),
               ('static_top_z', ctypes.c_uint8 * MAX_CELLS),
               ('static_cover', ctypes.c_uint16 * MAX_CELLS),
-              ('obs_template', ctypes.c_int8 * (MAX_LAYERS * MAX_CELLS))]
+              ('obs_template', ctypes.c_int8 * (MAX_LAYERS * MAX_CELLS)),
+              ('table', CampxTransition * (MAX_CELLS * N_ACTIONS))]
 
 
 assert ctypes.sizeof(CampxRule) == 64

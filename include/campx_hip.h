@@ -88,6 +88,14 @@ typedef struct CampxRule {
   int32_t reserved[3];
 } CampxRule;              /* 64 bytes */
 
+/* One entry of the (cell, action) transition table of a one-mover game. */
+typedef struct CampxTransition {
+  float reward;       /* summed reward of the frame (NaN = None) */
+  uint8_t next_cell;  /* row * cols + col after the frame */
+  uint8_t done;       /* 1: the episode terminated (discount 0) */
+  uint8_t reserved[2];
+} CampxTransition;    /* 8 bytes */
+
 /*
  * GameSpec: the immutable description of one game, produced once per game by the
  * host (campx_amd/gamespec.py from the ascii_art_to_game() arguments,
@@ -102,7 +110,8 @@ typedef struct CampxSpec {
   int32_t n_static;
   int32_t n_rules;
   int32_t any_reward;                   /* 0: nobody ever calls add_reward -> reward is NaN (None) */
-  int32_t reserved0[7];
+  int32_t table_valid;                  /* 1: `table` below is filled (campx_spec_compile) */
+  int32_t reserved0[6];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_MAX_DYN];     /* layer painted by dynamic thing d */
   int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop) */
@@ -115,6 +124,12 @@ typedef struct CampxSpec {
   uint16_t static_cover[CAMPX_MAX_CELLS];    /* bit s = static drape s covers the cell */
   /* layered board of the static scenery alone, [L][rows*cols] 0/1 */
   int8_t obs_template[CAMPX_MAX_LAYERS * CAMPX_MAX_CELLS];
+  /* Games with ONE moving thing: the whole update pass of a frame is a function of
+   * (cell the thing is in, action).  campx_spec_compile() tabulates it by running
+   * the rule interpreter kernel once over every (cell, action) pair; the frame
+   * loop then does one lookup instead of interpreting the rules.
+   * Index: cell * CAMPX_N_ACTIONS + action. */
+  CampxTransition table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
 } CampxSpec;
 
 /* Dynamic state of B environments, struct-of-arrays, DEVICE pointers. */
@@ -144,6 +159,15 @@ int32_t campx_spec_size(void);
 
 /* Check a HOST GameSpec: magic/version, bounds, rule operands. */
 int32_t campx_spec_validate(const CampxSpec* spec_host);
+
+/*
+ * Optional, once per game: fill spec_host->table for a game with n_dyn == 1 by
+ * running the rule interpreter kernel over all (cell, action) pairs on the current
+ * device, and set table_valid.  A no-op (table_valid stays 0) for n_dyn > 1.
+ * Set-up time only: allocates and frees its own scratch device memory and
+ * synchronises `stream`.  Upload the spec to the device AFTER this call.
+ */
+int32_t campx_spec_compile(CampxSpec* spec_host, void* stream);
 
 /*
  * Put B environments into the state its_showtime() leaves them in

@@ -15,6 +15,18 @@ from games_under_test import FUSED_GAMES
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=['table', 'interpreter'])
+def update_pass_mode(request):
+  """Every test runs twice: with the (cell, action) transition table that
+  campx_spec_compile() builds for one-mover games, and with the rule interpreter
+  only."""
+  from campx_amd import fused
+  saved = fused.COMPILE_TABLE
+  fused.COMPILE_TABLE = request.param == 'table'
+  yield request.param
+  fused.COMPILE_TABLE = saved
+
+
 def _same(a, b):
   a, b = np.asarray(a), np.asarray(b)
   if a.dtype.kind == 'f':
@@ -23,8 +35,11 @@ def _same(a, b):
 
 
 def _fused(name, batch):
+  from campx_amd import fused
   game = FUSED_GAMES[name](batch=batch, device='cuda')
   first = game.its_showtime()
+  one_mover = game.fused.n_dyn == 1
+  assert game.fused.uses_table == (fused.COMPILE_TABLE and one_mover)
   return game, first
 
 
