@@ -141,7 +141,7 @@ __device__ __forceinline__ void stream_out(const int8_t* lds, int8_t* dst, int n
   }
 }
 
-template <int K, bool kBoard, bool kNT, int kEnvs>
+template <int K, bool kBoard, bool kNT, int kEnvs, bool kTrace>
 __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
                                                         const CampxSpec* __restrict__ spec,
                                                         CampxState st,
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   const int n_live = (B - env0 < kEnvs) ? (int)(B - env0) : kEnvs;
 
   // ---- LDS carve-up (every offset a multiple of 16)
-  const int obs_bytes = (kEnvs * LHW + 15) & ~15;
-  const int board_bytes = kBoard ? ((kEnvs * HW + 15) & ~15) : 0;
+  const int obs_bytes = kTrace ? 0 : ((kEnvs * LHW + 15) & ~15);
+  const int board_bytes = (kBoard && !kTrace) ? ((kEnvs * HW + 15) & ~15) : 0;
   int8_t* obs_img = lds;
   int8_t* board_img = lds + obs_bytes;
   int8_t* tmpl = lds + obs_bytes + board_bytes;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   // ---- this wave's slice of the observation, as an LDS image
   int8_t* my_obs = obs_img + lane * LHW;
   int8_t* my_board = board_img + lane * HW;
-  if (mine) {
+  if (!kTrace && mine) {
     for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
     if (kBoard)
       for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)layer_char[top_layer[i]];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   }
   Things<K> img = pos;  // positions the image currently shows
 
-  if (emit_first) {
+  if (!kTrace && emit_first) {
     __syncthreads();
     stream_out<kNT>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
     if (kBoard) stream_out<kNT>(board_img, out.board + env0 * HW, n_live * HW, lane);
@@ -311,24 +311,37 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     if (!rb.any_reward) reward = __builtin_nanf("");
     ret += reward;
 
-    // ---- render: fix up the cells things left and entered, then stream out
-    __syncthreads();  // previous frame's reads of the image are done
+    if (kTrace) {
+      // ---- split path: record where things are (and whether they show); the
+      // render kernel turns that into observations.
+      if (live) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int was = img.r[k] * W + img.c[k];
-      const int now = pos.r[k] * W + pos.c[k];
-      if (mine && was != now) {
-        repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, was, pos);
-        repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, now, pos);
+        for (int k = 0; k < K; ++k) {
+          const int cell = pos.r[k] * W + pos.c[k];
+          const int vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
+          out.trace[((int64_t)k * T + t) * B + env] = (uint8_t)(cell | (vis << 7));
+        }
       }
+    } else {
+      // ---- render: fix up the cells things left and entered, then stream out
+      __syncthreads();  // previous frame's reads of the image are done
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int was = img.r[k] * W + img.c[k];
+        const int now = pos.r[k] * W + pos.c[k];
+        if (mine && was != now) {
+          repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, was, pos);
+          repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, now, pos);
+        }
+      }
+      img = pos;
+      __syncthreads();
+      stream_out<kNT>(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW,
+                      n_live * LHW, lane);
+      if (kBoard)
+        stream_out<kNT>(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW,
+                        n_live * HW, lane);
     }
-    img = pos;
-    __syncthreads();
-    stream_out<kNT>(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW, n_live * LHW,
-                    lane);
-    if (kBoard)
-      stream_out<kNT>(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW,
-                      n_live * HW, lane);
 
     if (live) {
       const int64_t at = (int64_t)t * B + env;
@@ -358,7 +371,7 @@ struct MoverParams {
   int32_t rows, cols, n_layers, dyn_layer, dyn_z, row0, col0;
 };
 
-template <bool kBoard, bool kNT, int kEnvs>
+template <bool kBoard, bool kNT, int kEnvs, bool kTrace>
 __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
@@ -373,8 +386,8 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   const int n_live = (B - env0 < kEnvs) ? (int)(B - env0) : kEnvs;
 
   // ---- LDS carve-up (every offset a multiple of 16)
-  const int obs_bytes = (kEnvs * LHW + 15) & ~15;
-  const int board_bytes = kBoard ? ((kEnvs * HW + 15) & ~15) : 0;
+  const int obs_bytes = kTrace ? 0 : ((kEnvs * LHW + 15) & ~15);
+  const int board_bytes = (kBoard && !kTrace) ? ((kEnvs * HW + 15) & ~15) : 0;
   int8_t* obs_img = lds;
   int8_t* board_img = lds + obs_bytes;
   uint2* table = reinterpret_cast<uint2*>(lds + obs_bytes + board_bytes);  // [HW*5] {reward, next|done<<8}
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   int8_t* my_obs = obs_img + lane * LHW;
   int8_t* my_board = board_img + lane * HW;
   const int mover_off = mp.dyn_layer * HW;
-  if (mine) {
+  if (!kTrace && mine) {
     for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
     if (kBoard)
       for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)scenery_char[i];
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   }
   int shown_at = cell;  // where the image shows the mover
 
-  if (emit_first) {
+  if (!kTrace && emit_first) {
     __syncthreads();
     stream_out<kNT>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
     if (kBoard) stream_out<kNT>(board_img, out.board + env0 * HW, n_live * HW, lane);
@@ -451,27 +464,32 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     over = (int)((tr.y >> 8) & 1u);
     ret += reward;
 
-    __syncthreads();  // previous frame's reads of the image are done
-    if (mine && cell != shown_at) {
-      const int was = paint[shown_at], now = paint[cell];
-      if (!(was & 0x8000)) {
-        my_obs[mover_off + shown_at] = 0;
-        my_obs[was] = 1;
-        if (kBoard) my_board[shown_at] = (int8_t)scenery_char[shown_at];
+    if (kTrace) {
+      if (live)
+        out.trace[(int64_t)t * B + env] = (uint8_t)(cell | ((paint[cell] & 0x8000) ? 0 : 0x80));
+    } else {
+      __syncthreads();  // previous frame's reads of the image are done
+      if (mine && cell != shown_at) {
+        const int was = paint[shown_at], now = paint[cell];
+        if (!(was & 0x8000)) {
+          my_obs[mover_off + shown_at] = 0;
+          my_obs[was] = 1;
+          if (kBoard) my_board[shown_at] = (int8_t)scenery_char[shown_at];
+        }
+        if (!(now & 0x8000)) {
+          my_obs[now] = 0;
+          my_obs[mover_off + cell] = 1;
+          if (kBoard) my_board[cell] = mover_char;
+        }
+        shown_at = cell;
       }
-      if (!(now & 0x8000)) {
-        my_obs[now] = 0;
-        my_obs[mover_off + cell] = 1;
-        if (kBoard) my_board[cell] = mover_char;
-      }
-      shown_at = cell;
+      __syncthreads();
+      stream_out<kNT>(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW,
+                      n_live * LHW, lane);
+      if (kBoard)
+        stream_out<kNT>(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW,
+                        n_live * HW, lane);
     }
-    __syncthreads();
-    stream_out<kNT>(obs_img, out.obs + (int64_t)t * out.obs_t_stride + env0 * LHW, n_live * LHW,
-                    lane);
-    if (kBoard)
-      stream_out<kNT>(board_img, out.board + (int64_t)t * out.board_t_stride + env0 * HW,
-                      n_live * HW, lane);
     if (live) {
       const int64_t at = (int64_t)t * B + env;
       if (out.reward) out.reward[at] = reward;
@@ -496,6 +514,97 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
   n += CAMPX_MAX_CELLS * sizeof(uint16_t) + CAMPX_MAX_CELLS;
   n += (size_t)kChunk * kWave + (size_t)LHW;
   return (n + 15) & ~(size_t)15;
+}
+
+// ---------------------------------------------------------------------------
+// Split path, second half: expand the trace (one byte per moving thing per frame)
+// into the observation stream.  One-shot blocks, one 16-byte store per thread,
+// block b writing bytes [b*16*kThreads, (b+1)*16*kThreads): the dispatcher walks
+// the output linearly, which is the access pattern that reaches the HBM write
+// ceiling on this chip (tools/probes/stream_probe.hip: 6.9 TB/s, against 5.4 TB/s
+// for persistent waves that each stream a private tile).
+//
+// The output is a sequence of rows of R bytes (R = L*H*W for the layered board,
+// H*W for the flat board), row q = t*B + env.  A row is the scenery's row with up
+// to two bytes changed per moving thing.  `rot` holds 16 byte-rotations of the
+// doubled scenery row so that any 16-byte window of consecutive rows is ONE
+// aligned ds_read_b128.
+struct RenderParams {
+  int32_t R;            // row bytes
+  uint32_t magic;       // floor(2^32 / R) + 1
+  int32_t n_dyn, HW;
+  int32_t is_board;
+  int32_t dyn_layer[CAMPX_MAX_DYN];
+  int32_t dyn_char[CAMPX_MAX_DYN];
+};
+
+__device__ __forceinline__ void poke(u32x4& v, int p, uint32_t val) {
+  // byte p of v = val, when 0 <= p < 16
+  const bool in = (unsigned)p < 16u;
+  const uint32_t sh = (uint32_t)(p & 3) * 8u;
+  const uint32_t keep = ~(0xffu << sh), bits = val << sh;
+  const int w = p >> 2;
+  v.x = (in && w == 0) ? ((v.x & keep) | bits) : v.x;
+  v.y = (in && w == 1) ? ((v.y & keep) | bits) : v.y;
+  v.z = (in && w == 2) ? ((v.z & keep) | bits) : v.z;
+  v.w = (in && w == 3) ? ((v.w & keep) | bits) : v.w;
+}
+
+template <int kThreads, bool kNT>
+__global__ __launch_bounds__(kThreads) void render_kernel(RenderParams rp,
+                                                          const CampxSpec* __restrict__ spec,
+                                                          const uint8_t* __restrict__ trace,
+                                                          int8_t* __restrict__ dst, int64_t n_rows) {
+  const int R = rp.R, HW = rp.HW;
+  const int pitch = ((R + 15) & ~15) + 16;
+  const int8_t* rot = rp.is_board ? spec->rot_board : spec->rot_obs;  // L1/L2-resident
+
+  const int64_t n_bytes = n_rows * R;
+  const int64_t off0 = (int64_t)blockIdx.x * (16 * kThreads);
+  const int64_t q0 = off0 / R;                       // scalar, once per wave
+  const int k0 = (int)(off0 - q0 * R);
+  const uint32_t local = (uint32_t)k0 + (uint32_t)threadIdx.x * 16u;
+  const uint32_t dq = __umulhi(local, rp.magic);     // local / R, exact for local < 2^16
+  const int k = (int)(local - dq * (uint32_t)R);
+  const int64_t q = q0 + dq;
+  const int64_t off = off0 + (int64_t)threadIdx.x * 16;
+  if (off >= n_bytes) return;
+
+  u32x4 v = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+  const bool two_rows = (k + 16 > R) && (q + 1 < n_rows);
+  for (int d = 0; d < rp.n_dyn; ++d) {
+    const uint8_t* plane = trace + (int64_t)d * n_rows;
+    const int a = plane[q];
+    const int b = two_rows ? (int)plane[q + 1] : 0;
+    const int set_base = rp.is_board ? 0 : rp.dyn_layer[d] * HW;
+    const uint32_t set_val = rp.is_board ? (uint32_t)rp.dyn_char[d] : 1u;
+    // row q occupies window bytes [-k, R-k); row q+1 starts at window byte R-k.
+    // An invisible thing changes nothing: its pokes are pushed out of range.
+    {
+      const int cell = a & 0x7f;
+      const int shift = (a & 0x80) ? 0 : (1 << 20);
+      if (!rp.is_board)
+        poke(v, (int)spec->static_top_layer[cell] * HW + cell - k + shift, 0u);
+      poke(v, set_base + cell - k + shift, set_val);
+    }
+    if (two_rows) {
+      const int cell = b & 0x7f;
+      const int shift = (b & 0x80) ? 0 : (1 << 20);
+      if (!rp.is_board)
+        poke(v, (int)spec->static_top_layer[cell] * HW + cell + (R - k) + shift, 0u);
+      poke(v, set_base + cell + (R - k) + shift, set_val);
+    }
+  }
+  if (off + 16 <= n_bytes) {
+    u32x4* o = reinterpret_cast<u32x4*>(dst + off);
+    if (kNT)
+      __builtin_nontemporal_store(v, o);
+    else
+      *o = v;
+  } else {  // ragged end of the buffer
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; off + j < n_bytes; ++j) dst[off + j] = (int8_t)(w[j >> 2] >> ((j & 3) * 8));
+  }
 }
 
 __global__ void check_actions_kernel(const int8_t* __restrict__ actions, int64_t n,
@@ -548,6 +657,21 @@ bool knob_store_nt() {
   }();
   return nt;
 }
+bool knob_no_split() {
+  static const bool off = [] {
+    const char* v = getenv("CAMPX_NO_SPLIT");
+    return v && v[0] == '1';
+  }();
+  return off;
+}
+int knob_render_threads() {
+  static const int n = [] {
+    const char* v = getenv("CAMPX_RENDER_THREADS");
+    const int t = v ? atoi(v) : 256;
+    return (t == 512 || t == 1024) ? t : 256;
+  }();
+  return n;
+}
 bool knob_no_table() {
   static const bool off = [] {
     const char* v = getenv("CAMPX_NO_TABLE");
@@ -599,8 +723,8 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   const RuleBlock rb = make_rule_block(s);
   const bool nt = knob_store_nt();
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
-  hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS>), grid, block, shmem, stream, rb, \
-                     spec_dev, st, actions, out, B, T, reset_first, emit_first)
+  hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
+                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first)
 #define CAMPX_LAUNCH(BOARD, NT)                \
   do {                                         \
     if (envs == 16)                            \
@@ -632,8 +756,8 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                      \
-  hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS>), grid, block, shmem, stream, mp, \
-                     spec_dev, st, actions, out, B, T, reset_first, emit_first)
+  hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS, false>), grid, block, shmem,    \
+                     stream, mp, spec_dev, st, actions, out, B, T, reset_first, emit_first)
 #define CAMPX_LAUNCH(BOARD, NT)                \
   do {                                         \
     if (envs == 16)                            \
@@ -654,6 +778,79 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
+// ---- split path: update pass -> trace, then one-shot render kernels
+template <int K>
+void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                    const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                    int32_t reset_first, hipStream_t stream) {
+  const size_t shmem = lds_bytes(s, false, 0);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const RuleBlock rb = make_rule_block(s);
+  hipLaunchKernelGGL((rollout_kernel<K, false, false, kWave, true>), grid, block, shmem, stream,
+                     rb, spec_dev, st, actions, out, B, T, reset_first, 0);
+}
+
+int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
+                      int8_t* dst, int64_t n_rows, bool is_board, hipStream_t stream) {
+  const int HW = s.rows * s.cols;
+  RenderParams rp;
+  memset(&rp, 0, sizeof(rp));
+  rp.R = is_board ? HW : s.n_layers * HW;
+  rp.magic = (uint32_t)((((uint64_t)1) << 32) / (uint32_t)rp.R) + 1u;
+  rp.n_dyn = s.n_dyn;
+  rp.HW = HW;
+  rp.is_board = is_board ? 1 : 0;
+  memcpy(rp.dyn_layer, s.dyn_layer, sizeof(rp.dyn_layer));
+  for (int d = 0; d < s.n_dyn; ++d) rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
+  const int threads = knob_render_threads();
+  const bool nt = knob_store_nt();
+  const size_t shmem = 0;
+  const int64_t n_vec = (n_rows * rp.R + 15) / 16;
+  const int64_t n_blocks = (n_vec + threads - 1) / threads;
+  if (n_blocks > 0x7fffffff) return CAMPX_EINVAL;
+  const dim3 grid((unsigned)n_blocks);
+#define CAMPX_RENDER(THREADS, NT)                                                          \
+  hipLaunchKernelGGL((render_kernel<THREADS, NT>), grid, dim3(THREADS), shmem, stream, rp, \
+                     spec_dev, trace, dst, n_rows)
+  if (threads == 1024) {
+    if (nt) CAMPX_RENDER(1024, true); else CAMPX_RENDER(1024, false);
+  } else if (threads == 512) {
+    if (nt) CAMPX_RENDER(512, true); else CAMPX_RENDER(512, false);
+  } else {
+    if (nt) CAMPX_RENDER(256, true); else CAMPX_RENDER(256, false);
+  }
+#undef CAMPX_RENDER
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                     int32_t reset_first, bool use_table, hipStream_t stream) {
+  if (use_table) {
+    const size_t shmem = table_lds_bytes(s, false, 0);
+    const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+    const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                            s.dyn_row0[0], s.dyn_col0[0]};
+    hipLaunchKernelGGL((rollout_table_kernel<false, false, kWave, true>), grid, block, shmem,
+                       stream, mp, spec_dev, st, actions, out, B, T, reset_first, 0);
+  } else {
+    switch (s.n_dyn) {
+      case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
+      case 2: launch_trace_k<2>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
+      case 3: launch_trace_k<3>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
+      default: launch_trace_k<4>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_failed(e);
+  const int64_t n_rows = (int64_t)T * B;
+  int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, n_rows, false, stream);
+  if (rc != CAMPX_OK) return rc;
+  if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, n_rows, true, stream);
+  return rc;
+}
+
 int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
                const int8_t* actions, CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
                int32_t emit_first, void* stream, bool interpreter_only = false) {
@@ -666,7 +863,19 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (v != CAMPX_OK) return v;
   if (lds_bytes(*spec_host, out.board != nullptr, kWave) > 64 * 1024) return CAMPX_ESPEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table())
+  const bool use_table =
+      spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table();
+  {
+    const int64_t HW = (int64_t)spec_host->rows * spec_host->cols;
+    const int64_t LHW = HW * spec_host->n_layers;
+    const bool split = out.trace && spec_host->render_valid && T > 0 && !emit_first && !interpreter_only && LHW >= 16 &&
+                       out.obs_t_stride == B * LHW &&
+                       (!out.board || (out.board_t_stride == B * HW && HW >= 16)) &&
+                       !knob_no_split();
+    if (split)
+      return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
+  }
+  if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {
     case 1:
@@ -737,6 +946,18 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   const int32_t v = campx_spec_validate(spec);
   if (v != CAMPX_OK) return v;
   spec->table_valid = 0;
+  {
+    const int HW = spec->rows * spec->cols, LHW = spec->n_layers * HW;
+    const int pitch_obs = ((LHW + 15) & ~15) + 16, pitch_board = ((HW + 15) & ~15) + 16;
+    for (int r = 0; r < 16; ++r) {
+      for (int j = 0; j < pitch_obs; ++j)
+        spec->rot_obs[r * pitch_obs + j] = spec->obs_template[(j + r) % LHW];
+      for (int j = 0; j < pitch_board; ++j)
+        spec->rot_board[r * pitch_board + j] =
+            (int8_t)spec->layer_char[spec->static_top_layer[(j + r) % HW]];
+    }
+    spec->render_valid = 1;
+  }
   if (spec->n_dyn != 1) return CAMPX_OK;
   const int W = spec->cols, HW = spec->rows * spec->cols;
   const int LHW = spec->n_layers * HW, n = HW * CAMPX_N_ACTIONS;

@@ -38,6 +38,9 @@ from .rendering import Observation
 # (campx_spec_compile) and let the frame loop look it up.  Tests switch this off to
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
+# Rollouts that keep every frame: run the update pass and the render as two
+# kernels (needs a [K, T, B] byte trace buffer).  Tests also run with this off.
+SPLIT_ROLLOUT = False
 
 
 def _ptr(t):
@@ -150,7 +153,7 @@ class FusedGame(object):
   def showtime(self):
     """its_showtime(): state from the art, first observation, reward None."""
     out = _hip.CampxOutputs(_ptr(self._obs), 0, _ptr(self._board), 0,
-                            None, None, None)
+                            None, None, None, None)
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_reset_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(), out,
@@ -162,7 +165,7 @@ class FusedGame(object):
     ids = self._action_ids(actions, (self.batch,))
     out = _hip.CampxOutputs(_ptr(self._obs), 0, _ptr(self._board), 0,
                             _ptr(self._reward), _ptr(self._discount),
-                            _ptr(self._step_done))
+                            _ptr(self._step_done), None)
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_rollout_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(),
@@ -209,8 +212,11 @@ class FusedGame(object):
     reward = torch.empty((T, B), dtype=torch.float32, device=dev)
     discount = torch.empty((T, B), dtype=torch.float32, device=dev)
     done = torch.empty((T, B), dtype=torch.uint8, device=dev)
+    # The compact trajectory; giving it lets the library take its two-kernel path.
+    trace = (torch.empty((self.n_dyn, T, B), dtype=torch.uint8, device=dev)
+             if keep_obs and SPLIT_ROLLOUT else None)
     out = _hip.CampxOutputs(_ptr(obs), obs_stride, _ptr(board), board_stride,
-                            _ptr(reward), _ptr(discount), _ptr(done))
+                            _ptr(reward), _ptr(discount), _ptr(done), _ptr(trace))
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_rollout_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(),
@@ -219,4 +225,4 @@ class FusedGame(object):
     self.frame = T if reset_first else self.frame + T
     return dict(obs=obs, board=board,
                 reward=reward if self.any_reward else None,
-                discount=discount, done=done)
+                discount=discount, done=done, trace=trace)

@@ -65,7 +65,8 @@ class CampxSpec(ctypes.Structure):
               ('n_static', ctypes.c_int32), ('n_rules', ctypes.c_int32),
               ('any_reward', ctypes.c_int32),
               ('table_valid', ctypes.c_int32),
-              ('reserved0', ctypes.c_int32 * 6),
+              ('render_valid', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 5),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * MAX_DYN),
               ('dyn_z', ctypes.c_int32 * MAX_DYN),
@@ -76,7 +77,9 @@ class CampxSpec(ctypes.Structure):
               ('static_top_z', ctypes.c_uint8 * MAX_CELLS),
               ('static_cover', ctypes.c_uint16 * MAX_CELLS),
               ('obs_template', ctypes.c_int8 * (MAX_LAYERS * MAX_CELLS)),
-              ('table', CampxTransition * (MAX_CELLS * N_ACTIONS))]
+              ('table', CampxTransition * (MAX_CELLS * N_ACTIONS)),
+              ('rot_obs', ctypes.c_int8 * (16 * (MAX_LAYERS * MAX_CELLS + 16))),
+              ('rot_board', ctypes.c_int8 * (16 * (MAX_CELLS + 16)))]
 
 
 assert ctypes.sizeof(CampxRule) == 64

@@ -111,7 +111,8 @@ typedef struct CampxSpec {
   int32_t n_rules;
   int32_t any_reward;                   /* 0: nobody ever calls add_reward -> reward is NaN (None) */
   int32_t table_valid;                  /* 1: `table` below is filled (campx_spec_compile) */
-  int32_t reserved0[6];
+  int32_t render_valid;                 /* 1: `rot_obs` / `rot_board` below are filled */
+  int32_t reserved0[5];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_MAX_DYN];     /* layer painted by dynamic thing d */
   int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop) */
@@ -130,6 +131,14 @@ typedef struct CampxSpec {
    * loop then does one lookup instead of interpreting the rules.
    * Index: cell * CAMPX_N_ACTIONS + action. */
   CampxTransition table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+  /* For the render kernel of the two-kernel path, filled by campx_spec_compile():
+   * 16 byte-rotations of the scenery's row (the layered board, resp. the flat board,
+   * of the static scenery), each continued cyclically, so that any 16 consecutive
+   * bytes of back-to-back rows are one aligned 16-byte load:
+   *   rot[r * pitch + j] = row[(j + r) mod R],  pitch = round_up(R, 16) + 16,
+   * R = L*rows*cols (rot_obs) or rows*cols (rot_board).  16-byte aligned in the blob. */
+  int8_t rot_obs[16 * (CAMPX_MAX_LAYERS * CAMPX_MAX_CELLS + 16)];
+  int8_t rot_board[16 * (CAMPX_MAX_CELLS + 16)];
 } CampxSpec;
 
 /* Dynamic state of B environments, struct-of-arrays, DEVICE pointers. */
@@ -152,6 +161,13 @@ typedef struct CampxOutputs {
   float* reward;      /* [T, B]; NaN where the reference returns None */
   float* discount;    /* [T, B] 1.0, or 0.0 on the frame the episode ended (plot.py:179-184) */
   uint8_t* done;      /* [T, B] game-over flag after the frame */
+  uint8_t* trace;     /* optional [K, T, B]: for moving thing d at frame t in environment e,
+                         bits 0-6 = the cell (row*cols + col) it is in after the frame, bit 7 = 1
+                         when it is the character that cell shows.  A compact trajectory in
+                         its own right; and when it is given and frames are stored back to
+                         back (obs_t_stride == B*L*rows*cols), the library runs the update
+                         pass and the render as two kernels, which streams the observations
+                         to HBM faster (DESIGN.md "Kernels").  Written only on that path. */
 } CampxOutputs;
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */
@@ -161,9 +177,10 @@ int32_t campx_spec_size(void);
 int32_t campx_spec_validate(const CampxSpec* spec_host);
 
 /*
- * Optional, once per game: fill spec_host->table for a game with n_dyn == 1 by
- * running the rule interpreter kernel over all (cell, action) pairs on the current
- * device, and set table_valid.  A no-op (table_valid stays 0) for n_dyn > 1.
+ * Optional, once per game: derive the acceleration tables of a GameSpec.
+ *   - rot_obs / rot_board (render_valid): host arithmetic on the scenery tables.
+ *   - table (table_valid), only for n_dyn == 1: the rule interpreter kernel is run
+ *     over all (cell, action) pairs on the current device.
  * Set-up time only: allocates and frees its own scratch device memory and
  * synchronises `stream`.  Upload the spec to the device AFTER this call.
  */

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=['table', 'interpreter'])
 def update_pass_mode(request):
-  """Every test runs twice: with the (cell, action) transition table that
+  """Every test runs with the (cell, action) transition table that
   campx_spec_compile() builds for one-mover games, and with the rule interpreter
   only."""
   from campx_amd import fused
@@ -25,6 +25,17 @@ def update_pass_mode(request):
   fused.COMPILE_TABLE = request.param == 'table'
   yield request.param
   fused.COMPILE_TABLE = saved
+
+
+@pytest.fixture(autouse=True, params=['split', 'fused'])
+def rollout_path(request):
+  """... and with rollouts as two kernels (update pass -> trace -> render) or as the
+  single fused kernel."""
+  from campx_amd import fused
+  saved = fused.SPLIT_ROLLOUT
+  fused.SPLIT_ROLLOUT = request.param == 'split'
+  yield request.param
+  fused.SPLIT_ROLLOUT = saved
 
 
 def _same(a, b):

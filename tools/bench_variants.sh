@@ -1,15 +1,18 @@
 #!/bin/bash
 # A/B the kernel's tuning knobs on the GPU box: prints one bench line per variant.
-for notable in 0 1; do
-for envs in 64 32; do
-for nt in 1 0; do
-  echo "== CAMPX_NO_TABLE=$notable CAMPX_ENVS_PER_WAVE=$envs CAMPX_STORE_NT=$nt"
-  CAMPX_NO_TABLE=$notable CAMPX_ENVS_PER_WAVE=$envs CAMPX_STORE_NT=$nt python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+run() {
+  echo "== $*"
+  env "$@" python bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('value %.3e  kernel_ms %.4f  GB/s %.0f  frac %.3f' % (d['value'], d['roofline']['kernel_ms'], d['roofline']['achieved'], d['roofline']['frac']))
+        d = json.loads(l); print('value %.3e  ms/step %.4f kernel_ms %.4f  GB/s %.0f  frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved'], d['roofline']['frac']))
 "
-done
-done
-done
+}
+run CAMPX_NO_SPLIT=1
+run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=256
+run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=512
+run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=1024
+run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=256 CAMPX_STORE_NT=0
+run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=1024 CAMPX_STORE_NT=0
+run CAMPX_NO_SPLIT=0 CAMPX_NO_TABLE=1
