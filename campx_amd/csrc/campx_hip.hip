@@ -79,6 +79,11 @@ __device__ __forceinline__ void put(int (&v)[K], int d, int x) {
   for (int k = 0; k < K; ++k) v[k] = (d == k) ? x : v[k];
 }
 
+// Trace entry of one moving thing at one frame (CampxOutputs.trace).
+__device__ __forceinline__ uint32_t pack_trace(int set_off, int clear_off, int cell, uint32_t vis) {
+  return (uint32_t)set_off | ((uint32_t)clear_off << 11) | ((uint32_t)cell << 22) | (vis << 29);
+}
+
 // Cyclic one-cell move: 0 left (col-1), 1 right, 2 up (row-1), 3 down, else stay
 // (examples/boat_race.py:42-49).  Branch-free: the action differs per lane.
 __device__ __forceinline__ void moved(int a, int H, int W, int r, int c, int& r2, int& c2) {
@@ -122,6 +127,34 @@ __device__ __forceinline__ void repaint_cell(const RuleBlock& rb, const LdsTable
 
 // Stream `nbytes` of an LDS image to global memory.  16-byte vector path when the
 // destination is 16-byte aligned, byte path otherwise (odd batch tails only).
+// Copy this lane's next actions (frames t .. t+kChunk-1) into LDS.  All loads of a
+// group of 16 are issued before any is used; rows past the end are clamped so that
+// there is no branch between the loads (a branch makes hipcc wait for each load
+// before issuing the next: 64 serial HBM round trips per chunk).
+template <int kLanes>
+__device__ __forceinline__ void stage_actions(int8_t* staged, const int8_t* __restrict__ actions,
+                                              int64_t B, int32_t T, int t, int64_t env, bool live,
+                                              int lane) {
+  const int64_t col = live ? env : 0;  // any valid column
+  if (T - t >= 16) {
+    const int n = (T - t < kChunk) ? T - t : kChunk;
+    for (int r0 = 0; r0 < n; r0 += 16) {
+      int8_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        int row = t + r0 + j;
+        row = row < T ? row : T - 1;
+        v[j] = actions[(int64_t)row * B + col];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) staged[(r0 + j) * kLanes + lane] = live ? v[j] : (int8_t)4;
+    }
+  } else {
+    for (int r = 0; r < T - t; ++r)
+      staged[r * kLanes + lane] = live ? actions[(int64_t)(t + r) * B + col] : (int8_t)4;
+  }
+}
+
 template <bool kNT>
 __device__ __forceinline__ void stream_out(const int8_t* lds, int8_t* dst, int nbytes, int lane) {
   if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
@@ -222,12 +255,8 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
 
   for (int t = 0; t < T; ++t) {
     const int in_chunk = t & (kChunk - 1);
-    if (in_chunk == 0) {  // each lane stages its own environment's next actions
-      const int n = (T - t < kChunk) ? T - t : kChunk;
-      if (mine)
-        for (int r = 0; r < n; ++r)
-          staged[r * kEnvs + lane] = live ? actions[(int64_t)(t + r) * B + env] : (int8_t)4;
-    }
+    if (in_chunk == 0 && mine)  // each lane stages its own environment's next actions
+      stage_actions<kEnvs>(staged, actions, B, T, t, env, live, lane);
     int a = mine ? staged[in_chunk * kEnvs + lane] : 4;
     a = ((unsigned)a > 4u) ? 4 : a;
 
@@ -318,8 +347,9 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const int cell = pos.r[k] * W + pos.c[k];
-          const int vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
-          out.trace[((int64_t)k * T + t) * B + env] = (uint8_t)(cell | (vis << 7));
+          const uint32_t vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
+          out.trace[((int64_t)k * T + t) * B + env] =
+              pack_trace(rb.dyn_layer[k] * HW + cell, top_layer[cell] * HW + cell, cell, vis);
         }
       }
     } else {
@@ -371,7 +401,7 @@ struct MoverParams {
   int32_t rows, cols, n_layers, dyn_layer, dyn_z, row0, col0;
 };
 
-template <bool kBoard, bool kNT, int kEnvs, bool kTrace>
+template <bool kBoard, bool kNT, int kEnvs>
 __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
@@ -386,8 +416,8 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   const int n_live = (B - env0 < kEnvs) ? (int)(B - env0) : kEnvs;
 
   // ---- LDS carve-up (every offset a multiple of 16)
-  const int obs_bytes = kTrace ? 0 : ((kEnvs * LHW + 15) & ~15);
-  const int board_bytes = (kBoard && !kTrace) ? ((kEnvs * HW + 15) & ~15) : 0;
+  const int obs_bytes = (kEnvs * LHW + 15) & ~15;
+  const int board_bytes = kBoard ? ((kEnvs * HW + 15) & ~15) : 0;
   int8_t* obs_img = lds;
   int8_t* board_img = lds + obs_bytes;
   uint2* table = reinterpret_cast<uint2*>(lds + obs_bytes + board_bytes);  // [HW*5] {reward, next|done<<8}
@@ -425,7 +455,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   int8_t* my_obs = obs_img + lane * LHW;
   int8_t* my_board = board_img + lane * HW;
   const int mover_off = mp.dyn_layer * HW;
-  if (!kTrace && mine) {
+  if (mine) {
     for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
     if (kBoard)
       for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)scenery_char[i];
@@ -438,7 +468,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   }
   int shown_at = cell;  // where the image shows the mover
 
-  if (!kTrace && emit_first) {
+  if (emit_first) {
     __syncthreads();
     stream_out<kNT>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
     if (kBoard) stream_out<kNT>(board_img, out.board + env0 * HW, n_live * HW, lane);
@@ -446,12 +476,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
 
   for (int t = 0; t < T; ++t) {
     const int in_chunk = t & (kChunk - 1);
-    if (in_chunk == 0) {
-      const int n = (T - t < kChunk) ? T - t : kChunk;
-      if (mine)
-        for (int r = 0; r < n; ++r)
-          staged[r * kEnvs + lane] = live ? actions[(int64_t)(t + r) * B + env] : (int8_t)4;
-    }
+    if (in_chunk == 0 && mine) stage_actions<kEnvs>(staged, actions, B, T, t, env, live, lane);
     int a = mine ? staged[in_chunk * kEnvs + lane] : 4;
     a = ((unsigned)a > 4u) ? 4 : a;
     if (over) {  // rebuilt from the art before its next action
@@ -464,10 +489,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     over = (int)((tr.y >> 8) & 1u);
     ret += reward;
 
-    if (kTrace) {
-      if (live)
-        out.trace[(int64_t)t * B + env] = (uint8_t)(cell | ((paint[cell] & 0x8000) ? 0 : 0x80));
-    } else {
+    {
       __syncthreads();  // previous frame's reads of the image are done
       if (mine && cell != shown_at) {
         const int was = paint[shown_at], now = paint[cell];
@@ -517,24 +539,108 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
 }
 
 // ---------------------------------------------------------------------------
-// Split path, second half: expand the trace (one byte per moving thing per frame)
-// into the observation stream.  One-shot blocks, one 16-byte store per thread,
-// block b writing bytes [b*16*kThreads, (b+1)*16*kThreads): the dispatcher walks
-// the output linearly, which is the access pattern that reaches the HBM write
-// ceiling on this chip (tools/probes/stream_probe.hip: 6.9 TB/s, against 5.4 TB/s
-// for persistent waves that each stream a private tile).
+// Split path, first half, one-mover games: the update pass alone, from the
+// transition table.  The only loop-carried dependency of a frame is
+// cell -> table[cell, action] -> cell, one LDS read; frames are therefore processed
+// kUnroll at a time: first the dependent chain of lookups, then all their outputs,
+// which are independent of each other and pipeline freely.
+constexpr int kUnroll = 16;
+
+__global__ __launch_bounds__(kWave) void trace_table_kernel(MoverParams mp,
+                                                            const CampxSpec* __restrict__ spec,
+                                                            CampxState st,
+                                                            const int8_t* __restrict__ actions,
+                                                            CampxOutputs out, int64_t B, int32_t T,
+                                                            int32_t reset_first) {
+  __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+  __shared__ uint32_t entry[CAMPX_MAX_CELLS];  // trace entry of the mover when at that cell
+  __shared__ int8_t staged[kChunk * kWave];
+  const int lane = threadIdx.x;
+  const int W = mp.cols, HW = mp.rows * mp.cols;
+  const int64_t env = (int64_t)blockIdx.x * kWave + lane;
+  const bool live = env < B;
+
+  for (int i = lane; i < HW * CAMPX_N_ACTIONS; i += kWave) {
+    const CampxTransition tr = spec->table[i];
+    table[i] = make_uint2(__float_as_uint(tr.reward), (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8));
+  }
+  for (int i = lane; i < HW; i += kWave) {
+    const int layer = spec->static_top_layer[i];
+    const uint32_t vis = spec->static_top_z[i] > mp.dyn_z ? 0u : 1u;
+    entry[i] = pack_trace(mp.dyn_layer * HW + i, layer * HW + i, i, vis);
+  }
+  __syncthreads();
+
+  const int cell0 = mp.row0 * W + mp.col0;
+  int cell = cell0, over = 0;
+  float ret = 0.0f;
+  if (!reset_first && live) {
+    cell = (int)st.pos[env] * W + (int)st.pos[B + env];
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+
+  for (int t0 = 0; t0 < T; t0 += kUnroll) {
+    if ((t0 & (kChunk - 1)) == 0) stage_actions<kWave>(staged, actions, B, T, t0, env, live, lane);
+    const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
+    uint2 e[kUnroll];
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      if (j < n) {
+        int a = staged[((t0 + j) & (kChunk - 1)) * kWave + lane];
+        a = ((unsigned)a > 4u) ? 4 : a;
+        if (over) {  // rebuilt from the art before its next action
+          cell = cell0;
+          ret = 0.0f;
+        }
+        e[j] = table[cell * CAMPX_N_ACTIONS + a];
+        cell = (int)(e[j].y & 0xffu);
+        over = (int)((e[j].y >> 8) & 1u);
+        ret += __uint_as_float(e[j].x);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < kUnroll; ++j) {
+        if (j < n) {
+          const int64_t at = (int64_t)(t0 + j) * B + env;
+          const uint32_t done = (e[j].y >> 8) & 1u;
+          out.trace[at] = entry[e[j].y & 0xffu];
+          if (out.reward) out.reward[at] = __uint_as_float(e[j].x);
+          if (out.discount) out.discount[at] = done ? 0.0f : 1.0f;
+          if (out.done) out.done[at] = (uint8_t)done;
+        }
+      }
+    }
+  }
+
+  if (live) {
+    st.pos[env] = (int8_t)(cell / W);
+    st.pos[B + env] = (int8_t)(cell % W);
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Split path, second half: expand the trace into the observation stream.
+// One-shot blocks, ONE aligned 16-byte store per thread, block (x, t) writing bytes
+// [x*4096, (x+1)*4096) of frame t: the dispatcher walks the output linearly.  That
+// is the store pattern that reaches the HBM write ceiling on this chip
+// (tools/probes: 6.9 TB/s, against 5.4 TB/s for long-lived waves that each stream a
+// private tile, whatever the tile size).
 //
-// The output is a sequence of rows of R bytes (R = L*H*W for the layered board,
-// H*W for the flat board), row q = t*B + env.  A row is the scenery's row with up
-// to two bytes changed per moving thing.  `rot` holds 16 byte-rotations of the
-// doubled scenery row so that any 16-byte window of consecutive rows is ONE
-// aligned ds_read_b128.
+// A frame is B rows of R bytes (R = L*H*W for the layered board, H*W for the flat
+// board).  A row is the scenery's row with at most two bytes changed per moving
+// thing, given by its trace entry.  spec->rot_* hold 16 byte-rotations of the
+// cyclically continued scenery row, so any 16-byte window of back-to-back rows is
+// ONE aligned 16-byte load (L1-resident).
 struct RenderParams {
-  int32_t R;            // row bytes
-  uint32_t magic;       // floor(2^32 / R) + 1
-  int32_t n_dyn, HW;
-  int32_t is_board;
-  int32_t dyn_layer[CAMPX_MAX_DYN];
+  uint32_t R;                 // row bytes
+  uint32_t m, sh1, sh2;       // exact n / R for 32-bit n (Granlund-Montgomery)
+  uint32_t slab_bytes;        // B * R, a multiple of 16
+  int32_t n_dyn, is_board;
+  int64_t B;
   int32_t dyn_char[CAMPX_MAX_DYN];
 };
 
@@ -550,60 +656,78 @@ __device__ __forceinline__ void poke(u32x4& v, int p, uint32_t val) {
   v.w = (in && w == 3) ? ((v.w & keep) | bits) : v.w;
 }
 
-template <int kThreads, bool kNT>
-__global__ __launch_bounds__(kThreads) void render_kernel(RenderParams rp,
-                                                          const CampxSpec* __restrict__ spec,
-                                                          const uint8_t* __restrict__ trace,
-                                                          int8_t* __restrict__ dst, int64_t n_rows) {
-  const int R = rp.R, HW = rp.HW;
+// One 16-byte chunk of frame `t`: bytes [off, off+16) of the frame.
+template <int K, bool kBoard>
+__device__ __forceinline__ u32x4 render_chunk(const RenderParams& rp, const int8_t* __restrict__ rot,
+                                              const uint32_t* __restrict__ trace, int64_t n_rows,
+                                              int64_t row0, uint32_t off) {
+  const int R = (int)rp.R;
+  const uint32_t hi = __umulhi(rp.m, off);
+  const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
+  const int k = (int)(off - row * rp.R);                           // off % R
+  const int64_t q = row0 + row;                                    // row of the trajectory
   const int pitch = ((R + 15) & ~15) + 16;
-  const int8_t* rot = rp.is_board ? spec->rot_board : spec->rot_obs;  // L1/L2-resident
-
-  const int64_t n_bytes = n_rows * R;
-  const int64_t off0 = (int64_t)blockIdx.x * (16 * kThreads);
-  const int64_t q0 = off0 / R;                       // scalar, once per wave
-  const int k0 = (int)(off0 - q0 * R);
-  const uint32_t local = (uint32_t)k0 + (uint32_t)threadIdx.x * 16u;
-  const uint32_t dq = __umulhi(local, rp.magic);     // local / R, exact for local < 2^16
-  const int k = (int)(local - dq * (uint32_t)R);
-  const int64_t q = q0 + dq;
-  const int64_t off = off0 + (int64_t)threadIdx.x * 16;
-  if (off >= n_bytes) return;
-
-  u32x4 v = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
-  const bool two_rows = (k + 16 > R) && (q + 1 < n_rows);
-  for (int d = 0; d < rp.n_dyn; ++d) {
-    const uint8_t* plane = trace + (int64_t)d * n_rows;
-    const int a = plane[q];
-    const int b = two_rows ? (int)plane[q + 1] : 0;
-    const int set_base = rp.is_board ? 0 : rp.dyn_layer[d] * HW;
-    const uint32_t set_val = rp.is_board ? (uint32_t)rp.dyn_char[d] : 1u;
-    // row q occupies window bytes [-k, R-k); row q+1 starts at window byte R-k.
-    // An invisible thing changes nothing: its pokes are pushed out of range.
-    {
-      const int cell = a & 0x7f;
-      const int shift = (a & 0x80) ? 0 : (1 << 20);
-      if (!rp.is_board)
-        poke(v, (int)spec->static_top_layer[cell] * HW + cell - k + shift, 0u);
-      poke(v, set_base + cell - k + shift, set_val);
-    }
-    if (two_rows) {
-      const int cell = b & 0x7f;
-      const int shift = (b & 0x80) ? 0 : (1 << 20);
-      if (!rp.is_board)
-        poke(v, (int)spec->static_top_layer[cell] * HW + cell + (R - k) + shift, 0u);
-      poke(v, set_base + cell + (R - k) + shift, set_val);
+  // Issue every load before using any: the window of the scenery and, per moving
+  // thing, the trace entries of the (at most two) rows this chunk overlaps.  A chunk
+  // that runs past its row continues in the next row of the SAME frame (frames are
+  // multiples of 16 bytes); when it does not, the clamped second entry is ignored.
+  const u32x4 scenery = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+  const bool two_rows = k + 16 > R;
+  const int64_t q1 = two_rows ? q + 1 : q;
+  uint32_t e0[K], e1[K];
+#pragma unroll
+  for (int d = 0; d < K; ++d) {
+    e0[d] = trace[(int64_t)d * n_rows + q];
+    e1[d] = trace[(int64_t)d * n_rows + q1];
+  }
+  u32x4 v = scenery;
+#pragma unroll
+  for (int d = 0; d < K; ++d) {
+    // Row q occupies chunk bytes [-k, R-k); row q+1 starts at chunk byte R-k.  A thing
+    // that is not visible changes nothing: its pokes are pushed out of range.
+    const int hide0 = ((e0[d] >> 29) & 1u) ? 0 : (1 << 20);
+    const int hide1 = (((e1[d] >> 29) & 1u) && two_rows) ? 0 : (1 << 20);
+    if (kBoard) {
+      poke(v, (int)((e0[d] >> 22) & 0x7fu) - k + hide0, (uint32_t)rp.dyn_char[d]);
+      poke(v, (int)((e1[d] >> 22) & 0x7fu) + (R - k) + hide1, (uint32_t)rp.dyn_char[d]);
+    } else {
+      poke(v, (int)((e0[d] >> 11) & 0x7ffu) - k + hide0, 0u);
+      poke(v, (int)(e0[d] & 0x7ffu) - k + hide0, 1u);
+      poke(v, (int)((e1[d] >> 11) & 0x7ffu) + (R - k) + hide1, 0u);
+      poke(v, (int)(e1[d] & 0x7ffu) + (R - k) + hide1, 1u);
     }
   }
-  if (off + 16 <= n_bytes) {
-    u32x4* o = reinterpret_cast<u32x4*>(dst + off);
-    if (kNT)
-      __builtin_nontemporal_store(v, o);
-    else
-      *o = v;
-  } else {  // ragged end of the buffer
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    for (int j = 0; off + j < n_bytes; ++j) dst[off + j] = (int8_t)(w[j >> 2] >> ((j & 3) * 8));
+  return v;
+}
+
+// Block (x, t) writes bytes [x * 4096 * kPer, (x+1) * 4096 * kPer) of frame t, each
+// thread kPer chunks 4096 bytes apart (so every store instruction of a wave is one
+// contiguous KiB).
+template <int K, bool kBoard, bool kNT, int kPer>
+__global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
+                                                     const CampxSpec* __restrict__ spec,
+                                                     const uint32_t* __restrict__ trace,
+                                                     int8_t* __restrict__ dst, int64_t n_rows) {
+  const int8_t* rot = kBoard ? spec->rot_board : spec->rot_obs;
+  const int64_t row0 = (int64_t)blockIdx.y * rp.B;
+  int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;
+  const uint32_t base = blockIdx.x * (4096u * kPer) + threadIdx.x * 16u;
+  u32x4 v[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const uint32_t off = base + j * 4096u;
+    if (off < rp.slab_bytes) v[j] = render_chunk<K, kBoard>(rp, rot, trace, n_rows, row0, off);
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const uint32_t off = base + j * 4096u;
+    if (off < rp.slab_bytes) {
+      u32x4* o = reinterpret_cast<u32x4*>(frame + off);
+      if (kNT)
+        __builtin_nontemporal_store(v[j], o);
+      else
+        *o = v[j];
+    }
   }
 }
 
@@ -664,11 +788,11 @@ bool knob_no_split() {
   }();
   return off;
 }
-int knob_render_threads() {
+int knob_render_per_thread() {
   static const int n = [] {
-    const char* v = getenv("CAMPX_RENDER_THREADS");
-    const int t = v ? atoi(v) : 256;
-    return (t == 512 || t == 1024) ? t : 256;
+    const char* v = getenv("CAMPX_RENDER_PER_THREAD");
+    const int t = v ? atoi(v) : 2;
+    return (t == 1 || t == 4) ? t : 2;
   }();
   return n;
 }
@@ -756,8 +880,8 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                      \
-  hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS, false>), grid, block, shmem,    \
-                     stream, mp, spec_dev, st, actions, out, B, T, reset_first, emit_first)
+  hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS>), grid, block, shmem, stream, mp, \
+                     spec_dev, st, actions, out, B, T, reset_first, emit_first)
 #define CAMPX_LAUNCH(BOARD, NT)                \
   do {                                         \
     if (envs == 16)                            \
@@ -790,50 +914,79 @@ void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
                      rb, spec_dev, st, actions, out, B, T, reset_first, 0);
 }
 
-int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
-                      int8_t* dst, int64_t n_rows, bool is_board, hipStream_t stream) {
+int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint32_t* trace,
+                      int8_t* dst, int64_t B, int32_t T, bool is_board, hipStream_t stream) {
   const int HW = s.rows * s.cols;
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
-  rp.R = is_board ? HW : s.n_layers * HW;
-  rp.magic = (uint32_t)((((uint64_t)1) << 32) / (uint32_t)rp.R) + 1u;
+  rp.R = (uint32_t)(is_board ? HW : s.n_layers * HW);
+  // exact unsigned 32-bit division by R (Granlund & Montgomery 1994, fig. 4.1)
+  uint32_t l = 0;
+  while ((1ull << l) < rp.R) ++l;
+  rp.m = (uint32_t)(((1ull << 32) * ((1ull << l) - rp.R)) / rp.R + 1);
+  rp.sh1 = l < 1 ? l : 1;
+  rp.sh2 = l > 0 ? l - 1 : 0;
+  rp.slab_bytes = (uint32_t)(B * rp.R);
   rp.n_dyn = s.n_dyn;
-  rp.HW = HW;
   rp.is_board = is_board ? 1 : 0;
-  memcpy(rp.dyn_layer, s.dyn_layer, sizeof(rp.dyn_layer));
+  rp.B = B;
   for (int d = 0; d < s.n_dyn; ++d) rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
-  const int threads = knob_render_threads();
+  const int per = knob_render_per_thread();
+  const uint32_t span = 4096u * (uint32_t)per;
+  const dim3 grid((rp.slab_bytes + span - 1) / span, (unsigned)T);
+  const int64_t n_rows = (int64_t)T * B;
   const bool nt = knob_store_nt();
-  const size_t shmem = 0;
-  const int64_t n_vec = (n_rows * rp.R + 15) / 16;
-  const int64_t n_blocks = (n_vec + threads - 1) / threads;
-  if (n_blocks > 0x7fffffff) return CAMPX_EINVAL;
-  const dim3 grid((unsigned)n_blocks);
-#define CAMPX_RENDER(THREADS, NT)                                                          \
-  hipLaunchKernelGGL((render_kernel<THREADS, NT>), grid, dim3(THREADS), shmem, stream, rp, \
+#define CAMPX_RENDER4(KK, BOARD, NT, PER)                                                   \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, PER>), grid, dim3(256), 0, stream, rp, \
                      spec_dev, trace, dst, n_rows)
-  if (threads == 1024) {
-    if (nt) CAMPX_RENDER(1024, true); else CAMPX_RENDER(1024, false);
-  } else if (threads == 512) {
-    if (nt) CAMPX_RENDER(512, true); else CAMPX_RENDER(512, false);
-  } else {
-    if (nt) CAMPX_RENDER(256, true); else CAMPX_RENDER(256, false);
+#define CAMPX_RENDER3(KK, BOARD, NT)                                        \
+  do {                                                                      \
+    if (per == 1) CAMPX_RENDER4(KK, BOARD, NT, 1);                          \
+    else if (per == 2) CAMPX_RENDER4(KK, BOARD, NT, 2);                     \
+    else CAMPX_RENDER4(KK, BOARD, NT, 4);                                   \
+  } while (0)
+#define CAMPX_RENDER2(KK, BOARD)                                            \
+  do {                                                                      \
+    if (nt) CAMPX_RENDER3(KK, BOARD, true); else CAMPX_RENDER3(KK, BOARD, false); \
+  } while (0)
+#define CAMPX_RENDER1(KK)                                                   \
+  do {                                                                      \
+    if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
+  } while (0)
+  switch (s.n_dyn) {
+    case 1: CAMPX_RENDER1(1); break;
+    case 2: CAMPX_RENDER1(2); break;
+    case 3: CAMPX_RENDER1(3); break;
+    default: CAMPX_RENDER1(4); break;
   }
-#undef CAMPX_RENDER
+#undef CAMPX_RENDER1
+#undef CAMPX_RENDER2
+#undef CAMPX_RENDER3
+#undef CAMPX_RENDER4
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+// Can this call take the two-kernel path?  Frames must be stored back to back and be
+// whole 16-byte chunks, and a chunk may span at most two rows.
+bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T) {
+  const int64_t HW = (int64_t)s.rows * s.cols, LHW = HW * s.n_layers;
+  if (!out.trace || !s.render_valid || T <= 0 || T > 65535 || knob_no_split()) return false;
+  if (LHW < 16 || (B * LHW) % 16 != 0 || B * LHW >= (1ll << 32)) return false;
+  if (out.obs_t_stride != B * LHW) return false;
+  if (out.board && (HW < 16 || (B * HW) % 16 != 0 || out.board_t_stride != B * HW)) return false;
+  return true;
 }
 
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   if (use_table) {
-    const size_t shmem = table_lds_bytes(s, false, 0);
-    const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
-    hipLaunchKernelGGL((rollout_table_kernel<false, false, kWave, true>), grid, block, shmem,
-                       stream, mp, spec_dev, st, actions, out, B, T, reset_first, 0);
+    hipLaunchKernelGGL(trace_table_kernel, grid, block, 0, stream, mp, spec_dev, st, actions, out,
+                       B, T, reset_first);
   } else {
     switch (s.n_dyn) {
       case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
@@ -844,10 +997,9 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
-  const int64_t n_rows = (int64_t)T * B;
-  int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, n_rows, false, stream);
+  int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, B, T, false, stream);
   if (rc != CAMPX_OK) return rc;
-  if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, n_rows, true, stream);
+  if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, B, T, true, stream);
   return rc;
 }
 
@@ -865,16 +1017,8 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool use_table =
       spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table();
-  {
-    const int64_t HW = (int64_t)spec_host->rows * spec_host->cols;
-    const int64_t LHW = HW * spec_host->n_layers;
-    const bool split = out.trace && spec_host->render_valid && T > 0 && !emit_first && !interpreter_only && LHW >= 16 &&
-                       out.obs_t_stride == B * LHW &&
-                       (!out.board || (out.board_t_stride == B * HW && HW >= 16)) &&
-                       !knob_no_split();
-    if (split)
-      return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
-  }
+  if (!emit_first && !interpreter_only && split_ok(*spec_host, out, B, T))
+    return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {

@@ -38,8 +38,10 @@ from .rendering import Observation
 # (campx_spec_compile) and let the frame loop look it up.  Tests switch this off to
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
-# Rollouts that keep every frame: run the update pass and the render as two
-# kernels (needs a [K, T, B] byte trace buffer).  Tests also run with this off.
+# Rollouts that keep every frame can run the update pass and the render as two
+# kernels (needs a [K, T, B] int32 trace buffer).  Parity-tested in both settings;
+# off by default because on MI355X the single fused kernel is currently the faster
+# of the two (DESIGN.md "Kernels", profiles/).
 SPLIT_ROLLOUT = False
 
 
@@ -213,7 +215,7 @@ class FusedGame(object):
     discount = torch.empty((T, B), dtype=torch.float32, device=dev)
     done = torch.empty((T, B), dtype=torch.uint8, device=dev)
     # The compact trajectory; giving it lets the library take its two-kernel path.
-    trace = (torch.empty((self.n_dyn, T, B), dtype=torch.uint8, device=dev)
+    trace = (torch.empty((self.n_dyn, T, B), dtype=torch.int32, device=dev)
              if keep_obs and SPLIT_ROLLOUT else None)
     out = _hip.CampxOutputs(_ptr(obs), obs_stride, _ptr(board), board_stride,
                             _ptr(reward), _ptr(discount), _ptr(done), _ptr(trace))

@@ -161,13 +161,18 @@ typedef struct CampxOutputs {
   float* reward;      /* [T, B]; NaN where the reference returns None */
   float* discount;    /* [T, B] 1.0, or 0.0 on the frame the episode ended (plot.py:179-184) */
   uint8_t* done;      /* [T, B] game-over flag after the frame */
-  uint8_t* trace;     /* optional [K, T, B]: for moving thing d at frame t in environment e,
-                         bits 0-6 = the cell (row*cols + col) it is in after the frame, bit 7 = 1
-                         when it is the character that cell shows.  A compact trajectory in
-                         its own right; and when it is given and frames are stored back to
-                         back (obs_t_stride == B*L*rows*cols), the library runs the update
-                         pass and the render as two kernels, which streams the observations
-                         to HBM faster (DESIGN.md "Kernels").  Written only on that path. */
+  uint32_t* trace;    /* optional [K, T, B]: for moving thing d at frame t in environment e,
+                           bits 0-10  byte offset, inside the environment's L*rows*cols
+                                      layered board, of the 1 this thing paints
+                           bits 11-21 byte offset of the scenery's 1 that it covers
+                           bits 22-28 the cell (row*cols + col) it is in after the frame
+                           bit  29    1 when it is the character that cell shows; when 0
+                                      it is hidden and changes nothing in the observation
+                         A compact trajectory in its own right; and when it is given, frames
+                         are stored back to back (obs_t_stride == B*L*rows*cols) and are whole
+                         16-byte multiples, the library runs the update pass and the render as
+                         two kernels, which streams the observations to HBM faster (DESIGN.md
+                         "Kernels").  Written only on that path. */
 } CampxOutputs;
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */

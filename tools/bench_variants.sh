@@ -10,9 +10,9 @@ for l in sys.stdin:
 "
 }
 run CAMPX_NO_SPLIT=1
-run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=256
-run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=512
-run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=1024
-run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=256 CAMPX_STORE_NT=0
-run CAMPX_NO_SPLIT=0 CAMPX_RENDER_THREADS=1024 CAMPX_STORE_NT=0
-run CAMPX_NO_SPLIT=0 CAMPX_NO_TABLE=1
+run CAMPX_RENDER_PER_THREAD=1
+run CAMPX_RENDER_PER_THREAD=2
+run CAMPX_RENDER_PER_THREAD=4
+run CAMPX_RENDER_PER_THREAD=1 CAMPX_STORE_NT=0
+run CAMPX_RENDER_PER_THREAD=2 CAMPX_STORE_NT=0
+run CAMPX_RENDER_PER_THREAD=4 CAMPX_STORE_NT=0
