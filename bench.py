@@ -63,31 +63,53 @@ def parse_args():
 
 
 def cpu_baseline(game_name, frames, seconds):
-  """Time the CPU oracle (a port, not the reference) on a bounded sample."""
+  """Time the CPU oracle (a port, not the reference) on a bounded sample.
+
+  The sample is `n` back-to-back episodes of a fixed batch (the GPU step's own
+  shape, capped at 65 536 environments), with `n` chosen from a short calibration
+  run so that the timed part takes about `seconds`.
+  """
   from campx_amd import games, gamespec
   from oracle import cpu as oracle_cpu
   build = getattr(games, game_name).build
-  og = oracle_cpu.OracleGame.from_description(gamespec.describe(build()))
   cores = oracle_cpu.set_threads(os.cpu_count() or 1)
   rng = np.random.RandomState(7)
-  probe = rng.randint(0, 5, size=(frames, 2048)).astype(np.int8)
-  og.rollout(probe[:2], reset_first=True, keep_obs=False, want_board=False)
-  t0 = time.perf_counter()
-  og.rollout(probe, reset_first=True, keep_obs=False, want_board=False)
-  rate = probe.size / (time.perf_counter() - t0)
-  batch = int(max(2048, min(1 << 20, rate * seconds / frames)) // 64 * 64)
+  batch = 65536
   actions = rng.randint(0, 5, size=(frames, batch)).astype(np.int8)
   og = oracle_cpu.OracleGame.from_description(gamespec.describe(build()))
+  og.rollout(actions[:2], reset_first=True, keep_obs=False, want_board=False)
   t0 = time.perf_counter()
   og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
+  once = time.perf_counter() - t0
+  episodes = int(max(1, min(200, round(seconds / once))))
+  t0 = time.perf_counter()
+  for _ in range(episodes):
+    og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
   dt = time.perf_counter() - t0
+  actions = np.broadcast_to(actions, (episodes,) + actions.shape)
   return {
       'value': actions.size / dt, 'unit': 'env-steps/s', 'cores': cores,
       'kind': 'port',
-      'sample': '{} x {} frames of the same game and action distribution, '
-                'oracle/campx_oracle.c with OpenMP over environments, {:.1f} s'
-                .format(batch, frames, dt),
+      'sample': '{} episodes x {} environments x {} frames of the same game and '
+                'action distribution, oracle/campx_oracle.c (every frame rendered) '
+                'with OpenMP over environments, {:.1f} s'
+                .format(episodes, batch, frames, dt),
   }
+
+
+def measured_traffic(game, batch, frames):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes, or None.
+
+  bench.py cannot run the profiler on itself; the figure comes from
+  profiles/r01_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
+  command) and is only reported for the exact configuration it was measured on.
+  """
+  try:
+    with open(os.path.join(REPO, 'profiles', 'r01_traffic.json')) as f:
+      table = json.load(f)
+    return table['{}:{}:{}'.format(game, batch, frames)]['traffic_bytes']
+  except (OSError, KeyError, ValueError):
+    return None
 
 
 def main():
@@ -170,6 +192,7 @@ def main():
     env_steps = B * T * args.steps * world
     bytes_per_launch = BYTES_PER_ENV_STEP[args.game] * B * T
     achieved = bytes_per_launch / kernel_s / 1e9
+    traffic = measured_traffic(args.game, B, T)
     line = {
         'metric': 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X',
         'value': env_steps / elapsed,
@@ -200,8 +223,9 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
-            'kernel': 'rollout_kernel',
+            'traffic': traffic / 1e9 / kernel_s if traffic else None,
+            'traffic_bytes_per_launch': traffic,
+            'kernel': 'rollout_table_kernel' if fused.uses_table else 'rollout_kernel',
             'kernel_ms': kernel_s * 1e3,
             'bytes_per_env_step': BYTES_PER_ENV_STEP[args.game],
             'bytes_per_launch': bytes_per_launch,

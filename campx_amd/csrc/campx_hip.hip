@@ -79,6 +79,15 @@ __device__ __forceinline__ void put(int (&v)[K], int d, int x) {
   for (int k = 0; k < K; ++k) v[k] = (d == k) ? x : v[k];
 }
 
+// Which tile of environments a workgroup owns.  Workgroup b is observed to run on
+// XCD b % 8 (MI355X_MICROARCH.md); mode 1 gives each XCD a contiguous eighth of the
+// batch so that what one L2 evicts is contiguous in memory.  Speed only: any
+// bijection is correct.
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t n, int mode) {
+  if (mode == 1 && (n & 7u) == 0) return (b & 7u) * (n >> 3) + (b >> 3);
+  return b;
+}
+
 // Trace entry of one moving thing at one frame (CampxOutputs.trace).
 __device__ __forceinline__ uint32_t pack_trace(int set_off, int clear_off, int cell, uint32_t vis) {
   return (uint32_t)set_off | ((uint32_t)clear_off << 11) | ((uint32_t)cell << 22) | (vis << 29);
@@ -180,12 +189,13 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
                                                         CampxState st,
                                                         const int8_t* __restrict__ actions,
                                                         CampxOutputs out, int64_t B, int32_t T,
-                                                        int32_t reset_first, int32_t emit_first) {
+                                                        int32_t reset_first, int32_t emit_first,
+                                                        int32_t xcd_mode) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   const int lane = threadIdx.x;
   const int H = rb.rows, W = rb.cols, HW = H * W, L = rb.n_layers, LHW = L * HW;
   // A wave owns kEnvs consecutive environments (lanes >= kEnvs only help stream).
-  const int64_t env0 = (int64_t)blockIdx.x * kEnvs;
+  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, xcd_mode) * kEnvs;
   const int64_t env = env0 + lane;
   const bool mine = lane < kEnvs;
   const bool live = mine && env < B;
@@ -405,11 +415,11 @@ template <bool kBoard, bool kNT, int kEnvs>
 __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, int32_t emit_first) {
+    int32_t reset_first, int32_t emit_first, int32_t xcd_mode) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   const int lane = threadIdx.x;
   const int W = mp.cols, HW = mp.rows * mp.cols, LHW = mp.n_layers * HW;
-  const int64_t env0 = (int64_t)blockIdx.x * kEnvs;
+  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, xcd_mode) * kEnvs;
   const int64_t env = env0 + lane;
   const bool mine = lane < kEnvs;
   const bool live = mine && env < B;
@@ -781,6 +791,13 @@ bool knob_store_nt() {
   }();
   return nt;
 }
+int knob_xcd() {
+  static const int m = [] {
+    const char* v = getenv("CAMPX_XCD_MODE");
+    return v ? atoi(v) : 0;
+  }();
+  return m;
+}
 bool knob_no_split() {
   static const bool off = [] {
     const char* v = getenv("CAMPX_NO_SPLIT");
@@ -848,7 +865,7 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   const bool nt = knob_store_nt();
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
   hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
-                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first)
+                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd())
 #define CAMPX_LAUNCH(BOARD, NT)                \
   do {                                         \
     if (envs == 16)                            \
@@ -881,7 +898,7 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
                           s.dyn_row0[0], s.dyn_col0[0]};
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                      \
   hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS>), grid, block, shmem, stream, mp, \
-                     spec_dev, st, actions, out, B, T, reset_first, emit_first)
+                     spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd())
 #define CAMPX_LAUNCH(BOARD, NT)                \
   do {                                         \
     if (envs == 16)                            \
@@ -911,7 +928,7 @@ void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const RuleBlock rb = make_rule_block(s);
   hipLaunchKernelGGL((rollout_kernel<K, false, false, kWave, true>), grid, block, shmem, stream,
-                     rb, spec_dev, st, actions, out, B, T, reset_first, 0);
+                     rb, spec_dev, st, actions, out, B, T, reset_first, 0, 0);
 }
 
 int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint32_t* trace,
