@@ -551,80 +551,140 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
 // ---------------------------------------------------------------------------
 // Split path, first half, one-mover games: the update pass alone, from the
 // transition table.  The only loop-carried dependency of a frame is
-// cell -> table[cell, action] -> cell, one LDS read; frames are therefore processed
-// kUnroll at a time: first the dependent chain of lookups, then all their outputs,
-// which are independent of each other and pipeline freely.
+// cell -> table[cell, action] -> cell: one LDS read.  A workgroup is four waves:
+//   wave 0 (producer) runs that dependent chain for 64 environments, kUnroll frames
+//           at a time, and leaves {reward, next cell, done} in an LDS ring;
+//   waves 1-3 (consumers) turn the previous group into the four output streams
+//           (trace, reward, discount, done), four environments per lane so that
+//           every global store is 16 bytes wide, while wave 0 runs the next group;
+//           wave 1 also prefetches the actions one 64-frame chunk ahead.
+// One s_barrier per group; the ring is double-buffered.
 constexpr int kUnroll = 16;
 
-__global__ __launch_bounds__(kWave) void trace_table_kernel(MoverParams mp,
-                                                            const CampxSpec* __restrict__ spec,
-                                                            CampxState st,
-                                                            const int8_t* __restrict__ actions,
-                                                            CampxOutputs out, int64_t B, int32_t T,
-                                                            int32_t reset_first) {
+constexpr int kStepWaves = 4;  // 1 producer + 3 consumers
+
+__global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first) {
   __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
   __shared__ uint32_t entry[CAMPX_MAX_CELLS];  // trace entry of the mover when at that cell
-  __shared__ int8_t staged[kChunk * kWave];
-  const int lane = threadIdx.x;
+  __shared__ int8_t staged[2][kChunk * kWave];  // actions, double-buffered per 64 frames
+  __shared__ __attribute__((aligned(16))) uint2 ring[2][kUnroll][kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool producer = threadIdx.x < kWave;
   const int W = mp.cols, HW = mp.rows * mp.cols;
-  const int64_t env = (int64_t)blockIdx.x * kWave + lane;
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
   const bool live = env < B;
 
-  for (int i = lane; i < HW * CAMPX_N_ACTIONS; i += kWave) {
+  const int consumer_lane = (int)threadIdx.x - kWave;            // 0 .. 191 in the consumers
+  const bool stager = threadIdx.x >= kWave && threadIdx.x < 2 * kWave;  // wave 1 fetches actions
+  for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kStepWaves * kWave) {
     const CampxTransition tr = spec->table[i];
     table[i] = make_uint2(__float_as_uint(tr.reward), (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8));
   }
-  for (int i = lane; i < HW; i += kWave) {
+  for (int i = threadIdx.x; i < HW; i += kStepWaves * kWave) {
     const int layer = spec->static_top_layer[i];
     const uint32_t vis = spec->static_top_z[i] > mp.dyn_z ? 0u : 1u;
     entry[i] = pack_trace(mp.dyn_layer * HW + i, layer * HW + i, i, vis);
   }
-  __syncthreads();
+  // Wave 1 also fetches the actions, one 64-frame chunk ahead of the producer, so
+  // that the producer's loop is nothing but the dependent chain.
+  if (stager && T > 0) stage_actions<kWave>(staged[0], actions, B, T, 0, env, live, lane);
 
   const int cell0 = mp.row0 * W + mp.col0;
   int cell = cell0, over = 0;
   float ret = 0.0f;
-  if (!reset_first && live) {
+  if (producer && !reset_first && live) {
     cell = (int)st.pos[env] * W + (int)st.pos[B + env];
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
   }
+  const bool wide = (B & 3) == 0;  // 16-byte stores need 4-environment alignment
+  constexpr int kGroupsPerChunk = kChunk / kUnroll;
 
-  for (int t0 = 0; t0 < T; t0 += kUnroll) {
-    if ((t0 & (kChunk - 1)) == 0) stage_actions<kWave>(staged, actions, B, T, t0, env, live, lane);
-    const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
-    uint2 e[kUnroll];
+  __syncthreads();
+
+  const int n_groups = (T + kUnroll - 1) / kUnroll;
+  for (int g = 0; g <= n_groups; ++g) {
+    if (producer) {
+      const int t0 = g * kUnroll;
+      if (g < n_groups) {
+        const int8_t* my_actions = staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * kWave + lane;
+        const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
+        int acts[kUnroll];
 #pragma unroll
-    for (int j = 0; j < kUnroll; ++j) {
-      if (j < n) {
-        int a = staged[((t0 + j) & (kChunk - 1)) * kWave + lane];
-        a = ((unsigned)a > 4u) ? 4 : a;
-        if (over) {  // rebuilt from the art before its next action
-          cell = cell0;
-          ret = 0.0f;
-        }
-        e[j] = table[cell * CAMPX_N_ACTIONS + a];
-        cell = (int)(e[j].y & 0xffu);
-        over = (int)((e[j].y >> 8) & 1u);
-        ret += __uint_as_float(e[j].x);
-      }
-    }
-    if (live) {
+        for (int j = 0; j < kUnroll; ++j) acts[j] = my_actions[j * kWave];
 #pragma unroll
-      for (int j = 0; j < kUnroll; ++j) {
-        if (j < n) {
-          const int64_t at = (int64_t)(t0 + j) * B + env;
-          const uint32_t done = (e[j].y >> 8) & 1u;
-          out.trace[at] = entry[e[j].y & 0xffu];
-          if (out.reward) out.reward[at] = __uint_as_float(e[j].x);
-          if (out.discount) out.discount[at] = done ? 0.0f : 1.0f;
-          if (out.done) out.done[at] = (uint8_t)done;
+        for (int j = 0; j < kUnroll; ++j) {
+          if (j < n) {
+            int a = acts[j];
+            a = ((unsigned)a > 4u) ? 4 : a;
+            if (over) {  // rebuilt from the art before its next action
+              cell = cell0;
+              ret = 0.0f;
+            }
+            const uint2 e = table[cell * CAMPX_N_ACTIONS + a];
+            cell = (int)(e.y & 0xffu);
+            over = (int)((e.y >> 8) & 1u);
+            ret += __uint_as_float(e.x);
+            ring[g & 1][j][lane] = e;
+          }
         }
       }
+    } else {
+      if (stager && (g % kGroupsPerChunk) == 0) {  // producer enters chunk g/4: fetch the next
+        const int t_next = (g / kGroupsPerChunk + 1) * kChunk;
+        if (t_next < T)
+          stage_actions<kWave>(staged[(t_next / kChunk) & 1], actions, B, T, t_next, env, live, lane);
+      }
+      if (g == 0) {
+        __syncthreads();
+        continue;
+      }
+      const int gp = g - 1, t0 = gp * kUnroll;
+      const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
+      // item = (frame j, group of 4 environments q): 16 items per frame
+      for (int item = consumer_lane; item < n * (kWave / 4); item += (kStepWaves - 1) * kWave) {
+        const int j = item >> 4, q = item & 15;
+        const int64_t e0 = env0 + 4 * q;
+        if (e0 >= B) continue;
+        const uint2* src = &ring[gp & 1][j][4 * q];
+        uint2 e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = src[i];
+        uint32_t tr[4];
+        float rw[4], dc[4];
+        uint8_t dn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t done = (e[i].y >> 8) & 1u;
+          tr[i] = entry[e[i].y & 0xffu];
+          rw[i] = __uint_as_float(e[i].x);
+          dc[i] = done ? 0.0f : 1.0f;
+          dn[i] = (uint8_t)done;
+        }
+        const int64_t at = (int64_t)(t0 + j) * B + e0;
+        if (wide && e0 + 4 <= B) {
+          *reinterpret_cast<uint4*>(out.trace + at) = make_uint4(tr[0], tr[1], tr[2], tr[3]);
+          if (out.reward) *reinterpret_cast<float4*>(out.reward + at) = make_float4(rw[0], rw[1], rw[2], rw[3]);
+          if (out.discount) *reinterpret_cast<float4*>(out.discount + at) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+          if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
+        } else {
+          for (int i = 0; i < 4 && e0 + i < B; ++i) {
+            out.trace[at + i] = tr[i];
+            if (out.reward) out.reward[at + i] = rw[i];
+            if (out.discount) out.discount[at + i] = dc[i];
+            if (out.done) out.done[at + i] = dn[i];
+          }
+        }
+      }
     }
+    __syncthreads();
   }
 
-  if (live) {
+  if (producer && live) {
     st.pos[env] = (int8_t)(cell / W);
     st.pos[B + env] = (int8_t)(cell % W);
     st.done[env] = (uint8_t)over;
@@ -666,77 +726,100 @@ __device__ __forceinline__ void poke(u32x4& v, int p, uint32_t val) {
   v.w = (in && w == 3) ? ((v.w & keep) | bits) : v.w;
 }
 
-// One 16-byte chunk of frame `t`: bytes [off, off+16) of the frame.
-template <int K, bool kBoard>
-__device__ __forceinline__ u32x4 render_chunk(const RenderParams& rp, const int8_t* __restrict__ rot,
-                                              const uint32_t* __restrict__ trace, int64_t n_rows,
-                                              int64_t row0, uint32_t off) {
-  const int R = (int)rp.R;
-  const uint32_t hi = __umulhi(rp.m, off);
-  const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
-  const int k = (int)(off - row * rp.R);                           // off % R
-  const int64_t q = row0 + row;                                    // row of the trajectory
-  const int pitch = ((R + 15) & ~15) + 16;
-  // Issue every load before using any: the window of the scenery and, per moving
-  // thing, the trace entries of the (at most two) rows this chunk overlaps.  A chunk
-  // that runs past its row continues in the next row of the SAME frame (frames are
-  // multiples of 16 bytes); when it does not, the clamped second entry is ignored.
-  const u32x4 scenery = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
-  const bool two_rows = k + 16 > R;
-  const int64_t q1 = two_rows ? q + 1 : q;
-  uint32_t e0[K], e1[K];
-#pragma unroll
-  for (int d = 0; d < K; ++d) {
-    e0[d] = trace[(int64_t)d * n_rows + q];
-    e1[d] = trace[(int64_t)d * n_rows + q1];
-  }
-  u32x4 v = scenery;
-#pragma unroll
-  for (int d = 0; d < K; ++d) {
-    // Row q occupies chunk bytes [-k, R-k); row q+1 starts at chunk byte R-k.  A thing
-    // that is not visible changes nothing: its pokes are pushed out of range.
-    const int hide0 = ((e0[d] >> 29) & 1u) ? 0 : (1 << 20);
-    const int hide1 = (((e1[d] >> 29) & 1u) && two_rows) ? 0 : (1 << 20);
-    if (kBoard) {
-      poke(v, (int)((e0[d] >> 22) & 0x7fu) - k + hide0, (uint32_t)rp.dyn_char[d]);
-      poke(v, (int)((e1[d] >> 22) & 0x7fu) + (R - k) + hide1, (uint32_t)rp.dyn_char[d]);
-    } else {
-      poke(v, (int)((e0[d] >> 11) & 0x7ffu) - k + hide0, 0u);
-      poke(v, (int)(e0[d] & 0x7ffu) - k + hide0, 1u);
-      poke(v, (int)((e1[d] >> 11) & 0x7ffu) + (R - k) + hide1, 0u);
-      poke(v, (int)(e1[d] & 0x7ffu) + (R - k) + hide1, 1u);
-    }
-  }
-  return v;
-}
-
-// Block (x, t) writes bytes [x * 4096 * kPer, (x+1) * 4096 * kPer) of frame t, each
-// thread kPer chunks 4096 bytes apart (so every store instruction of a wave is one
-// contiguous KiB).
-template <int K, bool kBoard, bool kNT, int kPer>
+// Block (x, t) writes bytes [x*4096, (x+1)*4096) of frame t; each of its four waves
+// owns one aligned KiB of it (every store instruction of a wave is one aligned,
+// contiguous KiB: tools/probes show -12..-21 % for anything less aligned).
+//
+// A wave first lays the scenery's bytes for its KiB into LDS (one aligned 16-byte
+// load from the rotated scenery table per lane), then the few lanes that hold a
+// patch - (row overlapping the window) x (moving thing) x (set | clear) - write their
+// single byte into it, then every lane reads its 16 bytes back and stores them.
+// Nothing is shared between waves, so there is no workgroup barrier.
+template <int K, bool kBoard, bool kNT, int kWin>
 __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
                                                      const CampxSpec* __restrict__ spec,
                                                      const uint32_t* __restrict__ trace,
                                                      int8_t* __restrict__ dst, int64_t n_rows) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[4 * kWin * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // this wave's kWin consecutive KiB windows of the frame
+  const uint32_t woff0 = (blockIdx.x * 4u + (uint32_t)wave) * (1024u * kWin);
+  if (woff0 >= rp.slab_bytes) return;
+  int8_t* win0 = lds + wave * (kWin * 1024);
+  const int R = (int)rp.R;
+  const int pitch = ((R + 15) & ~15) + 16;
   const int8_t* rot = kBoard ? spec->rot_board : spec->rot_obs;
-  const int64_t row0 = (int64_t)blockIdx.y * rp.B;
-  int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;
-  const uint32_t base = blockIdx.x * (4096u * kPer) + threadIdx.x * 16u;
-  u32x4 v[kPer];
+  constexpr int P = kBoard ? K : 2 * K;                // patches per row
+  const uint32_t* frame_trace = trace + (int64_t)blockIdx.y * rp.B;
+
+  // ---- scenery: issue all loads, then park them in LDS
+  u32x4 scen[kWin];
 #pragma unroll
-  for (int j = 0; j < kPer; ++j) {
-    const uint32_t off = base + j * 4096u;
-    if (off < rp.slab_bytes) v[j] = render_chunk<K, kBoard>(rp, rot, trace, n_rows, row0, off);
+  for (int j = 0; j < kWin; ++j) {
+    const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
+    const uint32_t hi = __umulhi(rp.m, off);
+    const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
+    const int k = (int)(off - row * rp.R);                           // off % R
+    scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+  }
+
+  // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear)
+  const uint32_t span = 1024u * kWin;
+  const uint32_t whi = __umulhi(rp.m, woff0);
+  const uint32_t first_row = (((woff0 - whi) >> rp.sh1) + whi) >> rp.sh2;
+  const uint32_t wend = (woff0 + span - 1u < rp.slab_bytes) ? woff0 + span - 1u : rp.slab_bytes - 1u;
+  const uint32_t ehi = __umulhi(rp.m, wend);
+  const uint32_t last_row = (((wend - ehi) >> rp.sh1) + ehi) >> rp.sh2;
+  const int slots = (int)(last_row - first_row + 1u) * P;
+  constexpr int kMaxIter = 2;                          // slots <= 128 covers the common case
+  uint32_t ent[kMaxIter];
+#pragma unroll
+  for (int it = 0; it < kMaxIter; ++it) {
+    const int sidx = lane + it * kWave;
+    const int r = sidx / P, p = sidx - r * P;
+    const int d = kBoard ? p : (p >> 1);
+    uint32_t row = first_row + (uint32_t)r;
+    row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
+    ent[it] = frame_trace[(int64_t)d * n_rows + row];
   }
 #pragma unroll
-  for (int j = 0; j < kPer; ++j) {
-    const uint32_t off = base + j * 4096u;
-    if (off < rp.slab_bytes) {
-      u32x4* o = reinterpret_cast<u32x4*>(frame + off);
+  for (int j = 0; j < kWin; ++j)
+    *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16) = scen[j];
+
+  auto apply = [&](int sidx, uint32_t e) {
+    const int r = sidx / P, p = sidx - r * P;
+    const int d = kBoard ? p : (p >> 1);
+    int byte;   // offset inside the row
+    int8_t val;
+    if (kBoard) {
+      byte = (int)((e >> 22) & 0x7fu);
+      val = (int8_t)rp.dyn_char[d];
+    } else {
+      byte = (p & 1) ? (int)(e & 0x7ffu) : (int)((e >> 11) & 0x7ffu);
+      val = (int8_t)(p & 1);
+    }
+    const int64_t at = (int64_t)(first_row + (uint32_t)r) * R + byte - (int64_t)woff0;
+    if (sidx < slots && ((e >> 29) & 1u) && at >= 0 && at < (int64_t)span) win0[at] = val;
+  };
+#pragma unroll
+  for (int it = 0; it < kMaxIter; ++it) apply(lane + it * kWave, ent[it]);
+  for (int sidx = lane + kMaxIter * kWave; sidx < slots; sidx += kWave) {   // tiny rows only
+    const int r = sidx / P, p = sidx - r * P;
+    const int d = kBoard ? p : (p >> 1);
+    apply(sidx, frame_trace[(int64_t)d * n_rows + first_row + (uint32_t)r]);
+  }
+
+  // ---- out: kWin aligned, contiguous KiB stores per wave
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+    const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
+    if (off < rp.slab_bytes) {                         // frames are whole 16-byte chunks
+      const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
+      u32x4* o = reinterpret_cast<u32x4*>(dst + (int64_t)blockIdx.y * rp.slab_bytes + off);
       if (kNT)
-        __builtin_nontemporal_store(v[j], o);
+        __builtin_nontemporal_store(v, o);
       else
-        *o = v[j];
+        *o = v;
     }
   }
 }
@@ -948,23 +1031,26 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint3
   rp.is_board = is_board ? 1 : 0;
   rp.B = B;
   for (int d = 0; d < s.n_dyn; ++d) rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
-  const int per = knob_render_per_thread();
-  const uint32_t span = 4096u * (uint32_t)per;
-  const dim3 grid((rp.slab_bytes + span - 1) / span, (unsigned)T);
+  const int win = knob_render_per_thread();
+  const uint32_t span = 4096u * (uint32_t)win;
+  const dim3 grid((rp.slab_bytes + span - 1u) / span, (unsigned)T);
   const int64_t n_rows = (int64_t)T * B;
   const bool nt = knob_store_nt();
-#define CAMPX_RENDER4(KK, BOARD, NT, PER)                                                   \
-  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, PER>), grid, dim3(256), 0, stream, rp, \
-                     spec_dev, trace, dst, n_rows)
-#define CAMPX_RENDER3(KK, BOARD, NT)                                        \
-  do {                                                                      \
-    if (per == 1) CAMPX_RENDER4(KK, BOARD, NT, 1);                          \
-    else if (per == 2) CAMPX_RENDER4(KK, BOARD, NT, 2);                     \
-    else CAMPX_RENDER4(KK, BOARD, NT, 4);                                   \
+#define CAMPX_RENDER3(KK, BOARD, NT)                                                            \
+  do {                                                                                          \
+    if (win == 1)                                                                               \
+      hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, 1>), grid, dim3(256), 0, stream, rp,     \
+                         spec_dev, trace, dst, n_rows);                                         \
+    else if (win == 2)                                                                          \
+      hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, 2>), grid, dim3(256), 0, stream, rp,     \
+                         spec_dev, trace, dst, n_rows);                                         \
+    else                                                                                        \
+      hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, 4>), grid, dim3(256), 0, stream, rp,     \
+                         spec_dev, trace, dst, n_rows);                                         \
   } while (0)
-#define CAMPX_RENDER2(KK, BOARD)                                            \
-  do {                                                                      \
-    if (nt) CAMPX_RENDER3(KK, BOARD, true); else CAMPX_RENDER3(KK, BOARD, false); \
+#define CAMPX_RENDER2(KK, BOARD)                                                    \
+  do {                                                                              \
+    if (nt) CAMPX_RENDER3(KK, BOARD, true); else CAMPX_RENDER3(KK, BOARD, false);   \
   } while (0)
 #define CAMPX_RENDER1(KK)                                                   \
   do {                                                                      \
@@ -979,7 +1065,6 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint3
 #undef CAMPX_RENDER1
 #undef CAMPX_RENDER2
 #undef CAMPX_RENDER3
-#undef CAMPX_RENDER4
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
@@ -998,12 +1083,12 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
-  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave));
   if (use_table) {
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
-    hipLaunchKernelGGL(trace_table_kernel, grid, block, 0, stream, mp, spec_dev, st, actions, out,
-                       B, T, reset_first);
+    hipLaunchKernelGGL(trace_table_kernel, grid, dim3(kStepWaves * kWave), 0, stream, mp, spec_dev,
+                       st, actions, out, B, T, reset_first);
   } else {
     switch (s.n_dyn) {
       case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;

@@ -26,6 +26,7 @@ its next action is applied; `done` (also `game.fused.done`) tells which ones end
 """
 
 import ctypes
+import os
 
 import torch
 
@@ -42,7 +43,7 @@ COMPILE_TABLE = True
 # kernels (needs a [K, T, B] int32 trace buffer).  Parity-tested in both settings;
 # off by default because on MI355X the single fused kernel is currently the faster
 # of the two (DESIGN.md "Kernels", profiles/).
-SPLIT_ROLLOUT = False
+SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '0') == '1'
 
 
 def _ptr(t):

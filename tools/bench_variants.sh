@@ -9,7 +9,5 @@ for l in sys.stdin:
         d = json.loads(l); print('value %.3e  ms/step %.4f kernel_ms %.4f  GB/s %.0f  frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved'], d['roofline']['frac']))
 "
 }
-run CAMPX_XCD_MODE=0
-run CAMPX_XCD_MODE=1
-run CAMPX_XCD_MODE=0 CAMPX_STORE_NT=0
-run CAMPX_XCD_MODE=1 CAMPX_STORE_NT=0
+run CAMPX_SPLIT=0
+run CAMPX_SPLIT=1 CAMPX_RENDER_PER_THREAD=1

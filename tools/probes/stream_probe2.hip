@@ -41,6 +41,14 @@ __global__ __launch_bounds__(256) void oneshot_tiles256(u32x4* dst, int n_tiles,
   if (i < tile_vec) dst[((size_t)t * n_tiles + w) * tile_vec + i] = u32x4{1u, 2u, 3u, 4u};
 }
 
+// One-shot block per (frame, tile): THREADS threads write the tile's `tile_vec`
+// 16-byte chunks, thread i taking chunks i, i+THREADS, ...
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void oneshot_tile_block(u32x4* dst, int tile_vec) {
+  u32x4* out = dst + (size_t)blockIdx.x * tile_vec;
+  for (int i = threadIdx.x; i < tile_vec; i += THREADS) out[i] = u32x4{1u, 2u, 3u, (uint32_t)i};
+}
+
 template <int WAIT>
 __global__ __launch_bounds__(64) void persistent(u32x4* dst, int n_tiles, int tile_vec, int T) {
   const int lane = threadIdx.x;
@@ -76,6 +84,10 @@ int main() {
   printf("D  one-shot linear, 64-thread blocks       %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
   ms = timeit([&] { hipLaunchKernelGGL(oneshot_linear<1024>, dim3((unsigned)((nvec + 1023) / 1024)), dim3(1024), 0, 0, buf, nvec); });
   printf("D' one-shot linear, 1024-thread blocks     %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+  for (int shift : {4, 8, 16, 32}) {   // in 16-byte units: 64, 128, 256, 512 bytes
+    ms = timeit([&] { hipLaunchKernelGGL(oneshot_linear<256>, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, buf + shift, nvec - 64); });
+    printf("A+ one-shot linear, base shifted by %4d B    %.4f ms %.0f GB/s\n", shift * 16, ms, bytes / ms / 1e6);
+  }
   const int pieces = (tile_vec + 63) / 64;
   for (int order = 0; order < 2; ++order) {
     ms = timeit([&] { hipLaunchKernelGGL(oneshot_tiles, dim3((unsigned)(T * n_tiles * pieces)), dim3(64), 0, 0, buf, n_tiles, pieces, tile_vec, order); });
@@ -84,6 +96,29 @@ int main() {
   for (int order = 0; order < 2; ++order) {
     ms = timeit([&] { hipLaunchKernelGGL(oneshot_tiles256, dim3((unsigned)(T * n_tiles * pieces / 4)), dim3(256), 0, 0, buf, n_tiles, pieces, tile_vec, order); });
     printf("E%d one-shot 256-thr blocks, %s  %.4f ms %.0f GB/s\n", order, order ? "piece-major (tile stride)" : "tile-major (linear)      ", ms, bytes / ms / 1e6);
+  }
+  ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<256>, dim3((unsigned)(T * n_tiles)), dim3(256), 0, 0, buf, tile_vec); });
+  printf("F  one-shot block per (frame,tile), 256 thr    %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+  ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<512>, dim3((unsigned)(T * n_tiles)), dim3(512), 0, 0, buf, tile_vec); });
+  printf("F  one-shot block per (frame,tile), 512 thr    %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+  ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<704>, dim3((unsigned)(T * n_tiles)), dim3(704), 0, 0, buf, tile_vec); });
+  printf("G  one-shot block per (frame,tile), 704 thr    %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+  ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<128>, dim3((unsigned)(T * n_tiles)), dim3(128), 0, 0, buf, tile_vec); });
+  printf("F  one-shot block per (frame,tile), 128 thr    %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+  {
+    const int tv = 1400;  // 128 environments x 175 B = 22 400 B = 175 whole 128-byte lines
+    const unsigned nb = (unsigned)(T * n_tiles / 2);
+    ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<256>, dim3(nb), dim3(256), 0, 0, buf, tv); });
+    printf("H  one-shot block per (frame, 128-env tile), 256 thr   %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<512>, dim3(nb), dim3(512), 0, 0, buf, tv); });
+    printf("H  one-shot block per (frame, 128-env tile), 512 thr   %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<1024>, dim3(nb), dim3(1024), 0, 0, buf, tv); });
+    printf("H  one-shot block per (frame, 128-env tile), 1024 thr  %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+    const int tv2 = 2800;  // 256 environments
+    ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<1024>, dim3(nb / 2), dim3(1024), 0, 0, buf, tv2); });
+    printf("H  one-shot block per (frame, 256-env tile), 1024 thr  %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(oneshot_tile_block<256>, dim3(nb / 2), dim3(256), 0, 0, buf, tv2); });
+    printf("H  one-shot block per (frame, 256-env tile), 256 thr   %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
   }
   ms = timeit([&] { hipLaunchKernelGGL(persistent<-1>, dim3(n_tiles), dim3(64), 0, 0, buf, n_tiles, tile_vec, T); });
   printf("C  persistent, no wait                     %.4f ms %.0f GB/s\n", ms, bytes / ms / 1e6);
