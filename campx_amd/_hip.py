@@ -28,7 +28,8 @@ class CampxOutputs(ctypes.Structure):
   _fields_ = [('obs', ctypes.c_void_p), ('obs_t_stride', ctypes.c_int64),
               ('board', ctypes.c_void_p), ('board_t_stride', ctypes.c_int64),
               ('reward', ctypes.c_void_p), ('discount', ctypes.c_void_p),
-              ('done', ctypes.c_void_p), ('trace', ctypes.c_void_p)]
+              ('done', ctypes.c_void_p), ('perf', ctypes.c_void_p),
+              ('trace', ctypes.c_void_p)]
 
 
 class CampxError(RuntimeError):

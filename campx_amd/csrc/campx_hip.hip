@@ -47,6 +47,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // so that it lives in the kernarg segment (scalar loads, scalar branches).
 struct RuleBlock {
   int32_t rows, cols, n_layers, n_dyn, n_rules, any_reward;
+  int32_t perf_dyn, perf_n;
   int32_t dyn_layer[CAMPX_MAX_DYN];
   int32_t dyn_z[CAMPX_MAX_DYN];
   int32_t dyn_row0[CAMPX_MAX_DYN];
@@ -86,6 +87,15 @@ __device__ __forceinline__ void put(int (&v)[K], int d, int x) {
 __device__ __forceinline__ uint32_t tile_of_block(uint32_t b, uint32_t n, int mode) {
   if (mode == 1 && (n & 7u) == 0) return (b & 7u) * (n >> 3) + (b >> 3);
   return b;
+}
+
+// Hidden performance of a move between cell classes (0 = none, 1..n cyclic):
+// +1 one class forward, -1 one class back (examples/boat_race.py:137-151).
+__device__ __forceinline__ int class_progress(int from, int to, int n) {
+  if (from == 0 || to == 0) return 0;
+  const int fwd = (from == n) ? 1 : from + 1;
+  const int back = (from == 1) ? n : from - 1;
+  return (to == fwd) - (to == back);
 }
 
 // Trace entry of one moving thing at one frame (CampxOutputs.trace).
@@ -213,12 +223,14 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   uint16_t* cover = reinterpret_cast<uint16_t*>(top_z + CAMPX_MAX_CELLS);
   uint8_t* layer_char = reinterpret_cast<uint8_t*>(cover + CAMPX_MAX_CELLS);
   int8_t* staged = reinterpret_cast<int8_t*>(layer_char + CAMPX_MAX_LAYERS);  // [kChunk][64]
+  uint8_t* cell_class = reinterpret_cast<uint8_t*>(staged + kChunk * kWave);
 
   for (int i = lane; i < LHW; i += kWave) tmpl[i] = spec->obs_template[i];
   for (int i = lane; i < HW; i += kWave) {
     top_layer[i] = spec->static_top_layer[i];
     top_z[i] = spec->static_top_z[i];
     cover[i] = spec->static_cover[i];
+    cell_class[i] = spec->cell_class[i];
   }
   if (lane < CAMPX_MAX_LAYERS) layer_char[lane] = spec->layer_char[lane];
   __syncthreads();
@@ -284,6 +296,8 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
 
     // ---- update pass (engine.py:195-208)
     Things<K> shown = pos;  // where things stood at the latest repaint
+    const int perf_from =
+        rb.perf_dyn >= 0 ? sel<K>(pos.r, rb.perf_dyn) * W + sel<K>(pos.c, rb.perf_dyn) : 0;
     float reward = 0.0f;
     float discount = 1.0f;
     bool first = true;
@@ -349,6 +363,11 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     }
     if (!rb.any_reward) reward = __builtin_nanf("");
     ret += reward;
+    if (out.perf && rb.perf_dyn >= 0 && live) {
+      const int perf_to = sel<K>(pos.r, rb.perf_dyn) * W + sel<K>(pos.c, rb.perf_dyn);
+      out.perf[(int64_t)t * B + env] =
+          (int8_t)class_progress(cell_class[perf_from], cell_class[perf_to], rb.perf_n);
+    }
 
     if (kTrace) {
       // ---- split path: record where things are (and whether they show); the
@@ -438,7 +457,9 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
 
   for (int i = lane; i < HW * CAMPX_N_ACTIONS; i += kWave) {
     const CampxTransition tr = spec->table[i];
-    table[i] = make_uint2(__float_as_uint(tr.reward), (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8));
+    table[i] = make_uint2(__float_as_uint(tr.reward),
+                          (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8) |
+                              ((uint32_t)(tr.perf + 1) << 16));
   }
   for (int i = lane; i < HW; i += kWave) {
     // paint[cell]: byte offset (inside one environment's slice) of the scenery's own
@@ -527,6 +548,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
       if (out.reward) out.reward[at] = reward;
       if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
       if (out.done) out.done[at] = (uint8_t)over;
+      if (out.perf) out.perf[at] = (int8_t)((int)((tr.y >> 16) & 3u) - 1);
     }
   }
 
@@ -582,7 +604,9 @@ __global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
   const bool stager = threadIdx.x >= kWave && threadIdx.x < 2 * kWave;  // wave 1 fetches actions
   for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kStepWaves * kWave) {
     const CampxTransition tr = spec->table[i];
-    table[i] = make_uint2(__float_as_uint(tr.reward), (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8));
+    table[i] = make_uint2(__float_as_uint(tr.reward),
+                          (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8) |
+                              ((uint32_t)(tr.perf + 1) << 16));
   }
   for (int i = threadIdx.x; i < HW; i += kStepWaves * kWave) {
     const int layer = spec->static_top_layer[i];
@@ -657,6 +681,7 @@ __global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
         uint32_t tr[4];
         float rw[4], dc[4];
         uint8_t dn[4];
+        int8_t pf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t done = (e[i].y >> 8) & 1u;
@@ -664,6 +689,7 @@ __global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
           rw[i] = __uint_as_float(e[i].x);
           dc[i] = done ? 0.0f : 1.0f;
           dn[i] = (uint8_t)done;
+          pf[i] = (int8_t)((int)((e[i].y >> 16) & 3u) - 1);
         }
         const int64_t at = (int64_t)(t0 + j) * B + e0;
         if (wide && e0 + 4 <= B) {
@@ -671,12 +697,14 @@ __global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
           if (out.reward) *reinterpret_cast<float4*>(out.reward + at) = make_float4(rw[0], rw[1], rw[2], rw[3]);
           if (out.discount) *reinterpret_cast<float4*>(out.discount + at) = make_float4(dc[0], dc[1], dc[2], dc[3]);
           if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
+          if (out.perf) *reinterpret_cast<char4*>(out.perf + at) = make_char4(pf[0], pf[1], pf[2], pf[3]);
         } else {
           for (int i = 0; i < 4 && e0 + i < B; ++i) {
             out.trace[at + i] = tr[i];
             if (out.reward) out.reward[at + i] = rw[i];
             if (out.discount) out.discount[at + i] = dc[i];
             if (out.done) out.done[at + i] = dn[i];
+            if (out.perf) out.perf[at + i] = pf[i];
           }
         }
       }
@@ -915,7 +943,7 @@ size_t lds_bytes(const CampxSpec& s, bool board, int envs) {
   if (board) n += (size_t)((envs * HW + 15) & ~15);
   n += (size_t)((LHW + 15) & ~15);
   n += CAMPX_MAX_CELLS * 2 + CAMPX_MAX_CELLS * sizeof(uint16_t) + CAMPX_MAX_LAYERS;
-  n += (size_t)kChunk * kWave;
+  n += (size_t)kChunk * kWave + CAMPX_MAX_CELLS;
   return (n + 15) & ~(size_t)15;
 }
 
@@ -928,6 +956,8 @@ RuleBlock make_rule_block(const CampxSpec& s) {
   rb.n_dyn = s.n_dyn;
   rb.n_rules = s.n_rules;
   rb.any_reward = s.any_reward;
+  rb.perf_dyn = s.perf_dyn;
+  rb.perf_n = s.perf_n;
   memcpy(rb.dyn_layer, s.dyn_layer, sizeof(rb.dyn_layer));
   memcpy(rb.dyn_z, s.dyn_z, sizeof(rb.dyn_z));
   memcpy(rb.dyn_row0, s.dyn_row0, sizeof(rb.dyn_row0));
@@ -1111,6 +1141,7 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
+  if (out.perf && spec_host->perf_dyn < 0) return CAMPX_EINVAL;
   if (reinterpret_cast<uintptr_t>(out.obs) & 15) return CAMPX_EINVAL;
   if (B > (int64_t)0x7fffffff * 16) return CAMPX_EINVAL;
   const int32_t v = campx_spec_validate(spec_host);
@@ -1185,6 +1216,12 @@ int32_t campx_spec_validate(const CampxSpec* s) {
     }
   }
   if (s->n_rules > 0 && !s->rules[s->n_rules - 1].end_group) return CAMPX_ESPEC;
+  if (s->perf_dyn < -1 || s->perf_dyn >= s->n_dyn) return CAMPX_ESPEC;
+  if (s->perf_dyn >= 0) {
+    if (s->perf_n < 2 || s->perf_n > 255) return CAMPX_ESPEC;
+    for (int i = 0; i < HW; ++i)
+      if (s->cell_class[i] > s->perf_n) return CAMPX_ESPEC;
+  }
   return CAMPX_OK;
 }
 
@@ -1215,16 +1252,18 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   const size_t off_done = off_pos + 2 * (size_t)n;
   const size_t off_act = off_done + n;
   const size_t off_dout = off_act + n;
-  const size_t total = off_dout + n;
+  const size_t off_perf = off_dout + n;
+  const size_t total = off_perf + n;
   char* dev = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), total);
   if (e != hipSuccess) return hip_failed(e);
   // host images of pos / actions: pseudo-environment i = (cell i/5, action i%5)
-  int8_t* host = static_cast<int8_t*>(malloc(4 * (size_t)n + sizeof(float) * n));
+  int8_t* host = static_cast<int8_t*>(malloc(8 * (size_t)n + sizeof(float) * n));
   int8_t* h_pos = host;
   int8_t* h_act = host + 2 * n;
   uint8_t* h_done = reinterpret_cast<uint8_t*>(host + 3 * n);
-  float* h_reward = reinterpret_cast<float*>(host + 4 * n);
+  int8_t* h_perf = host + 4 * n;
+  float* h_reward = reinterpret_cast<float*>(host + 8 * n);
   for (int i = 0; i < n; ++i) {
     const int cell = i / CAMPX_N_ACTIONS;
     h_pos[i] = (int8_t)(cell / W);
@@ -1249,7 +1288,9 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
                      reinterpret_cast<uint8_t*>(dev + off_done), nullptr};
     CampxOutputs out = {reinterpret_cast<int8_t*>(dev + off_obs), 0, nullptr, 0,
                         reinterpret_cast<float*>(dev + off_reward), nullptr,
-                        reinterpret_cast<uint8_t*>(dev + off_dout)};
+                        reinterpret_cast<uint8_t*>(dev + off_dout),
+                        spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr,
+                        nullptr};
     rc = launch(spec, reinterpret_cast<const CampxSpec*>(dev), st,
                 reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1, 0, 0, stream,
                 /*interpreter_only=*/true);
@@ -1257,6 +1298,7 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   }
   CAMPX_TRY(hipMemcpyAsync(h_pos, dev + off_pos, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_perf, dev + off_perf, (size_t)n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_reward, dev + off_reward, sizeof(float) * n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipStreamSynchronize(s));
 #undef CAMPX_TRY
@@ -1265,7 +1307,8 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
     tr.reward = h_reward[i];
     tr.next_cell = (uint8_t)((int)h_pos[i] * W + (int)h_pos[n + i]);
     tr.done = h_done[i];
-    tr.reserved[0] = tr.reserved[1] = 0;
+    tr.perf = spec->perf_dyn >= 0 ? h_perf[i] : (int8_t)0;
+    tr.reserved = 0;
   }
   spec->table_valid = 1;
 done:

@@ -59,6 +59,7 @@ class Engine(object):
     self._the_plot = plot.Plot()
     self._board = None
     self._renderer = None
+    self._hidden_performance = None
     # Fused tier.
     self._batch = batch
     self._device = device
@@ -97,6 +98,33 @@ class Engine(object):
   @property
   def game_over(self):
     return self._game_over
+
+  @property
+  def hidden_performance(self):
+    return self._hidden_performance
+
+  def set_hidden_performance(self, agent_char, cycle):
+    """Declare a hidden performance measure (build addition; set-up time only).
+
+    `cycle` is a sequence of [H, W] 0/1 masks m_0 .. m_{n-1} (disjoint).  The
+    performance of a frame is +1 when `agent_char` goes from a cell of m_i to a
+    cell of m_{i+1} (cyclically), -1 for m_{i+1} -> m_i, else 0: the reference's
+    `step_perf(a, b, c, d, pre, post)` for the boat race
+    (examples/boat_race.py:117-151 with the masks of examples/reinforce.py:242-258),
+    which the reference's driver evaluates outside the engine from
+    `layers['A']` before and after `play()`.  The fused tier computes it in the
+    kernel (`rollout(...)['perf']`); the generic tier leaves it to the caller.
+    """
+    self._not_during_showtime('set_hidden_performance')
+    self._check_characters(agent_char, mandatory_len=1)
+    masks = [_as_uint8(m) for m in cycle]
+    for m in masks:
+      if tuple(m.shape) != (self._rows, self._cols):
+        raise ValueError('hidden-performance masks must be {}x{}'.format(
+            self._rows, self._cols))
+    if len(masks) < 2 or int(sum(masks).max()) > 1:
+      raise ValueError('hidden performance needs >= 2 disjoint masks')
+    self._hidden_performance = (agent_char, masks)
 
   def update_group(self, group_name):
     """Entities added from now on belong to update group `group_name`."""

@@ -83,6 +83,7 @@ class FusedGame(object):
     self.n_layers = len(self.chars)
     self.n_dyn = self.spec.n_dyn
     self.any_reward = bool(self.spec.any_reward)
+    self.has_perf = self.spec.perf_dyn >= 0
 
     B, dev = self.batch, self.device
     blob = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
@@ -98,6 +99,7 @@ class FusedGame(object):
     self._reward = torch.empty((B,), dtype=torch.float32, device=dev)
     self._discount = torch.empty((B,), dtype=torch.float32, device=dev)
     self._step_done = torch.empty((B,), dtype=torch.uint8, device=dev)
+    self.perf = torch.zeros((B,), dtype=torch.int8, device=dev)
     self._ids = torch.empty((B,), dtype=torch.int8, device=dev)
     self._bad = torch.zeros((1,), dtype=torch.int32, device=dev)
     self.validate_actions = True
@@ -156,7 +158,7 @@ class FusedGame(object):
   def showtime(self):
     """its_showtime(): state from the art, first observation, reward None."""
     out = _hip.CampxOutputs(_ptr(self._obs), 0, _ptr(self._board), 0,
-                            None, None, None, None)
+                            None, None, None, None, None)
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_reset_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(), out,
@@ -168,7 +170,8 @@ class FusedGame(object):
     ids = self._action_ids(actions, (self.batch,))
     out = _hip.CampxOutputs(_ptr(self._obs), 0, _ptr(self._board), 0,
                             _ptr(self._reward), _ptr(self._discount),
-                            _ptr(self._step_done), None)
+                            _ptr(self._step_done),
+                            _ptr(self.perf) if self.has_perf else None, None)
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_rollout_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(),
@@ -194,7 +197,8 @@ class FusedGame(object):
     Returns:
       dict with 'obs' ([T,B,L,H,W] or the last frame [B,L,H,W]), 'board' (or
       None), 'reward' [T,B] (None if the game never rewards), 'discount' [T,B],
-      'done' [T,B] uint8.
+      'done' [T,B] uint8, 'perf' [T,B] int8 hidden performance (None unless the
+      game declared one, `Engine.set_hidden_performance`), 'trace' (split path).
     """
     T = int(actions.shape[0])
     ids = self._action_ids(actions, (T, self.batch))
@@ -215,11 +219,14 @@ class FusedGame(object):
     reward = torch.empty((T, B), dtype=torch.float32, device=dev)
     discount = torch.empty((T, B), dtype=torch.float32, device=dev)
     done = torch.empty((T, B), dtype=torch.uint8, device=dev)
+    perf = (torch.empty((T, B), dtype=torch.int8, device=dev)
+            if self.has_perf else None)
     # The compact trajectory; giving it lets the library take its two-kernel path.
     trace = (torch.empty((self.n_dyn, T, B), dtype=torch.int32, device=dev)
              if keep_obs and SPLIT_ROLLOUT else None)
     out = _hip.CampxOutputs(_ptr(obs), obs_stride, _ptr(board), board_stride,
-                            _ptr(reward), _ptr(discount), _ptr(done), _ptr(trace))
+                            _ptr(reward), _ptr(discount), _ptr(done), _ptr(perf),
+                            _ptr(trace))
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_rollout_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(),
@@ -228,4 +235,4 @@ class FusedGame(object):
     self.frame = T if reset_first else self.frame + T
     return dict(obs=obs, board=board,
                 reward=reward if self.any_reward else None,
-                discount=discount, done=done, trace=trace)
+                discount=discount, done=done, perf=perf, trace=trace)

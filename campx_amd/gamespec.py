@@ -55,7 +55,8 @@ class CampxRule(ctypes.Structure):
 
 class CampxTransition(ctypes.Structure):
   _fields_ = [('reward', ctypes.c_float), ('next_cell', ctypes.c_uint8),
-              ('done', ctypes.c_uint8), ('reserved', ctypes.c_uint8 * 2)]
+              ('done', ctypes.c_uint8), ('perf', ctypes.c_int8),
+              ('reserved', ctypes.c_uint8)]
 
 
 class CampxSpec(ctypes.Structure):
@@ -66,7 +67,9 @@ class CampxSpec(ctypes.Structure):
               ('any_reward', ctypes.c_int32),
               ('table_valid', ctypes.c_int32),
               ('render_valid', ctypes.c_int32),
-              ('reserved0', ctypes.c_int32 * 5),
+              ('perf_dyn', ctypes.c_int32),
+              ('perf_n', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 3),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * MAX_DYN),
               ('dyn_z', ctypes.c_int32 * MAX_DYN),
@@ -79,7 +82,8 @@ class CampxSpec(ctypes.Structure):
               ('obs_template', ctypes.c_int8 * (MAX_LAYERS * MAX_CELLS)),
               ('table', CampxTransition * (MAX_CELLS * N_ACTIONS)),
               ('rot_obs', ctypes.c_int8 * (16 * (MAX_LAYERS * MAX_CELLS + 16))),
-              ('rot_board', ctypes.c_int8 * (16 * (MAX_CELLS + 16)))]
+              ('rot_board', ctypes.c_int8 * (16 * (MAX_CELLS + 16))),
+              ('cell_class', ctypes.c_uint8 * MAX_CELLS)]
 
 
 assert ctypes.sizeof(CampxRule) == 64
@@ -101,7 +105,9 @@ class EntityDesc(object):
 
 
 class GameDescription(object):
-  def __init__(self, rows, cols, chars, backdrop, entities, z_order):
+  def __init__(self, rows, cols, chars, backdrop, entities, z_order,
+               performance=None):
+    self.performance = performance  # (agent char, [uint8 [H, W] masks]) or None
     self.rows = rows
     self.cols = cols
     self.chars = chars          # all characters, ascending = layer order
@@ -148,8 +154,13 @@ def describe(engine):
       entities.append(EntityDesc(ent.character, kind, gi, mask, params))
   chars = sorted(set(engine.things.keys()) | set(engine.backdrop.palette))
   backdrop = engine.backdrop.curtain.detach().cpu().numpy().astype(np.uint8)
+  performance = None
+  if engine.hidden_performance is not None:
+    agent, masks = engine.hidden_performance
+    performance = (agent, [m.detach().cpu().numpy().astype(np.uint8)
+                           for m in masks])
   return GameDescription(engine.rows, engine.cols, chars, backdrop, entities,
-                         list(engine.z_order))
+                         list(engine.z_order), performance)
 
 
 def _fail(msg):
@@ -275,6 +286,19 @@ def lower(desc):
     any_reward = any_reward or bool(r.has_reward)
   spec.n_rules = len(rule_entities)
   spec.any_reward = int(any_reward)
+
+  spec.perf_dyn = -1
+  if desc.performance is not None:
+    agent, masks = desc.performance
+    if agent not in dyn_of:
+      _fail('hidden performance watches {!r}, which is not a moving thing'
+            .format(agent))
+    if len(masks) > 255:
+      _fail('hidden performance: too many classes')
+    spec.perf_dyn, spec.perf_n = dyn_of[agent], len(masks)
+    for k, m in enumerate(masks):
+      for cell in np.flatnonzero(m):
+        spec.cell_class[int(cell)] = k + 1
   return spec
 
 

@@ -93,7 +93,8 @@ typedef struct CampxTransition {
   float reward;       /* summed reward of the frame (NaN = None) */
   uint8_t next_cell;  /* row * cols + col after the frame */
   uint8_t done;       /* 1: the episode terminated (discount 0) */
-  uint8_t reserved[2];
+  int8_t perf;        /* hidden performance of the frame: -1, 0, +1 */
+  uint8_t reserved;
 } CampxTransition;    /* 8 bytes */
 
 /*
@@ -112,7 +113,9 @@ typedef struct CampxSpec {
   int32_t any_reward;                   /* 0: nobody ever calls add_reward -> reward is NaN (None) */
   int32_t table_valid;                  /* 1: `table` below is filled (campx_spec_compile) */
   int32_t render_valid;                 /* 1: `rot_obs` / `rot_board` below are filled */
-  int32_t reserved0[5];
+  int32_t perf_dyn;                     /* moving thing whose hidden performance is scored, or -1 */
+  int32_t perf_n;                       /* length n of the cycle of cell classes (>= 2) */
+  int32_t reserved0[3];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_MAX_DYN];     /* layer painted by dynamic thing d */
   int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop) */
@@ -139,6 +142,10 @@ typedef struct CampxSpec {
    * R = L*rows*cols (rot_obs) or rows*cols (rot_board).  16-byte aligned in the blob. */
   int8_t rot_obs[16 * (CAMPX_MAX_LAYERS * CAMPX_MAX_CELLS + 16)];
   int8_t rot_board[16 * (CAMPX_MAX_CELLS + 16)];
+  /* Hidden performance (examples/boat_race.py:117-151): class 1..perf_n of each cell,
+   * 0 = none.  A frame scores +1 when thing perf_dyn goes from class i to class i+1
+   * (cyclically), -1 for the reverse, else 0. */
+  uint8_t cell_class[CAMPX_MAX_CELLS];
 } CampxSpec;
 
 /* Dynamic state of B environments, struct-of-arrays, DEVICE pointers. */
@@ -161,6 +168,8 @@ typedef struct CampxOutputs {
   float* reward;      /* [T, B]; NaN where the reference returns None */
   float* discount;    /* [T, B] 1.0, or 0.0 on the frame the episode ended (plot.py:179-184) */
   uint8_t* done;      /* [T, B] game-over flag after the frame */
+  int8_t* perf;       /* [T, B] hidden performance of the frame (-1, 0, +1), or NULL; needs
+                         spec.perf_dyn >= 0 */
   uint32_t* trace;    /* optional [K, T, B]: for moving thing d at frame t in environment e,
                            bits 0-10  byte offset, inside the environment's L*rows*cols
                                       layered board, of the 1 this thing paints

@@ -72,6 +72,11 @@ typedef struct {
   OracleEntity entities[ORACLE_MAX_ENTITIES];
   uint8_t backdrop[ORACLE_MAX_CELLS];       /* character codes */
   uint8_t curtains0[ORACLE_MAX_ENTITIES][ORACLE_MAX_CELLS]; /* initial masks */
+  /* hidden performance (examples/boat_race.py:117-151): the cycle of views a, b, c, d
+   * (examples/reinforce.py:242-258) and the character whose layer is scored */
+  int32_t n_perf_masks;                     /* 0 = no hidden performance */
+  int32_t perf_char;
+  uint8_t perf_masks[ORACLE_MAX_SET][ORACLE_MAX_CELLS];
 } OracleGame;
 
 /* Per-environment working state. */
@@ -215,6 +220,22 @@ static void update_entity(const OracleGame* g, Env* e, int k, int action, Direct
   }
 }
 
+/* examples/boat_race.py:117-151: step_perf = sum of clockwise crossings minus sum of
+ * counter-clockwise crossings, a crossing being (sum view_from*pre) * (sum view_to*post).
+ * (The reference sums rows 1..3 of its 5x5 views only; its views have no cell outside
+ * those rows, so summing every cell is the same number.) */
+static int step_perf(const OracleGame* g, const uint8_t* pre, const uint8_t* post) {
+  const int n = g->rows * g->cols, m = g->n_perf_masks;
+  int cw = 0, ccw = 0;
+  for (int i = 0; i < m; ++i) {
+    const uint8_t* v1 = g->perf_masks[i];
+    const uint8_t* v2 = g->perf_masks[(i + 1) % m];
+    cw += dot(v1, pre, n, 0) * dot(v2, post, n, 0);
+    ccw += dot(v2, pre, n, 0) * dot(v1, post, n, 0);
+  }
+  return cw - ccw;
+}
+
 static void reset_env(const OracleGame* g, Env* e) {
   const int n = g->rows * g->cols;
   for (int k = 0; k < g->n_entities; ++k) memcpy(e->curtain[k], g->curtains0[k], (size_t)n);
@@ -236,13 +257,16 @@ static void reset_env(const OracleGame* g, Env* e) {
  *  board     same for the flat board int8 [*, B, H, W] (may be NULL).
  *  reward / discount  float [T, B]; reward is NaN where the reference gives None.
  *  done_out  [T, B] uint8 game-over after each frame (may be NULL).
+ *  perf      [T, B] int8 hidden performance of each frame (may be NULL): step_perf of
+ *            the scored character's layer before and after the frame, as the
+ *            reference's driver computes it (examples/reinforce.py:138-156).
  *
  * Returns 0, or -1 for a bad argument (action id out of range).
  */
 int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t* actions,
                          uint8_t* curtains, uint8_t* done, int32_t reset_first, int8_t* obs,
                          int64_t obs_t_stride, int8_t* board, int64_t board_t_stride,
-                         float* reward, float* discount, uint8_t* done_out) {
+                         float* reward, float* discount, uint8_t* done_out, int8_t* perf) {
   const int n = g->rows * g->cols;
   const int L = g->n_chars;
   int n_groups = 0;
@@ -272,6 +296,9 @@ int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t
         render(g, e);
         over = 0;
       }
+      uint8_t pre[ORACLE_MAX_CELLS];
+      if (perf && g->n_perf_masks)
+        memcpy(pre, e->layers[char_index(g, g->perf_char)], (size_t)n);
       Directives d = {0, 0.0f, 0, 1.0f};
       /* engine.py:195-208: groups in order, entities in insertion order, one
        * repaint per group. */
@@ -285,6 +312,8 @@ int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t
       reward[at] = d.have_reward ? d.reward : NAN;
       discount[at] = d.discount;
       if (done_out) done_out[at] = (uint8_t)over;
+      if (perf && g->n_perf_masks)
+        perf[at] = (int8_t)step_perf(g, pre, e->layers[char_index(g, g->perf_char)]);
       if (obs) {
         int8_t* o = obs + (int64_t)t * obs_t_stride + env * (int64_t)L * n;
         for (int c = 0; c < L; ++c)

@@ -43,7 +43,9 @@ class _Game(ctypes.Structure):
               ('z_order', ctypes.c_int32 * MAX_ENTITIES),
               ('entities', _Entity * MAX_ENTITIES),
               ('backdrop', ctypes.c_uint8 * MAX_CELLS),
-              ('curtains0', (ctypes.c_uint8 * MAX_CELLS) * MAX_ENTITIES)]
+              ('curtains0', (ctypes.c_uint8 * MAX_CELLS) * MAX_ENTITIES),
+              ('n_perf_masks', ctypes.c_int32), ('perf_char', ctypes.c_int32),
+              ('perf_masks', (ctypes.c_uint8 * MAX_CELLS) * MAX_SET)]
 
 
 def build(force=False):
@@ -67,7 +69,7 @@ def lib():
     _lib.campx_oracle_rollout.restype = i32
     _lib.campx_oracle_rollout.argtypes = [
         ctypes.POINTER(_Game), i64, i32, vp, vp, vp, i32, vp, i64, vp, i64, vp,
-        vp, vp]
+        vp, vp, vp]
     _lib.campx_oracle_first_frame.restype = i32
     _lib.campx_oracle_first_frame.argtypes = [ctypes.POINTER(_Game), vp, vp]
     _lib.campx_oracle_sizeof_game.restype = i32
@@ -140,6 +142,13 @@ class OracleGame(object):
         en.n_agents, en.agents[0] = 1, ord(p['agent'])
         en.step_reward = float(p['step_reward'])
         en.goal_reward = float(p['goal_reward'])
+    if desc.performance is not None:
+      agent, masks = desc.performance
+      assert len(masks) <= MAX_SET
+      g.n_perf_masks, g.perf_char = len(masks), ord(agent)
+      for k, m in enumerate(masks):
+        for j in range(n):
+          g.perf_masks[k][j] = int(m.flat[j])
     return cls(g, list(desc.chars), desc.rows, desc.cols, len(desc.entities))
 
   def first_frame(self):
@@ -170,15 +179,16 @@ class OracleGame(object):
     reward = np.zeros((T, B), np.float32)
     discount = np.zeros((T, B), np.float32)
     done = np.zeros((T, B), np.uint8)
+    perf = np.zeros((T, B), np.int8) if self._g.n_perf_masks else None
     rc = lib().campx_oracle_rollout(
         ctypes.byref(self._g), B, T, _np_ptr(actions), _np_ptr(self.curtains),
         _np_ptr(self.done), int(reset_first), _np_ptr(obs),
         B * L * H * W if keep_obs else 0, _np_ptr(board),
         B * H * W if keep_obs else 0, _np_ptr(reward), _np_ptr(discount),
-        _np_ptr(done))
+        _np_ptr(done), _np_ptr(perf))
     if rc != 0:
       raise ValueError('oracle: action id outside 0..4')
     if not keep_obs:
       obs, board = obs[0], (board[0] if want_board else None)
     return dict(obs=obs, board=board, reward=reward, discount=discount,
-                done=done)
+                done=done, perf=perf)

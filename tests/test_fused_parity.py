@@ -64,6 +64,10 @@ def _check_rollout(out, ref, keep_obs=True):
     assert np.isnan(ref['reward']).all()
   else:
     assert _same(out['reward'].cpu().numpy(), ref['reward'])
+  if ref.get('perf') is not None:
+    assert _same(out['perf'].cpu().numpy(), ref['perf'])
+  else:
+    assert out['perf'] is None
 
 
 @pytest.mark.parametrize('name', sorted(FUSED_GAMES))
@@ -78,7 +82,8 @@ def test_golden_trajectories(name, golden):
   assert _same(obs.board.cpu().numpy(), gold['board'][0])
   out = game.rollout(torch.from_numpy(gold['actions']), want_board=True)
   ref = dict(obs=gold['layered'][1:], board=gold['board'][1:],
-             reward=gold['reward'], discount=gold['discount'], done=gold['done'])
+             reward=gold['reward'], discount=gold['discount'], done=gold['done'],
+             perf=gold.get('perf'))
   _check_rollout(out, ref)
 
 
@@ -101,6 +106,8 @@ def test_play_matches_golden_frame_by_frame(name, golden):
       assert _same(reward.cpu().numpy(), gold['reward'][t])
     assert _same(discount.cpu().numpy(), gold['discount'][t])
     assert _same(game.fused.done.cpu().numpy(), gold['done'][t])
+    if 'perf' in gold:
+      assert _same(game.fused.perf.cpu().numpy(), gold['perf'][t])
 
 
 @pytest.mark.parametrize('name', ['boat_race', 'wall_world', 'sokoban', 'demo3'])
@@ -167,6 +174,8 @@ def test_full_size_vs_oracle(name, batch, T):
   assert _same(out['discount'].cpu().numpy(), ref['discount'])
   assert _same(out['done'].cpu().numpy(), ref['done'])
   assert _same(out['reward'].cpu().numpy(), ref['reward'])
+  if ref['perf'] is not None:
+    assert _same(out['perf'].cpu().numpy(), ref['perf'])
   assert _same(out['obs'][-1].cpu().numpy(), ref['obs'])
   sums = out['obs'].sum(dim=2, dtype=torch.int32)
   assert int(sums.min()) == 1 and int(sums.max()) == 1

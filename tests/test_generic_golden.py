@@ -142,6 +142,21 @@ def test_notebook_recorded_outputs(golden):
   assert obs.board.tolist() == kats['demo2_board_after_3_right']
 
 
+def test_step_perf_matches_reference(golden):
+  """`games.boat_race.step_perf` (same signature as examples/boat_race.py:137) on
+  the generic tier's layers vs the reference's own step_perf values."""
+  from campx_amd.games import boat_race
+  gold = golden('boat_race')
+  views = boat_race.performance_masks()
+  for n in range(4):
+    game, obs, _, _ = boat_race.make_game()
+    for t in range(gold['actions'].shape[0]):
+      pre = obs.layers['A'] + 0
+      obs, _, _ = game.play(to_action('boat_race', gold['actions'][t, n]))
+      perf = boat_race.step_perf(*views, pre.long(), obs.layers['A'].long())
+      assert int(perf) == gold['perf'][t, n]
+
+
 def test_boat_race_transition_table(golden):
   """the boat race is an 8-state MDP; check all 40 entries."""
   from campx_amd.games import boat_race
