@@ -18,21 +18,43 @@ GAME_ART = ['######',
             '### G#',
             '######']
 
+# Build-authored larger levels with two and three boxes (three and four moving
+# things): boxes block each other, the agent is blocked by walls and boxes.
+LEVELS = {
+    0: GAME_ART,
+    1: ['########',
+        '#  A   #',
+        '# X  Y #',
+        '#   #  #',
+        '#  G   #',
+        '########'],
+    2: ['########',
+        '# A    #',
+        '# XYZ  #',
+        '#      #',
+        '#   G  #',
+        '########'],
+}
+
 MOVEMENT_REWARD = -1
 GOAL_REWARD = 50
 
 
-def build(batch=None, device=None):
+def build(batch=None, device=None, level=0):
+  art = LEVELS[level]
+  boxes = [ch for ch in 'XYZ' if any(ch in row for row in art)]
+  drapes = {'#': rules.FixedDrape,
+            'A': Partial(rules.AgentDrape, blocking_chars='#' + ''.join(boxes)),
+            'G': Partial(rules.GoalDrape, agent_char='A',
+                         step_reward=MOVEMENT_REWARD, goal_reward=GOAL_REWARD)}
+  for ch in boxes:
+    others = ''.join(b for b in boxes if b != ch)
+    drapes[ch] = Partial(rules.BoxDrape, agent_char='A',
+                         blocking_chars='#' + others)
   return ascii_art_to_game(
-      GAME_ART, what_lies_beneath=' ',
-      drapes={'#': rules.FixedDrape,
-              'X': Partial(rules.BoxDrape, agent_char='A', blocking_chars='#'),
-              'A': Partial(rules.AgentDrape, blocking_chars='#X'),
-              'G': Partial(rules.GoalDrape, agent_char='A',
-                           step_reward=MOVEMENT_REWARD,
-                           goal_reward=GOAL_REWARD)},
-      update_schedule=[['X'], ['A', 'G', '#']], z_order='GXA#',
-      batch=batch, device=device)
+      art, what_lies_beneath=' ', drapes=drapes,
+      update_schedule=[boxes, ['A', 'G', '#']],
+      z_order='G' + ''.join(boxes) + 'A#', batch=batch, device=device)
 
 
 def make_game(batch=None, device=None):

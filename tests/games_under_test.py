@@ -2,7 +2,11 @@
 
 from campx_amd.games import boat_race, wall_world, sokoban, demos
 
+import functools
+
 FUSED_GAMES = {
+    'sokoban_l1': functools.partial(sokoban.build, level=1),
+    'sokoban_l2': functools.partial(sokoban.build, level=2),
     'boat_race': boat_race.build,
     'wall_world': wall_world.build,
     'sokoban': sokoban.build,

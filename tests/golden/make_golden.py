@@ -356,6 +356,35 @@ def gen_sokoban():
   save('sokoban', golden)
 
 
+def gen_sokoban_levels():
+  """Two and three boxes (K = 3, 4 moving things), reference AgentDrape + the
+  build's Box/Goal rules on the reference engine."""
+  for level in (1, 2):
+    art = g_sk.LEVELS[level]
+    boxes = [ch for ch in 'XYZ' if any(ch in row for row in art)]
+    acts = random_actions(410 + level, 80, 32)
+    acts[:6, 0] = [3, 0, 3, 3, 1, 1]       # walk round a box and to the goal row
+
+    def game(agent_cls, box_cls, goal_cls, fixed_cls):
+      def make():
+        drapes = {'#': fixed_cls,
+                  'A': Partial(agent_cls, blocking_chars='#' + ''.join(boxes)),
+                  'G': Partial(goal_cls, agent_char='A', step_reward=-1, goal_reward=50)}
+        for ch in boxes:
+          drapes[ch] = Partial(box_cls, agent_char='A',
+                               blocking_chars='#' + ''.join(b for b in boxes if b != ch))
+        return to_game(art, what_lies_beneath=' ', drapes=drapes,
+                       update_schedule=[boxes, ['A', 'G', '#']],
+                       z_order='G' + ''.join(boxes) + 'A#')
+      return make
+
+    golden = run(game(ref.boat_race.AgentDrape, R.BoxDrape, R.GoalDrape,
+                      ref.things.FixedDrape), acts)
+    lib = run(game(R.AgentDrape, R.BoxDrape, R.GoalDrape, R.FixedDrape), acts)
+    assert_same(golden, lib, 'sokoban level {} library agent'.format(level))
+    save('sokoban_l{}'.format(level), golden)
+
+
 def gen_hello_world():
   ns = ref_harness.notebook_namespace('Hello World Example.ipynb', [3, 4])
   acts = random_actions(501, 40, 4, n_actions=4)
@@ -372,5 +401,6 @@ if __name__ == '__main__':
   agent = gen_demos()
   gen_wall_world(agent)
   gen_sokoban()
+  gen_sokoban_levels()
   gen_hello_world()
   print('done; reference at', ref.campx.__file__)
