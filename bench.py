@@ -57,6 +57,11 @@ def parse_args():
   p.add_argument('--frames', type=int, default=100,
                  help='Engine.play() frames per launch (episode length)')
   p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--gather-every', type=int, default=8,
+                 help='episodes per RCCL all-gather of the episode-return log')
+  p.add_argument('--force-dist', action='store_true',
+                 help='initialise torch.distributed (RCCL) and run the episode-return '
+                      'all-gather even with one rank (smoke test of the N>1 path)')
   p.add_argument('--cpu-seconds', type=float, default=12.0,
                  help='target duration of the CPU baseline sample')
   return p.parse_args()
@@ -126,13 +131,18 @@ def main():
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   dist = None
-  if world > 1:
+  if world > 1 or args.force_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=device)
+    os.environ.setdefault('MASTER_PORT', '29533')
+    # 256 KiB-per-rank messages are latency-bound: two channels are plenty and keep
+    # the collective's workgroups from occupying compute units the rollout needs.
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', '2')
+    os.environ.setdefault('NCCL_MIN_NCHANNELS', '1')
+    dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
 
   from campx_amd import games
-  from campx_amd.distributed import ReturnGatherer
+  from campx_amd.distributed import ReturnLog
 
   name, default_batch = WORKLOADS[args.game]
   B = args.batch or default_batch
@@ -149,12 +159,18 @@ def main():
   streams = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8)
              .to(device) for _ in range(2)]
   obs = torch.empty((T, B, L, H, W), dtype=torch.int8, device=device)
-  gatherer = ReturnGatherer(B, device, dist) if world > 1 else None
+  # Episode returns are logged per rank and all-gathered over RCCL every
+  # `--gather-every` episodes (campx_amd.distributed.ReturnLog): the kernel
+  # accumulates each episode's returns straight into its row of the log, so nothing
+  # but the rollout kernel ever runs on the rollout's stream.
+  log = ReturnLog(B, args.gather_every, device, dist) if dist is not None else None
 
   def one_step(i):
+    if log is not None:
+      fused.ret = log.row()
     out = fused.rollout(streams[i & 1], obs=obs, reset_first=True)
-    if gatherer is not None:
-      gatherer.gather_async(fused.ret)
+    if log is not None:
+      log.episode_done()
     return out
 
   def fence():
@@ -171,12 +187,14 @@ def main():
   t0 = time.perf_counter()
   for i in range(args.steps):
     starts[i].record()               # torch's current stream = the launch stream
+    if log is not None:
+      fused.ret = log.row()
     out = fused.rollout(streams[i & 1], obs=obs, reset_first=True)
     stops[i].record()
-    if gatherer is not None:
-      gatherer.gather_async(fused.ret)
-  if gatherer is not None:
-    gatherer.wait()
+    if log is not None:
+      log.episode_done()
+  if log is not None:
+    log.wait()
   fence()
   elapsed = time.perf_counter() - t0
   if dist is not None:
@@ -212,8 +230,9 @@ def main():
             'frames_per_step': T,
             'step': 'one rollout launch = one {}-frame episode for every '
                     'environment, all frames written to HBM'.format(T),
-            'parallelism': 'env-sharded x{}, RCCL all-gather of episode '
-                           'returns off the step path'.format(world)
+            'parallelism': 'env-sharded x{}, RCCL all-gather of the episode-'
+                           'return log every {} episodes, off the step path'
+                           .format(world, args.gather_every)
                            if world > 1 else 'single GPU',
             'mean_episode_return': mean_return,
         },

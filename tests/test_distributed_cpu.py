@@ -17,7 +17,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from campx_amd import gamespec
-from campx_amd.distributed import shard_range, ReturnGatherer, episode_stats
+from campx_amd.distributed import shard_range, ReturnGatherer, ReturnLog, episode_stats
 from campx_amd.games import boat_race
 
 
@@ -54,6 +54,16 @@ def _worker(rank, world, port, global_batch, frames, out_dir):
       gatherer.gather_async(returns)
     gathered = gatherer.wait()
     assert gathered.shape == (global_batch,)
+    # the episode-return log: 5 episodes, gathered in blocks of 2
+    log = ReturnLog(stop - start, 2, 'cpu', dist)
+    for episode in range(5):
+      row = log.row()
+      row.copy_(returns + episode)            # stands in for the kernel's accumulation
+      full = log.episode_done()
+      assert full == (episode % 2 == 1)
+    block = log.wait()                        # episodes 2 and 3
+    assert block.shape == (world, 2, stop - start)
+    assert torch.equal(block[rank, 0], returns + 2) and torch.equal(block[rank, 1], returns + 3)
     if rank == 0:
       np.save(os.path.join(out_dir, 'gathered.npy'), gathered.numpy())
       mean, lo, hi = episode_stats(gathered)

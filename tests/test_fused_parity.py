@@ -179,3 +179,32 @@ def test_full_size_vs_oracle(name, batch, T):
   assert _same(out['obs'][-1].cpu().numpy(), ref['obs'])
   sums = out['obs'].sum(dim=2, dtype=torch.int32)
   assert int(sums.min()) == 1 and int(sums.max()) == 1
+
+
+def test_return_gatherer_on_gpu_single_rank_rccl(tmp_path):
+  """The RCCL all-gather of episode returns (bench.py's N>1 path) with one rank."""
+  import subprocess
+  import sys
+  import os
+  code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+from campx_amd.distributed import ReturnGatherer
+from campx_amd.games import boat_race
+game = boat_race.build(batch=4096, device=dev); game.its_showtime()
+g = ReturnGatherer(4096, dev, dist)
+acts = torch.randint(0, 5, (50, 4096), dtype=torch.int8, device=dev)
+for episode in range(3):
+    out = game.rollout(acts, reset_first=True, keep_obs=False)
+    g.gather_async(game.fused.ret)
+got = g.wait(); torch.cuda.synchronize()
+assert torch.equal(got, out['reward'].sum(0)), 'gathered returns differ'
+dist.destroy_process_group()
+print('ok')
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
