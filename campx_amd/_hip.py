@@ -9,8 +9,8 @@ import os
 
 from .gamespec import CampxSpec
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc',
-                         'libcampx_hip.so')
+_LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
 
 EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
            'campx_reset_launch',

@@ -18,7 +18,8 @@ OUT = os.path.join(HERE, 'csrc', 'libcampx_hip.so')
 INCLUDE = os.path.join(REPO, 'include')
 
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-               '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+               '-ffp-contract=off', '-Wall', '-Wno-unused-function',
+               '-Wno-pass-failed']
 
 
 def find_hipcc():

@@ -39,11 +39,11 @@ from .rendering import Observation
 # (campx_spec_compile) and let the frame loop look it up.  Tests switch this off to
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
-# Rollouts that keep every frame can run the update pass and the render as two
-# kernels (needs a [K, T, B] int32 trace buffer).  Parity-tested in both settings;
-# off by default because on MI355X the single fused kernel is currently the faster
-# of the two (DESIGN.md "Kernels", profiles/).
-SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '0') == '1'
+# Rollouts that keep every frame run the update pass and the render as two kernels
+# (needs a [K, T, B] int32 trace buffer): 0.196 ms vs 0.224 ms per 100-frame launch of
+# the boat race at B = 65 536 (DESIGN.md "Kernels", profiles/).  CAMPX_SPLIT=0 keeps
+# everything in the single fused kernel; parity tests run both.
+SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') == '1'
 
 
 def _ptr(t):
