@@ -13,6 +13,7 @@ _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
 
 EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
+           'campx_pair_table_bytes', 'campx_pair_table_build',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_check_actions_launch',
            'campx_onehot_to_ids_launch', 'campx_strerror',
@@ -21,7 +22,7 @@ EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
 
 class CampxState(ctypes.Structure):
   _fields_ = [('pos', ctypes.c_void_p), ('done', ctypes.c_void_p),
-              ('ret', ctypes.c_void_p)]
+              ('ret', ctypes.c_void_p), ('pair_table', ctypes.c_void_p)]
 
 
 class CampxOutputs(ctypes.Structure):
@@ -50,6 +51,10 @@ def _load():
   lib.campx_spec_validate.argtypes = [spec_p]
   lib.campx_spec_compile.restype = i32
   lib.campx_spec_compile.argtypes = [spec_p, vp]
+  lib.campx_pair_table_bytes.restype = i64
+  lib.campx_pair_table_bytes.argtypes = [spec_p]
+  lib.campx_pair_table_build.restype = i32
+  lib.campx_pair_table_build.argtypes = [spec_p, vp, vp, vp]
   lib.campx_reset_launch.restype = i32
   lib.campx_reset_launch.argtypes = [spec_p, vp, CampxState, CampxOutputs, i64, vp]
   lib.campx_rollout_launch.restype = i32

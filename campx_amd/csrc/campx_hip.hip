@@ -1,5 +1,5 @@
-// campx_hip.hip - fused step + render kernel for batched CampX grid worlds on
-// MI355X (gfx950, CDNA4), and the C ABI declared in include/campx_hip.h.
+// campx_hip.hip - batched CampX grid-world engine for MI355X (gfx950, CDNA4), and the
+// C ABI declared in include/campx_hip.h.
 //
 // What one launch computes, per environment and per frame, is the reference's
 // Engine.play() (campx/engine.py:114-166): every entity's update() in schedule
@@ -7,21 +7,23 @@
 // discount / game-over bookkeeping (campx/plot.py:161-211, engine.py:285-292) and
 // the occluded layered-board render (campx/rendering.py:104-219).
 //
-// How it is mapped to the hardware (DESIGN.md has the numbers):
-//   * one lane = one environment, one 64-lane wavefront = one workgroup = 64
-//     consecutive environments; no inter-wave communication at all.
-//   * the game is static data: per-cell "what the scenery shows here" tables and
-//     the layered board of the scenery alone sit in LDS; the rule list arrives in
-//     the kernarg segment so the interpreter's loads and branches are scalar.
-//   * the dynamic state (row, col of each moving thing) lives in VGPRs for all T
-//     frames of a launch.
-//   * the wave's slice of the output, 64 x L*H*W bytes, is kept as a persistent
-//     image in LDS.  A frame changes a handful of bytes of it (the cells things
-//     left and entered); then the whole image is streamed out with ds_read_b128 +
-//     global_store_dwordx4, 1 KiB per wave-instruction, fully coalesced.  The
-//     observation really is written to HBM every frame: that write stream is the
-//     algorithmic traffic and the roofline of the kernel.
-//   * no MFMA: there is no contraction anywhere in this path.
+// Kernels (DESIGN.md section 3 has the numbers):
+//   rollout_kernel        rule interpreter + render, fused.  One lane = one
+//                         environment, one wave = one workgroup = 64 environments;
+//                         rules arrive in the kernarg segment (scalar loads/branches),
+//                         scenery tables and the wave's 64 x L*H*W-byte output image
+//                         live in LDS; a frame patches a few bytes of the image and
+//                         streams it out, 1 KiB per wave-instruction.
+//   rollout_table_kernel  same, for games with one moving thing: the update pass is a
+//                         lookup in a (cell, action) table that campx_spec_compile()
+//                         fills by running rollout_kernel over every pair.
+//   trace_table_kernel    the update pass alone (producer wave + consumer waves),
+//   render_kernel         and the observation stream alone: one-shot blocks, every
+//                         wave one aligned KiB store - the store pattern that reaches
+//                         the chip's HBM write ceiling.  The default for rollouts of
+//                         one-mover games.
+// No MFMA anywhere: the path has no contraction; every kernel is bound by the HBM
+// write stream of observations.
 //
 // Compiled with -ffp-contract=off: rewards are sums of a few float terms and must
 // round exactly like the reference's float32 tensor arithmetic.
@@ -749,6 +751,164 @@ __global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Split path, first half, two-mover games: the update pass from the
+// (cell, cell, action) pair table (campx_pair_table_build).  Same producer/consumer
+// layout as trace_table_kernel; the table sits in LDS when it fits (kLds) and is read
+// through L1/L2 otherwise.
+struct PairParams {
+  int32_t rows, cols, n_layers;
+  int32_t dyn_layer[2], row0[2], col0[2];
+  int32_t lds_table;  // entries fit in LDS
+};
+
+constexpr int kPairLdsEntries = 8192;  // 32 KiB of LDS for the table
+
+__device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW) {
+  return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kStepWaves* kWave) void trace_pair_kernel(
+    PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first) {
+  __shared__ uint32_t lds_entries[kLds ? kPairLdsEntries : 1];
+  __shared__ float reward_list[256];
+  __shared__ uint16_t scenery_off[CAMPX_MAX_CELLS];  // byte offset of the scenery's 1 per cell
+  __shared__ int8_t staged[2][kChunk * kWave];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kUnroll][kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool producer = threadIdx.x < kWave;
+  const int W = pp.cols, HW = pp.rows * pp.cols;
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
+  const bool live = env < B;
+  const int consumer_lane = (int)threadIdx.x - kWave;
+  const bool stager = threadIdx.x >= kWave && threadIdx.x < 2 * kWave;
+
+  const float* g_rewards = static_cast<const float*>(st.pair_table);
+  const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
+  const int n_entries = HW * HW * CAMPX_N_ACTIONS;
+  if (kLds)
+    for (int i = threadIdx.x; i < n_entries; i += kStepWaves * kWave) lds_entries[i] = g_entries[i];
+  for (int i = threadIdx.x; i < 256; i += kStepWaves * kWave) reward_list[i] = g_rewards[i];
+  for (int i = threadIdx.x; i < HW; i += kStepWaves * kWave)
+    scenery_off[i] = (uint16_t)(spec->static_top_layer[i] * HW + i);
+  if (stager && T > 0) stage_actions<kWave>(staged[0], actions, B, T, 0, env, live, lane);
+
+  const uint32_t init0 = (uint32_t)(pp.row0[0] * W + pp.col0[0]);
+  const uint32_t init1 = (uint32_t)(pp.row0[1] * W + pp.col0[1]);
+  uint32_t c0 = init0, c1 = init1;
+  int over = 0;
+  float ret = 0.0f;
+  if (producer && !reset_first && live) {
+    c0 = (uint32_t)((int)st.pos[env] * W + (int)st.pos[B + env]);
+    c1 = (uint32_t)((int)st.pos[2 * B + env] * W + (int)st.pos[3 * B + env]);
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+  const bool wide = (B & 3) == 0;
+  constexpr int kGroupsPerChunk = kChunk / kUnroll;
+  __syncthreads();
+
+  const int n_groups = (T + kUnroll - 1) / kUnroll;
+  for (int g = 0; g <= n_groups; ++g) {
+    if (producer) {
+      const int t0 = g * kUnroll;
+      if (g < n_groups) {
+        const int8_t* my_actions = staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * kWave + lane;
+        const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
+        uint32_t act[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+          const int a = my_actions[j * kWave];
+          act[j] = ((unsigned)a > 4u) ? 4u : (uint32_t)a;
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+          if (j < n) {
+            if (over) {  // rebuilt from the art before its next action
+              c0 = init0;
+              c1 = init1;
+            }
+            const uint32_t idx = pair_index(c0, c1, HW) + act[j];
+            const uint32_t e = kLds ? lds_entries[idx] : g_entries[idx];
+            c0 = e & 0x7fu;
+            c1 = (e >> 7) & 0x7fu;
+            ring[g & 1][j][lane] = e;
+            ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
+            over = (int)((e >> 16) & 1u);
+          }
+        }
+      }
+    } else {
+      if (stager && (g % kGroupsPerChunk) == 0) {
+        const int t_next = (g / kGroupsPerChunk + 1) * kChunk;
+        if (t_next < T)
+          stage_actions<kWave>(staged[(t_next / kChunk) & 1], actions, B, T, t_next, env, live, lane);
+      }
+      if (g == 0) {
+        __syncthreads();
+        continue;
+      }
+      const int gp = g - 1, t0 = gp * kUnroll;
+      const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
+      const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
+      for (int item = consumer_lane; item < n * (kWave / 4); item += (kStepWaves - 1) * kWave) {
+        const int j = item >> 4, q = item & 15;
+        const int64_t e0 = env0 + 4 * q;
+        if (e0 >= B) continue;
+        const uint4 e4 = *reinterpret_cast<const uint4*>(&ring[gp & 1][j][4 * q]);
+        const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+        uint32_t ta[4], tb[4];
+        float rw[4], dc[4];
+        uint8_t dn[4];
+        int8_t pf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t a = e[i] & 0x7fu, b = (e[i] >> 7) & 0x7fu;
+          const uint32_t done = (e[i] >> 16) & 1u;
+          ta[i] = pack_trace(pp.dyn_layer[0] * HW + (int)a, scenery_off[a], (int)a, (e[i] >> 14) & 1u);
+          tb[i] = pack_trace(pp.dyn_layer[1] * HW + (int)b, scenery_off[b], (int)b, (e[i] >> 15) & 1u);
+          rw[i] = reward_list[(e[i] >> 19) & 0xffu];
+          dc[i] = done ? 0.0f : 1.0f;
+          dn[i] = (uint8_t)done;
+          pf[i] = (int8_t)((int)((e[i] >> 17) & 3u) - 1);
+        }
+        const int64_t at = (int64_t)(t0 + j) * B + e0;
+        if (wide && e0 + 4 <= B) {
+          *reinterpret_cast<uint4*>(out.trace + at) = make_uint4(ta[0], ta[1], ta[2], ta[3]);
+          *reinterpret_cast<uint4*>(out.trace + plane + at) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+          if (out.reward) *reinterpret_cast<float4*>(out.reward + at) = make_float4(rw[0], rw[1], rw[2], rw[3]);
+          if (out.discount) *reinterpret_cast<float4*>(out.discount + at) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+          if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
+          if (out.perf) *reinterpret_cast<char4*>(out.perf + at) = make_char4(pf[0], pf[1], pf[2], pf[3]);
+        } else {
+          for (int i = 0; i < 4 && e0 + i < B; ++i) {
+            out.trace[at + i] = ta[i];
+            out.trace[plane + at + i] = tb[i];
+            if (out.reward) out.reward[at + i] = rw[i];
+            if (out.discount) out.discount[at + i] = dc[i];
+            if (out.done) out.done[at + i] = dn[i];
+            if (out.perf) out.perf[at + i] = pf[i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (producer && live) {
+    st.pos[env] = (int8_t)(c0 / (uint32_t)W);
+    st.pos[B + env] = (int8_t)(c0 % (uint32_t)W);
+    st.pos[2 * B + env] = (int8_t)(c1 / (uint32_t)W);
+    st.pos[3 * B + env] = (int8_t)(c1 % (uint32_t)W);
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Split path, second half: expand the trace into the observation stream.
 // One-shot blocks, ONE aligned 16-byte store per thread, block (x, t) writing bytes
 // [x*4096, (x+1)*4096) of frame t: the dispatcher walks the output linearly.  That
@@ -769,18 +929,6 @@ struct RenderParams {
   int64_t B;
   int32_t dyn_char[CAMPX_MAX_DYN];
 };
-
-__device__ __forceinline__ void poke(u32x4& v, int p, uint32_t val) {
-  // byte p of v = val, when 0 <= p < 16
-  const bool in = (unsigned)p < 16u;
-  const uint32_t sh = (uint32_t)(p & 3) * 8u;
-  const uint32_t keep = ~(0xffu << sh), bits = val << sh;
-  const int w = p >> 2;
-  v.x = (in && w == 0) ? ((v.x & keep) | bits) : v.x;
-  v.y = (in && w == 1) ? ((v.y & keep) | bits) : v.y;
-  v.z = (in && w == 2) ? ((v.z & keep) | bits) : v.z;
-  v.w = (in && w == 3) ? ((v.w & keep) | bits) : v.w;
-}
 
 // Block (x, t) writes bytes [x*4096, (x+1)*4096) of frame t; each of its four waves
 // owns one aligned KiB of it (every store instruction of a wave is one aligned,
@@ -1147,6 +1295,24 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
                             s.dyn_row0[0], s.dyn_col0[0]};
     hipLaunchKernelGGL(trace_table_kernel, grid, dim3(kStepWaves * kWave), 0, stream, mp, spec_dev,
                        st, actions, out, B, T, reset_first);
+  } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
+    PairParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.rows = s.rows;
+    pp.cols = s.cols;
+    pp.n_layers = s.n_layers;
+    for (int d = 0; d < 2; ++d) {
+      pp.dyn_layer[d] = s.dyn_layer[d];
+      pp.row0[d] = s.dyn_row0[d];
+      pp.col0[d] = s.dyn_col0[d];
+    }
+    const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
+    if (n_entries <= kPairLdsEntries)
+      hipLaunchKernelGGL(trace_pair_kernel<true>, grid, dim3(kStepWaves * kWave), 0, stream, pp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    else
+      hipLaunchKernelGGL(trace_pair_kernel<false>, grid, dim3(kStepWaves * kWave), 0, stream, pp,
+                         spec_dev, st, actions, out, B, T, reset_first);
   } else {
     switch (s.n_dyn) {
       case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
@@ -1313,7 +1479,7 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   CAMPX_TRY(hipMemsetAsync(dev + off_done, 0, (size_t)n, s));
   {
     CampxState st = {reinterpret_cast<int8_t*>(dev + off_pos),
-                     reinterpret_cast<uint8_t*>(dev + off_done), nullptr};
+                     reinterpret_cast<uint8_t*>(dev + off_done), nullptr, nullptr};
     CampxOutputs out = {reinterpret_cast<int8_t*>(dev + off_obs), 0, nullptr, 0,
                         reinterpret_cast<float*>(dev + off_reward), nullptr,
                         reinterpret_cast<uint8_t*>(dev + off_dout),
@@ -1339,6 +1505,118 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
     tr.reserved = 0;
   }
   spec->table_valid = 1;
+done:
+  free(host);
+  (void)hipFree(dev);
+  return rc;
+}
+
+int64_t campx_pair_table_bytes(const CampxSpec* spec) {
+  if (!spec || campx_spec_validate(spec) != CAMPX_OK || spec->n_dyn != 2) return 0;
+  const int64_t HW = (int64_t)spec->rows * spec->cols;
+  const int64_t bytes = 256 * (int64_t)sizeof(float) + HW * HW * CAMPX_N_ACTIONS * (int64_t)sizeof(uint32_t);
+  return bytes <= (1 << 20) ? bytes : 0;
+}
+
+int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev, void* table_dev,
+                               void* stream) {
+  const int64_t bytes = campx_pair_table_bytes(spec);
+  if (bytes == 0 || !spec_dev || !table_dev) return CAMPX_EINVAL;
+  const int W = spec->cols, HW = spec->rows * spec->cols;
+  const int n = HW * HW * CAMPX_N_ACTIONS;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // scratch: obs | trace[2][n] | reward[n] | pos[4][n] | done[n] | actions[n] | done_out[n] | perf[n]
+  const size_t off_trace = ((size_t)n * spec->n_layers * HW + 255) & ~(size_t)255;
+  const size_t off_reward = off_trace + 2 * sizeof(uint32_t) * (size_t)n;
+  const size_t off_pos = off_reward + sizeof(float) * (size_t)n;
+  const size_t off_done = off_pos + 4 * (size_t)n;
+  const size_t off_act = off_done + n;
+  const size_t off_dout = off_act + n;
+  const size_t off_perf = off_dout + n;
+  const size_t total = off_perf + n;
+  char* dev = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), total);
+  if (e != hipSuccess) return hip_failed(e);
+  const size_t host_bytes = (size_t)n * (4 + 1 + 1 + 1 + 8 + 4) + (size_t)bytes;
+  char* host = static_cast<char*>(malloc(host_bytes));
+  int8_t* h_pos = reinterpret_cast<int8_t*>(host);
+  int8_t* h_act = h_pos + 4 * (size_t)n;
+  uint8_t* h_done = reinterpret_cast<uint8_t*>(h_act + n);
+  int8_t* h_perf = reinterpret_cast<int8_t*>(h_done + n);
+  uint32_t* h_trace = reinterpret_cast<uint32_t*>(h_perf + n + ((8 - (7 * (size_t)n) % 8) % 8));
+  float* h_reward = reinterpret_cast<float*>(h_trace + 2 * (size_t)n);
+  float* h_table = h_reward + n;
+  uint32_t* h_entries = reinterpret_cast<uint32_t*>(h_table + 256);
+  for (int i = 0; i < n; ++i) {
+    const int a = i % CAMPX_N_ACTIONS, c1 = (i / CAMPX_N_ACTIONS) % HW, c0 = i / (CAMPX_N_ACTIONS * HW);
+    h_pos[i] = (int8_t)(c0 / W);
+    h_pos[n + i] = (int8_t)(c0 % W);
+    h_pos[2 * n + i] = (int8_t)(c1 / W);
+    h_pos[3 * n + i] = (int8_t)(c1 % W);
+    h_act[i] = (int8_t)a;
+  }
+  int32_t rc = CAMPX_OK;
+  int n_rewards = 0;
+#define CAMPX_TRY(call)           \
+  do {                            \
+    e = (call);                   \
+    if (e != hipSuccess) {        \
+      rc = hip_failed(e);         \
+      goto done;                  \
+    }                             \
+  } while (0)
+  CAMPX_TRY(hipMemcpyAsync(dev + off_pos, h_pos, 4 * (size_t)n, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemcpyAsync(dev + off_act, h_act, (size_t)n, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemsetAsync(dev + off_done, 0, (size_t)n, s));
+  CAMPX_TRY(hipMemsetAsync(dev + off_perf, 0, (size_t)n, s));
+  {
+    CampxState st = {reinterpret_cast<int8_t*>(dev + off_pos),
+                     reinterpret_cast<uint8_t*>(dev + off_done), nullptr, nullptr};
+    CampxOutputs out = {reinterpret_cast<int8_t*>(dev), 0, nullptr, 0,
+                        reinterpret_cast<float*>(dev + off_reward), nullptr,
+                        reinterpret_cast<uint8_t*>(dev + off_dout),
+                        spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr,
+                        reinterpret_cast<uint32_t*>(dev + off_trace)};
+    // the interpreter in trace mode: positions, visibility, reward, done, perf
+    launch_trace_k<2>(*spec, spec_dev, st, reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1,
+                      0, s);
+    CAMPX_TRY(hipGetLastError());
+  }
+  CAMPX_TRY(hipMemcpyAsync(h_trace, dev + off_trace, 2 * sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_reward, dev + off_reward, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_perf, dev + off_perf, (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < 256; ++i) h_table[i] = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    uint32_t bits;
+    memcpy(&bits, &h_reward[i], 4);
+    int idx = -1;
+    for (int k = 0; k < n_rewards; ++k) {
+      uint32_t have;
+      memcpy(&have, &h_table[k], 4);
+      if (have == bits) {
+        idx = k;
+        break;
+      }
+    }
+    if (idx < 0) {
+      if (n_rewards == 256) {
+        rc = CAMPX_ESPEC;
+        goto done;
+      }
+      idx = n_rewards++;
+      h_table[idx] = h_reward[i];
+    }
+    const uint32_t ta = h_trace[i], tb = h_trace[n + i];
+    const int perf = spec->perf_dyn >= 0 ? h_perf[i] : 0;
+    h_entries[i] = ((ta >> 22) & 0x7fu) | (((tb >> 22) & 0x7fu) << 7) | (((ta >> 29) & 1u) << 14) |
+                   (((tb >> 29) & 1u) << 15) | ((uint32_t)(h_done[i] & 1) << 16) |
+                   ((uint32_t)(perf + 1) << 17) | ((uint32_t)idx << 19);
+  }
+  CAMPX_TRY(hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipStreamSynchronize(s));
+#undef CAMPX_TRY
 done:
   free(host);
   (void)hipFree(dev);

@@ -43,7 +43,8 @@ COMPILE_TABLE = True
 # (needs a [K, T, B] int32 trace buffer): 0.196 ms vs 0.224 ms per 100-frame launch of
 # the boat race at B = 65 536 (DESIGN.md "Kernels", profiles/).  CAMPX_SPLIT=0 keeps
 # everything in the single fused kernel; parity tests run both.
-SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') == '1'
+SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') in ('1', 'force')
+FORCE_SPLIT = os.environ.get('CAMPX_SPLIT', '') == 'force'   # also for multi-mover games
 
 
 def _ptr(t):
@@ -89,6 +90,20 @@ class FusedGame(object):
     blob = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
                             dtype=torch.uint8)
     self._spec_dev = blob.to(dev)
+    # Two-mover games: the (cell, cell, action) table of the update pass.
+    self._pair_table = None
+    n_pair = int(_hip.lib.campx_pair_table_bytes(ctypes.byref(self.spec)))
+    if COMPILE_TABLE and n_pair > 0:
+      table = torch.empty((n_pair,), dtype=torch.uint8, device=dev)
+      with torch.cuda.device(self.device):
+        rc = _hip.lib.campx_pair_table_build(
+            ctypes.byref(self.spec), _ptr(self._spec_dev), _ptr(table),
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+      if rc == 0:
+        self._pair_table = table
+      elif rc != -2:          # -2: more than 256 distinct rewards -> just interpret
+        _hip.check(rc, 'campx_pair_table_build')
+    self.uses_table = self.uses_table or self._pair_table is not None
     self.pos = torch.zeros((2 * self.n_dyn, B), dtype=torch.int8, device=dev)
     self.done = torch.zeros((B,), dtype=torch.uint8, device=dev)
     self.ret = torch.zeros((B,), dtype=torch.float32, device=dev)
@@ -111,7 +126,8 @@ class FusedGame(object):
     return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
   def _state(self):
-    return _hip.CampxState(_ptr(self.pos), _ptr(self.done), _ptr(self.ret))
+    return _hip.CampxState(_ptr(self.pos), _ptr(self.done), _ptr(self.ret),
+                           _ptr(self._pair_table))
 
   def _observation(self, obs, board):
     layers = {ch: obs[:, i] for i, ch in enumerate(self.chars)}
@@ -222,8 +238,11 @@ class FusedGame(object):
     perf = (torch.empty((T, B), dtype=torch.int8, device=dev)
             if self.has_perf else None)
     # The compact trajectory; giving it lets the library take its two-kernel path.
+    # (Games with several movers interpret their rules per frame in one wave; for
+    # them the single fused kernel is still the faster path unless forced.)
+    split = SPLIT_ROLLOUT and (self.uses_table or FORCE_SPLIT)
     trace = (torch.empty((self.n_dyn, T, B), dtype=torch.int32, device=dev)
-             if keep_obs and SPLIT_ROLLOUT else None)
+             if keep_obs and split else None)
     out = _hip.CampxOutputs(_ptr(obs), obs_stride, _ptr(board), board_stride,
                             _ptr(reward), _ptr(discount), _ptr(done), _ptr(perf),
                             _ptr(trace))

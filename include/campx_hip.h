@@ -154,6 +154,9 @@ typedef struct CampxState {
   uint8_t* done;   /* [B] game-over latch (campx/engine.py:285); a latched environment is
                       rebuilt from the art before its next action is applied */
   float* ret;      /* [B] return accumulated since the last rebuild, or NULL */
+  const void* pair_table; /* optional, games with exactly two moving things: the device table
+                      campx_pair_table_build() filled; lets the two-kernel path look the
+                      update pass up instead of interpreting the rules.  NULL = interpret. */
 } CampxState;
 
 /* Per-frame outputs, DEVICE pointers; any of them except `obs` may be NULL.
@@ -199,6 +202,25 @@ int32_t campx_spec_validate(const CampxSpec* spec_host);
  * synchronises `stream`.  Upload the spec to the device AFTER this call.
  */
 int32_t campx_spec_compile(CampxSpec* spec_host, void* stream);
+
+/*
+ * Games with exactly TWO moving things: the update pass of a frame is a function of
+ * (cell of thing 0, cell of thing 1, action).  campx_pair_table_bytes() is the size of
+ * its table for this game (0 when n_dyn != 2 or the table would exceed 1 MiB);
+ * campx_pair_table_build() fills caller-allocated DEVICE memory of that size by
+ * running the rule interpreter kernel over every (cell, cell, action) triple, the same
+ * way campx_spec_compile() does for one-mover games (set-up time only: scratch
+ * allocation + stream synchronisation inside).  Returns CAMPX_ESPEC when a frame of
+ * this game can pay more than 256 distinct rewards (the table indexes a reward list).
+ * Layout: 256 floats (reward list), then rows*cols * rows*cols * 5 uint32 entries,
+ * index ((cell0 * rows*cols) + cell1) * 5 + action:
+ *   bits 0-6 cell of thing 0 after the frame, 7-13 cell of thing 1, 14/15 whether
+ *   thing 0 / 1 is the character its cell shows, 16 done, 17-18 perf + 1,
+ *   19-26 index into the reward list.
+ */
+int64_t campx_pair_table_bytes(const CampxSpec* spec_host);
+int32_t campx_pair_table_build(const CampxSpec* spec_host, const CampxSpec* spec_dev,
+                               void* table_dev, void* stream);
 
 /*
  * Put B environments into the state its_showtime() leaves them in

@@ -32,10 +32,10 @@ def rollout_path(request):
   """... and with rollouts as two kernels (update pass -> trace -> render) or as the
   single fused kernel."""
   from campx_amd import fused
-  saved = fused.SPLIT_ROLLOUT
-  fused.SPLIT_ROLLOUT = request.param == 'split'
+  saved = fused.SPLIT_ROLLOUT, fused.FORCE_SPLIT
+  fused.SPLIT_ROLLOUT = fused.FORCE_SPLIT = request.param == 'split'
   yield request.param
-  fused.SPLIT_ROLLOUT = saved
+  fused.SPLIT_ROLLOUT, fused.FORCE_SPLIT = saved
 
 
 def _same(a, b):
@@ -49,8 +49,8 @@ def _fused(name, batch):
   from campx_amd import fused
   game = FUSED_GAMES[name](batch=batch, device='cuda')
   first = game.its_showtime()
-  one_mover = game.fused.n_dyn == 1
-  assert game.fused.uses_table == (fused.COMPILE_TABLE and one_mover)
+  tabulated = game.fused.n_dyn <= 2      # (cell, action) or (cell, cell, action) tables
+  assert game.fused.uses_table == (fused.COMPILE_TABLE and tabulated)
   return game, first
 
 
