@@ -102,7 +102,7 @@ def cpu_baseline(game_name, frames, seconds):
   }
 
 
-def measured_traffic(game, batch, frames):
+def measured_traffic(game, batch, frames, path):
   """HBM bytes per launch from the committed rocprofv3 PMC passes, or None.
 
   bench.py cannot run the profiler on itself; the figure comes from
@@ -112,7 +112,7 @@ def measured_traffic(game, batch, frames):
   try:
     with open(os.path.join(REPO, 'profiles', 'r01_traffic.json')) as f:
       table = json.load(f)
-    return table['{}:{}:{}'.format(game, batch, frames)]['traffic_bytes']
+    return table['{}:{}:{}:{}'.format(game, batch, frames, path)]['traffic_bytes']
   except (OSError, KeyError, ValueError):
     return None
 
@@ -210,7 +210,15 @@ def main():
     env_steps = B * T * args.steps * world
     bytes_per_launch = BYTES_PER_ENV_STEP[args.game] * B * T
     achieved = bytes_per_launch / kernel_s / 1e9
-    traffic = measured_traffic(args.game, B, T)
+    from campx_amd import fused as fused_mod
+    split = fused_mod.SPLIT_ROLLOUT and (fused.uses_table or fused_mod.FORCE_SPLIT)
+    traffic = measured_traffic(args.game, B, T, 'split' if split else 'fused')
+    if split:
+      kernels = ('trace_table_kernel' if fused.n_dyn == 1 else
+                 'trace_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
+                 'rollout_kernel<trace>') + ' + render_kernel'
+    else:
+      kernels = 'rollout_table_kernel' if fused.n_dyn == 1 and fused.uses_table else 'rollout_kernel'
     line = {
         'metric': 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X',
         'value': env_steps / elapsed,
@@ -244,7 +252,9 @@ def main():
             'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic / 1e9 / kernel_s if traffic else None,
             'traffic_bytes_per_launch': traffic,
-            'kernel': 'rollout_table_kernel' if fused.uses_table else 'rollout_kernel',
+            'kernel': kernels,
+            'kernel_note': 'kernel_ms spans every kernel of one rollout launch '
+                           '(events on the launch stream around the call)',
             'kernel_ms': kernel_s * 1e3,
             'bytes_per_env_step': BYTES_PER_ENV_STEP[args.game],
             'bytes_per_launch': bytes_per_launch,
