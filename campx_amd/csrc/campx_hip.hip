@@ -169,6 +169,22 @@ __device__ __forceinline__ void repaint_cell(const RuleBlock& rb, const LdsTable
 
 // Stream `nbytes` of an LDS image to global memory.  16-byte vector path when the
 // destination is 16-byte aligned, byte path otherwise (odd batch tails only).
+// 16-byte store of four floats from the update pass (reward, discount).  They are
+// not read again by this launch: CAMPX_STEP_STREAM=1 sends them with the streaming
+// policy of the observation stores.
+#ifndef CAMPX_STEP_STREAM
+#define CAMPX_STEP_STREAM 0
+#endif
+__device__ __forceinline__ void store_f4(float* p, const float (&v)[4]) {
+  const u32x4 bits = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                      __float_as_uint(v[3])};
+#if CAMPX_STEP_STREAM
+  store16_streaming(reinterpret_cast<u32x4*>(p), bits);
+#else
+  *reinterpret_cast<u32x4*>(p) = bits;
+#endif
+}
+
 // Copy this lane's next actions (frames t .. t+kChunk-1) into LDS.  All loads of a
 // group of 16 are issued before any is used; rows past the end are clamped so that
 // there is no branch between the loads (a branch makes hipcc wait for each load
@@ -724,8 +740,8 @@ __global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
         const int64_t at = (int64_t)(t0 + j) * B + e0;
         if (wide && e0 + 4 <= B) {
           *reinterpret_cast<uint4*>(out.trace + at) = make_uint4(tr[0], tr[1], tr[2], tr[3]);
-          if (out.reward) *reinterpret_cast<float4*>(out.reward + at) = make_float4(rw[0], rw[1], rw[2], rw[3]);
-          if (out.discount) *reinterpret_cast<float4*>(out.discount + at) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+          if (out.reward) store_f4(out.reward + at, rw);
+          if (out.discount) store_f4(out.discount + at, dc);
           if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
           if (out.perf) *reinterpret_cast<char4*>(out.perf + at) = make_char4(pf[0], pf[1], pf[2], pf[3]);
         } else {
@@ -879,8 +895,8 @@ __global__ __launch_bounds__(kStepWaves* kWave) void trace_pair_kernel(
         if (wide && e0 + 4 <= B) {
           *reinterpret_cast<uint4*>(out.trace + at) = make_uint4(ta[0], ta[1], ta[2], ta[3]);
           *reinterpret_cast<uint4*>(out.trace + plane + at) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-          if (out.reward) *reinterpret_cast<float4*>(out.reward + at) = make_float4(rw[0], rw[1], rw[2], rw[3]);
-          if (out.discount) *reinterpret_cast<float4*>(out.discount + at) = make_float4(dc[0], dc[1], dc[2], dc[3]);
+          if (out.reward) store_f4(out.reward + at, rw);
+          if (out.discount) store_f4(out.discount + at, dc);
           if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
           if (out.perf) *reinterpret_cast<char4*>(out.perf + at) = make_char4(pf[0], pf[1], pf[2], pf[3]);
         } else {
