@@ -30,7 +30,7 @@ class CampxOutputs(ctypes.Structure):
               ('board', ctypes.c_void_p), ('board_t_stride', ctypes.c_int64),
               ('reward', ctypes.c_void_p), ('discount', ctypes.c_void_p),
               ('done', ctypes.c_void_p), ('perf', ctypes.c_void_p),
-              ('trace', ctypes.c_void_p)]
+              ('trace', ctypes.c_void_p), ('obs_format', ctypes.c_int32)]
 
 
 class CampxError(RuntimeError):

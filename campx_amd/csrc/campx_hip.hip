@@ -955,7 +955,7 @@ struct RenderParams {
 // patch - (row overlapping the window) x (moving thing) x (set | clear) - write their
 // single byte into it, then every lane reads its 16 bytes back and stores them.
 // Nothing is shared between waves, so there is no workgroup barrier.
-template <int K, bool kBoard, bool kNT, int kWin>
+template <int K, bool kBoard, bool kNT, int kWin, int kFmt>
 __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
                                                      const CampxSpec* __restrict__ spec,
                                                      const uint32_t* __restrict__ trace,
@@ -1029,17 +1029,42 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
     apply(sidx, frame_trace[(int64_t)d * n_rows + first_row + (uint32_t)r]);
   }
 
-  // ---- out: kWin aligned, contiguous KiB stores per wave
+  // ---- out: aligned, contiguous KiB stores
+  if (kFmt == 0) {
 #pragma unroll
-  for (int j = 0; j < kWin; ++j) {
-    const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
-    if (off < rp.slab_bytes) {                         // frames are whole 16-byte chunks
-      const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
-      u32x4* o = reinterpret_cast<u32x4*>(dst + (int64_t)blockIdx.y * rp.slab_bytes + off);
-      if (kNT)
-        store16_streaming(o, v);
-      else
-        *o = v;
+    for (int j = 0; j < kWin; ++j) {
+      const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
+      if (off < rp.slab_bytes) {                         // frames are whole 16-byte chunks
+        const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
+        u32x4* o = reinterpret_cast<u32x4*>(dst + (int64_t)blockIdx.y * rp.slab_bytes + off);
+        if (kNT)
+          store16_streaming(o, v);
+        else
+          *o = v;
+      }
+    }
+  } else {
+    // 16-bit observations (f16 / bf16 0.0 and 1.0) for a policy network: a lane turns
+    // 8 bytes of the image into 8 halves; lanes stay contiguous, so each store
+    // instruction is again one aligned KiB (of 512 elements).
+    constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+#pragma unroll
+    for (int h = 0; h < 2 * kWin; ++h) {
+      const uint32_t elem = woff0 + (uint32_t)h * 512u + (uint32_t)lane * 8u;  // in the frame
+      if (elem < rp.slab_bytes) {
+        const uint2 b = *reinterpret_cast<const uint2*>(win0 + h * 512 + lane * 8);
+        u32x4 v;
+        v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * kOne;
+        v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * kOne;
+        v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * kOne;
+        v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * kOne;
+        u32x4* o = reinterpret_cast<u32x4*>(
+            dst + 2 * ((int64_t)blockIdx.y * rp.slab_bytes + (int64_t)elem));
+        if (kNT)
+          store16_streaming(o, v);
+        else
+          *o = v;
+      }
     }
   }
 }
@@ -1237,7 +1262,8 @@ void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
 }
 
 int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint32_t* trace,
-                      int8_t* dst, int64_t B, int32_t T, bool is_board, hipStream_t stream) {
+                      int8_t* dst, int64_t B, int32_t T, bool is_board, int fmt,
+                      hipStream_t stream) {
   const int HW = s.rows * s.cols;
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -1253,22 +1279,21 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint3
   rp.is_board = is_board ? 1 : 0;
   rp.B = B;
   for (int d = 0; d < s.n_dyn; ++d) rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
-  const int win = knob_render_per_thread();
+  const int win = fmt ? 2 : knob_render_per_thread();
   const uint32_t span = 4096u * (uint32_t)win;
   const dim3 grid((rp.slab_bytes + span - 1u) / span, (unsigned)T);
   const int64_t n_rows = (int64_t)T * B;
   const bool nt = knob_store_nt();
-#define CAMPX_RENDER3(KK, BOARD, NT)                                                            \
-  do {                                                                                          \
-    if (win == 1)                                                                               \
-      hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, 1>), grid, dim3(256), 0, stream, rp,     \
-                         spec_dev, trace, dst, n_rows);                                         \
-    else if (win == 2)                                                                          \
-      hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, 2>), grid, dim3(256), 0, stream, rp,     \
-                         spec_dev, trace, dst, n_rows);                                         \
-    else                                                                                        \
-      hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, 4>), grid, dim3(256), 0, stream, rp,     \
-                         spec_dev, trace, dst, n_rows);                                         \
+#define CAMPX_RENDER4(KK, BOARD, NT, WIN, FMT)                                              \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, WIN, FMT>), grid, dim3(256), 0, stream,  \
+                     rp, spec_dev, trace, dst, n_rows)
+#define CAMPX_RENDER3(KK, BOARD, NT)                                  \
+  do {                                                                \
+    if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 2, 1);       \
+    else if (!BOARD && fmt == 2) CAMPX_RENDER4(KK, false, NT, 2, 2);  \
+    else if (win == 1) CAMPX_RENDER4(KK, BOARD, NT, 1, 0);            \
+    else if (win == 2) CAMPX_RENDER4(KK, BOARD, NT, 2, 0);            \
+    else CAMPX_RENDER4(KK, BOARD, NT, 4, 0);                          \
   } while (0)
 #define CAMPX_RENDER2(KK, BOARD)                                                    \
   do {                                                                              \
@@ -1287,6 +1312,7 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint3
 #undef CAMPX_RENDER1
 #undef CAMPX_RENDER2
 #undef CAMPX_RENDER3
+#undef CAMPX_RENDER4
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
@@ -1339,9 +1365,9 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
-  int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, B, T, false, stream);
+  int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, B, T, false, out.obs_format, stream);
   if (rc != CAMPX_OK) return rc;
-  if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, B, T, true, stream);
+  if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, B, T, true, 0, stream);
   return rc;
 }
 
@@ -1360,8 +1386,10 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool use_table =
       spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table();
+  if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
   if (!emit_first && !interpreter_only && split_ok(*spec_host, out, B, T))
     return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
+  if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;  // 16-bit needs the render kernel
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {

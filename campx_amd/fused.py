@@ -72,12 +72,13 @@ class FusedGame(object):
     self.spec = gamespec.lower(self.description)
     _hip.check(_hip.lib.campx_spec_validate(ctypes.byref(self.spec)),
                'campx_spec_validate')
-    if COMPILE_TABLE:
-      with torch.cuda.device(self.device):
-        _hip.check(_hip.lib.campx_spec_compile(
-            ctypes.byref(self.spec),
-            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
-            'campx_spec_compile')
+    with torch.cuda.device(self.device):
+      _hip.check(_hip.lib.campx_spec_compile(
+          ctypes.byref(self.spec),
+          ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+          'campx_spec_compile')
+    if not COMPILE_TABLE:
+      self.spec.table_valid = 0     # keep the render tables, interpret the rules
     self.uses_table = bool(self.spec.table_valid)
     self.chars = list(self.description.chars)
     self.rows, self.cols = engine.rows, engine.cols
@@ -198,7 +199,7 @@ class FusedGame(object):
     return self._observation(self._obs, self._board), reward, self._discount
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True,
-              reset_first=False, want_board=False):
+              reset_first=False, want_board=False, obs_dtype=torch.int8):
     """T frames in one launch.
 
     Args:
@@ -210,6 +211,11 @@ class FusedGame(object):
       board: optional int8 [T, B, H, W] buffer for the flat boards.
       reset_first: rebuild all environments from the art before frame 0 (a new
           episode, as `make_game()` per episode in examples/reinforce.py:122).
+      obs_dtype: torch.int8 (default), torch.float16 or torch.bfloat16.  The
+          16-bit forms are the policy-network input the reference's driver makes
+          with `layered_board.view(-1).float()` (examples/reinforce.py:123,149),
+          written directly by the render kernel; they need `keep_obs` and a game
+          that takes the two-kernel path.
     Returns:
       dict with 'obs' ([T,B,L,H,W] or the last frame [B,L,H,W]), 'board' (or
       None), 'reward' [T,B] (None if the game never rewards), 'discount' [T,B],
@@ -219,15 +225,20 @@ class FusedGame(object):
     T = int(actions.shape[0])
     ids = self._action_ids(actions, (T, self.batch))
     B, L, H, W, dev = self.batch, self.n_layers, self.rows, self.cols, self.device
+    formats = {torch.int8: 0, torch.float16: 1, torch.bfloat16: 2}
+    if obs_dtype not in formats:
+      raise ValueError('obs_dtype must be torch.int8, float16 or bfloat16')
     if keep_obs:
       if obs is None:
-        obs = torch.empty((T, B, L, H, W), dtype=torch.int8, device=dev)
-      elif (tuple(obs.shape) != (T, B, L, H, W) or obs.dtype != torch.int8
+        obs = torch.empty((T, B, L, H, W), dtype=obs_dtype, device=dev)
+      elif (tuple(obs.shape) != (T, B, L, H, W) or obs.dtype != obs_dtype
             or not obs.is_contiguous() or obs.device != dev):
-        raise ValueError('obs must be a contiguous int8 [T,B,L,H,W] tensor on '
-                         + str(dev))
+        raise ValueError('obs must be a contiguous {} [T,B,L,H,W] tensor on {}'
+                         .format(obs_dtype, dev))
       obs_stride = B * L * H * W
     else:
+      if formats[obs_dtype]:
+        raise ValueError('16-bit observations need keep_obs=True')
       obs, obs_stride = self._obs, 0
     if want_board and board is None:
       board = torch.empty((T, B, H, W), dtype=torch.int8, device=dev)
@@ -240,12 +251,12 @@ class FusedGame(object):
     # The compact trajectory; giving it lets the library take its two-kernel path.
     # (Games with several movers interpret their rules per frame in one wave; for
     # them the single fused kernel is still the faster path unless forced.)
-    split = SPLIT_ROLLOUT and (self.uses_table or FORCE_SPLIT)
+    split = (SPLIT_ROLLOUT and (self.uses_table or FORCE_SPLIT)) or bool(formats[obs_dtype])
     trace = (torch.empty((self.n_dyn, T, B), dtype=torch.int32, device=dev)
              if keep_obs and split else None)
     out = _hip.CampxOutputs(_ptr(obs), obs_stride, _ptr(board), board_stride,
                             _ptr(reward), _ptr(discount), _ptr(done), _ptr(perf),
-                            _ptr(trace))
+                            _ptr(trace), formats[obs_dtype])
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_rollout_launch(
           ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(),

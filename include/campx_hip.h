@@ -54,6 +54,8 @@ enum {
   CAMPX_ENODEV = -4    /* no gfx950 device */
 };
 
+enum { CAMPX_OBS_INT8 = 0, CAMPX_OBS_F16 = 1, CAMPX_OBS_BF16 = 2 };
+
 /* Rule opcodes: the update() bodies of the reference's example entities. */
 enum {
   /* Move dynamic thing `dyn` one cell by the action, cyclically; if the cell it
@@ -185,6 +187,13 @@ typedef struct CampxOutputs {
                          16-byte multiples, the library runs the update pass and the render as
                          two kernels, which streams the observations to HBM faster (DESIGN.md
                          "Kernels").  Written only on that path. */
+  int32_t obs_format; /* element type of `obs` (obs_t_stride counts elements):
+                         CAMPX_OBS_INT8 0/1 bytes (the default, 0);
+                         CAMPX_OBS_F16 / CAMPX_OBS_BF16: 0.0 / 1.0 in that format, the tensor
+                         the reference's driver builds with `layered_board.view(-1).float()`
+                         (examples/reinforce.py:123,149) handed over without a conversion
+                         pass.  16-bit formats are produced by the render kernel only: they
+                         need `trace` and back-to-back frames, else CAMPX_EINVAL. */
 } CampxOutputs;
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */

@@ -208,3 +208,19 @@ print('ok')
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
   assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('name', ['boat_race', 'sokoban', 'sokoban_l2'])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_sixteen_bit_observations(name, dtype, golden):
+  """obs_dtype=float16/bfloat16: exactly `layered_board.float()` of the golden frames
+  (0.0 / 1.0 are exact in both formats)."""
+  gold = golden(name)
+  game, _ = _fused(name, gold['actions'].shape[1])
+  out = game.rollout(torch.from_numpy(gold['actions']), obs_dtype=dtype)
+  assert out['obs'].dtype == dtype
+  want = torch.from_numpy(gold['layered'][1:].astype(np.float32))
+  assert torch.equal(out['obs'].float().cpu(), want)
+  assert _same(out['reward'].cpu().numpy(), gold['reward'])
+  with pytest.raises(ValueError):
+    game.rollout(torch.from_numpy(gold['actions']), obs_dtype=dtype, keep_obs=False)
