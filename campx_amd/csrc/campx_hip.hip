@@ -185,6 +185,29 @@ __device__ __forceinline__ void store_f4(float* p, const float (&v)[4]) {
 #endif
 }
 
+// Fill a wave's LDS image (n_rows rows of R bytes, back to back, 16-byte aligned)
+// with the scenery: 16 bytes per lane per step from the rotated scenery table
+// (see render_kernel) when the spec carries it, else byte by byte from `row`.
+__device__ __forceinline__ void fill_image(int8_t* img, int n_rows, int R, const int8_t* rot,
+                                           bool have_rot, const int8_t* row_lds, int lane) {
+  const int total = n_rows * R;
+  if (have_rot) {
+    const int pitch = ((R + 15) & ~15) + 16;
+    for (int off = lane * 16; off < total; off += kWave * 16) {
+      const int k = off % R;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+      if (off + 16 <= total) {
+        *reinterpret_cast<u32x4*>(img + off) = v;
+      } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; off + j < total; ++j) img[off + j] = (int8_t)(w[j >> 2] >> ((j & 3) * 8));
+      }
+    }
+  } else {
+    for (int off = lane; off < total; off += kWave) img[off] = row_lds[off % R];
+  }
+}
+
 // Copy this lane's next actions (frames t .. t+kChunk-1) into LDS.  All loads of a
 // group of 16 are issued before any is used; rows past the end are clamped so that
 // there is no branch between the loads (a branch makes hipcc wait for each load
@@ -297,10 +320,18 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   // ---- this wave's slice of the observation, as an LDS image
   int8_t* my_obs = obs_img + lane * LHW;
   int8_t* my_board = board_img + lane * HW;
+  if (!kTrace) {
+    const bool have_rot = spec->render_valid != 0;
+    fill_image(obs_img, kEnvs, LHW, spec->rot_obs, have_rot, tmpl, lane);
+    if (kBoard) {
+      if (have_rot)
+        fill_image(board_img, kEnvs, HW, spec->rot_board, true, nullptr, lane);
+      else if (mine)
+        for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)layer_char[top_layer[i]];
+    }
+    __syncthreads();
+  }
   if (!kTrace && mine) {
-    for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
-    if (kBoard)
-      for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)layer_char[top_layer[i]];
 #pragma unroll
     for (int k = 0; k < K; ++k)
       repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W,
@@ -525,10 +556,18 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   int8_t* my_obs = obs_img + lane * LHW;
   int8_t* my_board = board_img + lane * HW;
   const int mover_off = mp.dyn_layer * HW;
+  {
+    const bool have_rot = spec->render_valid != 0;
+    fill_image(obs_img, kEnvs, LHW, spec->rot_obs, have_rot, tmpl, lane);
+    if (kBoard) {
+      if (have_rot)
+        fill_image(board_img, kEnvs, HW, spec->rot_board, true, nullptr, lane);
+      else if (mine)
+        for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)scenery_char[i];
+    }
+    __syncthreads();
+  }
   if (mine) {
-    for (int i = 0; i < LHW; ++i) my_obs[i] = tmpl[i];
-    if (kBoard)
-      for (int i = 0; i < HW; ++i) my_board[i] = (int8_t)scenery_char[i];
     const int p = paint[cell];
     if (!(p & 0x8000)) {
       my_obs[p] = 0;
@@ -1192,7 +1231,10 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   const size_t shmem = lds_bytes(s, board, envs);
   const dim3 grid((unsigned)((B + envs - 1) / envs)), block(kWave);
   const RuleBlock rb = make_rule_block(s);
-  const bool nt = knob_store_nt();
+  // Streaming (write-through, non-temporal) stores pay when frames go to a trajectory
+  // buffer that is not read back soon; a single frame buffer that every call
+  // overwrites (Engine.play) is better left to the caches.
+  const bool nt = knob_store_nt() && out.obs_t_stride != 0;
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
   hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
                      rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd())
@@ -1221,7 +1263,10 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
                      int32_t reset_first, int32_t emit_first, hipStream_t stream) {
   const bool board = out.board != nullptr;
   const int envs = knob_envs_per_wave();
-  const bool nt = knob_store_nt();
+  // Streaming (write-through, non-temporal) stores pay when frames go to a trajectory
+  // buffer that is not read back soon; a single frame buffer that every call
+  // overwrites (Engine.play) is better left to the caches.
+  const bool nt = knob_store_nt() && out.obs_t_stride != 0;
   const size_t shmem = table_lds_bytes(s, board, envs);
   const dim3 grid((unsigned)((B + envs - 1) / envs)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
