@@ -224,3 +224,36 @@ def test_sixteen_bit_observations(name, dtype, golden):
   assert _same(out['reward'].cpu().numpy(), gold['reward'])
   with pytest.raises(ValueError):
     game.rollout(torch.from_numpy(gold['actions']), obs_dtype=dtype, keep_obs=False)
+
+
+def test_very_long_rollout_falls_back_to_the_fused_kernel():
+  """T > 65 535 frames cannot be a render-kernel grid dimension: the launch takes the
+  single-kernel path and must still be exact (also crosses many 64-frame action chunks)."""
+  T, B = 66000, 16
+  rng = np.random.RandomState(5)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  game, _ = _fused('boat_race', B)
+  out = game.rollout(torch.from_numpy(actions), reset_first=True)
+  og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES['boat_race']()))
+  ref = og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
+  assert _same(out['reward'].cpu().numpy(), ref['reward'])
+  assert _same(out['perf'].cpu().numpy(), ref['perf'])
+  assert _same(out['obs'][-1].cpu().numpy(), ref['obs'])
+  sums = out['obs'].sum(dim=2, dtype=torch.int32)
+  assert int(sums.min()) == 1 and int(sums.max()) == 1
+
+
+def test_unvalidated_out_of_range_actions_mean_stay():
+  """With validation off the kernels treat ids outside 0..4 as 4 (stay), as the header says."""
+  game_a, _ = _fused('sokoban', 256)
+  game_b, _ = _fused('sokoban', 256)
+  game_a.fused.validate_actions = game_b.fused.validate_actions = False
+  rng = np.random.RandomState(9)
+  acts = rng.randint(0, 5, size=(40, 256)).astype(np.int8)
+  weird = acts.copy()
+  stay = acts == 4
+  weird[stay] = rng.choice([5, 9, 127, -1, -128], size=int(stay.sum())).astype(np.int8)
+  a = game_a.rollout(torch.from_numpy(acts), want_board=True)
+  b = game_b.rollout(torch.from_numpy(weird), want_board=True)
+  assert torch.equal(a['obs'], b['obs']) and torch.equal(a['reward'], b['reward'])
+  assert torch.equal(a['done'], b['done']) and torch.equal(a['board'], b['board'])
