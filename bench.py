@@ -49,8 +49,8 @@ WORKLOADS = {
 def parse_args():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=20)
-  p.add_argument('--warmup', type=int, default=3)
+  p.add_argument('--steps', type=int, default=30)
+  p.add_argument('--warmup', type=int, default=5)
   p.add_argument('--game', default='boat_race', choices=sorted(WORKLOADS))
   p.add_argument('--batch', type=int, default=None,
                  help='environments per GPU (default: the BASELINE config)')
