@@ -135,10 +135,6 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
-    # 256 KiB-per-rank messages are latency-bound: two channels are plenty and keep
-    # the collective's workgroups from occupying compute units the rollout needs.
-    os.environ.setdefault('NCCL_MAX_NCHANNELS', '2')
-    os.environ.setdefault('NCCL_MIN_NCHANNELS', '1')
     dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
 
   from campx_amd import games
