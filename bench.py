@@ -2,8 +2,13 @@
 """Headline benchmark: env-steps/sec, boat race 5x5, 65 536 environments per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+With N > 1 (and no WORLD_SIZE in the environment) this process starts N child
+ranks itself - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py ...` - BEFORE anything touches the
+GPU, relays their output and exits with their return code.  Started under
+torch.distributed.run directly it is one of those ranks (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment).
 
 One "step" of this bench = one pass of the hot path over one batch of synthetic
 input = ONE rollout launch: an episode of `--frames` (default 100, the
@@ -11,29 +16,27 @@ reference's episode length, examples/reinforce.py:36) consecutive Engine.play()
 frames for every environment of the rank's shard, rebuilt from the art at the
 start (make_game() per episode, reinforce.py:122), on a committed-seed random
 action stream already resident in HBM.  Every frame's layered board
-[B, L, H, W] int8, reward, discount and done flag are written to HBM
-(trajectory buffers [T, B, ...]), nothing is skipped or cached.
+[B, L, H, W] int8, reward, discount, done flag and hidden performance are written
+to HBM (trajectory buffers [T, B, ...]), nothing is skipped or cached.
 
 Multi-GPU: environments are independent, so the batch is sharded (weak scaling:
-65 536 per rank) with NO collective on the step path; after each episode the
-ranks all-gather their per-environment episode returns over RCCL for logging, on
-a side stream.
+65 536 per rank) with NO collective on the step path; the ranks all-gather their
+per-environment episode returns over RCCL for logging, off the step path.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
   sys.path.insert(0, REPO)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 # Algorithmic bytes per env-step, SURVEY.md section 8(d):
@@ -44,9 +47,11 @@ WORKLOADS = {
     'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
     'sokoban': ('side_effects_sokoban 6x6 (build-authored level 0)', 131072),
 }
+HEADLINE_METRIC = 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X'
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_traffic.json')
 
 
-def parse_args():
+def parse_args(argv=None):
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
   p.add_argument('--steps', type=int, default=30)
@@ -57,15 +62,51 @@ def parse_args():
   p.add_argument('--frames', type=int, default=100,
                  help='Engine.play() frames per launch (episode length)')
   p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--no-extras', action='store_true',
+                 help='skip play()-mode and the wall_world / sokoban side measurements')
   p.add_argument('--gather-every', type=int, default=8,
                  help='episodes per RCCL all-gather of the episode-return log')
   p.add_argument('--force-dist', action='store_true',
-                 help='initialise torch.distributed (RCCL) and run the episode-return '
+                 help='go through the multi-rank launcher and the RCCL episode-return '
                       'all-gather even with one rank (smoke test of the N>1 path)')
   p.add_argument('--cpu-seconds', type=float, default=12.0,
                  help='target duration of the CPU baseline sample')
-  return p.parse_args()
+  p.add_argument('--standin', default=None,
+                 help='TESTS ONLY: "module:function" building a CPU stand-in for the '
+                      'batched engine; ranks then use gloo and no GPU, and the line is '
+                      'marked as a dry run (tests/test_bench_launcher.py)')
+  return p.parse_args(argv)
 
+
+# ------------------------------------------------------------------- launcher
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+  """Start `n` ranks of this script under torch.distributed.run; return their rc.
+
+  Called before this process has made any GPU call (nothing may exec or fork a
+  GPU-initialised process on this pool); the children are ordinary subprocesses
+  and their stdout (rank 0's JSON line) is relayed line by line.
+  """
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+         '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env.setdefault('OMP_NUM_THREADS', '1')
+  proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+  for line in proc.stdout:
+    sys.stdout.write(line)
+    sys.stdout.flush()
+  return proc.wait()
+
+
+# ------------------------------------------------------------ CPU baselines
 
 def cpu_baseline(game_name, frames, seconds):
   """Time the CPU oracle (a port, not the reference) on a bounded sample.
@@ -74,6 +115,7 @@ def cpu_baseline(game_name, frames, seconds):
   shape, capped at 65 536 environments), with `n` chosen from a short calibration
   run so that the timed part takes about `seconds`.
   """
+  import numpy as np
   from campx_amd import games, gamespec
   from oracle import cpu as oracle_cpu
   build = getattr(games, game_name).build
@@ -91,9 +133,8 @@ def cpu_baseline(game_name, frames, seconds):
   for _ in range(episodes):
     og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
   dt = time.perf_counter() - t0
-  actions = np.broadcast_to(actions, (episodes,) + actions.shape)
   return {
-      'value': actions.size / dt, 'unit': 'env-steps/s', 'cores': cores,
+      'value': episodes * actions.size / dt, 'unit': 'env-steps/s', 'cores': cores,
       'kind': 'port',
       'sample': '{} episodes x {} environments x {} frames of the same game and '
                 'action distribution, oracle/campx_oracle.c (every frame rendered) '
@@ -102,93 +143,125 @@ def cpu_baseline(game_name, frames, seconds):
   }
 
 
+def generic_b1(seconds=3.0):
+  """This repo's generic tier (Python update() bodies, torch CPU ops, B = 1).
+
+  The execution model of the reference itself (campx/engine.py:114-324), on this
+  host: the number to hold against the reference's own 955 env-steps/s
+  (measured in the build container).
+  """
+  import torch
+  from campx_amd.games import boat_race
+  torch.set_num_threads(1)
+  game, _, _, _ = boat_race.make_game()
+  acts = [torch.nn.functional.one_hot(torch.tensor(a), 5).float()
+          for a in (1, 1, 3, 3, 0, 0, 2, 2)]
+  for i in range(20):
+    game.play(acts[i % 8])
+  n, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < seconds:
+    for i in range(50):
+      game.play(acts[i % 8])
+    n += 50
+  dt = time.perf_counter() - t0
+  return {'value': n / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+          'sample': '{} Engine.play() calls of the boat race on the generic tier '
+                    '(batch=None), one-hot actions, {:.1f} s'.format(n, dt)}
+
+
+# -------------------------------------------------------------- measurements
+
 def measured_traffic(game, batch, frames, path):
   """HBM bytes per launch from the committed rocprofv3 PMC passes, or None.
 
   bench.py cannot run the profiler on itself; the figure comes from
-  profiles/r01_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
+  profiles/r02_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
   command) and is only reported for the exact configuration it was measured on.
   """
   try:
-    with open(os.path.join(REPO, 'profiles', 'r01_traffic.json')) as f:
+    with open(TRAFFIC_FILE) as f:
       table = json.load(f)
     return table['{}:{}:{}:{}'.format(game, batch, frames, path)]['traffic_bytes']
   except (OSError, KeyError, ValueError):
     return None
 
 
-def main():
-  args = parse_args()
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      sys.exit('bench.py --gpus {} must be launched with torch.distributed.run '
-               '--nproc-per-node {}'.format(args.gpus, args.gpus))
-    args.gpus = world
-  assert torch.cuda.is_available(), 'bench.py needs a HIP device'
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
-  dist = None
-  if world > 1 or args.force_dist:
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+def kernel_names(fused, split):
+  if split:
+    first = ('update_table_kernel' if fused.n_dyn == 1 else
+             'update_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
+             'rollout_kernel<trace>')
+    return first + ' + render_kernel'
+  return ('rollout_table_kernel' if fused.n_dyn == 1 and fused.uses_table
+          else 'rollout_kernel')
 
-  from campx_amd import games
-  from campx_amd.distributed import ReturnLog
 
-  name, default_batch = WORKLOADS[args.game]
-  B = args.batch or default_batch
-  T = args.frames
-  game = getattr(games, args.game).build(batch=B, device=device)
+def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_every,
+                    standin=None):
+  """Warm up, then time exactly `steps` rollout launches.  Returns a dict.
+
+  Wall clock: perf_counter around the timed region, bracketed by synchronize +
+  barrier on both sides.  Kernel time: ONE pair of HIP events on the launch stream
+  around the same `steps` launches (mean per launch, inter-launch gaps included), so
+  the timed region carries no per-launch event packets.  A second, untimed pass of
+  the same launches with an event pair per launch gives the median / min / max.
+  """
+  import numpy as np
+  import torch
+  on_gpu = standin is None
+  if on_gpu:
+    from campx_amd import games
+    game = getattr(games, game_name).build(batch=B, device=device)
+  else:
+    game = standin(game_name, B)
   game.its_showtime()
   fused = game.fused
-  fused.validate_actions = False      # no host sync inside the timed region
-  L, H, W = fused.n_layers, fused.rows, fused.cols
+  fused.validate_actions = False      # no host read-back inside the timed region
 
   # Synthetic actions: host RNG (so a CPU run can consume the same stream),
   # uploaded once, before the timed region.
   gen = torch.Generator(device='cpu').manual_seed(0xC0FFEE + rank)
   streams = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8)
              .to(device) for _ in range(2)]
-  obs = torch.empty((T, B, L, H, W), dtype=torch.int8, device=device)
-  # Episode returns are logged per rank and all-gathered over RCCL every
-  # `--gather-every` episodes (campx_amd.distributed.ReturnLog): the kernel
-  # accumulates each episode's returns straight into its row of the log, so nothing
-  # but the rollout kernel ever runs on the rollout's stream.
-  log = ReturnLog(B, args.gather_every, device, dist) if dist is not None else None
+  # Output buffers are allocated once; a step is then a single op dispatch.
+  bufs = fused.rollout_buffers(T)
+  log = None
+  if dist is not None:
+    # Episode returns are logged per rank and all-gathered every `gather_every`
+    # episodes (campx_amd.distributed.ReturnLog): the kernel accumulates each
+    # episode's returns straight into its row of the log, so nothing but the
+    # rollout kernels ever runs on the rollout's stream.
+    from campx_amd.distributed import ReturnLog
+    log = ReturnLog(B, gather_every, device, dist)
 
   def one_step(i):
     if log is not None:
       fused.ret = log.row()
-    out = fused.rollout(streams[i & 1], obs=obs, reset_first=True)
+    out = fused.rollout(streams[i & 1], out=bufs, reset_first=True)
     if log is not None:
       log.episode_done()
     return out
 
   def fence():
-    torch.cuda.synchronize(device)
+    if on_gpu:
+      torch.cuda.synchronize(device)
     if dist is not None:
       dist.barrier()
-      torch.cuda.synchronize(device)
+      if on_gpu:
+        torch.cuda.synchronize(device)
 
-  for i in range(args.warmup):
+  for i in range(warmup):
     one_step(i)
   fence()
-  starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-  stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+  if on_gpu:
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()                      # torch's current stream = the launch stream
   t0 = time.perf_counter()
-  for i in range(args.steps):
-    starts[i].record()               # torch's current stream = the launch stream
-    if log is not None:
-      fused.ret = log.row()
-    out = fused.rollout(streams[i & 1], obs=obs, reset_first=True)
-    stops[i].record()
-    if log is not None:
-      log.episode_done()
+  for i in range(steps):
+    out = one_step(i)
+  if on_gpu:
+    ev1.record()
   if log is not None:
     log.wait()
   fence()
@@ -198,25 +271,122 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, stops)]
-  kernel_s = float(np.mean(kernel_ms)) / 1e3
-  mean_return = float(out['reward'].sum(0).mean())
+  result = dict(fused=fused, elapsed=elapsed, log=log, out=out,
+                mean_return=float(out['reward'].sum(0).mean())
+                if out['reward'] is not None else None)
+  if on_gpu:
+    result['kernel_ms'] = ev0.elapsed_time(ev1) / steps
+    # untimed second pass: one event pair per launch
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    for i in range(steps):
+      starts[i].record()
+      one_step(i)
+      stops[i].record()
+    if log is not None:
+      log.wait()
+    fence()
+    per = [s.elapsed_time(e) for s, e in zip(starts, stops)]
+    result['per_launch_ms'] = {'median': float(np.median(per)), 'min': float(min(per)),
+                               'max': float(max(per)), 'mean': float(np.mean(per))}
+  return result
+
+
+def roofline(game_name, B, T, fused, kernel_ms, per_launch):
+  from campx_amd import fused as fused_mod
+  bytes_per_launch = BYTES_PER_ENV_STEP[game_name] * B * T
+  achieved = bytes_per_launch / (kernel_ms / 1e3) / 1e9
+  split = fused_mod.SPLIT_ROLLOUT and (fused.uses_table or fused_mod.FORCE_SPLIT)
+  traffic = measured_traffic(game_name, B, T, 'split' if split else 'fused')
+  return {
+      'bound': 'hbm',
+      'achieved': achieved,
+      'peak': HBM_PEAK_GBS,
+      'unit': 'GB/s',
+      'frac': achieved / HBM_PEAK_GBS,
+      'traffic': traffic,
+      'traffic_note': 'HBM bytes per launch (WRITE_SIZE + FETCH_SIZE, separate '
+                      'rocprofv3 --pmc passes, profiles/r02_traffic.json)',
+      'kernel': kernel_names(fused, split),
+      'kernel_note': 'kernel_ms = HIP-event time around the timed launches / steps: '
+                     'every kernel of a rollout launch plus the gaps between launches',
+      'kernel_ms': kernel_ms,
+      'per_launch_ms': per_launch,
+      'bytes_per_env_step': BYTES_PER_ENV_STEP[game_name],
+      'bytes_per_launch': bytes_per_launch,
+  }
+
+
+def play_mode(device, B=65536, calls=2000):
+  """Engine.play() per frame (one launch per frame, state round-trips HBM)."""
+  import torch
+  from campx_amd.games import boat_race
+  game, _, _, _ = boat_race.make_game(batch=B, device=device)
+  acts = torch.randint(0, 5, (64, B), dtype=torch.int8, device=device)
+  rows = [acts[i] for i in range(64)]
+  modes = {}
+  for name, validate in (('validate_lazy', True), ('validate_off', False),
+                         ('validate_sync', 'sync')):
+    game.fused.validate_actions = validate
+    for i in range(50):
+      game.play(rows[i & 63])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(calls):
+      game.play(rows[i & 63])
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / calls
+    modes[name] = {'us_per_call': dt * 1e6, 'env_steps_per_s': B / dt}
+  return {'workload': 'boat_race 5x5, batch={}, Engine.play() per frame through '
+                      'campx::step, {} calls'.format(B, calls), **modes}
+
+
+def run_rank(args):
+  import torch
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  standin = None
+  if args.standin:
+    import importlib
+    mod, fn = args.standin.split(':')
+    standin = getattr(importlib.import_module(mod), fn)
+    device = torch.device('cpu')
+  else:
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+  dist = None
+  if world > 1 or args.force_dist:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(_free_port()))
+    if standin is not None:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+      dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+    world = dist.get_world_size()      # as the process group reports it
+
+  name, default_batch = WORKLOADS[args.game]
+  B = args.batch or default_batch
+  T = args.frames
+  m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
+                      args.gather_every, standin)
+  fused, elapsed = m['fused'], m['elapsed']
+
+  gathered_ok = None
+  if m['log'] is not None:
+    block = m['log'].wait()            # [world, episodes, B] of the last full block
+    if block is not None:
+      mine = m['log']._log[m['log']._last]
+      gathered_ok = bool(block.shape[0] == world and torch.equal(block[rank], mine))
 
   if rank == 0:
     env_steps = B * T * args.steps * world
-    bytes_per_launch = BYTES_PER_ENV_STEP[args.game] * B * T
-    achieved = bytes_per_launch / kernel_s / 1e9
-    from campx_amd import fused as fused_mod
-    split = fused_mod.SPLIT_ROLLOUT and (fused.uses_table or fused_mod.FORCE_SPLIT)
-    traffic = measured_traffic(args.game, B, T, 'split' if split else 'fused')
-    if split:
-      kernels = ('trace_table_kernel' if fused.n_dyn == 1 else
-                 'trace_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
-                 'rollout_kernel<trace>') + ' + render_kernel'
-    else:
-      kernels = 'rollout_table_kernel' if fused.n_dyn == 1 and fused.uses_table else 'rollout_kernel'
+    headline = args.game == 'boat_race' and B == 65536
     line = {
-        'metric': 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X',
+        'metric': HEADLINE_METRIC if headline else
+                  'env-steps/sec at batch={}, {}, 1/2/4/8 MI355X'.format(B, name),
         'value': env_steps / elapsed,
         'unit': 'env-steps/s',
         'n_gpus': world,
@@ -227,43 +397,71 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': 'int8',
-        'data': 'synthetic',
+        'data': 'synthetic' if standin is None else
+                'synthetic; CPU STAND-IN DRY RUN of the launcher, not a measurement',
         'config': {
             'workload': '{}, batch={} per GPU, random actions'.format(name, B),
             'global_batch': B * world,
             'frames_per_step': T,
             'step': 'one rollout launch = one {}-frame episode for every '
                     'environment, all frames written to HBM'.format(T),
-            'parallelism': 'env-sharded x{}, RCCL all-gather of the episode-'
+            'parallelism': 'env-sharded x{}, {} all-gather of the episode-'
                            'return log every {} episodes, off the step path'
-                           .format(world, args.gather_every)
-                           if world > 1 else 'single GPU',
-            'mean_episode_return': mean_return,
-        },
-        'roofline': {
-            'bound': 'hbm',
-            'achieved': achieved,
-            'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS,
-            'traffic': traffic / 1e9 / kernel_s if traffic else None,
-            'traffic_bytes_per_launch': traffic,
-            'kernel': kernels,
-            'kernel_note': 'kernel_ms spans every kernel of one rollout launch '
-                           '(events on the launch stream around the call)',
-            'kernel_ms': kernel_s * 1e3,
-            'bytes_per_env_step': BYTES_PER_ENV_STEP[args.game],
-            'bytes_per_launch': bytes_per_launch,
+                           .format(world, 'gloo' if standin else 'RCCL',
+                                   args.gather_every)
+                           if dist is not None else 'single GPU',
+            'world': world,
+            'gathered_log_matches_local': gathered_ok,
+            'mean_episode_return': m['mean_return'],
         },
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if standin is None:
+      line['roofline'] = roofline(args.game, B, T, fused, m['kernel_ms'],
+                                  m['per_launch_ms'])
+    solo = world == 1 and standin is None and dist is None
+    if solo and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds)
+      line['cpu_baseline']['generic_b1'] = generic_b1()
+      line['cpu_baseline']['reference_b1_build_container'] = {
+          'value': 954.8, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference',
+          'sample': 'the reference itself, boat race B=1, measured in the build '
+                    'container (BASELINE.md section 2); it cannot run on the GPU box'}
     else:
       line['cpu_baseline'] = None
-    print(json.dumps(line))
+    if solo and not args.no_extras and headline:
+      del m
+      torch.cuda.empty_cache()
+      line['play_mode'] = play_mode(device)
+      also = []
+      for other in ('wall_world', 'sokoban'):
+        oname, ob = WORKLOADS[other]
+        steps = max(5, args.steps // 3)
+        om = measure_rollout(other, ob, T, steps, 3, device, 0, None, 0)
+        also.append({
+            'workload': '{}, batch={}, random actions, {} frames per launch'.format(
+                oname, ob, T),
+            'value': ob * T * steps / om['elapsed'], 'unit': 'env-steps/s',
+            'steps': steps, 'ms_per_step': om['elapsed'] / steps * 1e3,
+            'roofline': roofline(other, ob, T, om['fused'], om['kernel_ms'],
+                                 om['per_launch_ms'])})
+        del om
+        torch.cuda.empty_cache()
+      line['also'] = also
+    print(json.dumps(line), flush=True)
   if dist is not None:
+    dist.barrier()
     dist.destroy_process_group()
 
 
+def main(argv=None):
+  argv = sys.argv[1:] if argv is None else argv
+  args = parse_args(argv)
+  if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_dist):
+    # Not under a launcher yet: become one.  No GPU call has happened in this process.
+    return launch_ranks(args.gpus, argv)
+  run_rank(args)
+  return 0
+
+
 if __name__ == '__main__':
-  main()
+  sys.exit(main())

@@ -1,7 +1,15 @@
-"""ctypes binding of libcampx_hip.so (the C ABI in include/campx_hip.h).
+"""Bindings of the native code: libcampx_hip.so and libcampx_torch.so.
 
-Importing this module loads the library and fails loudly if it has not been
-built: there is no CPU fallback for the fused tier.
+* `lib` is the ctypes binding of the C ABI in include/campx_hip.h.  The fused tier
+  uses it at set-up time (spec validation / compilation, error strings); the
+  per-frame entry points are bound too, as the stub INTEGRATION.md shows a CampX
+  maintainer, and tests call them directly.
+* `ops` is `torch.ops.campx` after loading libcampx_torch.so: the custom ops
+  `campx::reset / step / rollout / onehot_to_ids / check_actions` that
+  `Engine.its_showtime() / play() / rollout()` lower to (csrc/campx_torch.cpp).
+
+Importing this module loads both and fails loudly if either has not been built:
+there is no CPU fallback for the fused tier.
 """
 
 import ctypes
@@ -30,7 +38,8 @@ class CampxOutputs(ctypes.Structure):
               ('board', ctypes.c_void_p), ('board_t_stride', ctypes.c_int64),
               ('reward', ctypes.c_void_p), ('discount', ctypes.c_void_p),
               ('done', ctypes.c_void_p), ('perf', ctypes.c_void_p),
-              ('trace', ctypes.c_void_p), ('obs_format', ctypes.c_int32)]
+              ('trace', ctypes.c_void_p), ('obs_format', ctypes.c_int32),
+              ('bad_count', ctypes.c_void_p), ('bad_flag', ctypes.c_void_p)]
 
 
 class CampxError(RuntimeError):
@@ -78,6 +87,22 @@ def _load():
 
 
 lib = _load()
+
+_OPS_PATH = os.path.join(os.path.dirname(_LIB_PATH), 'libcampx_torch.so')
+
+
+def _load_ops():
+  if not os.path.exists(_OPS_PATH):
+    raise ImportError(
+        '{} is missing: build it with `python -m campx_amd.build` (needs hipcc '
+        'and torch). The fused tier has no CPU fallback.'.format(_OPS_PATH))
+  import torch
+  torch.ops.load_library(_OPS_PATH)
+  return torch.ops.campx
+
+
+ops = _load_ops()
+OP_NAMES = ('reset', 'step', 'rollout', 'onehot_to_ids', 'check_actions')
 
 
 def check(code, what):

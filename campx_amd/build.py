@@ -1,9 +1,13 @@
-"""Compile the HIP library in-tree: campx_amd/csrc/libcampx_hip.so (gfx950 only).
+"""Compile the native code in-tree (gfx950 only):
 
-    python -m campx_amd.build
+    campx_amd/csrc/libcampx_hip.so    kernels + the C ABI (include/campx_hip.h)
+    campx_amd/csrc/libcampx_torch.so  the torch custom ops campx::step / rollout / ...
+                                      (csrc/campx_torch.cpp), linked against the former
 
-hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the
-working tree to the GPU box.
+    python -m campx_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so files are git-ignored but travel with
+the working tree to the GPU box.
 """
 
 import os
@@ -49,5 +53,37 @@ def build_hip(force=False, verbose=False):
   return OUT
 
 
+TORCH_SRC = os.path.join(HERE, 'csrc', 'campx_torch.cpp')
+TORCH_OUT = os.path.join(HERE, 'csrc', 'libcampx_torch.so')
+
+
+def build_torch_ops(force=False, verbose=False):
+  """Build libcampx_torch.so (TORCH_LIBRARY registration of the campx:: ops)."""
+  build_hip(force=False, verbose=verbose)
+  if (not force and os.path.exists(TORCH_OUT) and os.path.getmtime(TORCH_OUT) >= max(
+      os.path.getmtime(TORCH_SRC), os.path.getmtime(OUT),
+      os.path.getmtime(os.path.join(INCLUDE, 'campx_hip.h')))):
+    return TORCH_OUT
+  import torch
+  tdir = os.path.dirname(os.path.abspath(torch.__file__))
+  cmd = [find_hipcc(), '-O2', '-std=c++17', '-shared', '-fPIC', '-DUSE_ROCM',
+         '-Wno-unused-result',
+         '-D_GLIBCXX_USE_CXX11_ABI={}'.format(int(torch._C._GLIBCXX_USE_CXX11_ABI)),
+         '-I', INCLUDE, '-I', os.path.join(tdir, 'include'),
+         '-I', os.path.join(tdir, 'include', 'torch', 'csrc', 'api', 'include'),
+         TORCH_SRC, '-L', os.path.join(tdir, 'lib'), '-lc10', '-ltorch_cpu', '-ltorch',
+         '-lc10_hip', '-ltorch_hip', '-L', os.path.join(HERE, 'csrc'), '-lcampx_hip',
+         '-Wl,-rpath,$ORIGIN', '-o', TORCH_OUT + '.tmp']
+  if verbose:
+    print(' '.join(cmd))
+  subprocess.run(cmd, check=True)
+  os.replace(TORCH_OUT + '.tmp', TORCH_OUT)
+  return TORCH_OUT
+
+
+def build_all(force=False, verbose=False):
+  return build_hip(force, verbose), build_torch_ops(force, verbose)
+
+
 if __name__ == '__main__':
-  print(build_hip(force='--force' in sys.argv, verbose=True))
+  print(build_all(force='--force' in sys.argv, verbose=True))

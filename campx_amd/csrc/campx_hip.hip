@@ -17,7 +17,7 @@
 //   rollout_table_kernel  same, for games with one moving thing: the update pass is a
 //                         lookup in a (cell, action) table that campx_spec_compile()
 //                         fills by running rollout_kernel over every pair.
-//   trace_table_kernel    the update pass alone (producer wave + consumer waves),
+//   update_*_kernel       the update pass alone (producer, consumer and loader waves),
 //   render_kernel         and the observation stream alone: one-shot blocks, every
 //                         wave one aligned KiB store - the store pattern that reaches
 //                         the chip's HBM write ceiling.  The default for rollouts of
@@ -58,11 +58,11 @@ __device__ __forceinline__ void store16_streaming(u32x4* p, u32x4 v) {
 #if CAMPX_NT_FLAVOR == 1
   __builtin_nontemporal_store(v, p);
 #elif CAMPX_NT_FLAVOR == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #elif CAMPX_NT_FLAVOR == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #endif
 }
 
@@ -121,9 +121,10 @@ __device__ __forceinline__ int class_progress(int from, int to, int n) {
   return (to == fwd) - (to == back);
 }
 
-// Trace entry of one moving thing at one frame (CampxOutputs.trace).
-__device__ __forceinline__ uint32_t pack_trace(int set_off, int clear_off, int cell, uint32_t vis) {
-  return (uint32_t)set_off | ((uint32_t)clear_off << 11) | ((uint32_t)cell << 22) | (vis << 29);
+// Trace entry of one moving thing at one frame (CampxOutputs.trace): the cell it is in
+// and whether it is the character that cell shows.
+__device__ __forceinline__ uint8_t pack_trace(int cell, uint32_t vis) {
+  return (uint8_t)((uint32_t)cell | (vis << 7));
 }
 
 // Cyclic one-cell move: 0 left (col-1), 1 right, 2 up (row-1), 3 down, else stay
@@ -213,10 +214,11 @@ __device__ __forceinline__ void fill_image(int8_t* img, int n_rows, int R, const
 // there is no branch between the loads (a branch makes hipcc wait for each load
 // before issuing the next: 64 serial HBM round trips per chunk).
 template <int kLanes>
-__device__ __forceinline__ void stage_actions(int8_t* staged, const int8_t* __restrict__ actions,
-                                              int64_t B, int32_t T, int t, int64_t env, bool live,
-                                              int lane) {
+__device__ __forceinline__ int stage_actions(int8_t* staged, const int8_t* __restrict__ actions,
+                                             int64_t B, int32_t T, int t, int64_t env, bool live,
+                                             int lane) {
   const int64_t col = live ? env : 0;  // any valid column
+  int bad = 0;  // ids outside 0..4 among this lane's real (unclamped) rows
   if (T - t >= 16) {
     const int n = (T - t < kChunk) ? T - t : kChunk;
     for (int r0 = 0; r0 < n; r0 += 16) {
@@ -228,11 +230,28 @@ __device__ __forceinline__ void stage_actions(int8_t* staged, const int8_t* __re
         v[j] = actions[(int64_t)row * B + col];
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) staged[(r0 + j) * kLanes + lane] = live ? v[j] : (int8_t)4;
+      for (int j = 0; j < 16; ++j) {
+        staged[(r0 + j) * kLanes + lane] = live ? v[j] : (int8_t)4;
+        bad += (live && t + r0 + j < T && (unsigned)v[j] > 4u) ? 1 : 0;
+      }
     }
   } else {
-    for (int r = 0; r < T - t; ++r)
-      staged[r * kLanes + lane] = live ? actions[(int64_t)(t + r) * B + col] : (int8_t)4;
+    for (int r = 0; r < T - t; ++r) {
+      const int8_t v = live ? actions[(int64_t)(t + r) * B + col] : (int8_t)4;
+      staged[r * kLanes + lane] = v;
+      bad += ((unsigned)v > 4u) ? 1 : 0;
+    }
+  }
+  return bad;
+}
+
+// Ids outside 0..4 act as 4 (stay); the kernel that read them says so here (see
+// CampxOutputs.bad_count / bad_flag) instead of a separate checking launch.
+__device__ __forceinline__ void report_bad_actions(const CampxOutputs& out, int bad) {
+  if (bad) {
+    if (out.bad_count) atomicAdd(out.bad_count, bad);
+    if (out.bad_flag)
+      __hip_atomic_store(out.bad_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -338,6 +357,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
                               pos.r[k] * W + pos.c[k], pos);
   }
   Things<K> img = pos;  // positions the image currently shows
+  int bad = 0;
 
   if (!kTrace && emit_first) {
     __syncthreads();
@@ -348,7 +368,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   for (int t = 0; t < T; ++t) {
     const int in_chunk = t & (kChunk - 1);
     if (in_chunk == 0 && mine)  // each lane stages its own environment's next actions
-      stage_actions<kEnvs>(staged, actions, B, T, t, env, live, lane);
+      bad += stage_actions<kEnvs>(staged, actions, B, T, t, env, live, lane);
     int a = mine ? staged[in_chunk * kEnvs + lane] : 4;
     a = ((unsigned)a > 4u) ? 4 : a;
 
@@ -447,8 +467,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
         for (int k = 0; k < K; ++k) {
           const int cell = pos.r[k] * W + pos.c[k];
           const uint32_t vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
-          out.trace[((int64_t)k * T + t) * B + env] =
-              pack_trace(rb.dyn_layer[k] * HW + cell, top_layer[cell] * HW + cell, cell, vis);
+          out.trace[((int64_t)k * T + t) * B + env] = pack_trace(cell, vis);
         }
       }
     } else {
@@ -489,6 +508,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
+  report_bad_actions(out, bad);
 }
 
 
@@ -576,6 +596,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     }
   }
   int shown_at = cell;  // where the image shows the mover
+  int bad = 0;
 
   if (emit_first) {
     __syncthreads();
@@ -585,7 +606,8 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
 
   for (int t = 0; t < T; ++t) {
     const int in_chunk = t & (kChunk - 1);
-    if (in_chunk == 0 && mine) stage_actions<kEnvs>(staged, actions, B, T, t, env, live, lane);
+    if (in_chunk == 0 && mine)
+      bad += stage_actions<kEnvs>(staged, actions, B, T, t, env, live, lane);
     int a = mine ? staged[in_chunk * kEnvs + lane] : 4;
     a = ((unsigned)a > 4u) ? 4 : a;
     if (over) {  // rebuilt from the art before its next action
@@ -636,6 +658,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
+  report_bad_actions(out, bad);
 }
 
 size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
@@ -649,167 +672,305 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
 }
 
 // ---------------------------------------------------------------------------
-// Split path, first half, one-mover games: the update pass alone, from the
-// transition table.  The only loop-carried dependency of a frame is
-// cell -> table[cell, action] -> cell: one LDS read.  A workgroup is four waves:
-//   wave 0 (producer) runs that dependent chain for 64 environments, kUnroll frames
-//           at a time, and leaves {reward, next cell, done} in an LDS ring;
-//   waves 1-3 (consumers) turn the previous group into the four output streams
-//           (trace, reward, discount, done), four environments per lane so that
-//           every global store is 16 bytes wide, while wave 0 runs the next group;
-//           wave 1 also prefetches the actions one 64-frame chunk ahead.
-// One s_barrier per group; the ring is double-buffered.
-constexpr int kUnroll = 16;
+// Split path, first half: the update pass alone.  Out: the trace (one byte per moving
+// thing per frame per environment: cell + "is the character its cell shows") and the
+// per-frame scalars (reward, discount, done, perf).
+//
+// The only loop-carried dependency of a frame is state -> table[state, action] ->
+// state: one LDS read.  A workgroup owns kEnvs = 64 * kProd consecutive environments
+// and has three kinds of waves:
+//   kProd producer waves   run that dependent chain, one environment per lane,
+//                          kGroup frames at a time, into a double-buffered LDS ring;
+//   kCons consumer waves   turn the previous group into the output streams while the
+//                          producers run the next one: 16 bytes per lane per store
+//                          (4 environments of a float stream, 16 of a byte stream),
+//                          write-through, so that nothing is left dirty in L2 for the
+//                          end-of-kernel flush and the render kernel behind it;
+//   1 loader wave          brings the actions in, 16 bytes per lane per load, one
+//                          64-frame chunk ahead.  It issues no stores, so waiting for
+//                          its loads never waits for a store (vmcnt is in order).
+// One s_barrier per group.
+constexpr int kGroup = 16;
 
-constexpr int kStepWaves = 4;  // 1 producer + 3 consumers
+// Cache policy of the update kernels' output stores (A/B builds): 0 plain, 1 sc0 sc1
+// (write-through), 2 sc0 sc1 nt.
+#ifndef CAMPX_UPD_FLAVOR
+#define CAMPX_UPD_FLAVOR 1
+#endif
+__device__ __forceinline__ void store16_update(void* p, u32x4 v) {
+#if CAMPX_UPD_FLAVOR == 0
+  *reinterpret_cast<u32x4*>(p) = v;
+#elif CAMPX_UPD_FLAVOR == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
 
-__global__ __launch_bounds__(kStepWaves * kWave) void trace_table_kernel(
+// Number of bytes >= 5 (as unsigned) among the 16 of v: the action ids outside 0..4.
+__device__ __forceinline__ int count_bad16(u32x4 v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t hi = (((w[i] & 0x7f7f7f7fu) + 0x7b7b7b7bu) | w[i]) & 0x80808080u;
+    n += __builtin_popcount(hi);
+  }
+  return n;
+}
+
+// The loader wave's state: one chunk (kChunk frames x kEnvs environments) of actions in
+// flight in registers between issue() and land().
+template <int kEnvs>
+struct ActionLoader {
+  static constexpr int kVecPerRow = kEnvs / 16;
+  static constexpr int kPerLane = kChunk * kVecPerRow / kWave;
+  u32x4 pend[kPerLane];
+
+  // 16-byte loads; rows past T and environments past B are clamped to valid ones (no
+  // branch between the loads) and neutralised in land().
+  __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
+                                        int t0, int64_t env0, int lane) {
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+      const int v = lane + i * kWave;
+      const int r = v / kVecPerRow, q = v % kVecPerRow;
+      int row = t0 + r;
+      row = row < T ? row : T - 1;
+      int64_t e = env0 + 16 * q;
+      e = e < B ? e : 0;
+      pend[i] = *reinterpret_cast<const u32x4*>(actions + (int64_t)row * B + e);
+    }
+  }
+
+  __device__ __forceinline__ int land(int8_t* staged, int64_t B, int32_t T, int t0, int64_t env0,
+                                      int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+      const int v = lane + i * kWave;
+      const int r = v / kVecPerRow, q = v % kVecPerRow;
+      const bool real = (t0 + r < T) && (env0 + 16 * q < B);
+      const u32x4 stay = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+      *reinterpret_cast<u32x4*>(staged + r * kEnvs + 16 * q) = real ? pend[i] : stay;
+      bad += real ? count_bad16(pend[i]) : 0;
+    }
+    return bad;
+  }
+};
+
+// Batches that are not a multiple of 16 environments: byte by byte, synchronously.
+template <int kEnvs>
+__device__ __forceinline__ int stage_bytes(int8_t* staged, const int8_t* __restrict__ actions,
+                                           int64_t B, int32_t T, int t0, int64_t env0, int lane) {
+  int bad = 0;
+  for (int i = lane; i < kChunk * kEnvs; i += kWave) {
+    const int r = i / kEnvs, e = i % kEnvs;
+    const bool real = (t0 + r < T) && (env0 + e < B);
+    const int8_t a = real ? actions[(int64_t)(t0 + r) * B + env0 + e] : (int8_t)4;
+    staged[i] = a;
+    bad += ((unsigned)a > 4u) ? 1 : 0;
+  }
+  return bad;
+}
+
+// Four bytes (the low byte of each argument) as one dword.
+__device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return (a & 0xffu) | ((b & 0xffu) << 8) | ((c & 0xffu) << 16) | (d << 24);
+}
+
+template <int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
+  // LDS entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
+  // from (the art's cell when this frame ended the episode: the rebuild is folded into
+  // the chain), [16:22] the cell after this frame, [23] whether the mover shows there,
+  // [24] done, [25:26] perf + 1.  The ring keeps x and the upper half of y.
   __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
-  __shared__ uint32_t entry[CAMPX_MAX_CELLS];  // trace entry of the mover when at that cell
-  __shared__ int8_t staged[2][kChunk * kWave];  // actions, double-buffered per 64 frames
-  __shared__ __attribute__((aligned(16))) uint2 ring[2][kUnroll][kWave];
-  const int lane = threadIdx.x & (kWave - 1);
-  const bool producer = threadIdx.x < kWave;
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
+  __shared__ __attribute__((aligned(16))) float ring_r[2][kGroup][E];
+  __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kGroup][E];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool producer = wave < kProd, loader = wave == kProd + kCons;
   const int W = mp.cols, HW = mp.rows * mp.cols;
-  const int64_t env0 = (int64_t)blockIdx.x * kWave;
-  const int64_t env = env0 + lane;
-  const bool live = env < B;
+  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const bool wide = (B & 15) == 0;  // 16-byte global accesses need 16-environment alignment
 
-  const int consumer_lane = (int)threadIdx.x - kWave;            // 0 .. 191 in the consumers
-  const bool stager = threadIdx.x >= kWave && threadIdx.x < 2 * kWave;  // wave 1 fetches actions
-  // LDS entry: x = reward; y = [0:15] byte offset of the row of the cell the NEXT frame
-  // starts from (the art's cell when this frame ended the episode: the rebuild is
-  // folded into the chain), [16:22] the cell after this frame, [23] done, [24:25] perf+1.
   const int cell0 = mp.row0 * W + mp.col0;
   constexpr int kRowBytes = CAMPX_N_ACTIONS * (int)sizeof(uint2);
-  for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kStepWaves * kWave) {
+  for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kThreads) {
     const CampxTransition tr = spec->table[i];
     const uint32_t from = tr.done ? (uint32_t)cell0 : (uint32_t)tr.next_cell;
+    const uint32_t vis = spec->static_top_z[tr.next_cell] > mp.dyn_z ? 0u : 1u;
     table[i] = make_uint2(__float_as_uint(tr.reward),
-                          (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) |
-                              ((uint32_t)tr.done << 23) | ((uint32_t)(tr.perf + 1) << 24));
+                          (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) | (vis << 23) |
+                              ((uint32_t)tr.done << 24) | ((uint32_t)(tr.perf + 1) << 25));
   }
-  for (int i = threadIdx.x; i < HW; i += kStepWaves * kWave) {
-    const int layer = spec->static_top_layer[i];
-    const uint32_t vis = spec->static_top_z[i] > mp.dyn_z ? 0u : 1u;
-    entry[i] = pack_trace(mp.dyn_layer * HW + i, layer * HW + i, i, vis);
+  ActionLoader<E> ld;
+  int bad = 0;
+  if (loader && T > 0) {
+    if (wide) {
+      ld.issue(actions, B, T, 0, env0, lane);
+      bad += ld.land(staged[0], B, T, 0, env0, lane);
+    } else {
+      bad += stage_bytes<E>(staged[0], actions, B, T, 0, env0, lane);
+    }
   }
-  // Wave 1 also fetches the actions, one 64-frame chunk ahead of the producer, so
-  // that the producer's loop is nothing but the dependent chain.
-  if (stager && T > 0) stage_actions<kWave>(staged[0], actions, B, T, 0, env, live, lane);
 
+  const int le = wave * kWave + lane;  // producers: this lane's environment in the workgroup
+  const int64_t env = env0 + le;
+  const bool live = producer && env < B;
   int cell = cell0, over = 0;
   float ret = 0.0f;
-  if (producer && !reset_first && live) {
+  if (live && !reset_first) {
     cell = (int)st.pos[env] * W + (int)st.pos[B + env];
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
   }
   uint32_t row_off = (uint32_t)(over ? cell0 : cell) * kRowBytes;  // the chain's state
   const char* table_bytes = reinterpret_cast<const char*>(table);
-  const bool wide = (B & 3) == 0;  // 16-byte stores need 4-environment alignment
-  constexpr int kGroupsPerChunk = kChunk / kUnroll;
-
+  const int clane = (int)threadIdx.x - kProd * kWave;  // consumers: 0 .. CL-1
+  constexpr int kGroupsPerChunk = kChunk / kGroup;
   __syncthreads();
 
-  const int n_groups = (T + kUnroll - 1) / kUnroll;
+  const int n_groups = (T + kGroup - 1) / kGroup;
   for (int g = 0; g <= n_groups; ++g) {
     if (producer) {
-      const int t0 = g * kUnroll;
       if (g < n_groups) {
-        const int8_t* my_actions = staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * kWave + lane;
-        const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
-        uint32_t col_off[kUnroll];  // action * sizeof(entry), off the dependent chain
+        const int t0 = g * kGroup;
+        const int8_t* my_actions =
+            staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * E + le;
+        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+        uint32_t col_off[kGroup];  // action * sizeof(entry), off the dependent chain
 #pragma unroll
-        for (int j = 0; j < kUnroll; ++j) {
-          const int a = my_actions[j * kWave];
+        for (int j = 0; j < kGroup; ++j) {
+          const int a = my_actions[j * E];
           col_off[j] = (((unsigned)a > 4u) ? 4u : (uint32_t)a) * (uint32_t)sizeof(uint2);
         }
 #pragma unroll
-        for (int j = 0; j < kUnroll; ++j) {
+        for (int j = 0; j < kGroup; ++j) {
           if (j < n) {
             // the dependent chain: row offset -> entry -> row offset
             const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
             row_off = e.y & 0xffffu;
-            ring[g & 1][j][lane] = e;
+            ring_r[g & 1][j][le] = __uint_as_float(e.x);
+            ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
             // off the chain: the return restarts after an episode end
             ret = (over ? 0.0f : ret) + __uint_as_float(e.x);
-            over = (int)((e.y >> 23) & 1u);
+            over = (int)((e.y >> 24) & 1u);
             cell = (int)((e.y >> 16) & 0x7fu);
           }
         }
       }
-    } else {
-      if (stager && (g % kGroupsPerChunk) == 0) {  // producer enters chunk g/4: fetch the next
-        const int t_next = (g / kGroupsPerChunk + 1) * kChunk;
-        if (t_next < T)
-          stage_actions<kWave>(staged[(t_next / kChunk) & 1], actions, B, T, t_next, env, live, lane);
-      }
-      if (g == 0) {
-        __syncthreads();
-        continue;
-      }
-      const int gp = g - 1, t0 = gp * kUnroll;
-      const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
-      // item = (frame j, group of 4 environments q): 16 items per frame
-      for (int item = consumer_lane; item < n * (kWave / 4); item += (kStepWaves - 1) * kWave) {
-        const int j = item >> 4, q = item & 15;
-        const int64_t e0 = env0 + 4 * q;
-        if (e0 >= B) continue;
-        const uint2* src = &ring[gp & 1][j][4 * q];
-        uint2 e[4];
+    } else if (!loader) {
+      if (g > 0) {
+        const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
+        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+        // ---- float streams: item = (frame j, 4 environments)
+        constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = src[i];
-        uint32_t tr[4];
-        float rw[4], dc[4];
-        uint8_t dn[4];
-        int8_t pf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t done = (e[i].y >> 23) & 1u;
-          tr[i] = entry[(e[i].y >> 16) & 0x7fu];
-          rw[i] = __uint_as_float(e[i].x);
-          dc[i] = done ? 0.0f : 1.0f;
-          dn[i] = (uint8_t)done;
-          pf[i] = (int8_t)((int)((e[i].y >> 24) & 3u) - 1);
-        }
-        const int64_t at = (int64_t)(t0 + j) * B + e0;
-        if (wide && e0 + 4 <= B) {
-          *reinterpret_cast<uint4*>(out.trace + at) = make_uint4(tr[0], tr[1], tr[2], tr[3]);
-          if (out.reward) store_f4(out.reward + at, rw);
-          if (out.discount) store_f4(out.discount + at, dc);
-          if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
-          if (out.perf) *reinterpret_cast<char4*>(out.perf + at) = make_char4(pf[0], pf[1], pf[2], pf[3]);
-        } else {
-          for (int i = 0; i < 4 && e0 + i < B; ++i) {
-            out.trace[at + i] = tr[i];
-            if (out.reward) out.reward[at + i] = rw[i];
-            if (out.discount) out.discount[at + i] = dc[i];
-            if (out.done) out.done[at + i] = dn[i];
-            if (out.perf) out.perf[at + i] = pf[i];
+        for (int it = 0; it < kItA; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QA, q = item % QA;
+          const int64_t e0 = env0 + 4 * q;
+          if (j < n && e0 < B) {
+            const u32x4 r4 = *reinterpret_cast<const u32x4*>(&ring_r[rb][j][4 * q]);
+            const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
+            const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
+                                    (y4.y >> 24) & 1u};
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (wide) {
+              if (out.reward) store16_update(out.reward + at, r4);
+              if (out.discount) {
+                const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
+                                  dn[2] ? 0u : 0x3f800000u, dn[3] ? 0u : 0x3f800000u};
+                store16_update(out.discount + at, d4);
+              }
+            } else {
+              const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
+              for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                if (out.discount) out.discount[at + i] = dn[i] ? 0.0f : 1.0f;
+              }
+            }
           }
+        }
+        // ---- byte streams: item = (frame j, 16 environments)
+        constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
+#pragma unroll
+        for (int it = 0; it < kItB; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QB, q = item % QB;
+          const int64_t e0 = env0 + 16 * q;
+          if (item < kGroup * QB && j < n && e0 < B) {
+            const u32x4 ya = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q]);
+            const u32x4 yb = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q + 8]);
+            const uint32_t w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+            uint32_t tr[4], dn[4], pf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t lo = w[2 * k], hi = w[2 * k + 1];  // two environments each
+              tr[k] = pack4(lo, lo >> 16, hi, (hi >> 16) & 0xffu);
+              dn[k] = pack4((lo >> 8) & 1u, (lo >> 24) & 1u, (hi >> 8) & 1u, (hi >> 24) & 1u);
+              pf[k] = pack4(((lo >> 9) & 3u) - 1u, ((lo >> 25) & 3u) - 1u, ((hi >> 9) & 3u) - 1u,
+                            (((hi >> 25) & 3u) - 1u) & 0xffu);
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (wide) {
+              const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
+              store16_update(out.trace + at, t4);
+              if (out.done) {
+                const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                store16_update(out.done + at, d4);
+              }
+              if (out.perf) {
+                const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                store16_update(out.perf + at, p4);
+              }
+            } else {
+              for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                const int sh = (i & 3) * 8;
+                out.trace[at + i] = (uint8_t)(tr[i >> 2] >> sh);
+                if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      // loader: while the producers are in chunk c, fetch chunk c + 1
+      const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+      const int t_next = (c + 1) * kChunk;
+      if (t_next < T) {
+        if (wide) {
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, lane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, lane);
+        } else if (phase == 0) {
+          bad += stage_bytes<E>(staged[(c + 1) & 1], actions, B, T, t_next, env0, lane);
         }
       }
     }
     __syncthreads();
   }
 
-  if (producer && live) {
+  if (live) {
     st.pos[env] = (int8_t)(cell / W);
     st.pos[B + env] = (int8_t)(cell % W);
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
+  report_bad_actions(out, bad);
 }
 
 // ---------------------------------------------------------------------------
-// Split path, first half, two-mover games: the update pass from the
-// (cell, cell, action) pair table (campx_pair_table_build).  Same producer/consumer
-// layout as trace_table_kernel; the table sits in LDS when it fits (kLds) and is read
-// through L1/L2 otherwise.
+// Two-mover games: the same layout over the (cell, cell, action) pair table
+// (campx_pair_table_build).  The table sits in LDS when it fits (kLds) and is read
+// through L1/L2 otherwise; the ring holds the table entries themselves.
 struct PairParams {
   int32_t rows, cols, n_layers;
   int32_t dyn_layer[2], row0[2], col0[2];
@@ -822,65 +983,73 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW)
   return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;
 }
 
-template <bool kLds>
-__global__ __launch_bounds__(kStepWaves* kWave) void trace_pair_kernel(
+template <bool kLds, int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
   __shared__ uint32_t lds_entries[kLds ? kPairLdsEntries : 1];
   __shared__ float reward_list[256];
-  __shared__ uint16_t scenery_off[CAMPX_MAX_CELLS];  // byte offset of the scenery's 1 per cell
-  __shared__ int8_t staged[2][kChunk * kWave];
-  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kUnroll][kWave];
-  const int lane = threadIdx.x & (kWave - 1);
-  const bool producer = threadIdx.x < kWave;
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool producer = wave < kProd, loader = wave == kProd + kCons;
   const int W = pp.cols, HW = pp.rows * pp.cols;
-  const int64_t env0 = (int64_t)blockIdx.x * kWave;
-  const int64_t env = env0 + lane;
-  const bool live = env < B;
-  const int consumer_lane = (int)threadIdx.x - kWave;
-  const bool stager = threadIdx.x >= kWave && threadIdx.x < 2 * kWave;
+  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const bool wide = (B & 15) == 0;
 
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
   const int n_entries = HW * HW * CAMPX_N_ACTIONS;
   if (kLds)
-    for (int i = threadIdx.x; i < n_entries; i += kStepWaves * kWave) lds_entries[i] = g_entries[i];
-  for (int i = threadIdx.x; i < 256; i += kStepWaves * kWave) reward_list[i] = g_rewards[i];
-  for (int i = threadIdx.x; i < HW; i += kStepWaves * kWave)
-    scenery_off[i] = (uint16_t)(spec->static_top_layer[i] * HW + i);
-  if (stager && T > 0) stage_actions<kWave>(staged[0], actions, B, T, 0, env, live, lane);
+    for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
+  for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
+  ActionLoader<E> ld;
+  int bad = 0;
+  if (loader && T > 0) {
+    if (wide) {
+      ld.issue(actions, B, T, 0, env0, lane);
+      bad += ld.land(staged[0], B, T, 0, env0, lane);
+    } else {
+      bad += stage_bytes<E>(staged[0], actions, B, T, 0, env0, lane);
+    }
+  }
 
+  const int le = wave * kWave + lane;
+  const int64_t env = env0 + le;
+  const bool live = producer && env < B;
   const uint32_t init0 = (uint32_t)(pp.row0[0] * W + pp.col0[0]);
   const uint32_t init1 = (uint32_t)(pp.row0[1] * W + pp.col0[1]);
   uint32_t c0 = init0, c1 = init1;
   int over = 0;
   float ret = 0.0f;
-  if (producer && !reset_first && live) {
+  if (live && !reset_first) {
     c0 = (uint32_t)((int)st.pos[env] * W + (int)st.pos[B + env]);
     c1 = (uint32_t)((int)st.pos[2 * B + env] * W + (int)st.pos[3 * B + env]);
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
   }
-  const bool wide = (B & 3) == 0;
-  constexpr int kGroupsPerChunk = kChunk / kUnroll;
+  const int clane = (int)threadIdx.x - kProd * kWave;
+  constexpr int kGroupsPerChunk = kChunk / kGroup;
   __syncthreads();
 
-  const int n_groups = (T + kUnroll - 1) / kUnroll;
+  const int n_groups = (T + kGroup - 1) / kGroup;
   for (int g = 0; g <= n_groups; ++g) {
     if (producer) {
-      const int t0 = g * kUnroll;
       if (g < n_groups) {
-        const int8_t* my_actions = staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * kWave + lane;
-        const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
-        uint32_t act[kUnroll];
+        const int t0 = g * kGroup;
+        const int8_t* my_actions =
+            staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * E + le;
+        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+        uint32_t act[kGroup];
 #pragma unroll
-        for (int j = 0; j < kUnroll; ++j) {
-          const int a = my_actions[j * kWave];
+        for (int j = 0; j < kGroup; ++j) {
+          const int a = my_actions[j * E];
           act[j] = ((unsigned)a > 4u) ? 4u : (uint32_t)a;
         }
 #pragma unroll
-        for (int j = 0; j < kUnroll; ++j) {
+        for (int j = 0; j < kGroup; ++j) {
           if (j < n) {
             if (over) {  // rebuilt from the art before its next action
               c0 = init0;
@@ -890,70 +1059,117 @@ __global__ __launch_bounds__(kStepWaves* kWave) void trace_pair_kernel(
             const uint32_t e = kLds ? lds_entries[idx] : g_entries[idx];
             c0 = e & 0x7fu;
             c1 = (e >> 7) & 0x7fu;
-            ring[g & 1][j][lane] = e;
+            ring[g & 1][j][le] = e;
             ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
             over = (int)((e >> 16) & 1u);
           }
         }
       }
-    } else {
-      if (stager && (g % kGroupsPerChunk) == 0) {
-        const int t_next = (g / kGroupsPerChunk + 1) * kChunk;
-        if (t_next < T)
-          stage_actions<kWave>(staged[(t_next / kChunk) & 1], actions, B, T, t_next, env, live, lane);
-      }
-      if (g == 0) {
-        __syncthreads();
-        continue;
-      }
-      const int gp = g - 1, t0 = gp * kUnroll;
-      const int n = (T - t0 < kUnroll) ? T - t0 : kUnroll;
-      const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
-      for (int item = consumer_lane; item < n * (kWave / 4); item += (kStepWaves - 1) * kWave) {
-        const int j = item >> 4, q = item & 15;
-        const int64_t e0 = env0 + 4 * q;
-        if (e0 >= B) continue;
-        const uint4 e4 = *reinterpret_cast<const uint4*>(&ring[gp & 1][j][4 * q]);
-        const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
-        uint32_t ta[4], tb[4];
-        float rw[4], dc[4];
-        uint8_t dn[4];
-        int8_t pf[4];
+    } else if (!loader) {
+      if (g > 0) {
+        const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
+        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+        const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
+        constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t a = e[i] & 0x7fu, b = (e[i] >> 7) & 0x7fu;
-          const uint32_t done = (e[i] >> 16) & 1u;
-          ta[i] = pack_trace(pp.dyn_layer[0] * HW + (int)a, scenery_off[a], (int)a, (e[i] >> 14) & 1u);
-          tb[i] = pack_trace(pp.dyn_layer[1] * HW + (int)b, scenery_off[b], (int)b, (e[i] >> 15) & 1u);
-          rw[i] = reward_list[(e[i] >> 19) & 0xffu];
-          dc[i] = done ? 0.0f : 1.0f;
-          dn[i] = (uint8_t)done;
-          pf[i] = (int8_t)((int)((e[i] >> 17) & 3u) - 1);
-        }
-        const int64_t at = (int64_t)(t0 + j) * B + e0;
-        if (wide && e0 + 4 <= B) {
-          *reinterpret_cast<uint4*>(out.trace + at) = make_uint4(ta[0], ta[1], ta[2], ta[3]);
-          *reinterpret_cast<uint4*>(out.trace + plane + at) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-          if (out.reward) store_f4(out.reward + at, rw);
-          if (out.discount) store_f4(out.discount + at, dc);
-          if (out.done) *reinterpret_cast<uchar4*>(out.done + at) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
-          if (out.perf) *reinterpret_cast<char4*>(out.perf + at) = make_char4(pf[0], pf[1], pf[2], pf[3]);
-        } else {
-          for (int i = 0; i < 4 && e0 + i < B; ++i) {
-            out.trace[at + i] = ta[i];
-            out.trace[plane + at + i] = tb[i];
-            if (out.reward) out.reward[at + i] = rw[i];
-            if (out.discount) out.discount[at + i] = dc[i];
-            if (out.done) out.done[at + i] = dn[i];
-            if (out.perf) out.perf[at + i] = pf[i];
+        for (int it = 0; it < kItA; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QA, q = item % QA;
+          const int64_t e0 = env0 + 4 * q;
+          if (j < n && e0 < B) {
+            const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][4 * q]);
+            const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+            uint32_t rw[4], dc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
+              dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (wide) {
+              if (out.reward) {
+                const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
+                store16_update(out.reward + at, r4);
+              }
+              if (out.discount) {
+                const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
+                store16_update(out.discount + at, d4);
+              }
+            } else {
+              for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
+              }
+            }
           }
+        }
+        constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
+#pragma unroll
+        for (int it = 0; it < kItB; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QB, q = item % QB;
+          const int64_t e0 = env0 + 16 * q;
+          if (item < kGroup * QB && j < n && e0 < B) {
+            uint32_t ta[4], tb[4], dn[4], pf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][16 * q + 4 * k]);
+              const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+              uint32_t a[4], b[4], d[4], p[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                a[i] = (e[i] & 0x7fu) | (((e[i] >> 14) & 1u) << 7);
+                b[i] = ((e[i] >> 7) & 0x7fu) | (((e[i] >> 15) & 1u) << 7);
+                d[i] = (e[i] >> 16) & 1u;
+                p[i] = (((e[i] >> 17) & 3u) - 1u) & 0xffu;
+              }
+              ta[k] = pack4(a[0], a[1], a[2], a[3]);
+              tb[k] = pack4(b[0], b[1], b[2], b[3]);
+              dn[k] = pack4(d[0], d[1], d[2], d[3]);
+              pf[k] = pack4(p[0], p[1], p[2], p[3]);
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (wide) {
+              const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
+              store16_update(out.trace + at, a4);
+              store16_update(out.trace + plane + at, b4);
+              if (out.done) {
+                const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                store16_update(out.done + at, d4);
+              }
+              if (out.perf) {
+                const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                store16_update(out.perf + at, p4);
+              }
+            } else {
+              for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                const int sh = (i & 3) * 8;
+                out.trace[at + i] = (uint8_t)(ta[i >> 2] >> sh);
+                out.trace[plane + at + i] = (uint8_t)(tb[i >> 2] >> sh);
+                if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+      const int t_next = (c + 1) * kChunk;
+      if (t_next < T) {
+        if (wide) {
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, lane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, lane);
+        } else if (phase == 0) {
+          bad += stage_bytes<E>(staged[(c + 1) & 1], actions, B, T, t_next, env0, lane);
         }
       }
     }
     __syncthreads();
   }
 
-  if (producer && live) {
+  if (live) {
     st.pos[env] = (int8_t)(c0 / (uint32_t)W);
     st.pos[B + env] = (int8_t)(c0 % (uint32_t)W);
     st.pos[2 * B + env] = (int8_t)(c1 / (uint32_t)W);
@@ -961,6 +1177,7 @@ __global__ __launch_bounds__(kStepWaves* kWave) void trace_pair_kernel(
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
+  report_bad_actions(out, bad);
 }
 
 // ---------------------------------------------------------------------------
@@ -980,36 +1197,42 @@ struct RenderParams {
   uint32_t R;                 // row bytes
   uint32_t m, sh1, sh2;       // exact n / R for 32-bit n (Granlund-Montgomery)
   uint32_t slab_bytes;        // B * R, a multiple of 16
-  int32_t n_dyn, is_board;
+  int32_t n_dyn, is_board, cells;
   int64_t B;
   int32_t dyn_char[CAMPX_MAX_DYN];
+  int32_t dyn_off[CAMPX_MAX_DYN];   // byte offset of moving thing d's layer inside a row
 };
 
-// Block (x, t) writes bytes [x*4096, (x+1)*4096) of frame t; each of its four waves
-// owns one aligned KiB of it (every store instruction of a wave is one aligned,
+// Block (x, t) writes bytes [x*4096*kWin, (x+1)*4096*kWin) of frame t; each of its four
+// waves owns kWin aligned KiB of it (every store instruction of a wave is one aligned,
 // contiguous KiB: tools/probes show -12..-21 % for anything less aligned).
 //
-// A wave first lays the scenery's bytes for its KiB into LDS (one aligned 16-byte
+// A wave first lays the scenery's bytes for its window into LDS (one aligned 16-byte
 // load from the rotated scenery table per lane), then the few lanes that hold a
 // patch - (row overlapping the window) x (moving thing) x (set | clear) - write their
 // single byte into it, then every lane reads its 16 bytes back and stores them.
-// Nothing is shared between waves, so there is no workgroup barrier.
+// A patch comes from the thing's trace byte (cell, visible): the 1 it paints is at
+// dyn_off + cell, the scenery's 1 it hides at scen_off[cell], a per-wave LDS copy of
+// spec->static_top_layer[cell] * cells + cell.  Nothing is shared between waves, so
+// there is no workgroup barrier.
 template <int K, bool kBoard, bool kNT, int kWin, int kFmt>
 __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
                                                      const CampxSpec* __restrict__ spec,
-                                                     const uint32_t* __restrict__ trace,
+                                                     const uint8_t* __restrict__ trace,
                                                      int8_t* __restrict__ dst, int64_t n_rows) {
   __shared__ __attribute__((aligned(16))) int8_t lds[4 * kWin * 1024];
+  __shared__ uint16_t scen_off_all[4][CAMPX_MAX_CELLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // this wave's kWin consecutive KiB windows of the frame
   const uint32_t woff0 = (blockIdx.x * 4u + (uint32_t)wave) * (1024u * kWin);
   if (woff0 >= rp.slab_bytes) return;
   int8_t* win0 = lds + wave * (kWin * 1024);
+  uint16_t* scen_off = scen_off_all[wave];
   const int R = (int)rp.R;
   const int pitch = ((R + 15) & ~15) + 16;
   const int8_t* rot = kBoard ? spec->rot_board : spec->rot_obs;
   constexpr int P = kBoard ? K : 2 * K;                // patches per row
-  const uint32_t* frame_trace = trace + (int64_t)blockIdx.y * rp.B;
+  const uint8_t* frame_trace = trace + (int64_t)blockIdx.y * rp.B;
 
   // ---- scenery: issue all loads, then park them in LDS
   u32x4 scen[kWin];
@@ -1021,6 +1244,9 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
     const int k = (int)(off - row * rp.R);                           // off % R
     scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
   }
+  // the scenery layer of two cells per lane (kBoard needs none of it)
+  uint32_t top2 = 0;
+  if (!kBoard) top2 = *reinterpret_cast<const uint16_t*>(spec->static_top_layer + 2 * lane);
 
   // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear)
   const uint32_t span = 1024u * kWin;
@@ -1039,26 +1265,33 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
     const int d = kBoard ? p : (p >> 1);
     uint32_t row = first_row + (uint32_t)r;
     row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
-    ent[it] = frame_trace[(int64_t)d * n_rows + row];
+    ent[it] = (it == 0 || slots > kWave) ? frame_trace[(int64_t)d * n_rows + row] : 0u;
   }
 #pragma unroll
   for (int j = 0; j < kWin; ++j)
     *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16) = scen[j];
+  if (!kBoard) {
+    const uint32_t c = 2u * (uint32_t)lane;
+    const uint32_t lo = (top2 & 0xffu) * (uint32_t)rp.cells + c;
+    const uint32_t hi2 = (top2 >> 8) * (uint32_t)rp.cells + c + 1u;
+    *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
+  }
 
   auto apply = [&](int sidx, uint32_t e) {
     const int r = sidx / P, p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
+    const int cell = (int)(e & 0x7fu);
     int byte;   // offset inside the row
     int8_t val;
     if (kBoard) {
-      byte = (int)((e >> 22) & 0x7fu);
+      byte = cell;
       val = (int8_t)rp.dyn_char[d];
     } else {
-      byte = (p & 1) ? (int)(e & 0x7ffu) : (int)((e >> 11) & 0x7ffu);
+      byte = (p & 1) ? rp.dyn_off[d] + cell : (int)scen_off[cell];
       val = (int8_t)(p & 1);
     }
     const int64_t at = (int64_t)(first_row + (uint32_t)r) * R + byte - (int64_t)woff0;
-    if (sidx < slots && ((e >> 29) & 1u) && at >= 0 && at < (int64_t)span) win0[at] = val;
+    if (sidx < slots && (e >> 7) && at >= 0 && at < (int64_t)span) win0[at] = val;
   };
 #pragma unroll
   for (int it = 0; it < kMaxIter; ++it) apply(lane + it * kWave, ent[it]);
@@ -1276,7 +1509,7 @@ void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
                      rb, spec_dev, st, actions, out, B, T, reset_first, 0, 0);
 }
 
-int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint32_t* trace,
+int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
                       int8_t* dst, int64_t B, int32_t T, bool is_board, int fmt,
                       hipStream_t stream) {
   const int HW = s.rows * s.cols;
@@ -1293,7 +1526,11 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint3
   rp.n_dyn = s.n_dyn;
   rp.is_board = is_board ? 1 : 0;
   rp.B = B;
-  for (int d = 0; d < s.n_dyn; ++d) rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
+  rp.cells = HW;
+  for (int d = 0; d < s.n_dyn; ++d) {
+    rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
+    rp.dyn_off[d] = s.dyn_layer[d] * HW;
+  }
   constexpr int kWin = 2;  // KiB windows per wave: 1 / 2 / 4 measured 0.227 / 0.197 / 0.211 ms
   const uint32_t span = 4096u * (uint32_t)kWin;
   const dim3 grid((rp.slab_bytes + span - 1u) / span, (unsigned)T);
@@ -1341,14 +1578,24 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
   return true;
 }
 
+// Shape of the update kernels' workgroups (A/B builds): producer and consumer waves.
+#ifndef CAMPX_UPD_PROD
+#define CAMPX_UPD_PROD 2
+#endif
+#ifndef CAMPX_UPD_CONS
+#define CAMPX_UPD_CONS 2
+#endif
+
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
-  const dim3 grid((unsigned)((B + kWave - 1) / kWave));
+  constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS;
+  constexpr int kEnvs = kProd * kWave;
+  const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block((kProd + kCons + 1) * kWave);
   if (use_table) {
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
-    hipLaunchKernelGGL(trace_table_kernel, grid, dim3(kStepWaves * kWave), 0, stream, mp, spec_dev,
+    hipLaunchKernelGGL((update_table_kernel<kProd, kCons>), grid, block, 0, stream, mp, spec_dev,
                        st, actions, out, B, T, reset_first);
   } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
     PairParams pp;
@@ -1363,10 +1610,10 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
     }
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
     if (n_entries <= kPairLdsEntries)
-      hipLaunchKernelGGL(trace_pair_kernel<true>, grid, dim3(kStepWaves * kWave), 0, stream, pp,
+      hipLaunchKernelGGL((update_pair_kernel<true, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
     else
-      hipLaunchKernelGGL(trace_pair_kernel<false>, grid, dim3(kStepWaves * kWave), 0, stream, pp,
+      hipLaunchKernelGGL((update_pair_kernel<false, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
   } else {
     switch (s.n_dyn) {
@@ -1510,6 +1757,10 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   if (e != hipSuccess) return hip_failed(e);
   // host images of pos / actions: pseudo-environment i = (cell i/5, action i%5)
   int8_t* host = static_cast<int8_t*>(malloc(8 * (size_t)n + sizeof(float) * n));
+  if (!host) {
+    (void)hipFree(dev);
+    return CAMPX_ENOMEM;
+  }
   int8_t* h_pos = host;
   int8_t* h_act = host + 2 * n;
   uint8_t* h_done = reinterpret_cast<uint8_t*>(host + 3 * n);
@@ -1584,7 +1835,7 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
   hipStream_t s = static_cast<hipStream_t>(stream);
   // scratch: obs | trace[2][n] | reward[n] | pos[4][n] | done[n] | actions[n] | done_out[n] | perf[n]
   const size_t off_trace = ((size_t)n * spec->n_layers * HW + 255) & ~(size_t)255;
-  const size_t off_reward = off_trace + 2 * sizeof(uint32_t) * (size_t)n;
+  const size_t off_reward = (off_trace + 2 * (size_t)n + 255) & ~(size_t)255;
   const size_t off_pos = off_reward + sizeof(float) * (size_t)n;
   const size_t off_done = off_pos + 4 * (size_t)n;
   const size_t off_act = off_done + n;
@@ -1594,16 +1845,22 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
   char* dev = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), total);
   if (e != hipSuccess) return hip_failed(e);
-  const size_t host_bytes = (size_t)n * (4 + 1 + 1 + 1 + 8 + 4) + (size_t)bytes;
+  // host scratch, 4-byte arrays first so that nothing needs an alignment pad:
+  // reward[n] | table (256 floats + n entries) | pos[4][n] | act[n] | done[n] | perf[n] | trace[2][n]
+  const size_t host_bytes = (size_t)n * 4 + (size_t)bytes + (size_t)n * (4 + 1 + 1 + 1 + 2);
   char* host = static_cast<char*>(malloc(host_bytes));
-  int8_t* h_pos = reinterpret_cast<int8_t*>(host);
+  if (!host) {
+    (void)hipFree(dev);
+    return CAMPX_ENOMEM;
+  }
+  float* h_reward = reinterpret_cast<float*>(host);
+  float* h_table = h_reward + n;
+  uint32_t* h_entries = reinterpret_cast<uint32_t*>(h_table + 256);
+  int8_t* h_pos = reinterpret_cast<int8_t*>(h_entries + n);
   int8_t* h_act = h_pos + 4 * (size_t)n;
   uint8_t* h_done = reinterpret_cast<uint8_t*>(h_act + n);
   int8_t* h_perf = reinterpret_cast<int8_t*>(h_done + n);
-  uint32_t* h_trace = reinterpret_cast<uint32_t*>(h_perf + n + ((8 - (7 * (size_t)n) % 8) % 8));
-  float* h_reward = reinterpret_cast<float*>(h_trace + 2 * (size_t)n);
-  float* h_table = h_reward + n;
-  uint32_t* h_entries = reinterpret_cast<uint32_t*>(h_table + 256);
+  uint8_t* h_trace = reinterpret_cast<uint8_t*>(h_perf + n);
   for (int i = 0; i < n; ++i) {
     const int a = i % CAMPX_N_ACTIONS, c1 = (i / CAMPX_N_ACTIONS) % HW, c0 = i / (CAMPX_N_ACTIONS * HW);
     h_pos[i] = (int8_t)(c0 / W);
@@ -1633,13 +1890,13 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
                         reinterpret_cast<float*>(dev + off_reward), nullptr,
                         reinterpret_cast<uint8_t*>(dev + off_dout),
                         spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr,
-                        reinterpret_cast<uint32_t*>(dev + off_trace)};
+                        reinterpret_cast<uint8_t*>(dev + off_trace)};
     // the interpreter in trace mode: positions, visibility, reward, done, perf
     launch_trace_k<2>(*spec, spec_dev, st, reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1,
                       0, s);
     CAMPX_TRY(hipGetLastError());
   }
-  CAMPX_TRY(hipMemcpyAsync(h_trace, dev + off_trace, 2 * sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_trace, dev + off_trace, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_reward, dev + off_reward, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, (size_t)n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_perf, dev + off_perf, (size_t)n, hipMemcpyDeviceToHost, s));
@@ -1667,8 +1924,8 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
     }
     const uint32_t ta = h_trace[i], tb = h_trace[n + i];
     const int perf = spec->perf_dyn >= 0 ? h_perf[i] : 0;
-    h_entries[i] = ((ta >> 22) & 0x7fu) | (((tb >> 22) & 0x7fu) << 7) | (((ta >> 29) & 1u) << 14) |
-                   (((tb >> 29) & 1u) << 15) | ((uint32_t)(h_done[i] & 1) << 16) |
+    h_entries[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
+                   ((uint32_t)(h_done[i] & 1) << 16) |
                    ((uint32_t)(perf + 1) << 17) | ((uint32_t)idx << 19);
   }
   CAMPX_TRY(hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s));
@@ -1727,6 +1984,8 @@ const char* campx_strerror(int32_t code) {
       return "HIP launch failed (see campx_last_hip_error)";
     case CAMPX_ENODEV:
       return "no usable HIP device";
+    case CAMPX_ENOMEM:
+      return "out of host memory";
     default:
       return "unknown campx error";
   }

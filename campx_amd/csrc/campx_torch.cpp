@@ -1,0 +1,305 @@
+// campx_torch.cpp - the torch custom-op face of libcampx_hip.so.
+//
+// `Engine.play()` / `Engine.rollout()` / `Engine.its_showtime()` of a batched engine
+// lower to these ops (campx_amd/fused.py); they are what replaces the reference's
+// per-frame Python path  Engine.play -> _update_and_render -> <entity>.update ->
+// _render -> renderer.render  (campx/engine.py:114-324, campx/rendering.py:104-219).
+//
+//   campx::reset    its_showtime(): state from the art + the first observation
+//   campx::step     one Engine.play() frame for B environments
+//   campx::rollout  T consecutive frames in one launch
+//   campx::onehot_to_ids / campx::check_actions   action-format helpers
+//
+// Contract: every tensor is caller-owned and contiguous; outputs are written in
+// place (declared mutable in the schema, so functionalization and torch.compile see
+// the writes); the work is enqueued on torch's CURRENT HIP stream of the tensors'
+// device and nothing synchronises.  Registered for the CUDA dispatch key (= HIP on
+// ROCm) and Meta (shape-free no-op, which is also the fake-tensor implementation).
+// There is deliberately no CPU kernel: calling these with CPU state raises.
+//
+// The ops only unpack tensors into the C ABI of include/campx_hip.h; all kernels
+// live in campx_hip.hip.
+
+#include <ATen/core/Tensor.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime.h>
+#include <torch/library.h>
+
+#include <optional>
+
+#include "campx_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+void check_ok(int32_t rc, const char* what) {
+  TORCH_CHECK(rc == CAMPX_OK, what, " failed: ", campx_strerror(rc), " (code ", rc, ", hipError ",
+              campx_last_hip_error(), ")");
+}
+
+const CampxSpec* host_spec(const Tensor& spec_host) {
+  TORCH_CHECK(spec_host.device().is_cpu() && spec_host.scalar_type() == at::kByte &&
+                  spec_host.is_contiguous() && spec_host.numel() == (int64_t)sizeof(CampxSpec),
+              "campx: spec_host must be a contiguous CPU uint8 tensor of ", sizeof(CampxSpec),
+              " bytes (the CampxSpec blob)");
+  return reinterpret_cast<const CampxSpec*>(spec_host.data_ptr());
+}
+
+void want(const Tensor& t, const char* name, at::ScalarType dtype, const c10::Device& dev,
+          c10::IntArrayRef shape) {
+  TORCH_CHECK(t.device() == dev, "campx: ", name, " must be on ", dev, ", it is on ", t.device());
+  TORCH_CHECK(t.scalar_type() == dtype, "campx: ", name, " must be ", dtype, ", it is ",
+              t.scalar_type());
+  TORCH_CHECK(t.is_contiguous(), "campx: ", name, " must be contiguous");
+  TORCH_CHECK(t.sizes() == shape, "campx: ", name, " must have shape ", shape, ", it has ",
+              t.sizes());
+}
+
+template <typename T>
+T* opt_ptr(const OptTensor& t) {
+  return t.has_value() ? reinterpret_cast<T*>(t->data_ptr()) : nullptr;
+}
+
+// Device-visible address of the bad-action flag: device memory, or pinned host memory
+// (so that the host can poll it without a stream synchronisation).
+int32_t* flag_ptr(const OptTensor& t, const c10::Device& dev) {
+  if (!t.has_value()) return nullptr;
+  TORCH_CHECK(t->scalar_type() == at::kInt && t->numel() >= 1 && t->is_contiguous(),
+              "campx: bad_flag must be a contiguous int32 tensor");
+  if (t->device() == dev) return reinterpret_cast<int32_t*>(t->data_ptr());
+  TORCH_CHECK(t->device().is_cpu() && t->is_pinned(),
+              "campx: bad_flag must live on the state's device or in pinned host memory");
+  void* mapped = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&mapped, t->data_ptr(), 0);
+  TORCH_CHECK(e == hipSuccess, "campx: hipHostGetDevicePointer(bad_flag) failed: ",
+              hipGetErrorString(e));
+  return static_cast<int32_t*>(mapped);
+}
+
+struct Game {
+  const CampxSpec* spec_host;
+  const CampxSpec* spec_dev;
+  CampxState state;
+  c10::Device dev;
+  int64_t B, K, L, H, W;
+};
+
+Game unpack_game(const Tensor& spec_host, const Tensor& spec_dev, const Tensor& pos,
+                 const Tensor& done, const OptTensor& ret, const OptTensor& pair_table) {
+  const CampxSpec* hs = host_spec(spec_host);
+  TORCH_CHECK(pos.device().is_cuda(), "campx: the fused tier runs on a HIP device only; state is on ",
+              pos.device(), " (there is no CPU implementation of these ops)");
+  const c10::Device dev = pos.device();
+  TORCH_CHECK(pos.dim() == 2, "campx: pos must be [2*K, B]");
+  const int64_t K = hs->n_dyn, B = pos.size(1);
+  want(pos, "pos", at::kChar, dev, {2 * K, B});
+  want(done, "done", at::kByte, dev, {B});
+  if (ret.has_value()) want(*ret, "ret", at::kFloat, dev, {B});
+  TORCH_CHECK(spec_dev.device() == dev && spec_dev.scalar_type() == at::kByte &&
+                  spec_dev.is_contiguous() && spec_dev.numel() == (int64_t)sizeof(CampxSpec),
+              "campx: spec_dev must be the CampxSpec blob as a uint8 tensor on ", dev);
+  if (pair_table.has_value())
+    TORCH_CHECK(pair_table->device() == dev && pair_table->is_contiguous() &&
+                    pair_table->nbytes() == (size_t)campx_pair_table_bytes(hs),
+                "campx: pair_table has the wrong size or device");
+  Game g{hs,
+         reinterpret_cast<const CampxSpec*>(spec_dev.data_ptr()),
+         CampxState{reinterpret_cast<int8_t*>(pos.data_ptr()),
+                    reinterpret_cast<uint8_t*>(done.data_ptr()), opt_ptr<float>(ret),
+                    pair_table.has_value() ? pair_table->data_ptr() : nullptr},
+         dev,
+         B,
+         K,
+         hs->n_layers,
+         hs->rows,
+         hs->cols};
+  return g;
+}
+
+int32_t obs_format_of(const Tensor& obs) {
+  switch (obs.scalar_type()) {
+    case at::kChar: return CAMPX_OBS_INT8;
+    case at::kHalf: return CAMPX_OBS_F16;
+    case at::kBFloat16: return CAMPX_OBS_BF16;
+    default: TORCH_CHECK(false, "campx: obs must be int8, float16 or bfloat16, it is ", obs.scalar_type());
+  }
+  return 0;
+}
+
+void reset(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+           const OptTensor& ret, const OptTensor& pair_table, Tensor& obs, const OptTensor& board) {
+  const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
+  want(obs, "obs", at::kChar, g.dev, {g.B, g.L, g.H, g.W});
+  if (board.has_value()) want(*board, "board", at::kChar, g.dev, {g.B, g.H, g.W});
+  CampxOutputs out{};
+  out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.board = opt_ptr<int8_t>(board);
+  const c10::hip::HIPGuard guard(g.dev);
+  check_ok(campx_reset_launch(g.spec_host, g.spec_dev, g.state, out, g.B,
+                              c10::hip::getCurrentHIPStream().stream()),
+           "campx_reset_launch");
+}
+
+void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+             const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions, Tensor& obs,
+             const OptTensor& board, const OptTensor& reward, const OptTensor& discount,
+             const OptTensor& step_done, const OptTensor& perf, const OptTensor& trace,
+             const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first) {
+  const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
+  TORCH_CHECK(actions.dim() == 2, "campx::rollout: actions must be int8 [T, B]");
+  const int64_t T = actions.size(0);
+  TORCH_CHECK(T <= 0x7fffffff, "campx::rollout: too many frames");
+  want(actions, "actions", at::kChar, g.dev, {T, g.B});
+  CampxOutputs out{};
+  out.obs_format = obs_format_of(obs);
+  const bool keep = obs.dim() == 5;  // every frame kept, else one frame buffer overwritten
+  if (keep)
+    want(obs, "obs", obs.scalar_type(), g.dev, {T, g.B, g.L, g.H, g.W});
+  else
+    want(obs, "obs", obs.scalar_type(), g.dev, {g.B, g.L, g.H, g.W});
+  out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.obs_t_stride = keep ? g.B * g.L * g.H * g.W : 0;
+  if (board.has_value()) {
+    if (board->dim() == 4) {
+      want(*board, "board", at::kChar, g.dev, {T, g.B, g.H, g.W});
+      out.board_t_stride = g.B * g.H * g.W;
+    } else {
+      want(*board, "board", at::kChar, g.dev, {g.B, g.H, g.W});
+    }
+    out.board = opt_ptr<int8_t>(board);
+  }
+  if (reward.has_value()) want(*reward, "reward", at::kFloat, g.dev, {T, g.B});
+  if (discount.has_value()) want(*discount, "discount", at::kFloat, g.dev, {T, g.B});
+  if (step_done.has_value()) want(*step_done, "step_done", at::kByte, g.dev, {T, g.B});
+  if (perf.has_value()) want(*perf, "perf", at::kChar, g.dev, {T, g.B});
+  if (trace.has_value()) want(*trace, "trace", at::kByte, g.dev, {g.K, T, g.B});
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
+  out.reward = opt_ptr<float>(reward);
+  out.discount = opt_ptr<float>(discount);
+  out.done = opt_ptr<uint8_t>(step_done);
+  out.perf = opt_ptr<int8_t>(perf);
+  out.trace = opt_ptr<uint8_t>(trace);
+  out.bad_count = opt_ptr<int32_t>(bad_count);
+  out.bad_flag = flag_ptr(bad_flag, g.dev);
+  const c10::hip::HIPGuard guard(g.dev);
+  check_ok(campx_rollout_launch(g.spec_host, g.spec_dev, g.state, reinterpret_cast<const int8_t*>(actions.data_ptr()),
+                                out, g.B, (int32_t)T, reset_first ? 1 : 0,
+                                c10::hip::getCurrentHIPStream().stream()),
+           "campx_rollout_launch");
+}
+
+// One Engine.play() frame: actions [B], per-frame outputs [B].
+void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+          const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions, Tensor& obs,
+          const OptTensor& board, const OptTensor& reward, const OptTensor& discount,
+          const OptTensor& step_done, const OptTensor& perf, const OptTensor& bad_count,
+          const OptTensor& bad_flag) {
+  const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
+  want(actions, "actions", at::kChar, g.dev, {g.B});
+  want(obs, "obs", at::kChar, g.dev, {g.B, g.L, g.H, g.W});
+  if (board.has_value()) want(*board, "board", at::kChar, g.dev, {g.B, g.H, g.W});
+  if (reward.has_value()) want(*reward, "reward", at::kFloat, g.dev, {g.B});
+  if (discount.has_value()) want(*discount, "discount", at::kFloat, g.dev, {g.B});
+  if (step_done.has_value()) want(*step_done, "step_done", at::kByte, g.dev, {g.B});
+  if (perf.has_value()) want(*perf, "perf", at::kChar, g.dev, {g.B});
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
+  CampxOutputs out{};
+  out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.board = opt_ptr<int8_t>(board);
+  out.reward = opt_ptr<float>(reward);
+  out.discount = opt_ptr<float>(discount);
+  out.done = opt_ptr<uint8_t>(step_done);
+  out.perf = opt_ptr<int8_t>(perf);
+  out.bad_count = opt_ptr<int32_t>(bad_count);
+  out.bad_flag = flag_ptr(bad_flag, g.dev);
+  const c10::hip::HIPGuard guard(g.dev);
+  check_ok(campx_rollout_launch(g.spec_host, g.spec_dev, g.state,
+                                reinterpret_cast<const int8_t*>(actions.data_ptr()), out, g.B, 1, 0,
+                                c10::hip::getCurrentHIPStream().stream()),
+           "campx_rollout_launch");
+}
+
+void onehot_to_ids(const Tensor& onehot, Tensor& ids, Tensor& bad_count) {
+  TORCH_CHECK(onehot.device().is_cuda(), "campx::onehot_to_ids: HIP tensors only");
+  const c10::Device dev = onehot.device();
+  const int64_t n = ids.numel();
+  TORCH_CHECK(onehot.scalar_type() == at::kFloat && onehot.is_contiguous() &&
+                  onehot.numel() == n * CAMPX_N_ACTIONS,
+              "campx::onehot_to_ids: onehot must be contiguous float32 [..., 5]");
+  TORCH_CHECK(ids.device() == dev && ids.scalar_type() == at::kChar && ids.is_contiguous(),
+              "campx::onehot_to_ids: ids must be contiguous int8 on ", dev);
+  want(bad_count, "bad_count", at::kInt, dev, {1});
+  const c10::hip::HIPGuard guard(dev);
+  check_ok(campx_onehot_to_ids_launch(reinterpret_cast<const float*>(onehot.data_ptr()),
+                                      reinterpret_cast<int8_t*>(ids.data_ptr()), n,
+                                      reinterpret_cast<int32_t*>(bad_count.data_ptr()),
+                                      c10::hip::getCurrentHIPStream().stream()),
+           "campx_onehot_to_ids_launch");
+}
+
+void check_actions(const Tensor& actions, Tensor& bad_count) {
+  TORCH_CHECK(actions.device().is_cuda(), "campx::check_actions: HIP tensors only");
+  const c10::Device dev = actions.device();
+  TORCH_CHECK(actions.scalar_type() == at::kChar && actions.is_contiguous(),
+              "campx::check_actions: actions must be contiguous int8");
+  want(bad_count, "bad_count", at::kInt, dev, {1});
+  const c10::hip::HIPGuard guard(dev);
+  check_ok(campx_check_actions_launch(reinterpret_cast<const int8_t*>(actions.data_ptr()),
+                                      actions.numel(),
+                                      reinterpret_cast<int32_t*>(bad_count.data_ptr()),
+                                      c10::hip::getCurrentHIPStream().stream()),
+           "campx_check_actions_launch");
+}
+
+// Meta / fake-tensor implementations: the ops return nothing and write in place, so
+// there is nothing to infer.
+void reset_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
+                Tensor&, const OptTensor&) {}
+void rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
+                  const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
+                  const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
+                  const OptTensor&, bool) {}
+void step_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
+               const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
+               const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&) {}
+void onehot_to_ids_meta(const Tensor&, Tensor&, Tensor&) {}
+void check_actions_meta(const Tensor&, Tensor&) {}
+
+}  // namespace
+
+TORCH_LIBRARY(campx, m) {
+  m.def(
+      "reset(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
+      "Tensor? pair_table, Tensor(d!) obs, Tensor(e!)? board) -> ()");
+  m.def(
+      "step(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
+      "Tensor? pair_table, Tensor actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
+      "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!)? bad_count, "
+      "Tensor(k!)? bad_flag) -> ()");
+  m.def(
+      "rollout(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
+      "Tensor? pair_table, Tensor actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
+      "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!)? trace, "
+      "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first) -> ()");
+  m.def("onehot_to_ids(Tensor onehot, Tensor(a!) ids, Tensor(b!) bad_count) -> ()");
+  m.def("check_actions(Tensor actions, Tensor(a!) bad_count) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(campx, CUDA, m) {
+  m.impl("reset", &reset);
+  m.impl("step", &step);
+  m.impl("rollout", &rollout);
+  m.impl("onehot_to_ids", &onehot_to_ids);
+  m.impl("check_actions", &check_actions);
+}
+
+TORCH_LIBRARY_IMPL(campx, Meta, m) {
+  m.impl("reset", &reset_meta);
+  m.impl("step", &step_meta);
+  m.impl("rollout", &rollout_meta);
+  m.impl("onehot_to_ids", &onehot_to_ids_meta);
+  m.impl("check_actions", &check_actions_meta);
+}

@@ -1,11 +1,12 @@
-"""The fused tier: B environments stepped by the HIP kernel.
+"""The fused tier: B environments stepped by the HIP kernels.
 
 `FusedGame` is what a batched `Engine` delegates to after `its_showtime()`.  It
 lowers the engine to a GameSpec (`gamespec`), keeps the dynamic state and the
-output buffers as torch tensors in HBM, and calls the C ABI of
-libcampx_hip.so (`_hip`, include/campx_hip.h) on torch's current HIP stream.
-PyTorch is used for device memory and streams only; every per-frame computation
-is inside the kernel.
+output buffers as torch tensors in HBM, and advances them with the torch custom
+ops `campx::reset / step / rollout` (csrc/campx_torch.cpp), which unpack the
+tensors into the C ABI of libcampx_hip.so (include/campx_hip.h) on torch's
+current HIP stream.  PyTorch is used for device memory, streams and op dispatch
+only; every per-frame computation is inside the kernels.
 
 There is no CPU path here: constructing a FusedGame without a HIP device raises.
 
@@ -19,10 +20,19 @@ campx/engine.py:166):
 The tensors returned by `play()` are the engine's own buffers and are overwritten
 by the next call, like the reference's (campx/rendering.py:59-64): copy to keep.
 
-Deviation from the reference, inherent to batching: game-over is per
-environment.  Instead of raising on `play()` after termination
-(campx/engine.py:149-151) a finished environment is rebuilt from the art before
-its next action is applied; `done` (also `game.fused.done`) tells which ones ended.
+Deviations from the reference, inherent to batching:
+
+* game-over is per environment.  Instead of raising on `play()` after termination
+  (campx/engine.py:149-151) a finished environment is rebuilt from the art before
+  its next action is applied; `done` (also `game.fused.done`) tells which ones ended.
+* the reference asserts `sum(act) == 1` inside the agent's update
+  (examples/boat_race.py:48).  Here the kernel that reads the action ids counts the
+  ones outside 0..4 (they act as "stay") and raises a flag in host-mapped memory;
+  `validate_actions=True` (default) makes `play()` / `rollout()` look at that flag -
+  a plain host read, no stream synchronisation - so the ValueError surfaces on the
+  first call after the GPU has consumed the bad ids; `validate_actions='sync'`
+  synchronises and raises in the offending call; `False` never looks.
+  `check_actions()` synchronises and raises on demand.
 """
 
 import ctypes
@@ -40,11 +50,12 @@ from .rendering import Observation
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
 # Rollouts that keep every frame run the update pass and the render as two kernels
-# (needs a [K, T, B] int32 trace buffer): 0.196 ms vs 0.224 ms per 100-frame launch of
-# the boat race at B = 65 536 (DESIGN.md "Kernels", profiles/).  CAMPX_SPLIT=0 keeps
-# everything in the single fused kernel; parity tests run both.
+# (needs a [K, T, B] uint8 trace buffer; DESIGN.md "Kernels", profiles/).
+# CAMPX_SPLIT=0 keeps everything in the single fused kernel; parity tests run both.
 SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') in ('1', 'force')
 FORCE_SPLIT = os.environ.get('CAMPX_SPLIT', '') == 'force'   # also for multi-mover games
+
+_OBS_DTYPES = (torch.int8, torch.float16, torch.bfloat16)
 
 
 def _ptr(t):
@@ -88,9 +99,11 @@ class FusedGame(object):
     self.has_perf = self.spec.perf_dyn >= 0
 
     B, dev = self.batch, self.device
-    blob = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
-                            dtype=torch.uint8)
-    self._spec_dev = blob.to(dev)
+    # The GameSpec blob twice: on the host (the library reads it to choose and
+    # parameterise kernels) and on the device (the kernels' tables).
+    self._spec_host = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
+                                       dtype=torch.uint8)
+    self._spec_dev = self._spec_host.to(dev)
     # Two-mover games: the (cell, cell, action) table of the update pass.
     self._pair_table = None
     n_pair = int(_hip.lib.campx_pair_table_bytes(ctypes.byref(self.spec)))
@@ -116,27 +129,46 @@ class FusedGame(object):
     self._discount = torch.empty((B,), dtype=torch.float32, device=dev)
     self._step_done = torch.empty((B,), dtype=torch.uint8, device=dev)
     self.perf = torch.zeros((B,), dtype=torch.int8, device=dev)
-    self._ids = torch.empty((B,), dtype=torch.int8, device=dev)
+    self._perf_arg = self.perf if self.has_perf else None
+    # Bad-action bookkeeping: a device counter and a flag in pinned (device-mapped)
+    # host memory that the kernels set and the host reads without synchronising.
     self._bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    self._bad_flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    self._bad_flag_view = self._bad_flag.numpy()
     self.validate_actions = True
     self.frame = -1
-    self._play_args = None
+    self._observation_cache = self._observation(self._obs, self._board)
+    self._step = _hip.ops.step.default
+    self._rollout = _hip.ops.rollout.default
 
   # ------------------------------------------------------------------ helpers
-
-  def _stream(self):
-    return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
-  def _state(self):
-    return _hip.CampxState(_ptr(self.pos), _ptr(self.done), _ptr(self.ret),
-                           _ptr(self._pair_table))
 
   def _observation(self, obs, board):
     layers = {ch: obs[:, i] for i, ch in enumerate(self.chars)}
     return Observation(board=board, layers=layers, layered_board=obs)
 
+  def _raise_bad(self):
+    n = int(self._bad.item())          # synchronises: we are about to raise anyway
+    self._bad.zero_()
+    self._bad_flag_view[0] = 0
+    if n:
+      raise ValueError('{} action ids are outside 0..{}'.format(
+          n, gamespec.N_ACTIONS - 1))
+
+  def check_actions(self):
+    """Synchronise and raise ValueError if any consumed action id was outside 0..4."""
+    torch.cuda.synchronize(self.device)
+    self._raise_bad()
+
+  def _after_launch(self):
+    mode = self.validate_actions
+    if mode == 'sync':
+      self._raise_bad()
+    elif mode and self._bad_flag_view[0]:
+      self._raise_bad()
+
   def _action_ids(self, actions, expect):
-    """Normalise to int8 ids on the device; one-hot floats go through the kernel."""
+    """Normalise to int8 ids on the device; one-hot floats go through a kernel."""
     if not torch.is_tensor(actions):
       actions = torch.as_tensor(actions)
     actions = actions.to(self.device)
@@ -146,77 +178,85 @@ class FusedGame(object):
             tuple(expect) + (gamespec.N_ACTIONS,), tuple(actions.shape)))
       onehot = actions.to(torch.float32).contiguous()
       ids = torch.empty(expect, dtype=torch.int8, device=self.device)
-      self._bad.zero_()
-      with torch.cuda.device(self.device):
-        _hip.check(_hip.lib.campx_onehot_to_ids_launch(
-            _ptr(onehot), _ptr(ids), ids.numel(), _ptr(self._bad),
-            self._stream()), 'campx_onehot_to_ids_launch')
-      if self.validate_actions and int(self._bad.item()):
+      count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+      _hip.ops.onehot_to_ids(onehot, ids, count)
+      if self.validate_actions and int(count.item()):
         # the reference asserts sum(act) == 1 (examples/boat_race.py:48)
         raise ValueError('{} action rows are not exactly one-hot'.format(
-            int(self._bad.item())))
+            int(count.item())))
       return ids
     if tuple(actions.shape) != tuple(expect):
       raise ValueError('action ids must have shape {}, got {}'.format(
           tuple(expect), tuple(actions.shape)))
-    ids = actions.to(torch.int8).contiguous()
-    if self.validate_actions:
-      self._bad.zero_()
-      with torch.cuda.device(self.device):
-        _hip.check(_hip.lib.campx_check_actions_launch(
-            _ptr(ids), ids.numel(), _ptr(self._bad), self._stream()),
-            'campx_check_actions_launch')
-      if int(self._bad.item()):
-        raise ValueError('{} action ids are outside 0..{}'.format(
-            int(self._bad.item()), gamespec.N_ACTIONS - 1))
-    return ids
+    if actions.dtype != torch.int8:
+      # narrow without wrapping: 256 must not turn into 0 ("left")
+      actions = actions.clamp(-1, gamespec.N_ACTIONS).to(torch.int8)
+    return actions.contiguous()
 
   # --------------------------------------------------------------------- API
 
   def showtime(self):
     """its_showtime(): state from the art, first observation, reward None."""
-    out = _hip.CampxOutputs(_ptr(self._obs), 0, _ptr(self._board), 0,
-                            None, None, None, None, None)
-    with torch.cuda.device(self.device):
-      _hip.check(_hip.lib.campx_reset_launch(
-          ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(), out,
-          self.batch, self._stream()), 'campx_reset_launch')
+    _hip.ops.reset(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                   self._pair_table, self._obs, self._board)
     self.frame = 0
-    return self._observation(self._obs, self._board), None, 1.0
+    return self._observation_cache, None, 1.0
 
   def play(self, actions):
     # The per-call host path is kept short: the engine's own buffers never move, so
-    # the argument structs and the returned Observation (views of those buffers)
-    # are built once.
-    if (self.validate_actions or not torch.is_tensor(actions)
-        or actions.dtype != torch.int8 or actions.device != self.device
-        or actions.shape != (self.batch,) or not actions.is_contiguous()):
-      ids = self._action_ids(actions, (self.batch,))
-    else:
+    # the returned Observation (views of those buffers) is built once, and ids that
+    # already are an int8 [B] device tensor go straight to the op.
+    if (torch.is_tensor(actions) and actions.dtype == torch.int8
+        and actions.device == self.device and actions.shape == (self.batch,)
+        and actions.is_contiguous()):
       ids = actions
-    if self._play_args is None or self._play_args[0] is not self.ret:
-      out = _hip.CampxOutputs(_ptr(self._obs), 0, _ptr(self._board), 0,
-                              _ptr(self._reward), _ptr(self._discount),
-                              _ptr(self._step_done),
-                              _ptr(self.perf) if self.has_perf else None, None)
-      self._play_args = (self.ret, self._state(), out,
-                         self._observation(self._obs, self._board),
-                         ctypes.byref(self.spec), _ptr(self._spec_dev))
-    _, state, out, observation, spec_ref, spec_dev = self._play_args
-    if torch.cuda.current_device() != self.device.index:
-      with torch.cuda.device(self.device):
-        rc = _hip.lib.campx_rollout_launch(spec_ref, spec_dev, state, _ptr(ids), out,
-                                           self.batch, 1, 0, self._stream())
     else:
-      rc = _hip.lib.campx_rollout_launch(spec_ref, spec_dev, state, _ptr(ids), out,
-                                         self.batch, 1, 0, self._stream())
-    if rc:
-      _hip.check(rc, 'campx_rollout_launch')
+      ids = self._action_ids(actions, (self.batch,))
+    validate = self.validate_actions
+    self._step(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+               self._pair_table, ids, self._obs, self._board, self._reward,
+               self._discount, self._step_done, self._perf_arg,
+               self._bad if validate else None,
+               self._bad_flag if validate else None)
     self.frame += 1
-    return observation, (self._reward if self.any_reward else None), self._discount
+    if validate:
+      self._after_launch()
+    return (self._observation_cache,
+            (self._reward if self.any_reward else None), self._discount)
+
+  def rollout_buffers(self, T, keep_obs=True, want_board=False,
+                      obs_dtype=torch.int8):
+    """Allocate the output buffers of a T-frame rollout once, for `rollout(out=...)`."""
+    B, L, H, W, dev = self.batch, self.n_layers, self.rows, self.cols, self.device
+    if obs_dtype not in _OBS_DTYPES:
+      raise ValueError('obs_dtype must be torch.int8, float16 or bfloat16')
+    sixteen = obs_dtype != torch.int8
+    if sixteen and not keep_obs:
+      raise ValueError('16-bit observations need keep_obs=True')
+    obs = (torch.empty((T, B, L, H, W), dtype=obs_dtype, device=dev)
+           if keep_obs else self._obs)
+    board = None
+    if want_board:
+      board = (torch.empty((T, B, H, W), dtype=torch.int8, device=dev)
+               if keep_obs else self._board)
+    # The compact trajectory; giving it lets the library take its two-kernel path.
+    # (Games with several movers interpret their rules per frame in one wave; for
+    # them the single fused kernel is still the faster path unless forced.)
+    split = (SPLIT_ROLLOUT and (self.uses_table or FORCE_SPLIT)) or sixteen
+    return dict(
+        obs=obs, board=board,
+        reward=(torch.empty((T, B), dtype=torch.float32, device=dev)
+                if self.any_reward else None),
+        discount=torch.empty((T, B), dtype=torch.float32, device=dev),
+        done=torch.empty((T, B), dtype=torch.uint8, device=dev),
+        perf=(torch.empty((T, B), dtype=torch.int8, device=dev)
+              if self.has_perf else None),
+        trace=(torch.empty((self.n_dyn, T, B), dtype=torch.uint8, device=dev)
+               if keep_obs and split else None))
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True,
-              reset_first=False, want_board=False, obs_dtype=torch.int8):
+              reset_first=False, want_board=False, obs_dtype=torch.int8,
+              out=None):
     """T frames in one launch.
 
     Args:
@@ -233,53 +273,44 @@ class FusedGame(object):
           with `layered_board.view(-1).float()` (examples/reinforce.py:123,149),
           written directly by the render kernel; they need `keep_obs` and a game
           that takes the two-kernel path.
+      out: a dict from `rollout_buffers()` (or a previous `rollout()` of the same
+          T and options) whose tensors are overwritten instead of allocating new
+          ones: the whole call is then one op dispatch.  Overrides
+          obs/board/keep_obs/want_board/obs_dtype.
     Returns:
       dict with 'obs' ([T,B,L,H,W] or the last frame [B,L,H,W]), 'board' (or
       None), 'reward' [T,B] (None if the game never rewards), 'discount' [T,B],
       'done' [T,B] uint8, 'perf' [T,B] int8 hidden performance (None unless the
-      game declared one, `Engine.set_hidden_performance`), 'trace' (split path).
+      game declared one, `Engine.set_hidden_performance`), 'trace' (split path:
+      uint8 [K,T,B], cell | visible << 7 per moving thing).
     """
     T = int(actions.shape[0])
-    ids = self._action_ids(actions, (T, self.batch))
-    B, L, H, W, dev = self.batch, self.n_layers, self.rows, self.cols, self.device
-    formats = {torch.int8: 0, torch.float16: 1, torch.bfloat16: 2}
-    if obs_dtype not in formats:
-      raise ValueError('obs_dtype must be torch.int8, float16 or bfloat16')
-    if keep_obs:
-      if obs is None:
-        obs = torch.empty((T, B, L, H, W), dtype=obs_dtype, device=dev)
-      elif (tuple(obs.shape) != (T, B, L, H, W) or obs.dtype != obs_dtype
-            or not obs.is_contiguous() or obs.device != dev):
+    if (torch.is_tensor(actions) and actions.dtype == torch.int8
+        and actions.device == self.device and actions.shape == (T, self.batch)
+        and actions.is_contiguous()):
+      ids = actions
+    else:
+      ids = self._action_ids(actions, (T, self.batch))
+    if out is None:
+      B, L, H, W, dev = self.batch, self.n_layers, self.rows, self.cols, self.device
+      if obs is not None and keep_obs and (
+          tuple(obs.shape) != (T, B, L, H, W) or obs.dtype != obs_dtype
+          or not obs.is_contiguous() or obs.device != dev):
         raise ValueError('obs must be a contiguous {} [T,B,L,H,W] tensor on {}'
                          .format(obs_dtype, dev))
-      obs_stride = B * L * H * W
-    else:
-      if formats[obs_dtype]:
-        raise ValueError('16-bit observations need keep_obs=True')
-      obs, obs_stride = self._obs, 0
-    if want_board and board is None:
-      board = torch.empty((T, B, H, W), dtype=torch.int8, device=dev)
-    board_stride = B * H * W if board is not None else 0
-    reward = torch.empty((T, B), dtype=torch.float32, device=dev)
-    discount = torch.empty((T, B), dtype=torch.float32, device=dev)
-    done = torch.empty((T, B), dtype=torch.uint8, device=dev)
-    perf = (torch.empty((T, B), dtype=torch.int8, device=dev)
-            if self.has_perf else None)
-    # The compact trajectory; giving it lets the library take its two-kernel path.
-    # (Games with several movers interpret their rules per frame in one wave; for
-    # them the single fused kernel is still the faster path unless forced.)
-    split = (SPLIT_ROLLOUT and (self.uses_table or FORCE_SPLIT)) or bool(formats[obs_dtype])
-    trace = (torch.empty((self.n_dyn, T, B), dtype=torch.int32, device=dev)
-             if keep_obs and split else None)
-    out = _hip.CampxOutputs(_ptr(obs), obs_stride, _ptr(board), board_stride,
-                            _ptr(reward), _ptr(discount), _ptr(done), _ptr(perf),
-                            _ptr(trace), formats[obs_dtype])
-    with torch.cuda.device(self.device):
-      _hip.check(_hip.lib.campx_rollout_launch(
-          ctypes.byref(self.spec), _ptr(self._spec_dev), self._state(),
-          _ptr(ids), out, B, T, int(bool(reset_first)), self._stream()),
-          'campx_rollout_launch')
+      out = self.rollout_buffers(T, keep_obs, want_board or board is not None,
+                                 obs_dtype)
+      if obs is not None and keep_obs:
+        out['obs'] = obs
+      if board is not None:
+        out['board'] = board
+    validate = self.validate_actions
+    self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                  self._pair_table, ids, out['obs'], out['board'], out['reward'],
+                  out['discount'], out['done'], out['perf'], out['trace'],
+                  self._bad if validate else None,
+                  self._bad_flag if validate else None, bool(reset_first))
     self.frame = T if reset_first else self.frame + T
-    return dict(obs=obs, board=board,
-                reward=reward if self.any_reward else None,
-                discount=discount, done=done, perf=perf, trace=trace)
+    if validate:
+      self._after_launch()
+    return out

@@ -51,7 +51,8 @@ enum {
   CAMPX_EINVAL = -1,   /* NULL / misaligned / out-of-range argument */
   CAMPX_ESPEC = -2,    /* GameSpec fails validation */
   CAMPX_ELAUNCH = -3,  /* HIP refused the launch (see campx_last_hip_error) */
-  CAMPX_ENODEV = -4    /* no gfx950 device */
+  CAMPX_ENODEV = -4,   /* no gfx950 device */
+  CAMPX_ENOMEM = -5    /* host scratch allocation failed (set-up calls only) */
 };
 
 enum { CAMPX_OBS_INT8 = 0, CAMPX_OBS_F16 = 1, CAMPX_OBS_BF16 = 2 };
@@ -175,15 +176,13 @@ typedef struct CampxOutputs {
   uint8_t* done;      /* [T, B] game-over flag after the frame */
   int8_t* perf;       /* [T, B] hidden performance of the frame (-1, 0, +1), or NULL; needs
                          spec.perf_dyn >= 0 */
-  uint32_t* trace;    /* optional [K, T, B]: for moving thing d at frame t in environment e,
-                           bits 0-10  byte offset, inside the environment's L*rows*cols
-                                      layered board, of the 1 this thing paints
-                           bits 11-21 byte offset of the scenery's 1 that it covers
-                           bits 22-28 the cell (row*cols + col) it is in after the frame
-                           bit  29    1 when it is the character that cell shows; when 0
-                                      it is hidden and changes nothing in the observation
-                         A compact trajectory in its own right; and when it is given, frames
-                         are stored back to back (obs_t_stride == B*L*rows*cols) and are whole
+  uint8_t* trace;     /* optional [K, T, B]: for moving thing d at frame t in environment e,
+                           bits 0-6  the cell (row*cols + col) it is in after the frame
+                           bit  7    1 when it is the character that cell shows; when 0 it
+                                     is hidden and changes nothing in the observation
+                         A compact trajectory in its own right (1 byte per thing per frame
+                         against L*rows*cols of observation); and when it is given, frames are
+                         stored back to back (obs_t_stride == B*L*rows*cols) and are whole
                          16-byte multiples, the library runs the update pass and the render as
                          two kernels, which streams the observations to HBM faster (DESIGN.md
                          "Kernels").  Written only on that path. */
@@ -194,6 +193,15 @@ typedef struct CampxOutputs {
                          (examples/reinforce.py:123,149) handed over without a conversion
                          pass.  16-bit formats are produced by the render kernel only: they
                          need `trace` and back-to-back frames, else CAMPX_EINVAL. */
+  int32_t* bad_count; /* optional device int32: += number of action ids outside 0..4 this call
+                         consumed (the reference asserts sum(act) == 1 per step,
+                         examples/boat_race.py:48; here the check rides in the kernel that
+                         reads the actions anyway and the caller looks when it likes).  Never
+                         reset by the library. */
+  int32_t* bad_flag;  /* optional int32, device memory or host memory mapped into the device
+                         (hipHostMalloc): set to 1, by a plain system-scope store, when the
+                         call consumed any id outside 0..4.  Lets a host poll for bad
+                         actions without a stream synchronisation. */
 } CampxOutputs;
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */

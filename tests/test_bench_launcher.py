@@ -1,0 +1,60 @@
+"""bench.py's own multi-rank launcher, on CPU.
+
+`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start its two
+ranks itself, before any GPU call, relay rank 0's JSON line and return the ranks'
+exit code.  Here the ranks run a CPU stand-in of the engine (tests/bench_standin.py)
+over gloo; on a GPU box the same code path runs the HIP engine over RCCL
+(`bench.py --gpus 1 --force-dist` is the one-GPU smoke test of it, test_fused_parity).
+"""
+
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  env['PYTHONPATH'] = os.pathsep.join([os.path.join(REPO, 'tests'), REPO,
+                                       env.get('PYTHONPATH', '')])
+  env.update(env_extra or {})
+  return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + extra,
+                        capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_gpus_2_spawns_two_ranks_and_prints_one_line():
+  r = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '64',
+            '--frames', '20', '--gather-every', '2',
+            '--standin', 'bench_standin:make'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  line = json.loads(lines[0])
+  assert line['n_gpus'] == 2 and line['config']['world'] == 2
+  assert line['config']['global_batch'] == 128
+  assert line['steps'] == 3 and line['warmup'] == 1
+  assert line['scaling'] == 'weak' and line['unit'] == 'env-steps/s'
+  # value = all ranks' env-steps over the (max over ranks) elapsed time
+  assert abs(line['value'] - 128 * 20 * 3 / (line['ms_per_step'] * 3e-3)) < 1e-6 * line['value']
+  assert line['config']['gathered_log_matches_local'] is True
+  assert 'DRY RUN' in line['data'] and line['cpu_baseline'] is None
+
+
+def test_force_dist_goes_through_the_launcher_with_one_rank():
+  r = _run(['--gpus', '1', '--force-dist', '--steps', '4', '--warmup', '0', '--batch', '32',
+            '--frames', '10', '--gather-every', '2', '--standin', 'bench_standin:make'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  assert line['n_gpus'] == 1 and line['config']['world'] == 1
+  assert line['config']['gathered_log_matches_local'] is True
+  assert 'all-gather' in line['config']['parallelism']
+
+
+def test_a_failing_rank_fails_the_launcher():
+  r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '16', '--frames', '4',
+            '--standin', 'bench_standin:no_such_function'])
+  assert r.returncode != 0
+  assert not [l for l in r.stdout.splitlines() if l.startswith('{')]

@@ -126,6 +126,7 @@ def test_random_streams_vs_oracle(name, batch):
 
 def test_one_hot_actions_and_validation():
   game, _ = _fused('boat_race', 128)
+  game.fused.validate_actions = 'sync'          # raise in the offending call
   ids = torch.randint(0, 5, (128,))
   onehot = torch.nn.functional.one_hot(ids, 5).float()
   obs_a, r_a, _ = game.play(onehot)
@@ -135,10 +136,45 @@ def test_one_hot_actions_and_validation():
   assert torch.equal(board_a, obs_b.board) and torch.equal(r_a, r_b)
   with pytest.raises(ValueError):
     game.play(torch.full((128,), 5))
+  with pytest.raises(ValueError):
+    game.play(torch.full((128,), 256))          # must not wrap to 0 when narrowed to int8
+  game.play(ids)                                # the error state was cleared
   bad = onehot.clone()
   bad[3] = 0.5
   with pytest.raises(ValueError):
     game.play(bad)
+
+
+def test_lazy_validation_flag_in_host_mapped_memory():
+  """Default mode: the kernel that reads the ids raises a flag in pinned host memory;
+  the host looks at it without synchronising, so the error surfaces at the latest in
+  the first call after a synchronisation - and check_actions() forces it."""
+  game, _ = _fused('boat_race', 256)
+  assert game.fused.validate_actions is True
+  good = torch.randint(0, 5, (256,), dtype=torch.int8, device='cuda')
+  bad = good.clone()
+  bad[17] = 9
+  bad[200] = -3
+  game.play(good)
+  game.fused.check_actions()                    # nothing wrong so far
+  try:
+    game.play(bad)                              # may or may not have been seen yet
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match='2 action ids'):
+      game.play(good)                           # flag is up: plain host read finds it
+  except ValueError as e:
+    assert '2 action ids' in str(e)
+  game.play(good)                               # cleared
+  game.fused.check_actions()
+  # rollouts count through the same flag, on every kernel path
+  acts = torch.randint(0, 5, (40, 256), dtype=torch.int8, device='cuda')
+  acts[7, 3] = 77
+  game.rollout(acts, reset_first=True)
+  with pytest.raises(ValueError, match='1 action ids'):
+    game.fused.check_actions()
+  game.fused.validate_actions = False           # never looks
+  game.rollout(acts, reset_first=True)
+  game.fused.check_actions()
 
 
 def test_keep_obs_false_leaves_last_frame(golden):
@@ -155,7 +191,8 @@ def test_reset_first_starts_new_episode(golden):
   a = game.rollout(acts, reset_first=True)
   b = game.rollout(acts, reset_first=True)
   assert torch.equal(a['obs'], b['obs']) and torch.equal(a['reward'], b['reward'])
-  assert _same(game.fused.ret.cpu().numpy() * 0, np.zeros(acts.shape[1], np.float32)) or True
+  # the running return restarted with the episode
+  assert _same(game.fused.ret.cpu().numpy(), b['reward'].sum(0).cpu().numpy())
 
 
 @pytest.mark.parametrize('name,batch,T', [('boat_race', 65536, 100),

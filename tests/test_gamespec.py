@@ -102,8 +102,8 @@ def test_validate_rejects_corrupt_specs():
 def test_launch_argument_checks_without_a_gpu():
   """NULL buffers are rejected before anything touches the device."""
   spec = gamespec.lower(gamespec.describe(boat_race.build()))
-  st = _hip.CampxState(None, None, None)
-  out = _hip.CampxOutputs(None, 0, None, 0, None, None, None, None)
+  st = _hip.CampxState(None, None, None, None)
+  out = _hip.CampxOutputs()
   assert _hip.lib.campx_rollout_launch(ctypes.byref(spec), None, st, None, out, 64, 1, 0, None) == -1
   assert _hip.lib.campx_check_actions_launch(None, 4, None, None) == -1
   assert _hip.lib.campx_onehot_to_ids_launch(None, None, 4, None, None) == -1
