@@ -16,13 +16,15 @@
 // device and nothing synchronises.  Registered for the CUDA dispatch key (= HIP on
 // ROCm) and Meta (shape-free no-op, which is also the fake-tensor implementation).
 // There is deliberately no CPU kernel: calling these with CPU state raises.
+// (ROCm builds of torch present HIP devices as device type "cuda"; the guard and stream
+// types below are torch's own names for that arrangement.)
 //
 // The ops only unpack tensors into the C ABI of include/campx_hip.h; all kernels
 // live in campx_hip.hip.
 
 #include <ATen/core/Tensor.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime.h>
 #include <torch/library.h>
 
@@ -137,9 +139,9 @@ void reset(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor&
   CampxOutputs out{};
   out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
   out.board = opt_ptr<int8_t>(board);
-  const c10::hip::HIPGuard guard(g.dev);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
   check_ok(campx_reset_launch(g.spec_host, g.spec_dev, g.state, out, g.B,
-                              c10::hip::getCurrentHIPStream().stream()),
+                              c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
            "campx_reset_launch");
 }
 
@@ -184,10 +186,10 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
   out.trace = opt_ptr<uint8_t>(trace);
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, g.dev);
-  const c10::hip::HIPGuard guard(g.dev);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
   check_ok(campx_rollout_launch(g.spec_host, g.spec_dev, g.state, reinterpret_cast<const int8_t*>(actions.data_ptr()),
                                 out, g.B, (int32_t)T, reset_first ? 1 : 0,
-                                c10::hip::getCurrentHIPStream().stream()),
+                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
            "campx_rollout_launch");
 }
 
@@ -215,10 +217,10 @@ void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& 
   out.perf = opt_ptr<int8_t>(perf);
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, g.dev);
-  const c10::hip::HIPGuard guard(g.dev);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
   check_ok(campx_rollout_launch(g.spec_host, g.spec_dev, g.state,
                                 reinterpret_cast<const int8_t*>(actions.data_ptr()), out, g.B, 1, 0,
-                                c10::hip::getCurrentHIPStream().stream()),
+                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
            "campx_rollout_launch");
 }
 
@@ -232,11 +234,11 @@ void onehot_to_ids(const Tensor& onehot, Tensor& ids, Tensor& bad_count) {
   TORCH_CHECK(ids.device() == dev && ids.scalar_type() == at::kChar && ids.is_contiguous(),
               "campx::onehot_to_ids: ids must be contiguous int8 on ", dev);
   want(bad_count, "bad_count", at::kInt, dev, {1});
-  const c10::hip::HIPGuard guard(dev);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   check_ok(campx_onehot_to_ids_launch(reinterpret_cast<const float*>(onehot.data_ptr()),
                                       reinterpret_cast<int8_t*>(ids.data_ptr()), n,
                                       reinterpret_cast<int32_t*>(bad_count.data_ptr()),
-                                      c10::hip::getCurrentHIPStream().stream()),
+                                      c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
            "campx_onehot_to_ids_launch");
 }
 
@@ -246,11 +248,11 @@ void check_actions(const Tensor& actions, Tensor& bad_count) {
   TORCH_CHECK(actions.scalar_type() == at::kChar && actions.is_contiguous(),
               "campx::check_actions: actions must be contiguous int8");
   want(bad_count, "bad_count", at::kInt, dev, {1});
-  const c10::hip::HIPGuard guard(dev);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   check_ok(campx_check_actions_launch(reinterpret_cast<const int8_t*>(actions.data_ptr()),
                                       actions.numel(),
                                       reinterpret_cast<int32_t*>(bad_count.data_ptr()),
-                                      c10::hip::getCurrentHIPStream().stream()),
+                                      c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
            "campx_check_actions_launch");
 }
 

@@ -195,27 +195,144 @@ def test_reset_first_starts_new_episode(golden):
   assert _same(game.fused.ret.cpu().numpy(), b['reward'].sum(0).cpu().numpy())
 
 
-@pytest.mark.parametrize('name,batch,T', [('boat_race', 65536, 100),
-                                          ('wall_world', 262144, 20),
-                                          ('sokoban', 131072, 50)])
-def test_full_size_vs_oracle(name, batch, T):
-  """BASELINE.json batch sizes, every frame's reward/discount/done and a sample of
-  full observations against the oracle; plus a size-independent invariant: every
-  cell of every environment shows exactly one character."""
-  rng = np.random.RandomState(1234)
-  actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
-  game, _ = _fused(name, batch)
+def _oracle_frames(og, actions, frames):
+  """Run the oracle over `actions`, keeping the full observation of the frames in
+  `frames` only (it keeps either every frame or the last one of a call, so the episode
+  is cut into calls that end at the sampled frames; its state carries across calls)."""
+  parts, obs_at, start = [], {}, 0
+  for stop in sorted(set(frames) | {actions.shape[0] - 1}):
+    ref = og.rollout(actions[start:stop + 1], reset_first=(start == 0), keep_obs=False,
+                     want_board=False)
+    parts.append(ref)
+    obs_at[stop] = ref['obs']
+    start = stop + 1
+  whole = {k: np.concatenate([p[k] for p in parts]) for k in ('reward', 'discount', 'done')}
+  whole['perf'] = (np.concatenate([p['perf'] for p in parts])
+                   if parts[0]['perf'] is not None else None)
+  return whole, obs_at
+
+
+def _check_full_size(game, og_factory, actions):
+  """BASELINE-size parity: every frame's reward / discount / done / perf for every
+  environment; the FULL observation of all environments at frames 0, 1, T/2, T-2, T-1;
+  the full observation of a strided sample of 4096 environments at EVERY frame; and a
+  size-independent invariant: every cell of every environment shows exactly one
+  character in every frame."""
+  T, batch = actions.shape
   out = game.rollout(torch.from_numpy(actions), reset_first=True)
-  og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES[name]()))
-  ref = og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
+  frames = sorted({0, 1, T // 2, T - 2, T - 1})
+  ref, obs_at = _oracle_frames(og_factory(), actions, frames)
   assert _same(out['discount'].cpu().numpy(), ref['discount'])
   assert _same(out['done'].cpu().numpy(), ref['done'])
   assert _same(out['reward'].cpu().numpy(), ref['reward'])
   if ref['perf'] is not None:
     assert _same(out['perf'].cpu().numpy(), ref['perf'])
-  assert _same(out['obs'][-1].cpu().numpy(), ref['obs'])
+  for t in frames:
+    assert _same(out['obs'][t].cpu().numpy(), obs_at[t]), 'frame %d' % t
+  stride = max(1, batch // 4096)
+  sample = og_factory().rollout(np.ascontiguousarray(actions[:, ::stride]), reset_first=True,
+                                keep_obs=True, want_board=False)
+  assert _same(out['obs'][:, ::stride].cpu().numpy(), sample['obs'])
   sums = out['obs'].sum(dim=2, dtype=torch.int32)
   assert int(sums.min()) == 1 and int(sums.max()) == 1
+  # the trace is a compact trajectory in its own right: cell of the first mover
+  if out['trace'] is not None:
+    cells = (out['trace'][0] & 0x7f).long()
+    layer = game.fused.spec.dyn_layer[0]
+    where = out['obs'][:, :, layer].reshape(T, batch, -1).long().argmax(dim=2)
+    shown = out['trace'][0] >> 7
+    assert torch.equal(cells[shown == 1], where[shown == 1])
+
+
+@pytest.mark.parametrize('name,batch,T', [('boat_race', 65536, 100),
+                                          ('wall_world', 262144, 100),
+                                          ('sokoban', 131072, 100)])
+def test_full_size_vs_oracle(name, batch, T):
+  """The three single-GPU BASELINE.json configurations at their full batch and the
+  100-frame episode the bench times."""
+  rng = np.random.RandomState(1234)
+  actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+  game, _ = _fused(name, batch)
+  desc = gamespec.describe(FUSED_GAMES[name]())
+  _check_full_size(game, lambda: cpu.OracleGame.from_description(desc), actions)
+
+
+COURTYARD_ART = ['#########',
+                 '#A  *   #',
+                 '# ## #> #',
+                 '#  *    #',
+                 '#> #  * #',
+                 '#     # #',
+                 '#########']
+
+
+def _courtyard_engine(batch):
+  from campx_amd import rules
+  from campx_amd.ascii_art import ascii_art_to_game, Partial
+  return ascii_art_to_game(
+      COURTYARD_ART, what_lies_beneath=' ',
+      drapes={'A': Partial(rules.AgentDrape, blocking_chars='#', step_reward=-0.5,
+                           reward_chars='*'),
+              '>': Partial(rules.DirectionalHoverRewardDrape,
+                           dctns=torch.tensor([0., 2., 0., 0., 0.]), base_reward=0.25),
+              '#': rules.FixedDrape, '*': rules.FixedDrape},
+      z_order='*>A#', update_schedule=[['A', '>'], ['*', '#']], batch=batch, device='cuda')
+
+
+def _courtyard_description():
+  """The same game written down by hand as the oracle's input - NOT read back from the
+  engine with gamespec.describe(), so a mis-read z-order / schedule / mask in describe()
+  (which the HIP lowering goes through) cannot hit both sides."""
+  art = np.array([list(row) for row in COURTYARD_ART])
+  mask = lambda ch: (art == ch).astype(np.uint8)
+  entities = [
+      gamespec.EntityDesc('A', 'agent', 0, mask('A'),
+                          dict(op='agent', blocking='#', step_reward=-0.5, reward_chars='*')),
+      gamespec.EntityDesc('>', 'dir_hover', 0, mask('>'),
+                          dict(op='dir_hover', agents='A', dctns=[0., 2., 0., 0., 0.],
+                               base_reward=0.25)),
+      gamespec.EntityDesc('*', 'fixed', 1, mask('*'), {}),
+      gamespec.EntityDesc('#', 'fixed', 1, mask('#'), {}),
+  ]
+  backdrop = np.full(art.shape, ord(' '), np.uint8)
+  return gamespec.GameDescription(7, 9, [' ', '#', '*', '>', 'A'], backdrop, entities,
+                                  ['*', '>', 'A', '#'])
+
+
+def test_full_size_on_an_art_outside_the_goldens_with_a_hand_written_description():
+  batch, T = 65536, 100
+  rng = np.random.RandomState(99)
+  actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+  game = _courtyard_engine(batch)
+  game.its_showtime()
+  desc = _courtyard_description()
+  _check_full_size(game, lambda: cpu.OracleGame.from_description(desc), actions)
+
+
+def test_two_mover_game_on_an_odd_sized_board():
+  """5x5 two-mover game: n = 5*HW^2 is not a multiple of 8 (the pair-table scratch
+  layout of campx_pair_table_build must not depend on that)."""
+  from campx_amd import rules
+  from campx_amd.ascii_art import ascii_art_to_game, Partial
+  art = ['#####', '#A  #', '# X #', '#  G#', '#####']
+
+  def build(batch=None, device=None):
+    return ascii_art_to_game(
+        art, what_lies_beneath=' ',
+        drapes={'#': rules.FixedDrape,
+                'A': Partial(rules.AgentDrape, blocking_chars='#X'),
+                'X': Partial(rules.BoxDrape, agent_char='A', blocking_chars='#'),
+                'G': Partial(rules.GoalDrape, agent_char='A', step_reward=-1, goal_reward=10)},
+        update_schedule=[['X'], ['A', 'G', '#']], z_order='GXA#', batch=batch, device=device)
+  batch = 320
+  game = build(batch, 'cuda')
+  game.its_showtime()
+  rng = np.random.RandomState(4)
+  og = cpu.OracleGame.from_description(gamespec.describe(build()))
+  for launch, T in enumerate([3, 40]):
+    actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), want_board=True)
+    _check_rollout(out, og.rollout(actions, reset_first=(launch == 0)))
 
 
 def test_return_gatherer_on_gpu_single_rank_rccl(tmp_path):
@@ -227,7 +344,10 @@ def test_return_gatherer_on_gpu_single_rank_rccl(tmp_path):
 import os, sys, torch
 sys.path.insert(0, %r)
 import torch.distributed as dist
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+import socket
+with socket.socket() as _s:
+    _s.bind(('127.0.0.1', 0)); _port = _s.getsockname()[1]
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_port))
 dev = torch.device('cuda', 0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 from campx_amd.distributed import ReturnGatherer
