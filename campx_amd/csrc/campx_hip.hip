@@ -977,7 +977,10 @@ struct PairParams {
   int32_t lds_table;  // entries fit in LDS
 };
 
-constexpr int kPairLdsEntries = 8192;  // 32 KiB of LDS for the table
+#ifndef CAMPX_PAIR_LDS_ENTRIES
+#define CAMPX_PAIR_LDS_ENTRIES 8192
+#endif
+constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 32 KiB of LDS for the table
 
 __device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW) {
   return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;
@@ -989,7 +992,7 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
-  __shared__ uint32_t lds_entries[kLds ? kPairLdsEntries : 1];
+  __shared__ uint32_t lds_entries[kLds && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
   __shared__ float reward_list[256];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
@@ -1215,16 +1218,34 @@ struct RenderParams {
 // dyn_off + cell, the scenery's 1 it hides at scen_off[cell], a per-wave LDS copy of
 // spec->static_top_layer[cell] * cells + cell.  Nothing is shared between waves, so
 // there is no workgroup barrier.
+// A/B knobs of the render kernel's shape: waves per block, KiB windows per wave, and
+// whether block indices are remapped so that each XCD (block b runs on XCD b % 8) sweeps
+// its own contiguous eighth of a frame instead of every eighth block of it.
+#ifndef CAMPX_RENDER_WAVES
+#define CAMPX_RENDER_WAVES 4
+#endif
+#ifndef CAMPX_RENDER_WIN
+#define CAMPX_RENDER_WIN 2
+#endif
+#ifndef CAMPX_RENDER_XCD
+#define CAMPX_RENDER_XCD 0
+#endif
+constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
+
 template <int K, bool kBoard, bool kNT, int kWin, int kFmt>
-__global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
+__global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderParams rp,
                                                      const CampxSpec* __restrict__ spec,
                                                      const uint8_t* __restrict__ trace,
                                                      int8_t* __restrict__ dst, int64_t n_rows) {
-  __shared__ __attribute__((aligned(16))) int8_t lds[4 * kWin * 1024];
-  __shared__ uint16_t scen_off_all[4][CAMPX_MAX_CELLS];
+  __shared__ __attribute__((aligned(16))) int8_t lds[kRenderWaves * kWin * 1024];
+  __shared__ uint16_t scen_off_all[kRenderWaves][CAMPX_MAX_CELLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // this wave's kWin consecutive KiB windows of the frame
-  const uint32_t woff0 = (blockIdx.x * 4u + (uint32_t)wave) * (1024u * kWin);
+  uint32_t bx = blockIdx.x;
+#if CAMPX_RENDER_XCD
+  if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+#endif
+  const uint32_t woff0 = (bx * (uint32_t)kRenderWaves + (uint32_t)wave) * (1024u * kWin);
   if (woff0 >= rp.slab_bytes) return;
   int8_t* win0 = lds + wave * (kWin * 1024);
   uint16_t* scen_off = scen_off_all[wave];
@@ -1234,21 +1255,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
   constexpr int P = kBoard ? K : 2 * K;                // patches per row
   const uint8_t* frame_trace = trace + (int64_t)blockIdx.y * rp.B;
 
-  // ---- scenery: issue all loads, then park them in LDS
-  u32x4 scen[kWin];
-#pragma unroll
-  for (int j = 0; j < kWin; ++j) {
-    const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
-    const uint32_t hi = __umulhi(rp.m, off);
-    const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
-    const int k = (int)(off - row * rp.R);                           // off % R
-    scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
-  }
-  // the scenery layer of two cells per lane (kBoard needs none of it)
-  uint32_t top2 = 0;
-  if (!kBoard) top2 = *reinterpret_cast<const uint16_t*>(spec->static_top_layer + 2 * lane);
-
-  // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear)
+  // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear).
+  // Their trace bytes come from HBM / L2: issue those loads first.
   const uint32_t span = 1024u * kWin;
   const uint32_t whi = __umulhi(rp.m, woff0);
   const uint32_t first_row = (((woff0 - whi) >> rp.sh1) + whi) >> rp.sh2;
@@ -1267,6 +1275,21 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams rp,
     row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
     ent[it] = (it == 0 || slots > kWave) ? frame_trace[(int64_t)d * n_rows + row] : 0u;
   }
+
+  // ---- scenery: issue all loads, then park them in LDS
+  u32x4 scen[kWin];
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+    const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
+    const uint32_t hi = __umulhi(rp.m, off);
+    const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
+    const int k = (int)(off - row * rp.R);                           // off % R
+    scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+  }
+  // the scenery layer of two cells per lane (kBoard needs none of it)
+  uint32_t top2 = 0;
+  if (!kBoard) top2 = *reinterpret_cast<const uint16_t*>(spec->static_top_layer + 2 * lane);
+
 #pragma unroll
   for (int j = 0; j < kWin; ++j)
     *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16) = scen[j];
@@ -1531,13 +1554,13 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
     rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
     rp.dyn_off[d] = s.dyn_layer[d] * HW;
   }
-  constexpr int kWin = 2;  // KiB windows per wave: 1 / 2 / 4 measured 0.227 / 0.197 / 0.211 ms
-  const uint32_t span = 4096u * (uint32_t)kWin;
+  constexpr int kWin = CAMPX_RENDER_WIN;  // KiB windows per wave: 1 / 2 / 4 measured 0.227 / 0.197 / 0.211 ms
+  const uint32_t span = 1024u * (uint32_t)(kWin * kRenderWaves);
   const dim3 grid((rp.slab_bytes + span - 1u) / span, (unsigned)T);
   const int64_t n_rows = (int64_t)T * B;
   const bool nt = knob_store_nt();
 #define CAMPX_RENDER4(KK, BOARD, NT, FMT)                                                   \
-  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, kWin, FMT>), grid, dim3(256), 0, stream, \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, kWin, FMT>), grid, dim3(kRenderWaves * kWave), 0, stream, \
                      rp, spec_dev, trace, dst, n_rows)
 #define CAMPX_RENDER3(KK, BOARD, NT)                               \
   do {                                                             \
@@ -1578,26 +1601,38 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
   return true;
 }
 
-// Shape of the update kernels' workgroups (A/B builds): producer and consumer waves.
+// Shape of the update kernels' workgroups: producer and consumer waves (A/B builds can
+// override).  Measured, whole rollout launch at the BASELINE sizes (gpurun_out/r2a):
+// one-mover table kernel, boat race: (1,1) 0.2006, (1,3) 0.2112, (2,2) 0.2034,
+// (2,4) 0.2005, (4,4) 0.1946 ms - the 256-environment workgroup writes 1 KiB / 256 B row
+// pieces instead of 512 / 128 B; pair kernel, sokoban: (1,1) 0.4432, (2,2) 0.4518,
+// (4,4) 0.4483 ms (its 32 KiB LDS table limits residency, smaller workgroups pack better).
 #ifndef CAMPX_UPD_PROD
-#define CAMPX_UPD_PROD 2
+#define CAMPX_UPD_PROD 4
 #endif
 #ifndef CAMPX_UPD_CONS
-#define CAMPX_UPD_CONS 2
+#define CAMPX_UPD_CONS 4
+#endif
+#ifndef CAMPX_PAIR_PROD
+#define CAMPX_PAIR_PROD 1
+#endif
+#ifndef CAMPX_PAIR_CONS
+#define CAMPX_PAIR_CONS 1
 #endif
 
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
-  constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS;
-  constexpr int kEnvs = kProd * kWave;
-  const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block((kProd + kCons + 1) * kWave);
   if (use_table) {
+    constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
+    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block((kProd + kCons + 1) * kWave);
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
     hipLaunchKernelGGL((update_table_kernel<kProd, kCons>), grid, block, 0, stream, mp, spec_dev,
                        st, actions, out, B, T, reset_first);
   } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
+    constexpr int kProd = CAMPX_PAIR_PROD, kCons = CAMPX_PAIR_CONS, kEnvs = kProd * kWave;
+    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block((kProd + kCons + 1) * kWave);
     PairParams pp;
     memset(&pp, 0, sizeof(pp));
     pp.rows = s.rows;

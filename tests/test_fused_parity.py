@@ -191,8 +191,14 @@ def test_reset_first_starts_new_episode(golden):
   a = game.rollout(acts, reset_first=True)
   b = game.rollout(acts, reset_first=True)
   assert torch.equal(a['obs'], b['obs']) and torch.equal(a['reward'], b['reward'])
-  # the running return restarted with the episode
-  assert _same(game.fused.ret.cpu().numpy(), b['reward'].sum(0).cpu().numpy())
+  # the running return restarted with the episode: it holds the rewards since the last
+  # rebuild (the frame after the latest termination before the final frame)
+  reward, done = b['reward'].cpu().numpy(), b['done'].cpu().numpy()
+  want = np.zeros(reward.shape[1], np.float32)
+  for t in range(reward.shape[0]):
+    restart = done[t - 1] == 1 if t else np.ones(reward.shape[1], bool)
+    want = np.where(restart, 0, want).astype(np.float32) + reward[t]
+  assert _same(game.fused.ret.cpu().numpy(), want)
 
 
 def _oracle_frames(og, actions, frames):
