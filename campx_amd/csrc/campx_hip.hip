@@ -661,6 +661,70 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
   report_bad_actions(out, bad);
 }
 
+// ---------------------------------------------------------------------------
+// One frame of a one-mover game: Engine.play().  There is no chain to follow, so this
+// is a one-shot kernel with two memory round trips: {state, action, scenery image} ->
+// table entry -> patch the image in LDS -> stream out.  The table entry carries what
+// painting the mover at its new cell needs (`paint`: scenery layer there, hidden flag),
+// so nothing else depends on it.  One wave = one workgroup = 64 environments.
+template <bool kBoard>
+__global__ __launch_bounds__(kWave) void step_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t reset_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const int lane = threadIdx.x;
+  const int W = mp.cols, HW = mp.rows * mp.cols, LHW = mp.n_layers * HW;
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
+  const bool live = env < B;
+  const int n_live = (B - env0 < kWave) ? (int)(B - env0) : kWave;
+  int8_t* obs_img = lds;
+  int8_t* board_img = lds + ((kWave * LHW + 15) & ~15);
+
+  int r = mp.row0, c = mp.col0, over = 0, a = 4;
+  float ret = 0.0f;
+  if (live) {
+    a = actions[env];
+    if (!reset_first) {
+      r = st.pos[env];
+      c = st.pos[B + env];
+      over = st.done[env];
+      if (st.ret) ret = st.ret[env];
+    }
+  }
+  fill_image(obs_img, kWave, LHW, spec->rot_obs, true, nullptr, lane);
+  if (kBoard) fill_image(board_img, kWave, HW, spec->rot_board, true, nullptr, lane);
+
+  const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
+  a = ((unsigned)a > 4u) ? 4 : a;
+  // a finished episode is rebuilt from the art before its next action
+  int cell = over ? mp.row0 * W + mp.col0 : r * W + c;
+  ret = over ? 0.0f : ret;
+  const CampxTransition tr = spec->table[cell * CAMPX_N_ACTIONS + a];
+  cell = tr.next_cell;
+  ret += tr.reward;
+  if (!(tr.paint & 0x80u)) {   // the mover shows at its cell
+    int8_t* my_obs = obs_img + lane * LHW;
+    my_obs[(int)(tr.paint & 0x7fu) * HW + cell] = 0;
+    my_obs[mp.dyn_layer * HW + cell] = 1;
+    if (kBoard) board_img[lane * HW + cell] = (int8_t)spec->layer_char[mp.dyn_layer];
+  }
+  if (live) {
+    if (out.reward) out.reward[env] = tr.reward;
+    if (out.discount) out.discount[env] = tr.done ? 0.0f : 1.0f;
+    if (out.done) out.done[env] = tr.done;
+    if (out.perf) out.perf[env] = tr.perf;
+    st.pos[env] = (int8_t)(cell / W);
+    st.pos[B + env] = (int8_t)(cell % W);
+    st.done[env] = tr.done;
+    if (st.ret) st.ret[env] = ret;
+  }
+  // one wave: LDS operations complete in order, no barrier needed
+  stream_out<false>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+  if (kBoard) stream_out<false>(board_img, out.board + env0 * HW, n_live * HW, lane);
+  report_bad_actions(out, bad);
+}
+
 size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   size_t n = (size_t)((envs * LHW + 15) & ~15);
@@ -1420,6 +1484,13 @@ bool knob_no_split() {
   }();
   return off;
 }
+bool knob_no_step() {
+  static const bool off = [] {
+    const char* v = getenv("CAMPX_NO_STEP");
+    return v && v[0] == '1';
+  }();
+  return off;
+}
 bool knob_no_table() {
   static const bool off = [] {
     const char* v = getenv("CAMPX_NO_TABLE");
@@ -1516,6 +1587,25 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   }
 #undef CAMPX_LAUNCH
 #undef CAMPX_LAUNCH_E
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t launch_step_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                          const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
+                          hipStream_t stream) {
+  const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
+  const bool board = out.board != nullptr;
+  const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                          s.dyn_row0[0], s.dyn_col0[0]};
+  if (board)
+    hipLaunchKernelGGL(step_table_kernel<true>, grid, block, shmem, stream, mp, spec_dev, st,
+                       actions, out, B, reset_first);
+  else
+    hipLaunchKernelGGL(step_table_kernel<false>, grid, block, shmem, stream, mp, spec_dev, st,
+                       actions, out, B, reset_first);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
@@ -1685,6 +1775,8 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (!emit_first && !interpreter_only && split_ok(*spec_host, out, B, T))
     return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;  // 16-bit needs the render kernel
+  if (use_table && T == 1 && !emit_first && spec_host->render_valid && !knob_no_step())
+    return launch_step_table(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {
@@ -1845,7 +1937,8 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
     tr.next_cell = (uint8_t)((int)h_pos[i] * W + (int)h_pos[n + i]);
     tr.done = h_done[i];
     tr.perf = spec->perf_dyn >= 0 ? h_perf[i] : (int8_t)0;
-    tr.reserved = 0;
+    tr.paint = (uint8_t)(spec->static_top_layer[tr.next_cell] |
+                         (spec->static_top_z[tr.next_cell] > spec->dyn_z[0] ? 0x80u : 0u));
   }
   spec->table_valid = 1;
 done:

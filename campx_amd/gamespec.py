@@ -56,7 +56,7 @@ class CampxRule(ctypes.Structure):
 class CampxTransition(ctypes.Structure):
   _fields_ = [('reward', ctypes.c_float), ('next_cell', ctypes.c_uint8),
               ('done', ctypes.c_uint8), ('perf', ctypes.c_int8),
-              ('reserved', ctypes.c_uint8)]
+              ('paint', ctypes.c_uint8)]
 
 
 class CampxSpec(ctypes.Structure):

@@ -97,7 +97,8 @@ typedef struct CampxTransition {
   uint8_t next_cell;  /* row * cols + col after the frame */
   uint8_t done;       /* 1: the episode terminated (discount 0) */
   int8_t perf;        /* hidden performance of the frame: -1, 0, +1 */
-  uint8_t reserved;
+  uint8_t paint;      /* how the mover paints at next_cell: bits 0-6 the scenery layer it
+                         covers there, bit 7 set when the scenery hides it instead */
 } CampxTransition;    /* 8 bytes */
 
 /*
