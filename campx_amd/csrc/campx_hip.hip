@@ -843,6 +843,11 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
   return (a & 0xffu) | ((b & 0xffu) << 8) | ((c & 0xffu) << 16) | (d << 24);
 }
 
+// A/B: give each XCD a contiguous eighth of the batch (see tile_of_block).
+#ifndef CAMPX_UPD_XCD
+#define CAMPX_UPD_XCD 0
+#endif
+
 template <int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
@@ -860,7 +865,7 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kern
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave == kProd + kCons;
   const int W = mp.cols, HW = mp.rows * mp.cols;
-  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
   const bool wide = (B & 15) == 0;  // 16-byte global accesses need 16-environment alignment
 
   const int cell0 = mp.row0 * W + mp.col0;
@@ -1033,8 +1038,12 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kern
 
 // ---------------------------------------------------------------------------
 // Two-mover games: the same layout over the (cell, cell, action) pair table
-// (campx_pair_table_build).  The table sits in LDS when it fits (kLds) and is read
-// through L1/L2 otherwise; the ring holds the table entries themselves.
+// (campx_pair_table_build).  The dependent chain goes through the table's compact
+// 16-bit half - entry -> index of the next frame's entries - which sits in LDS when it
+// fits (kChain 1; 2 = read through L1/L2); the 32-bit entries with everything a frame
+// outputs are fetched off the chain, straight from global memory (L1/L2-resident), as
+// each index becomes known, and go to the ring as they are.  Boards too large for
+// 16-bit indices chain through the entries themselves (kChain 0).
 struct PairParams {
   int32_t rows, cols, n_layers;
   int32_t dyn_layer[2], row0[2], col0[2];
@@ -1044,33 +1053,35 @@ struct PairParams {
 #ifndef CAMPX_PAIR_LDS_ENTRIES
 #define CAMPX_PAIR_LDS_ENTRIES 8192
 #endif
-constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 32 KiB of LDS for the table
+constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 16 KiB of LDS for the chain table
 
 __device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW) {
   return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;
 }
 
-template <bool kLds, int kProd, int kCons>
+template <int kChain, int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
-  __shared__ uint32_t lds_entries[kLds && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
+  __shared__ uint16_t lds_chain[kChain == 1 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
   __shared__ float reward_list[256];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave == kProd + kCons;
   const int W = pp.cols, HW = pp.rows * pp.cols;
-  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
   const bool wide = (B & 15) == 0;
 
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
   const int n_entries = HW * HW * CAMPX_N_ACTIONS;
-  if (kLds)
-    for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
+  const uint16_t* g_chain = reinterpret_cast<const uint16_t*>(g_entries + n_entries);
+  if (kChain == 1)
+    for (int i = threadIdx.x; i < (n_entries + 1) / 2; i += kThreads)
+      reinterpret_cast<uint32_t*>(lds_chain)[i] = reinterpret_cast<const uint32_t*>(g_chain)[i];
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
   ActionLoader<E> ld;
   int bad = 0;
@@ -1099,6 +1110,8 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
   }
   const int clane = (int)threadIdx.x - kProd * kWave;
   constexpr int kGroupsPerChunk = kChunk / kGroup;
+  // the chain's state: index of the entries the next frame starts from
+  uint32_t base = over ? pair_index(init0, init1, HW) : pair_index(c0, c1, HW);
   __syncthreads();
 
   const int n_groups = (T + kGroup - 1) / kGroup;
@@ -1115,20 +1128,42 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
           const int a = my_actions[j * E];
           act[j] = ((unsigned)a > 4u) ? 4u : (uint32_t)a;
         }
+        if (kChain == 0) {
 #pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          if (j < n) {
-            if (over) {  // rebuilt from the art before its next action
-              c0 = init0;
-              c1 = init1;
+          for (int j = 0; j < kGroup; ++j) {
+            if (j < n) {
+              if (over) {  // rebuilt from the art before its next action
+                c0 = init0;
+                c1 = init1;
+              }
+              const uint32_t idx = pair_index(c0, c1, HW) + act[j];
+              const uint32_t e = g_entries[idx];
+              c0 = e & 0x7fu;
+              c1 = (e >> 7) & 0x7fu;
+              ring[g & 1][j][le] = e;
+              ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
+              over = (int)((e >> 16) & 1u);
             }
-            const uint32_t idx = pair_index(c0, c1, HW) + act[j];
-            const uint32_t e = kLds ? lds_entries[idx] : g_entries[idx];
-            c0 = e & 0x7fu;
-            c1 = (e >> 7) & 0x7fu;
-            ring[g & 1][j][le] = e;
-            ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
-            over = (int)((e >> 16) & 1u);
+          }
+        } else {
+          uint32_t e[kGroup];
+#pragma unroll
+          for (int j = 0; j < kGroup; ++j) {
+            if (j < n) {
+              const uint32_t idx = base + act[j];
+              base = kChain == 1 ? lds_chain[idx] : g_chain[idx];   // the dependent chain
+              e[j] = g_entries[idx];                                // off the chain
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < kGroup; ++j) {
+            if (j < n) {
+              ring[g & 1][j][le] = e[j];
+              ret = (over ? 0.0f : ret) + reward_list[(e[j] >> 19) & 0xffu];
+              over = (int)((e[j] >> 16) & 1u);
+              c0 = e[j] & 0x7fu;
+              c1 = (e[j] >> 7) & 0x7fu;
+            }
           }
         }
       }
@@ -1284,15 +1319,22 @@ struct RenderParams {
 // there is no workgroup barrier.
 // A/B knobs of the render kernel's shape: waves per block, KiB windows per wave, and
 // whether block indices are remapped so that each XCD (block b runs on XCD b % 8) sweeps
-// its own contiguous eighth of a frame instead of every eighth block of it.
+// its own contiguous eighth of a frame instead of every eighth block of it (neighbouring
+// windows then share trace lines inside ONE L2).  Measured with rocprofv3, avg of 63
+// launches (gpurun_out/r2c), boat race / wall world / sokoban render in us:
+//   4 waves, 2 KiB, no remap   176.9 / 2006.7 / 361.8
+//   4 waves, 2 KiB, remap      173.5 / 1877.2 / 362.3
+//   2 waves, 2 KiB, remap      172.7 / 1873.7 / 363.6   <- default
+//   4 waves, 4 KiB, remap      190.3 / 2099.3 / 362.3
+//   2 waves, 4 KiB, remap      177.7 / 1984.6 / 356.0
 #ifndef CAMPX_RENDER_WAVES
-#define CAMPX_RENDER_WAVES 4
+#define CAMPX_RENDER_WAVES 2
 #endif
 #ifndef CAMPX_RENDER_WIN
 #define CAMPX_RENDER_WIN 2
 #endif
 #ifndef CAMPX_RENDER_XCD
-#define CAMPX_RENDER_XCD 0
+#define CAMPX_RENDER_XCD 1
 #endif
 constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 
@@ -1307,7 +1349,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   // this wave's kWin consecutive KiB windows of the frame
   uint32_t bx = blockIdx.x;
 #if CAMPX_RENDER_XCD
-  if ((gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+  bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);     // gridDim.x is a multiple of 8
 #endif
   const uint32_t woff0 = (bx * (uint32_t)kRenderWaves + (uint32_t)wave) * (1024u * kWin);
   if (woff0 >= rp.slab_bytes) return;
@@ -1646,7 +1688,8 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   }
   constexpr int kWin = CAMPX_RENDER_WIN;  // KiB windows per wave: 1 / 2 / 4 measured 0.227 / 0.197 / 0.211 ms
   const uint32_t span = 1024u * (uint32_t)(kWin * kRenderWaves);
-  const dim3 grid((rp.slab_bytes + span - 1u) / span, (unsigned)T);
+  // rounded up to a multiple of 8 for the XCD remap; surplus blocks exit at once
+  const dim3 grid((((rp.slab_bytes + span - 1u) / span) + 7u) & ~7u, (unsigned)T);
   const int64_t n_rows = (int64_t)T * B;
   const bool nt = knob_store_nt();
 #define CAMPX_RENDER4(KK, BOARD, NT, FMT)                                                   \
@@ -1704,10 +1747,10 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 #define CAMPX_UPD_CONS 4
 #endif
 #ifndef CAMPX_PAIR_PROD
-#define CAMPX_PAIR_PROD 1
+#define CAMPX_PAIR_PROD 4
 #endif
 #ifndef CAMPX_PAIR_CONS
-#define CAMPX_PAIR_CONS 1
+#define CAMPX_PAIR_CONS 4
 #endif
 
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
@@ -1734,11 +1777,14 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
       pp.col0[d] = s.dyn_col0[d];
     }
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
-    if (n_entries <= kPairLdsEntries)
-      hipLaunchKernelGGL((update_pair_kernel<true, kProd, kCons>), grid, block, 0, stream, pp,
+    if (n_entries > 65535)
+      hipLaunchKernelGGL((update_pair_kernel<0, kProd, kCons>), grid, block, 0, stream, pp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    else if (n_entries <= kPairLdsEntries)
+      hipLaunchKernelGGL((update_pair_kernel<1, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
     else
-      hipLaunchKernelGGL((update_pair_kernel<false, kProd, kCons>), grid, block, 0, stream, pp,
+      hipLaunchKernelGGL((update_pair_kernel<2, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
   } else {
     switch (s.n_dyn) {
@@ -1950,7 +1996,9 @@ done:
 int64_t campx_pair_table_bytes(const CampxSpec* spec) {
   if (!spec || campx_spec_validate(spec) != CAMPX_OK || spec->n_dyn != 2) return 0;
   const int64_t HW = (int64_t)spec->rows * spec->cols;
-  const int64_t bytes = 256 * (int64_t)sizeof(float) + HW * HW * CAMPX_N_ACTIONS * (int64_t)sizeof(uint32_t);
+  const int64_t n = HW * HW * CAMPX_N_ACTIONS;
+  int64_t bytes = 256 * (int64_t)sizeof(float) + n * (int64_t)sizeof(uint32_t);
+  if (n <= 65535) bytes += (n * (int64_t)sizeof(uint16_t) + 15) & ~(int64_t)15;  // chain table
   return bytes <= (1 << 20) ? bytes : 0;
 }
 
@@ -2055,6 +2103,18 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
     h_entries[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
                    ((uint32_t)(h_done[i] & 1) << 16) |
                    ((uint32_t)(perf + 1) << 17) | ((uint32_t)idx << 19);
+  }
+  if (n <= 65535) {
+    // chain table: where the NEXT frame's lookup starts, (cell0 * HW + cell1) * 5, with
+    // the rebuild from the art folded in for frames that end the episode
+    uint16_t* h_chain = reinterpret_cast<uint16_t*>(h_entries + n);
+    const uint32_t init = ((uint32_t)(spec->dyn_row0[0] * W + spec->dyn_col0[0]) * (uint32_t)HW +
+                           (uint32_t)(spec->dyn_row0[1] * W + spec->dyn_col0[1])) * CAMPX_N_ACTIONS;
+    for (int i = 0; i < n; ++i) {
+      const uint32_t e = h_entries[i];
+      const uint32_t next = ((e & 0x7fu) * (uint32_t)HW + ((e >> 7) & 0x7fu)) * CAMPX_N_ACTIONS;
+      h_chain[i] = (uint16_t)(((e >> 16) & 1u) ? init : next);
+    }
   }
   CAMPX_TRY(hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s));
   CAMPX_TRY(hipStreamSynchronize(s));

@@ -230,11 +230,14 @@ int32_t campx_spec_compile(CampxSpec* spec_host, void* stream);
  * way campx_spec_compile() does for one-mover games (set-up time only: scratch
  * allocation + stream synchronisation inside).  Returns CAMPX_ESPEC when a frame of
  * this game can pay more than 256 distinct rewards (the table indexes a reward list).
- * Layout: 256 floats (reward list), then rows*cols * rows*cols * 5 uint32 entries,
+ * Layout: 256 floats (reward list), then n = rows*cols * rows*cols * 5 uint32 entries,
  * index ((cell0 * rows*cols) + cell1) * 5 + action:
  *   bits 0-6 cell of thing 0 after the frame, 7-13 cell of thing 1, 14/15 whether
  *   thing 0 / 1 is the character its cell shows, 16 done, 17-18 perf + 1,
- *   19-26 index into the reward list.
+ *   19-26 index into the reward list;
+ * then, when n <= 65535, n uint16 "chain" entries (padded to 16 bytes): the index
+ * (cell0' * rows*cols + cell1') * 5 the next frame's lookup starts from, the art's cells
+ * when the frame ended the episode - the only thing the frame-to-frame dependency needs.
  */
 int64_t campx_pair_table_bytes(const CampxSpec* spec_host);
 int32_t campx_pair_table_build(const CampxSpec* spec_host, const CampxSpec* spec_dev,
