@@ -1066,6 +1066,7 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
     int32_t reset_first) {
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
   __shared__ uint16_t lds_chain[kChain == 1 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
+  __shared__ uint32_t lds_entries[kChain == 3 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
   __shared__ float reward_list[256];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
@@ -1082,6 +1083,8 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
   if (kChain == 1)
     for (int i = threadIdx.x; i < (n_entries + 1) / 2; i += kThreads)
       reinterpret_cast<uint32_t*>(lds_chain)[i] = reinterpret_cast<const uint32_t*>(g_chain)[i];
+  if (kChain == 3)
+    for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
   ActionLoader<E> ld;
   int bad = 0;
@@ -1128,7 +1131,7 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
           const int a = my_actions[j * E];
           act[j] = ((unsigned)a > 4u) ? 4u : (uint32_t)a;
         }
-        if (kChain == 0) {
+        if (kChain == 0 || kChain == 3) {
 #pragma unroll
           for (int j = 0; j < kGroup; ++j) {
             if (j < n) {
@@ -1137,7 +1140,7 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
                 c1 = init1;
               }
               const uint32_t idx = pair_index(c0, c1, HW) + act[j];
-              const uint32_t e = g_entries[idx];
+              const uint32_t e = kChain == 3 ? lds_entries[idx] : g_entries[idx];
               c0 = e & 0x7fu;
               c1 = (e >> 7) & 0x7fu;
               ring[g & 1][j][le] = e;
@@ -1533,6 +1536,13 @@ bool knob_no_step() {
   }();
   return off;
 }
+int knob_pair_mode() {
+  static const int m = [] {
+    const char* v = getenv("CAMPX_PAIR_MODE");
+    return v ? atoi(v) : 3;
+  }();
+  return m;
+}
 bool knob_no_table() {
   static const bool off = [] {
     const char* v = getenv("CAMPX_NO_TABLE");
@@ -1777,10 +1787,18 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
       pp.col0[d] = s.dyn_col0[d];
     }
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
-    if (n_entries > 65535)
+    // 3: entries in LDS, the chain goes through them; 1 / 2: 16-bit chain table in LDS /
+    // global with the entries fetched off the chain; 0: everything through L1/L2.
+    // Measured on sokoban (us per 100-frame launch, B = 131 072, (4,4) waves): 3: 51.4,
+    // 1: 68.9 (the per-lane random entry loads cost more than the shorter chain saves).
+    const int mode = knob_pair_mode();
+    if (n_entries > 65535 || mode == 0)
       hipLaunchKernelGGL((update_pair_kernel<0, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
-    else if (n_entries <= kPairLdsEntries)
+    else if (n_entries <= kPairLdsEntries && mode == 3)
+      hipLaunchKernelGGL((update_pair_kernel<3, kProd, kCons>), grid, block, 0, stream, pp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    else if (n_entries <= kPairLdsEntries && mode == 1)
       hipLaunchKernelGGL((update_pair_kernel<1, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
     else

@@ -12,7 +12,7 @@ for v in "$@"; do
   for g in $games; do
     d=/tmp/kt_${v}_$g
     rm -rf $d
-    (cd /tmp && CAMPX_LIB=$GRAFT_REPO_ROOT/build/variants/$v/libcampx_hip.so timeout 300 rocprofv3 --kernel-trace -d $d -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --game $g --steps 30 --warmup 3 --no-cpu-baseline --no-extras > $O/kt_${v}_$g.log 2>&1)
+    (cd /tmp && CAMPX_LIB=$GRAFT_REPO_ROOT/build/variants/$v/libcampx_hip.so timeout 300 rocprofv3 --kernel-trace -d $d -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --game $g --steps 30 --warmup 3 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} > $O/kt_${v}_$g.log 2>&1)
     python3 - $d/trace_results.db $v $g <<'PY'
 import sqlite3, sys
 db, v, g = sys.argv[1:4]
@@ -26,7 +26,7 @@ try:
     n = n.replace('(anonymous namespace)::', '').split('(')[0]
     tot += a
     print('KT %-10s %-10s %-44s n=%3d avg=%8.2f min=%8.2f max=%8.2f' % (v, g, n[:44], c, a/1e3, mn/1e3, mx/1e3))
-  print('KT %-10s %-10s SUM avg=%8.2f' % (v, g, tot/1e3))
+  print('KT %-10s %-10s SUM avg=%8.2f %s' % (v, g, tot/1e3, __import__('os').environ.get('BENCH_ARGS','')))
 except Exception as e:
   print('KT', v, g, 'failed', e)
 PY
