@@ -64,6 +64,9 @@ def parse_args(argv=None):
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-extras', action='store_true',
                  help='skip play()-mode and the wall_world / sokoban side measurements')
+  p.add_argument('--no-pipeline', action='store_true',
+                 help='issue each rollout as one in-order op instead of update pass (side '
+                      'stream, overlapping the previous launch) + render')
   p.add_argument('--gather-every', type=int, default=8,
                  help='episodes per RCCL all-gather of the episode-return log')
   p.add_argument('--force-dist', action='store_true',
@@ -197,7 +200,7 @@ def kernel_names(fused, split):
 
 
 def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_every,
-                    standin=None):
+                    standin=None, pipelined=True):
   """Warm up, then time exactly `steps` rollout launches.  Returns a dict.
 
   Wall clock: perf_counter around the timed region, bracketed by synchronize +
@@ -223,8 +226,12 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   gen = torch.Generator(device='cpu').manual_seed(0xC0FFEE + rank)
   streams = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8)
              .to(device) for _ in range(2)]
-  # Output buffers are allocated once; a step is then a single op dispatch.
-  bufs = fused.rollout_buffers(T)
+  # Output buffers are allocated once; a step is then op dispatches only.  Pipelined
+  # rollouts (the update pass of launch i+1 overlaps the observation stream of launch
+  # i) alternate two sets of scalars / trace over one observation buffer.
+  bufs = [fused.rollout_buffers(T)]
+  bufs.append(fused.rollout_buffers(T, share=bufs[0]) if pipelined else bufs[0])
+  pipelined = pipelined and bufs[0].get('trace') is not None
   log = None
   if dist is not None:
     # Episode returns are logged per rank and all-gathered every `gather_every`
@@ -237,7 +244,8 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   def one_step(i):
     if log is not None:
       fused.ret = log.row()
-    out = fused.rollout(streams[i & 1], out=bufs, reset_first=True)
+    out = fused.rollout(streams[i & 1], out=bufs[i & 1], reset_first=True,
+                        pipelined=pipelined)
     if log is not None:
       log.episode_done()
     return out
@@ -271,7 +279,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  result = dict(fused=fused, elapsed=elapsed, log=log, out=out,
+  result = dict(fused=fused, elapsed=elapsed, log=log, out=out, pipelined=pipelined,
                 mean_return=float(out['reward'].sum(0).mean())
                 if out['reward'] is not None else None)
   if on_gpu:
@@ -308,8 +316,10 @@ def roofline(game_name, B, T, fused, kernel_ms, per_launch):
       'traffic_note': 'HBM bytes per launch (WRITE_SIZE + FETCH_SIZE, separate '
                       'rocprofv3 --pmc passes, profiles/r02_traffic.json)',
       'kernel': kernel_names(fused, split),
-      'kernel_note': 'kernel_ms = HIP-event time around the timed launches / steps: '
-                     'every kernel of a rollout launch plus the gaps between launches',
+      'kernel_note': 'kernel_ms = HIP-event time on the launch stream around the timed '
+                     'launches / steps: every kernel of a rollout launch plus the gaps '
+                     'between launches (pipelined: the update pass of launch i+1 runs on '
+                     'a side stream under the render of launch i, which waits for it)',
       'kernel_ms': kernel_ms,
       'per_launch_ms': per_launch,
       'bytes_per_env_step': BYTES_PER_ENV_STEP[game_name],
@@ -371,7 +381,7 @@ def run_rank(args):
   B = args.batch or default_batch
   T = args.frames
   m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
-                      args.gather_every, standin)
+                      args.gather_every, standin, not args.no_pipeline)
   fused, elapsed = m['fused'], m['elapsed']
 
   gathered_ok = None
@@ -405,6 +415,7 @@ def run_rank(args):
             'frames_per_step': T,
             'step': 'one rollout launch = one {}-frame episode for every '
                     'environment, all frames written to HBM'.format(T),
+            'pipelined': m['pipelined'],
             'parallelism': 'env-sharded x{}, {} all-gather of the episode-'
                            'return log every {} episodes, off the step path'
                            .format(world, 'gloo' if standin else 'RCCL',
@@ -436,7 +447,8 @@ def run_rank(args):
       for other in ('wall_world', 'sokoban'):
         oname, ob = WORKLOADS[other]
         steps = max(5, args.steps // 3)
-        om = measure_rollout(other, ob, T, steps, 3, device, 0, None, 0)
+        om = measure_rollout(other, ob, T, steps, 3, device, 0, None, 0,
+                             pipelined=not args.no_pipeline)
         also.append({
             'workload': '{}, batch={}, random actions, {} frames per launch'.format(
                 oname, ob, T),

@@ -23,7 +23,8 @@ _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
 EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
            'campx_pair_table_bytes', 'campx_pair_table_build',
            'campx_reset_launch',
-           'campx_rollout_launch', 'campx_check_actions_launch',
+           'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
+           'campx_check_actions_launch',
            'campx_onehot_to_ids_launch', 'campx_strerror',
            'campx_last_hip_error', 'campx_device_arch')
 
@@ -69,6 +70,11 @@ def _load():
   lib.campx_rollout_launch.restype = i32
   lib.campx_rollout_launch.argtypes = [spec_p, vp, CampxState, vp, CampxOutputs,
                                        i64, i32, i32, vp]
+  lib.campx_update_launch.restype = i32
+  lib.campx_update_launch.argtypes = [spec_p, vp, CampxState, vp, CampxOutputs,
+                                      i64, i32, i32, vp]
+  lib.campx_render_launch.restype = i32
+  lib.campx_render_launch.argtypes = [spec_p, vp, CampxOutputs, i64, i32, vp]
   lib.campx_check_actions_launch.restype = i32
   lib.campx_check_actions_launch.argtypes = [vp, i64, vp, vp]
   lib.campx_onehot_to_ids_launch.restype = i32
@@ -102,7 +108,8 @@ def _load_ops():
 
 
 ops = _load_ops()
-OP_NAMES = ('reset', 'step', 'rollout', 'onehot_to_ids', 'check_actions')
+OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'onehot_to_ids',
+            'check_actions')
 
 
 def check(code, what):

@@ -1763,7 +1763,7 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 #define CAMPX_PAIR_CONS 4
 #endif
 
-int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
   if (use_table) {
@@ -1814,10 +1814,23 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
+  return CAMPX_OK;
+}
+
+int32_t launch_renders(const CampxSpec& s, const CampxSpec* spec_dev, CampxOutputs out, int64_t B,
+                       int32_t T, hipStream_t stream) {
   int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, B, T, false, out.obs_format, stream);
   if (rc != CAMPX_OK) return rc;
   if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, B, T, true, 0, stream);
   return rc;
+}
+
+int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                     int32_t reset_first, bool use_table, hipStream_t stream) {
+  const int32_t rc = launch_update(s, spec_dev, st, actions, out, B, T, reset_first, use_table, stream);
+  if (rc != CAMPX_OK) return rc;
+  return launch_renders(s, spec_dev, out, B, T, stream);
 }
 
 int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
@@ -2152,6 +2165,32 @@ int32_t campx_rollout_launch(const CampxSpec* spec_host, const CampxSpec* spec_d
                              CampxState state, const int8_t* actions, CampxOutputs out, int64_t B,
                              int32_t T, int32_t reset_first, void* stream) {
   return launch(spec_host, spec_dev, state, actions, out, B, T, reset_first, 0, stream);
+}
+
+int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
+                            const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                            int32_t reset_first, void* stream) {
+  if (!spec_host || !spec_dev || !st.pos || !st.done || !actions || !out.trace || B <= 0 || T <= 0)
+    return CAMPX_EINVAL;
+  if (out.perf && spec_host->perf_dyn < 0) return CAMPX_EINVAL;
+  const int32_t v = campx_spec_validate(spec_host);
+  if (v != CAMPX_OK) return v;
+  if (!spec_host->render_valid) return CAMPX_ESPEC;
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 && !knob_no_table();
+  return launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
+                       static_cast<hipStream_t>(stream));
+}
+
+int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxOutputs out,
+                            int64_t B, int32_t T, void* stream) {
+  if (!spec_host || !spec_dev || !out.trace || !out.obs || B <= 0 || T <= 0) return CAMPX_EINVAL;
+  if (reinterpret_cast<uintptr_t>(out.obs) & 15) return CAMPX_EINVAL;
+  if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
+  const int32_t v = campx_spec_validate(spec_host);
+  if (v != CAMPX_OK) return v;
+  CampxOutputs probe = out;   // the conditions of the two-kernel path, frames back to back
+  if (!split_ok(*spec_host, probe, B, T)) return CAMPX_EINVAL;
+  return launch_renders(*spec_host, spec_dev, out, B, T, static_cast<hipStream_t>(stream));
 }
 
 int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* bad_count,

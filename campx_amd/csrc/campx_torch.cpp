@@ -8,6 +8,7 @@
 //   campx::reset    its_showtime(): state from the art + the first observation
 //   campx::step     one Engine.play() frame for B environments
 //   campx::rollout  T consecutive frames in one launch
+//   campx::update / campx::render   the two kernels of a rollout as separate ops
 //   campx::onehot_to_ids / campx::check_actions   action-format helpers
 //
 // Contract: every tensor is caller-owned and contiguous; outputs are written in
@@ -193,6 +194,68 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
            "campx_rollout_launch");
 }
 
+// The two halves of the two-kernel rollout path as ops of their own, so that a caller
+// can issue them on different streams (fused.py rollout(pipelined=True)).
+void update(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+            const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions,
+            const OptTensor& reward, const OptTensor& discount, const OptTensor& step_done,
+            const OptTensor& perf, Tensor& trace, const OptTensor& bad_count,
+            const OptTensor& bad_flag, bool reset_first) {
+  const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
+  TORCH_CHECK(actions.dim() == 2, "campx::update: actions must be int8 [T, B]");
+  const int64_t T = actions.size(0);
+  TORCH_CHECK(T >= 1 && T <= 0x7fffffff, "campx::update: bad frame count");
+  want(actions, "actions", at::kChar, g.dev, {T, g.B});
+  want(trace, "trace", at::kByte, g.dev, {g.K, T, g.B});
+  if (reward.has_value()) want(*reward, "reward", at::kFloat, g.dev, {T, g.B});
+  if (discount.has_value()) want(*discount, "discount", at::kFloat, g.dev, {T, g.B});
+  if (step_done.has_value()) want(*step_done, "step_done", at::kByte, g.dev, {T, g.B});
+  if (perf.has_value()) want(*perf, "perf", at::kChar, g.dev, {T, g.B});
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
+  CampxOutputs out{};
+  out.reward = opt_ptr<float>(reward);
+  out.discount = opt_ptr<float>(discount);
+  out.done = opt_ptr<uint8_t>(step_done);
+  out.perf = opt_ptr<int8_t>(perf);
+  out.trace = reinterpret_cast<uint8_t*>(trace.data_ptr());
+  out.bad_count = opt_ptr<int32_t>(bad_count);
+  out.bad_flag = flag_ptr(bad_flag, g.dev);
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
+  check_ok(campx_update_launch(g.spec_host, g.spec_dev, g.state,
+                               reinterpret_cast<const int8_t*>(actions.data_ptr()), out, g.B,
+                               (int32_t)T, reset_first ? 1 : 0,
+                               c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+           "campx_update_launch");
+}
+
+void render(const Tensor& spec_host, const Tensor& spec_dev, const Tensor& trace, Tensor& obs,
+            const OptTensor& board) {
+  const CampxSpec* hs = host_spec(spec_host);
+  TORCH_CHECK(trace.device().is_cuda() && trace.dim() == 3, "campx::render: trace must be a HIP uint8 [K, T, B] tensor");
+  const c10::Device dev = trace.device();
+  const int64_t K = hs->n_dyn, T = trace.size(1), B = trace.size(2);
+  want(trace, "trace", at::kByte, dev, {K, T, B});
+  TORCH_CHECK(spec_dev.device() == dev && spec_dev.scalar_type() == at::kByte &&
+                  spec_dev.is_contiguous() && spec_dev.numel() == (int64_t)sizeof(CampxSpec),
+              "campx: spec_dev must be the CampxSpec blob as a uint8 tensor on ", dev);
+  CampxOutputs out{};
+  out.obs_format = obs_format_of(obs);
+  want(obs, "obs", obs.scalar_type(), dev, {T, B, hs->n_layers, hs->rows, hs->cols});
+  out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.obs_t_stride = B * hs->n_layers * hs->rows * hs->cols;
+  if (board.has_value()) {
+    want(*board, "board", at::kChar, dev, {T, B, hs->rows, hs->cols});
+    out.board = opt_ptr<int8_t>(board);
+    out.board_t_stride = B * hs->rows * hs->cols;
+  }
+  out.trace = reinterpret_cast<uint8_t*>(trace.data_ptr());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+  check_ok(campx_render_launch(hs, reinterpret_cast<const CampxSpec*>(spec_dev.data_ptr()), out, B,
+                               (int32_t)T,
+                               c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+           "campx_render_launch");
+}
+
 // One Engine.play() frame: actions [B], per-frame outputs [B].
 void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
           const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions, Tensor& obs,
@@ -267,6 +330,10 @@ void rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTenso
 void step_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
                const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&) {}
+void update_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
+                 const Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
+                 const OptTensor&, Tensor&, const OptTensor&, const OptTensor&, bool) {}
+void render_meta(const Tensor&, const Tensor&, const Tensor&, Tensor&, const OptTensor&) {}
 void onehot_to_ids_meta(const Tensor&, Tensor&, Tensor&) {}
 void check_actions_meta(const Tensor&, Tensor&) {}
 
@@ -286,6 +353,14 @@ TORCH_LIBRARY(campx, m) {
       "Tensor? pair_table, Tensor actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
       "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!)? trace, "
       "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first) -> ()");
+  m.def(
+      "update(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
+      "Tensor? pair_table, Tensor actions, Tensor(d!)? reward, Tensor(e!)? discount, "
+      "Tensor(f!)? step_done, Tensor(g!)? perf, Tensor(h!) trace, Tensor(i!)? bad_count, "
+      "Tensor(j!)? bad_flag, bool reset_first) -> ()");
+  m.def(
+      "render(Tensor spec_host, Tensor spec_dev, Tensor trace, Tensor(a!) obs, Tensor(b!)? board) "
+      "-> ()");
   m.def("onehot_to_ids(Tensor onehot, Tensor(a!) ids, Tensor(b!) bad_count) -> ()");
   m.def("check_actions(Tensor actions, Tensor(a!) bad_count) -> ()");
 }
@@ -294,6 +369,8 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
   m.impl("reset", &reset);
   m.impl("step", &step);
   m.impl("rollout", &rollout);
+  m.impl("update", &update);
+  m.impl("render", &render);
   m.impl("onehot_to_ids", &onehot_to_ids);
   m.impl("check_actions", &check_actions);
 }
@@ -302,6 +379,8 @@ TORCH_LIBRARY_IMPL(campx, Meta, m) {
   m.impl("reset", &reset_meta);
   m.impl("step", &step_meta);
   m.impl("rollout", &rollout_meta);
+  m.impl("update", &update_meta);
+  m.impl("render", &render_meta);
   m.impl("onehot_to_ids", &onehot_to_ids_meta);
   m.impl("check_actions", &check_actions_meta);
 }

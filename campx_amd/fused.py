@@ -140,6 +140,12 @@ class FusedGame(object):
     self._observation_cache = self._observation(self._obs, self._board)
     self._step = _hip.ops.step.default
     self._rollout = _hip.ops.rollout.default
+    self._update = _hip.ops.update.default
+    self._render = _hip.ops.render.default
+    # pipelined rollouts: the update pass runs on this side stream
+    self._aux = None
+    self._aux_event = None
+    self._aux_in_sync = False
 
   # ------------------------------------------------------------------ helpers
 
@@ -213,6 +219,7 @@ class FusedGame(object):
     else:
       ids = self._action_ids(actions, (self.batch,))
     validate = self.validate_actions
+    self._aux_in_sync = False
     self._step(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
                self._pair_table, ids, self._obs, self._board, self._reward,
                self._discount, self._step_done, self._perf_arg,
@@ -225,20 +232,27 @@ class FusedGame(object):
             (self._reward if self.any_reward else None), self._discount)
 
   def rollout_buffers(self, T, keep_obs=True, want_board=False,
-                      obs_dtype=torch.int8):
-    """Allocate the output buffers of a T-frame rollout once, for `rollout(out=...)`."""
+                      obs_dtype=torch.int8, share=None):
+    """Allocate the output buffers of a T-frame rollout once, for `rollout(out=...)`.
+
+    `share`: another such dict whose 'obs' / 'board' tensors this one reuses (the
+    second buffer set of pipelined rollouts needs its own scalars and trace only).
+    """
     B, L, H, W, dev = self.batch, self.n_layers, self.rows, self.cols, self.device
     if obs_dtype not in _OBS_DTYPES:
       raise ValueError('obs_dtype must be torch.int8, float16 or bfloat16')
     sixteen = obs_dtype != torch.int8
     if sixteen and not keep_obs:
       raise ValueError('16-bit observations need keep_obs=True')
-    obs = (torch.empty((T, B, L, H, W), dtype=obs_dtype, device=dev)
-           if keep_obs else self._obs)
-    board = None
-    if want_board:
-      board = (torch.empty((T, B, H, W), dtype=torch.int8, device=dev)
-               if keep_obs else self._board)
+    if share is not None:
+      obs, board = share['obs'], share['board']
+    else:
+      obs = (torch.empty((T, B, L, H, W), dtype=obs_dtype, device=dev)
+             if keep_obs else self._obs)
+      board = None
+      if want_board:
+        board = (torch.empty((T, B, H, W), dtype=torch.int8, device=dev)
+                 if keep_obs else self._board)
     # The compact trajectory; giving it lets the library take its two-kernel path.
     # (Games with several movers interpret their rules per frame in one wave; for
     # them the single fused kernel is still the faster path unless forced.)
@@ -256,7 +270,7 @@ class FusedGame(object):
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True,
               reset_first=False, want_board=False, obs_dtype=torch.int8,
-              out=None):
+              out=None, pipelined=False):
     """T frames in one launch.
 
     Args:
@@ -277,6 +291,15 @@ class FusedGame(object):
           T and options) whose tensors are overwritten instead of allocating new
           ones: the whole call is then one op dispatch.  Overrides
           obs/board/keep_obs/want_board/obs_dtype.
+      pipelined: run this call's update pass (a short latency-bound kernel) on a side
+          stream so that it overlaps the observation stream of the PREVIOUS rollout,
+          which is still running on the current stream; the render kernel then waits
+          for it by event.  Results are identical; the caller promises two things the
+          engine cannot check: (1) `actions` are ready - not being produced by work
+          still queued on the current stream - and (2) `out` is not the dict of the
+          previous pipelined call (alternate two `rollout_buffers()`; they may share
+          `obs`).  Needs the two-kernel path (`out['trace']`).  Open-loop action
+          streams (random exploration, scripted or replayed episodes) are the use.
     Returns:
       dict with 'obs' ([T,B,L,H,W] or the last frame [B,L,H,W]), 'board' (or
       None), 'reward' [T,B] (None if the game never rewards), 'discount' [T,B],
@@ -305,11 +328,32 @@ class FusedGame(object):
       if board is not None:
         out['board'] = board
     validate = self.validate_actions
-    self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
-                  self._pair_table, ids, out['obs'], out['board'], out['reward'],
-                  out['discount'], out['done'], out['perf'], out['trace'],
-                  self._bad if validate else None,
-                  self._bad_flag if validate else None, bool(reset_first))
+    if pipelined:
+      if out['trace'] is None:
+        raise ValueError('pipelined rollouts need the two-kernel path (a trace buffer: '
+                         'keep_obs=True on a game whose update pass is tabulated)')
+      main = torch.cuda.current_stream(self.device)
+      if self._aux is None:
+        self._aux = torch.cuda.Stream(self.device)
+        self._aux_event = torch.cuda.Event()
+      if not self._aux_in_sync:
+        self._aux.wait_stream(main)      # once: state set up by earlier non-pipelined work
+        self._aux_in_sync = True
+      with torch.cuda.stream(self._aux):
+        self._update(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                     self._pair_table, ids, out['reward'], out['discount'], out['done'],
+                     out['perf'], out['trace'], self._bad if validate else None,
+                     self._bad_flag if validate else None, bool(reset_first))
+        self._aux_event.record(self._aux)
+      main.wait_event(self._aux_event)
+      self._render(self._spec_host, self._spec_dev, out['trace'], out['obs'], out['board'])
+    else:
+      self._aux_in_sync = False
+      self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                    self._pair_table, ids, out['obs'], out['board'], out['reward'],
+                    out['discount'], out['done'], out['perf'], out['trace'],
+                    self._bad if validate else None,
+                    self._bad_flag if validate else None, bool(reset_first))
     self.frame = T if reset_first else self.frame + T
     if validate:
       self._after_launch()

@@ -266,6 +266,27 @@ int32_t campx_rollout_launch(const CampxSpec* spec_host, const CampxSpec* spec_d
                              CampxState state, const int8_t* actions, CampxOutputs out, int64_t B,
                              int32_t T, int32_t reset_first, void* stream);
 
+/*
+ * The two halves of campx_rollout_launch()'s two-kernel path, for callers that want to
+ * overlap them across calls (the update pass of launch i+1 is a short, latency-bound
+ * kernel that fits under the observation stream of launch i when issued on another
+ * stream; campx_amd/fused.py `rollout(pipelined=True)`):
+ *
+ *   campx_update_launch   the update pass alone: reads state and actions, writes state,
+ *                         out.trace (required) and the per-frame scalars out.reward /
+ *                         discount / done / perf / bad_*; ignores out.obs / out.board.
+ *   campx_render_launch   expands out.trace into out.obs (and out.board): frames back to
+ *                         back (obs_t_stride == B*L*rows*cols, whole 16-byte multiples,
+ *                         T <= 65535), else CAMPX_EINVAL.  Reads nothing but the trace
+ *                         and the spec.
+ * update then render on one stream == campx_rollout_launch().
+ */
+int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState state,
+                            const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                            int32_t reset_first, void* stream);
+int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxOutputs out,
+                            int64_t B, int32_t T, void* stream);
+
 /* *bad_count (device int32, caller-zeroed) += number of ids outside 0..4 in
  * actions[0..n). */
 int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* bad_count,

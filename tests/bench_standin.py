@@ -25,10 +25,10 @@ class _Fused(object):
     self.validate_actions = True
     self.ret = torch.zeros(batch)
 
-  def rollout_buffers(self, T):
+  def rollout_buffers(self, T, share=None):
     return {}
 
-  def rollout(self, actions, out=None, reset_first=False):
+  def rollout(self, actions, out=None, reset_first=False, pipelined=False):
     ref = self._og.rollout(actions.numpy(), reset_first=reset_first, keep_obs=False,
                            want_board=False)
     reward = torch.from_numpy(ref['reward'])

@@ -142,3 +142,69 @@ def test_torch_compile_traces_through_the_op_without_a_graph_break(golden):
   assert torch.equal(a, b)
   assert torch.equal(game_c.fused._obs, game_e.fused._obs)
   assert torch.equal(game_c.fused.pos, game_e.fused.pos)
+
+
+@pytest.mark.gpu
+def test_play_is_capturable_in_a_hip_graph():
+  """campx::step only enqueues kernels on the current stream (no allocation, no
+  synchronisation), so a policy-in-the-loop stretch of play() calls can be captured in a
+  HIP graph and replayed: one graph launch for many frames."""
+  game_g, game_e = _game(1024), _game(1024)
+  for g in (game_g, game_e):
+    g.fused.validate_actions = False
+  w = torch.randn(7 * 25, 5, device='cuda')
+
+  def frames(game, n):
+    f = game.fused
+    for _ in range(n):
+      ids = (f._obs.view(f.batch, -1).float() @ w).argmax(dim=1).to(torch.int8)
+      game.play(ids)
+
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):
+    frames(game_g, 2)                          # warm up allocations outside the capture
+  torch.cuda.current_stream().wait_stream(side)
+  frames(game_e, 2)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    frames(game_g, 6)
+  for _ in range(3):
+    graph.replay()
+  frames(game_e, 18)
+  torch.cuda.synchronize()
+  assert torch.equal(game_g.fused._obs, game_e.fused._obs)
+  assert torch.equal(game_g.fused.pos, game_e.fused.pos)
+  assert torch.equal(game_g.fused.ret, game_e.fused.ret)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['boat_race', 'sokoban', 'wall_world', 'sokoban_l2'])
+def test_pipelined_rollouts_match_in_order_rollouts(name):
+  """Update pass on a side stream, overlapping the previous launch's render: same bits."""
+  import sys, os
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from games_under_test import FUSED_GAMES
+  from campx_amd import fused as fused_mod
+  saved = fused_mod.FORCE_SPLIT
+  fused_mod.FORCE_SPLIT = True                  # K > 2 games take the two-kernel path too
+  try:
+    B, T = 4096, 40
+    a = FUSED_GAMES[name](batch=B, device='cuda'); a.its_showtime()
+    b = FUSED_GAMES[name](batch=B, device='cuda'); b.its_showtime()
+    gen = torch.Generator().manual_seed(3)
+    acts = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8).cuda() for _ in range(5)]
+    torch.cuda.synchronize()
+    bufs = [b.fused.rollout_buffers(T)]
+    bufs.append(b.fused.rollout_buffers(T, share=bufs[0]))
+    for i, x in enumerate(acts):
+      want = a.rollout(x, reset_first=(i % 2 == 0))
+      got = b.rollout(x, out=bufs[i & 1], reset_first=(i % 2 == 0), pipelined=True)
+      for k in ('obs', 'reward', 'discount', 'done', 'perf', 'trace'):
+        if want[k] is not None:
+          assert torch.equal(want[k], got[k]), (i, k)
+      if i == 2:                                 # an in-order call in between
+        o1, r1, _ = a.play(x[0]); o2, r2, _ = b.play(x[0])
+        assert torch.equal(o1.layered_board, o2.layered_board) and torch.equal(r1, r2)
+    assert torch.equal(a.fused.pos, b.fused.pos) and torch.equal(a.fused.ret, b.fused.ret)
+  finally:
+    fused_mod.FORCE_SPLIT = saved
