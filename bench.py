@@ -64,9 +64,10 @@ def parse_args(argv=None):
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-extras', action='store_true',
                  help='skip play()-mode and the wall_world / sokoban side measurements')
-  p.add_argument('--no-pipeline', action='store_true',
-                 help='issue each rollout as one in-order op instead of update pass (side '
-                      'stream, overlapping the previous launch) + render')
+  p.add_argument('--pipeline', action='store_true',
+                 help='A/B: issue the update pass of each rollout on a side stream so that '
+                      'it overlaps the previous launch (measured SLOWER: the two kernels '
+                      'contend for CU slots; DESIGN.md "Kernels")')
   p.add_argument('--gather-every', type=int, default=8,
                  help='episodes per RCCL all-gather of the episode-return log')
   p.add_argument('--force-dist', action='store_true',
@@ -200,7 +201,7 @@ def kernel_names(fused, split):
 
 
 def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_every,
-                    standin=None, pipelined=True):
+                    standin=None, pipelined=False):
   """Warm up, then time exactly `steps` rollout launches.  Returns a dict.
 
   Wall clock: perf_counter around the timed region, bracketed by synchronize +
@@ -381,7 +382,7 @@ def run_rank(args):
   B = args.batch or default_batch
   T = args.frames
   m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
-                      args.gather_every, standin, not args.no_pipeline)
+                      args.gather_every, standin, args.pipeline)
   fused, elapsed = m['fused'], m['elapsed']
 
   gathered_ok = None
@@ -448,7 +449,7 @@ def run_rank(args):
         oname, ob = WORKLOADS[other]
         steps = max(5, args.steps // 3)
         om = measure_rollout(other, ob, T, steps, 3, device, 0, None, 0,
-                             pipelined=not args.no_pipeline)
+                             pipelined=args.pipeline)
         also.append({
             'workload': '{}, batch={}, random actions, {} frames per launch'.format(
                 oname, ob, T),
