@@ -6,6 +6,6 @@ Each `make_game(batch=None, device=None)` returns what the reference's
 `batch=B` builds the fused HIP tier.
 """
 
-from . import boat_race, wall_world, sokoban, demos
+from . import boat_race, wall_world, sokoban, demos, hello_world
 
-__all__ = ['boat_race', 'wall_world', 'sokoban', 'demos']
+__all__ = ['boat_race', 'wall_world', 'sokoban', 'demos', 'hello_world']

@@ -13,9 +13,10 @@ with two faces:
 * `fused_rule()` returns a small declarative description that
   `campx_amd.fused` lowers into the GameSpec consumed by the HIP kernel.
 
-Action convention for every rule here (examples/boat_race.py:26): a 5-vector
+Action convention for the one-cell rules (examples/boat_race.py:26): a 5-vector
 one-hot `[left, right, up, down, stay]`; "left" is column-1 and "up" is row-1,
-both cyclic (boat_race.py:42-45).
+both cyclic (boat_race.py:42-45).  The Hello World rules (`RollingDrape`,
+`SlidingSprite`) take the notebook's integer actions 0..4.
 """
 
 import types
@@ -191,7 +192,77 @@ def bind(things):
                   step_reward=float(self.step_reward),
                   goal_reward=float(self.goal_reward))
 
+  class RollingDrape(things.Drape):
+    """A multi-cell drape whose whole mask rolls cyclically with the action.
+
+    Restates `RollingDrape` of the reference's Hello World notebook
+    (examples/Hello World Example.ipynb cell 3): the action is an integer; actions
+    0..3 roll the mask by `roll_shifts[a]` along axis `roll_axes[a]` and pay
+    `move_reward`; `quit_action` ends the episode (and pays nothing); anything else
+    is ignored.  (The notebook round-trips through numpy's `np.roll`; `torch.roll` is
+    the same permutation.)
+    """
+
+    def __init__(self, curtain, character, roll_axes=(0, 0, 1, 1),
+                 roll_shifts=(-1, 1, -1, 1), quit_action=4, move_reward=1):
+      super(RollingDrape, self).__init__(curtain, character)
+      self.roll_axes = tuple(roll_axes)
+      self.roll_shifts = tuple(roll_shifts)
+      self.quit_action = quit_action
+      self.move_reward = move_reward
+
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      del board, layers, backdrop, all_things
+      if actions is None:
+        return
+      a = int(actions)
+      if a == self.quit_action:
+        the_plot.terminate_episode()
+      if 0 <= a < len(self.roll_axes):
+        self.curtain.set_(torch.roll(self.curtain, self.roll_shifts[a],
+                                     self.roll_axes[a]))
+        the_plot.add_reward(self.move_reward)
+
+    def fused_rule(self):
+      n = len(self.roll_axes)
+      drow = [self.roll_shifts[a] if self.roll_axes[a] == 0 else 0 for a in range(n)]
+      dcol = [self.roll_shifts[a] if self.roll_axes[a] == 1 else 0 for a in range(n)]
+      return dict(op='shape', drow=drow, dcol=dcol,
+                  rewards=[float(self.move_reward)] * n,
+                  quit_action=self.quit_action)
+
+  class SlidingSprite(things.Sprite):
+    """A sprite that slides diagonally, cyclically (Hello World notebook cell 3).
+
+    `direction_set` in 0..3 picks one of four mappings from actions 0..3 to diagonal
+    steps; other actions are ignored.
+    """
+
+    _DX = ([-1, 1, -1, 1], [-1, 1, -1, 1], [1, -1, 1, -1], [1, -1, 1, -1])
+    _DY = ([-1, 1, 1, -1], [1, -1, -1, 1], [1, -1, -1, 1], [-1, 1, 1, -1])
+
+    def __init__(self, corner, position, character, direction_set):
+      super(SlidingSprite, self).__init__(corner, position, character)
+      self.direction_set = direction_set
+      self._dx = self._DX[direction_set]
+      self._dy = self._DY[direction_set]
+
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      del board, layers, backdrop, all_things, the_plot
+      if actions is None or int(actions) > 3:
+        return
+      a = int(actions)
+      self._position = self.Position(
+          (self._position.row + self._dy[a]) % self.corner.row,
+          (self._position.col + self._dx[a]) % self.corner.col)
+
+    def fused_rule(self):
+      return dict(op='shape', drow=list(self._dy), dcol=list(self._dx),
+                  rewards=[None] * 4, quit_action=None)
+
   return types.SimpleNamespace(
+      RollingDrape=RollingDrape,
+      SlidingSprite=SlidingSprite,
       AgentDrape=AgentDrape,
       DirectionalHoverRewardDrape=DirectionalHoverRewardDrape,
       BoxDrape=BoxDrape,
@@ -205,6 +276,11 @@ DirectionalHoverRewardDrape = _bound.DirectionalHoverRewardDrape
 BoxDrape = _bound.BoxDrape
 GoalDrape = _bound.GoalDrape
 FixedDrape = _bound.FixedDrape
+RollingDrape = _bound.RollingDrape
+SlidingSprite = _bound.SlidingSprite
 
 FUSED_RULE_CLASSES = (AgentDrape, DirectionalHoverRewardDrape, BoxDrape,
                       GoalDrape)
+# Rigidly translated things that interact with nothing: lowered to the shape tier
+# (gamespec.lower_shapes, csrc shape_rollout_kernel) instead of the one-cell model.
+SHAPE_RULE_CLASSES = (RollingDrape, SlidingSprite)

@@ -392,6 +392,17 @@ def gen_hello_world():
   acts[:, 1] = 0
   golden = run(lambda: ns['make_game'](), acts, to_action=int)
   assert golden['done'][25, 0] == 1 and golden['discount'][25, 0] == 0.0
+  # the library's RollingDrape / SlidingSprite, on the reference's engine and things
+  from campx_amd.games import hello_world as g_hw
+
+  def lib_game():
+    return to_game(
+        g_hw.HELLO_ART, what_lies_beneath=' ',
+        sprites={'1': Partial(R.SlidingSprite, 0), '2': Partial(R.SlidingSprite, 1),
+                 '3': Partial(R.SlidingSprite, 2), '4': Partial(R.SlidingSprite, 3)},
+        drapes={'@': R.RollingDrape}, z_order='12@34')
+  lib = run(lib_game, acts, to_action=int)
+  assert_same(golden, lib, 'hello world library rules')
   save('hello_world', golden)
 
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""profiles/r02_traffic.json from the rocprofv3 PMC passes of tools/profile.sh.
+
+    python tools/make_traffic.py gpurun_out/prof_r02_boat_race:boat_race:65536:100 ...
+
+Per configuration: WRITE_SIZE and FETCH_SIZE (KiB, separate passes) of the kernels of one
+rollout launch, per dispatch, summed.  WRITE_SIZE is taken at face value (it reads
+1146.9 MB for the render kernel's exactly 1146.88 MB of stores).  FETCH_SIZE follows
+MI355X_MICROARCH.md: it reports half the bytes of a wide (16 B/lane) coalesced stream,
+which is what the update kernels' action loads are (3.34 MB reported for 6.55 MB of
+actions), so their reading is doubled; the render kernel's loads are 1 B/lane trace bytes
+and 16-byte L1-resident table reads, taken raw.
+"""
+import json
+import os
+import sqlite3
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_dispatch(db, counter):
+  cur = sqlite3.connect(db).cursor()
+  rows = cur.execute(
+      'select kernel_name, avg(v) from (select kernel_name, dispatch_id, sum(value) as v '
+      'from counters_collection where counter_name = ? group by kernel_name, dispatch_id) '
+      'group by kernel_name', (counter,)).fetchall()
+  return {k: v * 1024.0 for k, v in rows}
+
+
+def main(specs):
+  table = {'_comment': __doc__.split('\n\n', 2)[2].strip().replace('\n', ' ')}
+  for spec in specs:
+    d, game, batch, frames = spec.split(':')
+    w = per_dispatch(os.path.join(d, 'pmc_write_results.db'), 'WRITE_SIZE')
+    f = per_dispatch(os.path.join(d, 'pmc_fetch_results.db'), 'FETCH_SIZE')
+    names = [k for k in w if 'render_kernel' in k or 'update_' in k]
+    short = [k.replace('(anonymous namespace)::', '').split('(')[0] for k in names]
+    wb = sum(w[k] for k in names)
+    fb = sum(f.get(k, 0.0) * (2.0 if 'update_' in k else 1.0) for k in names)
+    table['{}:{}:{}:split'.format(game, batch, frames)] = {
+        'kernels': ' + '.join(sorted(short)), 'write_bytes': wb, 'fetch_bytes': fb,
+        'traffic_bytes': wb + fb,
+        'source': 'profiles/r02_{}_rocprofv3.txt'.format(game)}
+  with open(os.path.join(REPO, 'profiles', 'r02_traffic.json'), 'w') as out:
+    json.dump(table, out, indent=1)
+  print(json.dumps(table, indent=1))
+
+
+if __name__ == '__main__':
+  main(sys.argv[1:])
