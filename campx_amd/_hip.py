@@ -15,7 +15,7 @@ there is no CPU fallback for the fused tier.
 import ctypes
 import os
 
-from .gamespec import CampxSpec
+from .gamespec import CampxSpec, CampxShapeSpec
 
 _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
@@ -24,7 +24,8 @@ EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
            'campx_pair_table_bytes', 'campx_pair_table_build',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
-           'campx_check_actions_launch',
+           'campx_shape_spec_size', 'campx_shape_spec_validate',
+           'campx_shape_rollout_launch', 'campx_check_actions_launch',
            'campx_onehot_to_ids_launch', 'campx_strerror',
            'campx_last_hip_error', 'campx_device_arch')
 
@@ -75,6 +76,14 @@ def _load():
                                       i64, i32, i32, vp]
   lib.campx_render_launch.restype = i32
   lib.campx_render_launch.argtypes = [spec_p, vp, CampxOutputs, i64, i32, vp]
+  shape_p = ctypes.POINTER(CampxShapeSpec)
+  lib.campx_shape_spec_size.restype = i32
+  lib.campx_shape_spec_size.argtypes = []
+  lib.campx_shape_spec_validate.restype = i32
+  lib.campx_shape_spec_validate.argtypes = [shape_p]
+  lib.campx_shape_rollout_launch.restype = i32
+  lib.campx_shape_rollout_launch.argtypes = [shape_p, vp, CampxState, vp, vp, CampxOutputs,
+                                             i64, i32, i32, i32, vp]
   lib.campx_check_actions_launch.restype = i32
   lib.campx_check_actions_launch.argtypes = [vp, i64, vp, vp]
   lib.campx_onehot_to_ids_launch.restype = i32
@@ -85,6 +94,9 @@ def _load():
   lib.campx_last_hip_error.argtypes = []
   lib.campx_device_arch.restype = i32
   lib.campx_device_arch.argtypes = [i32, ctypes.c_char_p, i32]
+  if lib.campx_shape_spec_size() != ctypes.sizeof(CampxShapeSpec):
+    raise ImportError('CampxShapeSpec layout mismatch between gamespec.py and '
+                      'libcampx_hip.so: rebuild the library')
   if lib.campx_spec_size() != ctypes.sizeof(CampxSpec):
     raise ImportError('CampxSpec layout mismatch between gamespec.py ({} B) and '
                       'libcampx_hip.so ({} B): rebuild the library'.format(
@@ -108,8 +120,8 @@ def _load_ops():
 
 
 ops = _load_ops()
-OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'onehot_to_ids',
-            'check_actions')
+OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'shape_rollout',
+            'onehot_to_ids', 'check_actions')
 
 
 def check(code, what):

@@ -785,19 +785,21 @@ __device__ __forceinline__ int count_bad16(u32x4 v) {
 
 // The loader wave's state: one chunk (kChunk frames x kEnvs environments) of actions in
 // flight in registers between issue() and land().
-template <int kEnvs>
+template <int kEnvs, int kLoaders>
 struct ActionLoader {
   static constexpr int kVecPerRow = kEnvs / 16;
-  static constexpr int kPerLane = kChunk * kVecPerRow / kWave;
+  static constexpr int kLanes = kWave * kLoaders;          // loader lanes of the workgroup
+  static constexpr int kPerLane = kChunk * kVecPerRow / kLanes;
   u32x4 pend[kPerLane];
 
   // 16-byte loads; rows past T and environments past B are clamped to valid ones (no
   // branch between the loads) and neutralised in land().
+  // `lane` counts over all loader waves: 0 .. kLanes-1
   __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
                                         int t0, int64_t env0, int lane) {
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
-      const int v = lane + i * kWave;
+      const int v = lane + i * kLanes;
       const int r = v / kVecPerRow, q = v % kVecPerRow;
       int row = t0 + r;
       row = row < T ? row : T - 1;
@@ -812,7 +814,7 @@ struct ActionLoader {
     int bad = 0;
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
-      const int v = lane + i * kWave;
+      const int v = lane + i * kLanes;
       const int r = v / kVecPerRow, q = v % kVecPerRow;
       const bool real = (t0 + r < T) && (env0 + 16 * q < B);
       const u32x4 stay = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
@@ -824,11 +826,11 @@ struct ActionLoader {
 };
 
 // Batches that are not a multiple of 16 environments: byte by byte, synchronously.
-template <int kEnvs>
+template <int kEnvs, int kLoaders>
 __device__ __forceinline__ int stage_bytes(int8_t* staged, const int8_t* __restrict__ actions,
                                            int64_t B, int32_t T, int t0, int64_t env0, int lane) {
   int bad = 0;
-  for (int i = lane; i < kChunk * kEnvs; i += kWave) {
+  for (int i = lane; i < kChunk * kEnvs; i += kWave * kLoaders) {
     const int r = i / kEnvs, e = i % kEnvs;
     const bool real = (t0 + r < T) && (env0 + e < B);
     const int8_t a = real ? actions[(int64_t)(t0 + r) * B + env0 + e] : (int8_t)4;
@@ -848,12 +850,16 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
 #define CAMPX_UPD_XCD 0
 #endif
 
+// loader waves of an update workgroup: one per 128 environments
+constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
+
 template <int kProd, int kCons>
-__global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kernel(
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) void update_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
-  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
+  constexpr int kLoad = update_loaders(kProd);
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   // LDS entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
   // from (the art's cell when this frame ended the episode: the rebuild is folded into
   // the chain), [16:22] the cell after this frame, [23] whether the mover shows there,
@@ -863,7 +869,8 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kern
   __shared__ __attribute__((aligned(16))) float ring_r[2][kGroup][E];
   __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kGroup][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const bool producer = wave < kProd, loader = wave == kProd + kCons;
+  const bool producer = wave < kProd, loader = wave >= kProd + kCons;
+  const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
   const int W = mp.cols, HW = mp.rows * mp.cols;
   const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
   const bool wide = (B & 15) == 0;  // 16-byte global accesses need 16-environment alignment
@@ -878,14 +885,14 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kern
                           (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) | (vis << 23) |
                               ((uint32_t)tr.done << 24) | ((uint32_t)(tr.perf + 1) << 25));
   }
-  ActionLoader<E> ld;
+  ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
     if (wide) {
-      ld.issue(actions, B, T, 0, env0, lane);
-      bad += ld.land(staged[0], B, T, 0, env0, lane);
+      ld.issue(actions, B, T, 0, env0, llane);
+      bad += ld.land(staged[0], B, T, 0, env0, llane);
     } else {
-      bad += stage_bytes<E>(staged[0], actions, B, T, 0, env0, lane);
+      bad += stage_bytes<E, kLoad>(staged[0], actions, B, T, 0, env0, llane);
     }
   }
 
@@ -1016,11 +1023,11 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_table_kern
       const int t_next = (c + 1) * kChunk;
       if (t_next < T) {
         if (wide) {
-          if (phase == 0) ld.issue(actions, B, T, t_next, env0, lane);
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
           if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, lane);
+            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
         } else if (phase == 0) {
-          bad += stage_bytes<E>(staged[(c + 1) & 1], actions, B, T, t_next, env0, lane);
+          bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
         }
       }
     }
@@ -1060,18 +1067,20 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW)
 }
 
 template <int kChain, int kProd, int kCons>
-__global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kernel(
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
-  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + 1) * kWave;
+  constexpr int kLoad = update_loaders(kProd);
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   __shared__ uint16_t lds_chain[kChain == 1 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
   __shared__ uint32_t lds_entries[kChain == 3 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
   __shared__ float reward_list[256];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const bool producer = wave < kProd, loader = wave == kProd + kCons;
+  const bool producer = wave < kProd, loader = wave >= kProd + kCons;
+  const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
   const int W = pp.cols, HW = pp.rows * pp.cols;
   const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
   const bool wide = (B & 15) == 0;
@@ -1086,14 +1095,14 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
   if (kChain == 3)
     for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
-  ActionLoader<E> ld;
+  ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
     if (wide) {
-      ld.issue(actions, B, T, 0, env0, lane);
-      bad += ld.land(staged[0], B, T, 0, env0, lane);
+      ld.issue(actions, B, T, 0, env0, llane);
+      bad += ld.land(staged[0], B, T, 0, env0, llane);
     } else {
-      bad += stage_bytes<E>(staged[0], actions, B, T, 0, env0, lane);
+      bad += stage_bytes<E, kLoad>(staged[0], actions, B, T, 0, env0, llane);
     }
   }
 
@@ -1176,7 +1185,7 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
         const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
         const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
         constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
-#pragma unroll
+#pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
         for (int it = 0; it < kItA; ++it) {
           const int item = clane + it * CL;
           const int j = item / QA, q = item % QA;
@@ -1263,11 +1272,11 @@ __global__ __launch_bounds__((kProd + kCons + 1) * kWave) void update_pair_kerne
       const int t_next = (c + 1) * kChunk;
       if (t_next < T) {
         if (wide) {
-          if (phase == 0) ld.issue(actions, B, T, t_next, env0, lane);
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
           if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, lane);
+            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
         } else if (phase == 0) {
-          bad += stage_bytes<E>(staged[(c + 1) & 1], actions, B, T, t_next, env0, lane);
+          bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
         }
       }
     }
@@ -1472,6 +1481,170 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// Shape tier (include/campx_hip.h): Hello World.  One wavefront = one environment; its
+// two H*W-byte images (the environment's backdrop, which sprites behind the first drape
+// paint into for good, and the frame's flat board of layer indices) live in LDS; all
+// control flow is wave-uniform, LDS operations of a wave complete in order, so there is
+// no barrier.  A frame: offsets += per-thing delta[action] (scalar), paint, then every
+// lane expands four board cells at a time into the L layer planes (one dword store per
+// plane) - campx/rendering.py:204-215's per-character equality.
+constexpr int kShapeWaves = 4;
+
+__device__ __forceinline__ int shape_cell(uint32_t packed, int orow, int ocol, int H, int W) {
+  int r = (int)(packed >> 8) + orow, c = (int)(packed & 0xffu) + ocol;
+  r = r >= H ? r - H : r;
+  c = c >= W ? c - W : c;
+  return r * W + c;
+}
+
+template <bool kBoard>
+__global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
+    const CampxShapeSpec* __restrict__ spec, CampxState st, int8_t* __restrict__ backdrop_state,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, int32_t emit_first) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_board[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int64_t env = (int64_t)blockIdx.x * kShapeWaves + wave;
+  if (env >= B) return;  // wave-uniform; no barriers below
+  const int H = spec->rows, W = spec->cols, HW = H * W, L = spec->n_layers, N = spec->n_things;
+  const int64_t LHW = (int64_t)L * HW;
+  uint8_t* bd = lds_backdrop[wave];
+  uint8_t* board = lds_board[wave];
+  const bool quads = (HW & 3) == 0;
+
+  int orow[CAMPX_SHAPE_MAX_THINGS], ocol[CAMPX_SHAPE_MAX_THINGS];
+#pragma unroll
+  for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k) orow[k] = ocol[k] = 0;
+  int over = 0;
+  float ret = 0.0f;
+  const bool fresh = reset_first != 0;
+  if (!fresh) {
+#pragma unroll
+    for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
+      if (k < N) {
+        orow[k] = st.pos[(int64_t)(2 * k) * B + env];
+        ocol[k] = st.pos[(int64_t)(2 * k + 1) * B + env];
+      }
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+  for (int i = lane; i < HW; i += kWave)
+    bd[i] = (fresh || !backdrop_state) ? spec->backdrop[i] : (uint8_t)backdrop_state[env * HW + i];
+
+  auto rebuild = [&]() {  // a fresh make_game() + its_showtime()
+#pragma unroll
+    for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k) orow[k] = ocol[k] = 0;
+    for (int i = lane; i < HW; i += kWave) bd[i] = spec->backdrop[i];
+  };
+
+  auto paint_and_emit = [&](int8_t* obs_dst, int8_t* board_dst) {
+    // sprites behind the first drape paint into the backdrop itself (rendering.py:128,150)
+    for (int z = 0; z < spec->first_drape; ++z) {
+      const CampxShapeThing& th = spec->things[z];
+      if (!th.visible) continue;
+      for (int i = lane; i < th.n_cells; i += kWave)
+        bd[shape_cell(spec->cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
+    }
+    if (quads)
+      for (int i = lane; i < HW / 4; i += kWave)
+        reinterpret_cast<uint32_t*>(board)[i] = reinterpret_cast<const uint32_t*>(bd)[i];
+    else
+      for (int i = lane; i < HW; i += kWave) board[i] = bd[i];
+    for (int z = spec->first_drape; z < N; ++z) {
+      const CampxShapeThing& th = spec->things[z];
+      if (!th.visible) continue;
+      for (int i = lane; i < th.n_cells; i += kWave)
+        board[shape_cell(spec->cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
+    }
+    // layers by equality (rendering.py:204-215)
+    if (quads) {
+      for (int q = lane; q < HW / 4; q += kWave) {
+        const uint32_t b4 = reinterpret_cast<const uint32_t*>(board)[q];
+        for (int l = 0; l < L; ++l) {
+          const uint32_t x = b4 ^ ((uint32_t)l * 0x01010101u);  // bytes < 0x80: zero iff equal
+          const uint32_t nz = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) & 0x80808080u;
+          *reinterpret_cast<uint32_t*>(obs_dst + (int64_t)l * HW + 4 * q) = (nz ^ 0x80808080u) >> 7;
+        }
+        if (kBoard)
+          *reinterpret_cast<uint32_t*>(board_dst + 4 * q) =
+              (uint32_t)spec->layer_char[b4 & 0xffu] | ((uint32_t)spec->layer_char[(b4 >> 8) & 0xffu] << 8) |
+              ((uint32_t)spec->layer_char[(b4 >> 16) & 0xffu] << 16) | ((uint32_t)spec->layer_char[b4 >> 24] << 24);
+      }
+    } else {
+      for (int i = lane; i < HW; i += kWave) {
+        const int b = board[i];
+        for (int l = 0; l < L; ++l) obs_dst[(int64_t)l * HW + i] = (int8_t)(b == l);
+        if (kBoard) board_dst[i] = (int8_t)spec->layer_char[b];
+      }
+    }
+  };
+
+  if (emit_first) paint_and_emit(out.obs + env * LHW, kBoard ? out.board + env * HW : nullptr);
+
+  int bad = 0;
+  for (int t = 0; t < T; ++t) {
+    const int a_raw = actions[(int64_t)t * B + env];  // wave-uniform
+    const bool valid = (unsigned)a_raw < (unsigned)CAMPX_N_ACTIONS;
+    bad += valid ? 0 : 1;
+    if (over) {
+      rebuild();
+      over = 0;
+      ret = 0.0f;
+    }
+    float reward = 0.0f, discount = 1.0f;
+    bool first = true;
+    if (valid) {
+      for (int u = 0; u < N; ++u) {  // update-schedule order (engine.py:200-204)
+        const int k = spec->update_order[u];
+        const CampxShapeThing& th = spec->things[k];
+        if ((th.terminate_mask >> a_raw) & 1) {  // plot.py:183-184
+          over = 1;
+          discount = 0.0f;
+        }
+        const int dr = th.drow[a_raw], dc = th.dcol[a_raw];
+#pragma unroll
+        for (int j = 0; j < CAMPX_SHAPE_MAX_THINGS; ++j)
+          if (j == k) {
+            int r = orow[j] + dr, c = ocol[j] + dc;
+            orow[j] = r >= H ? r - H : r;
+            ocol[j] = c >= W ? c - W : c;
+          }
+        if ((th.has_reward_mask >> a_raw) & 1) {  // plot.py:208-211: r + total
+          reward = first ? th.reward[a_raw] : th.reward[a_raw] + reward;
+          first = false;
+        }
+      }
+    }
+    if (first) reward = __builtin_nanf("");  // nobody called add_reward: None
+    ret += reward;
+    paint_and_emit(out.obs + (int64_t)t * out.obs_t_stride + env * LHW,
+                   kBoard ? out.board + (int64_t)t * out.board_t_stride + env * HW : nullptr);
+    if (lane == 0) {
+      const int64_t at = (int64_t)t * B + env;
+      if (out.reward) out.reward[at] = reward;
+      if (out.discount) out.discount[at] = discount;
+      if (out.done) out.done[at] = (uint8_t)over;
+    }
+  }
+
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
+      if (k < N) {
+        st.pos[(int64_t)(2 * k) * B + env] = (int8_t)orow[k];
+        st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)ocol[k];
+      }
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+  if (backdrop_state)
+    for (int i = lane; i < HW; i += kWave) backdrop_state[env * HW + i] = (int8_t)bd[i];
+  report_bad_actions(out, lane == 0 ? bad : 0);
+}
+
 
 __global__ void check_actions_kernel(const int8_t* __restrict__ actions, int64_t n,
                                      int32_t* bad_count) {
@@ -1768,14 +1941,16 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
                      int32_t reset_first, bool use_table, hipStream_t stream) {
   if (use_table) {
     constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
-    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block((kProd + kCons + 1) * kWave);
+    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
+        block((kProd + kCons + update_loaders(kProd)) * kWave);
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
     hipLaunchKernelGGL((update_table_kernel<kProd, kCons>), grid, block, 0, stream, mp, spec_dev,
                        st, actions, out, B, T, reset_first);
   } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
     constexpr int kProd = CAMPX_PAIR_PROD, kCons = CAMPX_PAIR_CONS, kEnvs = kProd * kWave;
-    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block((kProd + kCons + 1) * kWave);
+    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
+        block((kProd + kCons + update_loaders(kProd)) * kWave);
     PairParams pp;
     memset(&pp, 0, sizeof(pp));
     pp.rows = s.rows;
@@ -2191,6 +2366,70 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   CampxOutputs probe = out;   // the conditions of the two-kernel path, frames back to back
   if (!split_ok(*spec_host, probe, B, T)) return CAMPX_EINVAL;
   return launch_renders(*spec_host, spec_dev, out, B, T, static_cast<hipStream_t>(stream));
+}
+
+int32_t campx_shape_spec_size(void) { return (int32_t)sizeof(CampxShapeSpec); }
+
+int32_t campx_shape_spec_validate(const CampxShapeSpec* s) {
+  if (!s) return CAMPX_EINVAL;
+  if (s->magic != CAMPX_SHAPE_SPEC_MAGIC || s->version != CAMPX_SHAPE_SPEC_VERSION) return CAMPX_ESPEC;
+  if (s->rows < 1 || s->cols < 1 || s->rows > 127 || s->cols > 127) return CAMPX_ESPEC;
+  const int HW = s->rows * s->cols;
+  if (HW > CAMPX_SHAPE_MAX_CELLS) return CAMPX_ESPEC;
+  if (s->n_layers < 1 || s->n_layers > CAMPX_MAX_LAYERS) return CAMPX_ESPEC;
+  if (s->n_things < 1 || s->n_things > CAMPX_SHAPE_MAX_THINGS) return CAMPX_ESPEC;
+  if (s->first_drape < 0 || s->first_drape >= s->n_things) return CAMPX_ESPEC;
+  uint32_t seen = 0;
+  for (int u = 0; u < s->n_things; ++u) {
+    if (s->update_order[u] < 0 || s->update_order[u] >= s->n_things) return CAMPX_ESPEC;
+    seen |= 1u << s->update_order[u];
+  }
+  if (seen != (1u << s->n_things) - 1u) return CAMPX_ESPEC;
+  for (int k = 0; k < s->n_things; ++k) {
+    const CampxShapeThing& t = s->things[k];
+    if (t.layer < 0 || t.layer >= s->n_layers) return CAMPX_ESPEC;
+    if ((k < s->first_drape) != (t.is_sprite != 0) && k < s->first_drape) return CAMPX_ESPEC;
+    if (k == s->first_drape && t.is_sprite) return CAMPX_ESPEC;
+    if (t.n_cells < 0 || t.cell_begin < 0 || t.cell_begin + t.n_cells > CAMPX_SHAPE_MAX_LIST)
+      return CAMPX_ESPEC;
+    for (int i = 0; i < t.n_cells; ++i) {
+      const uint16_t c = s->cells[t.cell_begin + i];
+      if ((c >> 8) >= s->rows || (c & 0xff) >= s->cols) return CAMPX_ESPEC;
+    }
+    for (int a = 0; a < CAMPX_N_ACTIONS; ++a)
+      if (t.drow[a] < 0 || t.drow[a] >= s->rows || t.dcol[a] < 0 || t.dcol[a] >= s->cols)
+        return CAMPX_ESPEC;
+    if ((t.has_reward_mask | t.terminate_mask) >> CAMPX_N_ACTIONS) return CAMPX_ESPEC;
+  }
+  for (int i = 0; i < HW; ++i)
+    if (s->backdrop[i] >= s->n_layers) return CAMPX_ESPEC;
+  return CAMPX_OK;
+}
+
+int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxShapeSpec* spec_dev,
+                                   CampxState st, int8_t* backdrop_state, const int8_t* actions,
+                                   CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
+                                   int32_t emit_first, void* stream) {
+  if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
+    return CAMPX_EINVAL;
+  if (T > 0 && !actions) return CAMPX_EINVAL;
+  if (out.obs_format != CAMPX_OBS_INT8 || out.perf || out.trace) return CAMPX_EINVAL;
+  if (reinterpret_cast<uintptr_t>(out.obs) & 3) return CAMPX_EINVAL;
+  const int32_t v = campx_shape_spec_validate(spec_host);
+  if (v != CAMPX_OK) return v;
+  bool trails = false;
+  for (int k = 0; k < spec_host->first_drape; ++k) trails = trails || spec_host->things[k].visible;
+  if (trails && !backdrop_state) return CAMPX_EINVAL;
+  const dim3 grid((unsigned)((B + kShapeWaves - 1) / kShapeWaves)), block(kShapeWaves * kWave);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out.board)
+    hipLaunchKernelGGL(shape_rollout_kernel<true>, grid, block, 0, s, spec_dev, st, backdrop_state,
+                       actions, out, B, T, reset_first, emit_first);
+  else
+    hipLaunchKernelGGL(shape_rollout_kernel<false>, grid, block, 0, s, spec_dev, st, backdrop_state,
+                       actions, out, B, T, reset_first, emit_first);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
 int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* bad_count,

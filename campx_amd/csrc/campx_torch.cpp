@@ -9,6 +9,7 @@
 //   campx::step     one Engine.play() frame for B environments
 //   campx::rollout  T consecutive frames in one launch
 //   campx::update / campx::render   the two kernels of a rollout as separate ops
+//   campx::shape_rollout            the shape tier (Hello World): reset / step / rollout
 //   campx::onehot_to_ids / campx::check_actions   action-format helpers
 //
 // Contract: every tensor is caller-owned and contiguous; outputs are written in
@@ -30,6 +31,7 @@
 #include <torch/library.h>
 
 #include <optional>
+#include <vector>
 
 #include "campx_hip.h"
 
@@ -287,6 +289,77 @@ void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& 
            "campx_rollout_launch");
 }
 
+// Shape tier (Hello World): reset (actions = None, emit_first), one frame (actions [B],
+// obs [B, L, H, W]) or T frames (actions [T, B], obs [T, B, L, H, W]) through one op.
+void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+                   const OptTensor& ret, const OptTensor& backdrop_state, const OptTensor& actions,
+                   Tensor& obs, const OptTensor& board, const OptTensor& reward,
+                   const OptTensor& discount, const OptTensor& step_done,
+                   const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first,
+                   bool emit_first) {
+  TORCH_CHECK(spec_host.device().is_cpu() && spec_host.scalar_type() == at::kByte &&
+                  spec_host.is_contiguous() && spec_host.numel() == (int64_t)sizeof(CampxShapeSpec),
+              "campx: spec_host must be the CampxShapeSpec blob as a CPU uint8 tensor");
+  const CampxShapeSpec* hs = reinterpret_cast<const CampxShapeSpec*>(spec_host.data_ptr());
+  TORCH_CHECK(pos.device().is_cuda() && pos.dim() == 2,
+              "campx::shape_rollout: state must be on a HIP device (no CPU implementation)");
+  const c10::Device dev = pos.device();
+  const int64_t B = pos.size(1), N = hs->n_things, L = hs->n_layers, H = hs->rows, W = hs->cols;
+  want(pos, "pos", at::kChar, dev, {2 * N, B});
+  want(done, "done", at::kByte, dev, {B});
+  if (ret.has_value()) want(*ret, "ret", at::kFloat, dev, {B});
+  if (backdrop_state.has_value()) want(*backdrop_state, "backdrop_state", at::kChar, dev, {B, H * W});
+  TORCH_CHECK(spec_dev.device() == dev && spec_dev.scalar_type() == at::kByte &&
+                  spec_dev.is_contiguous() && spec_dev.numel() == (int64_t)sizeof(CampxShapeSpec),
+              "campx: spec_dev must be the CampxShapeSpec blob as a uint8 tensor on ", dev);
+  int64_t T = 0;
+  bool frames = false;  // outputs carry a leading frame axis
+  if (actions.has_value()) {
+    frames = actions->dim() == 2;
+    T = frames ? actions->size(0) : 1;
+    if (frames) want(*actions, "actions", at::kChar, dev, {T, B});
+    else want(*actions, "actions", at::kChar, dev, {B});
+  }
+  CampxOutputs out{};
+  auto shape = [&](std::initializer_list<int64_t> tail) {
+    std::vector<int64_t> v;
+    if (frames) v.push_back(T);
+    v.push_back(B);
+    v.insert(v.end(), tail);
+    return v;
+  };
+  const bool keep = frames && obs.dim() == 5;
+  if (keep || !frames) want(obs, "obs", at::kChar, dev, shape({L, H, W}));
+  else want(obs, "obs", at::kChar, dev, {B, L, H, W});
+  out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.obs_t_stride = keep ? B * L * H * W : 0;
+  if (board.has_value()) {
+    const bool bkeep = frames && board->dim() == 4;
+    if (bkeep) want(*board, "board", at::kChar, dev, {T, B, H, W});
+    else want(*board, "board", at::kChar, dev, {B, H, W});
+    out.board = opt_ptr<int8_t>(board);
+    out.board_t_stride = bkeep ? B * H * W : 0;
+  }
+  if (reward.has_value()) want(*reward, "reward", at::kFloat, dev, shape({}));
+  if (discount.has_value()) want(*discount, "discount", at::kFloat, dev, shape({}));
+  if (step_done.has_value()) want(*step_done, "step_done", at::kByte, dev, shape({}));
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, dev, {1});
+  out.reward = opt_ptr<float>(reward);
+  out.discount = opt_ptr<float>(discount);
+  out.done = opt_ptr<uint8_t>(step_done);
+  out.bad_count = opt_ptr<int32_t>(bad_count);
+  out.bad_flag = flag_ptr(bad_flag, dev);
+  CampxState state{reinterpret_cast<int8_t*>(pos.data_ptr()), reinterpret_cast<uint8_t*>(done.data_ptr()),
+                   opt_ptr<float>(ret), nullptr};
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+  check_ok(campx_shape_rollout_launch(
+               hs, reinterpret_cast<const CampxShapeSpec*>(spec_dev.data_ptr()), state,
+               opt_ptr<int8_t>(backdrop_state), opt_ptr<int8_t>(actions), out, B, (int32_t)T,
+               reset_first ? 1 : 0, emit_first ? 1 : 0,
+               c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+           "campx_shape_rollout_launch");
+}
+
 void onehot_to_ids(const Tensor& onehot, Tensor& ids, Tensor& bad_count) {
   TORCH_CHECK(onehot.device().is_cuda(), "campx::onehot_to_ids: HIP tensors only");
   const c10::Device dev = onehot.device();
@@ -334,6 +407,10 @@ void update_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor
                  const Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                  const OptTensor&, Tensor&, const OptTensor&, const OptTensor&, bool) {}
 void render_meta(const Tensor&, const Tensor&, const Tensor&, Tensor&, const OptTensor&) {}
+void shape_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
+                        const OptTensor&, const OptTensor&, Tensor&, const OptTensor&,
+                        const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
+                        const OptTensor&, bool, bool) {}
 void onehot_to_ids_meta(const Tensor&, Tensor&, Tensor&) {}
 void check_actions_meta(const Tensor&, Tensor&) {}
 
@@ -361,6 +438,11 @@ TORCH_LIBRARY(campx, m) {
   m.def(
       "render(Tensor spec_host, Tensor spec_dev, Tensor trace, Tensor(a!) obs, Tensor(b!)? board) "
       "-> ()");
+  m.def(
+      "shape_rollout(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, "
+      "Tensor(c!)? ret, Tensor(d!)? backdrop_state, Tensor? actions, Tensor(e!) obs, "
+      "Tensor(f!)? board, Tensor(g!)? reward, Tensor(h!)? discount, Tensor(i!)? step_done, "
+      "Tensor(j!)? bad_count, Tensor(k!)? bad_flag, bool reset_first, bool emit_first) -> ()");
   m.def("onehot_to_ids(Tensor onehot, Tensor(a!) ids, Tensor(b!) bad_count) -> ()");
   m.def("check_actions(Tensor actions, Tensor(a!) bad_count) -> ()");
 }
@@ -371,6 +453,7 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
   m.impl("rollout", &rollout);
   m.impl("update", &update);
   m.impl("render", &render);
+  m.impl("shape_rollout", &shape_rollout);
   m.impl("onehot_to_ids", &onehot_to_ids);
   m.impl("check_actions", &check_actions);
 }
@@ -381,6 +464,7 @@ TORCH_LIBRARY_IMPL(campx, Meta, m) {
   m.impl("rollout", &rollout_meta);
   m.impl("update", &update_meta);
   m.impl("render", &render_meta);
+  m.impl("shape_rollout", &shape_rollout_meta);
   m.impl("onehot_to_ids", &onehot_to_ids_meta);
   m.impl("check_actions", &check_actions_meta);
 }

@@ -206,8 +206,19 @@ class Engine(object):
     self._current_update_group = None
 
     if self._batch is not None:
-      from . import fused   # needs the HIP library; raises if it is missing
-      self._fused = fused.FusedGame(self, self._batch, self._device)
+      if not torch.cuda.is_available():
+        raise RuntimeError(
+            'the fused tier needs a HIP device (torch.cuda.is_available() is '
+            'False) and has no CPU fallback; use batch=None for the '
+            'single-environment generic tier')
+      from . import gamespec
+      description = gamespec.describe(self)
+      if description.is_shape_game:   # Hello-World-style rules: the shape tier
+        from . import shapes          # needs the HIP library; raises if it is missing
+        self._fused = shapes.ShapeGame(self, self._batch, self._device, description)
+      else:
+        from . import fused
+        self._fused = fused.FusedGame(self, self._batch, self._device)
       return self._fused.showtime()
 
     chars = set(self._sprites_and_drapes.keys()).union(self._backdrop.palette)

@@ -121,6 +121,11 @@ class GameDescription(object):
         return e
     raise KeyError(char)
 
+  @property
+  def is_shape_game(self):
+    """Rigidly translated, non-interacting things (Hello World): the shape tier."""
+    return any(e.kind == 'shape' for e in self.entities)
+
 
 def describe(engine):
   """Read a set-up `Engine` into a `GameDescription` (see module docstring)."""
@@ -137,10 +142,21 @@ def describe(engine):
   for gi, (_, members) in enumerate(groups):
     for ent in members:
       if isinstance(ent, _things.Sprite):
-        raise ValueError('fused tier: Sprites cannot be lowered yet ({!r}); use '
-                         'the generic tier (batch=None)'.format(ent.character))
+        if type(ent) not in _rules.SHAPE_RULE_CLASSES:
+          raise ValueError(
+              'fused tier: sprite {!r} is a {}, which cannot be lowered; use '
+              'campx_amd.rules.SlidingSprite or the generic tier (batch=None)'
+              .format(ent.character, type(ent).__name__))
+        params = dict(ent.fused_rule(), sprite=True, visible=bool(ent.visible))
+        mask = np.zeros((engine.rows, engine.cols), np.uint8)
+        mask[ent.position.row, ent.position.col] = 1
+        entities.append(EntityDesc(ent.character, 'shape', gi, mask, params))
+        continue
       if type(ent) is _things.FixedDrape:
         kind, params = 'fixed', {}
+      elif type(ent) in _rules.SHAPE_RULE_CLASSES:
+        params = dict(ent.fused_rule(), sprite=False, visible=True)
+        kind = 'shape'
       elif type(ent) in _rules.FUSED_RULE_CLASSES:
         params = ent.fused_rule()
         kind = params['op']
@@ -304,3 +320,117 @@ def lower(desc):
 
 def spec_bytes(spec):
   return ctypes.string_at(ctypes.addressof(spec), ctypes.sizeof(spec))
+
+
+# --------------------------------------------------------------- shape tier
+#
+# Games made of rigidly translated things that interact with nothing
+# (`rules.RollingDrape`, `rules.SlidingSprite`, `FixedDrape`): Hello World.  Things may
+# cover many cells and the board may be large, so they get their own spec and kernel
+# (include/campx_hip.h CampxShapeSpec, csrc shape_rollout_kernel).
+
+SHAPE_MAX_CELLS = 1024
+SHAPE_MAX_THINGS = 8
+SHAPE_MAX_LIST = 2048
+SHAPE_SPEC_MAGIC = 0x50485343
+SHAPE_SPEC_VERSION = 1
+
+
+class CampxShapeThing(ctypes.Structure):
+  _fields_ = [('layer', ctypes.c_int32), ('is_sprite', ctypes.c_int32),
+              ('visible', ctypes.c_int32), ('n_cells', ctypes.c_int32),
+              ('cell_begin', ctypes.c_int32), ('has_reward_mask', ctypes.c_int32),
+              ('terminate_mask', ctypes.c_int32), ('reserved', ctypes.c_int32),
+              ('drow', ctypes.c_int8 * 8), ('dcol', ctypes.c_int8 * 8),
+              ('reward', ctypes.c_float * 8)]
+
+
+class CampxShapeSpec(ctypes.Structure):
+  _fields_ = [('magic', ctypes.c_uint32), ('version', ctypes.c_uint32),
+              ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
+              ('n_layers', ctypes.c_int32), ('n_things', ctypes.c_int32),
+              ('first_drape', ctypes.c_int32), ('any_reward', ctypes.c_int32),
+              ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
+              ('update_order', ctypes.c_int32 * SHAPE_MAX_THINGS),
+              ('things', CampxShapeThing * SHAPE_MAX_THINGS),
+              ('backdrop', ctypes.c_uint8 * SHAPE_MAX_CELLS),
+              ('cells', ctypes.c_uint16 * SHAPE_MAX_LIST)]
+
+
+assert ctypes.sizeof(CampxShapeThing) == 80
+
+
+def lower_shapes(desc):
+  """`GameDescription` of a shape game -> `CampxShapeSpec` (ctypes, host memory).
+
+  Things are stored in z-order (back to front).  What the reference's renderer does
+  with sprites painted BEFORE the first drape in z-order is kept: `paint_all_of`
+  aliases the canvas with the backdrop's storage (campx/rendering.py:128), so those
+  sprites are written into the backdrop for good and leave trails; the first
+  `paint_drape` rebinds the canvas (rendering.py:178) and ends that.  `spec.backdrop`
+  is the backdrop as `its_showtime()` leaves it (their initial cells already painted);
+  the kernel keeps a per-environment copy as state.
+  """
+  H, W = desc.rows, desc.cols
+  HW = H * W
+  if HW > SHAPE_MAX_CELLS or H > 127 or W > 127:
+    _fail('{}x{} board is too large for the shape tier'.format(H, W))
+  if len(desc.chars) > MAX_LAYERS:
+    _fail('more than {} characters'.format(MAX_LAYERS))
+  for e in desc.entities:
+    if e.kind not in ('shape', 'fixed'):
+      _fail('{!r} is a {} rule: shape games (RollingDrape / SlidingSprite) cannot '
+            'be mixed with interacting rules'.format(e.char, e.kind))
+  if not 1 <= len(desc.entities) <= SHAPE_MAX_THINGS:
+    _fail('needs between 1 and {} things'.format(SHAPE_MAX_THINGS))
+  layer_of = {ch: i for i, ch in enumerate(desc.chars)}
+  order = [desc.entity(ch) for ch in desc.z_order]            # back to front
+  is_sprite = [bool(e.params.get('sprite')) for e in order]
+  if all(is_sprite):
+    _fail('a game with no drape at all cannot be lowered: the reference renderer '
+          'zeroes its own backdrop on the second render (campx/rendering.py:111,128)')
+  spec = CampxShapeSpec()
+  spec.magic, spec.version = SHAPE_SPEC_MAGIC, SHAPE_SPEC_VERSION
+  spec.rows, spec.cols = H, W
+  spec.n_layers, spec.n_things = len(desc.chars), len(order)
+  spec.first_drape = is_sprite.index(False)
+  for i, ch in enumerate(desc.chars):
+    spec.layer_char[i] = ord(ch)
+  index_of = {e.char: i for i, e in enumerate(order)}
+  for i, e in enumerate(desc.entities):                        # update-schedule order
+    spec.update_order[i] = index_of[e.char]
+  backdrop = np.array([[layer_of[chr(c)] for c in row] for row in desc.backdrop],
+                      dtype=np.uint8)
+  n_list, any_reward = 0, False
+  for i, e in enumerate(order):
+    t, p = spec.things[i], e.params
+    cells = np.argwhere(e.mask != 0)
+    if n_list + len(cells) > SHAPE_MAX_LIST:
+      _fail('the things of this game cover more than {} cells'.format(SHAPE_MAX_LIST))
+    t.layer, t.is_sprite = layer_of[e.char], int(is_sprite[i])
+    t.visible = int(p.get('visible', True))
+    t.n_cells, t.cell_begin = len(cells), n_list
+    for r, c in cells:
+      spec.cells[n_list] = (int(r) << 8) | int(c)
+      n_list += 1
+    if e.kind == 'shape':
+      n_act = len(p['drow'])
+      if n_act > N_ACTIONS or len(p['dcol']) != n_act or len(p['rewards']) != n_act:
+        _fail('{!r}: at most {} actions'.format(e.char, N_ACTIONS))
+      for a in range(n_act):
+        t.drow[a], t.dcol[a] = int(p['drow'][a]) % H, int(p['dcol'][a]) % W
+        if p['rewards'][a] is not None:
+          t.has_reward_mask |= 1 << a
+          t.reward[a] = float(p['rewards'][a])
+          any_reward = True
+      if p.get('quit_action') is not None:
+        if not 0 <= p['quit_action'] < N_ACTIONS:
+          _fail('{!r}: quit_action outside 0..{}'.format(e.char, N_ACTIONS - 1))
+        t.terminate_mask = 1 << int(p['quit_action'])
+    if i < spec.first_drape and t.visible:                     # the trail quirk
+      for r, c in cells:
+        backdrop[r, c] = t.layer
+  spec.any_reward = int(any_reward)
+  for i in range(HW):
+    spec.backdrop[i] = int(backdrop.flat[i])
+  return spec

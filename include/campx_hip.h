@@ -287,6 +287,74 @@ int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
 int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxOutputs out,
                             int64_t B, int32_t T, void* stream);
 
+/*
+ * ---- Shape tier --------------------------------------------------------------------
+ * Games made only of rigidly translated things that interact with nothing: the
+ * reference's Hello World (examples/Hello World Example.ipynb cell 3: RollingDrape
+ * `np.roll`s its whole mask, SlidingSprite moves diagonally, action 4 quits).  A thing
+ * is a set of art cells plus a cyclic (row, col) offset that the action changes; things
+ * may cover many cells and boards go up to CAMPX_SHAPE_MAX_CELLS cells, so these games
+ * have their own spec and kernel (one wavefront per environment).
+ *
+ * Rendering follows campx/engine.py:295-324 and campx/rendering.py:104-219 including
+ * the renderer's aliasing: paint_all_of() makes the canvas share the backdrop's storage
+ * (rendering.py:128) until the first paint_drape rebinds it (rendering.py:178), so
+ * sprites painted BEFORE the first drape in z-order are written into the backdrop for
+ * good and leave trails.  The backdrop is therefore per-environment state here.
+ */
+#define CAMPX_SHAPE_SPEC_MAGIC 0x50485343u /* 'CSHP' */
+#define CAMPX_SHAPE_SPEC_VERSION 1u
+#define CAMPX_SHAPE_MAX_CELLS 1024 /* rows * cols; rows, cols <= 127 */
+#define CAMPX_SHAPE_MAX_THINGS 8
+#define CAMPX_SHAPE_MAX_LIST 2048  /* cells covered by all things together */
+
+typedef struct CampxShapeThing {
+  int32_t layer;            /* layer (character) it paints */
+  int32_t is_sprite;        /* painted by paint_sprite (rendering.py:150), else paint_drape */
+  int32_t visible;          /* Sprite.visible (campx/things.py:380); drapes: 1 */
+  int32_t n_cells;          /* its shape: cells[cell_begin .. cell_begin + n_cells) */
+  int32_t cell_begin;
+  int32_t has_reward_mask;  /* bit a: action a makes it call Plot.add_reward(reward[a]) */
+  int32_t terminate_mask;   /* bit a: action a makes it call Plot.terminate_episode() */
+  int32_t reserved;
+  int8_t drow[8], dcol[8];  /* offset change per action, already modulo rows / cols (>= 0) */
+  float reward[8];
+} CampxShapeThing;          /* 80 bytes */
+
+typedef struct CampxShapeSpec {
+  uint32_t magic, version;
+  int32_t rows, cols;
+  int32_t n_layers;
+  int32_t n_things;                          /* stored in z-order, back to front */
+  int32_t first_drape;                       /* index of the first thing that is not a sprite */
+  int32_t any_reward;
+  uint8_t layer_char[CAMPX_MAX_LAYERS];
+  int32_t update_order[CAMPX_SHAPE_MAX_THINGS]; /* thing indices in update-schedule order
+                                                (rewards are summed in that order) */
+  CampxShapeThing things[CAMPX_SHAPE_MAX_THINGS];
+  uint8_t backdrop[CAMPX_SHAPE_MAX_CELLS];   /* layer per cell of the Backdrop as its_showtime()
+                                                leaves it (trail sprites' art cells painted) */
+  uint16_t cells[CAMPX_SHAPE_MAX_LIST];      /* art cell of each shape cell: row << 8 | col */
+} CampxShapeSpec;
+
+int32_t campx_shape_spec_size(void);
+int32_t campx_shape_spec_validate(const CampxShapeSpec* spec_host);
+
+/*
+ * Advance B environments of a shape game by T frames (T = 0 with emit_first: the
+ * its_showtime() observation).  State: state.pos [2*n_things, B] int8 = cyclic (row, col)
+ * offset of each thing from its art position, state.done, state.ret as for
+ * campx_rollout_launch, and `backdrop_state` [B, rows*cols] int8 layer per cell (the
+ * per-environment Backdrop; may be NULL when no visible sprite precedes the first
+ * drape).  Outputs: out.obs (int8 only), out.board, out.reward, out.discount, out.done,
+ * out.bad_count / bad_flag; frames at base + t * stride as for campx_rollout_launch.
+ * Action ids outside 0..4 move nothing, end nothing and are counted as bad.
+ */
+int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxShapeSpec* spec_dev,
+                                   CampxState state, int8_t* backdrop_state,
+                                   const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                                   int32_t reset_first, int32_t emit_first, void* stream);
+
 /* *bad_count (device int32, caller-zeroed) += number of ids outside 0..4 in
  * actions[0..n). */
 int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* bad_count,

@@ -15,6 +15,8 @@
  *   DirectionalHoverRewardDrape.update                         examples/boat_race.py:69-91 (Demo 4 cell 3)
  *   FixedDrape.update                                          campx/things.py:395-398
  *   BoxDrape / GoalDrape                                       build-authored rules (campx_amd/rules.py)
+ *   RollingDrape / SlidingSprite                               examples/Hello World Example.ipynb cell 3
+ *   paint_sprite and the canvas/backdrop aliasing              campx/rendering.py:128,150,178
  *
  * It is deliberately literal: every drape keeps a full H*W 0/1 curtain, moves are
  * cyclic whole-mask shifts blended by the one-hot action, blocking is the
@@ -43,7 +45,8 @@
 #define ORACLE_MAX_CHARS 32
 #define ORACLE_MAX_SET 8
 
-enum { KIND_FIXED = 0, KIND_AGENT = 1, KIND_DIR_HOVER = 2, KIND_BOX = 3, KIND_GOAL = 4 };
+enum { KIND_FIXED = 0, KIND_AGENT = 1, KIND_DIR_HOVER = 2, KIND_BOX = 3, KIND_GOAL = 4,
+       KIND_ROLLING = 5, KIND_SLIDING_SPRITE = 6 };
 
 /* One sprite/drape, in update-schedule order. Plain-old-data: ctypes mirrors it. */
 typedef struct {
@@ -61,6 +64,15 @@ typedef struct {
   float base_reward;                   /* DIR_HOVER */
   float dctns[5];                      /* DIR_HOVER */
   float goal_reward;                   /* GOAL */
+  /* Hello World rules: integer actions 0..3 move, `quit_action` terminates.
+   * ROLLING: np.roll(curtain, shift[a], axis[a]) and add_reward(step_reward);
+   * SLIDING_SPRITE: position += (dy[a], dx[a]) modulo the board. */
+  int32_t is_sprite;                   /* painted with paint_sprite at its position */
+  int32_t visible;
+  int32_t n_moves;                     /* actions 0..n_moves-1 move */
+  int32_t roll_axis[4], roll_shift[4]; /* ROLLING */
+  int32_t dy[4], dx[4];                /* SLIDING_SPRITE */
+  int32_t quit_action;                 /* ROLLING: -1 = none */
 } OracleEntity;
 
 typedef struct {
@@ -81,7 +93,8 @@ typedef struct {
 
 /* Per-environment working state. */
 typedef struct {
-  uint8_t curtain[ORACLE_MAX_ENTITIES][ORACLE_MAX_CELLS];
+  uint8_t curtain[ORACLE_MAX_ENTITIES][ORACLE_MAX_CELLS];  /* a sprite: one-hot at its position */
+  int32_t backdrop[ORACLE_MAX_CELLS];                 /* the Backdrop's curtain: mutable, see render() */
   int32_t board[ORACLE_MAX_CELLS];                    /* renderer canvas */
   uint8_t layers[ORACLE_MAX_CHARS][ORACLE_MAX_CELLS]; /* as of latest render */
 } Env;
@@ -98,23 +111,49 @@ static int entity_of_char(const OracleGame* g, int ch) {
   return -1;
 }
 
-/* engine.py:295-324 + rendering.py:104-219: backdrop, then every drape in
- * z-order overwrites (board - m*board + m*code), then one layer per character by
- * equality with the painted board. */
-static void render(const OracleGame* g, Env* e) {
+/* engine.py:295-324 + rendering.py:104-219: backdrop, then every thing in z-order:
+ * a sprite writes its character at its position (rendering.py:150), a drape overwrites
+ * (board - m*board + m*code) (rendering.py:174-178); then one layer per character by
+ * equality with the painted board.
+ *
+ * paint_all_of() does `board.set_(curtain)` (rendering.py:128): the canvas ALIASES the
+ * backdrop's storage until the first paint_drape rebinds it to a fresh tensor
+ * (rendering.py:178).  Sprites painted before the first drape therefore write into the
+ * backdrop itself, for good.  Restated literally: `canvas` points at the backdrop until
+ * the first drape copies it.  Returns -1 for a z-order without any drape (the reference
+ * then zeroes its own backdrop in clear(), rendering.py:111; nothing lowers such games). */
+static int render(const OracleGame* g, Env* e) {
   const int n = g->rows * g->cols;
-  for (int i = 0; i < n; ++i) e->board[i] = g->backdrop[i];
+  int32_t* canvas = e->backdrop;
+  int aliased = 1;
   for (int z = 0; z < g->n_entities; ++z) {
     const int k = g->z_order[z];
-    const int code = g->entities[k].ch;
-    for (int i = 0; i < n; ++i) {
-      const int m = e->curtain[k][i];
-      e->board[i] = e->board[i] - m * e->board[i] + m * code;
+    const OracleEntity* en = &g->entities[k];
+    const int code = en->ch;
+    if (en->is_sprite) {
+      if (!en->visible) continue;
+      for (int i = 0; i < n; ++i)
+        if (e->curtain[k][i]) canvas[i] = code;
+    } else {
+      if (aliased) {
+        for (int i = 0; i < n; ++i) e->board[i] = e->backdrop[i];
+        canvas = e->board;
+        aliased = 0;
+      }
+      for (int i = 0; i < n; ++i) {
+        const int m = e->curtain[k][i];
+        canvas[i] = canvas[i] - m * canvas[i] + m * code;
+      }
     }
+  }
+  if (aliased) {
+    if (g->n_entities) return -1;
+    for (int i = 0; i < n; ++i) e->board[i] = e->backdrop[i];
   }
   for (int c = 0; c < g->n_chars; ++c)
     for (int i = 0; i < n; ++i)
       e->layers[c][i] = (uint8_t)(e->board[i] == g->chars[c]);
+  return 0;
 }
 
 /* Cyclic one-cell shifts blended by the one-hot action (boat_race.py:42-49):
@@ -206,6 +245,40 @@ static void update_entity(const OracleGame* g, Env* e, int k, int action, Direct
         e->curtain[k][i] = (uint8_t)(move * b[i] + (1 - move) * e->curtain[k][i]);
       break;
     }
+    case KIND_ROLLING: {
+      /* Hello World cell 3 RollingDrape.update: quit, else np.roll + add_reward */
+      if (action == en->quit_action) {  /* plot.py:183-184 */
+        d->game_over = 1;
+        d->discount = 0.0f;
+      }
+      if (action < en->n_moves) {
+        const int H = g->rows, W = g->cols;
+        const int shift = en->roll_shift[action], axis = en->roll_axis[action];
+        for (int r = 0; r < H; ++r)
+          for (int c = 0; c < W; ++c) {
+            const int r2 = axis == 0 ? ((r + shift) % H + H) % H : r;
+            const int c2 = axis == 1 ? ((c + shift) % W + W) % W : c;
+            b[r2 * W + c2] = e->curtain[k][r * W + c];
+          }
+        memcpy(e->curtain[k], b, (size_t)n);
+        add_reward(d, en->step_reward);
+      }
+      break;
+    }
+    case KIND_SLIDING_SPRITE: {
+      /* Hello World cell 3 SlidingSprite.update: position + (dy, dx), modulo the board */
+      if (action < en->n_moves) {
+        const int H = g->rows, W = g->cols;
+        int at = 0;
+        for (int i = 0; i < n; ++i)
+          if (e->curtain[k][i]) at = i;
+        const int r2 = ((at / W + en->dy[action]) % H + H) % H;
+        const int c2 = ((at % W + en->dx[action]) % W + W) % W;
+        memset(e->curtain[k], 0, (size_t)n);
+        e->curtain[k][r2 * W + c2] = 1;
+      }
+      break;
+    }
     case KIND_GOAL: {
       /* campx_amd/rules.py GoalDrape.update */
       const int a = entity_of_char(g, en->agents[0]);
@@ -239,6 +312,7 @@ static int step_perf(const OracleGame* g, const uint8_t* pre, const uint8_t* pos
 static void reset_env(const OracleGame* g, Env* e) {
   const int n = g->rows * g->cols;
   for (int k = 0; k < g->n_entities; ++k) memcpy(e->curtain[k], g->curtains0[k], (size_t)n);
+  for (int i = 0; i < n; ++i) e->backdrop[i] = g->backdrop[i];
 }
 
 /*
@@ -247,6 +321,8 @@ static void reset_env(const OracleGame* g, Env* e) {
  *  curtains  [B, n_entities, H*W] uint8, in/out: the drapes' masks (the whole
  *            dynamic state of a game; pass NULL with reset_first=1 to start from
  *            the art and discard the final state).
+ *  backdrops [B, H*W] uint8 in/out, or NULL: the per-environment Backdrop curtain (it
+ *            changes only in games whose sprites paint into it, see render()).
  *  done      [B] uint8 in/out: game-over latch.  An environment whose latch is
  *            set is rebuilt from the art (make_game + its_showtime) before its
  *            next action is applied - the reference driver's behaviour at an
@@ -266,7 +342,8 @@ static void reset_env(const OracleGame* g, Env* e) {
 int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t* actions,
                          uint8_t* curtains, uint8_t* done, int32_t reset_first, int8_t* obs,
                          int64_t obs_t_stride, int8_t* board, int64_t board_t_stride,
-                         float* reward, float* discount, uint8_t* done_out, int8_t* perf) {
+                         float* reward, float* discount, uint8_t* done_out, int8_t* perf,
+                         uint8_t* backdrops) {
   const int n = g->rows * g->cols;
   const int L = g->n_chars;
   int n_groups = 0;
@@ -283,8 +360,9 @@ int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t
     } else {
       for (int k = 0; k < g->n_entities; ++k)
         memcpy(e->curtain[k], curtains + (env * g->n_entities + k) * n, (size_t)n);
+      for (int i = 0; i < n; ++i) e->backdrop[i] = backdrops ? backdrops[env * n + i] : g->backdrop[i];
     }
-    render(g, e);  /* the board the first frame's updates read */
+    if (render(g, e) != 0) bad = 1;  /* the board the first frame's updates read */
     for (int t = 0; t < T; ++t) {
       const int action = actions[(int64_t)t * B + env];
       if (action < 0 || action > 4) {
@@ -327,6 +405,8 @@ int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t
     if (curtains)
       for (int k = 0; k < g->n_entities; ++k)
         memcpy(curtains + (env * g->n_entities + k) * n, e->curtain[k], (size_t)n);
+    if (backdrops)
+      for (int i = 0; i < n; ++i) backdrops[env * n + i] = (uint8_t)e->backdrop[i];
     if (done) done[env] = (uint8_t)over;
     free(e);
   }

@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, '_build', 'libcampx_oracle.so')
 
 MAX_CELLS, MAX_ENTITIES, MAX_CHARS, MAX_SET = 1024, 16, 32, 8
-KINDS = {'fixed': 0, 'agent': 1, 'dir_hover': 2, 'box': 3, 'goal': 4}
+KINDS = {'fixed': 0, 'agent': 1, 'dir_hover': 2, 'box': 3, 'goal': 4,
+         'rolling': 5, 'sliding_sprite': 6}
 
 
 class _Entity(ctypes.Structure):
@@ -33,7 +34,12 @@ class _Entity(ctypes.Structure):
               ('agents', ctypes.c_int32 * MAX_SET),
               ('base_reward', ctypes.c_float),
               ('dctns', ctypes.c_float * 5),
-              ('goal_reward', ctypes.c_float)]
+              ('goal_reward', ctypes.c_float),
+              ('is_sprite', ctypes.c_int32), ('visible', ctypes.c_int32),
+              ('n_moves', ctypes.c_int32),
+              ('roll_axis', ctypes.c_int32 * 4), ('roll_shift', ctypes.c_int32 * 4),
+              ('dy', ctypes.c_int32 * 4), ('dx', ctypes.c_int32 * 4),
+              ('quit_action', ctypes.c_int32)]
 
 
 class _Game(ctypes.Structure):
@@ -96,6 +102,7 @@ class OracleGame(object):
     self.chars = chars
     self.rows, self.cols, self.n_entities = rows, cols, n_entities
     self.curtains = None
+    self.backdrops = None
     self.done = None
 
   @classmethod
@@ -114,7 +121,11 @@ class OracleGame(object):
       g.backdrop[i] = int(desc.backdrop.flat[i])
     for i, e in enumerate(desc.entities):
       en, p = g.entities[i], e.params
-      en.kind, en.ch, en.group = KINDS[e.kind], ord(e.char), e.group
+      kind = e.kind
+      if kind == 'shape':      # Hello World rules: a rolling drape or a sliding sprite
+        kind = 'sliding_sprite' if p['sprite'] else 'rolling'
+      en.kind, en.ch, en.group = KINDS[kind], ord(e.char), e.group
+      en.visible, en.quit_action = 1, -1
       for j in range(n):
         g.curtains0[i][j] = int(e.mask.flat[j])
       if e.kind == 'agent':
@@ -142,6 +153,23 @@ class OracleGame(object):
         en.n_agents, en.agents[0] = 1, ord(p['agent'])
         en.step_reward = float(p['step_reward'])
         en.goal_reward = float(p['goal_reward'])
+      elif e.kind == 'shape':
+        en.n_moves = len(p['drow'])
+        assert en.n_moves <= 4
+        en.visible = int(p['visible'])
+        if p['sprite']:
+          en.is_sprite = 1
+          for a in range(en.n_moves):
+            en.dy[a], en.dx[a] = int(p['drow'][a]), int(p['dcol'][a])
+        else:
+          for a in range(en.n_moves):
+            assert (p['drow'][a] == 0) != (p['dcol'][a] == 0)    # one axis per action
+            en.roll_axis[a] = 0 if p['drow'][a] else 1
+            en.roll_shift[a] = int(p['drow'][a] or p['dcol'][a])
+          rewards = set(p['rewards'])
+          assert len(rewards) == 1 and None not in rewards
+          en.has_step_reward, en.step_reward = 1, float(p['rewards'][0])
+          en.quit_action = -1 if p['quit_action'] is None else int(p['quit_action'])
     if desc.performance is not None:
       agent, masks = desc.performance
       assert len(masks) <= MAX_SET
@@ -171,6 +199,7 @@ class OracleGame(object):
     L, H, W = len(self.chars), self.rows, self.cols
     if self.curtains is None or self.curtains.shape[0] != B:
       self.curtains = np.zeros((B, self.n_entities, H * W), np.uint8)
+      self.backdrops = np.zeros((B, H * W), np.uint8)
       self.done = np.zeros((B,), np.uint8)
       reset_first = True
     Tk = T if keep_obs else 1
@@ -185,9 +214,9 @@ class OracleGame(object):
         _np_ptr(self.done), int(reset_first), _np_ptr(obs),
         B * L * H * W if keep_obs else 0, _np_ptr(board),
         B * H * W if keep_obs else 0, _np_ptr(reward), _np_ptr(discount),
-        _np_ptr(done), _np_ptr(perf))
+        _np_ptr(done), _np_ptr(perf), _np_ptr(self.backdrops))
     if rc != 0:
-      raise ValueError('oracle: action id outside 0..4')
+      raise ValueError('oracle: action id outside 0..4 (or a game without any drape)')
     if not keep_obs:
       obs, board = obs[0], (board[0] if want_board else None)
     return dict(obs=obs, board=board, reward=reward, discount=discount,

@@ -1,6 +1,6 @@
 """Name -> builder for every game that has a golden fixture and a fused lowering."""
 
-from campx_amd.games import boat_race, wall_world, sokoban, demos
+from campx_amd.games import boat_race, wall_world, sokoban, demos, hello_world
 
 import functools
 
@@ -15,3 +15,6 @@ FUSED_GAMES = {
     'demo3': demos.demo3,
     'demo4': demos.demo4,
 }
+
+# Games of the shape tier (rules.RollingDrape / rules.SlidingSprite): own spec and kernel.
+SHAPE_GAMES = {'hello_world': hello_world.build}

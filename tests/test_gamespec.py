@@ -136,10 +136,44 @@ def test_lowering_refuses_what_the_cell_model_cannot_express():
   class S(things.Sprite):
     def update(self, *a):
       pass
-  with pytest.raises(ValueError, match='Sprites cannot be lowered'):
+  with pytest.raises(ValueError, match="sprite 'S' is a S, which cannot be lowered"):
     lower(['AS'], ' ', sprites={'S': S}, drapes={'A': Partial(rules.AgentDrape, blocking_chars='')},
           z_order='SA')
+  # shape rules (Hello World) do not mix with interacting one-cell rules
+  with pytest.raises(ValueError, match='moving things|cannot be mixed'):
+    g = ascii_art_to_game(['A@'], ' ', drapes={'A': Partial(rules.AgentDrape, blocking_chars=''),
+                                                '@': rules.RollingDrape}, z_order='A@')
+    d = gamespec.describe(g)
+    assert d.is_shape_game
+    gamespec.lower_shapes(d)
   # board too large for the bit/cell tables
   with pytest.raises(ValueError, match='more than 128 cells'):
     lower(['A' + ' ' * 12] + [' ' * 13] * 9, ' ',
           drapes={'A': Partial(rules.AgentDrape, blocking_chars='')})
+
+
+def test_hello_world_lowers_to_a_valid_shape_spec():
+  from campx_amd.games import hello_world
+  desc = gamespec.describe(hello_world.build())
+  assert desc.is_shape_game and desc.z_order == list('12@34')
+  spec = gamespec.lower_shapes(desc)
+  assert _hip.lib.campx_shape_spec_validate(ctypes.byref(spec)) == 0
+  assert _hip.lib.campx_shape_spec_size() == ctypes.sizeof(gamespec.CampxShapeSpec)
+  assert (spec.rows, spec.cols, spec.n_layers, spec.n_things, spec.first_drape) == (13, 36, 7, 5, 2)
+  drape = spec.things[2]
+  assert (drape.is_sprite, drape.n_cells, drape.terminate_mask, drape.has_reward_mask) == (0, 59, 16, 15)
+  assert list(drape.drow)[:5] == [12, 1, 0, 0, 0] and list(drape.dcol)[:5] == [0, 0, 35, 1, 0]
+  # sprites 1 and 2 sit behind the drape: their art cells are already in the backdrop
+  # (the reference renderer's aliasing); sprites 3 and 4 are not
+  layer = {chr(spec.layer_char[i]): i for i in range(spec.n_layers)}
+  assert spec.backdrop[7 * 36 + 34] == layer['1'] and spec.backdrop[8 * 36 + 34] == layer['2']
+  assert spec.backdrop[9 * 36 + 34] == layer[' '] and spec.backdrop[11 * 36 + 34] == layer[' ']
+  # corrupting it is caught
+  spec.first_drape = 0          # thing 0 is a sprite: not a drape
+  assert _hip.lib.campx_shape_spec_validate(ctypes.byref(spec)) == -2
+
+
+def test_a_game_of_sprites_only_is_refused():
+  g = ascii_art_to_game(['1 '], ' ', sprites={'1': Partial(rules.SlidingSprite, 0)})
+  with pytest.raises(ValueError, match='no drape at all'):
+    gamespec.lower_shapes(gamespec.describe(g))

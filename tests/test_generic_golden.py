@@ -63,61 +63,14 @@ def test_library_rules_on_generic_tier(name, golden):
   replay(FUSED_GAMES[name], gold, name, envs=range(min(6, gold['actions'].shape[1])))
 
 
-# -- Hello World: sprites, a rolling drape, termination.  The classes below are the
-# test's own statement of the notebook's rules (Hello World cell 3); the golden was
-# produced by the notebook's classes on the reference engine.
-
-class RollingDrape(things.Drape):
-  AXES = [0, 0, 1, 1]
-  SHIFTS = [-1, 1, -1, 1]
-
-  def update(self, actions, board, layers, backdrop, all_things, the_plot):
-    if actions is None:
-      return
-    if actions == 4:
-      the_plot.terminate_episode()
-    if actions < 4:
-      self.curtain.set_(torch.roll(self.curtain, self.SHIFTS[actions], self.AXES[actions]))
-      the_plot.add_reward(1)
-
-
-class SlidingSprite(things.Sprite):
-  DX = ([-1, 1, -1, 1], [-1, 1, -1, 1], [1, -1, 1, -1], [1, -1, 1, -1])
-  DY = ([-1, 1, 1, -1], [1, -1, -1, 1], [1, -1, -1, 1], [-1, 1, 1, -1])
-
-  def __init__(self, corner, position, character, direction_set):
-    super(SlidingSprite, self).__init__(corner, position, character)
-    self._dx, self._dy = self.DX[direction_set], self.DY[direction_set]
-
-  def update(self, actions, board, layers, backdrop, all_things, the_plot):
-    if actions is None or actions > 3:
-      return
-    self._position = self.Position(
-        (self._position.row + self._dy[actions]) % self.corner.row,
-        (self._position.col + self._dx[actions]) % self.corner.col)
-
-
-HELLO_ART = ['                                    ',
-             '  #   #  ### #    #     ###         ',
-             '  #   # #    #    #    #   #        ',
-             '  ##### #### #    #    #   #        ',
-             '  #   # #    #    #    #   #        ',
-             '  #   #  ###  ###  ###  ###         ',
-             '                                    ',
-             '     @   @  @@@   @@@  @    @@@@  1 ',
-             '     @   @ @   @ @   @ @    @   @ 2 ',
-             '     @ @ @ @   @ @@@@  @    @   @ 3 ',
-             '     @ @ @ @   @ @   @ @    @   @   ',
-             '      @@@   @@@  @   @  @@@ @@@@  4 ',
-             '                                    ']
-
+# -- Hello World: sprites, a rolling drape, termination (campx_amd.games.hello_world uses
+# rules.RollingDrape / rules.SlidingSprite; the golden was produced by the notebook's own
+# classes on the reference engine, and make_golden.py asserts the library classes give
+# the same trajectory there).
 
 def hello_world():
-  return ascii_art_to_game(
-      HELLO_ART, what_lies_beneath=' ',
-      sprites={'1': Partial(SlidingSprite, 0), '2': Partial(SlidingSprite, 1),
-               '3': Partial(SlidingSprite, 2), '4': Partial(SlidingSprite, 3)},
-      drapes={'@': RollingDrape}, z_order='12@34')
+  from campx_amd.games import hello_world as g
+  return g.build()
 
 
 def test_hello_world_sprites_rolling_drape_and_termination(golden):

@@ -9,13 +9,15 @@ import pytest
 
 from campx_amd import gamespec
 from oracle import cpu
-from games_under_test import FUSED_GAMES
+from games_under_test import FUSED_GAMES, SHAPE_GAMES
+
+ALL_GAMES = dict(FUSED_GAMES, **SHAPE_GAMES)
 
 
-@pytest.mark.parametrize('name', sorted(FUSED_GAMES))
+@pytest.mark.parametrize('name', sorted(ALL_GAMES))
 def test_oracle_reproduces_reference_trajectories(name, golden):
   gold = golden(name)
-  og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES[name]()))
+  og = cpu.OracleGame.from_description(gamespec.describe(ALL_GAMES[name]()))
   assert [ord(c) for c in og.chars] == gold['chars'].tolist()
   obs0, board0 = og.first_frame()
   n = gold['actions'].shape[1]
@@ -51,3 +53,14 @@ def test_oracle_rejects_bad_action():
   og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES['boat_race']()))
   with pytest.raises(ValueError):
     og.rollout(np.full((1, 4), 7, np.int8), reset_first=True)
+
+
+def test_oracle_backdrop_state_carries_across_calls(golden):
+  """Hello World's sprites paint into the backdrop: it is state too."""
+  gold = golden('hello_world')
+  desc = gamespec.describe(SHAPE_GAMES['hello_world']())
+  og = cpu.OracleGame.from_description(desc)
+  for t in range(gold['actions'].shape[0]):
+    step = og.rollout(gold['actions'][t:t + 1], reset_first=(t == 0))
+    assert np.array_equal(step['obs'][0], gold['layered'][t + 1])
+  assert (og.backdrops != np.frombuffer(bytes(og._g.backdrop), np.uint8)[:13 * 36]).any()

@@ -1,0 +1,104 @@
+"""Shape tier (Hello World: rolling drape, sliding sprites, quit action) on the HIP
+device vs the reference-generated golden and the CPU oracle.  Bit-exact."""
+
+import numpy as np
+import pytest
+import torch
+
+from campx_amd import gamespec
+from campx_amd.games import hello_world
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+  a, b = np.asarray(a), np.asarray(b)
+  if a.dtype.kind == 'f':
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+  return np.array_equal(a, b)
+
+
+def _game(batch):
+  game = hello_world.build(batch=batch, device='cuda')
+  first = game.its_showtime()
+  from campx_amd import shapes
+  assert isinstance(game.fused, shapes.ShapeGame)
+  return game, first
+
+
+def test_golden_rollout(golden):
+  """The notebook's own classes on the reference engine -> same frames, incl. the
+  trails sprites 1 and 2 leave in the backdrop and the quit at frame 25 of env 0."""
+  gold = golden('hello_world')
+  T, N = gold['actions'].shape
+  game, (obs, reward, discount) = _game(N)
+  assert reward is None and discount == 1.0
+  assert [ord(c) for c in game.fused.chars] == gold['chars'].tolist()
+  assert _same(obs.layered_board.cpu().numpy(), gold['layered'][0])
+  assert _same(obs.board.cpu().numpy(), gold['board'][0])
+  out = game.rollout(torch.from_numpy(gold['actions']), want_board=True)
+  assert _same(out['obs'].cpu().numpy(), gold['layered'][1:])
+  assert _same(out['board'].cpu().numpy(), gold['board'][1:])
+  assert _same(out['reward'].cpu().numpy(), gold['reward'])
+  assert _same(out['discount'].cpu().numpy(), gold['discount'])
+  assert _same(out['done'].cpu().numpy(), gold['done'])
+  assert gold['done'][25, 0] == 1 and np.isnan(gold['reward'][25, 0])
+
+
+def test_play_frame_by_frame(golden):
+  gold = golden('hello_world')
+  T, N = gold['actions'].shape
+  game, _ = _game(N)
+  for t in range(T):
+    obs, reward, discount = game.play(torch.from_numpy(gold['actions'][t]))
+    assert _same(obs.layered_board.cpu().numpy(), gold['layered'][t + 1]), t
+    assert _same(obs.board.cpu().numpy(), gold['board'][t + 1])
+    for i, ch in enumerate(game.fused.chars):
+      assert _same(obs.layers[ch].cpu().numpy(), gold['layered'][t + 1][:, i])
+    assert _same(reward.cpu().numpy(), gold['reward'][t])
+    assert _same(discount.cpu().numpy(), gold['discount'][t])
+    assert _same(game.fused.done.cpu().numpy(), gold['done'][t])
+
+
+@pytest.mark.parametrize('batch', [1, 3, 64, 1000])
+def test_random_streams_vs_oracle(batch):
+  """Ragged batches, state (offsets, backdrop, latch) carried across launches, quits."""
+  rng = np.random.RandomState(batch)
+  game, _ = _game(batch)
+  og = cpu.OracleGame.from_description(gamespec.describe(hello_world.build()))
+  for launch, T in enumerate([1, 9, 40]):
+    actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), want_board=True)
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'board', 'reward', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
+  assert ref['done'].sum() > 0 or batch < 3
+
+
+def test_larger_batch_and_invariants():
+  batch, T = 8192, 50
+  rng = np.random.RandomState(7)
+  actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+  game, _ = _game(batch)
+  out = game.rollout(torch.from_numpy(actions), reset_first=True)
+  og = cpu.OracleGame.from_description(gamespec.describe(hello_world.build()))
+  stride = 16
+  ref = og.rollout(np.ascontiguousarray(actions[:, ::stride]), reset_first=True, want_board=False)
+  assert _same(out['obs'][:, ::stride].cpu().numpy(), ref['obs'])
+  assert _same(out['reward'][:, ::stride].cpu().numpy(), ref['reward'])
+  assert _same(out['done'][:, ::stride].cpu().numpy(), ref['done'])
+  sums = out['obs'].sum(dim=2, dtype=torch.int32)
+  assert int(sums.min()) == 1 and int(sums.max()) == 1
+
+
+def test_bad_action_ids_move_nothing_and_are_counted():
+  game, _ = _game(64)
+  game.fused.validate_actions = 'sync'
+  before = game.fused._obs.clone()
+  with pytest.raises(ValueError, match='64 action ids'):
+    game.play(torch.full((64,), 7))
+  game.fused.validate_actions = False
+  obs, reward, discount = game.play(torch.full((64,), 7))
+  assert torch.equal(obs.layered_board, before)
+  assert torch.isnan(reward).all() and (discount == 1).all()
