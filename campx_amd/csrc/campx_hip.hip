@@ -850,8 +850,14 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
 #define CAMPX_UPD_XCD 0
 #endif
 
-// loader waves of an update workgroup: one per 128 environments
+// loader waves of an update workgroup: one per 128 environments (a 256-environment
+// chunk held by one wave is 64 VGPRs of loads in flight: with two the pair kernel stops
+// spilling).  CAMPX_UPD_LOADERS overrides for A/B builds.
+#ifdef CAMPX_UPD_LOADERS
+constexpr int update_loaders(int) { return CAMPX_UPD_LOADERS; }
+#else
 constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
+#endif
 
 template <int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) void update_table_kernel(
