@@ -41,11 +41,16 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 # Algorithmic bytes per env-step, SURVEY.md section 8(d):
 # L*H*W obs + 4 reward + 1 action + 2*S state.
-BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194}
+BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194,
+                      # 6x8 boards, 6 / 7 characters, 3 / 4 moving things (S = 6 / 8)
+                      'sokoban_l1': 288 + 4 + 1 + 12 + 1, 'sokoban_l2': 336 + 4 + 1 + 16 + 1}
 WORKLOADS = {
     'boat_race': ('boat_race 5x5', 65536),
     'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
     'sokoban': ('side_effects_sokoban 6x6 (build-authored level 0)', 131072),
+    # not BASELINE configs: games with 3 and 4 moving things (rule interpreter path)
+    'sokoban_l1': ('sokoban 6x8 with two boxes (build-authored level 1)', 131072),
+    'sokoban_l2': ('sokoban 6x8 with three boxes (build-authored level 2)', 131072),
 }
 HEADLINE_METRIC = 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X'
 TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_traffic.json')
@@ -215,7 +220,10 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   on_gpu = standin is None
   if on_gpu:
     from campx_amd import games
-    game = getattr(games, game_name).build(batch=B, device=device)
+    if game_name.startswith('sokoban_l'):
+      game = games.sokoban.build(batch=B, device=device, level=int(game_name[-1]))
+    else:
+      game = getattr(games, game_name).build(batch=B, device=device)
   else:
     game = standin(game_name, B)
   game.its_showtime()
@@ -348,6 +356,27 @@ def play_mode(device, B=65536, calls=2000):
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / calls
     modes[name] = {'us_per_call': dt * 1e6, 'env_steps_per_s': B / dt}
+  # the same frames captured once in a HIP graph (campx::step only enqueues kernels on
+  # the current stream): one graph launch per 32 frames instead of 32 op dispatches
+  game.fused.validate_actions = False
+  side = torch.cuda.Stream(device)
+  with torch.cuda.stream(side):
+    for i in range(4):
+      game.play(rows[i])
+  torch.cuda.current_stream(device).wait_stream(side)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    for i in range(32):
+      game.play(rows[i])
+  for _ in range(5):
+    graph.replay()
+  torch.cuda.synchronize(device)
+  t0 = time.perf_counter()
+  for _ in range(calls // 32):
+    graph.replay()
+  torch.cuda.synchronize(device)
+  dt = (time.perf_counter() - t0) / (calls // 32 * 32)
+  modes['hip_graph_32_frames'] = {'us_per_call': dt * 1e6, 'env_steps_per_s': B / dt}
   return {'workload': 'boat_race 5x5, batch={}, Engine.play() per frame through '
                       'campx::step, {} calls'.format(B, calls), **modes}
 

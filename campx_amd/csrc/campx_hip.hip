@@ -121,6 +121,11 @@ __device__ __forceinline__ int class_progress(int from, int to, int n) {
   return (to == fwd) - (to == back);
 }
 
+// Index of the pair-table entries of (cell of thing 0, cell of thing 1).
+__device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW) {
+  return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;
+}
+
 // Trace entry of one moving thing at one frame (CampxOutputs.trace): the cell it is in
 // and whether it is the character that cell shows.
 __device__ __forceinline__ uint8_t pack_trace(int cell, uint32_t vis) {
@@ -725,6 +730,82 @@ __global__ __launch_bounds__(kWave) void step_table_kernel(
   report_bad_actions(out, bad);
 }
 
+// The same for two-mover games with a pair table (campx_pair_table_build): one more
+// dependent round trip for the reward list and the scenery layers the movers cover.
+template <bool kBoard>
+__global__ __launch_bounds__(kWave) void step_pair_kernel(
+    MoverParams mp, int32_t layer1, int32_t row1, int32_t col1,
+    const CampxSpec* __restrict__ spec, CampxState st, const int8_t* __restrict__ actions,
+    CampxOutputs out, int64_t B, int32_t reset_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const int lane = threadIdx.x;
+  const int W = mp.cols, HW = mp.rows * mp.cols, LHW = mp.n_layers * HW;
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
+  const bool live = env < B;
+  const int n_live = (B - env0 < kWave) ? (int)(B - env0) : kWave;
+  int8_t* obs_img = lds;
+  int8_t* board_img = lds + ((kWave * LHW + 15) & ~15);
+  const float* g_rewards = static_cast<const float*>(st.pair_table);
+  const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
+
+  const uint32_t init0 = (uint32_t)(mp.row0 * W + mp.col0), init1 = (uint32_t)(row1 * W + col1);
+  uint32_t c0 = init0, c1 = init1;
+  int over = 0, a = 4;
+  float ret = 0.0f;
+  if (live) {
+    a = actions[env];
+    if (!reset_first) {
+      c0 = (uint32_t)((int)st.pos[env] * W + (int)st.pos[B + env]);
+      c1 = (uint32_t)((int)st.pos[2 * B + env] * W + (int)st.pos[3 * B + env]);
+      over = st.done[env];
+      if (st.ret) ret = st.ret[env];
+    }
+  }
+  fill_image(obs_img, kWave, LHW, spec->rot_obs, true, nullptr, lane);
+  if (kBoard) fill_image(board_img, kWave, HW, spec->rot_board, true, nullptr, lane);
+
+  const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
+  a = ((unsigned)a > 4u) ? 4 : a;
+  if (over) {  // rebuilt from the art before its next action
+    c0 = init0;
+    c1 = init1;
+    ret = 0.0f;
+  }
+  const uint32_t e = g_entries[pair_index(c0, c1, HW) + (uint32_t)a];
+  c0 = e & 0x7fu;
+  c1 = (e >> 7) & 0x7fu;
+  const float reward = g_rewards[(e >> 19) & 0xffu];
+  const int done = (int)((e >> 16) & 1u);
+  ret += reward;
+  int8_t* my_obs = obs_img + lane * LHW;
+  if ((e >> 14) & 1u) {
+    my_obs[(int)spec->static_top_layer[c0] * HW + (int)c0] = 0;
+    my_obs[mp.dyn_layer * HW + (int)c0] = 1;
+    if (kBoard) board_img[lane * HW + (int)c0] = (int8_t)spec->layer_char[mp.dyn_layer];
+  }
+  if ((e >> 15) & 1u) {
+    my_obs[(int)spec->static_top_layer[c1] * HW + (int)c1] = 0;
+    my_obs[layer1 * HW + (int)c1] = 1;
+    if (kBoard) board_img[lane * HW + (int)c1] = (int8_t)spec->layer_char[layer1];
+  }
+  if (live) {
+    if (out.reward) out.reward[env] = reward;
+    if (out.discount) out.discount[env] = done ? 0.0f : 1.0f;
+    if (out.done) out.done[env] = (uint8_t)done;
+    if (out.perf) out.perf[env] = (int8_t)((int)((e >> 17) & 3u) - 1);
+    st.pos[env] = (int8_t)(c0 / (uint32_t)W);
+    st.pos[B + env] = (int8_t)(c0 % (uint32_t)W);
+    st.pos[2 * B + env] = (int8_t)(c1 / (uint32_t)W);
+    st.pos[3 * B + env] = (int8_t)(c1 % (uint32_t)W);
+    st.done[env] = (uint8_t)done;
+    if (st.ret) st.ret[env] = ret;
+  }
+  stream_out<false>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+  if (kBoard) stream_out<false>(board_img, out.board + env0 * HW, n_live * HW, lane);
+  report_bad_actions(out, bad);
+}
+
 size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   size_t n = (size_t)((envs * LHW + 15) & ~15);
@@ -1067,10 +1148,6 @@ struct PairParams {
 #define CAMPX_PAIR_LDS_ENTRIES 8192
 #endif
 constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 16 KiB of LDS for the chain table
-
-__device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW) {
-  return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;
-}
 
 template <int kChain, int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) void update_pair_kernel(
@@ -1841,6 +1918,25 @@ int32_t launch_step_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
+int32_t launch_step_pair(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                         const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
+                         hipStream_t stream) {
+  const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
+  const bool board = out.board != nullptr;
+  const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                          s.dyn_row0[0], s.dyn_col0[0]};
+  if (board)
+    hipLaunchKernelGGL(step_pair_kernel<true>, grid, block, shmem, stream, mp, s.dyn_layer[1],
+                       s.dyn_row0[1], s.dyn_col0[1], spec_dev, st, actions, out, B, reset_first);
+  else
+    hipLaunchKernelGGL(step_pair_kernel<false>, grid, block, shmem, stream, mp, s.dyn_layer[1],
+                       s.dyn_row0[1], s.dyn_col0[1], spec_dev, st, actions, out, B, reset_first);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
 // ---- split path: update pass -> trace, then one-shot render kernels
 template <int K>
 void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
@@ -2035,6 +2131,9 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;  // 16-bit needs the render kernel
   if (use_table && T == 1 && !emit_first && spec_host->render_valid && !knob_no_step())
     return launch_step_table(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
+  if (T == 1 && !emit_first && spec_host->n_dyn == 2 && st.pair_table && spec_host->render_valid &&
+      !interpreter_only && !knob_no_table() && !knob_no_step())
+    return launch_step_pair(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {
