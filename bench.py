@@ -313,7 +313,7 @@ def roofline(game_name, B, T, fused, kernel_ms, per_launch):
   from campx_amd import fused as fused_mod
   bytes_per_launch = BYTES_PER_ENV_STEP[game_name] * B * T
   achieved = bytes_per_launch / (kernel_ms / 1e3) / 1e9
-  split = fused_mod.SPLIT_ROLLOUT and (fused.uses_table or fused_mod.FORCE_SPLIT)
+  split = fused_mod.SPLIT_ROLLOUT
   traffic = measured_traffic(game_name, B, T, 'split' if split else 'fused')
   return {
       'bound': 'hbm',
@@ -476,8 +476,8 @@ def run_rank(args):
       also = []
       for other in ('wall_world', 'sokoban'):
         oname, ob = WORKLOADS[other]
-        steps = max(5, args.steps // 3)
-        om = measure_rollout(other, ob, T, steps, 3, device, 0, None, 0,
+        steps = args.steps
+        om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
                              pipelined=args.pipeline)
         also.append({
             'workload': '{}, batch={}, random actions, {} frames per launch'.format(

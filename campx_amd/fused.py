@@ -50,10 +50,12 @@ from .rendering import Observation
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
 # Rollouts that keep every frame run the update pass and the render as two kernels
-# (needs a [K, T, B] uint8 trace buffer; DESIGN.md "Kernels", profiles/).
-# CAMPX_SPLIT=0 keeps everything in the single fused kernel; parity tests run both.
-SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') in ('1', 'force')
-FORCE_SPLIT = os.environ.get('CAMPX_SPLIT', '') == 'force'   # also for multi-mover games
+# (needs a [K, T, B] uint8 trace buffer; DESIGN.md "Kernels", profiles/): faster for
+# every game, tabulated update pass or interpreted (sokoban with three boxes,
+# B = 131 072: 1.31 ms against 1.72 ms per 100-frame launch).  CAMPX_SPLIT=0 keeps
+# everything in the single fused kernel; parity tests run both.
+SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') != '0'
+FORCE_SPLIT = SPLIT_ROLLOUT   # kept for callers that toggled it: same as SPLIT_ROLLOUT now
 
 _OBS_DTYPES = (torch.int8, torch.float16, torch.bfloat16)
 
@@ -254,9 +256,7 @@ class FusedGame(object):
         board = (torch.empty((T, B, H, W), dtype=torch.int8, device=dev)
                  if keep_obs else self._board)
     # The compact trajectory; giving it lets the library take its two-kernel path.
-    # (Games with several movers interpret their rules per frame in one wave; for
-    # them the single fused kernel is still the faster path unless forced.)
-    split = (SPLIT_ROLLOUT and (self.uses_table or FORCE_SPLIT)) or sixteen
+    split = SPLIT_ROLLOUT or sixteen
     return dict(
         obs=obs, board=board,
         reward=(torch.empty((T, B), dtype=torch.float32, device=dev)

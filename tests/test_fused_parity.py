@@ -32,10 +32,10 @@ def rollout_path(request):
   """... and with rollouts as two kernels (update pass -> trace -> render) or as the
   single fused kernel."""
   from campx_amd import fused
-  saved = fused.SPLIT_ROLLOUT, fused.FORCE_SPLIT
-  fused.SPLIT_ROLLOUT = fused.FORCE_SPLIT = request.param == 'split'
+  saved = fused.SPLIT_ROLLOUT
+  fused.SPLIT_ROLLOUT = request.param == 'split'
   yield request.param
-  fused.SPLIT_ROLLOUT, fused.FORCE_SPLIT = saved
+  fused.SPLIT_ROLLOUT = saved
 
 
 def _same(a, b):

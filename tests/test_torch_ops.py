@@ -184,10 +184,7 @@ def test_pipelined_rollouts_match_in_order_rollouts(name):
   import sys, os
   sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
   from games_under_test import FUSED_GAMES
-  from campx_amd import fused as fused_mod
-  saved = fused_mod.FORCE_SPLIT
-  fused_mod.FORCE_SPLIT = True                  # K > 2 games take the two-kernel path too
-  try:
+  if True:
     B, T = 4096, 40
     a = FUSED_GAMES[name](batch=B, device='cuda'); a.its_showtime()
     b = FUSED_GAMES[name](batch=B, device='cuda'); b.its_showtime()
@@ -206,5 +203,3 @@ def test_pipelined_rollouts_match_in_order_rollouts(name):
         o1, r1, _ = a.play(x[0]); o2, r2, _ = b.play(x[0])
         assert torch.equal(o1.layered_board, o2.layered_board) and torch.equal(r1, r2)
     assert torch.equal(a.fused.pos, b.fused.pos) and torch.equal(a.fused.ret, b.fused.ret)
-  finally:
-    fused_mod.FORCE_SPLIT = saved
