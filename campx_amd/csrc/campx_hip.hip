@@ -967,7 +967,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) vo
   for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kThreads) {
     const CampxTransition tr = spec->table[i];
     const uint32_t from = tr.done ? (uint32_t)cell0 : (uint32_t)tr.next_cell;
-    const uint32_t vis = spec->static_top_z[tr.next_cell] > mp.dyn_z ? 0u : 1u;
+    const uint32_t vis = (tr.paint & 0x80u) ? 0u : 1u;  // scenery in front hides the mover
     table[i] = make_uint2(__float_as_uint(tr.reward),
                           (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) | (vis << 23) |
                               ((uint32_t)tr.done << 24) | ((uint32_t)(tr.perf + 1) << 25));
