@@ -75,6 +75,10 @@ def parse_args(argv=None):
                       'contend for CU slots; DESIGN.md "Kernels")')
   p.add_argument('--gather-every', type=int, default=8,
                  help='episodes per RCCL all-gather of the episode-return log')
+  p.add_argument('--episode-csv', default=None,
+                 help='rank 0: after the timed region, write the last all-gathered block of '
+                      'episode returns in the reference\'s CSV format '
+                      '(campx_amd/episode_log.py; examples/reinforce.py:270-284)')
   p.add_argument('--force-dist', action='store_true',
                  help='go through the multi-rank launcher and the RCCL episode-return '
                       'all-gather even with one rank (smoke test of the N>1 path)')
@@ -420,6 +424,14 @@ def run_rank(args):
     if block is not None:
       mine = m['log']._log[m['log']._last]
       gathered_ok = bool(block.shape[0] == world and torch.equal(block[rank], mine))
+
+  if rank == 0 and args.episode_csv and m['log'] is not None:
+    block = m['log'].wait()
+    if block is not None:
+      from campx_amd.episode_log import EpisodeCsvLog
+      csv_log = EpisodeCsvLog(args.episode_csv, run_id=0, frames_per_episode=T)
+      csv_log.block(block.cpu(), seconds=elapsed / args.steps * block.shape[1])
+      csv_log.close()
 
   if rank == 0:
     env_steps = B * T * args.steps * world

@@ -25,11 +25,14 @@ def _run(extra, env_extra=None):
                         capture_output=True, text=True, timeout=600, env=env)
 
 
-def test_gpus_2_spawns_two_ranks_and_prints_one_line():
+def test_gpus_2_spawns_two_ranks_and_prints_one_line(tmp_path):
+  csv_path = str(tmp_path / 'episodes.csv')
   r = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '64',
-            '--frames', '20', '--gather-every', '2',
+            '--frames', '20', '--gather-every', '2', '--episode-csv', csv_path,
             '--standin', 'bench_standin:make'])
   assert r.returncode == 0, r.stderr[-3000:]
+  rows = open(csv_path).read().strip().splitlines()
+  assert rows[0] == 'id,step,t(s),ep,L,R,R_av_5,P,P_av' and len(rows) == 3   # one block of 2
   lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
   assert len(lines) == 1, r.stdout
   line = json.loads(lines[0])

@@ -420,3 +420,39 @@ def test_unvalidated_out_of_range_actions_mean_stay():
   b = game_b.rollout(torch.from_numpy(weird), want_board=True)
   assert torch.equal(a['obs'], b['obs']) and torch.equal(a['reward'], b['reward'])
   assert torch.equal(a['done'], b['done']) and torch.equal(a['board'], b['board'])
+
+
+def test_raw_c_abi_through_ctypes(golden):
+  """The C ABI itself, bound with ctypes as INTEGRATION.md's stub does (no torch ops in
+  between): reset + one rollout of the boat-race golden, on a non-default stream."""
+  import ctypes
+  from campx_amd import _hip
+  from campx_amd.games import boat_race
+  gold = golden('boat_race')
+  T, B = gold['actions'].shape
+  spec = gamespec.lower(gamespec.describe(boat_race.build()))
+  stream = torch.cuda.Stream()
+  sp = ctypes.c_void_p(stream.cuda_stream)
+  _hip.check(_hip.lib.campx_spec_compile(ctypes.byref(spec), sp), 'compile')
+  dev = torch.device('cuda')
+  spec_dev = torch.frombuffer(bytearray(gamespec.spec_bytes(spec)), dtype=torch.uint8).to(dev)
+  L, H, W = spec.n_layers, spec.rows, spec.cols
+  z = lambda *s, dt=torch.int8: torch.zeros(s, dtype=dt, device=dev)
+  pos, done, ret = z(2, B), z(B, dt=torch.uint8), z(B, dt=torch.float32)
+  obs0, obs, trace = z(B, L, H, W), z(T, B, L, H, W), z(1, T, B, dt=torch.uint8)
+  reward, discount = z(T, B, dt=torch.float32), z(T, B, dt=torch.float32)
+  acts = torch.from_numpy(gold['actions']).to(dev)
+  p = lambda t: ctypes.c_void_p(t.data_ptr())
+  torch.cuda.synchronize()
+  st = _hip.CampxState(p(pos), p(done), p(ret), None)
+  out0 = _hip.CampxOutputs(p(obs0), 0)
+  _hip.check(_hip.lib.campx_reset_launch(ctypes.byref(spec), p(spec_dev), st, out0, B, sp), 'reset')
+  out = _hip.CampxOutputs(p(obs), B * L * H * W, None, 0, p(reward), p(discount), None, None,
+                          p(trace), 0, None, None)
+  _hip.check(_hip.lib.campx_rollout_launch(ctypes.byref(spec), p(spec_dev), st, p(acts), out, B, T,
+                                           0, sp), 'rollout')
+  stream.synchronize()
+  assert _same(obs0.cpu().numpy(), gold['layered'][0])
+  assert _same(obs.cpu().numpy(), gold['layered'][1:])
+  assert _same(reward.cpu().numpy(), gold['reward'])
+  assert _same(discount.cpu().numpy(), gold['discount'])

@@ -107,14 +107,12 @@ def test_opcheck():
   acts = torch.randint(0, 5, (128,), dtype=torch.int8, device='cuda')
   args = (f._spec_host, f._spec_dev, f.pos, f.done, f.ret, None, acts, f._obs, f._board,
           f._reward, f._discount, f._step_done, f.perf, f._bad, None)
-  torch.library.opcheck(torch.ops.campx.step.default, args,
-                        test_utils=('test_schema', 'test_faketensor'))
+  torch.library.opcheck(torch.ops.campx.step.default, args)      # all four checks
   acts = torch.randint(0, 5, (5, 128), dtype=torch.int8, device='cuda')
   b = f.rollout_buffers(5, want_board=True)
   args = (f._spec_host, f._spec_dev, f.pos, f.done, f.ret, None, acts, b['obs'], b['board'],
           b['reward'], b['discount'], b['done'], b['perf'], b['trace'], f._bad, None, True)
-  torch.library.opcheck(torch.ops.campx.rollout.default, args,
-                        test_utils=('test_schema', 'test_faketensor'))
+  torch.library.opcheck(torch.ops.campx.rollout.default, args)
 
 
 @pytest.mark.gpu
