@@ -865,14 +865,26 @@ __device__ __forceinline__ int count_bad16(u32x4 v) {
   return n;
 }
 
-// The loader wave's state: one chunk (kChunk frames x kEnvs environments) of actions in
+// Bytes > 4 (as unsigned) of v replaced by 4: an id outside 0..4 acts as "stay".
+__device__ __forceinline__ uint32_t clamp_ids(uint32_t w) {
+  const uint32_t hi = (((w & 0x7f7f7f7fu) + 0x7b7b7b7bu) | w) & 0x80808080u;  // bad bytes
+  const uint32_t m = (hi >> 7) * 0xffu;
+  return (w & ~m) | (0x04040404u & m);
+}
+
+// The staged actions of a chunk are packed two frames to a byte - frame 2p in the low
+// nibble of row p, frame 2p + 1 in the high one, already clamped to 0..4 - which halves
+// their LDS footprint (what decides how many update workgroups fit on a CU).
+//
+// The loader waves' state: one chunk (kChunk frames x kEnvs environments) of actions in
 // flight in registers between issue() and land().
 template <int kEnvs, int kLoaders>
 struct ActionLoader {
   static constexpr int kVecPerRow = kEnvs / 16;
   static constexpr int kLanes = kWave * kLoaders;          // loader lanes of the workgroup
-  static constexpr int kPerLane = kChunk * kVecPerRow / kLanes;
-  u32x4 pend[kPerLane];
+  static constexpr int kPairs = (kChunk / 2) * kVecPerRow / kLanes;   // row pairs per lane
+  static_assert(kPairs >= 1 && (kChunk / 2) * kVecPerRow % kLanes == 0, "loader shape");
+  u32x4 pend[2 * kPairs];
 
   // 16-byte loads; rows past T and environments past B are clamped to valid ones (no
   // branch between the loads) and neutralised in land().
@@ -880,14 +892,17 @@ struct ActionLoader {
   __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
                                         int t0, int64_t env0, int lane) {
 #pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
+    for (int i = 0; i < kPairs; ++i) {
       const int v = lane + i * kLanes;
-      const int r = v / kVecPerRow, q = v % kVecPerRow;
-      int row = t0 + r;
-      row = row < T ? row : T - 1;
+      const int rp = v / kVecPerRow, q = v % kVecPerRow;
       int64_t e = env0 + 16 * q;
       e = e < B ? e : 0;
-      pend[i] = *reinterpret_cast<const u32x4*>(actions + (int64_t)row * B + e);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int row = t0 + 2 * rp + h;
+        row = row < T ? row : T - 1;
+        pend[2 * i + h] = *reinterpret_cast<const u32x4*>(actions + (int64_t)row * B + e);
+      }
     }
   }
 
@@ -895,13 +910,20 @@ struct ActionLoader {
                                       int lane) {
     int bad = 0;
 #pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
+    for (int i = 0; i < kPairs; ++i) {
       const int v = lane + i * kLanes;
-      const int r = v / kVecPerRow, q = v % kVecPerRow;
-      const bool real = (t0 + r < T) && (env0 + 16 * q < B);
-      const u32x4 stay = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
-      *reinterpret_cast<u32x4*>(staged + r * kEnvs + 16 * q) = real ? pend[i] : stay;
-      bad += real ? count_bad16(pend[i]) : 0;
+      const int rp = v / kVecPerRow, q = v % kVecPerRow;
+      const bool here = env0 + 16 * q < B;
+      const bool real0 = here && (t0 + 2 * rp < T), real1 = here && (t0 + 2 * rp + 1 < T);
+      const u32x4 lo = pend[2 * i], hi = pend[2 * i + 1];
+      const uint32_t l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
+      uint32_t out[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        out[k] = (real0 ? clamp_ids(l[k]) : 0x04040404u) | ((real1 ? clamp_ids(h[k]) : 0x04040404u) << 4);
+      const u32x4 packed = {out[0], out[1], out[2], out[3]};
+      *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
+      bad += (real0 ? count_bad16(lo) : 0) + (real1 ? count_bad16(hi) : 0);
     }
     return bad;
   }
@@ -912,14 +934,29 @@ template <int kEnvs, int kLoaders>
 __device__ __forceinline__ int stage_bytes(int8_t* staged, const int8_t* __restrict__ actions,
                                            int64_t B, int32_t T, int t0, int64_t env0, int lane) {
   int bad = 0;
-  for (int i = lane; i < kChunk * kEnvs; i += kWave * kLoaders) {
-    const int r = i / kEnvs, e = i % kEnvs;
-    const bool real = (t0 + r < T) && (env0 + e < B);
-    const int8_t a = real ? actions[(int64_t)(t0 + r) * B + env0 + e] : (int8_t)4;
-    staged[i] = a;
-    bad += ((unsigned)a > 4u) ? 1 : 0;
+  for (int i = lane; i < (kChunk / 2) * kEnvs; i += kWave * kLoaders) {
+    const int rp = i / kEnvs, e = i % kEnvs;
+    uint32_t packed = 0;
+    for (int h = 0; h < 2; ++h) {
+      const int row = t0 + 2 * rp + h;
+      const bool real = (row < T) && (env0 + e < B);
+      const int8_t a = real ? actions[(int64_t)row * B + env0 + e] : (int8_t)4;
+      const bool ok = (unsigned)a <= 4u;
+      bad += ok ? 0 : 1;
+      packed |= (ok ? (uint32_t)a : 4u) << (4 * h);
+    }
+    staged[i] = (int8_t)packed;
   }
   return bad;
+}
+
+// The action of frame j (0 .. kGroup-1) of a group that starts at frame t0 of its chunk,
+// for environment `le` of the workgroup.
+template <int kEnvs>
+__device__ __forceinline__ uint32_t staged_action(const int8_t* chunk, int t0_in_chunk, int j,
+                                                   int le) {
+  const uint32_t b = (uint8_t)chunk[((t0_in_chunk + j) >> 1) * kEnvs + le];
+  return (b >> (4 * (j & 1))) & 0xfu;   // t0_in_chunk is a multiple of kGroup (even)
 }
 
 // Four bytes (the low byte of each argument) as one dword.
@@ -941,8 +978,14 @@ constexpr int update_loaders(int) { return CAMPX_UPD_LOADERS; }
 constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
 #endif
 
+// Register budget of the update kernels: two workgroups per CU (in waves per SIMD).
+constexpr int update_min_waves(int prod, int cons) {
+  return (2 * (prod + cons + update_loaders(prod)) + 3) / 4;
+}
+
 template <int kProd, int kCons>
-__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) void update_table_kernel(
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             update_min_waves(kProd, kCons)) void update_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
@@ -953,7 +996,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) vo
   // the chain), [16:22] the cell after this frame, [23] whether the mover shows there,
   // [24] done, [25:26] perf + 1.  The ring keeps x and the upper half of y.
   __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
-  __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) float ring_r[2][kGroup][E];
   __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kGroup][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -1001,125 +1044,134 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) vo
   __syncthreads();
 
   const int n_groups = (T + kGroup - 1) / kGroup;
-  for (int g = 0; g <= n_groups; ++g) {
-    if (producer) {
-      if (g < n_groups) {
-        const int t0 = g * kGroup;
-        const int8_t* my_actions =
-            staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * E + le;
-        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
-        uint32_t col_off[kGroup];  // action * sizeof(entry), off the dependent chain
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          const int a = my_actions[j * E];
-          col_off[j] = (((unsigned)a > 4u) ? 4u : (uint32_t)a) * (uint32_t)sizeof(uint2);
-        }
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          if (j < n) {
-            // the dependent chain: row offset -> entry -> row offset
-            const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
-            row_off = e.y & 0xffffu;
-            ring_r[g & 1][j][le] = __uint_as_float(e.x);
-            ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
-            // off the chain: the return restarts after an episode end
-            ret = (over ? 0.0f : ret) + __uint_as_float(e.x);
-            over = (int)((e.y >> 24) & 1u);
-            cell = (int)((e.y >> 16) & 0x7fu);
-          }
-        }
-      }
-    } else if (!loader) {
-      if (g > 0) {
-        const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
-        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
-        // ---- float streams: item = (frame j, 4 environments)
-        constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
-#pragma unroll
-        for (int it = 0; it < kItA; ++it) {
-          const int item = clane + it * CL;
-          const int j = item / QA, q = item % QA;
-          const int64_t e0 = env0 + 4 * q;
-          if (j < n && e0 < B) {
-            const u32x4 r4 = *reinterpret_cast<const u32x4*>(&ring_r[rb][j][4 * q]);
-            const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
-            const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
-                                    (y4.y >> 24) & 1u};
-            const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (wide) {
-              if (out.reward) store16_update(out.reward + at, r4);
-              if (out.discount) {
-                const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
-                                  dn[2] ? 0u : 0x3f800000u, dn[3] ? 0u : 0x3f800000u};
-                store16_update(out.discount + at, d4);
-              }
-            } else {
-              const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
-              for (int i = 0; i < 4 && e0 + i < B; ++i) {
-                if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
-                if (out.discount) out.discount[at + i] = dn[i] ? 0.0f : 1.0f;
-              }
+  // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
+  // agree): registers are then allocated per role, and the loads a loader keeps in flight
+  // across iterations do not take registers from the other two.
+  if (producer) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g < n_groups) {
+          const int t0 = g * kGroup;
+          const int8_t* chunk = staged[(t0 / kChunk) & 1];
+          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+          uint32_t col_off[kGroup];  // action * sizeof(entry), off the dependent chain
+  #pragma unroll
+          for (int j = 0; j < kGroup; ++j)
+            col_off[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le) * (uint32_t)sizeof(uint2);
+  #pragma unroll
+          for (int j = 0; j < kGroup; ++j) {
+            if (j < n) {
+              // the dependent chain: row offset -> entry -> row offset
+              const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
+              row_off = e.y & 0xffffu;
+              ring_r[g & 1][j][le] = __uint_as_float(e.x);
+              ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
+              // off the chain: the return restarts after an episode end
+              ret = (over ? 0.0f : ret) + __uint_as_float(e.x);
+              over = (int)((e.y >> 24) & 1u);
+              cell = (int)((e.y >> 16) & 0x7fu);
             }
           }
         }
-        // ---- byte streams: item = (frame j, 16 environments)
-        constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
-#pragma unroll
-        for (int it = 0; it < kItB; ++it) {
-          const int item = clane + it * CL;
-          const int j = item / QB, q = item % QB;
-          const int64_t e0 = env0 + 16 * q;
-          if (item < kGroup * QB && j < n && e0 < B) {
-            const u32x4 ya = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q]);
-            const u32x4 yb = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q + 8]);
-            const uint32_t w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
-            uint32_t tr[4], dn[4], pf[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const uint32_t lo = w[2 * k], hi = w[2 * k + 1];  // two environments each
-              tr[k] = pack4(lo, lo >> 16, hi, (hi >> 16) & 0xffu);
-              dn[k] = pack4((lo >> 8) & 1u, (lo >> 24) & 1u, (hi >> 8) & 1u, (hi >> 24) & 1u);
-              pf[k] = pack4(((lo >> 9) & 3u) - 1u, ((lo >> 25) & 3u) - 1u, ((hi >> 9) & 3u) - 1u,
-                            (((hi >> 25) & 3u) - 1u) & 0xffu);
-            }
-            const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (wide) {
-              const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
-              store16_update(out.trace + at, t4);
-              if (out.done) {
-                const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
-                store16_update(out.done + at, d4);
-              }
-              if (out.perf) {
-                const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
-                store16_update(out.perf + at, p4);
-              }
-            } else {
-              for (int i = 0; i < 16 && e0 + i < B; ++i) {
-                const int sh = (i & 3) * 8;
-                out.trace[at + i] = (uint8_t)(tr[i >> 2] >> sh);
-                if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
-                if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
-              }
-            }
-          }
-        }
-      }
-    } else {
-      // loader: while the producers are in chunk c, fetch chunk c + 1
-      const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
-      const int t_next = (c + 1) * kChunk;
-      if (t_next < T) {
-        if (wide) {
-          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
-          if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
-        } else if (phase == 0) {
-          bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
-        }
-      }
+      
+      __syncthreads();
     }
-    __syncthreads();
+  } else if (!loader) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g > 0) {
+          const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
+          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+          // ---- float streams: item = (frame j, 4 environments)
+          constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
+  #pragma unroll 1   // (unrolled, the iterations' LDS reads pile up in registers)
+          for (int it = 0; it < kItA; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QA, q = item % QA;
+            const int64_t e0 = env0 + 4 * q;
+            if (j < n && e0 < B) {
+              const u32x4 r4 = *reinterpret_cast<const u32x4*>(&ring_r[rb][j][4 * q]);
+              const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
+              const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
+                                      (y4.y >> 24) & 1u};
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (wide) {
+                if (out.reward) store16_update(out.reward + at, r4);
+                if (out.discount) {
+                  const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
+                                    dn[2] ? 0u : 0x3f800000u, dn[3] ? 0u : 0x3f800000u};
+                  store16_update(out.discount + at, d4);
+                }
+              } else {
+                const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
+                for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                  if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                  if (out.discount) out.discount[at + i] = dn[i] ? 0.0f : 1.0f;
+                }
+              }
+            }
+          }
+          // ---- byte streams: item = (frame j, 16 environments)
+          constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
+  #pragma unroll
+          for (int it = 0; it < kItB; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QB, q = item % QB;
+            const int64_t e0 = env0 + 16 * q;
+            if (item < kGroup * QB && j < n && e0 < B) {
+              const u32x4 ya = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q]);
+              const u32x4 yb = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q + 8]);
+              const uint32_t w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+              uint32_t tr[4], dn[4], pf[4];
+  #pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const uint32_t lo = w[2 * k], hi = w[2 * k + 1];  // two environments each
+                tr[k] = pack4(lo, lo >> 16, hi, (hi >> 16) & 0xffu);
+                dn[k] = pack4((lo >> 8) & 1u, (lo >> 24) & 1u, (hi >> 8) & 1u, (hi >> 24) & 1u);
+                pf[k] = pack4(((lo >> 9) & 3u) - 1u, ((lo >> 25) & 3u) - 1u, ((hi >> 9) & 3u) - 1u,
+                              (((hi >> 25) & 3u) - 1u) & 0xffu);
+              }
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (wide) {
+                const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
+                store16_update(out.trace + at, t4);
+                if (out.done) {
+                  const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                  store16_update(out.done + at, d4);
+                }
+                if (out.perf) {
+                  const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                  store16_update(out.perf + at, p4);
+                }
+              } else {
+                for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                  const int sh = (i & 3) * 8;
+                  out.trace[at + i] = (uint8_t)(tr[i >> 2] >> sh);
+                  if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                  if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+                }
+              }
+            }
+          }
+        }
+      
+      __syncthreads();
+    }
+  } else {
+    for (int g = 0; g <= n_groups; ++g) {
+        // loader: while the producers are in chunk c, fetch chunk c + 1
+        const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+        const int t_next = (c + 1) * kChunk;
+        if (t_next < T) {
+          if (wide) {
+            if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+            if (phase == kGroupsPerChunk - 1)
+              bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
+          } else if (phase == 0) {
+            bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+          }
+        }
+      
+      __syncthreads();
+    }
   }
 
   if (live) {
@@ -1151,16 +1203,17 @@ struct PairParams {
 constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 16 KiB of LDS for the chain table
 
 template <int kChain, int kProd, int kCons>
-__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) void update_pair_kernel(
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             update_min_waves(kProd, kCons)) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
   constexpr int kLoad = update_loaders(kProd);
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   __shared__ uint16_t lds_chain[kChain == 1 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
-  __shared__ uint32_t lds_entries[kChain == 3 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kChain 3: n_entries
   __shared__ float reward_list[256];
-  __shared__ __attribute__((aligned(16))) int8_t staged[2][kChunk * E];
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave >= kProd + kCons;
@@ -1211,160 +1264,168 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave) vo
   __syncthreads();
 
   const int n_groups = (T + kGroup - 1) / kGroup;
-  for (int g = 0; g <= n_groups; ++g) {
-    if (producer) {
-      if (g < n_groups) {
-        const int t0 = g * kGroup;
-        const int8_t* my_actions =
-            staged[(t0 / kChunk) & 1] + (t0 & (kChunk - 1)) * E + le;
-        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
-        uint32_t act[kGroup];
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          const int a = my_actions[j * E];
-          act[j] = ((unsigned)a > 4u) ? 4u : (uint32_t)a;
-        }
-        if (kChain == 0 || kChain == 3) {
-#pragma unroll
-          for (int j = 0; j < kGroup; ++j) {
-            if (j < n) {
-              if (over) {  // rebuilt from the art before its next action
-                c0 = init0;
-                c1 = init1;
+  // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
+  // agree): registers are then allocated per role, and the loads a loader keeps in flight
+  // across iterations do not take registers from the other two.
+  if (producer) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g < n_groups) {
+          const int t0 = g * kGroup;
+          const int8_t* chunk = staged[(t0 / kChunk) & 1];
+          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+          uint32_t act[kGroup];
+  #pragma unroll
+          for (int j = 0; j < kGroup; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+          if (kChain == 0 || kChain == 3) {
+  #pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+              if (j < n) {
+                if (over) {  // rebuilt from the art before its next action
+                  c0 = init0;
+                  c1 = init1;
+                }
+                const uint32_t idx = pair_index(c0, c1, HW) + act[j];
+                const uint32_t e = kChain == 3 ? lds_entries[idx] : g_entries[idx];
+                c0 = e & 0x7fu;
+                c1 = (e >> 7) & 0x7fu;
+                ring[g & 1][j][le] = e;
+                ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
+                over = (int)((e >> 16) & 1u);
               }
-              const uint32_t idx = pair_index(c0, c1, HW) + act[j];
-              const uint32_t e = kChain == 3 ? lds_entries[idx] : g_entries[idx];
-              c0 = e & 0x7fu;
-              c1 = (e >> 7) & 0x7fu;
-              ring[g & 1][j][le] = e;
-              ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
-              over = (int)((e >> 16) & 1u);
             }
-          }
-        } else {
-          uint32_t e[kGroup];
-#pragma unroll
-          for (int j = 0; j < kGroup; ++j) {
-            if (j < n) {
-              const uint32_t idx = base + act[j];
-              base = kChain == 1 ? lds_chain[idx] : g_chain[idx];   // the dependent chain
-              e[j] = g_entries[idx];                                // off the chain
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < kGroup; ++j) {
-            if (j < n) {
-              ring[g & 1][j][le] = e[j];
-              ret = (over ? 0.0f : ret) + reward_list[(e[j] >> 19) & 0xffu];
-              over = (int)((e[j] >> 16) & 1u);
-              c0 = e[j] & 0x7fu;
-              c1 = (e[j] >> 7) & 0x7fu;
-            }
-          }
-        }
-      }
-    } else if (!loader) {
-      if (g > 0) {
-        const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
-        const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
-        const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
-        constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
-#pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
-        for (int it = 0; it < kItA; ++it) {
-          const int item = clane + it * CL;
-          const int j = item / QA, q = item % QA;
-          const int64_t e0 = env0 + 4 * q;
-          if (j < n && e0 < B) {
-            const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][4 * q]);
-            const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
-            uint32_t rw[4], dc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
-              dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
-            }
-            const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (wide) {
-              if (out.reward) {
-                const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
-                store16_update(out.reward + at, r4);
+          } else {
+            uint32_t e[kGroup];
+  #pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+              if (j < n) {
+                const uint32_t idx = base + act[j];
+                base = kChain == 1 ? lds_chain[idx] : g_chain[idx];   // the dependent chain
+                e[j] = g_entries[idx];                                // off the chain
               }
-              if (out.discount) {
-                const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
-                store16_update(out.discount + at, d4);
-              }
-            } else {
-              for (int i = 0; i < 4 && e0 + i < B; ++i) {
-                if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
-                if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
+            }
+  #pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+              if (j < n) {
+                ring[g & 1][j][le] = e[j];
+                ret = (over ? 0.0f : ret) + reward_list[(e[j] >> 19) & 0xffu];
+                over = (int)((e[j] >> 16) & 1u);
+                c0 = e[j] & 0x7fu;
+                c1 = (e[j] >> 7) & 0x7fu;
               }
             }
           }
         }
-        constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
-#pragma unroll
-        for (int it = 0; it < kItB; ++it) {
-          const int item = clane + it * CL;
-          const int j = item / QB, q = item % QB;
-          const int64_t e0 = env0 + 16 * q;
-          if (item < kGroup * QB && j < n && e0 < B) {
-            uint32_t ta[4], tb[4], dn[4], pf[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][16 * q + 4 * k]);
-              const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
-              uint32_t a[4], b[4], d[4], p[4];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                a[i] = (e[i] & 0x7fu) | (((e[i] >> 14) & 1u) << 7);
-                b[i] = ((e[i] >> 7) & 0x7fu) | (((e[i] >> 15) & 1u) << 7);
-                d[i] = (e[i] >> 16) & 1u;
-                p[i] = (((e[i] >> 17) & 3u) - 1u) & 0xffu;
-              }
-              ta[k] = pack4(a[0], a[1], a[2], a[3]);
-              tb[k] = pack4(b[0], b[1], b[2], b[3]);
-              dn[k] = pack4(d[0], d[1], d[2], d[3]);
-              pf[k] = pack4(p[0], p[1], p[2], p[3]);
-            }
-            const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (wide) {
-              const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
-              store16_update(out.trace + at, a4);
-              store16_update(out.trace + plane + at, b4);
-              if (out.done) {
-                const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
-                store16_update(out.done + at, d4);
-              }
-              if (out.perf) {
-                const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
-                store16_update(out.perf + at, p4);
-              }
-            } else {
-              for (int i = 0; i < 16 && e0 + i < B; ++i) {
-                const int sh = (i & 3) * 8;
-                out.trace[at + i] = (uint8_t)(ta[i >> 2] >> sh);
-                out.trace[plane + at + i] = (uint8_t)(tb[i >> 2] >> sh);
-                if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
-                if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
-              }
-            }
-          }
-        }
-      }
-    } else {
-      const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
-      const int t_next = (c + 1) * kChunk;
-      if (t_next < T) {
-        if (wide) {
-          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
-          if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
-        } else if (phase == 0) {
-          bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
-        }
-      }
+      
+      __syncthreads();
     }
-    __syncthreads();
+  } else if (!loader) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g > 0) {
+          const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
+          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+          const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
+          constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
+  #pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
+          for (int it = 0; it < kItA; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QA, q = item % QA;
+            const int64_t e0 = env0 + 4 * q;
+            if (j < n && e0 < B) {
+              const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][4 * q]);
+              const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+              uint32_t rw[4], dc[4];
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
+                dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
+              }
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (wide) {
+                if (out.reward) {
+                  const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
+                  store16_update(out.reward + at, r4);
+                }
+                if (out.discount) {
+                  const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
+                  store16_update(out.discount + at, d4);
+                }
+              } else {
+                for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                  if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                  if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
+                }
+              }
+            }
+          }
+          constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
+  #pragma unroll
+          for (int it = 0; it < kItB; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QB, q = item % QB;
+            const int64_t e0 = env0 + 16 * q;
+            if (item < kGroup * QB && j < n && e0 < B) {
+              uint32_t ta[4], tb[4], dn[4], pf[4];
+  #pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][16 * q + 4 * k]);
+                const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+                uint32_t a[4], b[4], d[4], p[4];
+  #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  a[i] = (e[i] & 0x7fu) | (((e[i] >> 14) & 1u) << 7);
+                  b[i] = ((e[i] >> 7) & 0x7fu) | (((e[i] >> 15) & 1u) << 7);
+                  d[i] = (e[i] >> 16) & 1u;
+                  p[i] = (((e[i] >> 17) & 3u) - 1u) & 0xffu;
+                }
+                ta[k] = pack4(a[0], a[1], a[2], a[3]);
+                tb[k] = pack4(b[0], b[1], b[2], b[3]);
+                dn[k] = pack4(d[0], d[1], d[2], d[3]);
+                pf[k] = pack4(p[0], p[1], p[2], p[3]);
+              }
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (wide) {
+                const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
+                store16_update(out.trace + at, a4);
+                store16_update(out.trace + plane + at, b4);
+                if (out.done) {
+                  const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                  store16_update(out.done + at, d4);
+                }
+                if (out.perf) {
+                  const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                  store16_update(out.perf + at, p4);
+                }
+              } else {
+                for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                  const int sh = (i & 3) * 8;
+                  out.trace[at + i] = (uint8_t)(ta[i >> 2] >> sh);
+                  out.trace[plane + at + i] = (uint8_t)(tb[i >> 2] >> sh);
+                  if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                  if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+                }
+              }
+            }
+          }
+        }
+      
+      __syncthreads();
+    }
+  } else {
+    for (int g = 0; g <= n_groups; ++g) {
+        const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+        const int t_next = (c + 1) * kChunk;
+        if (t_next < T) {
+          if (wide) {
+            if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+            if (phase == kGroupsPerChunk - 1)
+              bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
+          } else if (phase == 0) {
+            bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+          }
+        }
+      
+      __syncthreads();
+    }
   }
 
   if (live) {
@@ -2074,7 +2135,8 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       hipLaunchKernelGGL((update_pair_kernel<0, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
     else if (n_entries <= kPairLdsEntries && mode == 3)
-      hipLaunchKernelGGL((update_pair_kernel<3, kProd, kCons>), grid, block, 0, stream, pp,
+      hipLaunchKernelGGL((update_pair_kernel<3, kProd, kCons>), grid, block,
+                         ((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
     else if (n_entries <= kPairLdsEntries && mode == 1)
       hipLaunchKernelGGL((update_pair_kernel<1, kProd, kCons>), grid, block, 0, stream, pp,
