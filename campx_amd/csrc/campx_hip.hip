@@ -978,10 +978,16 @@ constexpr int update_loaders(int) { return CAMPX_UPD_LOADERS; }
 constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
 #endif
 
-// Register budget of the update kernels: two workgroups per CU (in waves per SIMD).
-constexpr int update_min_waves(int prod, int cons) {
-  return (2 * (prod + cons + update_loaders(prod)) + 3) / 4;
-}
+// A/B knobs: roll the consumers' float-stream loop (fewer registers, measured +0.8 us on
+// the boat race), and a register cap in waves per SIMD (capping the pair kernel at 96
+// VGPRs for two workgroups per CU measured 47 us against 42 us uncapped at 110).
+#ifndef CAMPX_UPD_ROLL_A
+#define CAMPX_UPD_ROLL_A 0
+#endif
+#ifndef CAMPX_UPD_MINWAVES
+#define CAMPX_UPD_MINWAVES 1
+#endif
+constexpr int update_min_waves(int, int) { return CAMPX_UPD_MINWAVES; }
 
 template <int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
@@ -1082,7 +1088,11 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
           const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
           // ---- float streams: item = (frame j, 4 environments)
           constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
-  #pragma unroll 1   // (unrolled, the iterations' LDS reads pile up in registers)
+  #if CAMPX_UPD_ROLL_A
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
           for (int it = 0; it < kItA; ++it) {
             const int item = clane + it * CL;
             const int j = item / QA, q = item % QA;
