@@ -422,7 +422,7 @@ def run_rank(args):
   if m['log'] is not None:
     block = m['log'].wait()            # [world, episodes, B] of the last full block
     if block is not None:
-      mine = m['log']._log[m['log']._last]
+      mine = m['log'].last_local_block()
       gathered_ok = bool(block.shape[0] == world and torch.equal(block[rank], mine))
 
   if rank == 0 and args.episode_csv and m['log'] is not None:

@@ -141,6 +141,10 @@ class ReturnLog(object):
     self._last = i
     return True
 
+  def last_local_block(self):
+    """This rank's own `[episodes, batch]` rows of the most recently gathered block."""
+    return None if self._last is None else self._log[self._last]
+
   def wait(self):
     """Most recent gathered block `[world, episodes, batch]` (None before the first)."""
     if self._last is None:

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Shape tier (Hello World) throughput: rollout and play()."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from campx_amd.games import hello_world
+
+for B in (4096, 32768):
+  T = 100
+  game, _, _, _ = hello_world.make_game(batch=B, device='cuda')
+  game.fused.validate_actions = False
+  acts = torch.randint(0, 4, (T, B), dtype=torch.int8, device='cuda')
+  bufs = game.fused.rollout_buffers(T)
+  for _ in range(3):
+    game.rollout(acts, out=bufs, reset_first=True)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  n = 10
+  for _ in range(n):
+    game.rollout(acts, out=bufs, reset_first=True)
+  e1.record(); torch.cuda.synchronize()
+  ms = e0.elapsed_time(e1) / n
+  L, H, W = game.fused.n_layers, game.fused.rows, game.fused.cols
+  gb = B * T * (L * H * W + 9) / 1e9
+  print('hello_world B=%d T=%d: %.3f ms per launch, %.2e env-steps/s, %.2f TB/s of observations'
+        % (B, T, ms, B * T / ms * 1e3, gb / ms))
+  t0 = time.perf_counter()
+  for t in range(200):
+    game.play(acts[t % T])
+  torch.cuda.synchronize()
+  print('  play(): %.1f us per call' % ((time.perf_counter() - t0) / 200 * 1e6))
