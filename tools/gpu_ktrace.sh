@@ -27,6 +27,9 @@ try:
     tot += a
     print('KT %-10s %-10s %-44s n=%3d avg=%8.2f min=%8.2f max=%8.2f' % (v, g, n[:44], c, a/1e3, mn/1e3, mx/1e3))
   print('KT %-10s %-10s SUM avg=%8.2f %s' % (v, g, tot/1e3, __import__('os').environ.get('BENCH_ARGS','')))
+  if __import__('os').environ.get('PRINT_SEQ'):
+    seq = cur.execute("select end-start from kernels where name like '%render_kernel%' order by start").fetchall()
+    print('SEQ', v, g, ' '.join('%.0f' % (x[0]/1e3) for x in seq))
 except Exception as e:
   print('KT', v, g, 'failed', e)
 PY
