@@ -1654,31 +1654,21 @@ __device__ __forceinline__ int shape_cell(uint32_t packed, int orow, int ocol, i
   return r * W + c;
 }
 
-// kCoop: the four waves of a workgroup expand their environments' frames into ONE LDS
-// image (their observations are adjacent in memory, 4 * L*H*W bytes, 16-byte aligned when
-// H*W is a multiple of 4) and the whole workgroup streams it out with 16-byte stores, 1 KiB
-// per wave-instruction, one s_barrier per frame (the image is double-buffered); otherwise
-// every wave stores its own planes a dword (or byte) at a time.  4.40 -> see DESIGN 3.7.
-template <bool kBoard, bool kCoop>
+template <bool kBoard>
 __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     const CampxShapeSpec* __restrict__ spec, CampxState st, int8_t* __restrict__ backdrop_state,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first, int32_t emit_first) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ __attribute__((aligned(16))) uint8_t lds_board[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
-  extern __shared__ __attribute__((aligned(16))) int8_t lds_img[];  // kCoop: [2][4*(L*H*W + H*W)]
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int64_t env0 = (int64_t)blockIdx.x * kShapeWaves;
-  const int64_t env = env0 + wave;
-  const bool live = env < B;
-  if (!kCoop && !live) return;  // wave-uniform; the per-wave path has no barriers
-  const int n_live = (B - env0 < kShapeWaves) ? (int)(B - env0) : kShapeWaves;
+  const int64_t env = (int64_t)blockIdx.x * kShapeWaves + wave;
+  if (env >= B) return;  // wave-uniform; no barriers below
   const int H = spec->rows, W = spec->cols, HW = H * W, L = spec->n_layers, N = spec->n_things;
   const int64_t LHW = (int64_t)L * HW;
   uint8_t* bd = lds_backdrop[wave];
   uint8_t* board = lds_board[wave];
   const bool quads = (HW & 3) == 0;
-  const int img_bytes = kShapeWaves * (int)LHW, bimg_bytes = kBoard ? kShapeWaves * HW : 0;
 
   int orow[CAMPX_SHAPE_MAX_THINGS], ocol[CAMPX_SHAPE_MAX_THINGS];
 #pragma unroll
@@ -1686,7 +1676,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
   int over = 0;
   float ret = 0.0f;
   const bool fresh = reset_first != 0;
-  if (!fresh && live) {
+  if (!fresh) {
 #pragma unroll
     for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
       if (k < N) {
@@ -1697,8 +1687,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     if (st.ret) ret = st.ret[env];
   }
   for (int i = lane; i < HW; i += kWave)
-    bd[i] = (fresh || !backdrop_state || !live) ? spec->backdrop[i]
-                                                 : (uint8_t)backdrop_state[env * HW + i];
+    bd[i] = (fresh || !backdrop_state) ? spec->backdrop[i] : (uint8_t)backdrop_state[env * HW + i];
 
   auto rebuild = [&]() {  // a fresh make_game() + its_showtime()
 #pragma unroll
@@ -1706,8 +1695,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     for (int i = lane; i < HW; i += kWave) bd[i] = spec->backdrop[i];
   };
 
-  // paint this wave's environment: trails into the backdrop, then the frame's flat board
-  auto paint = [&]() {
+  auto paint_and_emit = [&](int8_t* obs_dst, int8_t* board_dst) {
     // sprites behind the first drape paint into the backdrop itself (rendering.py:128,150)
     for (int z = 0; z < spec->first_drape; ++z) {
       const CampxShapeThing& th = spec->things[z];
@@ -1726,10 +1714,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
       for (int i = lane; i < th.n_cells; i += kWave)
         board[shape_cell(spec->cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
     }
-  };
-
-  // layers by equality (rendering.py:204-215), into `obs_dst` / `board_dst` (LDS or global)
-  auto expand = [&](int8_t* obs_dst, int8_t* board_dst) {
+    // layers by equality (rendering.py:204-215)
     if (quads) {
       for (int q = lane; q < HW / 4; q += kWave) {
         const uint32_t b4 = reinterpret_cast<const uint32_t*>(board)[q];
@@ -1752,48 +1737,13 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     }
   };
 
-  // one frame out: slot = which half of the double-buffered image (kCoop)
-  auto emit = [&](int slot, int8_t* obs_frame, int8_t* board_frame, bool streaming) {
-    if (kCoop) {
-      int8_t* img = lds_img + slot * (img_bytes + bimg_bytes);
-      int8_t* bimg = img + img_bytes;
-      paint();
-      expand(img + wave * LHW, bimg + wave * HW);
-      __syncthreads();
-      const int n_obs = n_live * (int)LHW, n_board = n_live * HW;   // multiples of 4
-      int8_t* dst = obs_frame + env0 * LHW;
-      for (int i = threadIdx.x * 16; i < n_obs; i += kShapeWaves * kWave * 16) {
-        if (i + 16 <= n_obs) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(img + i);
-          if (streaming) store16_streaming(reinterpret_cast<u32x4*>(dst + i), v);
-          else *reinterpret_cast<u32x4*>(dst + i) = v;
-        } else {
-          for (int j = i; j < n_obs; j += 4)
-            *reinterpret_cast<uint32_t*>(dst + j) = *reinterpret_cast<const uint32_t*>(img + j);
-        }
-      }
-      if (kBoard) {
-        int8_t* bdst = board_frame + env0 * HW;
-        for (int i = threadIdx.x * 4; i < n_board; i += kShapeWaves * kWave * 4)
-          *reinterpret_cast<uint32_t*>(bdst + i) = *reinterpret_cast<const uint32_t*>(bimg + i);
-      }
-    } else {
-      paint();
-      expand(obs_frame + env * LHW, kBoard ? board_frame + env * HW : nullptr);
-    }
-  };
-
-  int slot = 0;
-  if (emit_first) {
-    emit(slot, out.obs, out.board, false);
-    slot ^= 1;
-  }
+  if (emit_first) paint_and_emit(out.obs + env * LHW, kBoard ? out.board + env * HW : nullptr);
 
   int bad = 0;
   for (int t = 0; t < T; ++t) {
-    const int a_raw = live ? actions[(int64_t)t * B + env] : 4;  // wave-uniform
+    const int a_raw = actions[(int64_t)t * B + env];  // wave-uniform
     const bool valid = (unsigned)a_raw < (unsigned)CAMPX_N_ACTIONS;
-    bad += (valid || !live) ? 0 : 1;
+    bad += valid ? 0 : 1;
     if (over) {
       rebuild();
       over = 0;
@@ -1801,7 +1751,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     }
     float reward = 0.0f, discount = 1.0f;
     bool first = true;
-    if (valid && live) {
+    if (valid) {
       for (int u = 0; u < N; ++u) {  // update-schedule order (engine.py:200-204)
         const int k = spec->update_order[u];
         const CampxShapeThing& th = spec->things[k];
@@ -1825,10 +1775,9 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     }
     if (first) reward = __builtin_nanf("");  // nobody called add_reward: None
     ret += reward;
-    emit(slot, out.obs + (int64_t)t * out.obs_t_stride,
-         kBoard ? out.board + (int64_t)t * out.board_t_stride : nullptr, out.obs_t_stride != 0);
-    slot ^= 1;
-    if (lane == 0 && live) {
+    paint_and_emit(out.obs + (int64_t)t * out.obs_t_stride + env * LHW,
+                   kBoard ? out.board + (int64_t)t * out.board_t_stride + env * HW : nullptr);
+    if (lane == 0) {
       const int64_t at = (int64_t)t * B + env;
       if (out.reward) out.reward[at] = reward;
       if (out.discount) out.discount[at] = discount;
@@ -1836,7 +1785,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     }
   }
 
-  if (lane == 0 && live) {
+  if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
       if (k < N) {
@@ -1846,10 +1795,11 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
-  if (backdrop_state && live)
+  if (backdrop_state)
     for (int i = lane; i < HW; i += kWave) backdrop_state[env * HW + i] = (int8_t)bd[i];
   report_bad_actions(out, lane == 0 ? bad : 0);
 }
+
 
 __global__ void check_actions_kernel(const int8_t* __restrict__ actions, int64_t n,
                                      int32_t* bad_count) {
@@ -2064,16 +2014,10 @@ template <int K>
 void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                     int32_t reset_first, hipStream_t stream) {
-  // Environments per wave in trace mode (A/B): the interpreter is latency-bound, fewer
-  // environments per wave = more waves = more chains in flight per CU.
-#ifndef CAMPX_TRACE_ENVS
-#define CAMPX_TRACE_ENVS 64
-#endif
-  constexpr int kEnvs = CAMPX_TRACE_ENVS;
   const size_t shmem = lds_bytes(s, false, 0);
-  const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)), block(kWave);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const RuleBlock rb = make_rule_block(s);
-  hipLaunchKernelGGL((rollout_kernel<K, false, false, kEnvs, true>), grid, block, shmem, stream,
+  hipLaunchKernelGGL((rollout_kernel<K, false, false, kWave, true>), grid, block, shmem, stream,
                      rb, spec_dev, st, actions, out, B, T, reset_first, 0, 0);
 }
 
@@ -2656,20 +2600,12 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
   if (trails && !backdrop_state) return CAMPX_EINVAL;
   const dim3 grid((unsigned)((B + kShapeWaves - 1) / kShapeWaves)), block(kShapeWaves * kWave);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // The cooperative image path needs dword-granular planes and 16-byte aligned frames.
-  const int HW = spec_host->rows * spec_host->cols, LHW = spec_host->n_layers * HW;
-  const bool coop = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(out.obs) & 15) == 0 &&
-                    ((B * LHW) % 16 == 0 || out.obs_t_stride == 0) && !knob_no_split();
-  const size_t shmem = coop ? (size_t)2 * kShapeWaves * (LHW + (out.board ? HW : 0)) : 0;
-#define CAMPX_SHAPE_LAUNCH(BOARD, COOP)                                                         \
-  hipLaunchKernelGGL((shape_rollout_kernel<BOARD, COOP>), grid, block, shmem, s, spec_dev, st, \
-                     backdrop_state, actions, out, B, T, reset_first, emit_first)
-  if (out.board) {
-    if (coop) CAMPX_SHAPE_LAUNCH(true, true); else CAMPX_SHAPE_LAUNCH(true, false);
-  } else {
-    if (coop) CAMPX_SHAPE_LAUNCH(false, true); else CAMPX_SHAPE_LAUNCH(false, false);
-  }
-#undef CAMPX_SHAPE_LAUNCH
+  if (out.board)
+    hipLaunchKernelGGL(shape_rollout_kernel<true>, grid, block, 0, s, spec_dev, st, backdrop_state,
+                       actions, out, B, T, reset_first, emit_first);
+  else
+    hipLaunchKernelGGL(shape_rollout_kernel<false>, grid, block, 0, s, spec_dev, st, backdrop_state,
+                       actions, out, B, T, reset_first, emit_first);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
