@@ -110,7 +110,7 @@ def test_play_matches_golden_frame_by_frame(name, golden):
       assert _same(game.fused.perf.cpu().numpy(), gold['perf'][t])
 
 
-@pytest.mark.parametrize('name', ['boat_race', 'wall_world', 'sokoban', 'demo3'])
+@pytest.mark.parametrize('name', ['boat_race', 'wall_world', 'sokoban', 'demo3', 'sokoban_l2'])
 @pytest.mark.parametrize('batch', [1, 63, 64, 65, 1000])
 def test_random_streams_vs_oracle(name, batch):
   """Ragged batch sizes (tail waves, unaligned strides), state carried across launches."""
@@ -260,6 +260,16 @@ def test_full_size_vs_oracle(name, batch, T):
   actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
   game, _ = _fused(name, batch)
   desc = gamespec.describe(FUSED_GAMES[name]())
+  _check_full_size(game, lambda: cpu.OracleGame.from_description(desc), actions)
+
+
+def test_three_boxes_at_a_larger_batch_vs_oracle():
+  """K = 4 (rule interpreter in both kernel paths) beyond the 32-environment golden."""
+  batch, T = 16384, 100
+  rng = np.random.RandomState(77)
+  actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+  game, _ = _fused('sokoban_l2', batch)
+  desc = gamespec.describe(FUSED_GAMES['sokoban_l2']())
   _check_full_size(game, lambda: cpu.OracleGame.from_description(desc), actions)
 
 
