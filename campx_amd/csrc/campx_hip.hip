@@ -2095,8 +2095,9 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 // override).  Measured, whole rollout launch at the BASELINE sizes (gpurun_out/r2a):
 // one-mover table kernel, boat race: (1,1) 0.2006, (1,3) 0.2112, (2,2) 0.2034,
 // (2,4) 0.2005, (4,4) 0.1946 ms - the 256-environment workgroup writes 1 KiB / 256 B row
-// pieces instead of 512 / 128 B; pair kernel, sokoban: (1,1) 0.4432, (2,2) 0.4518,
-// (4,4) 0.4483 ms (its 32 KiB LDS table limits residency, smaller workgroups pack better).
+// pieces instead of 512 / 128 B.  With the final kernels (gpurun_out/r2y, kernel time in
+// us): table kernel, boat race / wall world: (4,4) 16.4 / 73, (2,2) 17.1 / 66.5,
+// (4,2) 21.3 / 63; pair kernel, sokoban: (4,4) 44-50, (4,2) 42, (2,2) 62, (2,1) 57.
 #ifndef CAMPX_UPD_PROD
 #define CAMPX_UPD_PROD 4
 #endif
@@ -2107,7 +2108,7 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 #define CAMPX_PAIR_PROD 4
 #endif
 #ifndef CAMPX_PAIR_CONS
-#define CAMPX_PAIR_CONS 4
+#define CAMPX_PAIR_CONS 2
 #endif
 
 int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
