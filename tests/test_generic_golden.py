@@ -171,3 +171,79 @@ np.save('/tmp/_campx_boards.npy', np.array(boards)); np.save('/tmp/_campx_reward
   for n in range(3):
     assert np.array_equal(boards[n], gold['board'][1:, n])
     assert np.array_equal(rewards[n], gold['reward'][:, n])
+
+
+NOTEBOOK_GAMES = {
+    # golden name: (notebook, cells to exec, how the golden generator built the game)
+    'demo1': ('Demo 1: Simple Agent Example.ipynb', [2, 3],
+              "ascii_art_to_game(GAME_ART, what_lies_beneath=' ', drapes={'A': AgentDrape}, z_order='A')"),
+    'demo2': ('Demo 2: Simple Wall Example.ipynb', [2, 3],
+              "ascii_art_to_game(GAME_ART, what_lies_beneath=' ', drapes={'A': AgentDrape, "
+              "'#': things.FixedDrape}, z_order='A#')"),
+    'demo3': ('Demo 3: Hover Reward Example.ipynb', [2, 3],
+              "ascii_art_to_game(GAME_ART, what_lies_beneath=' ', drapes={'A': AgentDrape, "
+              "'#': things.FixedDrape, '*': things.FixedDrape}, z_order='*A#')"),
+    'demo4': ('Demo 4: Directional Hover Reward Example.ipynb', [2, 3],
+              "ascii_art_to_game(GAME_ART, what_lies_beneath=' ', drapes=dict("
+              "{'A': AgentDrape, '#': things.FixedDrape}, **{ch: Partial("
+              "DirectionalHoverRewardDrape, dctns=torch.FloatTensor(d)) for ch, d in "
+              "{'^': [0, 0, 1, 0, 0], '>': [0, 1, 0, 0, 0], 'v': [0, 0, 0, 1, 0], "
+              "'<': [1, 0, 0, 0, 0]}.items()}), z_order='^>v<A#', update_schedule='A^>v<#')"),
+    'hello_world': ('Hello World Example.ipynb', [3, 4], 'make_game()'),
+}
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/examples'),
+                    reason='reference tree not present (GPU box)')
+@pytest.mark.parametrize('name', sorted(NOTEBOOK_GAMES))
+def test_unmodified_notebook_cells_run_on_this_engine(name, golden, tmp_path):
+  """The Demo / Hello World notebooks' own code cells, read from the .ipynb under
+  /root/reference at run time and exec'd UNCHANGED against this repo's `campx` alias
+  (the reference's import lines), give the frames the reference engine gave."""
+  notebook, cells, build = NOTEBOOK_GAMES[name]
+  gold = golden(name)
+  n_env = min(3, gold['actions'].shape[1])
+  np.save(tmp_path / 'actions.npy', gold['actions'][:, :n_env])
+  code = r'''
+import json, sys, collections, itertools
+import numpy as np, torch, six
+sys.path.insert(0, %(repo)r)                       # this repo: `campx` -> campx_amd
+from campx import things                            # the reference's import lines
+from campx.ascii_art import ascii_art_to_game, Partial
+from campx import engine
+import campx
+assert campx.__file__.startswith(%(repo)r)
+nb = json.load(open('/root/reference/examples/' + %(notebook)r))
+ns = dict(globals())
+for i in %(cells)r:
+    exec(compile(''.join(nb['cells'][i]['source']), 'cell %%d' %% i, 'exec'), ns)
+acts = np.load(%(acts)r)
+hello = %(name)r == 'hello_world'
+boards, rewards, dones = [], [], []
+for n in range(acts.shape[1]):
+    game = eval(%(build)r, ns)
+    obs, r, d = game.its_showtime()
+    assert r is None and d == 1.0
+    for t in range(acts.shape[0]):
+        if game.game_over:
+            game = eval(%(build)r, ns); game.its_showtime()
+        a = int(acts[t, n])
+        onehot = [int(i == a) for i in range(5)]
+        obs, r, d = game.play(a if hello else (torch.tensor(onehot, dtype=torch.float32)
+                                               if %(name)r == 'demo4' else onehot))
+        boards.append(obs.board.numpy().copy())
+        rewards.append(float('nan') if r is None else float(r)); dones.append(int(game.game_over))
+np.save(%(out)r + '/boards.npy', np.array(boards)); np.save(%(out)r + '/rewards.npy', np.array(rewards))
+np.save(%(out)r + '/dones.npy', np.array(dones))
+''' % dict(repo=REPO, notebook=notebook, cells=cells, acts=str(tmp_path / 'actions.npy'),
+           name=name, build=build, out=str(tmp_path))
+  subprocess.run([sys.executable, '-c', code], check=True)
+  T = gold['actions'].shape[0]
+  H, W = gold['board'].shape[-2:]
+  boards = np.load(tmp_path / 'boards.npy').reshape(n_env, T, H, W)
+  rewards = np.load(tmp_path / 'rewards.npy').reshape(n_env, T)
+  dones = np.load(tmp_path / 'dones.npy').reshape(n_env, T)
+  for n in range(n_env):
+    assert np.array_equal(boards[n], gold['board'][1:, n])
+    assert np.array_equal(rewards[n], gold['reward'][:, n], equal_nan=True)
+    assert np.array_equal(dones[n], gold['done'][:, n])
