@@ -1661,8 +1661,15 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     int32_t reset_first, int32_t emit_first) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ __attribute__((aligned(16))) uint8_t lds_board[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
+  __shared__ uint16_t lds_cells[CAMPX_SHAPE_MAX_LIST];  // the things' shapes, once per workgroup
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int64_t env = (int64_t)blockIdx.x * kShapeWaves + wave;
+  {
+    const CampxShapeThing& last = spec->things[spec->n_things - 1];
+    const int n_list = last.cell_begin + last.n_cells;
+    for (int i = threadIdx.x; i < n_list; i += kShapeWaves * kWave) lds_cells[i] = spec->cells[i];
+  }
+  __syncthreads();       // the only barrier: every wave of the workgroup is still here
   if (env >= B) return;  // wave-uniform; no barriers below
   const int H = spec->rows, W = spec->cols, HW = H * W, L = spec->n_layers, N = spec->n_things;
   const int64_t LHW = (int64_t)L * HW;
@@ -1701,7 +1708,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
       const CampxShapeThing& th = spec->things[z];
       if (!th.visible) continue;
       for (int i = lane; i < th.n_cells; i += kWave)
-        bd[shape_cell(spec->cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
+        bd[shape_cell(lds_cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
     }
     if (quads)
       for (int i = lane; i < HW / 4; i += kWave)
@@ -1712,7 +1719,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
       const CampxShapeThing& th = spec->things[z];
       if (!th.visible) continue;
       for (int i = lane; i < th.n_cells; i += kWave)
-        board[shape_cell(spec->cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
+        board[shape_cell(lds_cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
     }
     // layers by equality (rendering.py:204-215)
     if (quads) {
@@ -1739,9 +1746,21 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
 
   if (emit_first) paint_and_emit(out.obs + env * LHW, kBoard ? out.board + env * HW : nullptr);
 
+  // Actions: lane j holds the action of frame (chunk start + j), one load per 64 frames,
+  // fetched a chunk ahead; a frame reads its own with a (wave-uniform) readlane, so the
+  // frame loop has no global load on its critical path.
+  auto fetch = [&](int t0) {
+    const int t = t0 + lane;
+    return (t < T) ? (int)actions[(int64_t)t * B + env] : 4;
+  };
+  int act_now = T > 0 ? fetch(0) : 4, act_next = 4;
   int bad = 0;
   for (int t = 0; t < T; ++t) {
-    const int a_raw = actions[(int64_t)t * B + env];  // wave-uniform
+    if ((t & (kWave - 1)) == 0) {
+      if (t) act_now = act_next;
+      act_next = fetch(t + kWave);
+    }
+    const int a_raw = __builtin_amdgcn_readlane(act_now, t & (kWave - 1));  // wave-uniform
     const bool valid = (unsigned)a_raw < (unsigned)CAMPX_N_ACTIONS;
     bad += valid ? 0 : 1;
     if (over) {
