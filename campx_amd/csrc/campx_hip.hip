@@ -91,7 +91,7 @@ struct LdsTables {
 // frame that way.  Byte lanes are selected with a shift instead.
 template <int K>
 struct Things {
-  uint32_t r, c;
+  uint32_t r, c, cell;   // cell = r * W + c, kept in step: most rules compare cells
 };
 
 template <int K>
@@ -102,6 +102,13 @@ __device__ __forceinline__ int sel(uint32_t v, int d) {
 template <int K>
 __device__ __forceinline__ void put(uint32_t& v, int d, int x) {
   v = (v & ~(0xffu << (8 * d))) | ((uint32_t)x << (8 * d));
+}
+
+template <int K>
+__device__ __forceinline__ void set_pos(Things<K>& p, int d, int r, int c, int W) {
+  put<K>(p.r, d, r);
+  put<K>(p.c, d, c);
+  put<K>(p.cell, d, r * W + c);
 }
 
 // Which tile of environments a workgroup owns.  Workgroup b is observed to run on
@@ -153,7 +160,7 @@ __device__ __forceinline__ int shown_layer(const RuleBlock& rb, const LdsTables&
   int z = t.top_z[cell];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const bool here = (sel<K>(p.r, k) * W + sel<K>(p.c, k) == cell) && (rb.dyn_z[k] > z);
+    const bool here = (sel<K>(p.cell, k) == cell) && (rb.dyn_z[k] > z);
     layer = here ? rb.dyn_layer[k] : layer;
     z = here ? rb.dyn_z[k] : z;
   }
@@ -324,19 +331,15 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
   const LdsTables tab = {top_layer, top_z, cover};
 
   // ---- dynamic state -> registers
-  Things<K> pos = {0u, 0u};
+  Things<K> pos = {0u, 0u, 0u};
   int over = 0;
   float ret = 0.0f;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    put<K>(pos.r, k, rb.dyn_row0[k]);
-    put<K>(pos.c, k, rb.dyn_col0[k]);
-  }
+  for (int k = 0; k < K; ++k) set_pos<K>(pos, k, rb.dyn_row0[k], rb.dyn_col0[k], W);
   if (!reset_first && live) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      put<K>(pos.r, k, st.pos[(int64_t)(2 * k) * B + env]);
-      put<K>(pos.c, k, st.pos[(int64_t)(2 * k + 1) * B + env]);
+      set_pos<K>(pos, k, st.pos[(int64_t)(2 * k) * B + env], st.pos[(int64_t)(2 * k + 1) * B + env], W);
     }
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
 #pragma unroll
     for (int k = 0; k < K; ++k)
       repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W,
-                              sel<K>(pos.r, k) * W + sel<K>(pos.c, k), pos);
+                              sel<K>(pos.cell, k), pos);
   }
   Things<K> img = pos;  // positions the image currently shows
   int bad = 0;
@@ -382,10 +385,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     // (examples/reinforce.py:122: make_game() per episode).
     if (over) {
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        put<K>(pos.r, k, rb.dyn_row0[k]);
-        put<K>(pos.c, k, rb.dyn_col0[k]);
-      }
+      for (int k = 0; k < K; ++k) set_pos<K>(pos, k, rb.dyn_row0[k], rb.dyn_col0[k], W);
       over = 0;
       ret = 0.0f;
     }
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     // ---- update pass (engine.py:195-208)
     Things<K> shown = pos;  // where things stood at the latest repaint
     const int perf_from =
-        rb.perf_dyn >= 0 ? sel<K>(pos.r, rb.perf_dyn) * W + sel<K>(pos.c, rb.perf_dyn) : 0;
+        rb.perf_dyn >= 0 ? sel<K>(pos.cell, rb.perf_dyn) : 0;
     float reward = 0.0f;
     float discount = 1.0f;
     bool first = true;
@@ -412,8 +412,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
           const bool blocked = (R.block_layers >> target) & 1u;
           r2 = blocked ? sel<K>(shown.r, d) : r2;
           c2 = blocked ? sel<K>(shown.c, d) : c2;
-          put<K>(pos.r, d, r2);
-          put<K>(pos.c, d, c2);
+          set_pos<K>(pos, d, r2, c2, W);
           if (R.has_reward) {
             float r = R.base;
             if (R.reward_layers) {
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
           break;
         }
         case CAMPX_OP_DIR_HOVER: {
-          const int cell = sel<K>(pos.r, d) * W + sel<K>(pos.c, d);
+          const int cell = sel<K>(pos.cell, d);
           const int under = shown_layer<K>(rb, tab, W, cell, shown);
           const float gate = (under == R.aux) ? 1.0f : 0.0f;
           add_reward(R.base + gate * R.bonus[a]);
@@ -438,12 +437,11 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
           moved(a, H, W, box_r, box_c, br, bc);
           const int beyond = shown_layer<K>(rb, tab, W, br * W + bc, shown);
           const bool go = (ar == box_r) && (ac == box_c) && !((R.block_layers >> beyond) & 1u);
-          put<K>(pos.r, d, go ? br : box_r);
-          put<K>(pos.c, d, go ? bc : box_c);
+          set_pos<K>(pos, d, go ? br : box_r, go ? bc : box_c, W);
           break;
         }
         case CAMPX_OP_GOAL: {
-          const int cell = sel<K>(pos.r, d) * W + sel<K>(pos.c, d);
+          const int cell = sel<K>(pos.cell, d);
           const int arrived = (cover[cell] >> R.aux) & 1;
           add_reward(R.base + (float)arrived * R.bonus[0]);
           if (arrived) {  // plot.py:183-184
@@ -460,7 +458,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     if (!rb.any_reward) reward = __builtin_nanf("");
     ret += reward;
     if (out.perf && rb.perf_dyn >= 0 && live) {
-      const int perf_to = sel<K>(pos.r, rb.perf_dyn) * W + sel<K>(pos.c, rb.perf_dyn);
+      const int perf_to = sel<K>(pos.cell, rb.perf_dyn);
       out.perf[(int64_t)t * B + env] =
           (int8_t)class_progress(cell_class[perf_from], cell_class[perf_to], rb.perf_n);
     }
@@ -471,7 +469,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
       if (live) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const int cell = sel<K>(pos.r, k) * W + sel<K>(pos.c, k);
+          const int cell = sel<K>(pos.cell, k);
           const uint32_t vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
           out.trace[((int64_t)k * T + t) * B + env] = pack_trace(cell, vis);
         }
@@ -481,8 +479,8 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
       __syncthreads();  // previous frame's reads of the image are done
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int was = sel<K>(img.r, k) * W + sel<K>(img.c, k);
-        const int now = sel<K>(pos.r, k) * W + sel<K>(pos.c, k);
+        const int was = sel<K>(img.cell, k);
+        const int now = sel<K>(pos.cell, k);
         if (mine && was != now) {
           repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, was, pos);
           repaint_cell<K, kBoard>(rb, tab, layer_char, my_obs, my_board, HW, W, now, pos);
