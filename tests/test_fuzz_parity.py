@@ -1,0 +1,115 @@
+"""Randomly generated games, batch sizes and episode lengths: HIP kernels vs the oracle.
+
+Seeded, so failures reproduce.  Covers what the fixed games do not: arbitrary wall /
+coin / hover-tile / box placements, boards of every aspect ratio up to 128 cells, one- to
+three-mover games, batches that are not multiples of 4 / 16 / 64 / 256 and episode
+lengths that are not multiples of the kernels' 16-frame groups and 64-frame chunks."""
+
+import numpy as np
+import pytest
+import torch
+
+from campx_amd import gamespec, rules
+from campx_amd.ascii_art import ascii_art_to_game, Partial
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+  a, b = np.asarray(a), np.asarray(b)
+  if a.dtype.kind == 'f':
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+  return np.array_equal(a, b)
+
+
+def random_game(rng):
+  """(builder, description of what was drawn) for a random legal game."""
+  H, W = int(rng.randint(2, 12)), int(rng.randint(2, 12))
+  while H * W > 128 or H * W < 4:
+    H, W = int(rng.randint(2, 12)), int(rng.randint(2, 12))
+  art = np.full((H, W), ' ', dtype='<U1')
+
+  free = list(zip(*np.where(art == ' ')))
+  if len(free) < 4:
+    return random_game(rng)
+  rng.shuffle(free)
+  art[free.pop()] = 'A'
+  n_boxes = int(rng.choice([0, 0, 1, 2])) if len(free) > 6 else 0
+  boxes = 'XY'[:n_boxes]
+  for ch in boxes:
+    art[free.pop()] = ch
+  coins = rng.rand() < 0.5 and not boxes
+  hover = rng.rand() < 0.5 and not boxes
+  goal = bool(boxes) or rng.rand() < 0.3
+  for _ in range(int(rng.randint(1, 4)) if coins else 0):
+    if free: art[free.pop()] = '*'
+  for _ in range(int(rng.randint(1, 3)) if hover else 0):
+    if free: art[free.pop()] = '>'
+  if goal and free:
+    art[free.pop()] = 'G'
+  else:
+    goal = False
+  rows = [''.join(r) for r in art]
+  step_reward = None if hover else float(rng.choice([-1, 0, 0.5]))
+  dctns = [float(x) for x in rng.choice([0, 1, 2, 3], size=5)]
+  base = float(rng.choice([-0.25, 0, 0.5]))
+
+  def build(batch=None, device=None):
+    drapes = {'#': rules.FixedDrape,
+              'A': Partial(rules.AgentDrape, blocking_chars='#' + boxes, step_reward=step_reward,
+                           reward_chars='*' if coins and '*' in ''.join(rows) else '')}
+    present = set(''.join(rows))
+    if '*' in present:
+      drapes['*'] = rules.FixedDrape
+    if '>' in present:
+      drapes['>'] = Partial(rules.DirectionalHoverRewardDrape,
+                            dctns=torch.tensor(dctns), base_reward=base)
+    if 'G' in present:
+      drapes['G'] = Partial(rules.GoalDrape, agent_char='A', step_reward=-1, goal_reward=7)
+    for ch in boxes:
+      drapes[ch] = Partial(rules.BoxDrape, agent_char='A',
+                           blocking_chars='#' + boxes.replace(ch, ''))
+    back = ''.join(c for c in '*>G' if c in drapes)
+    z_order = back + boxes + 'A' + ('#' if '#' in drapes else '')
+    first = [list(boxes)] if boxes else []
+    rest = ['A'] + [c for c in '>G*#' if c in drapes]
+    return ascii_art_to_game(rows, what_lies_beneath=' ', drapes=drapes,
+                             update_schedule=first + [rest], z_order=z_order,
+                             batch=batch, device=device)
+  return build, rows
+
+
+@pytest.mark.parametrize('mode', ['split-table', 'fused-interpreter'])
+@pytest.mark.parametrize('seed', range(12))
+def test_random_games(seed, mode):
+  from campx_amd import fused
+  rng = np.random.RandomState(1000 + seed)
+  build, rows = random_game(rng)
+  saved = fused.SPLIT_ROLLOUT, fused.COMPILE_TABLE
+  fused.SPLIT_ROLLOUT = mode.startswith('split')
+  fused.COMPILE_TABLE = mode.endswith('table')
+  try:
+    batch = int(rng.choice([1, 5, 16, 48, 100, 257, 272, 1024]))
+    game = build(batch=batch, device='cuda')
+    game.its_showtime()
+    og = cpu.OracleGame.from_description(gamespec.describe(build()))
+    for launch, T in enumerate([int(rng.randint(1, 40)), int(rng.randint(1, 150))]):
+      actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+      out = game.rollout(torch.from_numpy(actions), want_board=True)
+      ref = og.rollout(actions, reset_first=(launch == 0))
+      for k in ('obs', 'board', 'discount', 'done'):
+        assert _same(out[k].cpu().numpy(), ref[k]), (rows, batch, T, k)
+      if out['reward'] is None:
+        assert np.isnan(ref['reward']).all()
+      else:
+        assert _same(out['reward'].cpu().numpy(), ref['reward']), (rows, batch, T)
+    # and frame by frame through play()
+    acts = rng.randint(0, 5, size=(5, batch)).astype(np.int8)
+    ref = og.rollout(acts)
+    for t in range(5):
+      obs, reward, discount = game.play(torch.from_numpy(acts[t]))
+      assert _same(obs.layered_board.cpu().numpy(), ref['obs'][t]), (rows, batch, t)
+      assert _same(discount.cpu().numpy(), ref['discount'][t])
+  finally:
+    fused.SPLIT_ROLLOUT, fused.COMPILE_TABLE = saved
