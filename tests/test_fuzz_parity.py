@@ -5,6 +5,8 @@ coin / hover-tile / box placements, boards of every aspect ratio up to 128 cells
 three-mover games, batches that are not multiples of 4 / 16 / 64 / 256 and episode
 lengths that are not multiples of the kernels' 16-frame groups and 64-frame chunks."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -81,7 +83,7 @@ def random_game(rng):
 
 
 @pytest.mark.parametrize('mode', ['split-table', 'fused-interpreter'])
-@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_FUZZ_SEEDS', '12'))))
 def test_random_games(seed, mode):
   from campx_amd import fused
   rng = np.random.RandomState(1000 + seed)
