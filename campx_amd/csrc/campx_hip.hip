@@ -1510,7 +1510,9 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
                                                      int8_t* __restrict__ dst, int64_t n_rows) {
   __shared__ __attribute__((aligned(16))) int8_t lds[kRenderWaves * kWin * 1024];
   __shared__ uint16_t scen_off_all[kRenderWaves][CAMPX_MAX_CELLS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // readfirstlane: the wave index is uniform, and saying so keeps everything derived
+  // from it (window offsets, the divisions, base addresses) on the scalar unit
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // this wave's kWin consecutive KiB windows of the frame
   uint32_t bx = blockIdx.x;
 #if CAMPX_RENDER_XCD
@@ -1660,7 +1662,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
   __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ __attribute__((aligned(16))) uint8_t lds_board[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ uint16_t lds_cells[CAMPX_SHAPE_MAX_LIST];  // the things' shapes, once per workgroup
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1),
+            wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
   const int64_t env = (int64_t)blockIdx.x * kShapeWaves + wave;
   {
     const CampxShapeThing& last = spec->things[spec->n_things - 1];
