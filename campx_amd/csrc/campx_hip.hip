@@ -1662,8 +1662,9 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
   __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ __attribute__((aligned(16))) uint8_t lds_board[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ uint16_t lds_cells[CAMPX_SHAPE_MAX_LIST];  // the things' shapes, once per workgroup
-  const int lane = threadIdx.x & (kWave - 1),
-            wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  // (making `wave` provably uniform with readfirstlane moves this kernel's addressing to
+  // SGPRs, of which it then needs all 106: measured 4.03 against 3.67 ms)
   const int64_t env = (int64_t)blockIdx.x * kShapeWaves + wave;
   {
     const CampxShapeThing& last = spec->things[spec->n_things - 1];
