@@ -66,6 +66,18 @@ __device__ __forceinline__ void store16_streaming(u32x4* p, u32x4 v) {
 #endif
 }
 
+// The same store with the address as (wave-uniform 64-bit base in SGPRs) + (32-bit byte
+// offset per lane): no 64-bit vector address arithmetic.  `base` must be provably uniform
+// (kernel arguments, blockIdx).
+__device__ __forceinline__ void store16_streaming_at(const void* base, uint32_t off, u32x4 v) {
+#if CAMPX_NT_FLAVOR == 4
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base)
+               : "memory");
+#else
+  store16_streaming(reinterpret_cast<u32x4*>(const_cast<char*>(static_cast<const char*>(base)) + off), v);
+#endif
+}
+
 // The part of the GameSpec the interpreter reads every frame.  Passed BY VALUE
 // so that it lives in the kernarg segment (scalar loads, scalar branches).
 struct RuleBlock {
@@ -1586,8 +1598,10 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
       byte = (p & 1) ? rp.dyn_off[d] + cell : (int)scen_off[cell];
       val = (int8_t)(p & 1);
     }
-    const int64_t at = (int64_t)(first_row + (uint32_t)r) * R + byte - (int64_t)woff0;
-    if (sidx < slots && (e >> 7) && at >= 0 && at < (int64_t)span) win0[at] = val;
+    // offsets inside a frame fit 32 bits (split_ok); a patch left of the window wraps to a
+    // huge unsigned value and fails the one comparison
+    const uint32_t at = (first_row + (uint32_t)r) * (uint32_t)R + (uint32_t)byte - woff0;
+    if (sidx < slots && (e >> 7) && at < span) win0[at] = val;
   };
 #pragma unroll
   for (int it = 0; it < kMaxIter; ++it) apply(lane + it * kWave, ent[it]);
@@ -1604,11 +1618,11 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
       const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
       if (off < rp.slab_bytes) {                         // frames are whole 16-byte chunks
         const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
-        u32x4* o = reinterpret_cast<u32x4*>(dst + (int64_t)blockIdx.y * rp.slab_bytes + off);
+        const int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;   // uniform
         if (kNT)
-          store16_streaming(o, v);
+          store16_streaming_at(frame, off, v);
         else
-          *o = v;
+          *reinterpret_cast<u32x4*>(const_cast<int8_t*>(frame) + off) = v;
       }
     }
   } else {
