@@ -61,3 +61,15 @@ def test_a_failing_rank_fails_the_launcher():
             '--standin', 'bench_standin:no_such_function'])
   assert r.returncode != 0
   assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_gpus_8_the_baseline_config_5_shape():
+  """BASELINE config 5's launch shape (8 ranks, weak scaling) through the same launcher."""
+  r = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '32', '--frames', '8',
+            '--gather-every', '1', '--standin', 'bench_standin:make'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  assert line['n_gpus'] == 8 and line['config']['world'] == 8
+  assert line['config']['global_batch'] == 8 * 32
+  assert line['config']['gathered_log_matches_local'] is True
+  assert abs(line['value'] - 8 * 32 * 8 * 2 / (line['ms_per_step'] * 2e-3)) < 1e-6 * line['value']
