@@ -218,15 +218,29 @@ __device__ __forceinline__ void fill_image(int8_t* img, int n_rows, int R, const
                                            bool have_rot, const int8_t* row_lds, int lane) {
   const int total = n_rows * R;
   if (have_rot) {
+    // Four 16-byte loads in flight per lane before the first LDS write (one load per
+    // iteration made a launch of the one-frame kernels wait ~11 L2 round trips in a row);
+    // the offset inside the row advances incrementally instead of by a modulo per chunk.
     const int pitch = ((R + 15) & ~15) + 16;
-    for (int off = lane * 16; off < total; off += kWave * 16) {
-      const int k = off % R;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
-      if (off + 16 <= total) {
-        *reinterpret_cast<u32x4*>(img + off) = v;
-      } else {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        for (int j = 0; off + j < total; ++j) img[off + j] = (int8_t)(w[j >> 2] >> ((j & 3) * 8));
+    const int step = (kWave * 16) % R;
+    int k = (lane * 16) % R;
+    for (int off = lane * 16; off < total; off += 4 * kWave * 16) {
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+        k += step;
+        k = k >= R ? k - R : k;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = off + j * kWave * 16;
+        if (o + 16 <= total) {
+          *reinterpret_cast<u32x4*>(img + o) = v[j];
+        } else if (o < total) {
+          const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+          for (int b = 0; o + b < total; ++b) img[o + b] = (int8_t)(w[b >> 2] >> ((b & 3) * 8));
+        }
       }
     }
   } else {
