@@ -313,6 +313,34 @@ __device__ __forceinline__ void stream_out(const int8_t* lds, int8_t* dst, int n
   }
 }
 
+// The same for 16-bit observations (out_format CAMPX_OBS_F16 / _BF16): a lane turns 8 image
+// bytes (0 / 1) into 8 halves (0.0 / 1.0) and stores 16 bytes; `dst` counts elements.
+__device__ __forceinline__ void stream_out16(const int8_t* lds, int8_t* dst, int nbytes, int lane,
+                                             uint32_t one) {
+  uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+  const int nvec = nbytes >> 3;
+  for (int i = lane; i < nvec; i += kWave) {
+    const uint2 b = *reinterpret_cast<const uint2*>(lds + 8 * i);
+    u32x4 v;
+    v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * one;
+    v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * one;
+    v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * one;
+    v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * one;
+    *reinterpret_cast<u32x4*>(out + 8 * i) = v;
+  }
+  for (int i = (nvec << 3) + lane; i < nbytes; i += kWave) out[i] = lds[i] ? (uint16_t)one : (uint16_t)0;
+}
+
+// Observation of the one-frame kernels, in the format the caller asked for.
+__device__ __forceinline__ void step_stream_obs(const int8_t* img, const CampxOutputs& out,
+                                                int64_t first_elem, int nbytes, int lane) {
+  if (out.obs_format == CAMPX_OBS_INT8)
+    stream_out<false>(img, out.obs + first_elem, nbytes, lane);
+  else
+    stream_out16(img, out.obs + 2 * first_elem, nbytes, lane,
+                 out.obs_format == CAMPX_OBS_F16 ? 0x3C00u : 0x3F80u);
+}
+
 template <int K, bool kBoard, bool kNT, int kEnvs, bool kTrace>
 __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
                                                         const CampxSpec* __restrict__ spec,
@@ -750,7 +778,7 @@ __global__ __launch_bounds__(kWave) void step_table_kernel(
     if (st.ret) st.ret[env] = ret;
   }
   // one wave: LDS operations complete in order, no barrier needed
-  stream_out<false>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+  step_stream_obs(obs_img, out, env0 * LHW, n_live * LHW, lane);
   if (kBoard) stream_out<false>(board_img, out.board + env0 * HW, n_live * HW, lane);
   report_bad_actions(out, bad);
 }
@@ -826,7 +854,7 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
     st.done[env] = (uint8_t)done;
     if (st.ret) st.ret[env] = ret;
   }
-  stream_out<false>(obs_img, out.obs + env0 * LHW, n_live * LHW, lane);
+  step_stream_obs(obs_img, out, env0 * LHW, n_live * LHW, lane);
   if (kBoard) stream_out<false>(board_img, out.board + env0 * HW, n_live * HW, lane);
   report_bad_actions(out, bad);
 }
@@ -2251,12 +2279,13 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
   if (!emit_first && !interpreter_only && split_ok(*spec_host, out, B, T))
     return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
-  if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;  // 16-bit needs the render kernel
+  // (16-bit observations: the render kernel above, or the one-frame kernels below)
   if (use_table && T == 1 && !emit_first && spec_host->render_valid && !knob_no_step())
     return launch_step_table(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (T == 1 && !emit_first && spec_host->n_dyn == 2 && st.pair_table && spec_host->render_valid &&
       !interpreter_only && !knob_no_table() && !knob_no_step())
     return launch_step_pair(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
+  if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
   switch (spec_host->n_dyn) {

@@ -266,7 +266,8 @@ void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& 
           const OptTensor& bad_flag) {
   const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
   want(actions, "actions", at::kChar, g.dev, {g.B});
-  want(obs, "obs", at::kChar, g.dev, {g.B, g.L, g.H, g.W});
+  const int32_t format = obs_format_of(obs);   // int8, or f16 / bf16 for a policy network
+  want(obs, "obs", obs.scalar_type(), g.dev, {g.B, g.L, g.H, g.W});
   if (board.has_value()) want(*board, "board", at::kChar, g.dev, {g.B, g.H, g.W});
   if (reward.has_value()) want(*reward, "reward", at::kFloat, g.dev, {g.B});
   if (discount.has_value()) want(*discount, "discount", at::kFloat, g.dev, {g.B});
@@ -275,6 +276,7 @@ void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& 
   if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
   CampxOutputs out{};
   out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.obs_format = format;
   out.board = opt_ptr<int8_t>(board);
   out.reward = opt_ptr<float>(reward);
   out.discount = opt_ptr<float>(discount);

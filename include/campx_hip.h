@@ -192,8 +192,10 @@ typedef struct CampxOutputs {
                          CAMPX_OBS_F16 / CAMPX_OBS_BF16: 0.0 / 1.0 in that format, the tensor
                          the reference's driver builds with `layered_board.view(-1).float()`
                          (examples/reinforce.py:123,149) handed over without a conversion
-                         pass.  16-bit formats are produced by the render kernel only: they
-                         need `trace` and back-to-back frames, else CAMPX_EINVAL. */
+                         pass.  16-bit formats are produced by the render kernel (rollouts:
+                         they need `trace` and back-to-back frames) and by the one-frame
+                         kernels of one- and two-mover games with their tables (T == 1);
+                         anything else returns CAMPX_EINVAL. */
   int32_t* bad_count; /* optional device int32: += number of action ids outside 0..4 this call
                          consumed (the reference asserts sum(act) == 1 per step,
                          examples/boat_race.py:48; here the check rides in the kernel that

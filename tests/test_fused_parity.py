@@ -466,3 +466,30 @@ def test_raw_c_abi_through_ctypes(golden):
   assert _same(obs.cpu().numpy(), gold['layered'][1:])
   assert _same(reward.cpu().numpy(), gold['reward'])
   assert _same(discount.cpu().numpy(), gold['discount'])
+
+
+@pytest.mark.parametrize('name', ['boat_race', 'sokoban'])
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_sixteen_bit_play_observations(name, dtype, golden, update_pass_mode):
+  """The per-step consumer hand-off: play() writes the policy network's input dtype."""
+  gold = golden(name)
+  T, N = gold['actions'].shape
+  game, _ = _fused(name, N)
+  if update_pass_mode != 'table':
+    with pytest.raises(ValueError):
+      game.fused.set_play_obs_dtype(dtype)
+    return
+  game.fused.set_play_obs_dtype(dtype)
+  assert game.fused._obs.dtype == dtype
+  assert torch.equal(game.fused._obs.float().cpu(),
+                     torch.from_numpy(gold['layered'][0].astype(np.float32)))
+  for t in range(min(T, 25)):
+    obs, reward, discount = game.play(torch.from_numpy(gold['actions'][t]))
+    assert obs.layered_board.dtype == dtype
+    want = torch.from_numpy(gold['layered'][t + 1].astype(np.float32))
+    assert torch.equal(obs.layered_board.float().cpu(), want), t
+    assert _same(obs.board.cpu().numpy(), gold['board'][t + 1])
+    assert _same(reward.cpu().numpy(), gold['reward'][t])
+  game.fused.set_play_obs_dtype(torch.int8)
+  obs, _, _ = game.play(torch.from_numpy(gold['actions'][25]))
+  assert _same(obs.layered_board.cpu().numpy(), gold['layered'][26])
