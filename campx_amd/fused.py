@@ -264,6 +264,10 @@ class FusedGame(object):
     sixteen = obs_dtype != torch.int8
     if sixteen and not keep_obs:
       raise ValueError('16-bit observations need keep_obs=True')
+    if not keep_obs and self._obs.dtype != torch.int8:
+      raise ValueError('keep_obs=False renders into play()\'s frame buffer, which '
+                       'set_play_obs_dtype() made {}: set it back to int8 first'
+                       .format(self._obs.dtype))
     if share is not None:
       obs, board = share['obs'], share['board']
     else:
