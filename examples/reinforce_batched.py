@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""REINFORCE on the boat race, B environments at once, the whole loop on the GPU.
+
+The batched counterpart of the reference's driver (examples/reinforce.py): same policy
+network shape (one hidden layer, reinforce.py:53-67), same episode length (100), same
+log columns (`id,step,t(s),ep,L,R,R_av_5,P,P_av`, reinforce.py:270-284) - but one
+`Engine` holds B environments, `play()` hands the policy its input directly in bf16
+(`set_play_obs_dtype`, no `.float()` pass), actions are sampled on the device and go
+back into `play()` as int8 ids, and the hidden performance is scored in the kernel.
+
+    python examples/reinforce_batched.py --batch 4096 --episodes 20 --csv /tmp/log.csv
+
+A consumer of the engine, not part of it (RL drivers are out of
+scope); it exists to show the hand-off and is smoke-tested in tests/test_example.py.
+"""
+
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from campx_amd.episode_log import EpisodeCsvLog  # noqa: E402
+from campx_amd.games import boat_race  # noqa: E402
+
+
+class Policy(torch.nn.Module):
+  def __init__(self, n_in, hidden=32, n_out=5):
+    super().__init__()
+    self.affine1 = torch.nn.Linear(n_in, hidden)
+    self.affine2 = torch.nn.Linear(hidden, n_out)
+
+  def forward(self, x):
+    return torch.log_softmax(self.affine2(torch.relu(self.affine1(x))), dim=-1)
+
+
+def run(batch=4096, episodes=10, frames=100, gamma=0.99, lr=1e-2, csv=None, seed=0,
+        device='cuda'):
+  torch.manual_seed(seed)
+  game, obs, _, _ = boat_race.make_game(batch=batch, device=device)
+  fused = game.fused
+  fused.set_play_obs_dtype(torch.bfloat16)
+  fused.validate_actions = False                 # ids come from multinomial: always 0..4
+  n_in = fused.n_layers * fused.rows * fused.cols
+  policy = Policy(n_in).to(device=device, dtype=torch.bfloat16)
+  optim = torch.optim.Adam(policy.parameters(), lr=lr)
+  log = EpisodeCsvLog(csv, frames_per_episode=frames) if csv else None
+  history = []
+  for episode in range(episodes):
+    fused.rollout(torch.full((1, batch), 4, dtype=torch.int8, device=device),
+                  keep_obs=True, reset_first=True)     # new episode: rebuild from the art
+    obs, _, _ = game.play(torch.full((batch,), 4, dtype=torch.int8, device=device))
+    log_probs, rewards, perf = [], [], torch.zeros(batch, device=device)
+    for t in range(frames):
+      logp = policy(obs.layered_board.view(batch, n_in))          # bf16 in, no conversion
+      ids = torch.multinomial(logp.float().exp(), 1).squeeze(1)
+      log_probs.append(logp.gather(1, ids[:, None]).squeeze(1).float())
+      obs, reward, _ = game.play(ids.to(torch.int8))
+      rewards.append(reward.clone())
+      perf += fused.perf.float()
+    returns, running = [], torch.zeros(batch, device=device)
+    for r in reversed(rewards):
+      running = r + gamma * running
+      returns.append(running)
+    returns = torch.stack(returns[::-1])
+    returns = (returns - returns.mean()) / (returns.std() + 1e-6)
+    loss = -(torch.stack(log_probs) * returns).sum(0).mean()
+    optim.zero_grad()
+    loss.backward()
+    optim.step()
+    episode_return = torch.stack(rewards).sum(0)
+    history.append((float(loss), float(episode_return.mean()), float(perf.mean())))
+    if log:
+      log.episode(episode_return, perf, loss=float(loss))
+  if log:
+    log.close()
+  return history
+
+
+if __name__ == '__main__':
+  p = argparse.ArgumentParser()
+  p.add_argument('--batch', type=int, default=4096)
+  p.add_argument('--episodes', type=int, default=10)
+  p.add_argument('--frames', type=int, default=100)
+  p.add_argument('--csv', default=None)
+  args = p.parse_args()
+  for i, (loss, ret, perf) in enumerate(run(args.batch, args.episodes, args.frames, csv=args.csv)):
+    print('ep: {}, L: {:.3f}, R: {:.2f}, P: {:.2f}'.format(i, loss, ret, perf))
