@@ -71,9 +71,9 @@ def run(batch=4096, episodes=10, frames=100, gamma=0.99, lr=1e-2, csv=None, seed
     loss.backward()
     optim.step()
     episode_return = torch.stack(rewards).sum(0)
-    history.append((float(loss), float(episode_return.mean()), float(perf.mean())))
+    history.append((float(loss.detach()), float(episode_return.mean()), float(perf.mean())))
     if log:
-      log.episode(episode_return, perf, loss=float(loss))
+      log.episode(episode_return, perf, loss=float(loss.detach()))
   if log:
     log.close()
   return history
