@@ -210,6 +210,19 @@ class FusedGame(object):
     self.frame = 0
     return self._observation_cache, None, 1.0
 
+  def reset(self):
+    """A new episode for every environment: what `make_game()` + `its_showtime()` per
+    episode does in the reference's driver (examples/reinforce.py:122).  Returns the
+    first `(Observation, None, 1.0)` like `its_showtime()`."""
+    if self._obs.dtype != torch.int8:
+      first = torch.empty(self._obs.shape, dtype=torch.int8, device=self.device)
+      _hip.ops.reset(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                     self._pair_table, first, self._board)
+      self._obs.copy_(first)
+      self.frame = 0
+      return self._observation_cache, None, 1.0
+    return self.showtime()
+
   def set_play_obs_dtype(self, dtype):
     """Make `play()` return `layered_board` in `dtype` (torch.int8, float16 or bfloat16).
 

@@ -112,6 +112,10 @@ class ShapeGame(object):
     self.frame = 0
     return self._observation_cache, None, 1.0
 
+  def reset(self):
+    """A new episode for every environment (see `FusedGame.reset`)."""
+    return self.showtime()
+
   def play(self, actions):
     ids = self._ids(actions, (self.batch,))
     validate = self.validate_actions

@@ -49,9 +49,7 @@ def run(batch=4096, episodes=10, frames=100, gamma=0.99, lr=1e-2, csv=None, seed
   log = EpisodeCsvLog(csv, frames_per_episode=frames) if csv else None
   history = []
   for episode in range(episodes):
-    fused.rollout(torch.full((1, batch), 4, dtype=torch.int8, device=device),
-                  keep_obs=True, reset_first=True)     # new episode: rebuild from the art
-    obs, _, _ = game.play(torch.full((batch,), 4, dtype=torch.int8, device=device))
+    obs, _, _ = fused.reset()                           # new episode: rebuild from the art
     log_probs, rewards, perf = [], [], torch.zeros(batch, device=device)
     for t in range(frames):
       logp = policy(obs.layered_board.view(batch, n_in))          # bf16 in, no conversion

@@ -490,6 +490,10 @@ def test_sixteen_bit_play_observations(name, dtype, golden, update_pass_mode):
     assert torch.equal(obs.layered_board.float().cpu(), want), t
     assert _same(obs.board.cpu().numpy(), gold['board'][t + 1])
     assert _same(reward.cpu().numpy(), gold['reward'][t])
+  obs, reward, discount = game.fused.reset()       # a new episode, still 16-bit
+  assert reward is None and discount == 1.0
+  assert torch.equal(obs.layered_board.float().cpu(),
+                     torch.from_numpy(gold['layered'][0].astype(np.float32)))
   game.fused.set_play_obs_dtype(torch.int8)
-  obs, _, _ = game.play(torch.from_numpy(gold['actions'][25]))
-  assert _same(obs.layered_board.cpu().numpy(), gold['layered'][26])
+  obs, _, _ = game.play(torch.from_numpy(gold['actions'][0]))
+  assert _same(obs.layered_board.cpu().numpy(), gold['layered'][1])
