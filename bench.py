@@ -203,7 +203,7 @@ def kernel_names(fused, split):
   if split:
     first = ('update_table_kernel' if fused.n_dyn == 1 else
              'update_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
-             'rollout_kernel<trace>')
+             'update_tuple_kernel' if fused.uses_table else 'rollout_kernel<trace>')
     return first + ' + render_kernel'
   return ('rollout_table_kernel' if fused.n_dyn == 1 and fused.uses_table
           else 'rollout_kernel')

@@ -1502,6 +1502,241 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
 }
 
 // ---------------------------------------------------------------------------
+// Three- and four-mover games: the same producer / consumer / loader layout over a
+// direct-indexed (cell, cell, cell[, cell], action) table in GLOBAL memory
+// (campx_tuple_table_build: 4.4 MB for three movers on a 6x8 board, 212 MB for four).
+// 64-bit entries: bits 0-27 the things' cells after the frame (7 bits each), 28-31
+// whether each is the character its cell shows, 32 done, 33-34 perf + 1, 35-42 index into
+// the reward list.  The dependent chain is one global load per frame, so the kernel wants
+// every environment in flight at once: 8-frame groups keep the ring small enough for two
+// 256-environment workgroups per CU.
+struct TupleParams {
+  int32_t rows, cols, n_dyn;
+  int32_t row0[CAMPX_MAX_DYN], col0[CAMPX_MAX_DYN];
+};
+
+constexpr int kTupleGroup = 8;
+constexpr int64_t kTupleTableMaxBytes = 512ll << 20;  // four movers on a 6x8 board: 212 MB
+
+template <int K>
+__device__ __forceinline__ uint32_t tuple_index(uint32_t cells, uint32_t HW) {
+  uint32_t idx = cells & 0x7fu;
+#pragma unroll
+  for (int k = 1; k < K; ++k) idx = idx * HW + ((cells >> (7 * k)) & 0x7fu);
+  return idx * CAMPX_N_ACTIONS;
+}
+
+// Four waves per SIMD = two workgroups per CU, so that 131 072 environments are all in
+// flight at once (four movers: 131 -> 128 VGPRs; sokoban level 2 87 -> 65 us per launch).
+#ifndef CAMPX_TUPLE_MINWAVES
+#define CAMPX_TUPLE_MINWAVES 4
+#endif
+
+template <int K, int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             CAMPX_TUPLE_MINWAVES) void update_tuple_kernel(
+    TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B,
+    int32_t T, int32_t reset_first) {
+  constexpr int kLoad = update_loaders(kProd), kG = kTupleGroup;
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
+  __shared__ float reward_list[256];
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
+  __shared__ __attribute__((aligned(16))) uint64_t ring[2][kG][E];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool producer = wave < kProd, loader = wave >= kProd + kCons;
+  const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;
+  const int W = tp.cols;
+  const uint32_t HW = (uint32_t)(tp.rows * tp.cols);
+  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const bool wide = (B & 15) == 0;
+  const float* g_rewards = static_cast<const float*>(st.pair_table);
+  const uint64_t* g_entries = reinterpret_cast<const uint64_t*>(g_rewards + 256);
+  for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
+  ActionLoader<E, kLoad> ld;
+  int bad = 0;
+  if (loader && T > 0) {
+    if (wide) {
+      ld.issue(actions, B, T, 0, env0, llane);
+      bad += ld.land(staged[0], B, T, 0, env0, llane);
+    } else {
+      bad += stage_bytes<E, kLoad>(staged[0], actions, B, T, 0, env0, llane);
+    }
+  }
+  const int le = wave * kWave + lane;
+  const int64_t env = env0 + le;
+  const bool live = producer && env < B;
+  uint32_t init = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) init |= (uint32_t)(tp.row0[k] * W + tp.col0[k]) << (7 * k);
+  uint32_t cells = init;
+  int over = 0;
+  float ret = 0.0f;
+  if (live && !reset_first) {
+    cells = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      cells |= (uint32_t)((int)st.pos[(int64_t)(2 * k) * B + env] * W +
+                          (int)st.pos[(int64_t)(2 * k + 1) * B + env]) << (7 * k);
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+  const int clane = (int)threadIdx.x - kProd * kWave;
+  constexpr int kGroupsPerChunk = kChunk / kG;
+  __syncthreads();
+
+  const int n_groups = (T + kG - 1) / kG;
+  if (producer) {
+    for (int g = 0; g <= n_groups; ++g) {
+      if (g < n_groups) {
+        const int t0 = g * kG;
+        const int8_t* chunk = staged[(t0 / kChunk) & 1];
+        const int n = (T - t0 < kG) ? T - t0 : kG;
+        uint32_t act[kG];
+#pragma unroll
+        for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+#pragma unroll
+        for (int j = 0; j < kG; ++j) {
+          if (j < n) {
+            cells = over ? init : cells;  // rebuilt from the art before its next action
+            const uint64_t e = g_entries[tuple_index<K>(cells, HW) + act[j]];  // the chain
+            cells = (uint32_t)e & 0x0fffffffu;
+            ring[g & 1][j][le] = e;
+            ret = (over ? 0.0f : ret) + reward_list[(uint32_t)(e >> 35) & 0xffu];
+            over = (int)((e >> 32) & 1u);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if (!loader) {
+    for (int g = 0; g <= n_groups; ++g) {
+      if (g > 0) {
+        const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
+        const int n = (T - t0 < kG) ? T - t0 : kG;
+        const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
+        // ---- float streams: item = (frame j, 4 environments)
+        constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
+#pragma unroll 1
+        for (int it = 0; it < kItA; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QA, q = item % QA;
+          const int64_t e0 = env0 + 4 * q;
+          if (item < kG * QA && j < n && e0 < B) {
+            uint32_t rw[4], dc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t hi = (uint32_t)(ring[rb][j][4 * q + i] >> 32);
+              rw[i] = __float_as_uint(reward_list[(hi >> 3) & 0xffu]);
+              dc[i] = (hi & 1u) ? 0u : 0x3f800000u;
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (wide) {
+              if (out.reward) {
+                const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
+                store16_update(out.reward + at, r4);
+              }
+              if (out.discount) {
+                const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
+                store16_update(out.discount + at, d4);
+              }
+            } else {
+              for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
+              }
+            }
+          }
+        }
+        // ---- byte streams: item = (frame j, 16 environments)
+        constexpr int QB = E / 16, kItB = (kG * QB + CL - 1) / CL;
+#pragma unroll 1
+        for (int it = 0; it < kItB; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QB, q = item % QB;
+          const int64_t e0 = env0 + 16 * q;
+          if (item < kG * QB && j < n && e0 < B) {
+            uint32_t tr[K][4], dn[4], pf[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              uint32_t lo[4], hi[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint64_t e = ring[rb][j][16 * q + 4 * w + i];
+                lo[i] = (uint32_t)e;
+                hi[i] = (uint32_t)(e >> 32);
+              }
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                uint32_t b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  b[i] = ((lo[i] >> (7 * k)) & 0x7fu) | (((lo[i] >> (28 + k)) & 1u) << 7);
+                tr[k][w] = pack4(b[0], b[1], b[2], b[3]);
+              }
+              dn[w] = pack4(hi[0] & 1u, hi[1] & 1u, hi[2] & 1u, hi[3] & 1u);
+              pf[w] = pack4(((hi[0] >> 1) & 3u) - 1u, ((hi[1] >> 1) & 3u) - 1u,
+                            ((hi[2] >> 1) & 3u) - 1u, (((hi[3] >> 1) & 3u) - 1u) & 0xffu);
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (wide) {
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const u32x4 t4 = {tr[k][0], tr[k][1], tr[k][2], tr[k][3]};
+                store16_update(out.trace + k * plane + at, t4);
+              }
+              if (out.done) {
+                const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                store16_update(out.done + at, d4);
+              }
+              if (out.perf) {
+                const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                store16_update(out.perf + at, p4);
+              }
+            } else {
+              for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                const int sh = (i & 3) * 8;
+#pragma unroll
+                for (int k = 0; k < K; ++k) out.trace[k * plane + at + i] = (uint8_t)(tr[k][i >> 2] >> sh);
+                if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int g = 0; g <= n_groups; ++g) {
+      const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+      const int t_next = (c + 1) * kChunk;
+      if (t_next < T) {
+        if (wide) {
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
+        } else if (phase == 0) {
+          bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t c = (cells >> (7 * k)) & 0x7fu;
+      st.pos[(int64_t)(2 * k) * B + env] = (int8_t)(c / (uint32_t)W);
+      st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)(c % (uint32_t)W);
+    }
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+  report_bad_actions(out, bad);
+}
+
+// ---------------------------------------------------------------------------
 // Split path, second half: expand the trace into the observation stream.
 // One-shot blocks, ONE aligned 16-byte store per thread, block (x, t) writing bytes
 // [x*4096, (x+1)*4096) of frame t: the dispatcher walks the output linearly.  That
@@ -2187,6 +2422,12 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 #ifndef CAMPX_PAIR_CONS
 #define CAMPX_PAIR_CONS 2
 #endif
+#ifndef CAMPX_TUPLE_PROD
+#define CAMPX_TUPLE_PROD 4
+#endif
+#ifndef CAMPX_TUPLE_CONS
+#define CAMPX_TUPLE_CONS 2
+#endif
 
 int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
@@ -2232,6 +2473,25 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
     else
       hipLaunchKernelGGL((update_pair_kernel<2, kProd, kCons>), grid, block, 0, stream, pp,
                          spec_dev, st, actions, out, B, T, reset_first);
+  } else if (s.n_dyn >= 3 && st.pair_table && !knob_no_table()) {
+    constexpr int kProd = CAMPX_TUPLE_PROD, kCons = CAMPX_TUPLE_CONS, kEnvs = kProd * kWave;
+    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
+        block((kProd + kCons + update_loaders(kProd)) * kWave);
+    TupleParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.rows = s.rows;
+    tp.cols = s.cols;
+    tp.n_dyn = s.n_dyn;
+    for (int d = 0; d < s.n_dyn; ++d) {
+      tp.row0[d] = s.dyn_row0[d];
+      tp.col0[d] = s.dyn_col0[d];
+    }
+    if (s.n_dyn == 3)
+      hipLaunchKernelGGL((update_tuple_kernel<3, kProd, kCons>), grid, block, 0, stream, tp, st,
+                         actions, out, B, T, reset_first);
+    else
+      hipLaunchKernelGGL((update_tuple_kernel<4, kProd, kCons>), grid, block, 0, stream, tp, st,
+                         actions, out, B, T, reset_first);
   } else {
     switch (s.n_dyn) {
       case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
@@ -2457,26 +2717,34 @@ done:
 }
 
 int64_t campx_pair_table_bytes(const CampxSpec* spec) {
-  if (!spec || campx_spec_validate(spec) != CAMPX_OK || spec->n_dyn != 2) return 0;
+  if (!spec || campx_spec_validate(spec) != CAMPX_OK || spec->n_dyn < 2) return 0;
   const int64_t HW = (int64_t)spec->rows * spec->cols;
-  const int64_t n = HW * HW * CAMPX_N_ACTIONS;
-  int64_t bytes = 256 * (int64_t)sizeof(float) + n * (int64_t)sizeof(uint32_t);
-  if (n <= 65535) bytes += (n * (int64_t)sizeof(uint16_t) + 15) & ~(int64_t)15;  // chain table
-  return bytes <= (1 << 20) ? bytes : 0;
+  if (HW > 128) return 0;  // cells are 7-bit fields
+  int64_t n = CAMPX_N_ACTIONS;
+  for (int d = 0; d < spec->n_dyn; ++d) n *= HW;
+  if (spec->n_dyn == 2) {
+    int64_t bytes = 256 * (int64_t)sizeof(float) + n * (int64_t)sizeof(uint32_t);
+    if (n <= 65535) bytes += (n * (int64_t)sizeof(uint16_t) + 15) & ~(int64_t)15;  // chain table
+    return bytes <= (1 << 20) ? bytes : 0;
+  }
+  // three / four movers: 64-bit entries, read from global memory
+  const int64_t bytes = 256 * (int64_t)sizeof(float) + n * (int64_t)sizeof(uint64_t);
+  return bytes <= kTupleTableMaxBytes ? bytes : 0;
 }
 
 int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev, void* table_dev,
                                void* stream) {
   const int64_t bytes = campx_pair_table_bytes(spec);
   if (bytes == 0 || !spec_dev || !table_dev) return CAMPX_EINVAL;
-  const int W = spec->cols, HW = spec->rows * spec->cols;
-  const int n = HW * HW * CAMPX_N_ACTIONS;
+  const int K = spec->n_dyn, W = spec->cols, HW = spec->rows * spec->cols;
+  size_t n = CAMPX_N_ACTIONS;
+  for (int d = 0; d < K; ++d) n *= (size_t)HW;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // scratch: obs | trace[2][n] | reward[n] | pos[4][n] | done[n] | actions[n] | done_out[n] | perf[n]
-  const size_t off_trace = ((size_t)n * spec->n_layers * HW + 255) & ~(size_t)255;
-  const size_t off_reward = (off_trace + 2 * (size_t)n + 255) & ~(size_t)255;
-  const size_t off_pos = off_reward + sizeof(float) * (size_t)n;
-  const size_t off_done = off_pos + 4 * (size_t)n;
+  // device scratch: reward[n] | trace[K][n] | pos[2K][n] | done[n] | actions[n] | done_out[n] | perf[n]
+  // (the interpreter in trace mode writes no observations)
+  const size_t off_trace = sizeof(float) * n;
+  const size_t off_pos = off_trace + (size_t)K * n;
+  const size_t off_done = off_pos + 2 * (size_t)K * n;
   const size_t off_act = off_done + n;
   const size_t off_dout = off_act + n;
   const size_t off_perf = off_dout + n;
@@ -2484,32 +2752,37 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
   char* dev = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), total);
   if (e != hipSuccess) return hip_failed(e);
-  // host scratch, 4-byte arrays first so that nothing needs an alignment pad:
-  // reward[n] | table (256 floats + n entries) | pos[4][n] | act[n] | done[n] | perf[n] | trace[2][n]
-  const size_t host_bytes = (size_t)n * 4 + (size_t)bytes + (size_t)n * (4 + 1 + 1 + 1 + 2);
+  // host scratch, widest arrays first so that nothing needs an alignment pad:
+  // table (256 floats + entries [+ chain]) | reward[n] | pos[2K][n] | act[n] | done[n] | perf[n] | trace[K][n]
+  const size_t table_bytes = ((size_t)bytes + 7) & ~(size_t)7;
+  const size_t host_bytes = table_bytes + n * 4 + n * (size_t)(2 * K + 1 + 1 + 1 + K);
   char* host = static_cast<char*>(malloc(host_bytes));
   if (!host) {
     (void)hipFree(dev);
     return CAMPX_ENOMEM;
   }
-  float* h_reward = reinterpret_cast<float*>(host);
-  float* h_table = h_reward + n;
-  uint32_t* h_entries = reinterpret_cast<uint32_t*>(h_table + 256);
-  int8_t* h_pos = reinterpret_cast<int8_t*>(h_entries + n);
-  int8_t* h_act = h_pos + 4 * (size_t)n;
+  float* h_table = reinterpret_cast<float*>(host);
+  uint32_t* h_entries32 = reinterpret_cast<uint32_t*>(h_table + 256);
+  uint64_t* h_entries64 = reinterpret_cast<uint64_t*>(h_table + 256);
+  float* h_reward = reinterpret_cast<float*>(host + table_bytes);
+  int8_t* h_pos = reinterpret_cast<int8_t*>(h_reward + n);
+  int8_t* h_act = h_pos + 2 * (size_t)K * n;
   uint8_t* h_done = reinterpret_cast<uint8_t*>(h_act + n);
   int8_t* h_perf = reinterpret_cast<int8_t*>(h_done + n);
   uint8_t* h_trace = reinterpret_cast<uint8_t*>(h_perf + n);
-  for (int i = 0; i < n; ++i) {
-    const int a = i % CAMPX_N_ACTIONS, c1 = (i / CAMPX_N_ACTIONS) % HW, c0 = i / (CAMPX_N_ACTIONS * HW);
-    h_pos[i] = (int8_t)(c0 / W);
-    h_pos[n + i] = (int8_t)(c0 % W);
-    h_pos[2 * n + i] = (int8_t)(c1 / W);
-    h_pos[3 * n + i] = (int8_t)(c1 % W);
-    h_act[i] = (int8_t)a;
+  for (size_t i = 0; i < n; ++i) {  // index = ((cell_0 * HW + cell_1) * HW + ...) * 5 + action
+    size_t rest = i / CAMPX_N_ACTIONS;
+    h_act[i] = (int8_t)(i % CAMPX_N_ACTIONS);
+    for (int d = K - 1; d >= 0; --d) {
+      const int cell = (int)(rest % (size_t)HW);
+      rest /= (size_t)HW;
+      h_pos[(size_t)(2 * d) * n + i] = (int8_t)(cell / W);
+      h_pos[(size_t)(2 * d + 1) * n + i] = (int8_t)(cell % W);
+    }
   }
   int32_t rc = CAMPX_OK;
   int n_rewards = 0;
+  uint32_t reward_bits[256];
 #define CAMPX_TRY(call)           \
   do {                            \
     e = (call);                   \
@@ -2518,37 +2791,40 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
       goto done;                  \
     }                             \
   } while (0)
-  CAMPX_TRY(hipMemcpyAsync(dev + off_pos, h_pos, 4 * (size_t)n, hipMemcpyHostToDevice, s));
-  CAMPX_TRY(hipMemcpyAsync(dev + off_act, h_act, (size_t)n, hipMemcpyHostToDevice, s));
-  CAMPX_TRY(hipMemsetAsync(dev + off_done, 0, (size_t)n, s));
-  CAMPX_TRY(hipMemsetAsync(dev + off_perf, 0, (size_t)n, s));
+  CAMPX_TRY(hipMemcpyAsync(dev + off_pos, h_pos, 2 * (size_t)K * n, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemcpyAsync(dev + off_act, h_act, n, hipMemcpyHostToDevice, s));
+  CAMPX_TRY(hipMemsetAsync(dev + off_done, 0, n, s));
+  CAMPX_TRY(hipMemsetAsync(dev + off_perf, 0, n, s));
   {
     CampxState st = {reinterpret_cast<int8_t*>(dev + off_pos),
                      reinterpret_cast<uint8_t*>(dev + off_done), nullptr, nullptr};
-    CampxOutputs out = {reinterpret_cast<int8_t*>(dev), 0, nullptr, 0,
-                        reinterpret_cast<float*>(dev + off_reward), nullptr,
-                        reinterpret_cast<uint8_t*>(dev + off_dout),
-                        spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr,
-                        reinterpret_cast<uint8_t*>(dev + off_trace)};
+    CampxOutputs out;
+    memset(&out, 0, sizeof(out));
+    out.reward = reinterpret_cast<float*>(dev);
+    out.done = reinterpret_cast<uint8_t*>(dev + off_dout);
+    out.perf = spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr;
+    out.trace = reinterpret_cast<uint8_t*>(dev + off_trace);
     // the interpreter in trace mode: positions, visibility, reward, done, perf
-    launch_trace_k<2>(*spec, spec_dev, st, reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1,
-                      0, s);
+    const int8_t* acts = reinterpret_cast<const int8_t*>(dev + off_act);
+    switch (K) {
+      case 2: launch_trace_k<2>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, s); break;
+      case 3: launch_trace_k<3>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, s); break;
+      default: launch_trace_k<4>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, s); break;
+    }
     CAMPX_TRY(hipGetLastError());
   }
-  CAMPX_TRY(hipMemcpyAsync(h_trace, dev + off_trace, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
-  CAMPX_TRY(hipMemcpyAsync(h_reward, dev + off_reward, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
-  CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, (size_t)n, hipMemcpyDeviceToHost, s));
-  CAMPX_TRY(hipMemcpyAsync(h_perf, dev + off_perf, (size_t)n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_trace, dev + off_trace, (size_t)K * n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_reward, dev, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, n, hipMemcpyDeviceToHost, s));
+  CAMPX_TRY(hipMemcpyAsync(h_perf, dev + off_perf, n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipStreamSynchronize(s));
   for (int i = 0; i < 256; ++i) h_table[i] = 0.0f;
-  for (int i = 0; i < n; ++i) {
+  for (size_t i = 0; i < n; ++i) {
     uint32_t bits;
     memcpy(&bits, &h_reward[i], 4);
     int idx = -1;
     for (int k = 0; k < n_rewards; ++k) {
-      uint32_t have;
-      memcpy(&have, &h_table[k], 4);
-      if (have == bits) {
+      if (reward_bits[k] == bits) {
         idx = k;
         break;
       }
@@ -2559,24 +2835,34 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
         goto done;
       }
       idx = n_rewards++;
+      reward_bits[idx] = bits;
       h_table[idx] = h_reward[i];
     }
-    const uint32_t ta = h_trace[i], tb = h_trace[n + i];
-    const int perf = spec->perf_dyn >= 0 ? h_perf[i] : 0;
-    h_entries[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
-                   ((uint32_t)(h_done[i] & 1) << 16) |
-                   ((uint32_t)(perf + 1) << 17) | ((uint32_t)idx << 19);
+    const uint32_t perf = (uint32_t)((spec->perf_dyn >= 0 ? h_perf[i] : 0) + 1);
+    const uint32_t over = (uint32_t)(h_done[i] & 1);
+    if (K == 2) {
+      const uint32_t ta = h_trace[i], tb = h_trace[n + i];
+      h_entries32[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
+                       (over << 16) | (perf << 17) | ((uint32_t)idx << 19);
+    } else {
+      uint32_t lo = 0;
+      for (int d = 0; d < K; ++d) {
+        const uint32_t tr = h_trace[(size_t)d * n + i];
+        lo |= ((tr & 0x7fu) << (7 * d)) | ((tr >> 7) << (28 + d));
+      }
+      h_entries64[i] = (uint64_t)lo | ((uint64_t)(over | (perf << 1) | ((uint32_t)idx << 3)) << 32);
+    }
   }
-  if (n <= 65535) {
+  if (K == 2 && n <= 65535) {
     // chain table: where the NEXT frame's lookup starts, (cell0 * HW + cell1) * 5, with
     // the rebuild from the art folded in for frames that end the episode
-    uint16_t* h_chain = reinterpret_cast<uint16_t*>(h_entries + n);
+    uint16_t* h_chain = reinterpret_cast<uint16_t*>(h_entries32 + n);
     const uint32_t init = ((uint32_t)(spec->dyn_row0[0] * W + spec->dyn_col0[0]) * (uint32_t)HW +
                            (uint32_t)(spec->dyn_row0[1] * W + spec->dyn_col0[1])) * CAMPX_N_ACTIONS;
-    for (int i = 0; i < n; ++i) {
-      const uint32_t e = h_entries[i];
-      const uint32_t next = ((e & 0x7fu) * (uint32_t)HW + ((e >> 7) & 0x7fu)) * CAMPX_N_ACTIONS;
-      h_chain[i] = (uint16_t)(((e >> 16) & 1u) ? init : next);
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t en = h_entries32[i];
+      const uint32_t next = ((en & 0x7fu) * (uint32_t)HW + ((en >> 7) & 0x7fu)) * CAMPX_N_ACTIONS;
+      h_chain[i] = (uint16_t)(((en >> 16) & 1u) ? init : next);
     }
   }
   CAMPX_TRY(hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s));

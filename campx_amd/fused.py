@@ -106,7 +106,7 @@ class FusedGame(object):
     self._spec_host = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
                                        dtype=torch.uint8)
     self._spec_dev = self._spec_host.to(dev)
-    # Two-mover games: the (cell, cell, action) table of the update pass.
+    # Games with two to four movers: the (cell, ..., cell, action) table of the update pass.
     self._pair_table = None
     n_pair = int(_hip.lib.campx_pair_table_bytes(ctypes.byref(self.spec)))
     if COMPILE_TABLE and n_pair > 0:

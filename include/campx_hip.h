@@ -158,7 +158,7 @@ typedef struct CampxState {
   uint8_t* done;   /* [B] game-over latch (campx/engine.py:285); a latched environment is
                       rebuilt from the art before its next action is applied */
   float* ret;      /* [B] return accumulated since the last rebuild, or NULL */
-  const void* pair_table; /* optional, games with exactly two moving things: the device table
+  const void* pair_table; /* optional, games with two to four moving things: the device table
                       campx_pair_table_build() filled; lets the two-kernel path look the
                       update pass up instead of interpreting the rules.  NULL = interpret. */
 } CampxState;
@@ -224,22 +224,27 @@ int32_t campx_spec_validate(const CampxSpec* spec_host);
 int32_t campx_spec_compile(CampxSpec* spec_host, void* stream);
 
 /*
- * Games with exactly TWO moving things: the update pass of a frame is a function of
- * (cell of thing 0, cell of thing 1, action).  campx_pair_table_bytes() is the size of
- * its table for this game (0 when n_dyn != 2 or the table would exceed 1 MiB);
- * campx_pair_table_build() fills caller-allocated DEVICE memory of that size by
- * running the rule interpreter kernel over every (cell, cell, action) triple, the same
- * way campx_spec_compile() does for one-mover games (set-up time only: scratch
- * allocation + stream synchronisation inside).  Returns CAMPX_ESPEC when a frame of
- * this game can pay more than 256 distinct rewards (the table indexes a reward list).
- * Layout: 256 floats (reward list), then n = rows*cols * rows*cols * 5 uint32 entries,
- * index ((cell0 * rows*cols) + cell1) * 5 + action:
+ * Games with TWO TO FOUR moving things: the update pass of a frame is a function of
+ * (cell of thing 0, ..., cell of thing K-1, action).  campx_pair_table_bytes() is the
+ * size of its table for this game (0 when n_dyn < 2, or the table would exceed 1 MiB for
+ * two movers / 512 MiB for three and four); campx_pair_table_build() fills
+ * caller-allocated DEVICE memory of that size by running the rule interpreter kernel over
+ * every (cell, ..., cell, action) tuple, the same way campx_spec_compile() does for
+ * one-mover games (set-up time only: scratch allocation + stream synchronisation inside;
+ * about 19 bytes of host and of device scratch per tuple).  Returns CAMPX_ESPEC when a
+ * frame of this game can pay more than 256 distinct rewards (the table indexes a reward
+ * list).  Layout: 256 floats (reward list), then n = (rows*cols)^K * 5 entries, index
+ * ((cell0 * rows*cols + cell1) * rows*cols + ...) * 5 + action.
+ * Two movers, uint32 entries:
  *   bits 0-6 cell of thing 0 after the frame, 7-13 cell of thing 1, 14/15 whether
  *   thing 0 / 1 is the character its cell shows, 16 done, 17-18 perf + 1,
  *   19-26 index into the reward list;
  * then, when n <= 65535, n uint16 "chain" entries (padded to 16 bytes): the index
  * (cell0' * rows*cols + cell1') * 5 the next frame's lookup starts from, the art's cells
  * when the frame ended the episode - the only thing the frame-to-frame dependency needs.
+ * Three and four movers, uint64 entries:
+ *   bits 7d..7d+6 cell of thing d after the frame, 28+d whether it is the character its
+ *   cell shows, 32 done, 33-34 perf + 1, 35-42 index into the reward list.
  */
 int64_t campx_pair_table_bytes(const CampxSpec* spec_host);
 int32_t campx_pair_table_build(const CampxSpec* spec_host, const CampxSpec* spec_dev,

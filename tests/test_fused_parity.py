@@ -49,8 +49,9 @@ def _fused(name, batch):
   from campx_amd import fused
   game = FUSED_GAMES[name](batch=batch, device='cuda')
   first = game.its_showtime()
-  tabulated = game.fused.n_dyn <= 2      # (cell, action) or (cell, cell, action) tables
-  assert game.fused.uses_table == (fused.COMPILE_TABLE and tabulated)
+  # every library game fits a table: (cell, action), (cell, cell, action) or, for three and
+  # four movers, the global (cell, ..., action) table
+  assert game.fused.uses_table == fused.COMPILE_TABLE
   return game, first
 
 

@@ -29,7 +29,12 @@ def per_dispatch(db, counter):
 
 
 def main(specs):
-  table = {'_comment': __doc__.split('\n\n', 2)[2].strip().replace('\n', ' ')}
+  path = os.path.join(REPO, 'profiles', 'r02_traffic.json')
+  table = {}
+  if os.path.exists(path):          # configurations not named on the command line are kept
+    with open(path) as f:
+      table = json.load(f)
+  table['_comment'] = __doc__.split('\n\n', 2)[2].strip().replace('\n', ' ')
   for spec in specs:
     d, game, batch, frames = spec.split(':')
     w = per_dispatch(os.path.join(d, 'pmc_write_results.db'), 'WRITE_SIZE')
@@ -42,7 +47,7 @@ def main(specs):
         'kernels': ' + '.join(sorted(short)), 'write_bytes': wb, 'fetch_bytes': fb,
         'traffic_bytes': wb + fb,
         'source': 'profiles/r02_{}_rocprofv3.txt'.format(game)}
-  with open(os.path.join(REPO, 'profiles', 'r02_traffic.json'), 'w') as out:
+  with open(path, 'w') as out:
     json.dump(table, out, indent=1)
   print(json.dumps(table, indent=1))
 
