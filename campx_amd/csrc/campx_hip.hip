@@ -248,6 +248,47 @@ __device__ __forceinline__ void fill_image(int8_t* img, int n_rows, int R, const
   }
 }
 
+// The one-frame kernels' version of fill_image: kN 16-byte loads per lane issued back to
+// back (no branch between them: every offset of the cyclically continued row is a valid
+// address), landed in LDS later, so that a launch waits for ONE round trip per kN KiB of
+// image and the table lookup can be issued while they are in flight.  `k` is the offset
+// inside the row of this lane's next chunk and advances as the chunks are issued.
+template <int kN>
+__device__ __forceinline__ void fill_issue(u32x4 (&v)[kN], const int8_t* rot, int R, int& k) {
+  const int pitch = ((R + 15) & ~15) + 16;
+  const int step = (kWave * 16) % R;
+#pragma unroll
+  for (int j = 0; j < kN; ++j) {
+    v[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+    k += step;
+    k = k >= R ? k - R : k;
+  }
+}
+
+template <int kN>
+__device__ __forceinline__ void fill_land(const u32x4 (&v)[kN], int8_t* img, int total, int off0,
+                                          int lane) {
+#pragma unroll
+  for (int j = 0; j < kN; ++j) {
+    const int o = off0 + (j * kWave + lane) * 16;   // total = 64 rows: a multiple of 16
+    if (o < total) *reinterpret_cast<u32x4*>(img + o) = v[j];
+  }
+}
+
+// What is left of an image after the first kN chunks per lane.
+template <int kN>
+__device__ __forceinline__ void fill_rest(int8_t* img, int total, int R, const int8_t* rot, int& k,
+                                          int lane) {
+  for (int off0 = kN * kWave * 16; off0 < total; off0 += kN * kWave * 16) {
+    u32x4 v[kN];
+    fill_issue<kN>(v, rot, R, k);
+    fill_land<kN>(v, img, total, off0, lane);
+  }
+}
+
+constexpr int kStepObsLoads = 12;   // 12 KiB of a wave's observation image per round trip
+constexpr int kStepBoardLoads = 4;
+
 // Copy this lane's next actions (frames t .. t+kChunk-1) into LDS.  All loads of a
 // group of 16 are issued before any is used; rows past the end are clamped so that
 // there is no branch between the loads (a branch makes hipcc wait for each load
@@ -750,15 +791,37 @@ __global__ __launch_bounds__(kWave) void step_table_kernel(
       if (st.ret) ret = st.ret[env];
     }
   }
-  fill_image(obs_img, kWave, LHW, spec->rot_obs, true, nullptr, lane);
-  if (kBoard) fill_image(board_img, kWave, HW, spec->rot_board, true, nullptr, lane);
+  // ONE round trip: state and action (above), the whole transition table (5 KiB at most,
+  // copied to LDS so that the lookup which depends on the state is an LDS read rather than
+  // a second trip) and the scenery image, all in flight at once.
+  __shared__ __attribute__((aligned(16))) CampxTransition lds_table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+  constexpr int kTableLoads = (int)(sizeof(lds_table) / (16 * kWave));
+  static_assert(sizeof(lds_table) == (size_t)kTableLoads * 16 * kWave, "whole 16-byte chunks per lane");
+  u32x4 v_table[kTableLoads];
+#pragma unroll
+  for (int j = 0; j < kTableLoads; ++j)
+    v_table[j] = reinterpret_cast<const u32x4*>(spec->table)[j * kWave + lane];
+  u32x4 v_obs[kStepObsLoads], v_board[kStepBoardLoads];
+  int k_obs = (lane * 16) % LHW, k_board = (lane * 16) % HW;
+  fill_issue<kStepObsLoads>(v_obs, spec->rot_obs, LHW, k_obs);
+  if (kBoard) fill_issue<kStepBoardLoads>(v_board, spec->rot_board, HW, k_board);
 
   const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
   a = ((unsigned)a > 4u) ? 4 : a;
   // a finished episode is rebuilt from the art before its next action
   int cell = over ? mp.row0 * W + mp.col0 : r * W + c;
   ret = over ? 0.0f : ret;
-  const CampxTransition tr = spec->table[cell * CAMPX_N_ACTIONS + a];
+#pragma unroll
+  for (int j = 0; j < kTableLoads; ++j)
+    reinterpret_cast<u32x4*>(lds_table)[j * kWave + lane] = v_table[j];
+  // (one wave: LDS operations complete in order, no barrier needed)
+  const CampxTransition tr = lds_table[cell * CAMPX_N_ACTIONS + a];
+  fill_land<kStepObsLoads>(v_obs, obs_img, kWave * LHW, 0, lane);
+  fill_rest<kStepObsLoads>(obs_img, kWave * LHW, LHW, spec->rot_obs, k_obs, lane);
+  if (kBoard) {
+    fill_land<kStepBoardLoads>(v_board, board_img, kWave * HW, 0, lane);
+    fill_rest<kStepBoardLoads>(board_img, kWave * HW, HW, spec->rot_board, k_board, lane);
+  }
   cell = tr.next_cell;
   ret += tr.reward;
   if (!(tr.paint & 0x80u)) {   // the mover shows at its cell
@@ -815,8 +878,10 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
       if (st.ret) ret = st.ret[env];
     }
   }
-  fill_image(obs_img, kWave, LHW, spec->rot_obs, true, nullptr, lane);
-  if (kBoard) fill_image(board_img, kWave, HW, spec->rot_board, true, nullptr, lane);
+  u32x4 v_obs[kStepObsLoads], v_board[kStepBoardLoads];
+  int k_obs = (lane * 16) % LHW, k_board = (lane * 16) % HW;
+  fill_issue<kStepObsLoads>(v_obs, spec->rot_obs, LHW, k_obs);
+  if (kBoard) fill_issue<kStepBoardLoads>(v_board, spec->rot_board, HW, k_board);
 
   const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
   a = ((unsigned)a > 4u) ? 4 : a;
@@ -826,6 +891,12 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
     ret = 0.0f;
   }
   const uint32_t e = g_entries[pair_index(c0, c1, HW) + (uint32_t)a];
+  fill_land<kStepObsLoads>(v_obs, obs_img, kWave * LHW, 0, lane);
+  fill_rest<kStepObsLoads>(obs_img, kWave * LHW, LHW, spec->rot_obs, k_obs, lane);
+  if (kBoard) {
+    fill_land<kStepBoardLoads>(v_board, board_img, kWave * HW, 0, lane);
+    fill_rest<kStepBoardLoads>(board_img, kWave * HW, HW, spec->rot_board, k_board, lane);
+  }
   c0 = e & 0x7fu;
   c1 = (e >> 7) & 0x7fu;
   const float reward = g_rewards[(e >> 19) & 0xffu];
