@@ -1933,6 +1933,15 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
     *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
   }
 
+  // rp.dyn_off / dyn_char of a lane-varying thing: a chain of selects over the K kernel
+  // arguments (indexing the array made hipcc fetch it with a vector load from the kernarg
+  // segment and wait for it inside the patch branch: one more memory trip per wave)
+  auto of_thing = [&](const int32_t (&arr)[CAMPX_MAX_DYN], int d) {
+    int v = arr[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) v = (d == k) ? arr[k] : v;
+    return v;
+  };
   auto apply = [&](int sidx, uint32_t e) {
     const int r = sidx / P, p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
@@ -1941,9 +1950,9 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
     int8_t val;
     if (kBoard) {
       byte = cell;
-      val = (int8_t)rp.dyn_char[d];
+      val = (int8_t)of_thing(rp.dyn_char, d);
     } else {
-      byte = (p & 1) ? rp.dyn_off[d] + cell : (int)scen_off[cell];
+      byte = (p & 1) ? of_thing(rp.dyn_off, d) + cell : (int)scen_off[cell];
       val = (int8_t)(p & 1);
     }
     // offsets inside a frame fit 32 bits (split_ok); a patch left of the window wraps to a
