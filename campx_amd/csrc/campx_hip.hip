@@ -1936,10 +1936,12 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   // rp.dyn_off / dyn_char of a lane-varying thing: a chain of selects over the K kernel
   // arguments (indexing the array made hipcc fetch it with a vector load from the kernarg
   // segment and wait for it inside the patch branch: one more memory trip per wave)
+  // (readfirstlane makes each argument an opaque scalar: from three things up the
+  // optimiser otherwise turns the select chain back into the indexed load)
   auto of_thing = [&](const int32_t (&arr)[CAMPX_MAX_DYN], int d) {
-    int v = arr[0];
+    int v = __builtin_amdgcn_readfirstlane(arr[0]);
 #pragma unroll
-    for (int k = 1; k < K; ++k) v = (d == k) ? arr[k] : v;
+    for (int k = 1; k < K; ++k) v = (d == k) ? __builtin_amdgcn_readfirstlane(arr[k]) : v;
     return v;
   };
   auto apply = [&](int sidx, uint32_t e) {
