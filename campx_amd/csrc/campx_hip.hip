@@ -2027,34 +2027,59 @@ __device__ __forceinline__ int shape_cell(uint32_t packed, int orow, int ocol, i
   return r * W + c;
 }
 
+// Per-action effect of a frame on all things at once (built once per workgroup): the
+// offsets of up to eight things are one byte each in two 32-bit words per coordinate, so
+// a frame's whole update pass is four SWAR add-and-wrap on the scalar unit.
+struct ShapeAction {
+  uint32_t drow[2], dcol[2];  // byte k of word k / 4: thing k's offset change, 0 .. rows-1 / cols-1
+  float reward;               // summed in update-schedule order (plot.py:208-211: r + total)
+  uint32_t flags;             // bit 0: somebody terminates the episode; bit 1: somebody rewards
+};
+
+// What the kernel needs of a CampxShapeSpec besides its cell lists, by value in the
+// kernel arguments (scalar loads; campx_shape_rollout_launch builds it on the host).
+struct ShapeParams {
+  int32_t rows, cols, n_layers, n_things, first_drape, n_list;
+  uint32_t thing[CAMPX_SHAPE_MAX_THINGS];  // cell_begin | n_cells << 11 | layer << 23 | visible << 28
+  ShapeAction act[CAMPX_N_ACTIONS];
+  uint32_t layer_char[CAMPX_MAX_LAYERS / 4];
+};
+
+// bytes of r, d < n <= 127: (r + d) mod n per byte
+__device__ __forceinline__ uint32_t swar_add_wrap(uint32_t r, uint32_t d, uint32_t n) {
+  const uint32_t t = r + d;
+  const uint32_t ge = (t + (0x80u - n) * 0x01010101u) & 0x80808080u;  // bit 7: byte >= n
+  return t - (ge >> 7) * n;
+}
+
+#ifndef CAMPX_SHAPE_MINWAVES
+#define CAMPX_SHAPE_MINWAVES 1
+#endif
+
 template <bool kBoard>
-__global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
-    const CampxShapeSpec* __restrict__ spec, CampxState st, int8_t* __restrict__ backdrop_state,
-    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, int32_t emit_first) {
+__global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void shape_rollout_kernel(
+    ShapeParams sp, const CampxShapeSpec* __restrict__ spec, CampxState st,
+    int8_t* __restrict__ backdrop_state, const int8_t* __restrict__ actions, CampxOutputs out,
+    int64_t B, int32_t T, int32_t reset_first, int32_t emit_first) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ __attribute__((aligned(16))) uint8_t lds_board[kShapeWaves][CAMPX_SHAPE_MAX_CELLS];
   __shared__ uint16_t lds_cells[CAMPX_SHAPE_MAX_LIST];  // the things' shapes, once per workgroup
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  // (making `wave` provably uniform with readfirstlane moves this kernel's addressing to
-  // SGPRs, of which it then needs all 106: measured 4.03 against 3.67 ms)
+  __shared__ uint32_t lds_char[CAMPX_MAX_LAYERS / 4];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t env = (int64_t)blockIdx.x * kShapeWaves + wave;
-  {
-    const CampxShapeThing& last = spec->things[spec->n_things - 1];
-    const int n_list = last.cell_begin + last.n_cells;
-    for (int i = threadIdx.x; i < n_list; i += kShapeWaves * kWave) lds_cells[i] = spec->cells[i];
-  }
+  const int H = sp.rows, W = sp.cols, HW = H * W, L = sp.n_layers, N = sp.n_things;
+  for (int i = threadIdx.x; i < sp.n_list; i += kShapeWaves * kWave) lds_cells[i] = spec->cells[i];
+  if (kBoard && threadIdx.x < CAMPX_MAX_LAYERS / 4) lds_char[threadIdx.x] = sp.layer_char[threadIdx.x];
   __syncthreads();       // the only barrier: every wave of the workgroup is still here
   if (env >= B) return;  // wave-uniform; no barriers below
-  const int H = spec->rows, W = spec->cols, HW = H * W, L = spec->n_layers, N = spec->n_things;
   const int64_t LHW = (int64_t)L * HW;
   uint8_t* bd = lds_backdrop[wave];
   uint8_t* board = lds_board[wave];
   const bool quads = (HW & 3) == 0;
+  const int first_drape = sp.first_drape;
 
-  int orow[CAMPX_SHAPE_MAX_THINGS], ocol[CAMPX_SHAPE_MAX_THINGS];
-#pragma unroll
-  for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k) orow[k] = ocol[k] = 0;
+  uint32_t orow[2] = {0u, 0u}, ocol[2] = {0u, 0u};  // byte k of word k / 4: thing k's cyclic offset
   int over = 0;
   float ret = 0.0f;
   const bool fresh = reset_first != 0;
@@ -2062,8 +2087,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
 #pragma unroll
     for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
       if (k < N) {
-        orow[k] = st.pos[(int64_t)(2 * k) * B + env];
-        ocol[k] = st.pos[(int64_t)(2 * k + 1) * B + env];
+        orow[k >> 2] |= (uint32_t)(uint8_t)st.pos[(int64_t)(2 * k) * B + env] << (8 * (k & 3));
+        ocol[k >> 2] |= (uint32_t)(uint8_t)st.pos[(int64_t)(2 * k + 1) * B + env] << (8 * (k & 3));
       }
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
@@ -2072,54 +2097,70 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
     bd[i] = (fresh || !backdrop_state) ? spec->backdrop[i] : (uint8_t)backdrop_state[env * HW + i];
 
   auto rebuild = [&]() {  // a fresh make_game() + its_showtime()
-#pragma unroll
-    for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k) orow[k] = ocol[k] = 0;
+    orow[0] = orow[1] = ocol[0] = ocol[1] = 0u;
     for (int i = lane; i < HW; i += kWave) bd[i] = spec->backdrop[i];
   };
 
   auto paint_and_emit = [&](int8_t* obs_dst, int8_t* board_dst) {
-    // sprites behind the first drape paint into the backdrop itself (rendering.py:128,150)
-    for (int z = 0; z < spec->first_drape; ++z) {
-      const CampxShapeThing& th = spec->things[z];
-      if (!th.visible) continue;
-      for (int i = lane; i < th.n_cells; i += kWave)
-        bd[shape_cell(lds_cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
-    }
-    if (quads)
-      for (int i = lane; i < HW / 4; i += kWave)
-        reinterpret_cast<uint32_t*>(board)[i] = reinterpret_cast<const uint32_t*>(bd)[i];
-    else
-      for (int i = lane; i < HW; i += kWave) board[i] = bd[i];
-    for (int z = spec->first_drape; z < N; ++z) {
-      const CampxShapeThing& th = spec->things[z];
-      if (!th.visible) continue;
-      for (int i = lane; i < th.n_cells; i += kWave)
-        board[shape_cell(lds_cells[th.cell_begin + i], orow[z], ocol[z], H, W)] = (uint8_t)th.layer;
-    }
-    // layers by equality (rendering.py:204-215)
-    if (quads) {
-      for (int q = lane; q < HW / 4; q += kWave) {
-        const uint32_t b4 = reinterpret_cast<const uint32_t*>(board)[q];
-        for (int l = 0; l < L; ++l) {
-          const uint32_t x = b4 ^ ((uint32_t)l * 0x01010101u);  // bytes < 0x80: zero iff equal
-          const uint32_t nz = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) & 0x80808080u;
-          *reinterpret_cast<uint32_t*>(obs_dst + (int64_t)l * HW + 4 * q) = (nz ^ 0x80808080u) >> 7;
+    // Things back to front.  Sprites behind the first drape paint into the backdrop itself
+    // (rendering.py:128,150); the frame's board starts as a copy of it.
+    for (int z = 0; z < N; ++z) {   // everything about z is scalar
+      if (z == first_drape)
+        for (int i = lane; i * 16 < HW; i += kWave)   // (the arrays are whole 16-byte chunks)
+          reinterpret_cast<u32x4*>(board)[i] = reinterpret_cast<const u32x4*>(bd)[i];
+      const uint32_t th = sp.thing[z];
+      if ((th >> 28) & 1u) {
+        const int begin = (int)(th & 0x7ffu), n = (int)((th >> 11) & 0xfffu);
+        const uint8_t layer = (uint8_t)((th >> 23) & 0x1fu);
+        const int sh = 8 * (z & 3);
+        const int dr = (int)(((z < 4 ? orow[0] : orow[1]) >> sh) & 0xffu);
+        const int dc = (int)(((z < 4 ? ocol[0] : ocol[1]) >> sh) & 0xffu);
+        uint8_t* target = z < first_drape ? bd : board;
+        for (int i = lane; i < n; i += kWave) {
+          const uint32_t packed = lds_cells[begin + i];
+          int r = (int)(packed >> 8) + dr, c = (int)(packed & 0xffu) + dc;
+          r = r >= H ? r - H : r;
+          c = c >= W ? c - W : c;
+          target[r * W + c] = layer;
         }
-        if (kBoard)
-          *reinterpret_cast<uint32_t*>(board_dst + 4 * q) =
-              (uint32_t)spec->layer_char[b4 & 0xffu] | ((uint32_t)spec->layer_char[(b4 >> 8) & 0xffu] << 8) |
-              ((uint32_t)spec->layer_char[(b4 >> 16) & 0xffu] << 16) | ((uint32_t)spec->layer_char[b4 >> 24] << 24);
+      }
+    }
+    // layers by equality (rendering.py:204-215): eight cells per lane, one 8-byte store per
+    // layer plane.  A board of 8k + 4 cells: the last lane takes the last eight cells, four of
+    // which its neighbour also writes (same values), so every lane runs the same code.
+    if (quads && HW >= 8) {
+      for (int q = lane; 8 * q < HW; q += kWave) {
+        const uint32_t at = (uint32_t)(8 * q + 8 <= HW ? 8 * q : HW - 8);   // a multiple of 4
+        const uint32_t b0 = *reinterpret_cast<const uint32_t*>(board + at);
+        const uint32_t b1 = *reinterpret_cast<const uint32_t*>(board + at + 4);
+        int8_t* plane = obs_dst;   // uniform: the stores take it as their scalar base
+        uint32_t lc = 0u;
+        for (int l = 0; l < L; ++l) {
+          // bytes < 0x80: 0x80 - (b ^ l) has bit 7 set iff they are equal
+          const uint32_t e0 = ((0x80808080u - (b0 ^ lc)) & 0x80808080u) >> 7;
+          const uint32_t e1 = ((0x80808080u - (b1 ^ lc)) & 0x80808080u) >> 7;
+          *reinterpret_cast<uint2*>(plane + at) = make_uint2(e0, e1);
+          plane += HW;
+          lc += 0x01010101u;
+        }
+        if (kBoard) {
+          const uint8_t* ch = reinterpret_cast<const uint8_t*>(lds_char);
+          auto chars = [&](uint32_t b4) {
+            return (uint32_t)ch[b4 & 0xffu] | ((uint32_t)ch[(b4 >> 8) & 0xffu] << 8) |
+                   ((uint32_t)ch[(b4 >> 16) & 0xffu] << 16) | ((uint32_t)ch[b4 >> 24] << 24);
+          };
+          *reinterpret_cast<uint2*>(board_dst + at) = make_uint2(chars(b0), chars(b1));
+        }
       }
     } else {
       for (int i = lane; i < HW; i += kWave) {
         const int b = board[i];
         for (int l = 0; l < L; ++l) obs_dst[(int64_t)l * HW + i] = (int8_t)(b == l);
-        if (kBoard) board_dst[i] = (int8_t)spec->layer_char[b];
+        if (kBoard) board_dst[i] = (int8_t)reinterpret_cast<const uint8_t*>(lds_char)[b];
       }
     }
   };
 
-  if (emit_first) paint_and_emit(out.obs + env * LHW, kBoard ? out.board + env * HW : nullptr);
 
   // Actions: lane j holds the action of frame (chunk start + j), one load per 64 frames,
   // fetched a chunk ahead; a frame reads its own with a (wave-uniform) readlane, so the
@@ -2130,52 +2171,56 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
   };
   int act_now = T > 0 ? fetch(0) : 4, act_next = 4;
   int bad = 0;
-  for (int t = 0; t < T; ++t) {
-    if ((t & (kWave - 1)) == 0) {
+  int reward_buf = 0;
+  uint64_t over_mask = 0;
+  // frame -1 (emit_first): the its_showtime() observation, no update pass, written where
+  // frame 0 goes (one call site for the paint-and-emit code)
+  for (int t = emit_first ? -1 : 0; t < T; ++t) {
+    const bool showtime = t < 0;
+    if (!showtime && (t & (kWave - 1)) == 0) {
       if (t) act_now = act_next;
       act_next = fetch(t + kWave);
     }
-    const int a_raw = __builtin_amdgcn_readlane(act_now, t & (kWave - 1));  // wave-uniform
+    const int a_raw = showtime ? -1 : __builtin_amdgcn_readlane(act_now, t & (kWave - 1));  // wave-uniform
     const bool valid = (unsigned)a_raw < (unsigned)CAMPX_N_ACTIONS;
-    bad += valid ? 0 : 1;
-    if (over) {
+    bad += (valid || showtime) ? 0 : 1;
+    if (over && !showtime) {
       rebuild();
       over = 0;
       ret = 0.0f;
     }
-    float reward = 0.0f, discount = 1.0f;
-    bool first = true;
+    float reward = __builtin_nanf("");   // an id outside 0..4 moves nothing
     if (valid) {
-      for (int u = 0; u < N; ++u) {  // update-schedule order (engine.py:200-204)
-        const int k = spec->update_order[u];
-        const CampxShapeThing& th = spec->things[k];
-        if ((th.terminate_mask >> a_raw) & 1) {  // plot.py:183-184
-          over = 1;
-          discount = 0.0f;
-        }
-        const int dr = th.drow[a_raw], dc = th.dcol[a_raw];
-#pragma unroll
-        for (int j = 0; j < CAMPX_SHAPE_MAX_THINGS; ++j)
-          if (j == k) {
-            int r = orow[j] + dr, c = ocol[j] + dc;
-            orow[j] = r >= H ? r - H : r;
-            ocol[j] = c >= W ? c - W : c;
-          }
-        if ((th.has_reward_mask >> a_raw) & 1) {  // plot.py:208-211: r + total
-          reward = first ? th.reward[a_raw] : th.reward[a_raw] + reward;
-          first = false;
+      const ShapeAction& e = sp.act[a_raw];   // kernel argument, uniform index: scalar loads
+      orow[0] = swar_add_wrap(orow[0], e.drow[0], (uint32_t)H);
+      ocol[0] = swar_add_wrap(ocol[0], e.dcol[0], (uint32_t)W);
+      if (N > 4) {
+        orow[1] = swar_add_wrap(orow[1], e.drow[1], (uint32_t)H);
+        ocol[1] = swar_add_wrap(ocol[1], e.dcol[1], (uint32_t)W);
+      }
+      reward = e.reward;
+      if (e.flags & 1u) over = 1;  // plot.py:183-184 (discount 0 on that frame)
+    }
+    if (!showtime) ret += reward;
+    const int64_t slot = showtime ? 0 : t;
+    paint_and_emit(out.obs + slot * out.obs_t_stride + env * LHW,
+                   kBoard ? out.board + slot * out.board_t_stride + env * HW : nullptr);
+    if (!showtime) {
+      // the frame's scalars wait in lane (t mod 64) of a register / bit of a scalar mask and
+      // go out once per 64 frames, one store instruction per array
+      const int slot_lane = t & (kWave - 1);
+      reward_buf = lane == slot_lane ? (int)__float_as_uint(reward) : reward_buf;
+      over_mask = slot_lane == 0 ? (uint64_t)over : over_mask | ((uint64_t)over << slot_lane);
+      if (slot_lane == kWave - 1 || t == T - 1) {
+        const int t0 = t - slot_lane;
+        if (lane <= slot_lane) {
+          const int64_t at = (int64_t)(t0 + lane) * B + env;
+          const uint32_t ended = (uint32_t)(over_mask >> lane) & 1u;
+          if (out.reward) out.reward[at] = __uint_as_float((uint32_t)reward_buf);
+          if (out.discount) out.discount[at] = ended ? 0.0f : 1.0f;
+          if (out.done) out.done[at] = (uint8_t)ended;
         }
       }
-    }
-    if (first) reward = __builtin_nanf("");  // nobody called add_reward: None
-    ret += reward;
-    paint_and_emit(out.obs + (int64_t)t * out.obs_t_stride + env * LHW,
-                   kBoard ? out.board + (int64_t)t * out.board_t_stride + env * HW : nullptr);
-    if (lane == 0) {
-      const int64_t at = (int64_t)t * B + env;
-      if (out.reward) out.reward[at] = reward;
-      if (out.discount) out.discount[at] = discount;
-      if (out.done) out.done[at] = (uint8_t)over;
     }
   }
 
@@ -2183,8 +2228,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave) void shape_rollout_kernel(
 #pragma unroll
     for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
       if (k < N) {
-        st.pos[(int64_t)(2 * k) * B + env] = (int8_t)orow[k];
-        st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)ocol[k];
+        st.pos[(int64_t)(2 * k) * B + env] = (int8_t)((orow[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)((ocol[k >> 2] >> (8 * (k & 3))) & 0xffu);
       }
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
@@ -2644,6 +2689,47 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   }
 }
 
+// The update pass of every action (engine.py:200-204: things in update-schedule order,
+// rewards summed as r + total, plot.py:208-211) and the things' paint parameters, packed
+// for shape_rollout_kernel.  `s` has passed campx_shape_spec_validate.
+ShapeParams make_shape_params(const CampxShapeSpec& s) {
+  ShapeParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.rows = s.rows;
+  sp.cols = s.cols;
+  sp.n_layers = s.n_layers;
+  sp.n_things = s.n_things;
+  sp.first_drape = s.first_drape;
+  const CampxShapeThing& last = s.things[s.n_things - 1];
+  sp.n_list = last.cell_begin + last.n_cells;
+  for (int k = 0; k < s.n_things; ++k) {
+    const CampxShapeThing& th = s.things[k];
+    sp.thing[k] = (th.n_cells ? (uint32_t)th.cell_begin : 0u) | ((uint32_t)th.n_cells << 11) |
+                  ((uint32_t)th.layer << 23) | ((th.visible ? 1u : 0u) << 28);
+  }
+  for (int a = 0; a < CAMPX_N_ACTIONS; ++a) {
+    ShapeAction& e = sp.act[a];
+    bool first = true;
+    for (int u = 0; u < s.n_things; ++u) {
+      const int k = s.update_order[u];
+      const CampxShapeThing& th = s.things[k];
+      if ((th.terminate_mask >> a) & 1) e.flags |= 1u;  // plot.py:183-184
+      e.drow[k >> 2] |= (uint32_t)(uint8_t)th.drow[a] << (8 * (k & 3));
+      e.dcol[k >> 2] |= (uint32_t)(uint8_t)th.dcol[a] << (8 * (k & 3));
+      if ((th.has_reward_mask >> a) & 1) {
+        e.reward = first ? th.reward[a] : th.reward[a] + e.reward;
+        first = false;
+      }
+    }
+    if (first)
+      e.reward = __builtin_nanf("");  // nobody called add_reward: None
+    else
+      e.flags |= 2u;
+  }
+  memcpy(sp.layer_char, s.layer_char, CAMPX_MAX_LAYERS);
+  return sp;
+}
+
 }  // namespace
 
 extern "C" {
@@ -3039,7 +3125,8 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
   if (out.obs_format != CAMPX_OBS_INT8 || out.perf || out.trace) return CAMPX_EINVAL;
-  if (reinterpret_cast<uintptr_t>(out.obs) & 3) return CAMPX_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(out.obs) | reinterpret_cast<uintptr_t>(out.board)) & 3)
+    return CAMPX_EINVAL;
   const int32_t v = campx_shape_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
   bool trails = false;
@@ -3047,12 +3134,13 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
   if (trails && !backdrop_state) return CAMPX_EINVAL;
   const dim3 grid((unsigned)((B + kShapeWaves - 1) / kShapeWaves)), block(kShapeWaves * kWave);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const ShapeParams sp = make_shape_params(*spec_host);
   if (out.board)
-    hipLaunchKernelGGL(shape_rollout_kernel<true>, grid, block, 0, s, spec_dev, st, backdrop_state,
-                       actions, out, B, T, reset_first, emit_first);
+    hipLaunchKernelGGL(shape_rollout_kernel<true>, grid, block, 0, s, sp, spec_dev, st,
+                       backdrop_state, actions, out, B, T, reset_first, emit_first);
   else
-    hipLaunchKernelGGL(shape_rollout_kernel<false>, grid, block, 0, s, spec_dev, st, backdrop_state,
-                       actions, out, B, T, reset_first, emit_first);
+    hipLaunchKernelGGL(shape_rollout_kernel<false>, grid, block, 0, s, sp, spec_dev, st,
+                       backdrop_state, actions, out, B, T, reset_first, emit_first);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }

@@ -14,13 +14,16 @@ for B in (4096, 32768):
   for _ in range(3):
     game.rollout(acts, out=bufs, reset_first=True)
   torch.cuda.synchronize()
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  e0.record()
-  n = 10
-  for _ in range(n):
+  n = 20
+  ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+  ev[0].record()
+  for i in range(n):
     game.rollout(acts, out=bufs, reset_first=True)
-  e1.record(); torch.cuda.synchronize()
-  ms = e0.elapsed_time(e1) / n
+    ev[i + 1].record()
+  torch.cuda.synchronize()
+  per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+  ms = ev[0].elapsed_time(ev[n]) / n
+  print('  per launch: min %.3f median %.3f max %.3f ms' % (per[0], per[n // 2], per[-1]))
   L, H, W = game.fused.n_layers, game.fused.rows, game.fused.cols
   gb = B * T * (L * H * W + 9) / 1e9
   print('hello_world B=%d T=%d: %.3f ms per launch, %.2e env-steps/s, %.2f TB/s of observations'
