@@ -1582,8 +1582,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
 // every environment in flight at once: 8-frame groups keep the ring small enough for two
 // 256-environment workgroups per CU.
 struct TupleParams {
-  int32_t rows, cols, n_dyn;
-  int32_t row0[CAMPX_MAX_DYN], col0[CAMPX_MAX_DYN];
+  int32_t rows, cols, n_dyn, n_layers;
+  int32_t row0[CAMPX_MAX_DYN], col0[CAMPX_MAX_DYN], dyn_layer[CAMPX_MAX_DYN];
 };
 
 constexpr int kTupleGroup = 8;
@@ -1804,6 +1804,93 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
+  report_bad_actions(out, bad);
+}
+
+// Engine.play() for three- and four-mover games with their table: the one-frame kernel of
+// step_pair_kernel over the 64-bit entries.
+template <int K, bool kBoard>
+__global__ __launch_bounds__(kWave) void step_tuple_kernel(
+    TupleParams tp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t reset_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const int lane = threadIdx.x;
+  const int W = tp.cols, HW = tp.rows * tp.cols, LHW = tp.n_layers * HW;
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
+  const bool live = env < B;
+  const int n_live = (B - env0 < kWave) ? (int)(B - env0) : kWave;
+  int8_t* obs_img = lds;
+  int8_t* board_img = lds + ((kWave * LHW + 15) & ~15);
+  const float* g_rewards = static_cast<const float*>(st.pair_table);
+  const uint64_t* g_entries = reinterpret_cast<const uint64_t*>(g_rewards + 256);
+
+  uint32_t init = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) init |= (uint32_t)(tp.row0[k] * W + tp.col0[k]) << (7 * k);
+  uint32_t cells = init;
+  int over = 0, a = 4;
+  float ret = 0.0f;
+  if (live) {
+    a = actions[env];
+    if (!reset_first) {
+      cells = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        cells |= (uint32_t)((int)st.pos[(int64_t)(2 * k) * B + env] * W +
+                            (int)st.pos[(int64_t)(2 * k + 1) * B + env]) << (7 * k);
+      over = st.done[env];
+      if (st.ret) ret = st.ret[env];
+    }
+  }
+  u32x4 v_obs[kStepObsLoads], v_board[kStepBoardLoads];
+  int k_obs = (lane * 16) % LHW, k_board = (lane * 16) % HW;
+  fill_issue<kStepObsLoads>(v_obs, spec->rot_obs, LHW, k_obs);
+  if (kBoard) fill_issue<kStepBoardLoads>(v_board, spec->rot_board, HW, k_board);
+
+  const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
+  a = ((unsigned)a > 4u) ? 4 : a;
+  if (over) {  // rebuilt from the art before its next action
+    cells = init;
+    ret = 0.0f;
+  }
+  const uint64_t e = g_entries[tuple_index<K>(cells, (uint32_t)HW) + (uint32_t)a];
+  fill_land<kStepObsLoads>(v_obs, obs_img, kWave * LHW, 0, lane);
+  fill_rest<kStepObsLoads>(obs_img, kWave * LHW, LHW, spec->rot_obs, k_obs, lane);
+  if (kBoard) {
+    fill_land<kStepBoardLoads>(v_board, board_img, kWave * HW, 0, lane);
+    fill_rest<kStepBoardLoads>(board_img, kWave * HW, HW, spec->rot_board, k_board, lane);
+  }
+  const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+  const float reward = g_rewards[(hi >> 3) & 0xffu];
+  const int done = (int)(hi & 1u);
+  ret += reward;
+  int8_t* my_obs = obs_img + lane * LHW;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = (int)((lo >> (7 * k)) & 0x7fu);
+    if ((lo >> (28 + k)) & 1u) {   // it is the character its cell shows
+      my_obs[(int)spec->static_top_layer[c] * HW + c] = 0;
+      my_obs[tp.dyn_layer[k] * HW + c] = 1;
+      if (kBoard) board_img[lane * HW + c] = (int8_t)spec->layer_char[tp.dyn_layer[k]];
+    }
+  }
+  if (live) {
+    if (out.reward) out.reward[env] = reward;
+    if (out.discount) out.discount[env] = done ? 0.0f : 1.0f;
+    if (out.done) out.done[env] = (uint8_t)done;
+    if (out.perf) out.perf[env] = (int8_t)((int)((hi >> 1) & 3u) - 1);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t c = (lo >> (7 * k)) & 0x7fu;
+      st.pos[(int64_t)(2 * k) * B + env] = (int8_t)(c / (uint32_t)W);
+      st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)(c % (uint32_t)W);
+    }
+    st.done[env] = (uint8_t)done;
+    if (st.ret) st.ret[env] = ret;
+  }
+  step_stream_obs(obs_img, out, env0 * LHW, n_live * LHW, lane);
+  if (kBoard) stream_out<false>(board_img, out.board + env0 * HW, n_live * HW, lane);
   report_bad_actions(out, bad);
 }
 
@@ -2448,6 +2535,42 @@ int32_t launch_step_pair(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
+TupleParams make_tuple_params(const CampxSpec& s) {
+  TupleParams tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.rows = s.rows;
+  tp.cols = s.cols;
+  tp.n_dyn = s.n_dyn;
+  tp.n_layers = s.n_layers;
+  for (int d = 0; d < s.n_dyn; ++d) {
+    tp.row0[d] = s.dyn_row0[d];
+    tp.col0[d] = s.dyn_col0[d];
+    tp.dyn_layer[d] = s.dyn_layer[d];
+  }
+  return tp;
+}
+
+int32_t launch_step_tuple(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                          const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
+                          hipStream_t stream) {
+  const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
+  const bool board = out.board != nullptr;
+  const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
+  const TupleParams tp = make_tuple_params(s);
+#define CAMPX_STEP_TUPLE(KK, BOARD)                                                           \
+  hipLaunchKernelGGL((step_tuple_kernel<KK, BOARD>), grid, block, shmem, stream, tp, spec_dev, st, \
+                     actions, out, B, reset_first)
+  if (s.n_dyn == 3) {
+    if (board) CAMPX_STEP_TUPLE(3, true); else CAMPX_STEP_TUPLE(3, false);
+  } else {
+    if (board) CAMPX_STEP_TUPLE(4, true); else CAMPX_STEP_TUPLE(4, false);
+  }
+#undef CAMPX_STEP_TUPLE
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
 // ---- split path: update pass -> trace, then one-shot render kernels
 template <int K>
 void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
@@ -2604,15 +2727,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
     constexpr int kProd = CAMPX_TUPLE_PROD, kCons = CAMPX_TUPLE_CONS, kEnvs = kProd * kWave;
     const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
         block((kProd + kCons + update_loaders(kProd)) * kWave);
-    TupleParams tp;
-    memset(&tp, 0, sizeof(tp));
-    tp.rows = s.rows;
-    tp.cols = s.cols;
-    tp.n_dyn = s.n_dyn;
-    for (int d = 0; d < s.n_dyn; ++d) {
-      tp.row0[d] = s.dyn_row0[d];
-      tp.col0[d] = s.dyn_col0[d];
-    }
+    const TupleParams tp = make_tuple_params(s);
     if (s.n_dyn == 3)
       hipLaunchKernelGGL((update_tuple_kernel<3, kProd, kCons>), grid, block, 0, stream, tp, st,
                          actions, out, B, T, reset_first);
@@ -2672,6 +2787,9 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (T == 1 && !emit_first && spec_host->n_dyn == 2 && st.pair_table && spec_host->render_valid &&
       !interpreter_only && !knob_no_table() && !knob_no_step())
     return launch_step_pair(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
+  if (T == 1 && !emit_first && spec_host->n_dyn >= 3 && st.pair_table && spec_host->render_valid &&
+      !interpreter_only && !knob_no_table() && !knob_no_step())
+    return launch_step_tuple(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);

@@ -229,13 +229,12 @@ class FusedGame(object):
     The 16-bit forms are what the reference's driver builds per step with
     `board.layered_board.view(-1).float()` (examples/reinforce.py:149) to feed its policy:
     here the step kernel writes them directly (0.0 / 1.0), no conversion pass.  Needs a
-    game whose update pass is tabulated (one or two movers); the flat `board` stays int8.
+    game whose update pass is tabulated; the flat `board` stays int8.
     """
     if dtype not in _OBS_DTYPES:
       raise ValueError('obs dtype must be torch.int8, float16 or bfloat16')
     if dtype != torch.int8 and not self.uses_table:
-      raise ValueError('16-bit play() observations need a game with a tabulated update '
-                       'pass (one or two moving things)')
+      raise ValueError('16-bit play() observations need a game with a tabulated update pass')
     if dtype != self._obs.dtype:
       shown = self._obs.to(dtype)        # keep the frame currently shown
       self._obs = shown

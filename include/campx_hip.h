@@ -194,7 +194,7 @@ typedef struct CampxOutputs {
                          (examples/reinforce.py:123,149) handed over without a conversion
                          pass.  16-bit formats are produced by the render kernel (rollouts:
                          they need `trace` and back-to-back frames) and by the one-frame
-                         kernels of one- and two-mover games with their tables (T == 1);
+                         kernels of games with their tables (T == 1);
                          anything else returns CAMPX_EINVAL. */
   int32_t* bad_count; /* optional device int32: += number of action ids outside 0..4 this call
                          consumed (the reference asserts sum(act) == 1 per step,

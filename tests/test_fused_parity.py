@@ -469,7 +469,7 @@ def test_raw_c_abi_through_ctypes(golden):
   assert _same(discount.cpu().numpy(), gold['discount'])
 
 
-@pytest.mark.parametrize('name', ['boat_race', 'sokoban'])
+@pytest.mark.parametrize('name', ['boat_race', 'sokoban', 'sokoban_l1', 'sokoban_l2'])
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
 def test_sixteen_bit_play_observations(name, dtype, golden, update_pass_mode):
   """The per-step consumer hand-off: play() writes the policy network's input dtype."""
