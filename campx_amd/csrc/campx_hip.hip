@@ -2352,8 +2352,11 @@ __global__ void onehot_to_ids_kernel(const float* __restrict__ onehot, int8_t* _
         ++others;
       }
     }
-    bad += (ones != 1 || others != 0);
-    ids[i] = (int8_t)id;
+    const bool not_one_hot = ones != 1 || others != 0;
+    bad += not_one_hot;
+    // such a row becomes id 5: every kernel treats it as "stay" and reports it, so a
+    // caller need not look at the count before stepping
+    ids[i] = (int8_t)(not_one_hot ? CAMPX_N_ACTIONS : id);
   }
   if (bad) atomicAdd(bad_count, bad);
 }

@@ -370,7 +370,8 @@ int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* ba
 /* Convert one-hot float actions [n, 5] (the reference's action format,
  * examples/boat_race.py:154-184) to ids [n]; rows that are not exactly one-hot
  * are counted in *bad_count (device int32, caller-zeroed; the reference asserts
- * sum(act) == 1, boat_race.py:48). */
+ * sum(act) == 1, boat_race.py:48) and become id 5, which the step / rollout kernels
+ * treat as "stay" and report through bad_count / bad_flag like any other bad id. */
 int32_t campx_onehot_to_ids_launch(const float* onehot, int8_t* ids, int64_t n,
                                    int32_t* bad_count, void* stream);
 

@@ -146,6 +146,26 @@ def test_one_hot_actions_and_validation():
     game.play(bad)
 
 
+def test_lazy_validation_of_one_hot_rows():
+  """Default mode, one-hot input: a row that is not exactly one-hot moves nothing (id 5)
+  and is reported by the step kernel through the lazy flag - no synchronisation in play()."""
+  game, _ = _fused('boat_race', 64)
+  ids = torch.randint(0, 5, (64,))
+  onehot = torch.nn.functional.one_hot(ids, 5).float().cuda()
+  bad = onehot.clone()
+  bad[5] = 0.0                                  # all zeros
+  bad[9, :2] = 1.0                              # two ones
+  pos_before = game.fused.pos.clone()
+  game.play(bad)
+  pos_after = game.fused.pos.cpu()
+  assert torch.equal(pos_after[:, 5], pos_before.cpu()[:, 5])     # stayed
+  assert torch.equal(pos_after[:, 9], pos_before.cpu()[:, 9])
+  with pytest.raises(ValueError, match='2 action ids'):
+    game.fused.check_actions()
+  game.play(onehot)
+  game.fused.check_actions()                    # clean again
+
+
 def test_lazy_validation_flag_in_host_mapped_memory():
   """Default mode: the kernel that reads the ids raises a flag in pinned host memory;
   the host looks at it without synchronising, so the error surfaces at the latest in

@@ -19,3 +19,14 @@ for B in (1, 1024, 65536):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 200
     print('play() B=%6d validate=%d: %.1f us/frame  %.3e env-steps/s' % (B, validate, dt * 1e6, B / dt))
+  onehot = torch.nn.functional.one_hot(acts.long(), 5).float()
+  game.fused.validate_actions = True
+  for t in range(20):
+    game.play(onehot[t])
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for t in range(200):
+    game.play(onehot[t])
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / 200
+  print('play(one-hot float [B, 5]) B=%6d lazy validation: %.1f us/frame' % (B, dt * 1e6))
