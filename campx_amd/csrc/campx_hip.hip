@@ -17,11 +17,16 @@
 //   rollout_table_kernel  same, for games with one moving thing: the update pass is a
 //                         lookup in a (cell, action) table that campx_spec_compile()
 //                         fills by running rollout_kernel over every pair.
-//   update_*_kernel       the update pass alone (producer, consumer and loader waves),
+//   update_*_kernel       the update pass alone (producer, consumer and loader waves)
+//                         from the game's state table: (cell, action) in LDS for one
+//                         mover, (cell, cell, action) in LDS for two, (cell, ..., action)
+//                         in global memory for three and four,
 //   render_kernel         and the observation stream alone: one-shot blocks, every
 //                         wave one aligned KiB store - the store pattern that reaches
-//                         the chip's HBM write ceiling.  The default for rollouts of
-//                         one-mover games.
+//                         the chip's HBM write ceiling.  The default for rollouts.
+//   step_*_kernel         Engine.play(): one frame, one-shot, one wave per 64 environments.
+//   shape_rollout_kernel  Hello-World-style games (rigidly translated multi-cell things):
+//                         one wave per environment, scalar update pass.
 // No MFMA anywhere: the path has no contraction; every kernel is bound by the HBM
 // write stream of observations.
 //
