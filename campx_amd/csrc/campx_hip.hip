@@ -1117,7 +1117,7 @@ constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
 #endif
 constexpr int update_min_waves(int, int) { return CAMPX_UPD_MINWAVES; }
 
-template <int kProd, int kCons>
+template <int kProd, int kCons, int kG>   // kG: frames per group (a ring slot)
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
@@ -1131,8 +1131,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   // [24] done, [25:26] perf + 1.  The ring keeps x and the upper half of y.
   __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
-  __shared__ __attribute__((aligned(16))) float ring_r[2][kGroup][E];
-  __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kGroup][E];
+  __shared__ __attribute__((aligned(16))) float ring_r[2][kG][E];
+  __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kG][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave >= kProd + kCons;
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
@@ -1174,25 +1174,25 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   uint32_t row_off = (uint32_t)(over ? cell0 : cell) * kRowBytes;  // the chain's state
   const char* table_bytes = reinterpret_cast<const char*>(table);
   const int clane = (int)threadIdx.x - kProd * kWave;  // consumers: 0 .. CL-1
-  constexpr int kGroupsPerChunk = kChunk / kGroup;
+  constexpr int kGroupsPerChunk = kChunk / kG;
   __syncthreads();
 
-  const int n_groups = (T + kGroup - 1) / kGroup;
+  const int n_groups = (T + kG - 1) / kG;
   // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
   // agree): registers are then allocated per role, and the loads a loader keeps in flight
   // across iterations do not take registers from the other two.
   if (producer) {
     for (int g = 0; g <= n_groups; ++g) {
         if (g < n_groups) {
-          const int t0 = g * kGroup;
+          const int t0 = g * kG;
           const int8_t* chunk = staged[(t0 / kChunk) & 1];
-          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
-          uint32_t col_off[kGroup];  // action * sizeof(entry), off the dependent chain
+          const int n = (T - t0 < kG) ? T - t0 : kG;
+          uint32_t col_off[kG];  // action * sizeof(entry), off the dependent chain
   #pragma unroll
-          for (int j = 0; j < kGroup; ++j)
+          for (int j = 0; j < kG; ++j)
             col_off[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le) * (uint32_t)sizeof(uint2);
   #pragma unroll
-          for (int j = 0; j < kGroup; ++j) {
+          for (int j = 0; j < kG; ++j) {
             if (j < n) {
               // the dependent chain: row offset -> entry -> row offset
               const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
@@ -1212,10 +1212,10 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   } else if (!loader) {
     for (int g = 0; g <= n_groups; ++g) {
         if (g > 0) {
-          const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
-          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+          const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
+          const int n = (T - t0 < kG) ? T - t0 : kG;
           // ---- float streams: item = (frame j, 4 environments)
-          constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
+          constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
   #if CAMPX_UPD_ROLL_A
 #pragma unroll 1
 #else
@@ -1248,13 +1248,13 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             }
           }
           // ---- byte streams: item = (frame j, 16 environments)
-          constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
+          constexpr int QB = E / 16, kItB = (kG * QB + CL - 1) / CL;
   #pragma unroll
           for (int it = 0; it < kItB; ++it) {
             const int item = clane + it * CL;
             const int j = item / QB, q = item % QB;
             const int64_t e0 = env0 + 16 * q;
-            if (item < kGroup * QB && j < n && e0 < B) {
+            if (item < kG * QB && j < n && e0 < B) {
               const u32x4 ya = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q]);
               const u32x4 yb = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q + 8]);
               const uint32_t w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
@@ -1340,19 +1340,23 @@ struct PairParams {
 #endif
 constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 16 KiB of LDS for the chain table
 
+#ifndef CAMPX_PAIR_GROUP
+#define CAMPX_PAIR_GROUP 16   // frames per ring slot group (A/B builds)
+#endif
+
 template <int kChain, int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
-  constexpr int kLoad = update_loaders(kProd);
+  constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   __shared__ uint16_t lds_chain[kChain == 1 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kChain 3: n_entries
   __shared__ float reward_list[256];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
-  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kGroup][E];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kG][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave >= kProd + kCons;
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
@@ -1396,27 +1400,27 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     if (st.ret) ret = st.ret[env];
   }
   const int clane = (int)threadIdx.x - kProd * kWave;
-  constexpr int kGroupsPerChunk = kChunk / kGroup;
+  constexpr int kGroupsPerChunk = kChunk / kG;
   // the chain's state: index of the entries the next frame starts from
   uint32_t base = over ? pair_index(init0, init1, HW) : pair_index(c0, c1, HW);
   __syncthreads();
 
-  const int n_groups = (T + kGroup - 1) / kGroup;
+  const int n_groups = (T + kG - 1) / kG;
   // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
   // agree): registers are then allocated per role, and the loads a loader keeps in flight
   // across iterations do not take registers from the other two.
   if (producer) {
     for (int g = 0; g <= n_groups; ++g) {
         if (g < n_groups) {
-          const int t0 = g * kGroup;
+          const int t0 = g * kG;
           const int8_t* chunk = staged[(t0 / kChunk) & 1];
-          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
-          uint32_t act[kGroup];
+          const int n = (T - t0 < kG) ? T - t0 : kG;
+          uint32_t act[kG];
   #pragma unroll
-          for (int j = 0; j < kGroup; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+          for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
           if (kChain == 0 || kChain == 3) {
   #pragma unroll
-            for (int j = 0; j < kGroup; ++j) {
+            for (int j = 0; j < kG; ++j) {
               if (j < n) {
                 if (over) {  // rebuilt from the art before its next action
                   c0 = init0;
@@ -1432,9 +1436,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               }
             }
           } else {
-            uint32_t e[kGroup];
+            uint32_t e[kG];
   #pragma unroll
-            for (int j = 0; j < kGroup; ++j) {
+            for (int j = 0; j < kG; ++j) {
               if (j < n) {
                 const uint32_t idx = base + act[j];
                 base = kChain == 1 ? lds_chain[idx] : g_chain[idx];   // the dependent chain
@@ -1442,7 +1446,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               }
             }
   #pragma unroll
-            for (int j = 0; j < kGroup; ++j) {
+            for (int j = 0; j < kG; ++j) {
               if (j < n) {
                 ring[g & 1][j][le] = e[j];
                 ret = (over ? 0.0f : ret) + reward_list[(e[j] >> 19) & 0xffu];
@@ -1459,10 +1463,10 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   } else if (!loader) {
     for (int g = 0; g <= n_groups; ++g) {
         if (g > 0) {
-          const int gp = g - 1, t0 = gp * kGroup, rb = gp & 1;
-          const int n = (T - t0 < kGroup) ? T - t0 : kGroup;
+          const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
+          const int n = (T - t0 < kG) ? T - t0 : kG;
           const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
-          constexpr int QA = E / 4, kItA = (kGroup * QA + CL - 1) / CL;
+          constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
   #pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
           for (int it = 0; it < kItA; ++it) {
             const int item = clane + it * CL;
@@ -1495,13 +1499,13 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               }
             }
           }
-          constexpr int QB = E / 16, kItB = (kGroup * QB + CL - 1) / CL;
+          constexpr int QB = E / 16, kItB = (kG * QB + CL - 1) / CL;
   #pragma unroll
           for (int it = 0; it < kItB; ++it) {
             const int item = clane + it * CL;
             const int j = item / QB, q = item % QB;
             const int64_t e0 = env0 + 16 * q;
-            if (item < kGroup * QB && j < n && e0 < B) {
+            if (item < kG * QB && j < n && e0 < B) {
               uint32_t ta[4], tb[4], dn[4], pf[4];
   #pragma unroll
               for (int k = 0; k < 4; ++k) {
@@ -2543,6 +2547,37 @@ int32_t launch_step_pair(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
+constexpr int kBigEnvs = 8 * kWave;   // environments of a "big" update workgroup
+
+// Number of big workgroups from which launch_update prefers them: one per CU of the chip
+// (CAMPX_BIG_WGS overrides; a huge value turns them off).
+int64_t knob_big_workgroups() {
+  static const int64_t n = [] {
+    const char* v = getenv("CAMPX_BIG_WGS");
+    if (v && *v) return (int64_t)atoll(v);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return (int64_t)cus;
+  }();
+  return n;
+}
+
+PairParams make_pair_params(const CampxSpec& s) {
+  PairParams pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.rows = s.rows;
+  pp.cols = s.cols;
+  pp.n_layers = s.n_layers;
+  for (int d = 0; d < 2; ++d) {
+    pp.dyn_layer[d] = s.dyn_layer[d];
+    pp.row0[d] = s.dyn_row0[d];
+    pp.col0[d] = s.dyn_col0[d];
+  }
+  return pp;
+}
+
 TupleParams make_tuple_params(const CampxSpec& s) {
   TupleParams tp;
   memset(&tp, 0, sizeof(tp));
@@ -2690,28 +2725,40 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
+  // 512-environment workgroups (twice the row piece per store) once there are enough
+  // environments to give every CU one; 256-environment workgroups below that
+  const bool big = B >= (int64_t)kBigEnvs * knob_big_workgroups();
   if (use_table) {
-    constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
-    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
-        block((kProd + kCons + update_loaders(kProd)) * kWave);
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
-    hipLaunchKernelGGL((update_table_kernel<kProd, kCons>), grid, block, 0, stream, mp, spec_dev,
-                       st, actions, out, B, T, reset_first);
+    if (big) {
+      constexpr int kProd = 8, kCons = 4;
+      const dim3 grid((unsigned)((B + kBigEnvs - 1) / kBigEnvs)),
+          block((kProd + kCons + update_loaders(kProd)) * kWave);
+      hipLaunchKernelGGL((update_table_kernel<kProd, kCons, 8>), grid, block, 0, stream, mp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    } else {
+      constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
+      const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
+          block((kProd + kCons + update_loaders(kProd)) * kWave);
+      hipLaunchKernelGGL((update_table_kernel<kProd, kCons, kGroup>), grid, block, 0, stream, mp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    }
+  } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table() && big && knob_pair_mode() == 3 &&
+             s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS <= kPairLdsEntries) {
+    constexpr int kProd = 8, kCons = 4;
+    const dim3 grid((unsigned)((B + kBigEnvs - 1) / kBigEnvs)),
+        block((kProd + kCons + update_loaders(kProd)) * kWave);
+    const PairParams pp = make_pair_params(s);
+    const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
+    hipLaunchKernelGGL((update_pair_kernel<3, kProd, kCons>), grid, block,
+                       ((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15, stream, pp,
+                       spec_dev, st, actions, out, B, T, reset_first);
   } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
     constexpr int kProd = CAMPX_PAIR_PROD, kCons = CAMPX_PAIR_CONS, kEnvs = kProd * kWave;
     const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
         block((kProd + kCons + update_loaders(kProd)) * kWave);
-    PairParams pp;
-    memset(&pp, 0, sizeof(pp));
-    pp.rows = s.rows;
-    pp.cols = s.cols;
-    pp.n_layers = s.n_layers;
-    for (int d = 0; d < 2; ++d) {
-      pp.dyn_layer[d] = s.dyn_layer[d];
-      pp.row0[d] = s.dyn_row0[d];
-      pp.col0[d] = s.dyn_col0[d];
-    }
+    const PairParams pp = make_pair_params(s);
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
     // 3: entries in LDS, the chain goes through them; 1 / 2: 16-bit chain table in LDS /
     // global with the entries fetched off the chain; 0: everything through L1/L2.
