@@ -45,15 +45,15 @@ from . import gamespec
 from .rendering import Observation
 
 
-# One-mover games: tabulate the update pass per (cell, action) at showtime
-# (campx_spec_compile) and let the frame loop look it up.  Tests switch this off to
+# Tabulate the update pass at showtime - per (cell, action) for one mover
+# (campx_spec_compile), per (cell, ..., cell, action) for two to four
+# (campx_pair_table_build) - and let the frame loop look it up.  Tests switch this off to
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
 # Rollouts that keep every frame run the update pass and the render as two kernels
 # (needs a [K, T, B] uint8 trace buffer; DESIGN.md "Kernels", profiles/): faster for
-# every game, tabulated update pass or interpreted (sokoban with three boxes,
-# B = 131 072: 1.31 ms against 1.72 ms per 100-frame launch).  CAMPX_SPLIT=0 keeps
-# everything in the single fused kernel; parity tests run both.
+# every game, tabulated update pass or interpreted.  CAMPX_SPLIT=0 keeps everything in
+# the single fused kernel; parity tests run both.
 SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') != '0'
 FORCE_SPLIT = SPLIT_ROLLOUT   # kept for callers that toggled it: same as SPLIT_ROLLOUT now
 
