@@ -59,8 +59,10 @@ TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_traffic.json')
 def parse_args(argv=None):
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=30)
-  p.add_argument('--warmup', type=int, default=5)
+  # defaults: the chip needs ~5 ms of sustained launches before its clocks settle (5 warmup
+  # launches read 0.188 ms per step, 50 or 200 read 0.180: DESIGN.md section 5)
+  p.add_argument('--steps', type=int, default=100)
+  p.add_argument('--warmup', type=int, default=50)
   p.add_argument('--game', default='boat_race', choices=sorted(WORKLOADS))
   p.add_argument('--batch', type=int, default=None,
                  help='environments per GPU (default: the BASELINE config)')
