@@ -75,7 +75,7 @@ def parse_args(argv=None):
                  help='A/B: issue the update pass of each rollout on a side stream so that '
                       'it overlaps the previous launch (measured SLOWER: the two kernels '
                       'contend for CU slots; DESIGN.md "Kernels")')
-  p.add_argument('--gather-every', type=int, default=8,
+  p.add_argument('--gather-every', type=int, default=32,
                  help='episodes per RCCL all-gather of the episode-return log')
   p.add_argument('--episode-csv', default=None,
                  help='rank 0: after the timed region, write the last all-gathered block of '
