@@ -254,6 +254,8 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     # episode's returns straight into its row of the log, so nothing but the
     # rollout kernels ever runs on the rollout's stream.
     from campx_amd.distributed import ReturnLog
+    # (never rarer than once per timed region, so that a short run still exercises it)
+    gather_every = max(1, min(gather_every, steps))
     log = ReturnLog(B, gather_every, device, dist)
 
   def one_step(i):
@@ -463,7 +465,7 @@ def run_rank(args):
             'parallelism': 'env-sharded x{}, {} all-gather of the episode-'
                            'return log every {} episodes, off the step path'
                            .format(world, 'gloo' if standin else 'RCCL',
-                                   args.gather_every)
+                                   max(1, min(args.gather_every, args.steps)))
                            if dist is not None else 'single GPU',
             'world': world,
             'gathered_log_matches_local': gathered_ok,
