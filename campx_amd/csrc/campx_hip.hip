@@ -2189,12 +2189,23 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
   }
-  for (int i = lane; i < HW; i += kWave)
-    bd[i] = (fresh || !backdrop_state) ? spec->backdrop[i] : (uint8_t)backdrop_state[env * HW + i];
+  // the environment's backdrop, four cells per load when the board allows (env * HW is
+  // then a multiple of 4 too; the spec's array and torch allocations are 4-byte aligned)
+  const bool from_state = !fresh && backdrop_state != nullptr;
+  const uint8_t* bd_src = from_state ? reinterpret_cast<const uint8_t*>(backdrop_state) + env * HW
+                                     : spec->backdrop;
+  auto load_backdrop = [&](const uint8_t* src) {
+    if (quads)
+      for (int i = lane; 4 * i < HW; i += kWave)
+        reinterpret_cast<uint32_t*>(bd)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+    else
+      for (int i = lane; i < HW; i += kWave) bd[i] = src[i];
+  };
+  load_backdrop(bd_src);
 
   auto rebuild = [&]() {  // a fresh make_game() + its_showtime()
     orow[0] = orow[1] = ocol[0] = ocol[1] = 0u;
-    for (int i = lane; i < HW; i += kWave) bd[i] = spec->backdrop[i];
+    load_backdrop(spec->backdrop);
   };
 
   auto paint_and_emit = [&](int8_t* obs_dst, int8_t* board_dst) {
@@ -2330,8 +2341,13 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
   }
-  if (backdrop_state)
-    for (int i = lane; i < HW; i += kWave) backdrop_state[env * HW + i] = (int8_t)bd[i];
+  if (backdrop_state) {
+    if (quads)
+      for (int i = lane; 4 * i < HW; i += kWave)
+        reinterpret_cast<uint32_t*>(backdrop_state + env * HW)[i] = reinterpret_cast<const uint32_t*>(bd)[i];
+    else
+      for (int i = lane; i < HW; i += kWave) backdrop_state[env * HW + i] = (int8_t)bd[i];
+  }
   report_bad_actions(out, lane == 0 ? bad : 0);
 }
 
@@ -3298,7 +3314,8 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
   if (out.obs_format != CAMPX_OBS_INT8 || out.perf || out.trace) return CAMPX_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(out.obs) | reinterpret_cast<uintptr_t>(out.board)) & 3)
+  if ((reinterpret_cast<uintptr_t>(out.obs) | reinterpret_cast<uintptr_t>(out.board) |
+       reinterpret_cast<uintptr_t>(backdrop_state)) & 3)
     return CAMPX_EINVAL;
   const int32_t v = campx_shape_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
