@@ -18,3 +18,5 @@ FUSED_GAMES = {
 
 # Games of the shape tier (rules.RollingDrape / rules.SlidingSprite): own spec and kernel.
 SHAPE_GAMES = {'hello_world': hello_world.build}
+import shape_zoo  # noqa: E402  (tests/shape_zoo.py: more games of the same two rule classes)
+SHAPE_GAMES.update(shape_zoo.library_builders())

@@ -2,7 +2,7 @@
 
 Seeded, so failures reproduce.  Covers what the fixed games do not: arbitrary wall /
 coin / hover-tile / box placements, boards of every aspect ratio up to 128 cells, one- to
-three-mover games, batches that are not multiples of 4 / 16 / 64 / 256 and episode
+four-mover games (with and without their state tables), batches that are not multiples of 4 / 16 / 64 / 256 and episode
 lengths that are not multiples of the kernels' 16-frame groups and 64-frame chunks."""
 
 import os
@@ -37,8 +37,8 @@ def random_game(rng):
     return random_game(rng)
   rng.shuffle(free)
   art[free.pop()] = 'A'
-  n_boxes = int(rng.choice([0, 0, 1, 2])) if len(free) > 6 else 0
-  boxes = 'XY'[:n_boxes]
+  n_boxes = int(rng.choice([0, 0, 1, 2, 3])) if len(free) > 6 else 0
+  boxes = 'XYZ'[:n_boxes]
   for ch in boxes:
     art[free.pop()] = ch
   coins = rng.rand() < 0.5 and not boxes

@@ -14,7 +14,7 @@ import torch
 
 from campx_amd import things
 from campx_amd.ascii_art import ascii_art_to_game, Partial
-from games_under_test import FUSED_GAMES
+from games_under_test import FUSED_GAMES, SHAPE_GAMES
 from conftest import GOLDEN_DIR, REPO
 
 LIST_ACTION_GAMES = {'demo1', 'demo2', 'demo3', 'wall_world'}   # as in the notebooks
@@ -78,6 +78,14 @@ def test_hello_world_sprites_rolling_drape_and_termination(golden):
   before the first drape and leave trails."""
   gold = golden('hello_world')
   replay(hello_world, gold, 'hello_world', envs=range(gold['actions'].shape[1]), to_act=int)
+
+
+@pytest.mark.parametrize('name', sorted(n for n in SHAPE_GAMES if n != 'hello_world'))
+def test_shape_zoo_on_generic_tier(name, golden):
+  """tests/shape_zoo.py games: this repo's engine / renderer / Plot with the library rule
+  classes vs the reference's engine with the same classes (make_golden.py)."""
+  gold = golden(name)
+  replay(SHAPE_GAMES[name], gold, name, envs=range(gold['actions'].shape[1]), to_act=int)
 
 
 def test_notebook_recorded_outputs(golden):

@@ -8,6 +8,7 @@ import torch
 from campx_amd import gamespec
 from campx_amd.games import hello_world
 from oracle import cpu
+from games_under_test import SHAPE_GAMES
 
 pytestmark = pytest.mark.gpu
 
@@ -19,12 +20,54 @@ def _same(a, b):
   return np.array_equal(a, b)
 
 
-def _game(batch):
-  game = hello_world.build(batch=batch, device='cuda')
+def _game(batch, name='hello_world'):
+  game = SHAPE_GAMES[name](batch=batch, device='cuda')
   first = game.its_showtime()
   from campx_amd import shapes
   assert isinstance(game.fused, shapes.ShapeGame)
   return game, first
+
+
+ZOO = sorted(n for n in SHAPE_GAMES if n != 'hello_world')   # tests/shape_zoo.py
+
+
+@pytest.mark.parametrize('name', ZOO)
+def test_zoo_golden_rollout_and_play(name, golden):
+  """More arrangements of the two rule classes (odd / 8k+4 / 8k / tiny boards, eight things,
+  trails or none, a 150-cell drape, reward sums of three drapes) vs what the REFERENCE
+  engine did with them; one rollout, then frame by frame."""
+  gold = golden(name)
+  T, N = gold['actions'].shape
+  game, (obs, reward, discount) = _game(N, name)
+  assert [ord(c) for c in game.fused.chars] == gold['chars'].tolist()
+  assert _same(obs.layered_board.cpu().numpy(), gold['layered'][0])
+  assert _same(obs.board.cpu().numpy(), gold['board'][0])
+  out = game.rollout(torch.from_numpy(gold['actions']), want_board=True)
+  for key, want in (('obs', gold['layered'][1:]), ('board', gold['board'][1:]),
+                    ('reward', gold['reward']), ('discount', gold['discount']),
+                    ('done', gold['done'])):
+    assert _same(out[key].cpu().numpy(), want), key
+  game, _ = _game(N, name)
+  for t in range(T):
+    obs, reward, discount = game.play(torch.from_numpy(gold['actions'][t]))
+    assert _same(obs.layered_board.cpu().numpy(), gold['layered'][t + 1]), t
+    assert _same(obs.board.cpu().numpy(), gold['board'][t + 1]), t
+    assert _same(reward.cpu().numpy(), gold['reward'][t])
+    assert _same(discount.cpu().numpy(), gold['discount'][t])
+
+
+@pytest.mark.parametrize('name', ZOO)
+@pytest.mark.parametrize('batch', [5, 130])
+def test_zoo_random_streams_vs_oracle(name, batch):
+  rng = np.random.RandomState(batch)
+  game, _ = _game(batch, name)
+  og = cpu.OracleGame.from_description(gamespec.describe(SHAPE_GAMES[name]()))
+  for launch, T in enumerate([1, 70, 33]):        # across the 64-frame scalar buffer
+    actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), want_board=True)
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'board', 'reward', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
 
 
 def test_golden_rollout(golden):
