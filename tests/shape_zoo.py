@@ -2,9 +2,9 @@
 (rules.RollingDrape / rules.SlidingSprite) to reach what Hello World does not: more than
 four things (the second offset word), boards whose cell count is odd / 8k + 4 / 8k / below 8,
 a drape first in z-order (no trails) and several sprites before the first drape (trails),
-drapes that cover hundreds of cells, a static FixedDrape among the things, rewards of
-several drapes summed in update-schedule order (0.1 + 0.7 + 1.3 is order-sensitive in
-float32), a quit action that also rolls and pays.
+drapes that cover hundreds of cells, a static FixedDrape among the things, the rewards of
+several drapes summed in one frame (0.1 + 0.7 + 1.3), a quit action that also rolls and
+pays.
 
 `build(name, ...)` takes the engine bindings as arguments, so tests/golden/make_golden.py
 can build the very same games on the REFERENCE engine (its ascii_art_to_game, its things)

@@ -34,7 +34,7 @@ ZOO = sorted(n for n in SHAPE_GAMES if n != 'hello_world')   # tests/shape_zoo.p
 @pytest.mark.parametrize('name', ZOO)
 def test_zoo_golden_rollout_and_play(name, golden):
   """More arrangements of the two rule classes (odd / 8k+4 / 8k / tiny boards, eight things,
-  trails or none, a 150-cell drape, reward sums of three drapes) vs what the REFERENCE
+  trails or none, a 150-cell drape, three drapes rewarding in one frame) vs what the REFERENCE
   engine did with them; one rollout, then frame by frame."""
   gold = golden(name)
   T, N = gold['actions'].shape
