@@ -2212,9 +2212,13 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     // Things back to front.  Sprites behind the first drape paint into the backdrop itself
     // (rendering.py:128,150); the frame's board starts as a copy of it.
     for (int z = 0; z < N; ++z) {   // everything about z is scalar
+      // (loops over `base` have scalar trip counts: one pass for boards up to 1 024 cells
+      // here, for things up to 64 cells below)
       if (z == first_drape)
-        for (int i = lane; i * 16 < HW; i += kWave)   // (the arrays are whole 16-byte chunks)
-          reinterpret_cast<u32x4*>(board)[i] = reinterpret_cast<const u32x4*>(bd)[i];
+        for (int base = 0; base * 16 < HW; base += kWave) {   // whole 16-byte chunks of the arrays
+          const int i = base + lane;
+          if (i * 16 < HW) reinterpret_cast<u32x4*>(board)[i] = reinterpret_cast<const u32x4*>(bd)[i];
+        }
       const uint32_t th = sp.thing[z];
       if ((th >> 28) & 1u) {
         const int begin = (int)(th & 0x7ffu), n = (int)((th >> 11) & 0xfffu);
@@ -2223,12 +2227,15 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
         const int dr = (int)(((z < 4 ? orow[0] : orow[1]) >> sh) & 0xffu);
         const int dc = (int)(((z < 4 ? ocol[0] : ocol[1]) >> sh) & 0xffu);
         uint8_t* target = z < first_drape ? bd : board;
-        for (int i = lane; i < n; i += kWave) {
-          const uint32_t packed = lds_cells[begin + i];
-          int r = (int)(packed >> 8) + dr, c = (int)(packed & 0xffu) + dc;
-          r = r >= H ? r - H : r;
-          c = c >= W ? c - W : c;
-          target[r * W + c] = layer;
+        for (int base = 0; base < n; base += kWave) {
+          const int i = base + lane;
+          if (i < n) {
+            const uint32_t packed = lds_cells[begin + i];
+            int r = (int)(packed >> 8) + dr, c = (int)(packed & 0xffu) + dc;
+            r = r >= H ? r - H : r;
+            c = c >= W ? c - W : c;
+            target[r * W + c] = layer;
+          }
         }
       }
     }
@@ -2236,7 +2243,9 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     // layer plane.  A board of 8k + 4 cells: the last lane takes the last eight cells, four of
     // which its neighbour also writes (same values), so every lane runs the same code.
     if (quads && HW >= 8) {
-      for (int q = lane; 8 * q < HW; q += kWave) {
+      for (int qbase = 0; 8 * qbase < HW; qbase += kWave) {
+        const int q = qbase + lane;
+        if (8 * q >= HW) continue;
         const uint32_t at = (uint32_t)(8 * q + 8 <= HW ? 8 * q : HW - 8);   // a multiple of 4
         const uint32_t b0 = *reinterpret_cast<const uint32_t*>(board + at);
         const uint32_t b1 = *reinterpret_cast<const uint32_t*>(board + at + 4);
