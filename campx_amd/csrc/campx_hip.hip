@@ -1323,12 +1323,12 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
 
 // ---------------------------------------------------------------------------
 // Two-mover games: the same layout over the (cell, cell, action) pair table
-// (campx_pair_table_build).  The dependent chain goes through the table's compact
-// 16-bit half - entry -> index of the next frame's entries - which sits in LDS when it
-// fits (kChain 1; 2 = read through L1/L2); the 32-bit entries with everything a frame
-// outputs are fetched off the chain, straight from global memory (L1/L2-resident), as
-// each index becomes known, and go to the ring as they are.  Boards too large for
-// 16-bit indices chain through the entries themselves (kChain 0).
+// (campx_pair_table_build).  The dependent chain goes through the 32-bit entries
+// themselves, which carry everything a frame outputs and go to the ring as they are; they
+// sit in LDS (dynamic, kLdsEntries) when the table fits, else they are read through L1/L2.
+// (Chaining through a separate 16-bit next-index table in LDS with the entries fetched off
+// the chain from global memory was built and measured slower - 68.9 against 51.4 us - and
+// removed.)
 struct PairParams {
   int32_t rows, cols, n_layers;
   int32_t dyn_layer[2], row0[2], col0[2];
@@ -1338,13 +1338,13 @@ struct PairParams {
 #ifndef CAMPX_PAIR_LDS_ENTRIES
 #define CAMPX_PAIR_LDS_ENTRIES 8192
 #endif
-constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 16 KiB of LDS for the chain table
+constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 32 KiB of LDS for the entries at most
 
 #ifndef CAMPX_PAIR_GROUP
 #define CAMPX_PAIR_GROUP 16   // frames per ring slot group (A/B builds)
 #endif
 
-template <int kChain, int kProd, int kCons>
+template <bool kLdsEntries, int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
@@ -1352,8 +1352,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     int32_t reset_first) {
   constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
-  __shared__ uint16_t lds_chain[kChain == 1 && kPairLdsEntries > 0 ? kPairLdsEntries : 1];
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kChain 3: n_entries
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kLdsEntries: n_entries
   __shared__ float reward_list[256];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kG][E];
@@ -1367,11 +1366,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
   const int n_entries = HW * HW * CAMPX_N_ACTIONS;
-  const uint16_t* g_chain = reinterpret_cast<const uint16_t*>(g_entries + n_entries);
-  if (kChain == 1)
-    for (int i = threadIdx.x; i < (n_entries + 1) / 2; i += kThreads)
-      reinterpret_cast<uint32_t*>(lds_chain)[i] = reinterpret_cast<const uint32_t*>(g_chain)[i];
-  if (kChain == 3)
+  if (kLdsEntries)
     for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
   ActionLoader<E, kLoad> ld;
@@ -1401,8 +1396,6 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   }
   const int clane = (int)threadIdx.x - kProd * kWave;
   constexpr int kGroupsPerChunk = kChunk / kG;
-  // the chain's state: index of the entries the next frame starts from
-  uint32_t base = over ? pair_index(init0, init1, HW) : pair_index(c0, c1, HW);
   __syncthreads();
 
   const int n_groups = (T + kG - 1) / kG;
@@ -1418,42 +1411,20 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
           uint32_t act[kG];
   #pragma unroll
           for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
-          if (kChain == 0 || kChain == 3) {
   #pragma unroll
-            for (int j = 0; j < kG; ++j) {
-              if (j < n) {
-                if (over) {  // rebuilt from the art before its next action
-                  c0 = init0;
-                  c1 = init1;
-                }
-                const uint32_t idx = pair_index(c0, c1, HW) + act[j];
-                const uint32_t e = kChain == 3 ? lds_entries[idx] : g_entries[idx];
-                c0 = e & 0x7fu;
-                c1 = (e >> 7) & 0x7fu;
-                ring[g & 1][j][le] = e;
-                ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
-                over = (int)((e >> 16) & 1u);
+          for (int j = 0; j < kG; ++j) {
+            if (j < n) {
+              if (over) {  // rebuilt from the art before its next action
+                c0 = init0;
+                c1 = init1;
               }
-            }
-          } else {
-            uint32_t e[kG];
-  #pragma unroll
-            for (int j = 0; j < kG; ++j) {
-              if (j < n) {
-                const uint32_t idx = base + act[j];
-                base = kChain == 1 ? lds_chain[idx] : g_chain[idx];   // the dependent chain
-                e[j] = g_entries[idx];                                // off the chain
-              }
-            }
-  #pragma unroll
-            for (int j = 0; j < kG; ++j) {
-              if (j < n) {
-                ring[g & 1][j][le] = e[j];
-                ret = (over ? 0.0f : ret) + reward_list[(e[j] >> 19) & 0xffu];
-                over = (int)((e[j] >> 16) & 1u);
-                c0 = e[j] & 0x7fu;
-                c1 = (e[j] >> 7) & 0x7fu;
-              }
+              const uint32_t idx = pair_index(c0, c1, HW) + act[j];
+              const uint32_t e = kLdsEntries ? lds_entries[idx] : g_entries[idx];   // the chain
+              c0 = e & 0x7fu;
+              c1 = (e >> 7) & 0x7fu;
+              ring[g & 1][j][le] = e;
+              ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
+              over = (int)((e >> 16) & 1u);
             }
           }
         }
@@ -2769,40 +2740,28 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       hipLaunchKernelGGL((update_table_kernel<kProd, kCons, kGroup>), grid, block, 0, stream, mp,
                          spec_dev, st, actions, out, B, T, reset_first);
     }
-  } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table() && big && knob_pair_mode() == 3 &&
-             s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS <= kPairLdsEntries) {
-    constexpr int kProd = 8, kCons = 4;
-    const dim3 grid((unsigned)((B + kBigEnvs - 1) / kBigEnvs)),
-        block((kProd + kCons + update_loaders(kProd)) * kWave);
-    const PairParams pp = make_pair_params(s);
-    const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
-    hipLaunchKernelGGL((update_pair_kernel<3, kProd, kCons>), grid, block,
-                       ((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15, stream, pp,
-                       spec_dev, st, actions, out, B, T, reset_first);
   } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
-    constexpr int kProd = CAMPX_PAIR_PROD, kCons = CAMPX_PAIR_CONS, kEnvs = kProd * kWave;
-    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
-        block((kProd + kCons + update_loaders(kProd)) * kWave);
     const PairParams pp = make_pair_params(s);
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
-    // 3: entries in LDS, the chain goes through them; 1 / 2: 16-bit chain table in LDS /
-    // global with the entries fetched off the chain; 0: everything through L1/L2.
-    // Measured on sokoban (us per 100-frame launch, B = 131 072, (4,4) waves): 3: 51.4,
-    // 1: 68.9 (the per-lane random entry loads cost more than the shorter chain saves).
-    const int mode = knob_pair_mode();
-    if (n_entries > 65535 || mode == 0)
-      hipLaunchKernelGGL((update_pair_kernel<0, kProd, kCons>), grid, block, 0, stream, pp,
-                         spec_dev, st, actions, out, B, T, reset_first);
-    else if (n_entries <= kPairLdsEntries && mode == 3)
-      hipLaunchKernelGGL((update_pair_kernel<3, kProd, kCons>), grid, block,
-                         ((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15, stream, pp,
-                         spec_dev, st, actions, out, B, T, reset_first);
-    else if (n_entries <= kPairLdsEntries && mode == 1)
-      hipLaunchKernelGGL((update_pair_kernel<1, kProd, kCons>), grid, block, 0, stream, pp,
-                         spec_dev, st, actions, out, B, T, reset_first);
+    // the entries in LDS when they fit (CAMPX_PAIR_MODE=0: read them through L1/L2 anyway)
+    const bool in_lds = n_entries <= kPairLdsEntries && knob_pair_mode() != 0;
+    const size_t shmem = in_lds ? (((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15) : 0;
+#define CAMPX_PAIR_LAUNCH(PROD, CONS)                                                          \
+  do {                                                                                         \
+    const dim3 grid((unsigned)((B + (PROD) * kWave - 1) / ((PROD) * kWave))),                  \
+        block(((PROD) + (CONS) + update_loaders(PROD)) * kWave);                               \
+    if (in_lds)                                                                                \
+      hipLaunchKernelGGL((update_pair_kernel<true, PROD, CONS>), grid, block, shmem, stream,   \
+                         pp, spec_dev, st, actions, out, B, T, reset_first);                   \
+    else                                                                                       \
+      hipLaunchKernelGGL((update_pair_kernel<false, PROD, CONS>), grid, block, 0, stream, pp,  \
+                         spec_dev, st, actions, out, B, T, reset_first);                       \
+  } while (0)
+    if (big)
+      CAMPX_PAIR_LAUNCH(8, 4);
     else
-      hipLaunchKernelGGL((update_pair_kernel<2, kProd, kCons>), grid, block, 0, stream, pp,
-                         spec_dev, st, actions, out, B, T, reset_first);
+      CAMPX_PAIR_LAUNCH(CAMPX_PAIR_PROD, CAMPX_PAIR_CONS);
+#undef CAMPX_PAIR_LAUNCH
   } else if (s.n_dyn >= 3 && st.pair_table && !knob_no_table()) {
     constexpr int kProd = CAMPX_TUPLE_PROD, kCons = CAMPX_TUPLE_CONS, kEnvs = kProd * kWave;
     const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
@@ -3089,8 +3048,7 @@ int64_t campx_pair_table_bytes(const CampxSpec* spec) {
   int64_t n = CAMPX_N_ACTIONS;
   for (int d = 0; d < spec->n_dyn; ++d) n *= HW;
   if (spec->n_dyn == 2) {
-    int64_t bytes = 256 * (int64_t)sizeof(float) + n * (int64_t)sizeof(uint32_t);
-    if (n <= 65535) bytes += (n * (int64_t)sizeof(uint16_t) + 15) & ~(int64_t)15;  // chain table
+    const int64_t bytes = 256 * (int64_t)sizeof(float) + n * (int64_t)sizeof(uint32_t);
     return bytes <= (1 << 20) ? bytes : 0;
   }
   // three / four movers: 64-bit entries, read from global memory
@@ -3119,7 +3077,7 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev), total);
   if (e != hipSuccess) return hip_failed(e);
   // host scratch, widest arrays first so that nothing needs an alignment pad:
-  // table (256 floats + entries [+ chain]) | reward[n] | pos[2K][n] | act[n] | done[n] | perf[n] | trace[K][n]
+  // table (256 floats + entries) | reward[n] | pos[2K][n] | act[n] | done[n] | perf[n] | trace[K][n]
   const size_t table_bytes = ((size_t)bytes + 7) & ~(size_t)7;
   const size_t host_bytes = table_bytes + n * 4 + n * (size_t)(2 * K + 1 + 1 + 1 + K);
   char* host = static_cast<char*>(malloc(host_bytes));
@@ -3217,18 +3175,6 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
         lo |= ((tr & 0x7fu) << (7 * d)) | ((tr >> 7) << (28 + d));
       }
       h_entries64[i] = (uint64_t)lo | ((uint64_t)(over | (perf << 1) | ((uint32_t)idx << 3)) << 32);
-    }
-  }
-  if (K == 2 && n <= 65535) {
-    // chain table: where the NEXT frame's lookup starts, (cell0 * HW + cell1) * 5, with
-    // the rebuild from the art folded in for frames that end the episode
-    uint16_t* h_chain = reinterpret_cast<uint16_t*>(h_entries32 + n);
-    const uint32_t init = ((uint32_t)(spec->dyn_row0[0] * W + spec->dyn_col0[0]) * (uint32_t)HW +
-                           (uint32_t)(spec->dyn_row0[1] * W + spec->dyn_col0[1])) * CAMPX_N_ACTIONS;
-    for (size_t i = 0; i < n; ++i) {
-      const uint32_t en = h_entries32[i];
-      const uint32_t next = ((en & 0x7fu) * (uint32_t)HW + ((en >> 7) & 0x7fu)) * CAMPX_N_ACTIONS;
-      h_chain[i] = (uint16_t)(((en >> 16) & 1u) ? init : next);
     }
   }
   CAMPX_TRY(hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s));

@@ -238,10 +238,7 @@ int32_t campx_spec_compile(CampxSpec* spec_host, void* stream);
  * Two movers, uint32 entries:
  *   bits 0-6 cell of thing 0 after the frame, 7-13 cell of thing 1, 14/15 whether
  *   thing 0 / 1 is the character its cell shows, 16 done, 17-18 perf + 1,
- *   19-26 index into the reward list;
- * then, when n <= 65535, n uint16 "chain" entries (padded to 16 bytes): the index
- * (cell0' * rows*cols + cell1') * 5 the next frame's lookup starts from, the art's cells
- * when the frame ended the episode - the only thing the frame-to-frame dependency needs.
+ *   19-26 index into the reward list.
  * Three and four movers, uint64 entries:
  *   bits 7d..7d+6 cell of thing d after the frame, 28+d whether it is the character its
  *   cell shows, 32 done, 33-34 perf + 1, 35-42 index into the reward list.
