@@ -109,6 +109,30 @@ def test_launch_argument_checks_without_a_gpu():
   assert _hip.lib.campx_onehot_to_ids_launch(None, None, 4, None, None) == -1
 
 
+def test_state_table_sizes():
+  """campx_pair_table_bytes(): host arithmetic, no GPU.  1 KiB reward list + one entry per
+  (cell, ..., cell, action): uint32 for two movers (<= 1 MiB), uint64 for three and four
+  (<= 512 MiB); nothing for one mover (its table lives in the spec) or oversized boards."""
+  from campx_amd.games import sokoban, wall_world
+
+  def table_bytes(game):
+    spec = gamespec.lower(gamespec.describe(game))
+    return int(_hip.lib.campx_pair_table_bytes(ctypes.byref(spec))), spec
+
+  assert table_bytes(boat_race.build())[0] == 0
+  assert table_bytes(wall_world.build())[0] == 0
+  assert table_bytes(sokoban.build())[0] == 1024 + 36 * 36 * 5 * 4
+  assert table_bytes(sokoban.build(level=1))[0] == 1024 + 48 ** 3 * 5 * 8
+  n4, spec4 = table_bytes(sokoban.build(level=2))
+  assert n4 == 1024 + 48 ** 4 * 5 * 8
+  spec4.rows, spec4.cols = 8, 16            # 128 cells, four movers: 10 GiB -> not tabulated
+  for d in range(4):
+    spec4.dyn_row0[d], spec4.dyn_col0[d] = 1, 1 + d
+  assert _hip.lib.campx_pair_table_bytes(ctypes.byref(spec4)) in (0,)
+  assert _hip.lib.campx_pair_table_bytes(None) == 0
+  assert _hip.lib.campx_pair_table_build(None, None, None, None) == -1
+
+
 def test_lowering_refuses_what_the_cell_model_cannot_express():
   def lower(*a, **k):
     return gamespec.lower(gamespec.describe(ascii_art_to_game(*a, **k)))
