@@ -1919,6 +1919,10 @@ struct RenderParams {
 //   2 waves, 2 KiB, remap      172.7 / 1873.7 / 363.6   <- default
 //   4 waves, 4 KiB, remap      190.3 / 2099.3 / 362.3
 //   2 waves, 4 KiB, remap      177.7 / 1984.6 / 356.0
+// Again with settled clocks (250 launches after 50 warm-up ones, gpurun_out/t10, remap on):
+//   2 waves x 2 KiB 164.8 / 1842 / 338.1 (default)   4 x 2: 165.6 / 1873 / 340.0
+//   1 x 2: 166.1 / 1893 / 345.3   2 x 4: 180.2 / 1978 / 360.9   1 x 4: 179.4 / 2008 / 371.4
+//   4 x 1: 187.7 / 1994 / 388.7
 #ifndef CAMPX_RENDER_WAVES
 #define CAMPX_RENDER_WAVES 2
 #endif
