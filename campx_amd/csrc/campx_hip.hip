@@ -2648,15 +2648,18 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
     rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
     rp.dyn_off[d] = s.dyn_layer[d] * HW;
   }
-  constexpr int kWin = CAMPX_RENDER_WIN;  // KiB windows per wave: 1 / 2 / 4 measured 0.227 / 0.197 / 0.211 ms
-  const uint32_t span = 1024u * (uint32_t)(kWin * kRenderWaves);
+  // KiB of the int8 image per wave: what a wave WRITES is what counts (2 KiB: 164.8 us, 4 KiB:
+  // 180.2 us for the boat race), so the 16-bit formats take half the window
+  constexpr int kWin = CAMPX_RENDER_WIN, kWin16 = kWin > 1 ? kWin / 2 : 1;
+  const bool sixteen = !is_board && fmt != 0;
+  const uint32_t span = 1024u * (uint32_t)((sixteen ? kWin16 : kWin) * kRenderWaves);
   // rounded up to a multiple of 8 for the XCD remap; surplus blocks exit at once
   const dim3 grid((((rp.slab_bytes + span - 1u) / span) + 7u) & ~7u, (unsigned)T);
   const int64_t n_rows = (int64_t)T * B;
   const bool nt = knob_store_nt();
 #define CAMPX_RENDER4(KK, BOARD, NT, FMT)                                                   \
-  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, kWin, FMT>), grid, dim3(kRenderWaves * kWave), 0, stream, \
-                     rp, spec_dev, trace, dst, n_rows)
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT>), grid,      \
+                     dim3(kRenderWaves * kWave), 0, stream, rp, spec_dev, trace, dst, n_rows)
 #define CAMPX_RENDER3(KK, BOARD, NT)                               \
   do {                                                             \
     if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 1);       \
