@@ -2626,9 +2626,12 @@ void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
                      rb, spec_dev, st, actions, out, B, T, reset_first, 0, 0);
 }
 
+// `trace` points at the first frame to render, `T` frames from there; `plane_rows` is the
+// distance (in rows = environments) between two moving things' planes of the trace, i.e.
+// B times the number of frames the trace holds.
 int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
-                      int8_t* dst, int64_t B, int32_t T, bool is_board, int fmt,
-                      hipStream_t stream) {
+                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, bool is_board,
+                      int fmt, hipStream_t stream) {
   const int HW = s.rows * s.cols;
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -2655,7 +2658,7 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   const uint32_t span = 1024u * (uint32_t)((sixteen ? kWin16 : kWin) * kRenderWaves);
   // rounded up to a multiple of 8 for the XCD remap; surplus blocks exit at once
   const dim3 grid((((rp.slab_bytes + span - 1u) / span) + 7u) & ~7u, (unsigned)T);
-  const int64_t n_rows = (int64_t)T * B;
+  const int64_t n_rows = plane_rows;
   const bool nt = knob_store_nt();
 #define CAMPX_RENDER4(KK, BOARD, NT, FMT)                                                   \
   hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT>), grid,      \
@@ -2690,13 +2693,21 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
 
 // Can this call take the two-kernel path?  Frames must be stored back to back and be
 // whole 16-byte chunks, and a chunk may span at most two rows.
+// Strides of 0: every frame overwrites the first slot, so only the last survives - the
+// two-kernel path then renders just that one from the last row of the trace.
+bool last_frame_only(const CampxOutputs& out) {
+  return out.obs_t_stride == 0 && (!out.board || out.board_t_stride == 0) &&
+         out.obs_format == CAMPX_OBS_INT8;
+}
+
 bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T) {
   const int64_t HW = (int64_t)s.rows * s.cols, LHW = HW * s.n_layers;
   if (!out.trace || !s.render_valid || T <= 0 || T > 65535 || knob_no_split()) return false;
   if (LHW < 16 || (B * LHW) % 16 != 0 || B * LHW >= (1ll << 32)) return false;
-  if (out.obs_t_stride != B * LHW) return false;
-  if (out.board && (HW < 16 || (B * HW) % 16 != 0 || out.board_t_stride != B * HW)) return false;
-  return true;
+  if (out.board && (HW < 16 || (B * HW) % 16 != 0)) return false;
+  // every frame kept, back to back - or only the last one (strides 0)
+  const bool every = out.obs_t_stride == B * LHW && (!out.board || out.board_t_stride == B * HW);
+  return every || last_frame_only(out);
 }
 
 // Shape of the update kernels' workgroups: producer and consumer waves (A/B builds can
@@ -2795,9 +2806,15 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
 
 int32_t launch_renders(const CampxSpec& s, const CampxSpec* spec_dev, CampxOutputs out, int64_t B,
                        int32_t T, hipStream_t stream) {
-  int32_t rc = launch_render(s, spec_dev, out.trace, out.obs, B, T, false, out.obs_format, stream);
+  const int64_t plane_rows = (int64_t)T * B;
+  const uint8_t* first = out.trace;
+  if (last_frame_only(out)) {
+    first += (int64_t)(T - 1) * B;
+    T = 1;
+  }
+  int32_t rc = launch_render(s, spec_dev, first, out.obs, B, T, plane_rows, false, out.obs_format, stream);
   if (rc != CAMPX_OK) return rc;
-  if (out.board) rc = launch_render(s, spec_dev, out.trace, out.board, B, T, true, 0, stream);
+  if (out.board) rc = launch_render(s, spec_dev, first, out.board, B, T, plane_rows, true, 0, stream);
   return rc;
 }
 

@@ -306,7 +306,7 @@ class FusedGame(object):
         perf=(torch.empty((T, B), dtype=torch.int8, device=dev)
               if self.has_perf else None),
         trace=(torch.empty((self.n_dyn, T, B), dtype=torch.uint8, device=dev)
-               if keep_obs and split else None))
+               if split else None))
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True,
               reset_first=False, want_board=False, obs_dtype=torch.int8,
@@ -317,8 +317,9 @@ class FusedGame(object):
       actions: int tensor [T, B] of action ids.
       obs: optional int8 [T, B, L, H, W] buffer to write every frame's
           layered board into (allocated if None and `keep_obs`).  With
-          `keep_obs=False` every frame is still rendered and written, but into
-          the engine's single-frame buffer, so only the last one survives.
+          `keep_obs=False` only the last frame is kept, in the engine's single-frame
+          buffer (the two-kernel path renders just that one; the single fused kernel
+          writes every frame over the previous one).
       board: optional int8 [T, B, H, W] buffer for the flat boards.
       reset_first: rebuild all environments from the art before frame 0 (a new
           episode, as `make_game()` per episode in examples/reinforce.py:122).

@@ -186,7 +186,9 @@ typedef struct CampxOutputs {
                          stored back to back (obs_t_stride == B*L*rows*cols) and are whole
                          16-byte multiples, the library runs the update pass and the render as
                          two kernels, which streams the observations to HBM faster (DESIGN.md
-                         "Kernels").  Written only on that path. */
+                         "Kernels"); with strides of 0 (only the last frame survives) it
+                         renders just that frame from the last row of the trace.  Written
+                         only on that path. */
   int32_t obs_format; /* element type of `obs` (obs_t_stride counts elements):
                          CAMPX_OBS_INT8 0/1 bytes (the default, 0);
                          CAMPX_OBS_F16 / CAMPX_OBS_BF16: 0.0 / 1.0 in that format, the tensor

@@ -198,11 +198,25 @@ def test_lazy_validation_flag_in_host_mapped_memory():
   game.fused.check_actions()
 
 
-def test_keep_obs_false_leaves_last_frame(golden):
-  gold = golden('boat_race')
-  game, _ = _fused('boat_race', gold['actions'].shape[1])
-  out = game.rollout(torch.from_numpy(gold['actions']), keep_obs=False)
+@pytest.mark.parametrize('name', ['boat_race', 'sokoban', 'sokoban_l2', 'demo4'])
+def test_keep_obs_false_leaves_last_frame(name, golden):
+  """Only the last frame's observation (and board) is kept - the two-kernel path renders
+  just that one from the last row of the trace; the per-frame scalars are all there; and
+  the state carries into the next launch."""
+  gold = golden(name)
+  T, N = gold['actions'].shape
+  game, _ = _fused(name, N)
+  half = T // 2
+  out = game.rollout(torch.from_numpy(gold['actions'][:half]), keep_obs=False, want_board=True)
+  assert out['obs'].shape == gold['layered'][0].shape
+  assert _same(out['obs'].cpu().numpy(), gold['layered'][half])
+  assert _same(out['board'].cpu().numpy(), gold['board'][half])
+  assert _same(out['discount'].cpu().numpy(), gold['discount'][:half])
+  assert _same(out['done'].cpu().numpy(), gold['done'][:half])
+  out = game.rollout(torch.from_numpy(gold['actions'][half:]), keep_obs=False)
   assert _same(out['obs'].cpu().numpy(), gold['layered'][-1])
+  if out['reward'] is not None:
+    assert _same(out['reward'].cpu().numpy(), gold['reward'][half:])
 
 
 def test_reset_first_starts_new_episode(golden):
