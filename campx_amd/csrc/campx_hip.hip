@@ -2183,10 +2183,13 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     load_backdrop(spec->backdrop);
   };
 
-  auto paint_and_emit = [&](int8_t* obs_dst, int8_t* board_dst) {
+  // `emit` false: a frame whose observation nobody will see (time strides 0 and not the last
+  // frame) - only the sprites that paint into the backdrop (state) are painted.
+  auto paint_and_emit = [&](int8_t* obs_dst, int8_t* board_dst, bool emit) {
     // Things back to front.  Sprites behind the first drape paint into the backdrop itself
     // (rendering.py:128,150); the frame's board starts as a copy of it.
-    for (int z = 0; z < N; ++z) {   // everything about z is scalar
+    const int n_paint = emit ? N : first_drape;
+    for (int z = 0; z < n_paint; ++z) {   // everything about z is scalar
       // (loops over `base` have scalar trip counts: one pass for boards up to 1 024 cells
       // here, for things up to 64 cells below)
       if (z == first_drape)
@@ -2214,6 +2217,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
         }
       }
     }
+    if (!emit) return;
     // layers by equality (rendering.py:204-215): eight cells per lane, one 8-byte store per
     // layer plane.  A board of 8k + 4 cells: the last lane takes the last eight cells, four of
     // which its neighbour also writes (same values), so every lane runs the same code.
@@ -2264,6 +2268,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
   int bad = 0;
   int reward_buf = 0;
   uint64_t over_mask = 0;
+  // time strides 0: every frame would overwrite the same slot - emit only the last one
+  const bool last_only = out.obs_t_stride == 0 && (!kBoard || out.board_t_stride == 0);
   // frame -1 (emit_first): the its_showtime() observation, no update pass, written where
   // frame 0 goes (one call site for the paint-and-emit code)
   for (int t = emit_first ? -1 : 0; t < T; ++t) {
@@ -2295,7 +2301,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     if (!showtime) ret += reward;
     const int64_t slot = showtime ? 0 : t;
     paint_and_emit(out.obs + slot * out.obs_t_stride + env * LHW,
-                   kBoard ? out.board + slot * out.board_t_stride + env * HW : nullptr);
+                   kBoard ? out.board + slot * out.board_t_stride + env * HW : nullptr,
+                   !last_only || t == T - 1);
     if (!showtime) {
       // the frame's scalars wait in lane (t mod 64) of a register / bit of a scalar mask and
       // go out once per 64 frames, one store instruction per array

@@ -56,6 +56,24 @@ def test_zoo_golden_rollout_and_play(name, golden):
     assert _same(discount.cpu().numpy(), gold['discount'][t])
 
 
+@pytest.mark.parametrize('name', sorted(SHAPE_GAMES))
+def test_keep_obs_false_keeps_the_last_frame_and_the_trails(name, golden):
+  """Frames nobody sees are not expanded, but the sprites that paint into the backdrop are
+  still painted every frame: the last frame shows every trail."""
+  gold = golden(name)
+  T, N = gold['actions'].shape
+  game, _ = _game(N, name)
+  half = T // 2
+  out = game.rollout(torch.from_numpy(gold['actions'][:half]), keep_obs=False, want_board=True)
+  assert _same(out['obs'].cpu().numpy(), gold['layered'][half])
+  assert _same(out['board'].cpu().numpy(), gold['board'][half])
+  assert _same(out['reward'].cpu().numpy(), gold['reward'][:half])
+  assert _same(out['done'].cpu().numpy(), gold['done'][:half])
+  out = game.rollout(torch.from_numpy(gold['actions'][half:]), keep_obs=False)
+  assert _same(out['obs'].cpu().numpy(), gold['layered'][-1])
+  assert _same(out['discount'].cpu().numpy(), gold['discount'][half:])
+
+
 @pytest.mark.parametrize('name', ZOO)
 @pytest.mark.parametrize('batch', [5, 130])
 def test_zoo_random_streams_vs_oracle(name, batch):
