@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
                                                         const int8_t* __restrict__ actions,
                                                         CampxOutputs out, int64_t B, int32_t T,
                                                         int32_t reset_first, int32_t emit_first,
-                                                        int32_t xcd_mode) {
+                                                        int32_t xcd_mode, int64_t trace_plane) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
   const int lane = threadIdx.x;
   const int H = rb.rows, W = rb.cols, HW = H * W, L = rb.n_layers, LHW = L * HW;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
         for (int k = 0; k < K; ++k) {
           const int cell = sel<K>(pos.cell, k);
           const uint32_t vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
-          out.trace[((int64_t)k * T + t) * B + env] = pack_trace(cell, vis);
+          out.trace[(int64_t)k * trace_plane + (int64_t)t * B + env] = pack_trace(cell, vis);
         }
       }
     } else {
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first) {
+    int32_t reset_first, int64_t trace_plane) {
   constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kLdsEntries: n_entries
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
         if (g > 0) {
           const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
           const int n = (T - t0 < kG) ? T - t0 : kG;
-          const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
+          const int64_t plane = trace_plane;  // from one moving thing's trace to the next's
           constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
   #pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
           for (int it = 0; it < kItA; ++it) {
@@ -1587,7 +1587,7 @@ template <int K, int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              CAMPX_TUPLE_MINWAVES) void update_tuple_kernel(
     TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B,
-    int32_t T, int32_t reset_first) {
+    int32_t T, int32_t reset_first, int64_t trace_plane) {
   constexpr int kLoad = update_loaders(kProd), kG = kTupleGroup;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   __shared__ float reward_list[256];
@@ -1664,7 +1664,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
       if (g > 0) {
         const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
         const int n = (T - t0 < kG) ? T - t0 : kG;
-        const int64_t plane = (int64_t)T * B;  // one moving thing's trace plane
+        const int64_t plane = trace_plane;  // from one moving thing's trace to the next's
         // ---- float streams: item = (frame j, 4 environments)
         constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
 #pragma unroll 1
@@ -2409,6 +2409,22 @@ bool knob_no_step() {
   }();
   return off;
 }
+// Largest trace (bytes) one update + render pair of a rollout works on (launch_split).
+int64_t knob_trace_chunk_bytes() {
+  static const int64_t n = [] {
+    const char* v = getenv("CAMPX_TRACE_CHUNK_MB");
+    return (int64_t)(v && *v ? atoll(v) : 16) << 20;
+  }();
+  return n;
+}
+// ... and the largest trace a rollout may have and still run as one pair.
+int64_t knob_trace_whole_bytes() {
+  static const int64_t n = [] {
+    const char* v = getenv("CAMPX_TRACE_WHOLE_MB");
+    return (int64_t)(v && *v ? atoll(v) : 28) << 20;
+  }();
+  return n;
+}
 int knob_pair_mode() {
   static const int m = [] {
     const char* v = getenv("CAMPX_PAIR_MODE");
@@ -2474,7 +2490,8 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   const bool nt = knob_store_nt() && out.obs_t_stride != 0;
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
   hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
-                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd())
+                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd(), \
+                     (int64_t)T * B)
 #define CAMPX_LAUNCH(BOARD, NT) CAMPX_LAUNCH_E(BOARD, NT, 64)
   if (board) {
     if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);
@@ -2625,12 +2642,12 @@ int32_t launch_step_tuple(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
 template <int K>
 void launch_trace_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
-                    int32_t reset_first, hipStream_t stream) {
+                    int32_t reset_first, int64_t trace_plane, hipStream_t stream) {
   const size_t shmem = lds_bytes(s, false, 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const RuleBlock rb = make_rule_block(s);
   hipLaunchKernelGGL((rollout_kernel<K, false, false, kWave, true>), grid, block, shmem, stream,
-                     rb, spec_dev, st, actions, out, B, T, reset_first, 0, 0);
+                     rb, spec_dev, st, actions, out, B, T, reset_first, 0, 0, trace_plane);
 }
 
 // `trace` points at the first frame to render, `T` frames from there; `plane_rows` is the
@@ -2743,9 +2760,13 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 #define CAMPX_TUPLE_CONS 2
 #endif
 
+// `trace_plane`: rows (environments) from one moving thing's plane of the trace to the
+// next's - B times the frames the whole trace holds, which is more than T when the caller
+// runs a launch in chunks.
 int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
-                     int32_t reset_first, bool use_table, hipStream_t stream) {
+                     int32_t reset_first, bool use_table, int64_t trace_plane,
+                     hipStream_t stream) {
   // 512-environment workgroups (twice the row piece per store) once there are enough
   // environments to give every CU one; 256-environment workgroups below that
   const bool big = B >= (int64_t)kBigEnvs * knob_big_workgroups();
@@ -2777,10 +2798,10 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
         block(((PROD) + (CONS) + update_loaders(PROD)) * kWave);                               \
     if (in_lds)                                                                                \
       hipLaunchKernelGGL((update_pair_kernel<true, PROD, CONS>), grid, block, shmem, stream,   \
-                         pp, spec_dev, st, actions, out, B, T, reset_first);                   \
+                         pp, spec_dev, st, actions, out, B, T, reset_first, trace_plane);      \
     else                                                                                       \
       hipLaunchKernelGGL((update_pair_kernel<false, PROD, CONS>), grid, block, 0, stream, pp,  \
-                         spec_dev, st, actions, out, B, T, reset_first);                       \
+                         spec_dev, st, actions, out, B, T, reset_first, trace_plane);          \
   } while (0)
     if (big)
       CAMPX_PAIR_LAUNCH(8, 4);
@@ -2794,16 +2815,16 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
     const TupleParams tp = make_tuple_params(s);
     if (s.n_dyn == 3)
       hipLaunchKernelGGL((update_tuple_kernel<3, kProd, kCons>), grid, block, 0, stream, tp, st,
-                         actions, out, B, T, reset_first);
+                         actions, out, B, T, reset_first, trace_plane);
     else
       hipLaunchKernelGGL((update_tuple_kernel<4, kProd, kCons>), grid, block, 0, stream, tp, st,
-                         actions, out, B, T, reset_first);
+                         actions, out, B, T, reset_first, trace_plane);
   } else {
     switch (s.n_dyn) {
-      case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
-      case 2: launch_trace_k<2>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
-      case 3: launch_trace_k<3>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
-      default: launch_trace_k<4>(s, spec_dev, st, actions, out, B, T, reset_first, stream); break;
+      case 1: launch_trace_k<1>(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream); break;
+      case 2: launch_trace_k<2>(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream); break;
+      case 3: launch_trace_k<3>(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream); break;
+      default: launch_trace_k<4>(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream); break;
     }
   }
   hipError_t e = hipGetLastError();
@@ -2812,8 +2833,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
 }
 
 int32_t launch_renders(const CampxSpec& s, const CampxSpec* spec_dev, CampxOutputs out, int64_t B,
-                       int32_t T, hipStream_t stream) {
-  const int64_t plane_rows = (int64_t)T * B;
+                       int32_t T, int64_t plane_rows, hipStream_t stream) {
   const uint8_t* first = out.trace;
   if (last_frame_only(out)) {
     first += (int64_t)(T - 1) * B;
@@ -2828,9 +2848,42 @@ int32_t launch_renders(const CampxSpec& s, const CampxSpec* spec_dev, CampxOutpu
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
-  const int32_t rc = launch_update(s, spec_dev, st, actions, out, B, T, reset_first, use_table, stream);
-  if (rc != CAMPX_OK) return rc;
-  return launch_renders(s, spec_dev, out, B, T, stream);
+  const int64_t plane = (int64_t)T * B;
+  // The render kernel runs at the write ceiling only while the trace it reads stays cached
+  // (boat race, B = 65 536: 6.96 TB/s with a 26 MB trace at T = 400, 5.35 TB/s with 65 MB at
+  // T = 1 000; the same at B = 524 288, T = 100): run long launches as chunks of frames,
+  // update pass and render alternating, each chunk's trace at most 16 MB (CAMPX_TRACE_CHUNK_MB).
+  // (us per launch, render kernels only, no chunks / 28 / 16 / 8 MB: T = 1 000: 2 265 / 1 820 /
+  // 1 641 / 1 644; B = 524 288: 1 739 / 1 504 / 1 314 / 1 316 - gpurun_out/t16.  A 26 MB trace
+  // in one piece is still at full speed, so launches up to 28 MB (CAMPX_TRACE_WHOLE_MB) are not cut.)
+  const int64_t per_frame = (int64_t)s.n_dyn * B;
+  int64_t chunk = knob_trace_chunk_bytes() / per_frame;
+  chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
+  const bool whole = per_frame * T <= knob_trace_whole_bytes() || T <= chunk;
+  if (last_frame_only(out) || whole) {
+    const int32_t rc = launch_update(s, spec_dev, st, actions, out, B, T, reset_first, use_table,
+                                     plane, stream);
+    if (rc != CAMPX_OK) return rc;
+    return launch_renders(s, spec_dev, out, B, T, plane, stream);
+  }
+  const int64_t elem = out.obs_format == CAMPX_OBS_INT8 ? 1 : 2;
+  for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+    const int32_t n = (int32_t)(T - t0 < chunk ? T - t0 : chunk);
+    CampxOutputs part = out;
+    part.obs = out.obs + t0 * out.obs_t_stride * elem;
+    if (out.board) part.board = out.board + t0 * out.board_t_stride;
+    if (out.reward) part.reward = out.reward + t0 * B;
+    if (out.discount) part.discount = out.discount + t0 * B;
+    if (out.done) part.done = out.done + t0 * B;
+    if (out.perf) part.perf = out.perf + t0 * B;
+    part.trace = out.trace + t0 * B;
+    int32_t rc = launch_update(s, spec_dev, st, actions + t0 * B, part, B, n,
+                               t0 == 0 ? reset_first : 0, use_table, plane, stream);
+    if (rc != CAMPX_OK) return rc;
+    rc = launch_renders(s, spec_dev, part, B, n, plane, stream);
+    if (rc != CAMPX_OK) return rc;
+  }
+  return CAMPX_OK;
 }
 
 int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
@@ -3162,9 +3215,9 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
     // the interpreter in trace mode: positions, visibility, reward, done, perf
     const int8_t* acts = reinterpret_cast<const int8_t*>(dev + off_act);
     switch (K) {
-      case 2: launch_trace_k<2>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, s); break;
-      case 3: launch_trace_k<3>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, s); break;
-      default: launch_trace_k<4>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, s); break;
+      case 2: launch_trace_k<2>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, (int64_t)n, s); break;
+      case 3: launch_trace_k<3>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, (int64_t)n, s); break;
+      default: launch_trace_k<4>(*spec, spec_dev, st, acts, out, (int64_t)n, 1, 0, (int64_t)n, s); break;
     }
     CAMPX_TRY(hipGetLastError());
   }
@@ -3239,7 +3292,7 @@ int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   if (!spec_host->render_valid) return CAMPX_ESPEC;
   const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 && !knob_no_table();
   return launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
-                       static_cast<hipStream_t>(stream));
+                       (int64_t)T * B, static_cast<hipStream_t>(stream));
 }
 
 int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxOutputs out,
@@ -3251,7 +3304,7 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   if (v != CAMPX_OK) return v;
   CampxOutputs probe = out;   // the conditions of the two-kernel path, frames back to back
   if (!split_ok(*spec_host, probe, B, T)) return CAMPX_EINVAL;
-  return launch_renders(*spec_host, spec_dev, out, B, T, static_cast<hipStream_t>(stream));
+  return launch_renders(*spec_host, spec_dev, out, B, T, (int64_t)T * B, static_cast<hipStream_t>(stream));
 }
 
 int32_t campx_shape_spec_size(void) { return (int32_t)sizeof(CampxShapeSpec); }
