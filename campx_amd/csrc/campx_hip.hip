@@ -1891,6 +1891,7 @@ struct RenderParams {
   uint32_t R;                 // row bytes
   uint32_t m, sh1, sh2;       // exact n / R for 32-bit n (Granlund-Montgomery)
   uint32_t slab_bytes;        // B * R, a multiple of 16
+  uint32_t shift_base, shift_slab;  // (address of frame 0) and slab_bytes modulo the window span
   int32_t n_dyn, is_board, cells;
   int64_t B;
   int32_t dyn_char[CAMPX_MAX_DYN];
@@ -1949,8 +1950,17 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
 #if CAMPX_RENDER_XCD
   bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);     // gridDim.x is a multiple of 8
 #endif
-  const uint32_t woff0 = (bx * (uint32_t)kRenderWaves + (uint32_t)wave) * (1024u * kWin);
-  if (woff0 >= rp.slab_bytes) return;
+  // Windows are aligned in MEMORY, not in the frame: when a frame does not start on a
+  // window boundary (B * R not a multiple of the span) they start `shift` bytes before it,
+  // so every store of every frame is still one aligned KiB (499 984 environments: 4.2 TB/s
+  // with frame-aligned windows).  Offsets are modulo 2^32: the head window's start is
+  // "negative", its lanes before the frame fail the one `off < slab_bytes` test below.
+  const uint32_t span = 1024u * kWin;
+  const uint32_t shift = (rp.shift_base + blockIdx.y * rp.shift_slab) & (span - 1u);
+  const uint32_t widx = bx * (uint32_t)kRenderWaves + (uint32_t)wave;
+  if ((uint64_t)widx * span >= (uint64_t)rp.slab_bytes + shift) return;
+  const uint32_t woff0 = widx * span - shift;
+  const uint32_t wlo = widx * span < shift ? 0u : woff0;   // first byte inside the frame
   int8_t* win0 = lds + wave * (kWin * 1024);
   uint16_t* scen_off = scen_off_all[wave];
   const int R = (int)rp.R;
@@ -1961,9 +1971,8 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
 
   // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear).
   // Their trace bytes come from HBM / L2: issue those loads first.
-  const uint32_t span = 1024u * kWin;
-  const uint32_t whi = __umulhi(rp.m, woff0);
-  const uint32_t first_row = (((woff0 - whi) >> rp.sh1) + whi) >> rp.sh2;
+  const uint32_t whi = __umulhi(rp.m, wlo);
+  const uint32_t first_row = (((wlo - whi) >> rp.sh1) + whi) >> rp.sh2;
   const uint32_t wend = (woff0 + span - 1u < rp.slab_bytes) ? woff0 + span - 1u : rp.slab_bytes - 1u;
   const uint32_t ehi = __umulhi(rp.m, wend);
   const uint32_t last_row = (((wend - ehi) >> rp.sh1) + ehi) >> rp.sh2;
@@ -2679,9 +2688,15 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   // 180.2 us for the boat race), so the 16-bit formats take half the window
   constexpr int kWin = CAMPX_RENDER_WIN, kWin16 = kWin > 1 ? kWin / 2 : 1;
   const bool sixteen = !is_board && fmt != 0;
-  const uint32_t span = 1024u * (uint32_t)((sixteen ? kWin16 : kWin) * kRenderWaves);
+  const uint32_t wspan = 1024u * (uint32_t)(sixteen ? kWin16 : kWin);   // one wave's windows
+  const uint32_t span = wspan * kRenderWaves;                            // one block's
+  if (!sixteen) {   // windows aligned in memory (the 16-bit formats keep frame-aligned windows)
+    rp.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & (wspan - 1u));
+    rp.shift_slab = rp.slab_bytes & (wspan - 1u);
+  }
+  const uint64_t reach = (uint64_t)rp.slab_bytes + ((rp.shift_base | rp.shift_slab) ? wspan - 1u : 0u);
   // rounded up to a multiple of 8 for the XCD remap; surplus blocks exit at once
-  const dim3 grid((((rp.slab_bytes + span - 1u) / span) + 7u) & ~7u, (unsigned)T);
+  const dim3 grid((unsigned)((((reach + span - 1u) / span) + 7u) & ~(uint64_t)7), (unsigned)T);
   const int64_t n_rows = plane_rows;
   const bool nt = knob_store_nt();
 #define CAMPX_RENDER4(KK, BOARD, NT, FMT)                                                   \
@@ -2727,7 +2742,7 @@ bool last_frame_only(const CampxOutputs& out) {
 bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T) {
   const int64_t HW = (int64_t)s.rows * s.cols, LHW = HW * s.n_layers;
   if (!out.trace || !s.render_valid || T <= 0 || T > 65535 || knob_no_split()) return false;
-  if (LHW < 16 || (B * LHW) % 16 != 0 || B * LHW >= (1ll << 32)) return false;
+  if (LHW < 16 || (B * LHW) % 16 != 0 || B * LHW >= (1ll << 32) - 65536) return false;
   if (out.board && (HW < 16 || (B * HW) % 16 != 0)) return false;
   // every frame kept, back to back - or only the last one (strides 0)
   const bool every = out.obs_t_stride == B * LHW && (!out.board || out.board_t_stride == B * HW);
