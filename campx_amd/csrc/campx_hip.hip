@@ -1014,8 +1014,10 @@ struct ActionLoader {
   static_assert(kPairs >= 1 && (kChunk / 2) * kVecPerRow % kLanes == 0, "loader shape");
   u32x4 pend[2 * kPairs];
 
-  // 16-byte loads; rows past T and environments past B are clamped to valid ones (no
-  // branch between the loads) and neutralised in land().
+  // 16-byte loads (byte-aligned unless B % 16 == 0: unaligned 16-byte accesses are legal on
+  // this stack, tools/probes/unaligned_probe.hip); rows past T and groups of 16 environments
+  // that are not wholly below B are clamped to valid ones (no branch between the loads) and
+  // redone or neutralised in land().
   // `lane` counts over all loader waves: 0 .. kLanes-1
   __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
                                         int t0, int64_t env0, int lane) {
@@ -1024,7 +1026,7 @@ struct ActionLoader {
       const int v = lane + i * kLanes;
       const int rp = v / kVecPerRow, q = v % kVecPerRow;
       int64_t e = env0 + 16 * q;
-      e = e < B ? e : 0;
+      e = e + 16 <= B ? e : 0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int row = t0 + 2 * rp + h;
@@ -1034,16 +1036,41 @@ struct ActionLoader {
     }
   }
 
-  __device__ __forceinline__ int land(int8_t* staged, int64_t B, int32_t T, int t0, int64_t env0,
-                                      int lane) {
+  __device__ __forceinline__ int land(int8_t* staged, const int8_t* __restrict__ actions, int64_t B,
+                                      int32_t T, int t0, int64_t env0, int lane) {
     int bad = 0;
 #pragma unroll
     for (int i = 0; i < kPairs; ++i) {
       const int v = lane + i * kLanes;
       const int rp = v / kVecPerRow, q = v % kVecPerRow;
-      const bool here = env0 + 16 * q < B;
+      const int64_t e = env0 + 16 * q;
+      const bool here = e + 16 <= B;
       const bool real0 = here && (t0 + 2 * rp < T), real1 = here && (t0 + 2 * rp + 1 < T);
-      const u32x4 lo = pend[2 * i], hi = pend[2 * i + 1];
+      u32x4 lo = pend[2 * i], hi = pend[2 * i + 1];
+      if (!here && e < B) {
+        // the batch's last, partial group of environments (one lane of the last workgroup):
+        // byte by byte, "stay" past the end
+        uint32_t l[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+        uint32_t h[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+        for (int k = 0; e + k < B; ++k) {
+          const int sh = 8 * (k & 3);
+          if (t0 + 2 * rp < T) {
+            const uint32_t a = (uint8_t)actions[(int64_t)(t0 + 2 * rp) * B + e + k];
+            l[k >> 2] = (l[k >> 2] & ~(0xffu << sh)) | (a << sh);
+          }
+          if (t0 + 2 * rp + 1 < T) {
+            const uint32_t a = (uint8_t)actions[(int64_t)(t0 + 2 * rp + 1) * B + e + k];
+            h[k >> 2] = (h[k >> 2] & ~(0xffu << sh)) | (a << sh);
+          }
+        }
+        uint32_t out[4];
+        for (int k = 0; k < 4; ++k) out[k] = clamp_ids(l[k]) | (clamp_ids(h[k]) << 4);
+        const u32x4 packed = {out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
+        const u32x4 l4 = {l[0], l[1], l[2], l[3]}, h4 = {h[0], h[1], h[2], h[3]};
+        bad += count_bad16(l4) + count_bad16(h4);
+        continue;
+      }
       const uint32_t l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
       uint32_t out[4];
 #pragma unroll
@@ -1056,27 +1083,6 @@ struct ActionLoader {
     return bad;
   }
 };
-
-// Batches that are not a multiple of 16 environments: byte by byte, synchronously.
-template <int kEnvs, int kLoaders>
-__device__ __forceinline__ int stage_bytes(int8_t* staged, const int8_t* __restrict__ actions,
-                                           int64_t B, int32_t T, int t0, int64_t env0, int lane) {
-  int bad = 0;
-  for (int i = lane; i < (kChunk / 2) * kEnvs; i += kWave * kLoaders) {
-    const int rp = i / kEnvs, e = i % kEnvs;
-    uint32_t packed = 0;
-    for (int h = 0; h < 2; ++h) {
-      const int row = t0 + 2 * rp + h;
-      const bool real = (row < T) && (env0 + e < B);
-      const int8_t a = real ? actions[(int64_t)row * B + env0 + e] : (int8_t)4;
-      const bool ok = (unsigned)a <= 4u;
-      bad += ok ? 0 : 1;
-      packed |= (ok ? (uint32_t)a : 4u) << (4 * h);
-    }
-    staged[i] = (int8_t)packed;
-  }
-  return bad;
-}
 
 // The action of frame j (0 .. kGroup-1) of a group that starts at frame t0 of its chunk,
 // for environment `le` of the workgroup.
@@ -1138,7 +1144,6 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
   const int W = mp.cols, HW = mp.rows * mp.cols;
   const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
-  const bool wide = (B & 15) == 0;  // 16-byte global accesses need 16-environment alignment
 
   const int cell0 = mp.row0 * W + mp.col0;
   constexpr int kRowBytes = CAMPX_N_ACTIONS * (int)sizeof(uint2);
@@ -1153,12 +1158,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
-    if (wide) {
-      ld.issue(actions, B, T, 0, env0, llane);
-      bad += ld.land(staged[0], B, T, 0, env0, llane);
-    } else {
-      bad += stage_bytes<E, kLoad>(staged[0], actions, B, T, 0, env0, llane);
-    }
+    ld.issue(actions, B, T, 0, env0, llane);
+    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
   }
 
   const int le = wave * kWave + lane;  // producers: this lane's environment in the workgroup
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
                                       (y4.y >> 24) & 1u};
               const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (wide) {
+              if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
                 if (out.reward) store16_update(out.reward + at, r4);
                 if (out.discount) {
                   const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
@@ -1268,7 +1269,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                               (((hi >> 25) & 3u) - 1u) & 0xffu);
               }
               const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (wide) {
+              if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
                 const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
                 store16_update(out.trace + at, t4);
                 if (out.done) {
@@ -1299,13 +1300,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
         const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
         const int t_next = (c + 1) * kChunk;
         if (t_next < T) {
-          if (wide) {
-            if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
-            if (phase == kGroupsPerChunk - 1)
-              bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
-          } else if (phase == 0) {
-            bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
-          }
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
         }
       
       __syncthreads();
@@ -1361,7 +1358,6 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
   const int W = pp.cols, HW = pp.rows * pp.cols;
   const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
-  const bool wide = (B & 15) == 0;
 
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
@@ -1372,12 +1368,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
-    if (wide) {
-      ld.issue(actions, B, T, 0, env0, llane);
-      bad += ld.land(staged[0], B, T, 0, env0, llane);
-    } else {
-      bad += stage_bytes<E, kLoad>(staged[0], actions, B, T, 0, env0, llane);
-    }
+    ld.issue(actions, B, T, 0, env0, llane);
+    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
   }
 
   const int le = wave * kWave + lane;
@@ -1453,7 +1445,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
               }
               const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (wide) {
+              if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
                 if (out.reward) {
                   const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
                   store16_update(out.reward + at, r4);
@@ -1496,7 +1488,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 pf[k] = pack4(p[0], p[1], p[2], p[3]);
               }
               const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (wide) {
+              if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
                 const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
                 store16_update(out.trace + at, a4);
                 store16_update(out.trace + plane + at, b4);
@@ -1528,13 +1520,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
         const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
         const int t_next = (c + 1) * kChunk;
         if (t_next < T) {
-          if (wide) {
-            if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
-            if (phase == kGroupsPerChunk - 1)
-              bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
-          } else if (phase == 0) {
-            bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
-          }
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
         }
       
       __syncthreads();
@@ -1599,19 +1587,14 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   const int W = tp.cols;
   const uint32_t HW = (uint32_t)(tp.rows * tp.cols);
   const int64_t env0 = (int64_t)blockIdx.x * E;
-  const bool wide = (B & 15) == 0;
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint64_t* g_entries = reinterpret_cast<const uint64_t*>(g_rewards + 256);
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
-    if (wide) {
-      ld.issue(actions, B, T, 0, env0, llane);
-      bad += ld.land(staged[0], B, T, 0, env0, llane);
-    } else {
-      bad += stage_bytes<E, kLoad>(staged[0], actions, B, T, 0, env0, llane);
-    }
+    ld.issue(actions, B, T, 0, env0, llane);
+    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
   }
   const int le = wave * kWave + lane;
   const int64_t env = env0 + le;
@@ -1681,7 +1664,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               dc[i] = (hi & 1u) ? 0u : 0x3f800000u;
             }
             const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (wide) {
+            if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
               if (out.reward) {
                 const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
                 store16_update(out.reward + at, r4);
@@ -1729,7 +1712,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                             ((hi[2] >> 1) & 3u) - 1u, (((hi[3] >> 1) & 3u) - 1u) & 0xffu);
             }
             const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (wide) {
+            if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
 #pragma unroll
               for (int k = 0; k < K; ++k) {
                 const u32x4 t4 = {tr[k][0], tr[k][1], tr[k][2], tr[k][3]};
@@ -1762,13 +1745,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
       const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
       const int t_next = (c + 1) * kChunk;
       if (t_next < T) {
-        if (wide) {
-          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
-          if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], B, T, t_next, env0, llane);
-        } else if (phase == 0) {
-          bad += stage_bytes<E, kLoad>(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
-        }
+        if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+        if (phase == kGroupsPerChunk - 1)
+          bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
       }
       __syncthreads();
     }
@@ -1890,7 +1869,7 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
 struct RenderParams {
   uint32_t R;                 // row bytes
   uint32_t m, sh1, sh2;       // exact n / R for 32-bit n (Granlund-Montgomery)
-  uint32_t slab_bytes;        // B * R, a multiple of 16
+  uint32_t slab_bytes;        // B * R
   uint32_t shift_base, shift_slab;  // (address of frame 0) and slab_bytes modulo the window span
   int32_t n_dyn, is_board, cells;
   int64_t B;
@@ -1935,7 +1914,13 @@ struct RenderParams {
 #endif
 constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 
-template <int K, bool kBoard, bool kNT, int kWin, int kFmt>
+// kOdd: B * R is not a multiple of 16, so frames do not start on a 16-byte boundary and a
+// lane's (memory-aligned) 16-byte chunk can straddle two frames.  A chunk belongs to the
+// frame it STARTS in and is written whole, with the first bytes of the next frame's first
+// row (the trace plane is [T * B] rows: row B of this frame is row 0 of the next); only at
+// the two ends of a launch is a chunk written byte by byte - the part after the first
+// frame's start, the part before the last frame's end.
+template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false>
 __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderParams rp,
                                                      const CampxSpec* __restrict__ spec,
                                                      const uint8_t* __restrict__ trace,
@@ -1973,7 +1958,9 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   // Their trace bytes come from HBM / L2: issue those loads first.
   const uint32_t whi = __umulhi(rp.m, wlo);
   const uint32_t first_row = (((wlo - whi) >> rp.sh1) + whi) >> rp.sh2;
-  const uint32_t wend = (woff0 + span - 1u < rp.slab_bytes) ? woff0 + span - 1u : rp.slab_bytes - 1u;
+  const bool last_frame = blockIdx.y == gridDim.y - 1u;
+  const uint32_t frame_end = rp.slab_bytes + ((kOdd && !last_frame) ? 15u : 0u);   // exclusive
+  const uint32_t wend = (woff0 + span - 1u < frame_end) ? woff0 + span - 1u : frame_end - 1u;
   const uint32_t ehi = __umulhi(rp.m, wend);
   const uint32_t last_row = (((wend - ehi) >> rp.sh1) + ehi) >> rp.sh2;
   const int slots = (int)(last_row - first_row + 1u) * P;
@@ -1996,7 +1983,8 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
     const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
     const uint32_t hi = __umulhi(rp.m, off);
     const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
-    const int k = (int)(off - row * rp.R);                           // off % R
+    int k = (int)(off - row * rp.R);                                 // off % R
+    if (kOdd && off >= 0xfffffff0u) k = R - (int)(0u - off);         // starts 1..15 bytes before the frame
     scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
   }
   // the scenery layer of two cells per lane (kBoard needs none of it)
@@ -2055,13 +2043,23 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
 #pragma unroll
     for (int j = 0; j < kWin; ++j) {
       const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
-      if (off < rp.slab_bytes) {                         // frames are whole 16-byte chunks
+      const int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;   // uniform
+      if (off < rp.slab_bytes) {                         // the chunk starts inside the frame
         const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
-        const int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;   // uniform
-        if (kNT)
+        if (kOdd && last_frame && off + 16u > rp.slab_bytes) {   // the launch's last bytes
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          for (uint32_t i = 0; off + i < rp.slab_bytes; ++i)
+            const_cast<int8_t*>(frame)[off + i] = (int8_t)(w[i >> 2] >> ((i & 3u) * 8u));
+        } else if (kNT) {
           store16_streaming_at(frame, off, v);
-        else
+        } else {
           *reinterpret_cast<u32x4*>(const_cast<int8_t*>(frame) + off) = v;
+        }
+      } else if (kOdd && blockIdx.y == 0 && off >= 0xfffffff0u) {   // the launch's first bytes
+        const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t i = 0u - off; i < 16u; ++i)
+          const_cast<int8_t*>(frame)[(int32_t)(off + i)] = (int8_t)(w[i >> 2] >> ((i & 3u) * 8u));
       }
     }
   } else {
@@ -2699,14 +2697,16 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   const dim3 grid((unsigned)((((reach + span - 1u) / span) + 7u) & ~(uint64_t)7), (unsigned)T);
   const int64_t n_rows = plane_rows;
   const bool nt = knob_store_nt();
-#define CAMPX_RENDER4(KK, BOARD, NT, FMT)                                                   \
-  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT>), grid,      \
+  const bool odd = (rp.slab_bytes & 15u) != 0;   // (never with the 16-bit formats: split_ok)
+#define CAMPX_RENDER4(KK, BOARD, NT, FMT, ODD)                                              \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT, ODD>), grid, \
                      dim3(kRenderWaves * kWave), 0, stream, rp, spec_dev, trace, dst, n_rows)
-#define CAMPX_RENDER3(KK, BOARD, NT)                               \
-  do {                                                             \
-    if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 1);       \
-    else if (!BOARD && fmt == 2) CAMPX_RENDER4(KK, false, NT, 2);  \
-    else CAMPX_RENDER4(KK, BOARD, NT, 0);                          \
+#define CAMPX_RENDER3(KK, BOARD, NT)                                      \
+  do {                                                                    \
+    if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 1, false);       \
+    else if (!BOARD && fmt == 2) CAMPX_RENDER4(KK, false, NT, 2, false);  \
+    else if (odd) CAMPX_RENDER4(KK, BOARD, NT, 0, true);                  \
+    else CAMPX_RENDER4(KK, BOARD, NT, 0, false);                          \
   } while (0)
 #define CAMPX_RENDER2(KK, BOARD)                                                    \
   do {                                                                              \
@@ -2742,8 +2742,10 @@ bool last_frame_only(const CampxOutputs& out) {
 bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T) {
   const int64_t HW = (int64_t)s.rows * s.cols, LHW = HW * s.n_layers;
   if (!out.trace || !s.render_valid || T <= 0 || T > 65535 || knob_no_split()) return false;
-  if (LHW < 16 || (B * LHW) % 16 != 0 || B * LHW >= (1ll << 32) - 65536) return false;
-  if (out.board && (HW < 16 || (B * HW) % 16 != 0)) return false;
+  if (LHW < 16 || B * LHW >= (1ll << 32) - 65536) return false;
+  if (out.board && HW < 16) return false;
+  // frames that are not whole 16-byte chunks: int8 only (render_kernel's kOdd)
+  if (out.obs_format != CAMPX_OBS_INT8 && (B * LHW) % 16 != 0) return false;
   // every frame kept, back to back - or only the last one (strides 0)
   const bool every = out.obs_t_stride == B * LHW && (!out.board || out.board_t_stride == B * HW);
   return every || last_frame_only(out);
