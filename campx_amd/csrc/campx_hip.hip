@@ -2741,7 +2741,7 @@ bool last_frame_only(const CampxOutputs& out) {
 
 bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T) {
   const int64_t HW = (int64_t)s.rows * s.cols, LHW = HW * s.n_layers;
-  if (!out.trace || !s.render_valid || T <= 0 || T > 65535 || knob_no_split()) return false;
+  if (!out.trace || !s.render_valid || T <= 0 || knob_no_split()) return false;
   if (LHW < 16 || B * LHW >= (1ll << 32) - 65536) return false;
   if (out.board && HW < 16) return false;
   // frames that are not whole 16-byte chunks: int8 only (render_kernel's kOdd)
@@ -2876,7 +2876,8 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   const int64_t per_frame = (int64_t)s.n_dyn * B;
   int64_t chunk = knob_trace_chunk_bytes() / per_frame;
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
-  const bool whole = per_frame * T <= knob_trace_whole_bytes() || T <= chunk;
+  chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
+  const bool whole = (per_frame * T <= knob_trace_whole_bytes() && T <= 65535) || T <= chunk;
   if (last_frame_only(out) || whole) {
     const int32_t rc = launch_update(s, spec_dev, st, actions, out, B, T, reset_first, use_table,
                                      plane, stream);

@@ -434,9 +434,10 @@ def test_sixteen_bit_observations(name, dtype, golden):
     game.rollout(torch.from_numpy(gold['actions']), obs_dtype=dtype, keep_obs=False)
 
 
-def test_very_long_rollout_falls_back_to_the_fused_kernel():
-  """T > 65 535 frames cannot be a render-kernel grid dimension: the launch takes the
-  single-kernel path and must still be exact (also crosses many 64-frame action chunks)."""
+def test_very_long_rollout():
+  """T > 65 535 frames cannot be one render-kernel grid (a grid row per frame): the two-kernel
+  path runs it as chunks of at most 65 520 frames; must still be exact (also crosses many
+  64-frame action chunks)."""
   T, B = 66000, 16
   rng = np.random.RandomState(5)
   actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
