@@ -2869,11 +2869,13 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   // The render kernel runs at the write ceiling only while the trace it reads stays cached
   // (boat race, B = 65 536: 6.96 TB/s with a 26 MB trace at T = 400, 5.35 TB/s with 65 MB at
   // T = 1 000; the same at B = 524 288, T = 100): run long launches as chunks of frames,
-  // update pass and render alternating, each chunk's trace at most 16 MB (CAMPX_TRACE_CHUNK_MB).
+  // update pass and render alternating, each chunk's trace plane at most 16 MB (CAMPX_TRACE_CHUNK_MB).
   // (us per launch, render kernels only, no chunks / 28 / 16 / 8 MB: T = 1 000: 2 265 / 1 820 /
   // 1 641 / 1 644; B = 524 288: 1 739 / 1 504 / 1 314 / 1 316 - gpurun_out/t16.  A 26 MB trace
   // in one piece is still at full speed, so launches up to 28 MB (CAMPX_TRACE_WHOLE_MB) are not cut.)
-  const int64_t per_frame = (int64_t)s.n_dyn * B;
+  // (per moving thing's plane of the trace: sokoban with three boxes, four planes of 13 MB,
+  // renders at full speed in one piece, and 4 % slower cut in four)
+  const int64_t per_frame = B;
   int64_t chunk = knob_trace_chunk_bytes() / per_frame;
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
   chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
