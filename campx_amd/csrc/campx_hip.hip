@@ -1959,7 +1959,8 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   const uint32_t whi = __umulhi(rp.m, wlo);
   const uint32_t first_row = (((wlo - whi) >> rp.sh1) + whi) >> rp.sh2;
   const bool last_frame = blockIdx.y == gridDim.y - 1u;
-  const uint32_t frame_end = rp.slab_bytes + ((kOdd && !last_frame) ? 15u : 0u);   // exclusive
+  constexpr uint32_t kOut = kFmt ? 8u : 16u;   // image bytes of a lane's 16-byte store
+  const uint32_t frame_end = rp.slab_bytes + ((kOdd && !last_frame) ? kOut - 1u : 0u);   // exclusive
   const uint32_t wend = (woff0 + span - 1u < frame_end) ? woff0 + span - 1u : frame_end - 1u;
   const uint32_t ehi = __umulhi(rp.m, wend);
   const uint32_t last_row = (((wend - ehi) >> rp.sh1) + ehi) >> rp.sh2;
@@ -2070,19 +2071,27 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
 #pragma unroll
     for (int h = 0; h < 2 * kWin; ++h) {
       const uint32_t elem = woff0 + (uint32_t)h * 512u + (uint32_t)lane * 8u;  // in the frame
-      if (elem < rp.slab_bytes) {
+      uint16_t* frame16 = reinterpret_cast<uint16_t*>(dst) + (int64_t)blockIdx.y * rp.slab_bytes;
+      const bool inside = elem < rp.slab_bytes;
+      const bool head = kOdd && blockIdx.y == 0 && elem >= 0xfffffff8u;   // the launch's first elements
+      if (inside || head) {
         const uint2 b = *reinterpret_cast<const uint2*>(win0 + h * 512 + lane * 8);
         u32x4 v;
         v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * kOne;
         v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * kOne;
         v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * kOne;
         v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * kOne;
-        u32x4* o = reinterpret_cast<u32x4*>(
-            dst + 2 * ((int64_t)blockIdx.y * rp.slab_bytes + (int64_t)elem));
-        if (kNT)
-          store16_streaming(o, v);
-        else
-          *o = v;
+        if (head || (kOdd && last_frame && elem + 8u > rp.slab_bytes)) {   // element by element
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          for (uint32_t i = head ? 0u - elem : 0u; i < 8u && (head || elem + i < rp.slab_bytes); ++i)
+            frame16[(int32_t)(elem + i)] = (uint16_t)(w[i >> 1] >> ((i & 1u) * 16u));
+        } else {
+          u32x4* o = reinterpret_cast<u32x4*>(frame16 + elem);
+          if (kNT)
+            store16_streaming(o, v);
+          else
+            *o = v;
+        }
       }
     }
   }
@@ -2688,25 +2697,26 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   const bool sixteen = !is_board && fmt != 0;
   const uint32_t wspan = 1024u * (uint32_t)(sixteen ? kWin16 : kWin);   // one wave's windows
   const uint32_t span = wspan * kRenderWaves;                            // one block's
-  if (!sixteen) {   // windows aligned in memory (the 16-bit formats keep frame-aligned windows)
-    rp.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & (wspan - 1u));
-    rp.shift_slab = rp.slab_bytes & (wspan - 1u);
-  }
+  // windows aligned in memory; for the 16-bit formats in units of image bytes = elements
+  rp.shift_base = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> (sixteen ? 1 : 0)) & (wspan - 1u));
+  rp.shift_slab = rp.slab_bytes & (wspan - 1u);
   const uint64_t reach = (uint64_t)rp.slab_bytes + ((rp.shift_base | rp.shift_slab) ? wspan - 1u : 0u);
   // rounded up to a multiple of 8 for the XCD remap; surplus blocks exit at once
   const dim3 grid((unsigned)((((reach + span - 1u) / span) + 7u) & ~(uint64_t)7), (unsigned)T);
   const int64_t n_rows = plane_rows;
   const bool nt = knob_store_nt();
-  const bool odd = (rp.slab_bytes & 15u) != 0;   // (never with the 16-bit formats: split_ok)
+  const bool odd = (rp.slab_bytes & (sixteen ? 7u : 15u)) != 0;   // frames are not whole chunks
 #define CAMPX_RENDER4(KK, BOARD, NT, FMT, ODD)                                              \
   hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT, ODD>), grid, \
                      dim3(kRenderWaves * kWave), 0, stream, rp, spec_dev, trace, dst, n_rows)
 #define CAMPX_RENDER3(KK, BOARD, NT)                                      \
   do {                                                                    \
-    if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 1, false);       \
-    else if (!BOARD && fmt == 2) CAMPX_RENDER4(KK, false, NT, 2, false);  \
-    else if (odd) CAMPX_RENDER4(KK, BOARD, NT, 0, true);                  \
-    else CAMPX_RENDER4(KK, BOARD, NT, 0, false);                          \
+    if (!BOARD && fmt == 1 && odd) CAMPX_RENDER4(KK, false, NT, 1, true);   \
+    else if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 1, false);    \
+    else if (!BOARD && fmt == 2 && odd) CAMPX_RENDER4(KK, false, NT, 2, true); \
+    else if (!BOARD && fmt == 2) CAMPX_RENDER4(KK, false, NT, 2, false);    \
+    else if (odd) CAMPX_RENDER4(KK, BOARD, NT, 0, true);                    \
+    else CAMPX_RENDER4(KK, BOARD, NT, 0, false);                            \
   } while (0)
 #define CAMPX_RENDER2(KK, BOARD)                                                    \
   do {                                                                              \
@@ -2744,8 +2754,6 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
   if (!out.trace || !s.render_valid || T <= 0 || knob_no_split()) return false;
   if (LHW < 16 || B * LHW >= (1ll << 32) - 65536) return false;
   if (out.board && HW < 16) return false;
-  // frames that are not whole 16-byte chunks: int8 only (render_kernel's kOdd)
-  if (out.obs_format != CAMPX_OBS_INT8 && (B * LHW) % 16 != 0) return false;
   // every frame kept, back to back - or only the last one (strides 0)
   const bool every = out.obs_t_stride == B * LHW && (!out.board || out.board_t_stride == B * HW);
   return every || last_frame_only(out);

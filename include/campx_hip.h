@@ -183,8 +183,8 @@ typedef struct CampxOutputs {
                                      is hidden and changes nothing in the observation
                          A compact trajectory in its own right (1 byte per thing per frame
                          against L*rows*cols of observation); and when it is given, frames are
-                         stored back to back (obs_t_stride == B*L*rows*cols; any batch size
-                         for int8 observations), the library runs the update pass and the render as
+                         stored back to back (obs_t_stride == B*L*rows*cols; any batch size),
+                         the library runs the update pass and the render as
                          two kernels, which streams the observations to HBM faster (DESIGN.md
                          "Kernels"); with strides of 0 (only the last frame survives) it
                          renders just that frame from the last row of the trace.  Written

@@ -434,6 +434,24 @@ def test_sixteen_bit_observations(name, dtype, golden):
     game.rollout(torch.from_numpy(gold['actions']), obs_dtype=dtype, keep_obs=False)
 
 
+@pytest.mark.parametrize('name,batch', [('boat_race', 5), ('boat_race', 1001), ('sokoban', 63),
+                                        ('sokoban_l2', 77), ('wall_world', 3)])
+def test_sixteen_bit_observations_at_odd_batch_sizes(name, batch):
+  """Frames that are not whole 16-byte chunks (batch * L*H*W odd multiples): the render
+  kernel's chunks straddle frames; across two launches so that a launch boundary falls
+  mid-chunk too."""
+  rng = np.random.RandomState(batch)
+  game, _ = _fused(name, batch)
+  og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES[name]()))
+  for launch, T in enumerate([7, 33]):
+    actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), obs_dtype=torch.bfloat16)
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    assert out['obs'].dtype == torch.bfloat16
+    assert torch.equal(out['obs'].float().cpu(), torch.from_numpy(ref['obs'].astype(np.float32)))
+    assert _same(out['done'].cpu().numpy(), ref['done'])
+
+
 def test_very_long_rollout():
   """T > 65 535 frames cannot be one render-kernel grid (a grid row per frame): the two-kernel
   path runs it as chunks of at most 65 520 frames; must still be exact (also crosses many
