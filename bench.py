@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -278,6 +279,8 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   for i in range(warmup):
     one_step(i)
   fence()
+  gc.collect()
+  gc.disable()                        # no collector pause between two launches of the timed region
   if on_gpu:
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
@@ -291,6 +294,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     log.wait()
   fence()
   elapsed = time.perf_counter() - t0
+  gc.enable()
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
