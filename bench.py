@@ -60,8 +60,9 @@ TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_traffic.json')
 def parse_args(argv=None):
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  # defaults: the chip needs ~5 ms of sustained launches before its clocks settle (5 warmup
-  # launches read 0.188 ms per step, 50 or 200 read 0.180: DESIGN.md section 5)
+  # defaults: the timed region pays a fixed ~0.2 ms after the synchronise that opens it (the
+  # chip idles during the fence and ramps back): 30 timed launches read 0.186-0.193 ms per
+  # step, 100 read 0.181-0.183, whatever the warm-up (tools/gpu_warm_ab.sh)
   p.add_argument('--steps', type=int, default=100)
   p.add_argument('--warmup', type=int, default=50)
   p.add_argument('--game', default='boat_race', choices=sorted(WORKLOADS))
