@@ -279,9 +279,9 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
 
   for i in range(warmup):
     one_step(i)
-  fence()
-  gc.collect()
+  gc.collect()                        # (before the fence: the chip should not idle longer than it must)
   gc.disable()                        # no collector pause between two launches of the timed region
+  fence()
   if on_gpu:
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
