@@ -2471,6 +2471,16 @@ size_t lds_bytes(const CampxSpec& s, bool board, int envs) {
   return (n + 15) & ~(size_t)15;
 }
 
+// Kernels that keep a 64-environment image in dynamic LDS need more than HIP's default
+// 64 KiB for large rows (128 cells x 16 characters: 146 KiB of the CU's 160).
+constexpr size_t kLdsPerWorkgroup = 160 * 1024;
+template <typename Kernel>
+hipError_t allow_lds(Kernel kernel, size_t dynamic_bytes) {
+  if (dynamic_bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes);
+}
+
 RuleBlock make_rule_block(const CampxSpec& s) {
   RuleBlock rb;
   memset(&rb, 0, sizeof(rb));
@@ -2505,10 +2515,11 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   // overwrites (Engine.play) is better left to the caches.
   const bool nt = knob_store_nt() && out.obs_t_stride != 0;
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
+  (void)allow_lds(rollout_kernel<K, BOARD, NT, ENVS, false>, shmem);                         \
   hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
                      rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd(), \
                      (int64_t)T * B)
-#define CAMPX_LAUNCH(BOARD, NT) CAMPX_LAUNCH_E(BOARD, NT, 64)
+#define CAMPX_LAUNCH(BOARD, NT) do { CAMPX_LAUNCH_E(BOARD, NT, 64); } while (0)
   if (board) {
     if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);
   } else {
@@ -2535,9 +2546,10 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                      \
+  (void)allow_lds(rollout_table_kernel<BOARD, NT, ENVS>, shmem);                              \
   hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS>), grid, block, shmem, stream, mp, \
                      spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd())
-#define CAMPX_LAUNCH(BOARD, NT) CAMPX_LAUNCH_E(BOARD, NT, 64)
+#define CAMPX_LAUNCH(BOARD, NT) do { CAMPX_LAUNCH_E(BOARD, NT, 64); } while (0)
   if (board) {
     if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);
   } else {
@@ -2558,12 +2570,15 @@ int32_t launch_step_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
-  if (board)
+  if (board) {
+    (void)allow_lds(step_table_kernel<true>, shmem);
     hipLaunchKernelGGL(step_table_kernel<true>, grid, block, shmem, stream, mp, spec_dev, st,
                        actions, out, B, reset_first);
-  else
+  } else {
+    (void)allow_lds(step_table_kernel<false>, shmem);
     hipLaunchKernelGGL(step_table_kernel<false>, grid, block, shmem, stream, mp, spec_dev, st,
                        actions, out, B, reset_first);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
@@ -2577,12 +2592,15 @@ int32_t launch_step_pair(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
-  if (board)
+  if (board) {
+    (void)allow_lds(step_pair_kernel<true>, shmem);
     hipLaunchKernelGGL(step_pair_kernel<true>, grid, block, shmem, stream, mp, s.dyn_layer[1],
                        s.dyn_row0[1], s.dyn_col0[1], spec_dev, st, actions, out, B, reset_first);
-  else
+  } else {
+    (void)allow_lds(step_pair_kernel<false>, shmem);
     hipLaunchKernelGGL(step_pair_kernel<false>, grid, block, shmem, stream, mp, s.dyn_layer[1],
                        s.dyn_row0[1], s.dyn_col0[1], spec_dev, st, actions, out, B, reset_first);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
@@ -2642,8 +2660,11 @@ int32_t launch_step_tuple(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const TupleParams tp = make_tuple_params(s);
 #define CAMPX_STEP_TUPLE(KK, BOARD)                                                           \
-  hipLaunchKernelGGL((step_tuple_kernel<KK, BOARD>), grid, block, shmem, stream, tp, spec_dev, st, \
-                     actions, out, B, reset_first)
+  do {                                                                                        \
+    (void)allow_lds(step_tuple_kernel<KK, BOARD>, shmem);                                     \
+    hipLaunchKernelGGL((step_tuple_kernel<KK, BOARD>), grid, block, shmem, stream, tp, spec_dev, \
+                       st, actions, out, B, reset_first);                                     \
+  } while (0)
   if (s.n_dyn == 3) {
     if (board) CAMPX_STEP_TUPLE(3, true); else CAMPX_STEP_TUPLE(3, false);
   } else {
@@ -2925,7 +2946,7 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (B > (int64_t)0x7fffffff * 16) return CAMPX_EINVAL;
   const int32_t v = campx_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
-  if (lds_bytes(*spec_host, out.board != nullptr, kWave) > 64 * 1024) return CAMPX_ESPEC;
+  if (lds_bytes(*spec_host, out.board != nullptr, kWave) + 8 * 1024 > kLdsPerWorkgroup) return CAMPX_ESPEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool use_table =
       spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table();
@@ -3074,11 +3095,11 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   }
   if (spec->n_dyn != 1) return CAMPX_OK;
   const int W = spec->cols, HW = spec->rows * spec->cols;
-  const int LHW = spec->n_layers * HW, n = HW * CAMPX_N_ACTIONS;
+  const int n = HW * CAMPX_N_ACTIONS;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // One scratch allocation: spec | obs | reward | pos | done | actions | done_out
+  // One scratch allocation: spec | trace | reward | pos | done | actions | done_out
   const size_t off_obs = (sizeof(CampxSpec) + 255) & ~(size_t)255;
-  const size_t off_reward = (off_obs + (size_t)n * LHW + 255) & ~(size_t)255;
+  const size_t off_reward = (off_obs + (size_t)n + 255) & ~(size_t)255;   // (off_obs: the trace)
   const size_t off_pos = off_reward + sizeof(float) * n;
   const size_t off_done = off_pos + 2 * (size_t)n;
   const size_t off_act = off_done + n;
@@ -3121,15 +3142,16 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   {
     CampxState st = {reinterpret_cast<int8_t*>(dev + off_pos),
                      reinterpret_cast<uint8_t*>(dev + off_done), nullptr, nullptr};
-    CampxOutputs out = {reinterpret_cast<int8_t*>(dev + off_obs), 0, nullptr, 0,
-                        reinterpret_cast<float*>(dev + off_reward), nullptr,
-                        reinterpret_cast<uint8_t*>(dev + off_dout),
-                        spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr,
-                        nullptr};
-    rc = launch(spec, reinterpret_cast<const CampxSpec*>(dev), st,
-                reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1, 0, 0, stream,
-                /*interpreter_only=*/true);
-    if (rc != CAMPX_OK) goto done;
+    CampxOutputs out;
+    memset(&out, 0, sizeof(out));
+    out.reward = reinterpret_cast<float*>(dev + off_reward);
+    out.done = reinterpret_cast<uint8_t*>(dev + off_dout);
+    out.perf = spec->perf_dyn >= 0 ? reinterpret_cast<int8_t*>(dev + off_perf) : nullptr;
+    out.trace = reinterpret_cast<uint8_t*>(dev + off_obs);   // [1, 1, n], not read back
+    // the interpreter in trace mode (no observation image): one frame of every (cell, action)
+    launch_trace_k<1>(*spec, reinterpret_cast<const CampxSpec*>(dev), st,
+                      reinterpret_cast<const int8_t*>(dev + off_act), out, n, 1, 0, (int64_t)n, s);
+    CAMPX_TRY(hipGetLastError());
   }
   CAMPX_TRY(hipMemcpyAsync(h_pos, dev + off_pos, 2 * (size_t)n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, (size_t)n, hipMemcpyDeviceToHost, s));

@@ -455,6 +455,60 @@ def test_sixteen_bit_observations_at_odd_batch_sizes(name, batch):
     assert _same(out['done'].cpu().numpy(), ref['done'])
 
 
+def _large_row_game(H, W, extra, boxes='', batch=None, device=None):
+  from campx_amd import rules
+  from campx_amd.ascii_art import ascii_art_to_game, Partial
+  art = [[' '] * W for _ in range(H)]
+  for c in range(W):
+    art[0][c] = art[H - 1][c] = '#'
+  for r in range(H):
+    art[r][0] = art[r][W - 1] = '#'
+  art[1][1] = 'A'
+  for i, ch in enumerate(boxes):
+    art[2][2 + 2 * i] = ch
+  for i, ch in enumerate(extra):
+    art[3 + i // (W - 4)][2 + i % (W - 4)] = ch
+  drapes = {'#': rules.FixedDrape,
+            'A': Partial(rules.AgentDrape, blocking_chars='#' + boxes, step_reward=-1.0,
+                         reward_chars=extra[:1])}
+  for ch in extra:
+    drapes[ch] = rules.FixedDrape
+  for ch in boxes:
+    drapes[ch] = Partial(rules.BoxDrape, agent_char='A', blocking_chars='#' + boxes.replace(ch, ''))
+  schedule = ([list(boxes)] if boxes else []) + [['A'] + list(extra) + ['#']]
+  return ascii_art_to_game([''.join(r) for r in art], what_lies_beneath=' ', drapes=drapes,
+                           z_order=extra + boxes + 'A#', update_schedule=schedule,
+                           batch=batch, device=device)
+
+
+@pytest.mark.parametrize('H,W,extra,boxes', [(10, 10, 'abcdefgh', ''), (8, 16, 'abcdefghijklm', ''),
+                                             (8, 16, 'abcdefghijkl', 'X'), (10, 12, 'abcdefghi', 'XY')])
+def test_large_rows_up_to_128_cells_and_16_characters(H, W, extra, boxes):
+  """Rows of 1 100 - 2 048 bytes: the 64-environment LDS images of the one-frame and fused
+  kernels need up to 146 KiB of the CU's 160 (hipFuncAttributeMaxDynamicSharedMemorySize);
+  the two-kernel path does not care."""
+  import functools
+  build = functools.partial(_large_row_game, H, W, extra, boxes)
+  batch = 130
+  game = build(batch=batch, device='cuda')
+  obs, reward, discount = game.its_showtime()
+  og = cpu.OracleGame.from_description(gamespec.describe(build()))
+  obs0, board0 = og.first_frame()
+  assert _same(obs.layered_board.cpu().numpy()[7], obs0)
+  rng = np.random.RandomState(H * W)
+  actions = rng.randint(0, 5, size=(40, batch)).astype(np.int8)
+  out = game.rollout(torch.from_numpy(actions), want_board=True, reset_first=True)
+  ref = og.rollout(actions, reset_first=True)
+  _check_rollout(out, ref)
+  more = rng.randint(0, 5, size=(6, batch)).astype(np.int8)
+  ref = og.rollout(more)
+  for t in range(6):
+    obs, reward, discount = game.play(torch.from_numpy(more[t]))
+    assert _same(obs.layered_board.cpu().numpy(), ref['obs'][t]), t
+    assert _same(obs.board.cpu().numpy(), ref['board'][t])
+    assert _same(reward.cpu().numpy(), ref['reward'][t])
+
+
 def test_very_long_rollout():
   """T > 65 535 frames cannot be one render-kernel grid (a grid row per frame): the two-kernel
   path runs it as chunks of at most 65 520 frames; must still be exact (also crosses many
