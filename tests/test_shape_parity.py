@@ -163,3 +163,49 @@ def test_bad_action_ids_move_nothing_and_are_counted():
   obs, reward, discount = game.play(torch.full((64,), 7))
   assert torch.equal(obs.layered_board, before)
   assert torch.isnan(reward).all() and (discount == 1).all()
+
+
+def _limit_game(H, W, batch=None, device=None):
+  """Eight things (three big rolling drapes, four sprites, a static one) on an H x W board."""
+  from campx_amd import rules
+  from campx_amd.ascii_art import ascii_art_to_game, Partial
+  art = [[' '] * W for _ in range(H)]
+  for r in range(2, 14):
+    for c in range(2, W - 2):
+      art[r][c] = '@'
+  for r in range(15, 24):
+    for c in range(1, W - 1):
+      art[r][c] = '%'
+  for r in range(25, H - 1):
+    for c in range(4, W - 4):
+      art[r][c] = '&'
+  for i, ch in enumerate('1234'):
+    art[0][2 + 3 * i] = ch
+  for c in range(W):
+    art[H - 1][c] = '#'
+  sprites = {ch: Partial(rules.SlidingSprite, i) for i, ch in enumerate('1234')}
+  drapes = {'@': Partial(rules.RollingDrape, move_reward=0.5),
+            '%': Partial(rules.RollingDrape, roll_axes=(1, 1, 0, 0), roll_shifts=(3, -5, 2, -2),
+                         move_reward=0.25, quit_action=None),
+            '&': Partial(rules.RollingDrape, move_reward=1.0, quit_action=None),
+            '#': rules.FixedDrape}
+  return ascii_art_to_game([''.join(r) for r in art], what_lies_beneath=' ', sprites=sprites,
+                           drapes=drapes, z_order='12@3%#&4', update_schedule='4&#%3@21',
+                           batch=batch, device=device)
+
+
+@pytest.mark.parametrize('H,W', [(32, 32), (31, 33)])
+def test_boards_at_the_tier_limit(H, W):
+  """1 024 cells (the limit; four-cell path) and 1 023 (byte path), eight things, drapes of
+  hundreds of cells (several passes of the paint loop), against the oracle."""
+  batch = 37
+  game = _limit_game(H, W, batch=batch, device='cuda')
+  game.its_showtime()
+  og = cpu.OracleGame.from_description(gamespec.describe(_limit_game(H, W)))
+  rng = np.random.RandomState(1)
+  for launch, T in enumerate((1, 70)):
+    actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), want_board=True)
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'board', 'reward', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
