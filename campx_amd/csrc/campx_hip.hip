@@ -3347,7 +3347,8 @@ int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
 
 int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxOutputs out,
                             int64_t B, int32_t T, void* stream) {
-  if (!spec_host || !spec_dev || !out.trace || !out.obs || B <= 0 || T <= 0) return CAMPX_EINVAL;
+  if (!spec_host || !spec_dev || !out.trace || !out.obs || B <= 0 || T <= 0 || T > 65535)
+    return CAMPX_EINVAL;
   if (reinterpret_cast<uintptr_t>(out.obs) & 15) return CAMPX_EINVAL;
   if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
   const int32_t v = campx_spec_validate(spec_host);

@@ -282,10 +282,11 @@ int32_t campx_rollout_launch(const CampxSpec* spec_host, const CampxSpec* spec_d
  *                         out.trace (required) and the per-frame scalars out.reward /
  *                         discount / done / perf / bad_*; ignores out.obs / out.board.
  *   campx_render_launch   expands out.trace into out.obs (and out.board): frames back to
- *                         back (obs_t_stride == B*L*rows*cols, whole 16-byte multiples,
- *                         T <= 65535), else CAMPX_EINVAL.  Reads nothing but the trace
- *                         and the spec.
- * update then render on one stream == campx_rollout_launch().
+ *                         back (obs_t_stride == B*L*rows*cols) or only the last one
+ *                         (strides 0), T <= 65535 (one grid row per frame), else
+ *                         CAMPX_EINVAL.  Reads nothing but the trace and the spec.
+ * update then render on one stream == campx_rollout_launch(), which in addition runs
+ * launches whose trace planes (T*B bytes) exceed 28 MB as chunks of frames.
  */
 int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState state,
                             const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
