@@ -960,11 +960,14 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
 //                          (4 environments of a float stream, 16 of a byte stream),
 //                          write-through, so that nothing is left dirty in L2 for the
 //                          end-of-kernel flush and the render kernel behind it;
-//   1 loader wave          brings the actions in, 16 bytes per lane per load, one
-//                          64-frame chunk ahead.  It issues no stores, so waiting for
-//                          its loads never waits for a store (vmcnt is in order).
-// One s_barrier per group.
-constexpr int kGroup = 16;
+//   kProd / 2 loader waves bring the actions in, 16 bytes per lane per load, one
+//                          64-frame chunk ahead.  They issue no stores, so waiting for
+//                          their loads never waits for a store (vmcnt is in order).
+// One s_barrier per group, in each role's own loop.  The accesses are 16 bytes whatever the
+// batch size: dword-aligned for the float streams, byte-aligned for the byte streams and the
+// actions when B is not a multiple of 16 (legal on this stack; tools/probes/unaligned_probe.hip),
+// and only the batch's last, partial group of 16 environments goes byte by byte.
+constexpr int kGroup = 16;   // frames per group of the 256-environment workgroups
 
 // Cache policy of the update kernels' output stores (A/B builds): 0 plain, 1 sc0 sc1
 // (write-through), 2 sc0 sc1 nt.
