@@ -16,6 +16,9 @@ FUSED_GAMES = {
     'demo4': demos.demo4,
 }
 
+import big_rows_game  # noqa: E402  (tests/big_rows_game.py: 1 800-byte rows, 15 characters)
+FUSED_GAMES['big_rows'] = big_rows_game.library_builder()
+
 # Games of the shape tier (rules.RollingDrape / rules.SlidingSprite): own spec and kernel.
 SHAPE_GAMES = {'hello_world': hello_world.build}
 import shape_zoo  # noqa: E402  (tests/shape_zoo.py: more games of the same two rule classes)

@@ -20,6 +20,8 @@ Game sources:
               on the build-authored 10x10 board.
   sokoban     reference AgentDrape (boat_race.py) + the build's Box/Goal rules
               bound to the reference's `things`.
+  big_rows    tests/big_rows_game.py: sokoban's rules on a 10x12 board with 15 characters
+              (rows of 1800 bytes), reference AgentDrape + the build's Box/Goal rules.
   shape_zoo*  tests/shape_zoo.py: the build's RollingDrape / SlidingSprite (pinned to the
               notebook's classes by hello_world) in other arrangements, bound to the
               reference's `things`, on the reference's engine / renderer / Plot.
@@ -409,6 +411,24 @@ def gen_hello_world():
   save('hello_world', golden)
 
 
+def gen_big_rows():
+  """tests/big_rows_game.py: 10x12 board, 15 characters, three movers - the reference's
+  AgentDrape (boat_race.py) + the build's Box/Goal rules on the reference engine; the library
+  agent gives the same trajectory."""
+  sys.path.insert(0, os.path.join(REPO, 'tests'))
+  import big_rows_game as g
+  acts = random_actions(901, 60, 8)
+  acts[:8, 0] = [3, 1, 1, 3, 3, 3, 1, 1]     # push the first box down on the way
+  acts[:15, 1] = [3] * 7 + [1] * 8           # down the left column, along the bottom row: the goal
+  golden = run(lambda: g.build(to_game, Partial, ref.boat_race.AgentDrape, R.BoxDrape, R.GoalDrape,
+                               ref.things.FixedDrape), acts)
+  lib = run(lambda: g.build(to_game, Partial, R.AgentDrape, R.BoxDrape, R.GoalDrape, R.FixedDrape),
+            acts)
+  assert golden['done'][14, 1] == 1 and golden['reward'][14, 1] == 49
+  assert_same(golden, lib, 'big rows library agent')
+  save('big_rows', golden)
+
+
 def gen_shape_zoo():
   """tests/shape_zoo.py: more RollingDrape / SlidingSprite games, built on the reference's
   engine, renderer, Plot and things (the rule classes' update() bodies were pinned to the
@@ -432,4 +452,5 @@ if __name__ == '__main__':
   gen_sokoban_levels()
   gen_hello_world()
   gen_shape_zoo()
+  gen_big_rows()
   print('done; reference at', ref.campx.__file__)
