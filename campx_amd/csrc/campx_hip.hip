@@ -2796,6 +2796,12 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 #ifndef CAMPX_UPD_CONS
 #define CAMPX_UPD_CONS 4
 #endif
+#ifndef CAMPX_UPD_GROUP
+// frames per group of the 256-environment one-mover workgroups; kernel us per 100 frames at
+// B = 4 096 / 65 536 (gpurun_out/t20-t21): 4: 18.1 / 21.4, 8: 14.8 / 17.8, 16: 12.4 / 15.6,
+// 32: 12.7 / 16.8 - a group costs ~0.3 us of hand-over, a longer one more fill and drain
+#define CAMPX_UPD_GROUP 16
+#endif
 #ifndef CAMPX_PAIR_PROD
 #define CAMPX_PAIR_PROD 4
 #endif
@@ -2832,7 +2838,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
       const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
           block((kProd + kCons + update_loaders(kProd)) * kWave);
-      hipLaunchKernelGGL((update_table_kernel<kProd, kCons, kGroup>), grid, block, 0, stream, mp,
+      hipLaunchKernelGGL((update_table_kernel<kProd, kCons, CAMPX_UPD_GROUP>), grid, block, 0, stream, mp,
                          spec_dev, st, actions, out, B, T, reset_first);
     }
   } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
