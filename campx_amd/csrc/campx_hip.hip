@@ -35,6 +35,10 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include <stdlib.h>
 #include <string.h>
 
@@ -954,7 +958,7 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
 // state: one LDS read.  A workgroup owns kEnvs = 64 * kProd consecutive environments
 // and has three kinds of waves:
 //   kProd producer waves   run that dependent chain, one environment per lane,
-//                          kGroup frames at a time, into a double-buffered LDS ring;
+//                          a group of (16) frames at a time, into a double-buffered LDS ring;
 //   kCons consumer waves   turn the previous group into the output streams while the
 //                          producers run the next one: 16 bytes per lane per store
 //                          (4 environments of a float stream, 16 of a byte stream),
@@ -967,7 +971,6 @@ size_t table_lds_bytes(const CampxSpec& s, bool board, int envs) {
 // batch size: dword-aligned for the float streams, byte-aligned for the byte streams and the
 // actions when B is not a multiple of 16 (legal on this stack; tools/probes/unaligned_probe.hip),
 // and only the batch's last, partial group of 16 environments goes byte by byte.
-constexpr int kGroup = 16;   // frames per group of the 256-environment workgroups
 
 // Cache policy of the update kernels' output stores (A/B builds): 0 plain, 1 sc0 sc1
 // (write-through), 2 sc0 sc1 nt.
@@ -1087,13 +1090,13 @@ struct ActionLoader {
   }
 };
 
-// The action of frame j (0 .. kGroup-1) of a group that starts at frame t0 of its chunk,
+// The action of frame j of a group that starts at frame t0 of its chunk,
 // for environment `le` of the workgroup.
 template <int kEnvs>
 __device__ __forceinline__ uint32_t staged_action(const int8_t* chunk, int t0_in_chunk, int j,
                                                    int le) {
   const uint32_t b = (uint8_t)chunk[((t0_in_chunk + j) >> 1) * kEnvs + le];
-  return (b >> (4 * (j & 1))) & 0xfu;   // t0_in_chunk is a multiple of kGroup (even)
+  return (b >> (4 * (j & 1))) & 0xfu;   // t0_in_chunk is a multiple of the group size (even)
 }
 
 // Four bytes (the low byte of each argument) as one dword.
@@ -2480,8 +2483,19 @@ constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 template <typename Kernel>
 hipError_t allow_lds(Kernel kernel, size_t dynamic_bytes) {
   if (dynamic_bytes <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes);
+  // once per (device, kernel): what was granted is remembered
+  static std::mutex lock;
+  static std::map<std::pair<int, const void*>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::pair<int, const void*> key(dev, reinterpret_cast<const void*>(kernel));
+  std::lock_guard<std::mutex> guard(lock);
+  const auto it = granted.find(key);
+  if (it != granted.end() && it->second >= dynamic_bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(key.second, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)dynamic_bytes);
+  if (e == hipSuccess) granted[key] = dynamic_bytes;
+  return e;
 }
 
 RuleBlock make_rule_block(const CampxSpec& s) {
