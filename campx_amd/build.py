@@ -10,6 +10,7 @@ hipcc cross-compiles without a GPU.  The .so files are git-ignored but travel wi
 the working tree to the GPU box.
 """
 
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -17,11 +18,19 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = os.path.join(HERE, 'csrc', 'campx_hip.hip')
-OUT = os.path.join(HERE, 'csrc', 'libcampx_hip.so')
+CSRC = os.path.join(HERE, 'csrc')
+# One translation unit per kernel family + the C ABI / dispatch; an A/B variant of one
+# kernel rebuilds one object (tools/build_variants.py).
+UNITS = ('campx_api', 'k_interp', 'k_rollout_table', 'k_step', 'k_update', 'k_render',
+         'k_shape', 'k_misc')
+SRCS = [os.path.join(CSRC, u + '.hip') for u in UNITS]
+HEADERS = [os.path.join(CSRC, 'campx_common.hip.h'),
+           os.path.join(REPO, 'include', 'campx_hip.h')]
+OBJ_DIR = os.path.join(REPO, 'build', 'obj')
+OUT = os.path.join(CSRC, 'libcampx_hip.so')
 INCLUDE = os.path.join(REPO, 'include')
 
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
                '-ffp-contract=off', '-Wall', '-Wno-unused-function',
                '-Wno-pass-failed']
 
@@ -33,24 +42,51 @@ def find_hipcc():
   raise RuntimeError('hipcc not found (looked on PATH and in /opt/rocm/bin)')
 
 
+def _stale(target, sources):
+  return (not os.path.exists(target) or
+          os.path.getmtime(target) < max(os.path.getmtime(p) for p in sources))
+
+
 def needs_build():
-  if not os.path.exists(OUT):
-    return True
-  newest = max(os.path.getmtime(SRC),
-               os.path.getmtime(os.path.join(INCLUDE, 'campx_hip.h')))
-  return os.path.getmtime(OUT) < newest
+  return _stale(OUT, SRCS + HEADERS)
+
+
+def compile_units(obj_dir=OBJ_DIR, defines=(), force=False, verbose=False, jobs=4):
+  """hipcc -c every stale translation unit (in parallel); returns the object paths."""
+  os.makedirs(obj_dir, exist_ok=True)
+  hipcc = find_hipcc()
+  objs, todo = [], []
+  for unit, src in zip(UNITS, SRCS):
+    obj = os.path.join(obj_dir, unit + '.o')
+    objs.append(obj)
+    if force or _stale(obj, [src] + HEADERS):
+      todo.append([hipcc] + HIPCC_FLAGS + list(defines) +
+                  ['-I', INCLUDE, '-I', CSRC, '-c', src, '-o', obj])
+
+  def run(cmd):
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+
+  with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+    list(pool.map(run, todo))
+  return objs
+
+
+def link(objs, out, verbose=False):
+  cmd = [find_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out + '.tmp']
+  if verbose:
+    print(' '.join(cmd))
+  subprocess.run(cmd, check=True)
+  os.replace(out + '.tmp', out)
+  return out
 
 
 def build_hip(force=False, verbose=False):
   """Build libcampx_hip.so if it is missing or older than its sources."""
   if not force and not needs_build():
     return OUT
-  cmd = [find_hipcc()] + HIPCC_FLAGS + ['-I', INCLUDE, SRC, '-o', OUT + '.tmp']
-  if verbose:
-    print(' '.join(cmd))
-  subprocess.run(cmd, check=True)
-  os.replace(OUT + '.tmp', OUT)
-  return OUT
+  return link(compile_units(force=force, verbose=verbose), OUT, verbose)
 
 
 TORCH_SRC = os.path.join(HERE, 'csrc', 'campx_torch.cpp')

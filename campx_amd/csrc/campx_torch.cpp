@@ -18,13 +18,20 @@
 // device and nothing synchronises.  Registered for the CUDA dispatch key (= HIP on
 // ROCm) and Meta (shape-free no-op, which is also the fake-tensor implementation).
 // There is deliberately no CPU kernel: calling these with CPU state raises.
+// An ADInplaceOrView kernel (one boxed function, registered for every op) bumps the version
+// counter of every tensor an op writes, so that autograd refuses a backward pass through a
+// tensor that a later play() / rollout() has overwritten (the engine's frame buffers are
+// reused) instead of silently differentiating stale data.
 // (ROCm builds of torch present HIP devices as device type "cuda"; the guard and stream
 // types below are torch's own names for that arrangement.)
 //
 // The ops only unpack tensors into the C ABI of include/campx_hip.h; all kernels
-// live in campx_hip.hip.
+// live in csrc/k_*.hip.
 
 #include <ATen/core/Tensor.h>
+#include <ATen/core/dispatch/Dispatcher.h>
+#include <ATen/core/stack.h>
+#include <c10/core/impl/LocalDispatchKeySet.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime.h>
@@ -416,6 +423,28 @@ void shape_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const Op
 void onehot_to_ids_meta(const Tensor&, Tensor&, Tensor&) {}
 void check_actions_meta(const Tensor&, Tensor&) {}
 
+// ADInplaceOrView: run the op, then mark every argument the schema declares written
+// (`Tensor(a!)`) as modified in place.
+void run_then_bump_versions(const c10::OperatorHandle& op, c10::DispatchKeySet keys,
+                            torch::jit::Stack* stack) {
+  const auto& arguments = op.schema().arguments();
+  const size_t n = arguments.size();
+  at::Tensor written[16];
+  size_t n_written = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const c10::AliasInfo* alias = arguments[i].alias_info();
+    if (!alias || !alias->isWrite()) continue;
+    const c10::IValue& v = torch::jit::peek(*stack, i, n);
+    if (v.isTensor() && v.toTensor().defined() && n_written < 16) written[n_written++] = v.toTensor();
+  }
+  {
+    c10::impl::ExcludeDispatchKeyGuard below(c10::autograd_dispatch_keyset_with_ADInplaceOrView);
+    op.redispatchBoxed(keys & c10::after_ADInplaceOrView_keyset, stack);
+  }
+  for (size_t i = 0; i < n_written; ++i)
+    if (!written[i].is_inference()) written[i].unsafeGetTensorImpl()->bump_version();
+}
+
 }  // namespace
 
 TORCH_LIBRARY(campx, m) {
@@ -458,6 +487,12 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
   m.impl("shape_rollout", &shape_rollout);
   m.impl("onehot_to_ids", &onehot_to_ids);
   m.impl("check_actions", &check_actions);
+}
+
+TORCH_LIBRARY_IMPL(campx, ADInplaceOrView, m) {
+  for (const char* name : {"reset", "step", "rollout", "update", "render", "shape_rollout",
+                           "onehot_to_ids", "check_actions"})
+    m.impl(name, torch::CppFunction::makeFromBoxedFunction<&run_then_bump_versions>());
 }
 
 TORCH_LIBRARY_IMPL(campx, Meta, m) {

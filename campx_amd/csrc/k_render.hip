@@ -1,0 +1,324 @@
+// k_render.hip - render_kernel: expands the trace into the observation stream.
+#include "campx_common.hip.h"
+
+namespace campx_impl {
+
+// ---------------------------------------------------------------------------
+// Split path, second half: expand the trace into the observation stream.
+// One-shot blocks, ONE aligned 16-byte store per thread, block (x, t) writing bytes
+// [x*4096, (x+1)*4096) of frame t: the dispatcher walks the output linearly.  That
+// is the store pattern that reaches the HBM write ceiling on this chip
+// (tools/probes: 6.9 TB/s, against 5.4 TB/s for long-lived waves that each stream a
+// private tile, whatever the tile size).
+//
+// A frame is B rows of R bytes (R = L*H*W for the layered board, H*W for the flat
+// board).  A row is the scenery's row with at most two bytes changed per moving
+// thing, given by its trace entry.  spec->rot_* hold 16 byte-rotations of the
+// cyclically continued scenery row, so any 16-byte window of back-to-back rows is
+// ONE aligned 16-byte load (L1-resident).
+struct RenderParams {
+  uint32_t R;                 // row bytes
+  uint32_t m, sh1, sh2;       // exact n / R for 32-bit n (Granlund-Montgomery)
+  uint32_t slab_bytes;        // B * R
+  uint32_t shift_base, shift_slab;  // (address of frame 0) and slab_bytes modulo the window span
+  int32_t n_dyn, is_board, cells;
+  int64_t B;
+  int32_t dyn_char[CAMPX_MAX_DYN];
+  int32_t dyn_off[CAMPX_MAX_DYN];   // byte offset of moving thing d's layer inside a row
+};
+
+// Block (x, t) writes bytes [x*4096*kWin, (x+1)*4096*kWin) of frame t; each of its four
+// waves owns kWin aligned KiB of it (every store instruction of a wave is one aligned,
+// contiguous KiB: tools/probes show -12..-21 % for anything less aligned).
+//
+// A wave first lays the scenery's bytes for its window into LDS (one aligned 16-byte
+// load from the rotated scenery table per lane), then the few lanes that hold a
+// patch - (row overlapping the window) x (moving thing) x (set | clear) - write their
+// single byte into it, then every lane reads its 16 bytes back and stores them.
+// A patch comes from the thing's trace byte (cell, visible): the 1 it paints is at
+// dyn_off + cell, the scenery's 1 it hides at scen_off[cell], a per-wave LDS copy of
+// spec->static_top_layer[cell] * cells + cell.  Nothing is shared between waves, so
+// there is no workgroup barrier.
+// A/B knobs of the render kernel's shape: waves per block, KiB windows per wave, and
+// whether block indices are remapped so that each XCD (block b runs on XCD b % 8) sweeps
+// its own contiguous eighth of a frame instead of every eighth block of it (neighbouring
+// windows then share trace lines inside ONE L2).  Measured with rocprofv3, avg of 63
+// launches (gpurun_out/r2c), boat race / wall world / sokoban render in us:
+//   4 waves, 2 KiB, no remap   176.9 / 2006.7 / 361.8
+//   4 waves, 2 KiB, remap      173.5 / 1877.2 / 362.3
+//   2 waves, 2 KiB, remap      172.7 / 1873.7 / 363.6   <- default
+//   4 waves, 4 KiB, remap      190.3 / 2099.3 / 362.3
+//   2 waves, 4 KiB, remap      177.7 / 1984.6 / 356.0
+// Again with settled clocks (250 launches after 50 warm-up ones, gpurun_out/t10, remap on):
+//   2 waves x 2 KiB 164.8 / 1842 / 338.1 (default)   4 x 2: 165.6 / 1873 / 340.0
+//   1 x 2: 166.1 / 1893 / 345.3   2 x 4: 180.2 / 1978 / 360.9   1 x 4: 179.4 / 2008 / 371.4
+//   4 x 1: 187.7 / 1994 / 388.7
+#ifndef CAMPX_RENDER_WAVES
+#define CAMPX_RENDER_WAVES 2
+#endif
+#ifndef CAMPX_RENDER_WIN
+#define CAMPX_RENDER_WIN 2
+#endif
+#ifndef CAMPX_RENDER_XCD
+#define CAMPX_RENDER_XCD 1
+#endif
+constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
+
+// kOdd: B * R is not a multiple of 16, so frames do not start on a 16-byte boundary and a
+// lane's (memory-aligned) 16-byte chunk can straddle two frames.  A chunk belongs to the
+// frame it STARTS in and is written whole, with the first bytes of the next frame's first
+// row (the trace plane is [T * B] rows: row B of this frame is row 0 of the next); only at
+// the two ends of a launch is a chunk written byte by byte - the part after the first
+// frame's start, the part before the last frame's end.
+template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false>
+__global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderParams rp,
+                                                     const CampxSpec* __restrict__ spec,
+                                                     const uint8_t* __restrict__ trace,
+                                                     int8_t* __restrict__ dst, int64_t n_rows) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[kRenderWaves * kWin * 1024];
+  __shared__ uint16_t scen_off_all[kRenderWaves][CAMPX_MAX_CELLS];
+  // readfirstlane: the wave index is uniform, and saying so keeps everything derived
+  // from it (window offsets, the divisions, base addresses) on the scalar unit
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // this wave's kWin consecutive KiB windows of the frame
+  uint32_t bx = blockIdx.x;
+#if CAMPX_RENDER_XCD
+  bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);     // gridDim.x is a multiple of 8
+#endif
+  // Windows are aligned in MEMORY, not in the frame: when a frame does not start on a
+  // window boundary (B * R not a multiple of the span) they start `shift` bytes before it,
+  // so every store of every frame is still one aligned KiB (499 984 environments: 4.2 TB/s
+  // with frame-aligned windows).  Offsets are modulo 2^32: the head window's start is
+  // "negative", its lanes before the frame fail the one `off < slab_bytes` test below.
+  const uint32_t span = 1024u * kWin;
+  const uint32_t shift = (rp.shift_base + blockIdx.y * rp.shift_slab) & (span - 1u);
+  const uint32_t widx = bx * (uint32_t)kRenderWaves + (uint32_t)wave;
+  if ((uint64_t)widx * span >= (uint64_t)rp.slab_bytes + shift) return;
+  const uint32_t woff0 = widx * span - shift;
+  const uint32_t wlo = widx * span < shift ? 0u : woff0;   // first byte inside the frame
+  int8_t* win0 = lds + wave * (kWin * 1024);
+  uint16_t* scen_off = scen_off_all[wave];
+  const int R = (int)rp.R;
+  const int pitch = ((R + 15) & ~15) + 16;
+  const int8_t* rot = kBoard ? spec->rot_board : spec->rot_obs;
+  constexpr int P = kBoard ? K : 2 * K;                // patches per row
+  const uint8_t* frame_trace = trace + (int64_t)blockIdx.y * rp.B;
+
+  // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear).
+  // Their trace bytes come from HBM / L2: issue those loads first.
+  const uint32_t whi = __umulhi(rp.m, wlo);
+  const uint32_t first_row = (((wlo - whi) >> rp.sh1) + whi) >> rp.sh2;
+  const bool last_frame = blockIdx.y == gridDim.y - 1u;
+  constexpr uint32_t kOut = kFmt ? 8u : 16u;   // image bytes of a lane's 16-byte store
+  const uint32_t frame_end = rp.slab_bytes + ((kOdd && !last_frame) ? kOut - 1u : 0u);   // exclusive
+  const uint32_t wend = (woff0 + span - 1u < frame_end) ? woff0 + span - 1u : frame_end - 1u;
+  const uint32_t ehi = __umulhi(rp.m, wend);
+  const uint32_t last_row = (((wend - ehi) >> rp.sh1) + ehi) >> rp.sh2;
+  const int slots = (int)(last_row - first_row + 1u) * P;
+  constexpr int kMaxIter = 2;                          // slots <= 128 covers the common case
+  uint32_t ent[kMaxIter];
+#pragma unroll
+  for (int it = 0; it < kMaxIter; ++it) {
+    const int sidx = lane + it * kWave;
+    const int r = sidx / P, p = sidx - r * P;
+    const int d = kBoard ? p : (p >> 1);
+    uint32_t row = first_row + (uint32_t)r;
+    row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
+    ent[it] = (it == 0 || slots > kWave) ? frame_trace[(int64_t)d * n_rows + row] : 0u;
+  }
+
+  // ---- scenery: issue all loads, then park them in LDS
+  u32x4 scen[kWin];
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+    const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
+    const uint32_t hi = __umulhi(rp.m, off);
+    const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
+    int k = (int)(off - row * rp.R);                                 // off % R
+    if (kOdd && off >= 0xfffffff0u) k = R - (int)(0u - off);         // starts 1..15 bytes before the frame
+    scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+  }
+  // the scenery layer of two cells per lane (kBoard needs none of it)
+  uint32_t top2 = 0;
+  if (!kBoard) top2 = *reinterpret_cast<const uint16_t*>(spec->static_top_layer + 2 * lane);
+
+#pragma unroll
+  for (int j = 0; j < kWin; ++j)
+    *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16) = scen[j];
+  if (!kBoard) {
+    const uint32_t c = 2u * (uint32_t)lane;
+    const uint32_t lo = (top2 & 0xffu) * (uint32_t)rp.cells + c;
+    const uint32_t hi2 = (top2 >> 8) * (uint32_t)rp.cells + c + 1u;
+    *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
+  }
+
+  // rp.dyn_off / dyn_char of a lane-varying thing: a chain of selects over the K kernel
+  // arguments (indexing the array made hipcc fetch it with a vector load from the kernarg
+  // segment and wait for it inside the patch branch: one more memory trip per wave)
+  // (readfirstlane makes each argument an opaque scalar: from three things up the
+  // optimiser otherwise turns the select chain back into the indexed load)
+  auto of_thing = [&](const int32_t (&arr)[CAMPX_MAX_DYN], int d) {
+    int v = __builtin_amdgcn_readfirstlane(arr[0]);
+#pragma unroll
+    for (int k = 1; k < K; ++k) v = (d == k) ? __builtin_amdgcn_readfirstlane(arr[k]) : v;
+    return v;
+  };
+  auto apply = [&](int sidx, uint32_t e) {
+    const int r = sidx / P, p = sidx - r * P;
+    const int d = kBoard ? p : (p >> 1);
+    const int cell = (int)(e & 0x7fu);
+    int byte;   // offset inside the row
+    int8_t val;
+    if (kBoard) {
+      byte = cell;
+      val = (int8_t)of_thing(rp.dyn_char, d);
+    } else {
+      byte = (p & 1) ? of_thing(rp.dyn_off, d) + cell : (int)scen_off[cell];
+      val = (int8_t)(p & 1);
+    }
+    // offsets inside a frame fit 32 bits (split_ok); a patch left of the window wraps to a
+    // huge unsigned value and fails the one comparison
+    const uint32_t at = (first_row + (uint32_t)r) * (uint32_t)R + (uint32_t)byte - woff0;
+    if (sidx < slots && (e >> 7) && at < span) win0[at] = val;
+  };
+#pragma unroll
+  for (int it = 0; it < kMaxIter; ++it) apply(lane + it * kWave, ent[it]);
+  for (int sidx = lane + kMaxIter * kWave; sidx < slots; sidx += kWave) {   // tiny rows only
+    const int r = sidx / P, p = sidx - r * P;
+    const int d = kBoard ? p : (p >> 1);
+    apply(sidx, frame_trace[(int64_t)d * n_rows + first_row + (uint32_t)r]);
+  }
+
+  // ---- out: aligned, contiguous KiB stores
+  if (kFmt == 0) {
+#pragma unroll
+    for (int j = 0; j < kWin; ++j) {
+      const uint32_t off = woff0 + j * 1024u + (uint32_t)lane * 16u;
+      const int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;   // uniform
+      if (off < rp.slab_bytes) {                         // the chunk starts inside the frame
+        const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
+        if (kOdd && last_frame && off + 16u > rp.slab_bytes) {   // the launch's last bytes
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          for (uint32_t i = 0; off + i < rp.slab_bytes; ++i)
+            const_cast<int8_t*>(frame)[off + i] = (int8_t)(w[i >> 2] >> ((i & 3u) * 8u));
+        } else if (kNT) {
+          store16_streaming_at(frame, off, v);
+        } else {
+          *reinterpret_cast<u32x4*>(const_cast<int8_t*>(frame) + off) = v;
+        }
+      } else if (kOdd && blockIdx.y == 0 && off >= 0xfffffff0u) {   // the launch's first bytes
+        const u32x4 v = *reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t i = 0u - off; i < 16u; ++i)
+          const_cast<int8_t*>(frame)[(int32_t)(off + i)] = (int8_t)(w[i >> 2] >> ((i & 3u) * 8u));
+      }
+    }
+  } else {
+    // 16-bit observations (f16 / bf16 0.0 and 1.0) for a policy network: a lane turns
+    // 8 bytes of the image into 8 halves; lanes stay contiguous, so each store
+    // instruction is again one aligned KiB (of 512 elements).
+    constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+#pragma unroll
+    for (int h = 0; h < 2 * kWin; ++h) {
+      const uint32_t elem = woff0 + (uint32_t)h * 512u + (uint32_t)lane * 8u;  // in the frame
+      uint16_t* frame16 = reinterpret_cast<uint16_t*>(dst) + (int64_t)blockIdx.y * rp.slab_bytes;
+      const bool inside = elem < rp.slab_bytes;
+      const bool head = kOdd && blockIdx.y == 0 && elem >= 0xfffffff8u;   // the launch's first elements
+      if (inside || head) {
+        const uint2 b = *reinterpret_cast<const uint2*>(win0 + h * 512 + lane * 8);
+        u32x4 v;
+        v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * kOne;
+        v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * kOne;
+        v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * kOne;
+        v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * kOne;
+        if (head || (kOdd && last_frame && elem + 8u > rp.slab_bytes)) {   // element by element
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          for (uint32_t i = head ? 0u - elem : 0u; i < 8u && (head || elem + i < rp.slab_bytes); ++i)
+            frame16[(int32_t)(elem + i)] = (uint16_t)(w[i >> 1] >> ((i & 1u) * 16u));
+        } else {
+          u32x4* o = reinterpret_cast<u32x4*>(frame16 + elem);
+          if (kNT)
+            store16_streaming(o, v);
+          else
+            *o = v;
+        }
+      }
+    }
+  }
+}
+
+// `trace` points at the first frame to render, `T` frames from there; `plane_rows` is the
+// distance (in rows = environments) between two moving things' planes of the trace, i.e.
+// B times the number of frames the trace holds.
+int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
+                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, bool is_board,
+                      int fmt, hipStream_t stream) {
+  const int HW = s.rows * s.cols;
+  RenderParams rp;
+  memset(&rp, 0, sizeof(rp));
+  rp.R = (uint32_t)(is_board ? HW : s.n_layers * HW);
+  // exact unsigned 32-bit division by R (Granlund & Montgomery 1994, fig. 4.1)
+  uint32_t l = 0;
+  while ((1ull << l) < rp.R) ++l;
+  rp.m = (uint32_t)(((1ull << 32) * ((1ull << l) - rp.R)) / rp.R + 1);
+  rp.sh1 = l < 1 ? l : 1;
+  rp.sh2 = l > 0 ? l - 1 : 0;
+  rp.slab_bytes = (uint32_t)(B * rp.R);
+  rp.n_dyn = s.n_dyn;
+  rp.is_board = is_board ? 1 : 0;
+  rp.B = B;
+  rp.cells = HW;
+  for (int d = 0; d < s.n_dyn; ++d) {
+    rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
+    rp.dyn_off[d] = s.dyn_layer[d] * HW;
+  }
+  // KiB of the int8 image per wave: what a wave WRITES is what counts (2 KiB: 164.8 us, 4 KiB:
+  // 180.2 us for the boat race), so the 16-bit formats take half the window
+  constexpr int kWin = CAMPX_RENDER_WIN, kWin16 = kWin > 1 ? kWin / 2 : 1;
+  const bool sixteen = !is_board && fmt != 0;
+  const uint32_t wspan = 1024u * (uint32_t)(sixteen ? kWin16 : kWin);   // one wave's windows
+  const uint32_t span = wspan * kRenderWaves;                            // one block's
+  // windows aligned in memory; for the 16-bit formats in units of image bytes = elements
+  rp.shift_base = (uint32_t)((reinterpret_cast<uintptr_t>(dst) >> (sixteen ? 1 : 0)) & (wspan - 1u));
+  rp.shift_slab = rp.slab_bytes & (wspan - 1u);
+  const uint64_t reach = (uint64_t)rp.slab_bytes + ((rp.shift_base | rp.shift_slab) ? wspan - 1u : 0u);
+  // rounded up to a multiple of 8 for the XCD remap; surplus blocks exit at once
+  const dim3 grid((unsigned)((((reach + span - 1u) / span) + 7u) & ~(uint64_t)7), (unsigned)T);
+  const int64_t n_rows = plane_rows;
+  const bool nt = knob_store_nt();
+  const bool odd = (rp.slab_bytes & (sixteen ? 7u : 15u)) != 0;   // frames are not whole chunks
+#define CAMPX_RENDER4(KK, BOARD, NT, FMT, ODD)                                              \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT, ODD>), grid, \
+                     dim3(kRenderWaves * kWave), 0, stream, rp, spec_dev, trace, dst, n_rows)
+#define CAMPX_RENDER3(KK, BOARD, NT)                                      \
+  do {                                                                    \
+    if (!BOARD && fmt == 1 && odd) CAMPX_RENDER4(KK, false, NT, 1, true);   \
+    else if (!BOARD && fmt == 1) CAMPX_RENDER4(KK, false, NT, 1, false);    \
+    else if (!BOARD && fmt == 2 && odd) CAMPX_RENDER4(KK, false, NT, 2, true); \
+    else if (!BOARD && fmt == 2) CAMPX_RENDER4(KK, false, NT, 2, false);    \
+    else if (odd) CAMPX_RENDER4(KK, BOARD, NT, 0, true);                    \
+    else CAMPX_RENDER4(KK, BOARD, NT, 0, false);                            \
+  } while (0)
+#define CAMPX_RENDER2(KK, BOARD)                                                    \
+  do {                                                                              \
+    if (nt) CAMPX_RENDER3(KK, BOARD, true); else CAMPX_RENDER3(KK, BOARD, false);   \
+  } while (0)
+#define CAMPX_RENDER1(KK)                                                   \
+  do {                                                                      \
+    if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
+  } while (0)
+  switch (s.n_dyn) {
+    case 1: CAMPX_RENDER1(1); break;
+    case 2: CAMPX_RENDER1(2); break;
+    case 3: CAMPX_RENDER1(3); break;
+    default: CAMPX_RENDER1(4); break;
+  }
+#undef CAMPX_RENDER1
+#undef CAMPX_RENDER2
+#undef CAMPX_RENDER3
+#undef CAMPX_RENDER4
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+}  // namespace campx_impl

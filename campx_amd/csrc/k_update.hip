@@ -1,0 +1,965 @@
+// k_update.hip - the update pass of the two-kernel path from the game's state table:
+// producer / consumer / loader waves (update_table_kernel, update_pair_kernel,
+// update_tuple_kernel) and launch_update, which picks one (or the interpreter in trace mode).
+#include "campx_common.hip.h"
+
+namespace campx_impl {
+
+// ---------------------------------------------------------------------------
+// Split path, first half: the update pass alone.  Out: the trace (one byte per moving
+// thing per frame per environment: cell + "is the character its cell shows") and the
+// per-frame scalars (reward, discount, done, perf).
+//
+// The only loop-carried dependency of a frame is state -> table[state, action] ->
+// state: one LDS read.  A workgroup owns kEnvs = 64 * kProd consecutive environments
+// and has three kinds of waves:
+//   kProd producer waves   run that dependent chain, one environment per lane,
+//                          a group of (16) frames at a time, into a double-buffered LDS ring;
+//   kCons consumer waves   turn the previous group into the output streams while the
+//                          producers run the next one: 16 bytes per lane per store
+//                          (4 environments of a float stream, 16 of a byte stream),
+//                          write-through, so that nothing is left dirty in L2 for the
+//                          end-of-kernel flush and the render kernel behind it;
+//   kProd / 2 loader waves bring the actions in, 16 bytes per lane per load, one
+//                          64-frame chunk ahead.  They issue no stores, so waiting for
+//                          their loads never waits for a store (vmcnt is in order).
+// One s_barrier per group, in each role's own loop.  The accesses are 16 bytes whatever the
+// batch size: dword-aligned for the float streams, byte-aligned for the byte streams and the
+// actions when B is not a multiple of 16 (legal on this stack; tools/probes/unaligned_probe.hip),
+// and only the batch's last, partial group of 16 environments goes byte by byte.
+
+// Cache policy of the update kernels' output stores (A/B builds): 0 plain, 1 sc0 sc1
+// (write-through), 2 sc0 sc1 nt.
+#ifndef CAMPX_UPD_FLAVOR
+#define CAMPX_UPD_FLAVOR 1
+#endif
+__device__ __forceinline__ void store16_update(void* p, u32x4 v) {
+#if CAMPX_UPD_FLAVOR == 0
+  *reinterpret_cast<u32x4*>(p) = v;
+#elif CAMPX_UPD_FLAVOR == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
+// Number of bytes >= 5 (as unsigned) among the 16 of v: the action ids outside 0..4.
+__device__ __forceinline__ int count_bad16(u32x4 v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t hi = (((w[i] & 0x7f7f7f7fu) + 0x7b7b7b7bu) | w[i]) & 0x80808080u;
+    n += __builtin_popcount(hi);
+  }
+  return n;
+}
+
+// Bytes > 4 (as unsigned) of v replaced by 4: an id outside 0..4 acts as "stay".
+__device__ __forceinline__ uint32_t clamp_ids(uint32_t w) {
+  const uint32_t hi = (((w & 0x7f7f7f7fu) + 0x7b7b7b7bu) | w) & 0x80808080u;  // bad bytes
+  const uint32_t m = (hi >> 7) * 0xffu;
+  return (w & ~m) | (0x04040404u & m);
+}
+
+// The staged actions of a chunk are packed two frames to a byte - frame 2p in the low
+// nibble of row p, frame 2p + 1 in the high one, already clamped to 0..4 - which halves
+// their LDS footprint (what decides how many update workgroups fit on a CU).
+//
+// The loader waves' state: one chunk (kChunk frames x kEnvs environments) of actions in
+// flight in registers between issue() and land().
+template <int kEnvs, int kLoaders>
+struct ActionLoader {
+  static constexpr int kVecPerRow = kEnvs / 16;
+  static constexpr int kLanes = kWave * kLoaders;          // loader lanes of the workgroup
+  static constexpr int kPairs = (kChunk / 2) * kVecPerRow / kLanes;   // row pairs per lane
+  static_assert(kPairs >= 1 && (kChunk / 2) * kVecPerRow % kLanes == 0, "loader shape");
+  u32x4 pend[2 * kPairs];
+
+  // 16-byte loads (byte-aligned unless B % 16 == 0: unaligned 16-byte accesses are legal on
+  // this stack, tools/probes/unaligned_probe.hip); rows past T and groups of 16 environments
+  // that are not wholly below B are clamped to valid ones (no branch between the loads) and
+  // redone or neutralised in land().
+  // `lane` counts over all loader waves: 0 .. kLanes-1
+  __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
+                                        int t0, int64_t env0, int lane) {
+    // Clamped loads must stay inside the buffer's T * B bytes too (a C-ABI caller may have
+    // allocated exactly that): a batch of fewer than 16 environments has no whole group of
+    // 16 - land() takes all of it byte by byte - and its clamped loads read the buffer's
+    // last 16 bytes, or nothing at all when the whole buffer is shorter than that.
+    const int64_t last = (int64_t)T * B - 16;
+    if (last < 0) {   // uniform
+#pragma unroll
+      for (int i = 0; i < 2 * kPairs; ++i) pend[i] = u32x4{0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < kPairs; ++i) {
+      const int v = lane + i * kLanes;
+      const int rp = v / kVecPerRow, q = v % kVecPerRow;
+      int64_t e = env0 + 16 * q;
+      e = e + 16 <= B ? e : 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int row = t0 + 2 * rp + h;
+        row = row < T ? row : T - 1;
+        int64_t at = (int64_t)row * B + e;
+        at = at <= last ? at : last;   // (only ever changes a clamped, ignored load)
+        pend[2 * i + h] = *reinterpret_cast<const u32x4*>(actions + at);
+      }
+    }
+  }
+
+  __device__ __forceinline__ int land(int8_t* staged, const int8_t* __restrict__ actions, int64_t B,
+                                      int32_t T, int t0, int64_t env0, int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < kPairs; ++i) {
+      const int v = lane + i * kLanes;
+      const int rp = v / kVecPerRow, q = v % kVecPerRow;
+      const int64_t e = env0 + 16 * q;
+      const bool here = e + 16 <= B;
+      const bool real0 = here && (t0 + 2 * rp < T), real1 = here && (t0 + 2 * rp + 1 < T);
+      u32x4 lo = pend[2 * i], hi = pend[2 * i + 1];
+      if (!here && e < B) {
+        // the batch's last, partial group of environments (one lane of the last workgroup):
+        // byte by byte, "stay" past the end
+        uint32_t l[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+        uint32_t h[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+        for (int k = 0; e + k < B; ++k) {
+          const int sh = 8 * (k & 3);
+          if (t0 + 2 * rp < T) {
+            const uint32_t a = (uint8_t)actions[(int64_t)(t0 + 2 * rp) * B + e + k];
+            l[k >> 2] = (l[k >> 2] & ~(0xffu << sh)) | (a << sh);
+          }
+          if (t0 + 2 * rp + 1 < T) {
+            const uint32_t a = (uint8_t)actions[(int64_t)(t0 + 2 * rp + 1) * B + e + k];
+            h[k >> 2] = (h[k >> 2] & ~(0xffu << sh)) | (a << sh);
+          }
+        }
+        uint32_t out[4];
+        for (int k = 0; k < 4; ++k) out[k] = clamp_ids(l[k]) | (clamp_ids(h[k]) << 4);
+        const u32x4 packed = {out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
+        const u32x4 l4 = {l[0], l[1], l[2], l[3]}, h4 = {h[0], h[1], h[2], h[3]};
+        bad += count_bad16(l4) + count_bad16(h4);
+        continue;
+      }
+      const uint32_t l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
+      uint32_t out[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        out[k] = (real0 ? clamp_ids(l[k]) : 0x04040404u) | ((real1 ? clamp_ids(h[k]) : 0x04040404u) << 4);
+      const u32x4 packed = {out[0], out[1], out[2], out[3]};
+      *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
+      bad += (real0 ? count_bad16(lo) : 0) + (real1 ? count_bad16(hi) : 0);
+    }
+    return bad;
+  }
+};
+
+// The action of frame j of a group that starts at frame t0 of its chunk,
+// for environment `le` of the workgroup.
+template <int kEnvs>
+__device__ __forceinline__ uint32_t staged_action(const int8_t* chunk, int t0_in_chunk, int j,
+                                                   int le) {
+  const uint32_t b = (uint8_t)chunk[((t0_in_chunk + j) >> 1) * kEnvs + le];
+  return (b >> (4 * (j & 1))) & 0xfu;   // t0_in_chunk is a multiple of the group size (even)
+}
+
+// Four bytes (the low byte of each argument) as one dword.
+__device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return (a & 0xffu) | ((b & 0xffu) << 8) | ((c & 0xffu) << 16) | (d << 24);
+}
+
+// A/B: give each XCD a contiguous eighth of the batch (see tile_of_block).
+#ifndef CAMPX_UPD_XCD
+#define CAMPX_UPD_XCD 0
+#endif
+
+// loader waves of an update workgroup: one per 128 environments (a 256-environment
+// chunk held by one wave is 64 VGPRs of loads in flight: with two the pair kernel stops
+// spilling).  CAMPX_UPD_LOADERS overrides for A/B builds.
+#ifdef CAMPX_UPD_LOADERS
+constexpr int update_loaders(int) { return CAMPX_UPD_LOADERS; }
+#else
+constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
+#endif
+
+// A/B knobs: roll the consumers' float-stream loop (fewer registers, measured +0.8 us on
+// the boat race), and a register cap in waves per SIMD (capping the pair kernel at 96
+// VGPRs for two workgroups per CU measured 47 us against 42 us uncapped at 110).
+#ifndef CAMPX_UPD_ROLL_A
+#define CAMPX_UPD_ROLL_A 0
+#endif
+#ifndef CAMPX_UPD_MINWAVES
+#define CAMPX_UPD_MINWAVES 1
+#endif
+constexpr int update_min_waves(int, int) { return CAMPX_UPD_MINWAVES; }
+
+template <int kProd, int kCons, int kG>   // kG: frames per group (a ring slot)
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             update_min_waves(kProd, kCons)) void update_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first) {
+  constexpr int kLoad = update_loaders(kProd);
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
+  // LDS entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
+  // from (the art's cell when this frame ended the episode: the rebuild is folded into
+  // the chain), [16:22] the cell after this frame, [23] whether the mover shows there,
+  // [24] done, [25:26] perf + 1.  The ring keeps x and the upper half of y.
+  __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
+  __shared__ __attribute__((aligned(16))) float ring_r[2][kG][E];
+  __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kG][E];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool producer = wave < kProd, loader = wave >= kProd + kCons;
+  const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
+  const int W = mp.cols, HW = mp.rows * mp.cols;
+  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
+
+  const int cell0 = mp.row0 * W + mp.col0;
+  constexpr int kRowBytes = CAMPX_N_ACTIONS * (int)sizeof(uint2);
+  for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kThreads) {
+    const CampxTransition tr = spec->table[i];
+    const uint32_t from = tr.done ? (uint32_t)cell0 : (uint32_t)tr.next_cell;
+    const uint32_t vis = (tr.paint & 0x80u) ? 0u : 1u;  // scenery in front hides the mover
+    table[i] = make_uint2(__float_as_uint(tr.reward),
+                          (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) | (vis << 23) |
+                              ((uint32_t)tr.done << 24) | ((uint32_t)(tr.perf + 1) << 25));
+  }
+  ActionLoader<E, kLoad> ld;
+  int bad = 0;
+  if (loader && T > 0) {
+    ld.issue(actions, B, T, 0, env0, llane);
+    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
+  }
+
+  const int le = wave * kWave + lane;  // producers: this lane's environment in the workgroup
+  const int64_t env = env0 + le;
+  const bool live = producer && env < B;
+  int cell = cell0, over = 0;
+  float ret = 0.0f;
+  if (live && !reset_first) {
+    cell = (int)st.pos[env] * W + (int)st.pos[B + env];
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+  uint32_t row_off = (uint32_t)(over ? cell0 : cell) * kRowBytes;  // the chain's state
+  const char* table_bytes = reinterpret_cast<const char*>(table);
+  const int clane = (int)threadIdx.x - kProd * kWave;  // consumers: 0 .. CL-1
+  constexpr int kGroupsPerChunk = kChunk / kG;
+  __syncthreads();
+
+  const int n_groups = (T + kG - 1) / kG;
+  // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
+  // agree): registers are then allocated per role, and the loads a loader keeps in flight
+  // across iterations do not take registers from the other two.
+  if (producer) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g < n_groups) {
+          const int t0 = g * kG;
+          const int8_t* chunk = staged[(t0 / kChunk) & 1];
+          const int n = (T - t0 < kG) ? T - t0 : kG;
+          uint32_t col_off[kG];  // action * sizeof(entry), off the dependent chain
+  #pragma unroll
+          for (int j = 0; j < kG; ++j)
+            col_off[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le) * (uint32_t)sizeof(uint2);
+  #pragma unroll
+          for (int j = 0; j < kG; ++j) {
+            if (j < n) {
+              // the dependent chain: row offset -> entry -> row offset
+              const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
+              row_off = e.y & 0xffffu;
+              ring_r[g & 1][j][le] = __uint_as_float(e.x);
+              ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
+              // off the chain: the return restarts after an episode end
+              ret = (over ? 0.0f : ret) + __uint_as_float(e.x);
+              over = (int)((e.y >> 24) & 1u);
+              cell = (int)((e.y >> 16) & 0x7fu);
+            }
+          }
+        }
+      
+      __syncthreads();
+    }
+  } else if (!loader) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g > 0) {
+          const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
+          const int n = (T - t0 < kG) ? T - t0 : kG;
+          // ---- float streams: item = (frame j, 4 environments)
+          constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
+  #if CAMPX_UPD_ROLL_A
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+          for (int it = 0; it < kItA; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QA, q = item % QA;
+            const int64_t e0 = env0 + 4 * q;
+            if (j < n && e0 < B) {
+              const u32x4 r4 = *reinterpret_cast<const u32x4*>(&ring_r[rb][j][4 * q]);
+              const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
+              const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
+                                      (y4.y >> 24) & 1u};
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
+                if (out.reward) store16_update(out.reward + at, r4);
+                if (out.discount) {
+                  const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
+                                    dn[2] ? 0u : 0x3f800000u, dn[3] ? 0u : 0x3f800000u};
+                  store16_update(out.discount + at, d4);
+                }
+              } else {
+                const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
+                for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                  if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                  if (out.discount) out.discount[at + i] = dn[i] ? 0.0f : 1.0f;
+                }
+              }
+            }
+          }
+          // ---- byte streams: item = (frame j, 16 environments)
+          constexpr int QB = E / 16, kItB = (kG * QB + CL - 1) / CL;
+  #pragma unroll
+          for (int it = 0; it < kItB; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QB, q = item % QB;
+            const int64_t e0 = env0 + 16 * q;
+            if (item < kG * QB && j < n && e0 < B) {
+              const u32x4 ya = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q]);
+              const u32x4 yb = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q + 8]);
+              const uint32_t w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+              uint32_t tr[4], dn[4], pf[4];
+  #pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const uint32_t lo = w[2 * k], hi = w[2 * k + 1];  // two environments each
+                tr[k] = pack4(lo, lo >> 16, hi, (hi >> 16) & 0xffu);
+                dn[k] = pack4((lo >> 8) & 1u, (lo >> 24) & 1u, (hi >> 8) & 1u, (hi >> 24) & 1u);
+                pf[k] = pack4(((lo >> 9) & 3u) - 1u, ((lo >> 25) & 3u) - 1u, ((hi >> 9) & 3u) - 1u,
+                              (((hi >> 25) & 3u) - 1u) & 0xffu);
+              }
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
+                const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
+                store16_update(out.trace + at, t4);
+                if (out.done) {
+                  const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                  store16_update(out.done + at, d4);
+                }
+                if (out.perf) {
+                  const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                  store16_update(out.perf + at, p4);
+                }
+              } else {
+                for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                  const int sh = (i & 3) * 8;
+                  out.trace[at + i] = (uint8_t)(tr[i >> 2] >> sh);
+                  if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                  if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+                }
+              }
+            }
+          }
+        }
+      
+      __syncthreads();
+    }
+  } else {
+    for (int g = 0; g <= n_groups; ++g) {
+        // loader: while the producers are in chunk c, fetch chunk c + 1
+        const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+        const int t_next = (c + 1) * kChunk;
+        if (t_next < T) {
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+        }
+      
+      __syncthreads();
+    }
+  }
+
+  if (live) {
+    st.pos[env] = (int8_t)(cell / W);
+    st.pos[B + env] = (int8_t)(cell % W);
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+  report_bad_actions(out, bad);
+}
+
+// ---------------------------------------------------------------------------
+// Two-mover games: the same layout over the (cell, cell, action) pair table
+// (campx_pair_table_build).  The dependent chain goes through the 32-bit entries
+// themselves, which carry everything a frame outputs and go to the ring as they are; they
+// sit in LDS (dynamic, kLdsEntries) when the table fits, else they are read through L1/L2.
+// (Chaining through a separate 16-bit next-index table in LDS with the entries fetched off
+// the chain from global memory was built and measured slower - 68.9 against 51.4 us - and
+// removed.)
+struct PairParams {
+  int32_t rows, cols, n_layers;
+  int32_t dyn_layer[2], row0[2], col0[2];
+  int32_t lds_table;  // entries fit in LDS
+};
+
+#ifndef CAMPX_PAIR_LDS_ENTRIES
+#define CAMPX_PAIR_LDS_ENTRIES 8192
+#endif
+constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 32 KiB of LDS for the entries at most
+
+#ifndef CAMPX_PAIR_GROUP
+#define CAMPX_PAIR_GROUP 16   // frames per ring slot group (A/B builds)
+#endif
+
+template <bool kLdsEntries, int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             update_min_waves(kProd, kCons)) void update_pair_kernel(
+    PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, int64_t trace_plane) {
+  constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kLdsEntries: n_entries
+  __shared__ float reward_list[256];
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
+  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kG][E];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool producer = wave < kProd, loader = wave >= kProd + kCons;
+  const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
+  const int W = pp.cols, HW = pp.rows * pp.cols;
+  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
+
+  const float* g_rewards = static_cast<const float*>(st.pair_table);
+  const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
+  const int n_entries = HW * HW * CAMPX_N_ACTIONS;
+  if (kLdsEntries)
+    for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
+  for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
+  ActionLoader<E, kLoad> ld;
+  int bad = 0;
+  if (loader && T > 0) {
+    ld.issue(actions, B, T, 0, env0, llane);
+    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
+  }
+
+  const int le = wave * kWave + lane;
+  const int64_t env = env0 + le;
+  const bool live = producer && env < B;
+  const uint32_t init0 = (uint32_t)(pp.row0[0] * W + pp.col0[0]);
+  const uint32_t init1 = (uint32_t)(pp.row0[1] * W + pp.col0[1]);
+  uint32_t c0 = init0, c1 = init1;
+  int over = 0;
+  float ret = 0.0f;
+  if (live && !reset_first) {
+    c0 = (uint32_t)((int)st.pos[env] * W + (int)st.pos[B + env]);
+    c1 = (uint32_t)((int)st.pos[2 * B + env] * W + (int)st.pos[3 * B + env]);
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+  const int clane = (int)threadIdx.x - kProd * kWave;
+  constexpr int kGroupsPerChunk = kChunk / kG;
+  __syncthreads();
+
+  const int n_groups = (T + kG - 1) / kG;
+  // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
+  // agree): registers are then allocated per role, and the loads a loader keeps in flight
+  // across iterations do not take registers from the other two.
+  if (producer) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g < n_groups) {
+          const int t0 = g * kG;
+          const int8_t* chunk = staged[(t0 / kChunk) & 1];
+          const int n = (T - t0 < kG) ? T - t0 : kG;
+          uint32_t act[kG];
+  #pragma unroll
+          for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+  #pragma unroll
+          for (int j = 0; j < kG; ++j) {
+            if (j < n) {
+              if (over) {  // rebuilt from the art before its next action
+                c0 = init0;
+                c1 = init1;
+              }
+              const uint32_t idx = pair_index(c0, c1, HW) + act[j];
+              const uint32_t e = kLdsEntries ? lds_entries[idx] : g_entries[idx];   // the chain
+              c0 = e & 0x7fu;
+              c1 = (e >> 7) & 0x7fu;
+              ring[g & 1][j][le] = e;
+              ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
+              over = (int)((e >> 16) & 1u);
+            }
+          }
+        }
+      
+      __syncthreads();
+    }
+  } else if (!loader) {
+    for (int g = 0; g <= n_groups; ++g) {
+        if (g > 0) {
+          const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
+          const int n = (T - t0 < kG) ? T - t0 : kG;
+          const int64_t plane = trace_plane;  // from one moving thing's trace to the next's
+          constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
+  #pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
+          for (int it = 0; it < kItA; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QA, q = item % QA;
+            const int64_t e0 = env0 + 4 * q;
+            if (j < n && e0 < B) {
+              const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][4 * q]);
+              const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+              uint32_t rw[4], dc[4];
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
+                dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
+              }
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
+                if (out.reward) {
+                  const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
+                  store16_update(out.reward + at, r4);
+                }
+                if (out.discount) {
+                  const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
+                  store16_update(out.discount + at, d4);
+                }
+              } else {
+                for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                  if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                  if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
+                }
+              }
+            }
+          }
+          constexpr int QB = E / 16, kItB = (kG * QB + CL - 1) / CL;
+  #pragma unroll
+          for (int it = 0; it < kItB; ++it) {
+            const int item = clane + it * CL;
+            const int j = item / QB, q = item % QB;
+            const int64_t e0 = env0 + 16 * q;
+            if (item < kG * QB && j < n && e0 < B) {
+              uint32_t ta[4], tb[4], dn[4], pf[4];
+  #pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][16 * q + 4 * k]);
+                const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+                uint32_t a[4], b[4], d[4], p[4];
+  #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  a[i] = (e[i] & 0x7fu) | (((e[i] >> 14) & 1u) << 7);
+                  b[i] = ((e[i] >> 7) & 0x7fu) | (((e[i] >> 15) & 1u) << 7);
+                  d[i] = (e[i] >> 16) & 1u;
+                  p[i] = (((e[i] >> 17) & 3u) - 1u) & 0xffu;
+                }
+                ta[k] = pack4(a[0], a[1], a[2], a[3]);
+                tb[k] = pack4(b[0], b[1], b[2], b[3]);
+                dn[k] = pack4(d[0], d[1], d[2], d[3]);
+                pf[k] = pack4(p[0], p[1], p[2], p[3]);
+              }
+              const int64_t at = (int64_t)(t0 + j) * B + e0;
+              if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
+                const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
+                store16_update(out.trace + at, a4);
+                store16_update(out.trace + plane + at, b4);
+                if (out.done) {
+                  const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                  store16_update(out.done + at, d4);
+                }
+                if (out.perf) {
+                  const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                  store16_update(out.perf + at, p4);
+                }
+              } else {
+                for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                  const int sh = (i & 3) * 8;
+                  out.trace[at + i] = (uint8_t)(ta[i >> 2] >> sh);
+                  out.trace[plane + at + i] = (uint8_t)(tb[i >> 2] >> sh);
+                  if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                  if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+                }
+              }
+            }
+          }
+        }
+      
+      __syncthreads();
+    }
+  } else {
+    for (int g = 0; g <= n_groups; ++g) {
+        const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+        const int t_next = (c + 1) * kChunk;
+        if (t_next < T) {
+          if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+          if (phase == kGroupsPerChunk - 1)
+            bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+        }
+      
+      __syncthreads();
+    }
+  }
+
+  if (live) {
+    st.pos[env] = (int8_t)(c0 / (uint32_t)W);
+    st.pos[B + env] = (int8_t)(c0 % (uint32_t)W);
+    st.pos[2 * B + env] = (int8_t)(c1 / (uint32_t)W);
+    st.pos[3 * B + env] = (int8_t)(c1 % (uint32_t)W);
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+  report_bad_actions(out, bad);
+}
+
+// ---------------------------------------------------------------------------
+// Three- and four-mover games: the same producer / consumer / loader layout over a
+// direct-indexed (cell, cell, cell[, cell], action) table in GLOBAL memory
+// (campx_tuple_table_build: 4.4 MB for three movers on a 6x8 board, 212 MB for four).
+// 64-bit entries: bits 0-27 the things' cells after the frame (7 bits each), 28-31
+// whether each is the character its cell shows, 32 done, 33-34 perf + 1, 35-42 index into
+// the reward list.  The dependent chain is one global load per frame, so the kernel wants
+// every environment in flight at once: 8-frame groups keep the ring small enough for two
+// 256-environment workgroups per CU.
+// Four waves per SIMD = two workgroups per CU, so that 131 072 environments are all in
+// flight at once (four movers: 131 -> 128 VGPRs; sokoban level 2 87 -> 65 us per launch).
+#ifndef CAMPX_TUPLE_MINWAVES
+#define CAMPX_TUPLE_MINWAVES 4
+#endif
+
+template <int K, int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             CAMPX_TUPLE_MINWAVES) void update_tuple_kernel(
+    TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B,
+    int32_t T, int32_t reset_first, int64_t trace_plane) {
+  constexpr int kLoad = update_loaders(kProd), kG = kTupleGroup;
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
+  __shared__ float reward_list[256];
+  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
+  __shared__ __attribute__((aligned(16))) uint64_t ring[2][kG][E];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool producer = wave < kProd, loader = wave >= kProd + kCons;
+  const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;
+  const int W = tp.cols;
+  const uint32_t HW = (uint32_t)(tp.rows * tp.cols);
+  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const float* g_rewards = static_cast<const float*>(st.pair_table);
+  const uint64_t* g_entries = reinterpret_cast<const uint64_t*>(g_rewards + 256);
+  for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
+  ActionLoader<E, kLoad> ld;
+  int bad = 0;
+  if (loader && T > 0) {
+    ld.issue(actions, B, T, 0, env0, llane);
+    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
+  }
+  const int le = wave * kWave + lane;
+  const int64_t env = env0 + le;
+  const bool live = producer && env < B;
+  uint32_t init = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) init |= (uint32_t)(tp.row0[k] * W + tp.col0[k]) << (7 * k);
+  uint32_t cells = init;
+  int over = 0;
+  float ret = 0.0f;
+  if (live && !reset_first) {
+    cells = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      cells |= (uint32_t)((int)st.pos[(int64_t)(2 * k) * B + env] * W +
+                          (int)st.pos[(int64_t)(2 * k + 1) * B + env]) << (7 * k);
+    over = st.done[env];
+    if (st.ret) ret = st.ret[env];
+  }
+  const int clane = (int)threadIdx.x - kProd * kWave;
+  constexpr int kGroupsPerChunk = kChunk / kG;
+  __syncthreads();
+
+  const int n_groups = (T + kG - 1) / kG;
+  if (producer) {
+    for (int g = 0; g <= n_groups; ++g) {
+      if (g < n_groups) {
+        const int t0 = g * kG;
+        const int8_t* chunk = staged[(t0 / kChunk) & 1];
+        const int n = (T - t0 < kG) ? T - t0 : kG;
+        uint32_t act[kG];
+#pragma unroll
+        for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+#pragma unroll
+        for (int j = 0; j < kG; ++j) {
+          if (j < n) {
+            cells = over ? init : cells;  // rebuilt from the art before its next action
+            const uint64_t e = g_entries[tuple_index<K>(cells, HW) + act[j]];  // the chain
+            cells = (uint32_t)e & 0x0fffffffu;
+            ring[g & 1][j][le] = e;
+            ret = (over ? 0.0f : ret) + reward_list[(uint32_t)(e >> 35) & 0xffu];
+            over = (int)((e >> 32) & 1u);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if (!loader) {
+    for (int g = 0; g <= n_groups; ++g) {
+      if (g > 0) {
+        const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
+        const int n = (T - t0 < kG) ? T - t0 : kG;
+        const int64_t plane = trace_plane;  // from one moving thing's trace to the next's
+        // ---- float streams: item = (frame j, 4 environments)
+        constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
+#pragma unroll 1
+        for (int it = 0; it < kItA; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QA, q = item % QA;
+          const int64_t e0 = env0 + 4 * q;
+          if (item < kG * QA && j < n && e0 < B) {
+            uint32_t rw[4], dc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t hi = (uint32_t)(ring[rb][j][4 * q + i] >> 32);
+              rw[i] = __float_as_uint(reward_list[(hi >> 3) & 0xffu]);
+              dc[i] = (hi & 1u) ? 0u : 0x3f800000u;
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
+              if (out.reward) {
+                const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
+                store16_update(out.reward + at, r4);
+              }
+              if (out.discount) {
+                const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
+                store16_update(out.discount + at, d4);
+              }
+            } else {
+              for (int i = 0; i < 4 && e0 + i < B; ++i) {
+                if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
+                if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
+              }
+            }
+          }
+        }
+        // ---- byte streams: item = (frame j, 16 environments)
+        constexpr int QB = E / 16, kItB = (kG * QB + CL - 1) / CL;
+#pragma unroll 1
+        for (int it = 0; it < kItB; ++it) {
+          const int item = clane + it * CL;
+          const int j = item / QB, q = item % QB;
+          const int64_t e0 = env0 + 16 * q;
+          if (item < kG * QB && j < n && e0 < B) {
+            uint32_t tr[K][4], dn[4], pf[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              uint32_t lo[4], hi[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint64_t e = ring[rb][j][16 * q + 4 * w + i];
+                lo[i] = (uint32_t)e;
+                hi[i] = (uint32_t)(e >> 32);
+              }
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                uint32_t b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  b[i] = ((lo[i] >> (7 * k)) & 0x7fu) | (((lo[i] >> (28 + k)) & 1u) << 7);
+                tr[k][w] = pack4(b[0], b[1], b[2], b[3]);
+              }
+              dn[w] = pack4(hi[0] & 1u, hi[1] & 1u, hi[2] & 1u, hi[3] & 1u);
+              pf[w] = pack4(((hi[0] >> 1) & 3u) - 1u, ((hi[1] >> 1) & 3u) - 1u,
+                            ((hi[2] >> 1) & 3u) - 1u, (((hi[3] >> 1) & 3u) - 1u) & 0xffu);
+            }
+            const int64_t at = (int64_t)(t0 + j) * B + e0;
+            if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const u32x4 t4 = {tr[k][0], tr[k][1], tr[k][2], tr[k][3]};
+                store16_update(out.trace + k * plane + at, t4);
+              }
+              if (out.done) {
+                const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
+                store16_update(out.done + at, d4);
+              }
+              if (out.perf) {
+                const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
+                store16_update(out.perf + at, p4);
+              }
+            } else {
+              for (int i = 0; i < 16 && e0 + i < B; ++i) {
+                const int sh = (i & 3) * 8;
+#pragma unroll
+                for (int k = 0; k < K; ++k) out.trace[k * plane + at + i] = (uint8_t)(tr[k][i >> 2] >> sh);
+                if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
+                if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int g = 0; g <= n_groups; ++g) {
+      const int c = g / kGroupsPerChunk, phase = g % kGroupsPerChunk;
+      const int t_next = (c + 1) * kChunk;
+      if (t_next < T) {
+        if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
+        if (phase == kGroupsPerChunk - 1)
+          bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+      }
+      __syncthreads();
+    }
+  }
+
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t c = (cells >> (7 * k)) & 0x7fu;
+      st.pos[(int64_t)(2 * k) * B + env] = (int8_t)(c / (uint32_t)W);
+      st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)(c % (uint32_t)W);
+    }
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+  }
+  report_bad_actions(out, bad);
+}
+
+constexpr int kBigEnvs = 8 * kWave;   // environments of a "big" update workgroup
+
+// Number of big workgroups from which launch_update prefers them: one per CU of the chip
+// (CAMPX_BIG_WGS overrides; a huge value turns them off).
+int64_t knob_big_workgroups() {
+  static const int64_t forced = [] {
+    const char* v = getenv("CAMPX_BIG_WGS");
+    return (v && *v) ? (int64_t)atoll(v) : (int64_t)-1;
+  }();
+  if (forced >= 0) return forced;
+  // the current device's CU count, asked once per device (a process may drive several)
+  static std::mutex lock;
+  static std::map<int, int64_t> cus_of;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> guard(lock);
+  const auto it = cus_of.find(dev);
+  if (it != cus_of.end()) return it->second;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  cus_of[dev] = cus;
+  return (int64_t)cus;
+}
+
+PairParams make_pair_params(const CampxSpec& s) {
+  PairParams pp;
+  memset(&pp, 0, sizeof(pp));
+  pp.rows = s.rows;
+  pp.cols = s.cols;
+  pp.n_layers = s.n_layers;
+  for (int d = 0; d < 2; ++d) {
+    pp.dyn_layer[d] = s.dyn_layer[d];
+    pp.row0[d] = s.dyn_row0[d];
+    pp.col0[d] = s.dyn_col0[d];
+  }
+  return pp;
+}
+
+// Shape of the update kernels' workgroups: producer and consumer waves (A/B builds can
+// override).  Measured, whole rollout launch at the BASELINE sizes (gpurun_out/r2a):
+// one-mover table kernel, boat race: (1,1) 0.2006, (1,3) 0.2112, (2,2) 0.2034,
+// (2,4) 0.2005, (4,4) 0.1946 ms - the 256-environment workgroup writes 1 KiB / 256 B row
+// pieces instead of 512 / 128 B.  With the final kernels (gpurun_out/r2y, kernel time in
+// us): table kernel, boat race / wall world: (4,4) 16.4 / 73, (2,2) 17.1 / 66.5,
+// (4,2) 21.3 / 63; pair kernel, sokoban: (4,4) 44-50, (4,2) 42, (2,2) 62, (2,1) 57.
+#ifndef CAMPX_UPD_PROD
+#define CAMPX_UPD_PROD 4
+#endif
+#ifndef CAMPX_UPD_CONS
+#define CAMPX_UPD_CONS 4
+#endif
+#ifndef CAMPX_UPD_GROUP
+// frames per group of the 256-environment one-mover workgroups; kernel us per 100 frames at
+// B = 4 096 / 65 536 (gpurun_out/t20-t21): 4: 18.1 / 21.4, 8: 14.8 / 17.8, 16: 12.4 / 15.6,
+// 32: 12.7 / 16.8 - a group costs ~0.3 us of hand-over, a longer one more fill and drain
+#define CAMPX_UPD_GROUP 16
+#endif
+#ifndef CAMPX_PAIR_PROD
+#define CAMPX_PAIR_PROD 4
+#endif
+#ifndef CAMPX_PAIR_CONS
+#define CAMPX_PAIR_CONS 2
+#endif
+#ifndef CAMPX_TUPLE_PROD
+#define CAMPX_TUPLE_PROD 4
+#endif
+#ifndef CAMPX_TUPLE_CONS
+#define CAMPX_TUPLE_CONS 2
+#endif
+
+// `trace_plane`: rows (environments) from one moving thing's plane of the trace to the
+// next's - B times the frames the whole trace holds, which is more than T when the caller
+// runs a launch in chunks.
+int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                     int32_t reset_first, bool use_table, int64_t trace_plane,
+                     hipStream_t stream) {
+  // 512-environment workgroups (twice the row piece per store) once there are enough
+  // environments to give every CU one; 256-environment workgroups below that
+  const bool big = B >= (int64_t)kBigEnvs * knob_big_workgroups();
+  if (use_table) {
+    const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                            s.dyn_row0[0], s.dyn_col0[0]};
+    if (big) {
+      constexpr int kProd = 8, kCons = 4;
+      const dim3 grid((unsigned)((B + kBigEnvs - 1) / kBigEnvs)),
+          block((kProd + kCons + update_loaders(kProd)) * kWave);
+      hipLaunchKernelGGL((update_table_kernel<kProd, kCons, 8>), grid, block, 0, stream, mp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    } else {
+      constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
+      const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
+          block((kProd + kCons + update_loaders(kProd)) * kWave);
+      hipLaunchKernelGGL((update_table_kernel<kProd, kCons, CAMPX_UPD_GROUP>), grid, block, 0, stream, mp,
+                         spec_dev, st, actions, out, B, T, reset_first);
+    }
+  } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
+    const PairParams pp = make_pair_params(s);
+    const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
+    // the entries in LDS when they fit (CAMPX_PAIR_MODE=0: read them through L1/L2 anyway)
+    const bool in_lds = n_entries <= kPairLdsEntries && knob_pair_mode() != 0;
+    const size_t shmem = in_lds ? (((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15) : 0;
+#define CAMPX_PAIR_LAUNCH(PROD, CONS)                                                          \
+  do {                                                                                         \
+    const dim3 grid((unsigned)((B + (PROD) * kWave - 1) / ((PROD) * kWave))),                  \
+        block(((PROD) + (CONS) + update_loaders(PROD)) * kWave);                               \
+    if (in_lds)                                                                                \
+      hipLaunchKernelGGL((update_pair_kernel<true, PROD, CONS>), grid, block, shmem, stream,   \
+                         pp, spec_dev, st, actions, out, B, T, reset_first, trace_plane);      \
+    else                                                                                       \
+      hipLaunchKernelGGL((update_pair_kernel<false, PROD, CONS>), grid, block, 0, stream, pp,  \
+                         spec_dev, st, actions, out, B, T, reset_first, trace_plane);          \
+  } while (0)
+    if (big)
+      CAMPX_PAIR_LAUNCH(8, 4);
+    else
+      CAMPX_PAIR_LAUNCH(CAMPX_PAIR_PROD, CAMPX_PAIR_CONS);
+#undef CAMPX_PAIR_LAUNCH
+  } else if (s.n_dyn >= 3 && st.pair_table && !knob_no_table()) {
+    constexpr int kProd = CAMPX_TUPLE_PROD, kCons = CAMPX_TUPLE_CONS, kEnvs = kProd * kWave;
+    const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
+        block((kProd + kCons + update_loaders(kProd)) * kWave);
+    const TupleParams tp = make_tuple_params(s);
+    if (s.n_dyn == 3)
+      hipLaunchKernelGGL((update_tuple_kernel<3, kProd, kCons>), grid, block, 0, stream, tp, st,
+                         actions, out, B, T, reset_first, trace_plane);
+    else
+      hipLaunchKernelGGL((update_tuple_kernel<4, kProd, kCons>), grid, block, 0, stream, tp, st,
+                         actions, out, B, T, reset_first, trace_plane);
+  } else {
+    launch_trace(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_failed(e);
+  return CAMPX_OK;
+}
+
+}  // namespace campx_impl

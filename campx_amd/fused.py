@@ -149,6 +149,7 @@ class FusedGame(object):
     self._aux = None
     self._aux_event = None
     self._aux_in_sync = False
+    self._trace_readers = {}   # trace buffer address -> event after the render that read it
 
   # ------------------------------------------------------------------ helpers
 
@@ -335,11 +336,13 @@ class FusedGame(object):
       pipelined: run this call's update pass (a short latency-bound kernel) on a side
           stream so that it overlaps the observation stream of the PREVIOUS rollout,
           which is still running on the current stream; the render kernel then waits
-          for it by event.  Results are identical; the caller promises two things the
-          engine cannot check: (1) `actions` are ready - not being produced by work
-          still queued on the current stream - and (2) `out` is not the dict of the
-          previous pipelined call (alternate two `rollout_buffers()`; they may share
-          `obs`).  Needs the two-kernel path (`out['trace']`).  Open-loop action
+          for it by event, and an update pass waits for the render that last read the
+          trace buffer it is about to overwrite.  Results are identical; the caller
+          promises two things the engine cannot check: (1) `actions` are ready - not
+          being produced by work still queued on the current stream - and (2) `out` is
+          not the dict of the previous pipelined call (alternate two `rollout_buffers()`;
+          they may share `obs`), and its per-frame scalars have been consumed before it
+          comes round again.  Needs the two-kernel path (`out['trace']`).  Open-loop action
           streams (random exploration, scripted or replayed episodes) are the use.
     Returns:
       dict with 'obs' ([T,B,L,H,W] or the last frame [B,L,H,W]), 'board' (or
@@ -380,6 +383,14 @@ class FusedGame(object):
       if not self._aux_in_sync:
         self._aux.wait_stream(main)      # once: state set up by earlier non-pipelined work
         self._aux_in_sync = True
+        self._trace_readers.clear()      # ... which also covers every render issued so far
+      # The side stream runs ahead of the main one without bound; what it may not do is
+      # overwrite a trace buffer that a render on the main stream is still reading (with two
+      # alternating buffer sets: the render of two calls ago).
+      trace_key = out['trace'].data_ptr()
+      reader = self._trace_readers.get(trace_key)
+      if reader is not None:
+        self._aux.wait_event(reader)
       with torch.cuda.stream(self._aux):
         self._update(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
                      self._pair_table, ids, out['reward'], out['discount'], out['done'],
@@ -388,6 +399,9 @@ class FusedGame(object):
         self._aux_event.record(self._aux)
       main.wait_event(self._aux_event)
       self._render(self._spec_host, self._spec_dev, out['trace'], out['obs'], out['board'])
+      if reader is None:
+        reader = self._trace_readers[trace_key] = torch.cuda.Event()
+      reader.record(main)
     else:
       self._aux_in_sync = False
       self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,

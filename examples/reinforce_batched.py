@@ -52,7 +52,11 @@ def run(batch=4096, episodes=10, frames=100, gamma=0.99, lr=1e-2, csv=None, seed
     obs, _, _ = fused.reset()                           # new episode: rebuild from the art
     log_probs, rewards, perf = [], [], torch.zeros(batch, device=device)
     for t in range(frames):
-      logp = policy(obs.layered_board.view(batch, n_in))          # bf16 in, no conversion
+      # bf16 straight from the kernel, no conversion - but a COPY: play() overwrites the
+      # engine's frame buffer in place, and autograd keeps the policy's input for backward
+      # (the campx:: ops bump the buffer's version counter, so feeding the view itself makes
+      # backward() raise instead of differentiating the last frame T times)
+      logp = policy(obs.layered_board.view(batch, n_in).clone())
       ids = torch.multinomial(logp.float().exp(), 1).squeeze(1)
       log_probs.append(logp.gather(1, ids[:, None]).squeeze(1).float())
       obs, reward, _ = game.play(ids.to(torch.int8))

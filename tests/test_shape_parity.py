@@ -128,13 +128,22 @@ def test_random_streams_vs_oracle(batch):
   rng = np.random.RandomState(batch)
   game, _ = _game(batch)
   og = cpu.OracleGame.from_description(gamespec.describe(hello_world.build()))
+  # the running return: rewards since the latest rebuild; a frame nobody rewards (the quit
+  # action: reward None = NaN) adds nothing to it
+  want_ret, ended = np.zeros(batch, np.float32), np.zeros(batch, bool)
   for launch, T in enumerate([1, 9, 40]):
     actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
     out = game.rollout(torch.from_numpy(actions), want_board=True)
     ref = og.rollout(actions, reset_first=(launch == 0))
     for k in ('obs', 'board', 'reward', 'discount', 'done'):
       assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
+    for t in range(T):
+      want_ret = np.where(ended, 0, want_ret).astype(np.float32)
+      want_ret = want_ret + np.where(np.isnan(ref['reward'][t]), 0, ref['reward'][t]).astype(np.float32)
+      ended = ref['done'][t] == 1
+    assert _same(game.fused.ret.cpu().numpy(), want_ret), launch
   assert ref['done'].sum() > 0 or batch < 3
+  assert not np.isnan(want_ret).any()
 
 
 def test_larger_batch_and_invariants():

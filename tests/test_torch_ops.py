@@ -201,3 +201,39 @@ def test_pipelined_rollouts_match_in_order_rollouts(name):
         o1, r1, _ = a.play(x[0]); o2, r2, _ = b.play(x[0])
         assert torch.equal(o1.layered_board, o2.layered_board) and torch.equal(r1, r2)
     assert torch.equal(a.fused.pos, b.fused.pos) and torch.equal(a.fused.ret, b.fused.ret)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['boat_race', 'sokoban'])
+def test_pipelined_rollouts_do_not_overwrite_a_trace_still_being_rendered(name):
+  """Six pipelined calls with different actions, two alternating buffer sets with their own
+  observation buffers, ONE synchronisation at the end: the side stream must not start the
+  update pass of call i + 2 before the render of call i has read the trace they share.
+  Long renders (T = 100 at B = 65 536) against update passes a tenth as long make the
+  overrun certain without that ordering."""
+  import sys, os
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from games_under_test import FUSED_GAMES
+  B, T, N = 65536, 100, 6
+  a = FUSED_GAMES[name](batch=B, device='cuda'); a.its_showtime()
+  b = FUSED_GAMES[name](batch=B, device='cuda'); b.its_showtime()
+  gen = torch.Generator().manual_seed(11)
+  acts = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8).cuda() for _ in range(N)]
+  # what each call must show at a sample of frames, from in-order rollouts
+  frames = [0, T // 2, T - 1]
+  want = []
+  for i, x in enumerate(acts):
+    out = a.rollout(x, reset_first=(i == 0))
+    want.append([out['obs'][f].clone() for f in frames])
+  torch.cuda.synchronize()
+  bufs = [b.fused.rollout_buffers(T), b.fused.rollout_buffers(T)]
+  kept = []
+  for i, x in enumerate(acts):
+    got = b.rollout(x, out=bufs[i & 1], reset_first=(i == 0), pipelined=True)
+    # keep the sampled frames by a copy queued on the main stream (ordered after the render)
+    kept.append([got['obs'][f].clone() for f in frames])
+  torch.cuda.synchronize()
+  for i in range(N):
+    for j, f in enumerate(frames):
+      assert torch.equal(kept[i][j], want[i][j]), (i, f)
+  assert torch.equal(a.fused.pos, b.fused.pos)

@@ -3,6 +3,9 @@
 
     python tools/build_variants.py name:-DCAMPX_UPD_PROD=4,-DCAMPX_UPD_CONS=4 ...
 
+Each variant has its own object directory (build/variants/<name>/obj): the library is one
+translation unit per kernel family (campx_amd/build.py UNITS), compiled in parallel.
+
 Each directory also gets a copy of libcampx_torch.so (its rpath is $ORIGIN, so it binds
 to the variant next to it).  Run one with  CAMPX_LIB=build/variants/<name>/libcampx_hip.so.
 """
@@ -18,21 +21,14 @@ from campx_amd import build  # noqa: E402
 
 def main(specs):
   build.build_all()
-  procs = []
   for spec in specs:
     name, _, defs = spec.partition(':')
     d = os.path.join(REPO, 'build', 'variants', name)
     os.makedirs(d, exist_ok=True)
-    out = os.path.join(d, 'libcampx_hip.so')
-    cmd = [build.find_hipcc()] + build.HIPCC_FLAGS + [x for x in defs.split(',') if x] + [
-        '-I', build.INCLUDE, build.SRC, '-o', out]
-    procs.append((name, subprocess.Popen(cmd)))
+    objs = build.compile_units(obj_dir=os.path.join(d, 'obj'),
+                               defines=[x for x in defs.split(",") if x], jobs=8, force=True)
+    build.link(objs, os.path.join(d, 'libcampx_hip.so'))
     shutil.copy(build.TORCH_OUT, os.path.join(d, 'libcampx_torch.so'))
-    if len(procs) % 4 == 0:
-      for _, p in procs[-4:]:
-        p.wait()
-  for name, p in procs:
-    assert p.wait() == 0, name
     print('built', name)
 
 
