@@ -21,7 +21,7 @@ _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
 
 EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
-           'campx_pair_table_bytes', 'campx_pair_table_build',
+           'campx_pair_table_bytes', 'campx_pair_table_build', 'campx_pair_table_pack',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
            'campx_shape_spec_size', 'campx_shape_spec_validate',
@@ -66,6 +66,8 @@ def _load():
   lib.campx_pair_table_bytes.argtypes = [spec_p]
   lib.campx_pair_table_build.restype = i32
   lib.campx_pair_table_build.argtypes = [spec_p, vp, vp, vp]
+  lib.campx_pair_table_pack.restype = i32
+  lib.campx_pair_table_pack.argtypes = [spec_p, vp, vp, vp, vp, vp, vp]
   lib.campx_reset_launch.restype = i32
   lib.campx_reset_launch.argtypes = [spec_p, vp, CampxState, CampxOutputs, i64, vp]
   lib.campx_rollout_launch.restype = i32

@@ -4,8 +4,9 @@ Mirror of the reference's construction API (`campx/ascii_art.py:29-340`):
 `ascii_art_to_game(art, what_lies_beneath, sprites, drapes, backdrop,
 update_schedule, z_order, occlusion_in_layers)` and `Partial`.  Two keyword
 arguments are added at the end, `batch` and `device`; leaving them out gives the
-reference's single-environment engine, passing `batch=B` gives the fused HIP
-tier (see `engine.Engine`).
+reference's single-environment engine (or the process-wide default of
+`engine.set_default_batch`), passing `batch=B` gives the fused HIP tier (see
+`engine.Engine`).
 
 Behaviour kept from the reference:
 
@@ -27,7 +28,7 @@ import numpy as np
 import torch
 
 from . import things
-from .engine import Engine
+from .engine import Engine, _UNSET
 
 _ART_ERROR = (
     'the argument to ascii_art_to_uint8_nparray must be a list (or tuple) '
@@ -76,7 +77,7 @@ def ascii_art_to_game(art,
                       update_schedule=None,
                       z_order=None,
                       occlusion_in_layers=True,
-                      batch=None,
+                      batch=_UNSET,
                       device=None):
   """Turn an ASCII-art board plus entity classes into an initialised `Engine`.
 

@@ -190,7 +190,7 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
 
 int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState st,
                const int8_t* actions, CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
-               int32_t emit_first, void* stream, bool interpreter_only = false) {
+               int32_t emit_first, void* stream) {
   if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
@@ -201,24 +201,75 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (v != CAMPX_OK) return v;
   if (lds_bytes(*spec_host, out.board != nullptr, kWave) + 8 * 1024 > kLdsPerWorkgroup) return CAMPX_ESPEC;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool use_table =
-      spec_host->table_valid && spec_host->n_dyn == 1 && !interpreter_only && !knob_no_table();
+  // a host-tabulated game (table_only) has no rules: its tables are not optional
+  const bool only = spec_host->table_only != 0;
+  const bool no_table = knob_no_table() && !only;
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 && !no_table;
+  if (only && T > 0 && spec_host->n_dyn >= 2 && !st.pair_table) return CAMPX_ESPEC;
   if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
-  if (!emit_first && !interpreter_only && split_ok(*spec_host, out, B, T))
+  if (!emit_first && split_ok(*spec_host, out, B, T))
     return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
   // (16-bit observations: the render kernel above, or the one-frame kernels below)
   if (use_table && T == 1 && !emit_first && spec_host->render_valid && !knob_no_step())
     return launch_step_table(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (T == 1 && !emit_first && spec_host->n_dyn == 2 && st.pair_table && spec_host->render_valid &&
-      !interpreter_only && !knob_no_table() && !knob_no_step())
+      !no_table && !knob_no_step())
     return launch_step_pair(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (T == 1 && !emit_first && spec_host->n_dyn >= 3 && st.pair_table && spec_host->render_valid &&
-      !interpreter_only && !knob_no_table() && !knob_no_step())
+      !no_table && !knob_no_step())
     return launch_step_tuple(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;
   if (use_table)
     return launch_table(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
+  // (T == 0: the its_showtime() observation - positions from the art, no rule is run)
+  if (only && T > 0) return CAMPX_ESPEC;
   return launch_interp(*spec_host, spec_dev, st, actions, out, B, T, reset_first, emit_first, s);
+}
+
+// Pack one frame's outcome of every (cell, ..., cell, action) tuple into the pair / tuple
+// table format (include/campx_hip.h, campx_pair_table_build): `h_table` = 256 floats (the
+// reward list) followed by the entries.  CAMPX_ESPEC for more than 256 distinct rewards.
+int32_t pack_state_table(const CampxSpec& spec, size_t n, const uint8_t* h_trace,
+                         const float* h_reward, const uint8_t* h_done, const int8_t* h_perf,
+                         float* h_table) {
+  const int K = spec.n_dyn;
+  uint32_t* h_entries32 = reinterpret_cast<uint32_t*>(h_table + 256);
+  uint64_t* h_entries64 = reinterpret_cast<uint64_t*>(h_table + 256);
+  int n_rewards = 0;
+  uint32_t reward_bits[256];
+  for (int i = 0; i < 256; ++i) h_table[i] = 0.0f;
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t bits;
+    memcpy(&bits, &h_reward[i], 4);
+    int idx = -1;
+    for (int k = 0; k < n_rewards; ++k) {
+      if (reward_bits[k] == bits) {
+        idx = k;
+        break;
+      }
+    }
+    if (idx < 0) {
+      if (n_rewards == 256) return CAMPX_ESPEC;
+      idx = n_rewards++;
+      reward_bits[idx] = bits;
+      h_table[idx] = h_reward[i];
+    }
+    const uint32_t perf = (uint32_t)((spec.perf_dyn >= 0 && h_perf ? h_perf[i] : 0) + 1);
+    const uint32_t over = (uint32_t)(h_done[i] & 1);
+    if (K == 2) {
+      const uint32_t ta = h_trace[i], tb = h_trace[n + i];
+      h_entries32[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
+                       (over << 16) | (perf << 17) | ((uint32_t)idx << 19);
+    } else {
+      uint32_t lo = 0;
+      for (int d = 0; d < K; ++d) {
+        const uint32_t tr = h_trace[(size_t)d * n + i];
+        lo |= ((tr & 0x7fu) << (7 * d)) | ((tr >> 7) << (28 + d));
+      }
+      h_entries64[i] = (uint64_t)lo | ((uint64_t)(over | (perf << 1) | ((uint32_t)idx << 3)) << 32);
+    }
+  }
+  return CAMPX_OK;
 }
 
 }  // namespace campx_impl
@@ -271,6 +322,17 @@ int32_t campx_spec_validate(const CampxSpec* s) {
     }
   }
   if (s->n_rules > 0 && !s->rules[s->n_rules - 1].end_group) return CAMPX_ESPEC;
+  if (s->table_only != 0 && s->table_only != 1) return CAMPX_ESPEC;
+  if (s->table_only) {
+    if (s->n_rules != 0) return CAMPX_ESPEC;
+    if (s->n_dyn == 1) {   // the host-filled transition table is the game
+      if (!s->table_valid) return CAMPX_ESPEC;
+      for (int i = 0; i < HW * CAMPX_N_ACTIONS; ++i)
+        if (s->table[i].next_cell >= HW || s->table[i].done > 1 ||
+            (s->table[i].paint & 0x7fu) >= (uint32_t)s->n_layers)
+          return CAMPX_ESPEC;
+    }
+  }
   if (s->perf_dyn < -1 || s->perf_dyn >= s->n_dyn) return CAMPX_ESPEC;
   if (s->perf_dyn >= 0) {
     if (s->perf_n < 2 || s->perf_n > 255) return CAMPX_ESPEC;
@@ -283,7 +345,7 @@ int32_t campx_spec_validate(const CampxSpec* s) {
 int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
   const int32_t v = campx_spec_validate(spec);
   if (v != CAMPX_OK) return v;
-  spec->table_valid = 0;
+  if (!spec->table_only) spec->table_valid = 0;   // (a host-tabulated game: its table IS the game)
   {
     const int HW = spec->rows * spec->cols, LHW = spec->n_layers * HW;
     const int pitch_obs = ((LHW + 15) & ~15) + 16, pitch_board = ((HW + 15) & ~15) + 16;
@@ -296,7 +358,7 @@ int32_t campx_spec_compile(CampxSpec* spec, void* stream) {
     }
     spec->render_valid = 1;
   }
-  if (spec->n_dyn != 1) return CAMPX_OK;
+  if (spec->n_dyn != 1 || spec->table_only) return CAMPX_OK;
   const int W = spec->cols, HW = spec->rows * spec->cols;
   const int n = HW * CAMPX_N_ACTIONS;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -397,6 +459,7 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
                                void* stream) {
   const int64_t bytes = campx_pair_table_bytes(spec);
   if (bytes == 0 || !spec_dev || !table_dev) return CAMPX_EINVAL;
+  if (spec->table_only) return CAMPX_ESPEC;   // no rules to run: campx_pair_table_pack()
   const int K = spec->n_dyn, W = spec->cols, HW = spec->rows * spec->cols;
   size_t n = CAMPX_N_ACTIONS;
   for (int d = 0; d < K; ++d) n *= (size_t)HW;
@@ -423,8 +486,6 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
     return CAMPX_ENOMEM;
   }
   float* h_table = reinterpret_cast<float*>(host);
-  uint32_t* h_entries32 = reinterpret_cast<uint32_t*>(h_table + 256);
-  uint64_t* h_entries64 = reinterpret_cast<uint64_t*>(h_table + 256);
   float* h_reward = reinterpret_cast<float*>(host + table_bytes);
   int8_t* h_pos = reinterpret_cast<int8_t*>(h_reward + n);
   int8_t* h_act = h_pos + 2 * (size_t)K * n;
@@ -442,8 +503,6 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
     }
   }
   int32_t rc = CAMPX_OK;
-  int n_rewards = 0;
-  uint32_t reward_bits[256];
 #define CAMPX_TRY(call)           \
   do {                            \
     e = (call);                   \
@@ -475,47 +534,37 @@ int32_t campx_pair_table_build(const CampxSpec* spec, const CampxSpec* spec_dev,
   CAMPX_TRY(hipMemcpyAsync(h_done, dev + off_dout, n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipMemcpyAsync(h_perf, dev + off_perf, n, hipMemcpyDeviceToHost, s));
   CAMPX_TRY(hipStreamSynchronize(s));
-  for (int i = 0; i < 256; ++i) h_table[i] = 0.0f;
-  for (size_t i = 0; i < n; ++i) {
-    uint32_t bits;
-    memcpy(&bits, &h_reward[i], 4);
-    int idx = -1;
-    for (int k = 0; k < n_rewards; ++k) {
-      if (reward_bits[k] == bits) {
-        idx = k;
-        break;
-      }
-    }
-    if (idx < 0) {
-      if (n_rewards == 256) {
-        rc = CAMPX_ESPEC;
-        goto done;
-      }
-      idx = n_rewards++;
-      reward_bits[idx] = bits;
-      h_table[idx] = h_reward[i];
-    }
-    const uint32_t perf = (uint32_t)((spec->perf_dyn >= 0 ? h_perf[i] : 0) + 1);
-    const uint32_t over = (uint32_t)(h_done[i] & 1);
-    if (K == 2) {
-      const uint32_t ta = h_trace[i], tb = h_trace[n + i];
-      h_entries32[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
-                       (over << 16) | (perf << 17) | ((uint32_t)idx << 19);
-    } else {
-      uint32_t lo = 0;
-      for (int d = 0; d < K; ++d) {
-        const uint32_t tr = h_trace[(size_t)d * n + i];
-        lo |= ((tr & 0x7fu) << (7 * d)) | ((tr >> 7) << (28 + d));
-      }
-      h_entries64[i] = (uint64_t)lo | ((uint64_t)(over | (perf << 1) | ((uint32_t)idx << 3)) << 32);
-    }
-  }
+  rc = pack_state_table(*spec, n, h_trace, h_reward, h_done, h_perf, h_table);
+  if (rc != CAMPX_OK) goto done;
   CAMPX_TRY(hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s));
   CAMPX_TRY(hipStreamSynchronize(s));
 #undef CAMPX_TRY
 done:
   free(host);
   (void)hipFree(dev);
+  return rc;
+}
+
+int32_t campx_pair_table_pack(const CampxSpec* spec, const uint8_t* trace, const float* reward,
+                              const uint8_t* done, const int8_t* perf, void* table_dev,
+                              void* stream) {
+  const int64_t bytes = campx_pair_table_bytes(spec);
+  if (bytes == 0 || !trace || !reward || !done || !table_dev) return CAMPX_EINVAL;
+  const int K = spec->n_dyn, HW = spec->rows * spec->cols;
+  size_t n = CAMPX_N_ACTIONS;
+  for (int d = 0; d < K; ++d) n *= (size_t)HW;
+  for (size_t i = 0; i < (size_t)K * n; ++i)
+    if ((trace[i] & 0x7fu) >= (uint32_t)HW) return CAMPX_EINVAL;   // a cell outside the board
+  float* h_table = static_cast<float*>(malloc(((size_t)bytes + 7) & ~(size_t)7));
+  if (!h_table) return CAMPX_ENOMEM;
+  int32_t rc = pack_state_table(*spec, n, trace, reward, done, perf, h_table);
+  if (rc == CAMPX_OK) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(table_dev, h_table, (size_t)bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = hip_failed(e);
+  }
+  free(h_table);
   return rc;
 }
 
@@ -539,7 +588,8 @@ int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   const int32_t v = campx_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
   if (!spec_host->render_valid) return CAMPX_ESPEC;
-  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 && !knob_no_table();
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
+                         (!knob_no_table() || spec_host->table_only);
   return launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
                        (int64_t)T * B, static_cast<hipStream_t>(stream));
 }

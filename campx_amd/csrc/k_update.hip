@@ -921,7 +921,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       hipLaunchKernelGGL((update_table_kernel<kProd, kCons, CAMPX_UPD_GROUP>), grid, block, 0, stream, mp,
                          spec_dev, st, actions, out, B, T, reset_first);
     }
-  } else if (s.n_dyn == 2 && st.pair_table && !knob_no_table()) {
+  } else if (s.n_dyn == 2 && st.pair_table && (!knob_no_table() || s.table_only)) {
     const PairParams pp = make_pair_params(s);
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
     // the entries in LDS when they fit (CAMPX_PAIR_MODE=0: read them through L1/L2 anyway)
@@ -943,7 +943,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
     else
       CAMPX_PAIR_LAUNCH(CAMPX_PAIR_PROD, CAMPX_PAIR_CONS);
 #undef CAMPX_PAIR_LAUNCH
-  } else if (s.n_dyn >= 3 && st.pair_table && !knob_no_table()) {
+  } else if (s.n_dyn >= 3 && st.pair_table && (!knob_no_table() || s.table_only)) {
     constexpr int kProd = CAMPX_TUPLE_PROD, kCons = CAMPX_TUPLE_CONS, kEnvs = kProd * kWave;
     const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
         block((kProd + kCons + update_loaders(kProd)) * kWave);
@@ -955,6 +955,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       hipLaunchKernelGGL((update_tuple_kernel<4, kProd, kCons>), grid, block, 0, stream, tp, st,
                          actions, out, B, T, reset_first, trace_plane);
   } else {
+    if (s.table_only) return CAMPX_ESPEC;   // a host-tabulated game without its table
     launch_trace(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream);
   }
   hipError_t e = hipGetLastError();

@@ -10,13 +10,16 @@ generic tier  (`batch=None`, the default)
     model (engine.py:114-324) and is what unmodified `examples/boat_race.py` and
     the Demo notebooks run on.  CPU torch tensors, no native code.
 
-fused tier  (`batch=B`)
-    B independent environments advanced by ONE HIP kernel per `play()` /
-    `rollout()` (csrc/campx_hip.hip) over an int8 [B, L, H, W] layered board.
-    Every entity must be one of the declarative rule classes in
-    `campx_amd.rules`; `its_showtime()` lowers them to a GameSpec
-    (`campx_amd.fused`).  There is no CPU fallback: without the HIP library or
-    a GPU this tier raises.
+fused tier  (`batch=B`, or a process-wide default: `set_default_batch`, CAMPX_BATCH)
+    B independent environments advanced by the HIP kernels (csrc/k_*.hip) over an
+    int8 [B, L, H, W] layered board; `its_showtime()` compiles the game for them:
+    * entities from `campx_amd.rules` are lowered to a GameSpec whose state tables
+      the rule interpreter kernel builds on the device (`gamespec`, `fused`);
+    * ANY OTHER Python classes - the unmodified `examples/boat_race.py` classes,
+      the Demo notebooks' classes, a user's own - are tabulated on the host by
+      running their `update()` on the generic tier over every reachable state
+      (`tabulate`), and the same table + render kernels run the result.
+    There is no CPU fallback: without the HIP library or a GPU this tier raises.
 
 Error behaviour kept from the reference: `RuntimeError` for `play()` before
 `its_showtime()` or after game over (engine.py:146-151), for set-up calls during
@@ -30,6 +33,7 @@ Out of scope: the un-occluded renderer
 """
 
 import collections
+import os
 
 import torch
 
@@ -37,12 +41,39 @@ from . import plot
 from . import rendering
 from . import things
 
+# Process-wide default for `Engine(batch=None)`: lets set-up code written for the
+# reference - a zero-argument `make_game()` (examples/boat_race.py:93-115), a notebook
+# cell - build a batched engine without being edited.
+_DEFAULT_BATCH = [None, None]
+_UNSET = object()
+
+
+def set_default_batch(batch, device=None):
+  """Make every `Engine` constructed without `batch=` a batched one (None: back to the
+  reference's single-environment generic tier).  The environment variables CAMPX_BATCH /
+  CAMPX_DEVICE set the same default at import time."""
+  if batch is not None and int(batch) < 1:
+    raise ValueError('batch must be >= 1')
+  _DEFAULT_BATCH[0] = None if batch is None else int(batch)
+  _DEFAULT_BATCH[1] = device
+
+
+def get_default_batch():
+  return tuple(_DEFAULT_BATCH)
+
+
+if os.environ.get('CAMPX_BATCH'):
+  set_default_batch(int(os.environ['CAMPX_BATCH']), os.environ.get('CAMPX_DEVICE') or None)
+
 
 class Engine(object):
   """A grid-world game: entities, their update order, their z-order."""
 
-  def __init__(self, rows, cols, occlusion_in_layers=True, batch=None,
+  def __init__(self, rows, cols, occlusion_in_layers=True, batch=_UNSET,
                device=None):
+    if batch is _UNSET:      # not given: the process-wide default (normally None)
+      batch = _DEFAULT_BATCH[0]
+      device = _DEFAULT_BATCH[1] if device is None else device
     if not occlusion_in_layers:
       raise NotImplementedError(
           'occlusion_in_layers=False is not supported: the reference renderer '
@@ -64,6 +95,7 @@ class Engine(object):
     self._batch = batch
     self._device = device
     self._fused = None
+    self._action_set = None
 
   # ---------------------------------------------------------------- set-up
 
@@ -125,6 +157,17 @@ class Engine(object):
     if len(masks) < 2 or int(sum(masks).max()) > 1:
       raise ValueError('hidden performance needs >= 2 disjoint masks')
     self._hidden_performance = (agent_char, masks)
+
+  def set_action_set(self, actions):
+    """Build addition, batched engines of arbitrary Python classes only: the five objects
+    that stand for action ids 0..4 when the game is tabulated (default: the reference's
+    one-hot float vectors `[left, right, up, down, stay]`, examples/boat_race.py:26; a game
+    that takes integers, like Hello World, passes `range(5)`)."""
+    self._not_during_showtime('set_action_set')
+    actions = list(actions)
+    if len(actions) != 5:
+      raise ValueError('exactly 5 actions are needed')
+    self._action_set = actions
 
   def update_group(self, group_name):
     """Entities added from now on belong to update group `group_name`."""
@@ -200,11 +243,6 @@ class Engine(object):
     self._not_during_showtime('its_showtime')
     if self._backdrop is None:
       raise RuntimeError('its_showtime() called on an Engine with no Backdrop')
-    self._showtime = True
-    self._update_groups = [(name, self._update_groups[name])
-                           for name in sorted(self._update_groups.keys())]
-    self._current_update_group = None
-
     if self._batch is not None:
       if not torch.cuda.is_available():
         raise RuntimeError(
@@ -212,12 +250,27 @@ class Engine(object):
             'False) and has no CPU fallback; use batch=None for the '
             'single-environment generic tier')
       from . import gamespec
+      traced = None
+      if not gamespec.is_rule_game(self):
+        # arbitrary Python update() bodies: tabulate them on the host (a deep copy of this
+        # engine runs on the generic tier), then the table kernels take over
+        from . import tabulate
+        traced = tabulate.trace(self, actions=self._action_set)
+    self._showtime = True
+    self._update_groups = [(name, self._update_groups[name])
+                           for name in sorted(self._update_groups.keys())]
+    self._current_update_group = None
+
+    if self._batch is not None:
+      from . import fused
+      if traced is not None:
+        self._fused = fused.FusedGame(self, self._batch, self._device, traced=traced)
+        return self._fused.showtime()
       description = gamespec.describe(self)
       if description.is_shape_game:   # Hello-World-style rules: the shape tier
         from . import shapes          # needs the HIP library; raises if it is missing
         self._fused = shapes.ShapeGame(self, self._batch, self._device, description)
       else:
-        from . import fused
         self._fused = fused.FusedGame(self, self._batch, self._device)
       return self._fused.showtime()
 

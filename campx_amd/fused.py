@@ -66,7 +66,11 @@ def _ptr(t):
 
 class FusedGame(object):
 
-  def __init__(self, engine, batch, device=None):
+  def __init__(self, engine, batch, device=None, traced=None):
+    """`traced`: a `tabulate.TracedGame` - the update pass of a game whose entities are
+    arbitrary Python classes, tabulated on the host by running them on the generic tier;
+    without it the engine's entities must be `campx_amd.rules` classes and the tables are
+    built on the device by the rule interpreter."""
     if not torch.cuda.is_available():
       raise RuntimeError(
           'the fused tier needs a HIP device (torch.cuda.is_available() is '
@@ -81,8 +85,16 @@ class FusedGame(object):
     self.batch = int(batch)
     if self.batch < 1:
       raise ValueError('batch must be >= 1')
-    self.description = gamespec.describe(engine)
-    self.spec = gamespec.lower(self.description)
+    self.traced = traced
+    if traced is not None:
+      from . import tabulate
+      self.description = None
+      self.spec = tabulate.to_spec(traced)
+      self.chars = list(traced.chars)
+    else:
+      self.description = gamespec.describe(engine)
+      self.spec = gamespec.lower(self.description)
+      self.chars = list(self.description.chars)
     _hip.check(_hip.lib.campx_spec_validate(ctypes.byref(self.spec)),
                'campx_spec_validate')
     with torch.cuda.device(self.device):
@@ -90,10 +102,9 @@ class FusedGame(object):
           ctypes.byref(self.spec),
           ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
           'campx_spec_compile')
-    if not COMPILE_TABLE:
+    if not COMPILE_TABLE and traced is None:
       self.spec.table_valid = 0     # keep the render tables, interpret the rules
     self.uses_table = bool(self.spec.table_valid)
-    self.chars = list(self.description.chars)
     self.rows, self.cols = engine.rows, engine.cols
     self.n_layers = len(self.chars)
     self.n_dyn = self.spec.n_dyn
@@ -109,7 +120,24 @@ class FusedGame(object):
     # Games with two to four movers: the (cell, ..., cell, action) table of the update pass.
     self._pair_table = None
     n_pair = int(_hip.lib.campx_pair_table_bytes(ctypes.byref(self.spec)))
-    if COMPILE_TABLE and n_pair > 0:
+    if traced is not None and self.n_dyn >= 2:
+      if n_pair <= 0:
+        raise ValueError('fused tier: the state table of this game ({} moving things on {} '
+                         'cells) is too large'.format(self.n_dyn, self.rows * self.cols))
+      import numpy as np
+      table = torch.empty((n_pair,), dtype=torch.uint8, device=dev)
+      trace = np.ascontiguousarray(traced.trace_bytes())
+      reward = np.ascontiguousarray(traced.reward, dtype=np.float32)
+      done = np.ascontiguousarray(traced.done, dtype=np.uint8)
+      perf = np.ascontiguousarray(traced.perf, dtype=np.int8)
+      with torch.cuda.device(self.device):
+        _hip.check(_hip.lib.campx_pair_table_pack(
+            ctypes.byref(self.spec), trace.ctypes.data, reward.ctypes.data, done.ctypes.data,
+            perf.ctypes.data if self.has_perf else None, _ptr(table),
+            ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+            'campx_pair_table_pack')
+      self._pair_table = table
+    elif COMPILE_TABLE and n_pair > 0:
       table = torch.empty((n_pair,), dtype=torch.uint8, device=dev)
       with torch.cuda.device(self.device):
         rc = _hip.lib.campx_pair_table_build(
@@ -182,6 +210,13 @@ class FusedGame(object):
     if not torch.is_tensor(actions):
       actions = torch.as_tensor(actions)
     actions = actions.to(self.device)
+    # ONE action - the reference's `play(one_hot[5])` / `play(int)` call, as a driver or a
+    # notebook cell written for a single environment makes it - goes to every environment
+    if len(expect) == 1:
+      if actions.is_floating_point() and tuple(actions.shape) == (gamespec.N_ACTIONS,):
+        actions = actions.expand(expect[0], gamespec.N_ACTIONS)
+      elif not actions.is_floating_point() and actions.dim() == 0:
+        actions = actions.expand(expect[0])
     if actions.is_floating_point():
       if actions.shape != tuple(expect) + (gamespec.N_ACTIONS,):
         raise ValueError('one-hot actions must have shape {}, got {}'.format(

@@ -69,7 +69,8 @@ class CampxSpec(ctypes.Structure):
               ('render_valid', ctypes.c_int32),
               ('perf_dyn', ctypes.c_int32),
               ('perf_n', ctypes.c_int32),
-              ('reserved0', ctypes.c_int32 * 3),
+              ('table_only', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 2),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * MAX_DYN),
               ('dyn_z', ctypes.c_int32 * MAX_DYN),
@@ -125,6 +126,16 @@ class GameDescription(object):
   def is_shape_game(self):
     """Rigidly translated, non-interacting things (Hello World): the shape tier."""
     return any(e.kind == 'shape' for e in self.entities)
+
+
+def is_rule_game(engine):
+  """True when every entity is one of the `campx_amd.rules` classes (or a `FixedDrape`) over
+  the static default Backdrop: `describe()` + `lower()` apply and the tables are built on
+  the device.  Anything else is tabulated on the host (`campx_amd.tabulate`)."""
+  if type(engine.backdrop) is not _things.Backdrop:
+    return False
+  known = (_things.FixedDrape,) + _rules.FUSED_RULE_CLASSES + _rules.SHAPE_RULE_CLASSES
+  return all(type(ent) in known for ent in engine.things.values())
 
 
 def describe(engine):

@@ -1,0 +1,414 @@
+"""Tabulate a game made of arbitrary Python `update()` classes for the HIP table kernels.
+
+The fused tier's kernels do not need rules: their update pass is a lookup in a
+(cell, action) table (one moving thing) or a (cell, ..., cell, action) table (two to
+four), and their render is "static scenery + the moving things' cells"
+(csrc/k_update.hip, k_render.hip, k_step.hip).  For the rule classes in
+`campx_amd.rules` those tables are built on the device by running the rule interpreter.
+For anything else - the unmodified `examples/boat_race.py` classes, the Demo notebooks'
+classes, a user's own Drapes and Sprites - this module builds the same tables on the
+HOST by running the user's own code on the generic tier (`engine.Engine` with
+`batch=None`: the reference's execution model, campx/engine.py:114-324) over every state
+the game can reach:
+
+    breadth-first from the state `its_showtime()` leaves (campx/engine.py:487-544), for
+    each of the five actions: deep-copy the engine (entities must be deep-copyable,
+    campx/things.py:38), `play(action)`, read the entities' curtains / positions, the
+    Plot's reward / discount / game-over, and the rendered board.
+
+A state is identified by the byte image of every curtain, sprite position and the
+z-order.  Afterwards the moving things are the entities whose image differs between two
+reached states; everything else is scenery.  The tabulation is exact under conditions
+that are CHECKED while tabulating, never assumed (ValueError otherwise):
+
+* every moving thing occupies exactly one cell in every reached state (a drape's curtain
+  has exactly one 1; a sprite keeps its `visible` flag), there are at most four of them,
+  the board has at most 128 cells and 16 characters;
+* the Backdrop's curtain and the z-order never change (no `change_z_order`, no sprite
+  painted into the backdrop: campx/rendering.py:128,150);
+* every rendered board equals "backdrop, then things in z-order" computed from the cells
+  alone - which also yields whether a moving thing is the character its cell shows;
+* the discount is 1.0, or 0.0 on the frame `terminate_episode()` was called (the
+  device tiers' model; campx/plot.py:161-184, 232-257);
+* the entities' curtains ARE the state: when a state is reached again over a different
+  history, every action is replayed from that second engine and must reproduce the
+  tabulated next state, reward, discount, game-over and board.  A game that keeps hidden
+  state elsewhere (a counter in the Plot, the frame number) is refused here.
+
+Host logic only (numpy + the generic tier): runs without a GPU.  `fused.FusedGame`
+uploads the result.
+"""
+
+import collections
+import copy
+
+import numpy as np
+import torch
+
+from . import gamespec
+from . import things as _things
+
+N_ACTIONS = gamespec.N_ACTIONS
+# Upper bound on generic-tier play() calls one tabulation may spend (each costs a
+# deep copy + a frame of Python, ~2 ms): beyond it the game is refused with a pointer to
+# campx_amd.rules, whose tables are built on the device.
+MAX_PLAYS = 60000
+
+
+class TabulationError(ValueError):
+  pass
+
+
+def default_actions():
+  """The reference's action format (examples/boat_race.py:26, 154-184): one-hot float
+  vectors in the order left, right, up, down, stay."""
+  return [torch.eye(N_ACTIONS, dtype=torch.float32)[a].clone() for a in range(N_ACTIONS)]
+
+
+def _fail(msg):
+  raise TabulationError('cannot tabulate this game for the HIP tier: ' + msg)
+
+
+def _image(engine):
+  """(per-thing byte images in z-order, backdrop image, z-order string)."""
+  parts = []
+  for ch, ent in engine.things.items():
+    if isinstance(ent, _things.Sprite):
+      parts.append(bytes((ent.position.row & 0xff, ent.position.col & 0xff,
+                          1 if ent.visible else 0)))
+    else:
+      parts.append(ent.curtain.detach().to(torch.uint8).numpy().tobytes())
+  backdrop = engine.backdrop.curtain.detach().to(torch.int64).numpy().tobytes()
+  return tuple(parts), backdrop, ''.join(engine.things.keys())
+
+
+def _reward_f32(reward):
+  if reward is None:
+    return np.float32(np.nan)
+  if torch.is_tensor(reward):
+    return np.float32(reward.detach().to(torch.float32).item())
+  return np.float32(reward)
+
+
+class _Edge(object):
+  __slots__ = ('next', 'reward', 'discount', 'over', 'board')
+
+  def __init__(self, nxt, reward, discount, over, board):
+    self.next, self.reward, self.discount, self.over, self.board = (
+        nxt, reward, discount, over, board)
+
+  def same(self, other):
+    return (self.next == other.next and self.over == other.over and
+            self.discount == other.discount and self.board == other.board and
+            np.array_equal(np.array([self.reward]).view(np.uint32),
+                           np.array([other.reward]).view(np.uint32)))
+
+
+class TracedGame(object):
+  """The tabulated update pass of one game (plain numpy; see `trace`).
+
+  Attributes:
+    rows, cols, chars (ascending), z_order (characters back to front), backdrop
+      (uint8 [H, W] character codes);
+    movers: characters of the moving things in update-schedule order (K of them);
+    statics: [(character, uint8 [H, W] mask)] of the things that never change, in
+      update-schedule order;
+    init_cells: the movers' cells after `its_showtime()`;
+    n: (H*W)^K * 5 table entries, index ((cell_0 * HW + cell_1) ...) * 5 + action;
+    next_cells uint8 [K, n], visible uint8 [K, n], reward float32 [n] (NaN = None),
+    done uint8 [n], perf int8 [n], reached bool [n] (entries the game can get to; the
+    others are self-loops that pay nothing);
+    n_states, n_plays: size of the reachable state space and what tabulating it cost.
+  """
+
+  def trace_bytes(self):
+    """uint8 [K, n]: cell | visible << 7 - the kernels' trace format (CampxOutputs.trace)."""
+    return (self.next_cells | (self.visible << 7)).astype(np.uint8)
+
+  def cells_of(self, index):
+    HW, K = self.rows * self.cols, len(self.movers)
+    rest, cells = index // N_ACTIONS, []
+    for _ in range(K):
+      cells.append(rest % HW)
+      rest //= HW
+    return tuple(reversed(cells))
+
+  def index_of(self, cells, action=0):
+    HW, idx = self.rows * self.cols, 0
+    for c in cells:
+      idx = idx * HW + int(c)
+    return idx * N_ACTIONS + action
+
+  def model_board(self, cells):
+    """The flat board (character codes) when the movers stand at `cells`: backdrop, then
+    every thing in z-order (campx/engine.py:306-324)."""
+    board = self.backdrop.copy().reshape(-1)
+    static = dict(self.statics)
+    where = {ch: c for ch, c in zip(self.movers, cells)}
+    for ch in self.z_order:
+      if ch in where:
+        board[where[ch]] = ord(ch)
+      else:
+        board[static[ch].reshape(-1) != 0] = ord(ch)
+    return board.reshape(self.rows, self.cols)
+
+
+def trace(engine, actions=None, max_plays=MAX_PLAYS):
+  """Tabulate a set-up (not yet started) `Engine`; returns a `TracedGame`.
+
+  `engine` itself is not touched: a deep copy of it is put through `its_showtime()` on
+  the generic tier.  `actions`: the five objects handed to `play()` for action ids
+  0..4 (default: the reference's one-hot float vectors).
+  """
+  if engine.backdrop is None:
+    raise ValueError('the Engine has no Backdrop yet')
+  H, W = engine.rows, engine.cols
+  HW = H * W
+  chars = sorted(set(engine.things.keys()) | set(engine.backdrop.palette))
+  if HW > gamespec.MAX_CELLS:
+    _fail('{}x{} board has more than {} cells'.format(H, W, gamespec.MAX_CELLS))
+  if len(chars) > gamespec.MAX_LAYERS:
+    _fail('more than {} characters'.format(gamespec.MAX_LAYERS))
+  actions = default_actions() if actions is None else list(actions)
+  if len(actions) != N_ACTIONS:
+    raise ValueError('exactly {} actions are needed'.format(N_ACTIONS))
+
+  probe = copy.deepcopy(engine)
+  probe._batch, probe._device, probe._fused = None, None, None
+  obs, _, _ = probe.its_showtime()
+  if probe.game_over:
+    _fail('the episode is over after its_showtime()')
+
+  things0, backdrop0, z0 = _image(probe)
+  # state bookkeeping
+  index_of = {things0: 0}
+  images = [things0]
+  engines = [probe]          # an engine standing in that state, or None (only seen ended)
+  second = {}                # state -> an engine that arrived there over another history
+  boards = [obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()]
+  edges = {}
+  queue = collections.deque([0])
+  plays = [0]
+
+  def step(eng, a):
+    if plays[0] >= max_plays:
+      _fail('more than {} generic-tier frames would be needed (the reachable state space is '
+            'too large to tabulate on the host); express the game with campx_amd.rules, '
+            'whose tables are built on the device'.format(max_plays))
+    plays[0] += 1
+    obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
+    things, backdrop, z = _image(eng)
+    if backdrop != backdrop0:
+      _fail('the Backdrop changed during play (a Backdrop.update(), or a sprite painted '
+            'before the first drape in z-order writes into it: campx/rendering.py:128,150)')
+    if z != z0:
+      _fail('the z-order changed during play (Plot.change_z_order): generic tier only')
+    over = bool(eng.game_over)
+    discount = float(discount)
+    if discount != (0.0 if over else 1.0):
+      _fail('a frame reported discount {} ({}): the device tiers report 1.0, or 0.0 on the '
+            'frame the episode ends'.format(discount, 'terminated' if over else 'not terminated'))
+    board = obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()
+    return things, _reward_f32(reward), discount, over, board
+
+  while queue:
+    s = queue.popleft()
+    for a in range(N_ACTIONS):
+      eng = copy.deepcopy(engines[s])
+      things, reward, discount, over, board = step(eng, a)
+      t = index_of.get(things)
+      if t is None:
+        t = index_of[things] = len(images)
+        images.append(things)
+        boards.append(board)
+        engines.append(None)
+      elif boards[t] != board:
+        _fail('the same curtains rendered two different boards')
+      edges[(s, a)] = _Edge(t, reward, discount, over, board)
+      if not over:
+        if engines[t] is None:
+          engines[t] = eng
+          queue.append(t)
+        elif t not in second:    # (every (s, a) is played once: this is another history)
+          second[t] = eng
+
+  # ---- the curtains are the whole state: replay every action over a second history
+  for t, eng0 in second.items():
+    for a in range(N_ACTIONS):
+      eng = copy.deepcopy(eng0)
+      things, reward, discount, over, board = step(eng, a)
+      got = _Edge(index_of.get(things), reward, discount, over, board)
+      if not got.same(edges[(t, a)]):
+        _fail('the game keeps state outside its curtains and sprite positions (the Plot, the '
+              'frame number, attributes of an entity): the same board reached over two '
+              'histories answered action {} differently'.format(a))
+
+  # ---- who moves
+  order = list(probe.things.keys())                       # z-order
+  varying = [i for i in range(len(order))
+             if any(img[i] != things0[i] for img in images)]
+  schedule = []
+  for _, members in probe._update_groups:
+    schedule.extend(ent.character for ent in members)
+  movers = [ch for ch in schedule if order.index(ch) in varying]
+  if not 1 <= len(movers) <= gamespec.MAX_DYN:
+    _fail('needs between 1 and {} moving things, found {} ({})'.format(
+        gamespec.MAX_DYN, len(movers), ''.join(movers) or 'nothing moves'))
+  K = len(movers)
+
+  def cell_of(img, ch):
+    part = img[order.index(ch)]
+    ent = probe.things[ch]
+    if isinstance(ent, _things.Sprite):
+      if not part[2]:
+        _fail('sprite {!r} moves while invisible'.format(ch))
+      return part[0] * W + part[1]
+    mask = np.frombuffer(part, np.uint8)
+    if mask.max() > 1:
+      _fail('the curtain of {!r} holds values other than 0 and 1'.format(ch))
+    cells = np.flatnonzero(mask)
+    if len(cells) != 1:
+      _fail('moving drape {!r} covers {} cells in a reachable state; the table kernels '
+            'track a moving thing by the one cell it occupies'.format(ch, len(cells)))
+    return int(cells[0])
+
+  game = TracedGame()
+  game.rows, game.cols, game.chars = H, W, chars
+  game.z_order = order
+  game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
+  game.movers = movers
+  game.statics = []
+  for ch in schedule:
+    if ch in movers:
+      continue
+    ent = probe.things[ch]
+    if isinstance(ent, _things.Sprite):
+      mask = np.zeros((H, W), np.uint8)
+      if ent.visible:
+        mask[ent.position.row, ent.position.col] = 1
+    else:
+      mask = np.frombuffer(things0[order.index(ch)], np.uint8).reshape(H, W).copy()
+      if mask.max() > 1:
+        _fail('the curtain of {!r} holds values other than 0 and 1'.format(ch))
+    game.statics.append((ch, mask))
+  if len(game.statics) > gamespec.MAX_STATIC:
+    _fail('more than {} static things'.format(gamespec.MAX_STATIC))
+
+  state_cells = [tuple(cell_of(img, ch) for ch in movers) for img in images]
+  game.init_cells = state_cells[0]
+
+  # ---- every reached board is "backdrop + things in z-order" of the cells alone
+  for cells, board in zip(state_cells, boards):
+    model = game.model_board(cells)
+    if model.tobytes() != board:
+      _fail('a rendered board is not "backdrop, then every thing in z-order" of the moving '
+            'things\' cells')
+
+  # ---- hidden performance (examples/boat_race.py:117-151): classes of the watched mover
+  perf_of = None
+  if engine.hidden_performance is not None:
+    agent, masks = engine.hidden_performance
+    if agent not in movers:
+      _fail('hidden performance watches {!r}, which never moves'.format(agent))
+    cls = np.zeros(HW, np.int32)
+    for k, m in enumerate(masks):
+      cls[np.flatnonzero(m.detach().cpu().numpy().reshape(-1))] = k + 1
+    n_cls, who = len(masks), movers.index(agent)
+
+    def perf_of(src, dst):
+      a, b = int(cls[src[who]]), int(cls[dst[who]])
+      if a == 0 or b == 0:
+        return 0
+      fwd = 1 if a == n_cls else a + 1
+      back = n_cls if a == 1 else a - 1
+      return int(b == fwd) - int(b == back)
+
+  # ---- the dense table
+  n = HW ** K * N_ACTIONS
+  game.n = n
+  game.next_cells = np.zeros((K, n), np.uint8)
+  game.visible = np.zeros((K, n), np.uint8)
+  game.reward = np.full((n,), np.nan, np.float32)
+  game.done = np.zeros((n,), np.uint8)
+  game.perf = np.zeros((n,), np.int8)
+  game.reached = np.zeros((n,), bool)
+  # entries nobody can reach: stay where you are, pay nothing
+  idx = np.arange(n) // N_ACTIONS
+  for k in range(K - 1, -1, -1):
+    game.next_cells[k] = idx % HW
+    idx = idx // HW
+  codes = [ord(ch) for ch in movers]
+  for (s, a), e in edges.items():
+    i = game.index_of(state_cells[s], a)
+    dst = state_cells[e.next]
+    board = np.frombuffer(e.board, np.uint8)
+    for k in range(K):
+      game.next_cells[k, i] = dst[k]
+      game.visible[k, i] = int(board[dst[k]] == codes[k])
+    game.reward[i] = e.reward
+    game.done[i] = int(e.over)
+    game.perf[i] = perf_of(state_cells[s], dst) if perf_of else 0
+    game.reached[i] = True
+  game.any_reward = bool((~np.isnan(game.reward[game.reached])).any())
+  game.has_perf = perf_of is not None
+  game.perf_spec = engine.hidden_performance
+  game.n_states, game.n_plays = len(images), plays[0]
+  return game
+
+
+def to_spec(game):
+  """`TracedGame` -> `CampxSpec` with `table_only` set: scenery and paint parameters as
+  `gamespec.lower()` derives them, no rules, and - for one mover - the transition table
+  filled in (games with two to four movers hand `trace_bytes()` etc. to
+  campx_pair_table_pack)."""
+  H, W = game.rows, game.cols
+  HW = H * W
+  layer_of = {ch: i for i, ch in enumerate(game.chars)}
+  z_of = {ch: i + 1 for i, ch in enumerate(game.z_order)}
+  spec = gamespec.CampxSpec()
+  spec.magic, spec.version = gamespec.SPEC_MAGIC, gamespec.SPEC_VERSION
+  spec.rows, spec.cols = H, W
+  spec.n_layers = len(game.chars)
+  spec.n_dyn, spec.n_static = len(game.movers), len(game.statics)
+  spec.n_rules = 0
+  spec.table_only = 1
+  spec.any_reward = int(game.any_reward)
+  for i, ch in enumerate(game.chars):
+    spec.layer_char[i] = ord(ch)
+  for d, ch in enumerate(game.movers):
+    spec.dyn_layer[d] = layer_of[ch]
+    spec.dyn_z[d] = z_of[ch]
+    spec.dyn_row0[d], spec.dyn_col0[d] = divmod(int(game.init_cells[d]), W)
+  top_layer = np.array([[layer_of[chr(c)] for c in row] for row in game.backdrop], np.uint8)
+  top_z = np.zeros((H, W), np.uint8)
+  cover = np.zeros((H, W), np.uint16)
+  static_of = {ch: i for i, (ch, _) in enumerate(game.statics)}
+  masks = dict(game.statics)
+  for ch in game.z_order:
+    if ch in static_of:
+      m = masks[ch] != 0
+      top_layer[m] = layer_of[ch]
+      top_z[m] = z_of[ch]
+      cover[m] |= np.uint16(1 << static_of[ch])
+  for i in range(HW):
+    spec.static_top_layer[i] = int(top_layer.flat[i])
+    spec.static_top_z[i] = int(top_z.flat[i])
+    spec.static_cover[i] = int(cover.flat[i])
+    spec.obs_template[int(top_layer.flat[i]) * HW + i] = 1
+  spec.perf_dyn = -1
+  if game.has_perf:
+    agent, cycle = game.perf_spec
+    spec.perf_dyn, spec.perf_n = game.movers.index(agent), len(cycle)
+    for k, m in enumerate(cycle):
+      for cell in np.flatnonzero(m.detach().cpu().numpy().reshape(-1)):
+        spec.cell_class[int(cell)] = k + 1
+  if len(game.movers) == 1:
+    for i in range(game.n):
+      tr = spec.table[i]
+      nxt = int(game.next_cells[0, i])
+      tr.reward = float(game.reward[i])
+      tr.next_cell, tr.done, tr.perf = nxt, int(game.done[i]), int(game.perf[i])
+      in_front = spec.static_top_z[nxt] > spec.dyn_z[0]
+      tr.paint = int(spec.static_top_layer[nxt]) | (0x80 if in_front else 0)
+    spec.table_valid = 1
+  return spec

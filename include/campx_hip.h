@@ -21,8 +21,10 @@
  * Conventions
  *   - plain C, no exceptions: every function returns CAMPX_OK (0) or a negative
  *     CAMPX_E* code; campx_strerror() names it.
- *   - the library owns no memory and keeps no global state; all buffers are
- *     caller-allocated DEVICE memory unless a parameter says "host".
+ *   - the library owns no memory between calls: all buffers are caller-allocated DEVICE
+ *     memory unless a parameter says "host".  The only process-wide state is read-only
+ *     after first use: measurement knobs read once from the environment
+ *     and, per device, its CU count and the dynamic-LDS limit already granted to a kernel.
  *   - launches are asynchronous on the hipStream_t passed as `void* stream`
  *     (NULL = the default stream); nothing in here synchronises.
  *   - re-entrant; calls on distinct state buffers may be issued concurrently.
@@ -119,7 +121,13 @@ typedef struct CampxSpec {
   int32_t render_valid;                 /* 1: `rot_obs` / `rot_board` below are filled */
   int32_t perf_dyn;                     /* moving thing whose hidden performance is scored, or -1 */
   int32_t perf_n;                       /* length n of the cycle of cell classes (>= 2) */
-  int32_t reserved0[3];
+  int32_t table_only;                   /* 1: `rules` is empty and the update pass exists only as
+                                           tables the HOST filled by running the game's own Python
+                                           update() bodies over every reachable state
+                                           (campx_amd/tabulate.py: `table` for one mover,
+                                           campx_pair_table_pack() for two to four).  Calls that
+                                           would interpret the rules return CAMPX_ESPEC. */
+  int32_t reserved0[2];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_MAX_DYN];     /* layer painted by dynamic thing d */
   int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop) */
@@ -250,6 +258,22 @@ int32_t campx_pair_table_build(const CampxSpec* spec_host, const CampxSpec* spec
                                void* table_dev, void* stream);
 
 /*
+ * The same table from HOST arrays instead of the rule interpreter: for games whose update()
+ * bodies are arbitrary Python (the reference's own examples/boat_race.py:28-91 classes, a
+ * user's Drapes), tabulated on the host by running them (campx_amd/tabulate.py).  With
+ * n = (rows*cols)^K * 5 entries indexed as above:
+ *   trace   [K][n]  thing d after the frame: cell | (it is the character its cell shows) << 7
+ *   reward  [n]     summed reward of the frame, NaN = None (campx/plot.py:208-211)
+ *   done    [n]     1: the episode terminated on the frame
+ *   perf    [n]     hidden performance -1 / 0 / +1, or NULL
+ * Packs them into `table_dev` (campx_pair_table_bytes() bytes of device memory) and
+ * synchronises `stream`.  CAMPX_ESPEC for more than 256 distinct rewards.
+ */
+int32_t campx_pair_table_pack(const CampxSpec* spec_host, const uint8_t* trace,
+                              const float* reward, const uint8_t* done, const int8_t* perf,
+                              void* table_dev, void* stream);
+
+/*
  * Put B environments into the state its_showtime() leaves them in
  * (campx/engine.py:487-544: positions from the art, game-over clear, return 0)
  * and, if out->obs / out->board are non-NULL, write that first observation to
@@ -265,8 +289,9 @@ int32_t campx_reset_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev
  *
  * reset_first != 0 rebuilds every environment from the art before frame 0 (a
  * fresh make_game() per episode, examples/reinforce.py:122).
- * Action ids outside 0..4 are treated as 4 (stay) on the device; use
- * campx_check_actions_launch() to detect them.
+ * Action ids outside 0..4 are treated as 4 (stay) on the device; out.bad_count /
+ * out.bad_flag (or campx_check_actions_launch()) detect them.  `actions` needs no padding:
+ * nothing is read outside its T * B bytes.
  */
 int32_t campx_rollout_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
                              CampxState state, const int8_t* actions, CampxOutputs out, int64_t B,

@@ -1,0 +1,92 @@
+"""Walk a tabulated game on the CPU (numpy): the checker for host-tabulated games.
+
+TEST INFRASTRUCTURE (only tests/ and bench.py's cpu_baseline may import this).
+
+`campx_amd.tabulate.trace()` turns a game of arbitrary Python classes into a table
+(next cells, visibility, reward, done, perf per (cells, action)); the HIP kernels walk
+that table for B environments.  This module walks the same table with plain numpy
+indexing, one frame at a time, with the batched engine's episode rule: an environment
+whose episode ended is rebuilt from the start state before its next action (what the
+reference's driver does with `make_game()` per episode, examples/reinforce.py:122).
+Observations are rendered the way the reference renders them - backdrop, then every
+thing in z-order onto a flat board, layers by equality with the board
+(campx/engine.py:306-324, campx/rendering.py:204-215) - from the cells alone.
+
+It shares no code with the HIP path; that the table itself is right is pinned elsewhere
+(tests/test_tabulate.py: against the generic tier's own frames and against the
+reference-generated `tests/golden/boat_race_table.npz`).
+"""
+
+import numpy as np
+
+N_ACTIONS = 5
+
+
+class TableWalker(object):
+  """State of B environments of a `tabulate.TracedGame`."""
+
+  def __init__(self, game, batch):
+    self.game = game
+    self.B = int(batch)
+    self.K = len(game.movers)
+    self.HW = game.rows * game.cols
+    self.cells = np.tile(np.array(game.init_cells, np.int64)[:, None], (1, self.B))
+    self.over = np.zeros(self.B, bool)
+    self.ret = np.zeros(self.B, np.float32)
+
+  def _index(self, cells, actions):
+    idx = np.zeros(self.B, np.int64)
+    for k in range(self.K):
+      idx = idx * self.HW + cells[k]
+    return idx * N_ACTIONS + actions
+
+  def rollout(self, actions, reset_first=False):
+    """actions int8 [T, B] -> dict(cells [K, T, B], visible [K, T, B], reward, discount,
+    done, perf [T, B])."""
+    g = self.game
+    actions = np.asarray(actions)
+    T = actions.shape[0]
+    out = dict(cells=np.zeros((self.K, T, self.B), np.uint8),
+               visible=np.zeros((self.K, T, self.B), np.uint8),
+               reward=np.zeros((T, self.B), np.float32),
+               discount=np.zeros((T, self.B), np.float32),
+               done=np.zeros((T, self.B), np.uint8),
+               perf=np.zeros((T, self.B), np.int8))
+    if reset_first:
+      self.over[:] = True
+    init = np.array(g.init_cells, np.int64)[:, None]
+    for t in range(T):
+      a = actions[t].astype(np.int64)
+      a = np.where((a < 0) | (a > 4), 4, a)          # an id outside 0..4 acts as "stay"
+      cells = np.where(self.over[None, :], init, self.cells)
+      self.ret = np.where(self.over, np.float32(0), self.ret).astype(np.float32)
+      idx = self._index(cells, a)
+      assert g.reached[idx].all(), 'the walk left the tabulated (reachable) entries'
+      self.cells = g.next_cells[:, idx].astype(np.int64)
+      reward = g.reward[idx]
+      self.ret = (self.ret + np.where(np.isnan(reward), np.float32(0), reward)).astype(np.float32)
+      self.over = g.done[idx] != 0
+      out['cells'][:, t] = self.cells
+      out['visible'][:, t] = g.visible[:, idx]
+      out['reward'][t] = reward
+      out['done'][t] = self.over
+      out['discount'][t] = np.where(self.over, 0, 1)
+      out['perf'][t] = g.perf[idx]
+    return out
+
+  def render(self, cells):
+    """cells [K, N] -> (board int8 [N, H, W], layered int8 [N, L, H, W])."""
+    g = self.game
+    N = cells.shape[1]
+    board = np.tile(g.backdrop.reshape(1, -1).astype(np.int16), (N, 1))
+    static = dict(g.statics)
+    who = {ch: k for k, ch in enumerate(g.movers)}
+    rows = np.arange(N)
+    for ch in g.z_order:                              # back to front
+      if ch in who:
+        board[rows, cells[who[ch]]] = ord(ch)
+      else:
+        board[:, np.flatnonzero(static[ch].reshape(-1))] = ord(ch)
+    layered = np.stack([(board == ord(ch)) for ch in g.chars], axis=1).astype(np.int8)
+    return (board.astype(np.int8).reshape(N, g.rows, g.cols),
+            layered.reshape(N, len(g.chars), g.rows, g.cols))

@@ -1,0 +1,357 @@
+"""Games of arbitrary Python classes on the HIP tier: host-side tabulation
+(`campx_amd.tabulate`) and, on the GPU, the table + render kernels running the result.
+
+CPU part: the tabulator against (a) `tests/golden/boat_race_table.npz`, the boat race's
+transition table as the REFERENCE's engine plays the reference's unmodified
+examples/boat_race.py (`tests/golden/make_table_golden.py`), (b) this repo's generic tier
+playing the same classes frame by frame, (c) games it must refuse.
+GPU part (`-m gpu`): the interpreter-built table of the library boat race equals the
+fixture; test-local games (tests/traced_games.py: classes of this test suite, not the rule
+library; one mover, two movers with a sprite) at B = 65 536 against the generic tier and
+against `oracle/table_replay.py` bit for bit, through rollout (update_table_kernel /
+update_pair_kernel + render_kernel), the single fused kernel and play().
+"""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from campx_amd import engine as engine_mod
+from campx_amd import tabulate
+from campx_amd.games import boat_race
+from conftest import GOLDEN_DIR, REPO
+import traced_games
+
+REFERENCE_EXAMPLES = '/root/reference/examples'
+
+
+def _same(a, b):
+  a, b = np.asarray(a), np.asarray(b)
+  if a.dtype.kind == 'f':
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+  return np.array_equal(a, b)
+
+
+def _table_fixture():
+  with np.load(os.path.join(GOLDEN_DIR, 'boat_race_table.npz')) as f:
+    return {k: f[k] for k in f.files}
+
+
+def _check_against_fixture(game, fix):
+  """Every entry the reference could reach: next cell, reward, done, visibility, perf."""
+  assert game.movers == ['A'] and game.init_cells == (int(fix['cells'][0]),)
+  reached_cells = sorted({game.cells_of(i)[0] for i in np.flatnonzero(game.reached)})
+  assert reached_cells == sorted(fix['cells'].tolist())
+  for s, cell in enumerate(fix['cells']):
+    for a in range(5):
+      i = game.index_of((int(cell),), a)
+      assert game.reached[i]
+      assert game.next_cells[0, i] == fix['next_cell'][s, a], (cell, a)
+      assert _same(game.reward[i], fix['reward'][s, a]), (cell, a)
+      assert game.done[i] == fix['done'][s, a]
+      assert game.visible[0, i] == fix['visible'][s, a]
+      assert game.perf[i] == fix['perf'][s, a], (cell, a)
+      board = game.model_board((int(game.next_cells[0, i]),))
+      assert np.array_equal(board, fix['board'][s, a].astype(np.uint8))
+  assert (fix['discount'] == 1.0).all() and (fix['done'] == 0).all()
+
+
+# ------------------------------------------------------------------------------- CPU
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_EXAMPLES),
+                    reason='reference tree not present (GPU box)')
+def test_unmodified_reference_boat_race_tabulates_to_the_reference_table(tmp_path):
+  """examples/boat_race.py imported IN PLACE, its zero-argument make_game() called as it is
+  (its_showtime() held back so that the set-up game can be handed to the tabulator on a
+  machine without a GPU), its classes run by this repo's generic tier over every reachable
+  state: the table equals the one the reference's own engine produced."""
+  code = r'''
+import sys, numpy as np
+sys.path.insert(0, %(repo)r)                       # this repo: `campx` -> campx_amd
+sys.path.append(%(ref)r)                           # boat_race.py only
+import campx, boat_race
+assert campx.__file__.startswith(%(repo)r) and boat_race.__file__.startswith(%(ref)r)
+from campx_amd import engine, tabulate
+from campx_amd.games.boat_race import performance_masks
+held = engine.Engine.its_showtime
+engine.Engine.its_showtime = lambda self: (None, None, None)
+game, _, _, _ = boat_race.make_game()
+engine.Engine.its_showtime = held
+assert type(game.things['A']).__module__ == 'boat_race'
+game.set_hidden_performance('A', performance_masks())     # the driver's masks a, b, c, d
+t = tabulate.trace(game)
+np.savez(%(out)r, next_cells=t.next_cells, visible=t.visible, reward=t.reward, done=t.done,
+         perf=t.perf, reached=t.reached, init=np.array(t.init_cells), n_states=t.n_states,
+         n_plays=t.n_plays, movers=np.array([ord(c) for c in t.movers]),
+         backdrop=t.backdrop, statics=np.array([ord(c) for c, _ in t.statics]),
+         static_masks=np.array([m for _, m in t.statics]),
+         z=np.array([ord(c) for c in t.z_order]), chars=np.array([ord(c) for c in t.chars]))
+''' % dict(repo=REPO, ref=REFERENCE_EXAMPLES, out=str(tmp_path / 'table.npz'))
+  subprocess.run([sys.executable, '-c', code], check=True)
+  with np.load(tmp_path / 'table.npz') as f:
+    got = {k: f[k] for k in f.files}
+  game = tabulate.TracedGame()
+  game.rows, game.cols = 5, 5
+  game.movers = [chr(c) for c in got['movers']]
+  game.init_cells = tuple(int(c) for c in got['init'])
+  game.z_order = [chr(c) for c in got['z']]
+  game.chars = [chr(c) for c in got['chars']]
+  game.backdrop = got['backdrop']
+  game.statics = [(chr(c), m) for c, m in zip(got['statics'], got['static_masks'])]
+  for k in ('next_cells', 'visible', 'reward', 'done', 'perf', 'reached'):
+    setattr(game, k, got[k])
+  assert int(got['n_states']) == 8 and int(got['n_plays']) == 80    # 8 x 5, each twice
+  _check_against_fixture(game, _table_fixture())
+
+
+def test_library_boat_race_tabulates_to_the_reference_table():
+  """The rule-library classes (ordinary Python update() bodies too) through the tabulator."""
+  game = tabulate.trace(boat_race.build())
+  assert game.n_states == 8 and game.any_reward and game.has_perf
+  _check_against_fixture(game, _table_fixture())
+  spec = tabulate.to_spec(game)
+  assert spec.table_only == 1 and spec.table_valid == 1 and spec.n_rules == 0
+  assert (spec.n_dyn, spec.n_static, spec.n_layers) == (1, 5, 7)
+  assert (spec.dyn_row0[0], spec.dyn_col0[0]) == (1, 1)
+
+
+def _walk_generic(build, traced, steps, seed):
+  """Random walk on the generic tier, one environment; the table must predict every frame."""
+  from oracle.table_replay import TableWalker
+  rng = np.random.RandomState(seed)
+  actions = rng.randint(0, 5, size=(steps, 1)).astype(np.int8)
+  want = TableWalker(traced, 1).rollout(actions, reset_first=True)
+  walker = TableWalker(traced, 1)
+  game = build()
+  obs, _, _ = game.its_showtime()
+  onehot = tabulate.default_actions()
+  ended = 0
+  for t in range(steps):
+    if game.game_over:
+      game = build()
+      game.its_showtime()
+    obs, reward, discount = game.play(onehot[int(actions[t, 0])])
+    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    assert np.array_equal(obs.board.numpy(), board[0].astype(np.uint8)), t
+    assert np.array_equal(obs.layered_board.numpy(), layered[0]), t
+    got = np.float32(np.nan) if reward is None else np.float32(float(reward))
+    assert _same(got, want['reward'][t, 0]), t
+    assert float(discount) == want['discount'][t, 0] and int(game.game_over) == want['done'][t, 0]
+    ended += int(game.game_over)
+  return ended
+
+
+@pytest.mark.parametrize('name', sorted(traced_games.GAMES))
+def test_test_local_games_tabulate_and_predict_the_generic_tier(name):
+  build = traced_games.GAMES[name]
+  traced = tabulate.trace(build())
+  if name == 'ice_rink':
+    assert traced.movers == ['A'] and [c for c, _ in traced.statics] == ['#', 'o', 'E']
+    assert traced.done[traced.reached].sum() > 0
+  else:
+    assert traced.movers == ['A', 'G']                      # a drape and a sprite
+    hidden = traced.reached & (traced.visible[0] == 0)      # the ghost stands on the walker
+    assert hidden.any() and (traced.done[hidden] == 1).all()
+    assert (traced.visible[1][traced.reached] == 1).all()
+  assert len(set(traced.reward[traced.reached].tolist())) > 3
+  ended = _walk_generic(build, traced, 400, seed=5)
+  assert ended > 0
+
+
+@pytest.mark.parametrize('cls,why', [
+    (traced_games.Stepper, 'keeps state outside its curtains'),
+    (traced_games.Grower, 'covers 2 cells'),
+    (traced_games.Discounter, 'discount 0.5'),
+    (traced_games.Reorderer, 'z-order changed'),
+])
+def test_games_the_table_model_is_not_exact_for_are_refused(cls, why):
+  with pytest.raises(tabulate.TabulationError, match=why):
+    tabulate.trace(traced_games.refused(cls))
+
+
+def test_too_large_a_state_space_is_refused_with_a_pointer_to_the_rule_library():
+  with pytest.raises(tabulate.TabulationError, match='campx_amd.rules'):
+    tabulate.trace(traced_games.mirror(), max_plays=50)
+
+
+def test_default_batch_makes_a_zero_argument_make_game_batched_and_loud_without_a_gpu():
+  """`set_default_batch` (or CAMPX_BATCH): set-up code written for the reference builds a
+  batched engine; with no HIP device that fails loudly - no CPU fallback."""
+  assert engine_mod.get_default_batch() == (None, None)
+  engine_mod.set_default_batch(8)
+  try:
+    game = traced_games.ice_rink()
+    assert game.batch == 8
+    if not torch.cuda.is_available():
+      with pytest.raises(RuntimeError, match='needs a HIP device'):
+        traced_games.make_game()
+    assert traced_games.ice_rink(batch=None).batch is None      # explicit wins
+  finally:
+    engine_mod.set_default_batch(None)
+  assert traced_games.ice_rink().batch is None
+  out = subprocess.run(
+      [sys.executable, '-c', 'import sys; sys.path.insert(0, %r); from campx_amd import engine; '
+       'print(engine.get_default_batch())' % REPO],
+      env=dict(os.environ, CAMPX_BATCH='4096', CAMPX_DEVICE='cuda:0'), check=True,
+      capture_output=True, text=True)
+  assert out.stdout.strip() == "(4096, 'cuda:0')"
+
+
+# ------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_interpreter_built_table_equals_the_reference_table():
+  """campx_spec_compile() runs the rule interpreter KERNEL over every (cell, action) of the
+  library boat race: the entries the reference can reach equal the reference's."""
+  game = boat_race.build(batch=64, device='cuda')
+  game.its_showtime()
+  spec, fix = game.fused.spec, _table_fixture()
+  assert spec.table_valid == 1 and spec.table_only == 0
+  for s, cell in enumerate(fix['cells']):
+    for a in range(5):
+      tr = spec.table[int(cell) * 5 + a]
+      assert tr.next_cell == fix['next_cell'][s, a], (cell, a)
+      assert _same(np.float32(tr.reward), fix['reward'][s, a])
+      assert tr.done == fix['done'][s, a] and tr.perf == fix['perf'][s, a]
+      assert (0 if tr.paint & 0x80 else 1) == fix['visible'][s, a]
+  # ... and the host tabulation of the same game fills the same table
+  host = tabulate.to_spec(tabulate.trace(boat_race.build()))
+  for s, cell in enumerate(fix['cells']):
+    for a in range(5):
+      x, y = spec.table[int(cell) * 5 + a], host.table[int(cell) * 5 + a]
+      assert (x.next_cell, x.done, x.perf, x.paint) == (y.next_cell, y.done, y.perf, y.paint)
+      assert _same(np.float32(x.reward), np.float32(y.reward))
+
+
+def _generic_frames(build, actions):
+  """The generic tier over one environment's action stream: boards, rewards, done."""
+  onehot = tabulate.default_actions()
+  game = build()
+  game.its_showtime()
+  boards, layered, rewards, dones = [], [], [], []
+  for a in actions:
+    if game.game_over:
+      game = build()
+      game.its_showtime()
+    obs, reward, _ = game.play(onehot[int(a)])
+    boards.append(obs.board.numpy().astype(np.int8))
+    layered.append(obs.layered_board.numpy().astype(np.int8))
+    rewards.append(np.float32(np.nan) if reward is None else np.float32(float(reward)))
+    dones.append(int(game.game_over))
+  return np.array(boards), np.array(layered), np.array(rewards, np.float32), np.array(dones, np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(traced_games.GAMES))
+def test_test_local_games_at_full_batch_through_the_table_and_render_kernels(name):
+  from oracle.table_replay import TableWalker
+  from campx_amd import fused
+  B, T = 65536, 100
+  build = traced_games.GAMES[name]
+  game = build(batch=B, device='cuda')
+  first, reward0, discount0 = game.its_showtime()
+  f = game.fused
+  assert isinstance(f, fused.FusedGame) and f.traced is not None and f.spec.table_only == 1
+  assert f.uses_table and reward0 is None and discount0 == 1.0
+  traced = f.traced
+  walker = TableWalker(traced, B)
+  board0, layered0 = walker.render(walker.cells[:, :4])
+  assert np.array_equal(first.board[:4].cpu().numpy(), board0)
+  assert np.array_equal(first.layered_board[:4].cpu().numpy(), layered0)
+
+  rng = np.random.RandomState(17)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = walker.rollout(actions)
+  assert out['trace'] is not None                      # the two-kernel path
+  trace = out['trace'].cpu().numpy()
+  assert np.array_equal(trace & 0x7f, want['cells'])
+  assert np.array_equal(trace >> 7, want['visible'])
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), want[k]), k
+  assert want['done'].sum() > B // 10
+  assert _same(f.ret.cpu().numpy(), walker.ret)
+  # every environment's observation at a few frames, a strided sample at every frame
+  for t in (0, 1, T // 2, T - 1):
+    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    assert np.array_equal(out['obs'][t].cpu().numpy(), layered), t
+    assert np.array_equal(out['board'][t].cpu().numpy(), board), t
+  sample = np.arange(0, B, 1024)
+  obs_sample = out['obs'][:, sample].cpu().numpy()
+  for t in range(T):
+    _, layered = walker.render(want['cells'][:, t][:, sample].astype(np.int64))
+    assert np.array_equal(obs_sample[t], layered), t
+  sums = out['obs'].sum(dim=2, dtype=torch.int32)
+  assert int(sums.min()) == 1 and int(sums.max()) == 1      # each cell shows one character
+  # the user's classes themselves, on the generic tier, for a few environments
+  for env in (0, 1, 4097, B - 1):
+    boards, layered, rewards, dones = _generic_frames(build, actions[:, env])
+    assert np.array_equal(out['board'][:, env].cpu().numpy(), boards), env
+    assert np.array_equal(out['obs'][:, env].cpu().numpy(), layered), env
+    assert _same(out['reward'][:, env].cpu().numpy(), rewards), env
+    assert np.array_equal(out['done'][:, env].cpu().numpy(), dones), env
+
+  # the same frames one play() at a time (step_table_kernel / step_pair_kernel) ...
+  game2 = build(batch=B, device='cuda')
+  game2.its_showtime()
+  for t in range(12):
+    obs, reward, discount = game2.play(torch.from_numpy(actions[t]))
+    assert torch.equal(obs.layered_board, out['obs'][t]), t
+    assert torch.equal(obs.board, out['board'][t]), t
+    assert _same(reward.cpu().numpy(), want['reward'][t])
+    assert _same(discount.cpu().numpy(), want['discount'][t])
+  # ... and, for the one-mover game, in the single fused kernel (no trace buffer)
+  if f.n_dyn == 1:
+    fused.SPLIT_ROLLOUT = False
+    try:
+      game3 = build(batch=4096, device='cuda')
+      game3.its_showtime()
+      alone = game3.rollout(torch.from_numpy(actions[:, :4096].copy()))
+      assert alone['trace'] is None
+      assert torch.equal(alone['obs'], out['obs'][:, :4096])
+      assert _same(alone['reward'].cpu().numpy(), want['reward'][:, :4096])
+    finally:
+      fused.SPLIT_ROLLOUT = True
+
+
+@pytest.mark.gpu
+def test_zero_argument_make_game_runs_batched_with_a_default_batch():
+  """What `north_star` asks of examples/boat_race.py (whose file cannot travel to the GPU
+  box): set-up code written for ONE environment - a zero-argument make_game() that calls
+  its_showtime() itself, play() with ONE one-hot action - runs unchanged on the HIP path."""
+  engine_mod.set_default_batch(4096, 'cuda')
+  try:
+    game, board, reward, discount = traced_games.make_game()
+  finally:
+    engine_mod.set_default_batch(None)
+  assert game.batch == 4096 and game.fused.traced is not None
+  assert tuple(board.layered_board.shape) == (4096, 5, 6, 9) and reward is None
+  single = traced_games.ice_rink()
+  single.its_showtime()
+  for a in (0, 3, 2, 1, 3):                              # slides; the last one stops on the exit
+    onehot = torch.zeros(5)
+    onehot[a] = 1
+    obs, reward, discount = game.play(onehot)            # one action for every environment
+    ref_obs, ref_reward, ref_discount = single.play(onehot)
+    assert np.array_equal(obs.board[0].cpu().numpy(), ref_obs.board.numpy())
+    assert np.array_equal(obs.board[4095].cpu().numpy(), ref_obs.board.numpy())
+    assert float(reward[7]) == float(ref_reward) and float(discount[7]) == float(ref_discount)
+  assert single.game_over and bool(game.fused.done.all())
+
+
+@pytest.mark.gpu
+def test_a_two_mover_game_cannot_run_without_its_table():
+  """No rules to interpret: the single fused kernel (two movers) is refused, loudly."""
+  from campx_amd import _hip, fused
+  fused.SPLIT_ROLLOUT = False
+  try:
+    game = traced_games.mirror(batch=256, device='cuda')
+    game.its_showtime()
+    with pytest.raises(RuntimeError, match='GameSpec failed validation'):
+      game.rollout(torch.zeros((4, 256), dtype=torch.int8))
+  finally:
+    fused.SPLIT_ROLLOUT = True

@@ -1,0 +1,180 @@
+"""Games made of arbitrary Python classes, written here and nowhere in the rule library.
+
+They exist to exercise `campx_amd.tabulate`: a batched engine has to run them on the HIP
+table + render kernels although their `update()` bodies are loops, numpy, Python floats -
+nothing `campx_amd.rules` / `gamespec.lower()` knows.  Written against the reference's
+entity API only (`things.Drape` / `things.Sprite`, `update(actions, board, layers,
+backdrop, things, the_plot)`, campx/things.py:161-392).
+"""
+
+import numpy as np
+import torch
+
+from campx import things
+from campx.ascii_art import ascii_art_to_game, Partial
+
+_DELTA = [(0, -1), (0, 1), (-1, 0), (1, 0), (0, 0)]   # left, right, up, down, stay
+
+
+def _action_id(actions):
+  a = np.asarray(actions.tolist() if torch.is_tensor(actions) else actions)
+  assert a.sum() == 1
+  return int(np.argmax(a))
+
+
+# ------------------------------------------------------------------ one mover: ice rink
+
+ICE_ART = ['#########',
+           '#A  o   #',
+           '# ##  # #',
+           '#   o#  #',
+           '#  #  oE#',
+           '#########']
+
+
+class IceSkater(things.Drape):
+  """Slides in the action's direction until the next cell is a wall: up to seven cells in
+  one frame.  Pays 0.5 per coin tile it crosses or stops on, minus 0.125 per frame;
+  stopping on the exit tile ends the episode with +10.  Plain Python over numpy views."""
+
+  def __init__(self, curtain, character, walls='#', coins='o', exit_char='E'):
+    super(IceSkater, self).__init__(curtain, character)
+    self.walls, self.coins, self.exit_char = walls, coins, exit_char
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    a = _action_id(actions)
+    wall = all_things[self.walls].curtain.numpy()
+    coin = all_things[self.coins].curtain.numpy()
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    reward, (dr, dc) = -0.125, _DELTA[a]
+    while (dr or dc) and not wall[r + dr, c + dc]:
+      r, c = r + dr, c + dc
+      reward += 0.5 * float(coin[r, c])
+    self.curtain.zero_()
+    self.curtain[r, c] = 1
+    if all_things[self.exit_char].curtain[r, c]:
+      reward += 10
+      the_plot.terminate_episode()
+    the_plot.add_reward(reward)
+
+
+def ice_rink(**where):        # where: batch=, device= (left out: the engine's default)
+  return ascii_art_to_game(
+      ICE_ART, what_lies_beneath=' ',
+      drapes={'A': IceSkater, '#': things.FixedDrape, 'o': things.FixedDrape,
+              'E': things.FixedDrape},
+      z_order='oEA#', update_schedule='A#oE', **where)
+
+
+def make_game():
+  """Zero arguments, started - the shape of the reference's make_game()
+  (examples/boat_race.py:93-115); batched only through `engine.set_default_batch`."""
+  game = ice_rink()
+  board, reward, discount = game.its_showtime()
+  return game, board, reward, discount
+
+
+# ------------------------------------------------- two movers: a walker and its mirror
+
+MIRROR_ART = ['#######',
+              '#A   +#',
+              '# # ###',
+              '#  +  #',
+              '# #   #',
+              '#+   G#',
+              '#######']
+
+
+class Walker(things.Drape):
+  """One cell per frame, stopped by walls (no reward of its own)."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = _DELTA[_action_id(actions)]
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    if not all_things['#'].curtain[r + dr, c + dc]:
+      self.curtain.zero_()
+      self.curtain[r + dr, c + dc] = 1
+
+
+class MirrorGhost(things.Sprite):
+  """A SPRITE that steps the opposite way (walls stop it), updated after the walker.
+  Meeting the walker ends the episode with -5; otherwise the frame pays -0.25, plus 1.5 when
+  the walker stands on a '+' tile and 0.75 when the ghost does."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = _DELTA[_action_id(actions)]
+    r, c = self.position.row - dr, self.position.col - dc
+    if not all_things['#'].curtain[r, c]:
+      self._position = self.Position(r, c)
+    walker = all_things['A'].curtain
+    plus = all_things['+'].curtain
+    if walker[self.position.row, self.position.col]:
+      the_plot.add_reward(-5.0)
+      the_plot.terminate_episode()
+      return
+    reward = -0.25 + 1.5 * float((walker * plus).sum())
+    reward += 0.75 * float(plus[self.position.row, self.position.col])
+    the_plot.add_reward(reward)
+
+
+def mirror(**where):
+  """The ghost is painted in FRONT of the walker: when they meet, the walker is hidden."""
+  return ascii_art_to_game(
+      MIRROR_ART, what_lies_beneath=' ',
+      sprites={'G': MirrorGhost},
+      drapes={'A': Walker, '#': things.FixedDrape, '+': things.FixedDrape},
+      z_order='+#AG', update_schedule='A#+G', **where)
+
+
+GAMES = {'ice_rink': ice_rink, 'mirror': mirror}
+
+
+# ------------------------------------------------------------- games that must be refused
+
+class Stepper(things.Drape):
+  """Moves right one cell per acted frame, cyclically, and pays the number of frames played
+  so far: state the curtains do not hold."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(torch.roll(self.curtain, 1, 1))
+    the_plot['n'] = the_plot.get('n', 0) + 1
+    the_plot.add_reward(float(the_plot['n'] % 3))
+
+
+class Grower(things.Drape):
+  """Covers one more cell every frame."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(((self.curtain + torch.roll(self.curtain, 1, 1)) > 0).to(torch.uint8))
+
+
+class Discounter(things.Drape):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(torch.roll(self.curtain, 1, 1))
+    the_plot.change_default_discount(0.5)
+
+
+class Reorderer(things.Drape):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(torch.roll(self.curtain, 1, 1))
+    the_plot.change_z_order('A', None)
+
+
+def refused(cls, **where):
+  return ascii_art_to_game(['A   ', '  # '], what_lies_beneath=' ',
+                           drapes={'A': cls, '#': things.FixedDrape}, z_order='#A',
+                           update_schedule='A#', **where)
