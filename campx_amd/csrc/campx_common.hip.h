@@ -125,6 +125,10 @@ __device__ __forceinline__ int class_progress(int from, int to, int n) {
   return (to == fwd) - (to == back);
 }
 
+// What a frame's reward adds to the running return: a frame nobody rewarded reports None
+// (NaN, campx/plot.py:208-211) and adds nothing.
+__device__ __forceinline__ float real_reward(float r) { return r == r ? r : 0.0f; }
+
 // Index of the pair-table entries of (cell of thing 0, cell of thing 1).
 __device__ __forceinline__ uint32_t pair_index(uint32_t c0, uint32_t c1, int HW) {
   return (c0 * (uint32_t)HW + c1) * CAMPX_N_ACTIONS;

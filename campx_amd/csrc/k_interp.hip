@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
       if (R.end_group) shown = pos;
     }
     if (!rb.any_reward) reward = __builtin_nanf("");
-    ret += reward;
+    ret += real_reward(reward);
     if (out.perf && rb.perf_dyn >= 0 && live) {
       const int perf_to = sel<K>(pos.cell, rb.perf_dyn);
       out.perf[(int64_t)t * B + env] =

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     const float reward = __uint_as_float(tr.x);
     cell = (int)(tr.y & 0xffu);
     over = (int)((tr.y >> 8) & 1u);
-    ret += reward;
+    ret += real_reward(reward);
 
     {
       __syncthreads();  // previous frame's reads of the image are done

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kWave) void step_table_kernel(
     fill_rest<kStepBoardLoads>(board_img, kWave * HW, HW, spec->rot_board, k_board, lane);
   }
   cell = tr.next_cell;
-  ret += tr.reward;
+  ret += real_reward(tr.reward);
   if (!(tr.paint & 0x80u)) {   // the mover shows at its cell
     int8_t* my_obs = obs_img + lane * LHW;
     my_obs[(int)(tr.paint & 0x7fu) * HW + cell] = 0;
@@ -86,6 +86,198 @@ __global__ __launch_bounds__(kWave) void step_table_kernel(
   // one wave: LDS operations complete in order, no barrier needed
   step_stream_obs(obs_img, out, env0 * LHW, n_live * LHW, lane);
   if (kBoard) stream_out<false>(board_img, out.board + env0 * HW, n_live * HW, lane);
+  report_bad_actions(out, bad);
+}
+
+// ---------------------------------------------------------------------------
+// The default one-frame kernel of one-mover games: row-group-major.  A wave owns n
+// consecutive environments (n * R a multiple of 16 bytes, about 3 KiB: 16 environments of
+// the boat race = 2 800 B) instead of 64: four times as many waves as step_table_kernel,
+// each with a quarter of the image to fill and stream, so the chip sees one short burst
+// from every SIMD at once instead of a long serial stream from a quarter of them.
+// Everything the wave needs comes in ONE round trip - state and action of its n
+// environments (one per lane), the transition table (only the KiB in use: one for the boat
+// race), the scenery chunks of its span - then the lookup is an LDS read, the patch two LDS
+// bytes, the output up to four 16-byte stores per lane.  State stays in place: an
+// environment's row is read and written by one lane only (memory-aligned windows, as the
+// render kernel has them, would share rows between waves, which in-place state cannot allow).
+// Addresses are (uniform 64-bit base) + (32-bit lane offset) and the divisions by game
+// constants are multiplications by reciprocals from the launcher: a wave of the one-shot
+// kernel is a few hundred instructions, and with sixteen waves per CU that instruction
+// stream, not HBM, is most of the kernel's time above the launch floor.
+struct RowsParams {
+  int32_t cols, cells, R, dyn_layer, cell0, mover_char;
+  int32_t n;            // environments per wave
+  int32_t n_tab;        // KiB of the transition table in use (whole chunks per lane)
+  int32_t n_obs;        // KiB chunks of a wave's observation span, rounded up
+  uint32_t inv_w;       // cell / cols == (cell * inv_w) >> 16 for cell < 128
+  uint32_t inv_r;       // x / R == (x * inv_r) >> 24 for x < 1024
+  uint32_t inv_hw;      // x / cells == (x * inv_hw) >> 24 for x < 1024
+  uint32_t step_r;      // 1024 % R
+};
+
+constexpr int kRowsMaxChunks = 4;    // a wave's observation span is at most 4 KiB
+constexpr int kRowsTableLoads = 5;   // the whole table: 5 KiB = 5 chunks per lane
+#ifndef CAMPX_STEP_WAVES
+#define CAMPX_STEP_WAVES 1           // waves per workgroup (independent: no barrier); 1, 2, 4 measure alike
+#endif
+constexpr int kStepWaves = CAMPX_STEP_WAVES;
+
+template <bool kBoard, int kFmt, bool kNT>
+__global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
+    RowsParams rp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t reset_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t W = (uint32_t)rp.cols, HW = (uint32_t)rp.cells, R = (uint32_t)rp.R;
+  const uint32_t n = (uint32_t)rp.n;
+  // (block b runs on XCD b % 8: each XCD sweeps its own contiguous eighth of the frame)
+  const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t env0 = (int64_t)(blk * (uint32_t)kStepWaves + wave) * n;
+  if (env0 >= B) return;   // (uniform per wave; waves share nothing)
+  const uint32_t n_live = (B - env0 < (int64_t)n) ? (uint32_t)(B - env0) : n;
+  const uint32_t span = n * R, n_obs = (uint32_t)rp.n_obs, n_tab = (uint32_t)rp.n_tab;
+  int8_t* obs_img = lds + wave * ((n_obs + n_tab + (kBoard ? 1u : 0u)) << 10);
+  int8_t* board_img = obs_img + (n_obs << 10);
+  const uint2* lds_table = reinterpret_cast<const uint2*>(board_img + (kBoard ? 1024 : 0));
+
+  // ---- every load of the kernel, back to back (no branch between them: a conditional
+  // load makes hipcc wait for it at the join - one round trip per load; chunks past the
+  // table's / the span's end are clamped to valid addresses - every offset of the
+  // cyclically continued scenery row is one - and dropped when they land)
+  const bool mine = lane < n_live;
+  const uint32_t ln = mine ? lane : n_live - 1u;    // surplus lanes reload the last environment
+  int8_t* pos_r = st.pos + env0;
+  int8_t* pos_c = st.pos + B + env0;
+  uint8_t* done_base = st.done + env0;
+  // (no running return asked for: any valid address, the value is not used)
+  const float* ret_src = st.ret ? st.ret + env0 : reinterpret_cast<const float*>(spec) - ln;
+  int a = (actions + env0)[ln];
+  int r = pos_r[ln], c = pos_c[ln], over = done_base[ln];
+  float ret = ret_src[ln];
+  u32x4 v_table[kRowsTableLoads];
+  const uint32_t last_vec = (n_tab << 6) - 1u;
+#pragma unroll
+  for (int j = 0; j < kRowsTableLoads; ++j) {
+    uint32_t idx = (uint32_t)j * kWave + lane;
+    idx = idx < last_vec ? idx : last_vec;
+    v_table[j] = reinterpret_cast<const u32x4*>(spec->table)[idx];
+  }
+  u32x4 v_obs[kRowsMaxChunks], v_board;
+  {
+    const uint32_t pitch = ((R + 15u) & ~15u) + 16u;
+    const uint32_t x = lane * 16u;
+    uint32_t k = x - ((x * rp.inv_r) >> 24) * R;   // x % R
+#pragma unroll
+    for (int j = 0; j < kRowsMaxChunks; ++j) {
+      v_obs[j] = *reinterpret_cast<const u32x4*>(spec->rot_obs + ((k & 15u) * pitch + (k & ~15u)));
+      k += rp.step_r;
+      k = k >= R ? k - R : k;
+    }
+    if (kBoard) {   // n * HW <= 1 KiB (launcher)
+      const uint32_t bpitch = ((HW + 15u) & ~15u) + 16u;
+      const uint32_t kb = x - ((x * rp.inv_hw) >> 24) * HW;
+      v_board = *reinterpret_cast<const u32x4*>(spec->rot_board + ((kb & 15u) * bpitch + (kb & ~15u)));
+    }
+  }
+
+  // ---- the one wait of the kernel: everything above has been issued, all of it lands here
+  // (the empty asm statements keep hipcc from sinking a load into the branch that uses it)
+#pragma unroll
+  for (int j = 0; j < kRowsTableLoads; ++j) asm volatile("" : "+v"(v_table[j]));
+#pragma unroll
+  for (int j = 0; j < kRowsMaxChunks; ++j) asm volatile("" : "+v"(v_obs[j]));
+  const int bad = (mine && (unsigned)a > 4u) ? 1 : 0;
+  a = ((unsigned)a > 4u) ? 4 : a;
+  // a finished episode (or reset_first) is rebuilt from the art before its action
+  over = reset_first ? 1 : over;
+  uint32_t cell = over ? (uint32_t)rp.cell0 : (uint32_t)r * W + (uint32_t)c;
+  ret = over ? 0.0f : ret;
+  // ---- land (LDS operations of a wave complete in order: no barrier)
+  u32x4* tab_dst = reinterpret_cast<u32x4*>(const_cast<uint2*>(lds_table)) + lane;
+#pragma unroll
+  for (int j = 0; j < kRowsTableLoads; ++j)
+    if ((uint32_t)j < n_tab) tab_dst[j * kWave] = v_table[j];          // uniform condition
+  u32x4* img_dst = reinterpret_cast<u32x4*>(obs_img) + lane;
+#pragma unroll
+  for (int j = 0; j < kRowsMaxChunks; ++j)
+    if ((uint32_t)j < n_obs) img_dst[j * kWave] = v_obs[j];             // uniform condition
+  if (kBoard) reinterpret_cast<u32x4*>(board_img)[lane] = v_board;
+
+  const uint2 tr = lds_table[cell * CAMPX_N_ACTIONS + (uint32_t)a];     // CampxTransition
+  const float reward = __uint_as_float(tr.x);
+  cell = tr.y & 0xffu;
+  const uint32_t done = (tr.y >> 8) & 0xffu, paint = tr.y >> 24;
+  if (mine) {
+    if (!(paint & 0x80u)) {   // the mover shows at its cell
+      int8_t* my_obs = obs_img + lane * R;
+      my_obs[(paint & 0x7fu) * HW + cell] = 0;
+      my_obs[(uint32_t)rp.dyn_layer * HW + cell] = 1;
+      if (kBoard) board_img[lane * HW + cell] = (int8_t)rp.mover_char;
+    }
+    if (out.reward) (out.reward + env0)[lane] = reward;
+    if (out.discount) (out.discount + env0)[lane] = done ? 0.0f : 1.0f;
+    if (out.done) (out.done + env0)[lane] = (uint8_t)done;
+    if (out.perf) (out.perf + env0)[lane] = (int8_t)(tr.y >> 16);
+    const uint32_t row = (cell * rp.inv_w) >> 16;
+    pos_r[lane] = (int8_t)row;
+    pos_c[lane] = (int8_t)(cell - row * W);
+    done_base[lane] = (uint8_t)done;
+    if (st.ret) (st.ret + env0)[lane] = ret + real_reward(reward);
+  }
+  // ---- out: the wave's span, 16 bytes per lane per store
+  constexpr uint32_t kElem = kFmt ? 2u : 1u;
+  int8_t* obs_dst = out.obs + env0 * (int64_t)(R * kElem);
+  int8_t* board_dst = kBoard ? out.board + env0 * (int64_t)HW : nullptr;
+  if (n_live == n) {           // (every wave but, perhaps, the batch's last)
+    if (kFmt == 0) {
+#pragma unroll
+      for (int j = 0; j < kRowsMaxChunks; ++j) {
+        const uint32_t o = ((uint32_t)j * kWave + lane) * 16u;
+        if ((uint32_t)j < n_obs && o < span) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(obs_img + o);
+          if (kNT) store16_streaming_at(obs_dst, o, v);
+          else *reinterpret_cast<u32x4*>(obs_dst + o) = v;
+        }
+      }
+    } else {
+      // 16-bit observations (0.0 / 1.0 in f16 or bf16): 8 image bytes -> 16 output bytes
+      constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+#pragma unroll
+      for (int j = 0; j < 2 * kRowsMaxChunks; ++j) {
+        const uint32_t o = ((uint32_t)j * kWave + lane) * 8u;
+        if ((uint32_t)j < 2u * n_obs && o < span) {
+          const uint2 b = *reinterpret_cast<const uint2*>(obs_img + o);
+          u32x4 v;
+          v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * kOne;
+          v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * kOne;
+          v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * kOne;
+          v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * kOne;
+          if (kNT) store16_streaming_at(obs_dst, 2u * o, v);
+          else *reinterpret_cast<u32x4*>(obs_dst + 2u * o) = v;
+        }
+      }
+    }
+    if (kBoard && lane * 16u < n * HW)
+      *reinterpret_cast<u32x4*>(board_dst + lane * 16u) =
+          *reinterpret_cast<const u32x4*>(board_img + lane * 16u);
+  } else {                     // a partial group: element by element
+    const uint32_t live = n_live * R;
+    if (kFmt == 0) {
+#pragma unroll 1
+      for (uint32_t i = lane; i < live; i += kWave) obs_dst[i] = obs_img[i];
+    } else {
+      const uint16_t one = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+#pragma unroll 1
+      for (uint32_t i = lane; i < live; i += kWave)
+        reinterpret_cast<uint16_t*>(obs_dst)[i] = obs_img[i] ? one : (uint16_t)0;
+    }
+    if (kBoard) {
+#pragma unroll 1
+      for (uint32_t i = lane; i < n_live * HW; i += kWave) board_dst[i] = board_img[i];
+    }
+  }
   report_bad_actions(out, bad);
 }
 
@@ -144,7 +336,7 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
   c1 = (e >> 7) & 0x7fu;
   const float reward = g_rewards[(e >> 19) & 0xffu];
   const int done = (int)((e >> 16) & 1u);
-  ret += reward;
+  ret += real_reward(reward);
   int8_t* my_obs = obs_img + lane * LHW;
   if ((e >> 14) & 1u) {
     my_obs[(int)spec->static_top_layer[c0] * HW + (int)c0] = 0;
@@ -230,7 +422,7 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
   const float reward = g_rewards[(hi >> 3) & 0xffu];
   const int done = (int)(hi & 1u);
-  ret += reward;
+  ret += real_reward(reward);
   int8_t* my_obs = obs_img + lane * LHW;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -260,11 +452,104 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   report_bad_actions(out, bad);
 }
 
+// Environments per wave of step_rows_kernel for this game, or 0 when its rows do not fit the
+// kernel's shape: n * R and (with a board) n * HW must be multiples of 16 bytes - 8 for the
+// 16-bit formats -, n <= 64, the observation span at most 4 KiB and the board span 1 KiB.
+int rows_per_wave(const CampxSpec& s, bool board, int fmt) {
+  const int HW = s.rows * s.cols, R = s.n_layers * HW;
+  auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+  const int unit = fmt ? 8 : 16;
+  int n0 = unit / gcd(R, unit);
+  if (board) {
+    const int nb = 16 / gcd(HW, 16);
+    n0 = n0 / gcd(n0, nb) * nb;   // lcm
+  }
+  if (n0 > kWave || n0 * R > kRowsMaxChunks * 1024 || (board && n0 * HW > 1024) || R < 16 || HW < 4)
+    return 0;
+  // about 3 KiB of observation per wave, in whole multiples of n0
+  int n = n0 * (3072 / (n0 * R) > 0 ? 3072 / (n0 * R) : 1);
+  while (n > n0 && (n > kWave || (board && n * HW > 1024))) n -= n0;
+  return n;
+}
+
+static const bool g_no_rows_kernel = [] {
+  const char* v = getenv("CAMPX_NO_ROWS_STEP");
+  return v && v[0] == '1';
+}();
+// A/B: streaming (write-through, non-temporal) observation stores in the one-frame kernel
+static const bool g_step_nt = [] {
+  const char* v = getenv("CAMPX_STEP_NT");
+  return v && v[0] == '1';
+}();
+
+// A/B: dynamic LDS per workgroup in KiB (more than the kernel needs = fewer resident waves
+// per CU, so that the launch runs in phases and one phase's loads overlap another's stores)
+static const size_t g_step_lds_kb = [] {
+  const char* v = getenv("CAMPX_STEP_LDS_KB");
+  return (size_t)(v && *v ? atoi(v) : 0);
+}();
+
+int32_t launch_step_rows(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                         const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
+                         int n, hipStream_t stream) {
+  const int HW = s.rows * s.cols, R = s.n_layers * HW;
+  const bool board = out.board != nullptr;
+  RowsParams rp;
+  rp.cols = s.cols;
+  rp.cells = HW;
+  rp.R = R;
+  rp.dyn_layer = s.dyn_layer[0];
+  rp.cell0 = s.dyn_row0[0] * s.cols + s.dyn_col0[0];
+  rp.mover_char = s.layer_char[s.dyn_layer[0]];
+  rp.n = n;
+  rp.n_tab = (HW * CAMPX_N_ACTIONS * (int)sizeof(CampxTransition) + 1023) / 1024;
+  rp.n_obs = (n * R + 1023) / 1024;
+  // exact for the ranges the kernel uses them on (checked by tests/test_launch_math.py's
+  // restatement: cell < 128 with cols <= 127; x < 1024 with x * d < 2^24)
+  rp.inv_w = (65536u + (uint32_t)s.cols - 1u) / (uint32_t)s.cols;
+  rp.inv_r = ((1u << 24) + (uint32_t)R - 1u) / (uint32_t)R;
+  rp.inv_hw = ((1u << 24) + (uint32_t)HW - 1u) / (uint32_t)HW;
+  rp.step_r = 1024u % (uint32_t)R;
+  size_t shmem = (size_t)kStepWaves * 1024 * (size_t)(rp.n_obs + rp.n_tab + (board ? 1 : 0));
+  if (g_step_lds_kb * 1024 > shmem) shmem = g_step_lds_kb * 1024;
+  const int64_t waves = (B + n - 1) / n;
+  // rounded up to a multiple of 8 for the XCD remap; surplus waves exit at once
+  const dim3 grid((unsigned)((((waves + kStepWaves - 1) / kStepWaves) + 7) & ~(int64_t)7)),
+      block(kStepWaves * kWave);
+#define CAMPX_ROWS3(BOARD, FMT, NT)                                                                \
+  do {                                                                                             \
+    CAMPX_ALLOW_LDS((step_rows_kernel<BOARD, FMT, NT>), shmem);                                    \
+    hipLaunchKernelGGL((step_rows_kernel<BOARD, FMT, NT>), grid, block, shmem, stream, rp,         \
+                       spec_dev, st, actions, out, B, reset_first);                                \
+  } while (0)
+#define CAMPX_ROWS(BOARD, FMT)                                           \
+  do {                                                                   \
+    if (g_step_nt) CAMPX_ROWS3(BOARD, FMT, true); else CAMPX_ROWS3(BOARD, FMT, false); \
+  } while (0)
+  if (board) {
+    if (out.obs_format == CAMPX_OBS_F16) CAMPX_ROWS(true, 1);
+    else if (out.obs_format == CAMPX_OBS_BF16) CAMPX_ROWS(true, 2);
+    else CAMPX_ROWS(true, 0);
+  } else {
+    if (out.obs_format == CAMPX_OBS_F16) CAMPX_ROWS(false, 1);
+    else if (out.obs_format == CAMPX_OBS_BF16) CAMPX_ROWS(false, 2);
+    else CAMPX_ROWS(false, 0);
+  }
+#undef CAMPX_ROWS
+#undef CAMPX_ROWS3
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
 int32_t launch_step_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                           const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
                           hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
+  if (!g_no_rows_kernel) {
+    const int n = rows_per_wave(s, board, out.obs_format);
+    if (n > 0) return launch_step_rows(s, spec_dev, st, actions, out, B, reset_first, n, stream);
+  }
   const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],

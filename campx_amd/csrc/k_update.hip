@@ -275,7 +275,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               ring_r[g & 1][j][le] = __uint_as_float(e.x);
               ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
               // off the chain: the return restarts after an episode end
-              ret = (over ? 0.0f : ret) + __uint_as_float(e.x);
+              ret = (over ? 0.0f : ret) + real_reward(__uint_as_float(e.x));
               over = (int)((e.y >> 24) & 1u);
               cell = (int)((e.y >> 16) & 0x7fu);
             }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               c0 = e & 0x7fu;
               c1 = (e >> 7) & 0x7fu;
               ring[g & 1][j][le] = e;
-              ret = (over ? 0.0f : ret) + reward_list[(e >> 19) & 0xffu];
+              ret = (over ? 0.0f : ret) + real_reward(reward_list[(e >> 19) & 0xffu]);
               over = (int)((e >> 16) & 1u);
             }
           }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             const uint64_t e = g_entries[tuple_index<K>(cells, HW) + act[j]];  // the chain
             cells = (uint32_t)e & 0x0fffffffu;
             ring[g & 1][j][le] = e;
-            ret = (over ? 0.0f : ret) + reward_list[(uint32_t)(e >> 35) & 0xffu];
+            ret = (over ? 0.0f : ret) + real_reward(reward_list[(uint32_t)(e >> 35) & 0xffu]);
             over = (int)((e >> 32) & 1u);
           }
         }

@@ -26,7 +26,7 @@ def kernel_stats(db):
   rows = cur.execute(
       'select name, count(*), avg(end-start), min(end-start), max(end-start), '
       'max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), '
-      'max(grid_x), max(workgroup_x) from kernels group by name '
+      'grid_x, max(workgroup_x) from kernels group by name, grid_x '
       'order by sum(end-start) desc').fetchall()
   return rows
 
