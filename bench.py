@@ -125,12 +125,12 @@ def launch_ranks(n, argv):
 
 # ------------------------------------------------------------ CPU baselines
 
-def cpu_baseline(game_name, frames, seconds):
+def cpu_baseline(game_name, frames, seconds, batch=65536):
   """Time the CPU oracle (a port, not the reference) on a bounded sample.
 
-  The sample is `n` back-to-back episodes of a fixed batch (the GPU step's own
-  shape, capped at 65 536 environments), with `n` chosen from a short calibration
-  run so that the timed part takes about `seconds`.
+  The sample is `n` back-to-back episodes of `batch` environments (the GPU step's own
+  shape: BASELINE.md section 3 item 2), with `n` chosen from a short calibration run so
+  that the timed part takes about `seconds`.
   """
   import numpy as np
   from campx_amd import games, gamespec
@@ -138,7 +138,6 @@ def cpu_baseline(game_name, frames, seconds):
   build = getattr(games, game_name).build
   cores = oracle_cpu.set_threads(os.cpu_count() or 1)
   rng = np.random.RandomState(7)
-  batch = 65536
   actions = rng.randint(0, 5, size=(frames, batch)).astype(np.int8)
   og = oracle_cpu.OracleGame.from_description(gamespec.describe(build()))
   og.rollout(actions[:2], reset_first=True, keep_obs=False, want_board=False)
@@ -214,7 +213,7 @@ def kernel_names(fused, split):
 
 
 def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_every,
-                    standin=None, pipelined=False):
+                    standin=None, pipelined=False, with_log=False):
   """Warm up, then time exactly `steps` rollout launches.  Returns a dict.
 
   Wall clock: perf_counter around the timed region, bracketed by synchronize +
@@ -250,11 +249,12 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   bufs.append(fused.rollout_buffers(T, share=bufs[0]) if pipelined else bufs[0])
   pipelined = pipelined and bufs[0].get('trace') is not None
   log = None
-  if dist is not None:
+  if dist is not None or with_log:
     # Episode returns are logged per rank and all-gathered every `gather_every`
     # episodes (campx_amd.distributed.ReturnLog): the kernel accumulates each
     # episode's returns straight into its row of the log, so nothing but the
-    # rollout kernels ever runs on the rollout's stream.
+    # rollout kernels ever runs on the rollout's stream.  (Without a process group -
+    # RCCL could not be initialised on a one-GPU run - the "gather" is a local copy.)
     from campx_amd.distributed import ReturnLog
     # (never rarer than once per timed region, so that a short run still exercises it)
     gather_every = max(1, min(gather_every, steps))
@@ -279,6 +279,23 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
 
   for i in range(warmup):
     one_step(i)
+  # Settle: whatever --warmup was, the timed window opens only after at least 50 ms of GPU
+  # time in this process and on these buffers (a side measurement that starts right after
+  # empty_cache() and a new game otherwise reads several per cent low: round 2's sokoban
+  # read 0.790 of peak in the driver's run against 0.859 in its profile).  Untimed; the
+  # count is reported as config.settle_launches; `steps` / `warmup` stay as given.
+  settle = 0
+  if on_gpu:
+    probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    probe[0].record()
+    for i in range(4):
+      one_step(warmup + i)
+    probe[1].record()
+    probe[1].synchronize()
+    per = max(probe[0].elapsed_time(probe[1]) / 4, 1e-3)
+    settle = 4 + int(min(5000, max(0, 50.0 / per - 4)) + 0.999)
+    for i in range(4, settle):
+      one_step(warmup + i)
   gc.collect()                        # (before the fence: the chip should not idle longer than it must)
   gc.disable()                        # no collector pause between two launches of the timed region
   fence()
@@ -295,13 +312,16 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     log.wait()
   fence()
   elapsed = time.perf_counter() - t0
+  own_elapsed = elapsed               # this rank's; `elapsed` becomes the max over ranks
   gc.enable()
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-  result = dict(fused=fused, elapsed=elapsed, log=log, out=out, pipelined=pipelined,
+  result = dict(fused=fused, elapsed=elapsed, own_elapsed=own_elapsed, log=log, out=out,
+                pipelined=pipelined, settle=settle,
+                gather_every=gather_every if log is not None else None,
                 mean_return=float(out['reward'].sum(0).mean())
                 if out['reward'] is not None else None)
   if on_gpu:
@@ -407,24 +427,38 @@ def run_rank(args):
     device = torch.device('cpu')
   else:
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
+    if local_rank >= torch.cuda.device_count():
+      raise SystemExit('bench.py: rank {} wants GPU {} but this node shows {} HIP device(s)'
+                       .format(rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-  dist = None
-  if world > 1 or args.force_dist:
+  # Every run - one rank too - goes through the process group and the episode-return log,
+  # so that the N = 1 line times the same protocol as the ranks of an N > 1 run (the driver
+  # computes scaling efficiency from those lines).
+  dist, group_note = None, None
+  if world > 1 or args.force_dist or standin is None:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', str(_free_port()))
-    if standin is not None:
-      dist.init_process_group('gloo', rank=rank, world_size=world)
-    else:
-      dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
-    world = dist.get_world_size()      # as the process group reports it
+    try:
+      if standin is not None:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+      else:
+        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+      world = dist.get_world_size()      # as the process group reports it
+    except Exception as e:               # noqa: BLE001 - one rank can do without
+      if world > 1 or args.force_dist:
+        raise
+      group_note = 'RCCL process group could not be initialised ({}: {}); the episode-' \
+                   'return log is copied locally instead of all-gathered'.format(
+                       type(e).__name__, str(e)[:120])
+      dist = None
 
   name, default_batch = WORKLOADS[args.game]
   B = args.batch or default_batch
   T = args.frames
   m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
-                      args.gather_every, standin, args.pipeline)
+                      args.gather_every, standin, args.pipeline, with_log=True)
   fused, elapsed = m['fused'], m['elapsed']
 
   gathered_ok = None
@@ -433,6 +467,20 @@ def run_rank(args):
     if block is not None:
       mine = m['log'].last_local_block()
       gathered_ok = bool(block.shape[0] == world and torch.equal(block[rank], mine))
+  # per-rank figures for whoever reads the line: a straggler, or a rank whose part of the
+  # gathered log is wrong, shows here and not only in the max / the all()
+  per_rank_ms = [m['own_elapsed'] / args.steps * 1e3]
+  per_rank_ok = [gathered_ok]
+  if dist is not None:
+    mine = torch.tensor([m['own_elapsed'] / args.steps * 1e3,
+                         -1.0 if gathered_ok is None else float(gathered_ok)],
+                        dtype=torch.float64, device=device)
+    everyone = torch.zeros((world, 2), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(everyone.view(-1), mine)
+    everyone = everyone.cpu()
+    per_rank_ms = [float(x) for x in everyone[:, 0]]
+    per_rank_ok = [None if x < 0 else bool(x) for x in everyone[:, 1]]
+    gathered_ok = None if any(x is None for x in per_rank_ok) else all(per_rank_ok)
 
   if rank == 0 and args.episode_csv and m['log'] is not None:
     block = m['log'].wait()
@@ -469,18 +517,23 @@ def run_rank(args):
             'pipelined': m['pipelined'],
             'parallelism': 'env-sharded x{}, {} all-gather of the episode-'
                            'return log every {} episodes, off the step path'
-                           .format(world, 'gloo' if standin else 'RCCL',
-                                   max(1, min(args.gather_every, args.steps)))
-                           if dist is not None else 'single GPU',
+                           .format(world, 'gloo' if standin else 'RCCL', m['gather_every'])
+                           if dist is not None else
+                           'single GPU, no process group: ' + str(group_note),
             'world': world,
+            'rccl_world': world if (dist is not None and standin is None) else None,
+            'gather_every': m['gather_every'],
+            'settle_launches': m['settle'],
+            'per_rank_ms_per_step': per_rank_ms,
             'gathered_log_matches_local': gathered_ok,
+            'per_rank_gathered_log_matches_local': per_rank_ok,
             'mean_episode_return': m['mean_return'],
         },
     }
     if standin is None:
       line['roofline'] = roofline(args.game, B, T, fused, m['kernel_ms'],
                                   m['per_launch_ms'])
-    solo = world == 1 and standin is None and dist is None
+    solo = world == 1 and standin is None and not args.force_dist
     if solo and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds)
       line['cpu_baseline']['generic_b1'] = generic_b1()
@@ -505,8 +558,11 @@ def run_rank(args):
                 oname, ob, T),
             'value': ob * T * steps / om['elapsed'], 'unit': 'env-steps/s',
             'steps': steps, 'ms_per_step': om['elapsed'] / steps * 1e3,
+            'settle_launches': om['settle'],
             'roofline': roofline(other, ob, T, om['fused'], om['kernel_ms'],
-                                 om['per_launch_ms'])})
+                                 om['per_launch_ms']),
+            'cpu_baseline': None if args.no_cpu_baseline else
+                            cpu_baseline(other, T, args.cpu_seconds / 2, batch=ob)})
         del om
         torch.cuda.empty_cache()
       line['also'] = also
@@ -519,6 +575,13 @@ def run_rank(args):
 def main(argv=None):
   argv = sys.argv[1:] if argv is None else argv
   args = parse_args(argv)
+  if args.gpus > 1 and not args.standin:
+    import torch     # (counting devices does not initialise the GPU)
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+      sys.stderr.write('bench.py: --gpus {} asked for, but this node shows {} HIP device(s); '
+                       'nothing was launched\n'.format(args.gpus, have))
+      return 2
   if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_dist):
     # Not under a launcher yet: become one.  No GPU call has happened in this process.
     return launch_ranks(args.gpus, argv)

@@ -44,6 +44,12 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line(tmp_path):
   assert abs(line['value'] - 128 * 20 * 3 / (line['ms_per_step'] * 3e-3)) < 1e-6 * line['value']
   assert line['config']['gathered_log_matches_local'] is True
   assert 'DRY RUN' in line['data'] and line['cpu_baseline'] is None
+  # per-rank figures: one entry per rank, the line's time is their maximum
+  per_rank = line['config']['per_rank_ms_per_step']
+  assert len(per_rank) == 2 and abs(max(per_rank) - line['ms_per_step']) < 1e-6 * line['ms_per_step']
+  assert line['config']['per_rank_gathered_log_matches_local'] == [True, True]
+  assert line['config']['rccl_world'] is None          # gloo stand-in: no RCCL in this run
+  assert line['config']['gather_every'] == 2 and line['config']['settle_launches'] == 0
 
 
 def test_force_dist_goes_through_the_launcher_with_one_rank():
@@ -73,3 +79,30 @@ def test_gpus_8_the_baseline_config_5_shape():
   assert line['config']['global_batch'] == 8 * 32
   assert line['config']['gathered_log_matches_local'] is True
   assert abs(line['value'] - 8 * 32 * 8 * 2 / (line['ms_per_step'] * 2e-3)) < 1e-6 * line['value']
+  per_rank = line['config']['per_rank_ms_per_step']
+  assert len(per_rank) == 8 and all(t > 0 for t in per_rank)
+  assert abs(max(per_rank) - line['ms_per_step']) < 1e-6 * line['ms_per_step']
+  assert line['config']['per_rank_gathered_log_matches_local'] == [True] * 8
+  assert line['config']['gather_every'] == 1           # the clamp: never rarer than the run
+
+
+def test_one_rank_times_the_same_protocol_as_the_ranks_of_a_sharded_run():
+  """`--gpus 1`: the episode-return log and its gather are part of the step here too."""
+  r = _run(['--gpus', '1', '--steps', '4', '--warmup', '0', '--batch', '32', '--frames', '10',
+            '--gather-every', '64', '--standin', 'bench_standin:make'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  assert line['n_gpus'] == 1 and line['config']['gather_every'] == 4      # clamped to --steps
+  assert line['config']['gathered_log_matches_local'] is True
+  assert line['config']['per_rank_ms_per_step'] == [line['ms_per_step']]
+
+
+def test_more_gpus_than_the_node_has_fails_fast_with_a_clear_message():
+  """(no HIP device in the build container: 2 > 0)"""
+  import torch
+  if torch.cuda.device_count() >= 2:
+    return
+  r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'])
+  assert r.returncode == 2
+  assert '--gpus 2 asked for' in r.stderr and 'nothing was launched' in r.stderr
+  assert not r.stdout.strip()

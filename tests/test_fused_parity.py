@@ -290,10 +290,13 @@ def _check_full_size(game, og_factory, actions):
 
 @pytest.mark.parametrize('name,batch,T', [('boat_race', 65536, 100),
                                           ('wall_world', 262144, 100),
-                                          ('sokoban', 131072, 100)])
+                                          ('sokoban', 131072, 100),
+                                          ('boat_race', 524288, 100)])
 def test_full_size_vs_oracle(name, batch, T):
   """The three single-GPU BASELINE.json configurations at their full batch and the
-  100-frame episode the bench times."""
+  100-frame episode the bench times - and config 5's GLOBAL batch (524 288 = 8 x 65 536
+  environments) on one GPU: what the eight shards compute together, here in one piece
+  (its 52 MB trace plane also takes the launch through the chunked path)."""
   rng = np.random.RandomState(1234)
   actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
   game, _ = _fused(name, batch)
