@@ -415,6 +415,13 @@ def play_mode(device, B=65536, calls=2000):
 
 
 def run_rank(args):
+  # stdout carries ONE line, rank 0's JSON.  Libraries print there too (RCCL writes a version
+  # banner through C stdio, flushed whenever it likes - it came out AFTER the JSON line in a
+  # first run), so file descriptor 1 is pointed at stderr for the life of the rank and the
+  # line goes to a private duplicate of the real stdout at the very end.
+  sys.stdout.flush()
+  real_stdout = os.fdopen(os.dup(1), 'w')
+  os.dup2(2, 1)
   import torch
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -566,10 +573,13 @@ def run_rank(args):
         del om
         torch.cuda.empty_cache()
       line['also'] = also
-    print(json.dumps(line), flush=True)
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()
+  if rank == 0:
+    real_stdout.write(json.dumps(line) + '\n')
+    real_stdout.flush()
+  real_stdout.close()
 
 
 def main(argv=None):

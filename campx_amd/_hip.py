@@ -41,7 +41,8 @@ class CampxOutputs(ctypes.Structure):
               ('reward', ctypes.c_void_p), ('discount', ctypes.c_void_p),
               ('done', ctypes.c_void_p), ('perf', ctypes.c_void_p),
               ('trace', ctypes.c_void_p), ('obs_format', ctypes.c_int32),
-              ('bad_count', ctypes.c_void_p), ('bad_flag', ctypes.c_void_p)]
+              ('bad_count', ctypes.c_void_p), ('bad_flag', ctypes.c_void_p),
+              ('scalar_pitch', ctypes.c_int64)]
 
 
 class CampxError(RuntimeError):

@@ -134,20 +134,24 @@ bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T)
 int32_t launch_renders(const CampxSpec& s, const CampxSpec* spec_dev, CampxOutputs out, int64_t B,
                        int32_t T, int64_t plane_rows, hipStream_t stream) {
   const uint8_t* first = out.trace;
+  const int64_t pitch = row_pitch(out, B);
   if (last_frame_only(out)) {
-    first += (int64_t)(T - 1) * B;
+    first += (int64_t)(T - 1) * pitch;
     T = 1;
   }
-  int32_t rc = launch_render(s, spec_dev, first, out.obs, B, T, plane_rows, false, out.obs_format, stream);
+  int32_t rc = launch_render(s, spec_dev, first, out.obs, B, T, plane_rows, pitch, false,
+                             out.obs_format, stream);
   if (rc != CAMPX_OK) return rc;
-  if (out.board) rc = launch_render(s, spec_dev, first, out.board, B, T, plane_rows, true, 0, stream);
+  if (out.board)
+    rc = launch_render(s, spec_dev, first, out.board, B, T, plane_rows, pitch, true, 0, stream);
   return rc;
 }
 
 int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                      const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                      int32_t reset_first, bool use_table, hipStream_t stream) {
-  const int64_t plane = (int64_t)T * B;
+  const int64_t pitch = row_pitch(out, B);
+  const int64_t plane = (int64_t)T * pitch;
   // The render kernel runs at the write ceiling only while the trace it reads stays cached
   // (boat race, B = 65 536: 6.96 TB/s with a 26 MB trace at T = 400, 5.35 TB/s with 65 MB at
   // T = 1 000; the same at B = 524 288, T = 100): run long launches as chunks of frames,
@@ -174,11 +178,11 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
     CampxOutputs part = out;
     part.obs = out.obs + t0 * out.obs_t_stride * elem;
     if (out.board) part.board = out.board + t0 * out.board_t_stride;
-    if (out.reward) part.reward = out.reward + t0 * B;
-    if (out.discount) part.discount = out.discount + t0 * B;
-    if (out.done) part.done = out.done + t0 * B;
-    if (out.perf) part.perf = out.perf + t0 * B;
-    part.trace = out.trace + t0 * B;
+    if (out.reward) part.reward = out.reward + t0 * pitch;
+    if (out.discount) part.discount = out.discount + t0 * pitch;
+    if (out.done) part.done = out.done + t0 * pitch;
+    if (out.perf) part.perf = out.perf + t0 * pitch;
+    part.trace = out.trace + t0 * pitch;
     int32_t rc = launch_update(s, spec_dev, st, actions + t0 * B, part, B, n,
                                t0 == 0 ? reset_first : 0, use_table, plane, stream);
     if (rc != CAMPX_OK) return rc;
@@ -197,6 +201,7 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   if (out.perf && spec_host->perf_dyn < 0) return CAMPX_EINVAL;
   if (reinterpret_cast<uintptr_t>(out.obs) & 15) return CAMPX_EINVAL;
   if (B > (int64_t)0x7fffffff * 16) return CAMPX_EINVAL;
+  if (out.scalar_pitch && out.scalar_pitch < B) return CAMPX_EINVAL;
   const int32_t v = campx_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
   if (lds_bytes(*spec_host, out.board != nullptr, kWave) + 8 * 1024 > kLdsPerWorkgroup) return CAMPX_ESPEC;
@@ -590,8 +595,9 @@ int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   if (!spec_host->render_valid) return CAMPX_ESPEC;
   const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
                          (!knob_no_table() || spec_host->table_only);
+  if (out.scalar_pitch && out.scalar_pitch < B) return CAMPX_EINVAL;
   return launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
-                       (int64_t)T * B, static_cast<hipStream_t>(stream));
+                       (int64_t)T * row_pitch(out, B), static_cast<hipStream_t>(stream));
 }
 
 int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxOutputs out,
@@ -604,7 +610,9 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   if (v != CAMPX_OK) return v;
   CampxOutputs probe = out;   // the conditions of the two-kernel path, frames back to back
   if (!split_ok(*spec_host, probe, B, T)) return CAMPX_EINVAL;
-  return launch_renders(*spec_host, spec_dev, out, B, T, (int64_t)T * B, static_cast<hipStream_t>(stream));
+  if (out.scalar_pitch && out.scalar_pitch < B) return CAMPX_EINVAL;
+  return launch_renders(*spec_host, spec_dev, out, B, T, (int64_t)T * row_pitch(out, B),
+                        static_cast<hipStream_t>(stream));
 }
 
 const char* campx_strerror(int32_t code) {

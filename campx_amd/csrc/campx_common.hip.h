@@ -125,6 +125,17 @@ __device__ __forceinline__ int class_progress(int from, int to, int n) {
   return (to == fwd) - (to == back);
 }
 
+// Row pitch of the per-frame scalar streams and the trace (CampxOutputs.scalar_pitch), and
+// the extent of a row that may be written: with a pitch that leaves room for it the batch's
+// last 16-element group is stored whole (into the pad) instead of element by element.
+__host__ __device__ __forceinline__ int64_t row_pitch(const CampxOutputs& out, int64_t B) {
+  return out.scalar_pitch ? out.scalar_pitch : B;
+}
+__host__ __device__ __forceinline__ int64_t row_extent(const CampxOutputs& out, int64_t B) {
+  const int64_t up = (B + 15) & ~(int64_t)15;
+  return (out.scalar_pitch >= up) ? up : B;
+}
+
 // What a frame's reward adds to the running return: a frame nobody rewarded reports None
 // (NaN, campx/plot.py:208-211) and adds nothing.
 __device__ __forceinline__ float real_reward(float r) { return r == r ? r : 0.0f; }
@@ -485,8 +496,8 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
 
 // k_render.hip: the observation stream of the two-kernel path
 int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
-                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, bool is_board,
-                      int fmt, hipStream_t stream);
+                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, int64_t pitch,
+                      bool is_board, int fmt, hipStream_t stream);
 
 }  // namespace campx_impl
 

@@ -70,6 +70,43 @@ void want(const Tensor& t, const char* name, at::ScalarType dtype, const c10::De
               t.sizes());
 }
 
+// The per-frame scalar streams [T, B] and the trace [K, T, B] may be PADDED: contiguous
+// within a row, rows `pitch` >= B elements apart, the same pitch for every stream of a call
+// (the planes of the trace then T * pitch apart).  rollout_buffers() pads to a multiple of
+// 16 when the batch size is not one, so that every row starts aligned
+// (CampxOutputs.scalar_pitch).  `pitch` is 0 until the first stream has been seen.
+void want_rows(const Tensor& t, const char* name, at::ScalarType dtype, const c10::Device& dev,
+               int64_t T, int64_t B, int64_t& pitch) {
+  TORCH_CHECK(t.device() == dev, "campx: ", name, " must be on ", dev, ", it is on ", t.device());
+  TORCH_CHECK(t.scalar_type() == dtype, "campx: ", name, " must be ", dtype, ", it is ",
+              t.scalar_type());
+  TORCH_CHECK(t.dim() == 2 && t.size(0) == T && t.size(1) == B, "campx: ", name,
+              " must have shape [", T, ", ", B, "], it has ", t.sizes());
+  TORCH_CHECK(B == 1 || t.stride(1) == 1, "campx: ", name, " must be contiguous within a row");
+  if (T == 1) return;            // one row: its pitch is never used
+  const int64_t p = t.stride(0);
+  TORCH_CHECK(p >= B && (pitch == 0 || p == pitch), "campx: ", name, " has row pitch ", p,
+              "; every per-frame stream of a call must have the same pitch >= B");
+  pitch = p;
+}
+
+// (call it before want_rows: with one frame only the planes of the trace tell the pitch)
+void want_trace(const Tensor& t, const c10::Device& dev, int64_t K, int64_t T, int64_t B,
+                int64_t& pitch) {
+  TORCH_CHECK(t.device() == dev && t.scalar_type() == at::kByte && t.dim() == 3 &&
+                  t.size(0) == K && t.size(1) == T && t.size(2) == B,
+              "campx: trace must be uint8 [", K, ", ", T, ", ", B, "] on ", dev);
+  TORCH_CHECK(B == 1 || t.stride(2) == 1, "campx: trace must be contiguous within a row");
+  int64_t p = pitch;
+  if (T > 1) p = t.stride(1);
+  else if (K > 1) p = t.stride(0);
+  if (p == 0) return;            // one frame, one plane: nothing to tell
+  TORCH_CHECK(p >= B && (pitch == 0 || p == pitch) && (K == 1 || t.stride(0) == T * p),
+              "campx: trace must have the row pitch of the other per-frame streams and planes "
+              "T * pitch apart");
+  pitch = p;
+}
+
 template <typename T>
 T* opt_ptr(const OptTensor& t) {
   return t.has_value() ? reinterpret_cast<T*>(t->data_ptr()) : nullptr;
@@ -183,12 +220,14 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
     }
     out.board = opt_ptr<int8_t>(board);
   }
-  if (reward.has_value()) want(*reward, "reward", at::kFloat, g.dev, {T, g.B});
-  if (discount.has_value()) want(*discount, "discount", at::kFloat, g.dev, {T, g.B});
-  if (step_done.has_value()) want(*step_done, "step_done", at::kByte, g.dev, {T, g.B});
-  if (perf.has_value()) want(*perf, "perf", at::kChar, g.dev, {T, g.B});
-  if (trace.has_value()) want(*trace, "trace", at::kByte, g.dev, {g.K, T, g.B});
+  int64_t pitch = 0;
+  if (trace.has_value()) want_trace(*trace, g.dev, g.K, T, g.B, pitch);
+  if (reward.has_value()) want_rows(*reward, "reward", at::kFloat, g.dev, T, g.B, pitch);
+  if (discount.has_value()) want_rows(*discount, "discount", at::kFloat, g.dev, T, g.B, pitch);
+  if (step_done.has_value()) want_rows(*step_done, "step_done", at::kByte, g.dev, T, g.B, pitch);
+  if (perf.has_value()) want_rows(*perf, "perf", at::kChar, g.dev, T, g.B, pitch);
   if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
+  out.scalar_pitch = pitch;
   out.reward = opt_ptr<float>(reward);
   out.discount = opt_ptr<float>(discount);
   out.done = opt_ptr<uint8_t>(step_done);
@@ -215,13 +254,15 @@ void update(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor
   const int64_t T = actions.size(0);
   TORCH_CHECK(T >= 1 && T <= 0x7fffffff, "campx::update: bad frame count");
   want(actions, "actions", at::kChar, g.dev, {T, g.B});
-  want(trace, "trace", at::kByte, g.dev, {g.K, T, g.B});
-  if (reward.has_value()) want(*reward, "reward", at::kFloat, g.dev, {T, g.B});
-  if (discount.has_value()) want(*discount, "discount", at::kFloat, g.dev, {T, g.B});
-  if (step_done.has_value()) want(*step_done, "step_done", at::kByte, g.dev, {T, g.B});
-  if (perf.has_value()) want(*perf, "perf", at::kChar, g.dev, {T, g.B});
+  int64_t pitch = 0;
+  want_trace(trace, g.dev, g.K, T, g.B, pitch);
+  if (reward.has_value()) want_rows(*reward, "reward", at::kFloat, g.dev, T, g.B, pitch);
+  if (discount.has_value()) want_rows(*discount, "discount", at::kFloat, g.dev, T, g.B, pitch);
+  if (step_done.has_value()) want_rows(*step_done, "step_done", at::kByte, g.dev, T, g.B, pitch);
+  if (perf.has_value()) want_rows(*perf, "perf", at::kChar, g.dev, T, g.B, pitch);
   if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
   CampxOutputs out{};
+  out.scalar_pitch = pitch;
   out.reward = opt_ptr<float>(reward);
   out.discount = opt_ptr<float>(discount);
   out.done = opt_ptr<uint8_t>(step_done);
@@ -243,11 +284,13 @@ void render(const Tensor& spec_host, const Tensor& spec_dev, const Tensor& trace
   TORCH_CHECK(trace.device().is_cuda() && trace.dim() == 3, "campx::render: trace must be a HIP uint8 [K, T, B] tensor");
   const c10::Device dev = trace.device();
   const int64_t K = hs->n_dyn, T = trace.size(1), B = trace.size(2);
-  want(trace, "trace", at::kByte, dev, {K, T, B});
+  int64_t pitch = 0;
+  want_trace(trace, dev, K, T, B, pitch);
   TORCH_CHECK(spec_dev.device() == dev && spec_dev.scalar_type() == at::kByte &&
                   spec_dev.is_contiguous() && spec_dev.numel() == (int64_t)sizeof(CampxSpec),
               "campx: spec_dev must be the CampxSpec blob as a uint8 tensor on ", dev);
   CampxOutputs out{};
+  out.scalar_pitch = pitch;
   out.obs_format = obs_format_of(obs);
   want(obs, "obs", obs.scalar_type(), dev, {T, B, hs->n_layers, hs->rows, hs->cols});
   out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     ret += real_reward(reward);
     if (out.perf && rb.perf_dyn >= 0 && live) {
       const int perf_to = sel<K>(pos.cell, rb.perf_dyn);
-      out.perf[(int64_t)t * B + env] =
+      out.perf[(int64_t)t * row_pitch(out, B) + env] =
           (int8_t)class_progress(cell_class[perf_from], cell_class[perf_to], rb.perf_n);
     }
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
         for (int k = 0; k < K; ++k) {
           const int cell = sel<K>(pos.cell, k);
           const uint32_t vis = shown_layer<K>(rb, tab, W, cell, pos) == rb.dyn_layer[k];
-          out.trace[(int64_t)k * trace_plane + (int64_t)t * B + env] = pack_trace(cell, vis);
+          out.trace[(int64_t)k * trace_plane + (int64_t)t * row_pitch(out, B) + env] = pack_trace(cell, vis);
         }
       }
     } else {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     }
 
     if (live) {
-      const int64_t at = (int64_t)t * B + env;
+      const int64_t at = (int64_t)t * row_pitch(out, B) + env;
       if (out.reward) out.reward[at] = reward;
       if (out.discount) out.discount[at] = discount;
       if (out.done) out.done[at] = (uint8_t)over;
@@ -282,7 +282,7 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   CAMPX_ALLOW_LDS((rollout_kernel<K, BOARD, NT, ENVS, false>), shmem);                       \
   hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
                      rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd(), \
-                     (int64_t)T * B)
+                     (int64_t)T * row_pitch(out, B))
 #define CAMPX_LAUNCH(BOARD, NT) do { CAMPX_LAUNCH_E(BOARD, NT, 64); } while (0)
   if (board) {
     if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);

@@ -23,6 +23,7 @@ struct RenderParams {
   uint32_t shift_base, shift_slab;  // (address of frame 0) and slab_bytes modulo the window span
   int32_t n_dyn, is_board, cells;
   int64_t B;
+  int64_t pitch;              // rows of the trace from one frame to the next (B unless padded)
   int32_t dyn_char[CAMPX_MAX_DYN];
   int32_t dyn_off[CAMPX_MAX_DYN];   // byte offset of moving thing d's layer inside a row
 };
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   const int pitch = ((R + 15) & ~15) + 16;
   const int8_t* rot = kBoard ? spec->rot_board : spec->rot_obs;
   constexpr int P = kBoard ? K : 2 * K;                // patches per row
-  const uint8_t* frame_trace = trace + (int64_t)blockIdx.y * rp.B;
+  const uint8_t* frame_trace = trace + (int64_t)blockIdx.y * rp.pitch;
+  // (kOdd: a chunk that straddles two frames asks for "row B" = row 0 of the next frame)
+  auto trace_row = [&](uint32_t row) -> int64_t {
+    return (int64_t)row < rp.B ? (int64_t)row : (int64_t)row - rp.B + rp.pitch;
+  };
 
   // ---- patches: (row overlapping the windows) x (moving thing) x (set | clear).
   // Their trace bytes come from HBM / L2: issue those loads first.
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
     const int d = kBoard ? p : (p >> 1);
     uint32_t row = first_row + (uint32_t)r;
     row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
-    ent[it] = (it == 0 || slots > kWave) ? frame_trace[(int64_t)d * n_rows + row] : 0u;
+    ent[it] = (it == 0 || slots > kWave) ? frame_trace[(int64_t)d * n_rows + trace_row(row)] : 0u;
   }
 
   // ---- scenery: issue all loads, then park them in LDS
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   for (int sidx = lane + kMaxIter * kWave; sidx < slots; sidx += kWave) {   // tiny rows only
     const int r = sidx / P, p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
-    apply(sidx, frame_trace[(int64_t)d * n_rows + first_row + (uint32_t)r]);
+    apply(sidx, frame_trace[(int64_t)d * n_rows + trace_row(first_row + (uint32_t)r)]);
   }
 
   // ---- out: aligned, contiguous KiB stores
@@ -251,8 +256,8 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
 // distance (in rows = environments) between two moving things' planes of the trace, i.e.
 // B times the number of frames the trace holds.
 int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
-                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, bool is_board,
-                      int fmt, hipStream_t stream) {
+                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, int64_t pitch,
+                      bool is_board, int fmt, hipStream_t stream) {
   const int HW = s.rows * s.cols;
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
@@ -267,6 +272,7 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   rp.n_dyn = s.n_dyn;
   rp.is_board = is_board ? 1 : 0;
   rp.B = B;
+  rp.pitch = pitch;
   rp.cells = HW;
   for (int d = 0; d < s.n_dyn; ++d) {
     rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];

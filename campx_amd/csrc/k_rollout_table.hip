@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
                         n_live * HW, lane);
     }
     if (live) {
-      const int64_t at = (int64_t)t * B + env;
+      const int64_t at = (int64_t)t * row_pitch(out, B) + env;
       if (out.reward) out.reward[at] = reward;
       if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
       if (out.done) out.done[at] = (uint8_t)over;

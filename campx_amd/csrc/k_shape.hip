@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
       if (slot_lane == kWave - 1 || t == T - 1) {
         const int t0 = t - slot_lane;
         if (lane <= slot_lane) {
-          const int64_t at = (int64_t)(t0 + lane) * B + env;
+          const int64_t at = (int64_t)(t0 + lane) * row_pitch(out, B) + env;
           const uint32_t ended = (uint32_t)(over_mask >> lane) & 1u;
           if (out.reward) out.reward[at] = __uint_as_float((uint32_t)reward_buf);
           if (out.discount) out.discount[at] = ended ? 0.0f : 1.0f;

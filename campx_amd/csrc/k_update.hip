@@ -77,18 +77,20 @@ struct ActionLoader {
   u32x4 pend[2 * kPairs];
 
   // 16-byte loads (byte-aligned unless B % 16 == 0: unaligned 16-byte accesses are legal on
-  // this stack, tools/probes/unaligned_probe.hip); rows past T and groups of 16 environments
-  // that are not wholly below B are clamped to valid ones (no branch between the loads) and
-  // redone or neutralised in land().
+  // this stack, tools/probes/unaligned_probe.hip), no branch between them.  Rows past T are
+  // clamped to the last row and neutralised in land().  The batch's last, PARTIAL group of
+  // 16 environments is loaded like any other - its upper bytes are then the first
+  // environments of the next row, masked to "stay" in land() - except where that would read
+  // past the buffer's T * B bytes (the last row: a C-ABI caller may have allocated exactly
+  // that): there the load moves back to the buffer's last 16 bytes and land() shifts the
+  // wanted bytes down.  (Until round 3 the partial group went byte by byte: one lane's chain
+  // of thirty dependent loads per chunk, 20 us on top of every launch whose batch size is
+  // not a multiple of 16.)
   // `lane` counts over all loader waves: 0 .. kLanes-1
   __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
                                         int t0, int64_t env0, int lane) {
-    // Clamped loads must stay inside the buffer's T * B bytes too (a C-ABI caller may have
-    // allocated exactly that): a batch of fewer than 16 environments has no whole group of
-    // 16 - land() takes all of it byte by byte - and its clamped loads read the buffer's
-    // last 16 bytes, or nothing at all when the whole buffer is shorter than that.
     const int64_t last = (int64_t)T * B - 16;
-    if (last < 0) {   // uniform
+    if (last < 0) {   // uniform: a buffer shorter than one load; land() reads it byte by byte
 #pragma unroll
       for (int i = 0; i < 2 * kPairs; ++i) pend[i] = u32x4{0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
       return;
@@ -98,61 +100,93 @@ struct ActionLoader {
       const int v = lane + i * kLanes;
       const int rp = v / kVecPerRow, q = v % kVecPerRow;
       int64_t e = env0 + 16 * q;
-      e = e + 16 <= B ? e : 0;
+      e = e < B ? e : 0;               // a group wholly past the batch: any valid address
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int row = t0 + 2 * rp + h;
         row = row < T ? row : T - 1;
         int64_t at = (int64_t)row * B + e;
-        at = at <= last ? at : last;   // (only ever changes a clamped, ignored load)
+        at = at <= last ? at : last;
         pend[2 * i + h] = *reinterpret_cast<const u32x4*>(actions + at);
       }
     }
   }
 
+  // v shifted down by `bytes` (0..15) bytes, "stay" ids shifted in at the top
+  static __device__ __forceinline__ u32x4 shift_down(u32x4 v, uint32_t bytes) {
+    const uint32_t w[5] = {v.x, v.y, v.z, v.w, 0x04040404u};
+    const uint32_t dw = bytes >> 2, sub = bytes & 3u;
+    uint32_t x[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      uint32_t t = 0x04040404u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t = (dw == (uint32_t)k && i + k < 5) ? w[i + k < 5 ? i + k : 4] : t;
+      x[i] = t;
+    }
+    u32x4 r;
+    r.x = __builtin_amdgcn_alignbyte(x[1], x[0], sub);
+    r.y = __builtin_amdgcn_alignbyte(x[2], x[1], sub);
+    r.z = __builtin_amdgcn_alignbyte(x[3], x[2], sub);
+    r.w = __builtin_amdgcn_alignbyte(x[4], x[3], sub);
+    return r;
+  }
+
+  // bytes n .. 15 of v replaced by "stay"
+  static __device__ __forceinline__ u32x4 keep_low(u32x4 v, int n) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int have = n - 4 * i;                        // bytes of this dword that stay
+      const uint32_t m = have >= 4 ? 0xffffffffu : (have <= 0 ? 0u : (1u << (8 * have)) - 1u);
+      w[i] = (w[i] & m) | (0x04040404u & ~m);
+    }
+    return u32x4{w[0], w[1], w[2], w[3]};
+  }
+
   __device__ __forceinline__ int land(int8_t* staged, const int8_t* __restrict__ actions, int64_t B,
                                       int32_t T, int t0, int64_t env0, int lane) {
     int bad = 0;
+    const int64_t last = (int64_t)T * B - 16;
 #pragma unroll
     for (int i = 0; i < kPairs; ++i) {
       const int v = lane + i * kLanes;
       const int rp = v / kVecPerRow, q = v % kVecPerRow;
       const int64_t e = env0 + 16 * q;
-      const bool here = e + 16 <= B;
-      const bool real0 = here && (t0 + 2 * rp < T), real1 = here && (t0 + 2 * rp + 1 < T);
-      u32x4 lo = pend[2 * i], hi = pend[2 * i + 1];
-      if (!here && e < B) {
-        // the batch's last, partial group of environments (one lane of the last workgroup):
-        // byte by byte, "stay" past the end
-        uint32_t l[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
-        uint32_t h[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
-        for (int k = 0; e + k < B; ++k) {
-          const int sh = 8 * (k & 3);
-          if (t0 + 2 * rp < T) {
-            const uint32_t a = (uint8_t)actions[(int64_t)(t0 + 2 * rp) * B + e + k];
-            l[k >> 2] = (l[k >> 2] & ~(0xffu << sh)) | (a << sh);
-          }
-          if (t0 + 2 * rp + 1 < T) {
-            const uint32_t a = (uint8_t)actions[(int64_t)(t0 + 2 * rp + 1) * B + e + k];
-            h[k >> 2] = (h[k >> 2] & ~(0xffu << sh)) | (a << sh);
-          }
+      const int n_env = (B - e >= 16) ? 16 : (B - e <= 0 ? 0 : (int)(B - e));   // environments of the group
+      u32x4 both[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = t0 + 2 * rp + h;
+        u32x4 x = pend[2 * i + h];
+        if (last < 0) {
+          // (uniform) the whole buffer is shorter than one load: byte by byte
+          uint32_t w[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+          if (row < T)
+            for (int k = 0; k < n_env; ++k) {
+              const uint32_t a = (uint8_t)actions[(int64_t)row * B + e + k];
+              w[k >> 2] = (w[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (a << (8 * (k & 3)));
+            }
+          x = u32x4{w[0], w[1], w[2], w[3]};
+        } else if (n_env < 16 && n_env > 0) {
+          // the batch's partial group: where the load had to move back from the buffer's end,
+          // bring the wanted bytes down; then everything past the batch becomes "stay"
+          const int64_t at = (int64_t)(row < T ? row : T - 1) * B + e;
+          if (at > last) x = shift_down(x, (uint32_t)(at - last));
+          x = keep_low(x, n_env);
         }
-        uint32_t out[4];
-        for (int k = 0; k < 4; ++k) out[k] = clamp_ids(l[k]) | (clamp_ids(h[k]) << 4);
-        const u32x4 packed = {out[0], out[1], out[2], out[3]};
-        *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
-        const u32x4 l4 = {l[0], l[1], l[2], l[3]}, h4 = {h[0], h[1], h[2], h[3]};
-        bad += count_bad16(l4) + count_bad16(h4);
-        continue;
+        const bool real = row < T && n_env > 0;
+        if (!real) x = u32x4{0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+        bad += count_bad16(x);        // (neutralised bytes are 4: never counted)
+        both[h] = x;
       }
-      const uint32_t l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
+      const uint32_t l[4] = {both[0].x, both[0].y, both[0].z, both[0].w};
+      const uint32_t h4[4] = {both[1].x, both[1].y, both[1].z, both[1].w};
       uint32_t out[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        out[k] = (real0 ? clamp_ids(l[k]) : 0x04040404u) | ((real1 ? clamp_ids(h[k]) : 0x04040404u) << 4);
+      for (int k = 0; k < 4; ++k) out[k] = clamp_ids(l[k]) | (clamp_ids(h4[k]) << 4);
       const u32x4 packed = {out[0], out[1], out[2], out[3]};
       *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
-      bad += (real0 ? count_bad16(lo) : 0) + (real1 ? count_bad16(hi) : 0);
     }
     return bad;
   }
@@ -285,6 +319,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
       __syncthreads();
     }
   } else if (!loader) {
+    // rows of the output streams are P elements apart; Bv: how much of a row may be written
+    // (a padded pitch lets the batch's last group be stored whole, into the pad)
+    const int64_t P = row_pitch(out, B), Bv = row_extent(out, B);
     for (int g = 0; g <= n_groups; ++g) {
         if (g > 0) {
           const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
@@ -305,8 +342,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
               const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
                                       (y4.y >> 24) & 1u};
-              const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
+              const int64_t at = (int64_t)(t0 + j) * P + e0;
+              if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
                 if (out.reward) store16_update(out.reward + at, r4);
                 if (out.discount) {
                   const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
@@ -342,8 +379,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 pf[k] = pack4(((lo >> 9) & 3u) - 1u, ((lo >> 25) & 3u) - 1u, ((hi >> 9) & 3u) - 1u,
                               (((hi >> 25) & 3u) - 1u) & 0xffu);
               }
-              const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
+              const int64_t at = (int64_t)(t0 + j) * P + e0;
+              if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
                 const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
                 store16_update(out.trace + at, t4);
                 if (out.done) {
@@ -498,6 +535,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
       __syncthreads();
     }
   } else if (!loader) {
+    // rows of the output streams are P elements apart; Bv: how much of a row may be written
+    // (a padded pitch lets the batch's last group be stored whole, into the pad)
+    const int64_t P = row_pitch(out, B), Bv = row_extent(out, B);
     for (int g = 0; g <= n_groups; ++g) {
         if (g > 0) {
           const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
@@ -518,8 +558,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
                 dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
               }
-              const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
+              const int64_t at = (int64_t)(t0 + j) * P + e0;
+              if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
                 if (out.reward) {
                   const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
                   store16_update(out.reward + at, r4);
@@ -561,8 +601,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 dn[k] = pack4(d[0], d[1], d[2], d[3]);
                 pf[k] = pack4(p[0], p[1], p[2], p[3]);
               }
-              const int64_t at = (int64_t)(t0 + j) * B + e0;
-              if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
+              const int64_t at = (int64_t)(t0 + j) * P + e0;
+              if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
                 const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
                 store16_update(out.trace + at, a4);
                 store16_update(out.trace + plane + at, b4);
@@ -701,6 +741,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
       __syncthreads();
     }
   } else if (!loader) {
+    // rows of the output streams are P elements apart; Bv: how much of a row may be written
+    // (a padded pitch lets the batch's last group be stored whole, into the pad)
+    const int64_t P = row_pitch(out, B), Bv = row_extent(out, B);
     for (int g = 0; g <= n_groups; ++g) {
       if (g > 0) {
         const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
@@ -721,8 +764,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               rw[i] = __float_as_uint(reward_list[(hi >> 3) & 0xffu]);
               dc[i] = (hi & 1u) ? 0u : 0x3f800000u;
             }
-            const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (e0 + 4 <= B) {   // (dword-aligned; 16-byte aligned when B % 4 == 0)
+            const int64_t at = (int64_t)(t0 + j) * P + e0;
+            if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
               if (out.reward) {
                 const u32x4 r4 = {rw[0], rw[1], rw[2], rw[3]};
                 store16_update(out.reward + at, r4);
@@ -769,8 +812,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               pf[w] = pack4(((hi[0] >> 1) & 3u) - 1u, ((hi[1] >> 1) & 3u) - 1u,
                             ((hi[2] >> 1) & 3u) - 1u, (((hi[3] >> 1) & 3u) - 1u) & 0xffu);
             }
-            const int64_t at = (int64_t)(t0 + j) * B + e0;
-            if (e0 + 16 <= B) {  // (byte-aligned unless B % 16 == 0: unaligned stores are legal here)
+            const int64_t at = (int64_t)(t0 + j) * P + e0;
+            if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
 #pragma unroll
               for (int k = 0; k < K; ++k) {
                 const u32x4 t4 = {tr[k][0], tr[k][1], tr[k][2], tr[k][3]};

@@ -56,6 +56,9 @@ COMPILE_TABLE = True
 # the single fused kernel; parity tests run both.
 SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') != '0'
 FORCE_SPLIT = SPLIT_ROLLOUT   # kept for callers that toggled it: same as SPLIT_ROLLOUT now
+# Pad the rows of the per-frame streams to a multiple of 16 elements (see rollout_buffers).
+# CAMPX_ROW_PITCH=0 keeps them back to back: the A/B of tools/gpu_odd_ab.sh.
+PAD_ROWS = os.environ.get('CAMPX_ROW_PITCH', '1') != '0'
 
 _OBS_DTYPES = (torch.int8, torch.float16, torch.bfloat16)
 
@@ -333,16 +336,21 @@ class FusedGame(object):
                  if keep_obs else self._board)
     # The compact trajectory; giving it lets the library take its two-kernel path.
     split = SPLIT_ROLLOUT or sixteen
+    # The per-frame streams are [T, B] VIEWS of [T, pitch] arrays, pitch = B rounded up to a
+    # multiple of 16 (CampxOutputs.scalar_pitch): with a batch size that is not one, every
+    # row still starts 16-byte aligned and the update kernels store whole aligned groups
+    # (B = 65 535: 47 -> 16 us per 100 frames).  For B % 16 == 0 they are plain contiguous.
+    pitch = (B + 15) // 16 * 16 if PAD_ROWS else B
+
+    def rows(dtype, *lead):
+      return torch.empty(lead + (T, pitch), dtype=dtype, device=dev)[..., :B]
     return dict(
         obs=obs, board=board,
-        reward=(torch.empty((T, B), dtype=torch.float32, device=dev)
-                if self.any_reward else None),
-        discount=torch.empty((T, B), dtype=torch.float32, device=dev),
-        done=torch.empty((T, B), dtype=torch.uint8, device=dev),
-        perf=(torch.empty((T, B), dtype=torch.int8, device=dev)
-              if self.has_perf else None),
-        trace=(torch.empty((self.n_dyn, T, B), dtype=torch.uint8, device=dev)
-               if split else None))
+        reward=rows(torch.float32) if self.any_reward else None,
+        discount=rows(torch.float32),
+        done=rows(torch.uint8),
+        perf=rows(torch.int8) if self.has_perf else None,
+        trace=rows(torch.uint8, self.n_dyn) if split else None)
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True,
               reset_first=False, want_board=False, obs_dtype=torch.int8,

@@ -215,6 +215,17 @@ typedef struct CampxOutputs {
                          (hipHostMalloc): set to 1, by a plain system-scope store, when the
                          call consumed any id outside 0..4.  Lets a host poll for bad
                          actions without a stream synchronisation. */
+  int64_t scalar_pitch; /* elements from one frame's row to the next in reward, discount, done,
+                         perf and trace (the planes of `trace` are then T * scalar_pitch
+                         apart); 0 = B, rows back to back.  With a batch size that is not a
+                         multiple of 16 a row of a [T, B] array starts at any byte, and the
+                         update kernels' 16-byte stores are misaligned for most frames (legal,
+                         but 4.3 instead of 7 TB/s: 47 instead of 16 us per 100 frames at
+                         B = 65 535).  A caller can pad the arrays instead - [T, pitch] with
+                         pitch = B rounded up to a multiple of 16, the first B elements of a
+                         row used: every row then starts aligned and the kernels write whole
+                         16-byte groups (the pad holds unspecified values).  `actions` and the
+                         observation / board frames are never padded. */
 } CampxOutputs;
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */
