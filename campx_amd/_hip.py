@@ -26,7 +26,8 @@ EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
            'campx_shape_spec_size', 'campx_shape_spec_validate',
            'campx_shape_rollout_launch', 'campx_check_actions_launch',
-           'campx_onehot_to_ids_launch', 'campx_strerror',
+           'campx_onehot_to_ids_launch', 'campx_stream_create_cu_subset',
+           'campx_stream_destroy', 'campx_strerror',
            'campx_last_hip_error', 'campx_device_arch')
 
 
@@ -91,6 +92,10 @@ def _load():
   lib.campx_check_actions_launch.argtypes = [vp, i64, vp, vp]
   lib.campx_onehot_to_ids_launch.restype = i32
   lib.campx_onehot_to_ids_launch.argtypes = [vp, vp, i64, vp, vp]
+  lib.campx_stream_create_cu_subset.restype = i32
+  lib.campx_stream_create_cu_subset.argtypes = [i32, ctypes.POINTER(vp)]
+  lib.campx_stream_destroy.restype = i32
+  lib.campx_stream_destroy.argtypes = [vp]
   lib.campx_strerror.restype = ctypes.c_char_p
   lib.campx_strerror.argtypes = [i32]
   lib.campx_last_hip_error.restype = i32

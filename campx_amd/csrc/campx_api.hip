@@ -615,6 +615,36 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
                         static_cast<hipStream_t>(stream));
 }
 
+int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out) {
+  if (!stream_out) return CAMPX_EINVAL;
+  int dev = 0, cus = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return hip_failed(e);
+  if (n_cus < 1 || n_cus > cus) return CAMPX_EINVAL;
+  // bit i of the mask = compute unit i; every (cus / n_cus)-th one, so that the subset is
+  // spread over the XCDs and shader engines whatever their numbering
+  uint32_t mask[32];
+  memset(mask, 0, sizeof(mask));
+  const int words = (cus + 31) / 32;
+  if (words > 32) return CAMPX_EINVAL;
+  for (int k = 0; k < n_cus; ++k) {
+    const int cu = (int)(((int64_t)k * cus) / n_cus);
+    mask[cu >> 5] |= 1u << (cu & 31);
+  }
+  hipStream_t s = nullptr;
+  e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  if (e != hipSuccess) return hip_failed(e);
+  *stream_out = s;
+  return CAMPX_OK;
+}
+
+int32_t campx_stream_destroy(void* stream) {
+  if (!stream) return CAMPX_EINVAL;
+  const hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
 const char* campx_strerror(int32_t code) {
   switch (code) {
     case CAMPX_OK:

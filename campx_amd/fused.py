@@ -180,9 +180,23 @@ class FusedGame(object):
     self._aux = None
     self._aux_event = None
     self._aux_in_sync = False
+    self.aux_cus = int(os.environ.get('CAMPX_AUX_CUS', '0'))   # pipelined update passes: CU subset
     self._trace_readers = {}   # trace buffer address -> event after the render that read it
 
   # ------------------------------------------------------------------ helpers
+
+  def _side_stream(self):
+    """The stream of pipelined update passes: an ordinary one, or - `aux_cus = n` - one
+    confined to n compute units (campx_stream_create_cu_subset), so that the update pass
+    cannot take workgroup slots from the render kernel it runs under."""
+    if not self.aux_cus:
+      return torch.cuda.Stream(self.device)
+    raw = ctypes.c_void_p()
+    with torch.cuda.device(self.device):
+      _hip.check(_hip.lib.campx_stream_create_cu_subset(int(self.aux_cus), ctypes.byref(raw)),
+                 'campx_stream_create_cu_subset')
+    self._aux_raw = raw          # (lives as long as the game: destroyed with the process)
+    return torch.cuda.ExternalStream(raw.value, device=self.device)
 
   def _observation(self, obs, board):
     layers = {ch: obs[:, i] for i, ch in enumerate(self.chars)}
@@ -421,7 +435,7 @@ class FusedGame(object):
                          'keep_obs=True on a game whose update pass is tabulated)')
       main = torch.cuda.current_stream(self.device)
       if self._aux is None:
-        self._aux = torch.cuda.Stream(self.device)
+        self._aux = self._side_stream()
         self._aux_event = torch.cuda.Event()
       if not self._aux_in_sync:
         self._aux.wait_stream(main)      # once: state set up by earlier non-pipelined work

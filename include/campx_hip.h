@@ -411,6 +411,17 @@ int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* ba
 int32_t campx_onehot_to_ids_launch(const float* onehot, int8_t* ids, int64_t n,
                                    int32_t* bad_count, void* stream);
 
+/*
+ * A stream whose kernels may only run on `n_cus` of the device's compute units, spread evenly
+ * over the chip (hipExtStreamCreateWithCUMask).  For callers that overlap the short,
+ * latency-bound update pass of one launch with the observation stream of the previous one
+ * (campx_update_launch / campx_render_launch on two streams): confined to a few CUs the
+ * update pass cannot take workgroup slots from the render's blocks.  Destroy with
+ * campx_stream_destroy().  CAMPX_EINVAL unless 1 <= n_cus <= the device's CU count.
+ */
+int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out);
+int32_t campx_stream_destroy(void* stream);
+
 const char* campx_strerror(int32_t code);
 /* hipError_t of the most recent failed HIP call on this thread (0 if none). */
 int32_t campx_last_hip_error(void);
