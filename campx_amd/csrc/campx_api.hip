@@ -259,19 +259,24 @@ int32_t pack_state_table(const CampxSpec& spec, size_t n, const uint8_t* h_trace
       reward_bits[idx] = bits;
       h_table[idx] = h_reward[i];
     }
-    const uint32_t perf = (uint32_t)((spec.perf_dyn >= 0 && h_perf ? h_perf[i] : 0) + 1);
-    const uint32_t over = (uint32_t)(h_done[i] & 1);
+    const int pc = perf_code_of(spec, spec.perf_dyn >= 0 && h_perf ? h_perf[i] : 0);
+    if (pc < 0) return CAMPX_ESPEC;   // a value the spec's scale / offset cannot give
+    const uint32_t perf = (uint32_t)pc;
+    const uint32_t over = (uint32_t)(h_done[i] & 1), dcode = (uint32_t)(h_done[i] >> 4);
     if (K == 2) {
       const uint32_t ta = h_trace[i], tb = h_trace[n + i];
       h_entries32[i] = (ta & 0x7fu) | ((tb & 0x7fu) << 7) | ((ta >> 7) << 14) | ((tb >> 7) << 15) |
-                       (over << 16) | (perf << 17) | ((uint32_t)idx << 19);
+                       (over << 16) | ((perf & 3u) << 17) | ((uint32_t)idx << 19) | (dcode << 27) |
+                       ((perf >> 2) << 31);
     } else {
       uint32_t lo = 0;
       for (int d = 0; d < K; ++d) {
         const uint32_t tr = h_trace[(size_t)d * n + i];
         lo |= ((tr & 0x7fu) << (7 * d)) | ((tr >> 7) << (28 + d));
       }
-      h_entries64[i] = (uint64_t)lo | ((uint64_t)(over | (perf << 1) | ((uint32_t)idx << 3)) << 32);
+      const uint32_t hi = over | ((perf & 3u) << 1) | ((uint32_t)idx << 3) | ((perf >> 2) << 11) |
+                          (dcode << 12);
+      h_entries64[i] = (uint64_t)lo | ((uint64_t)hi << 32);
     }
   }
   return CAMPX_OK;
@@ -333,17 +338,31 @@ int32_t campx_spec_validate(const CampxSpec* s) {
     if (s->n_dyn == 1) {   // the host-filled transition table is the game
       if (!s->table_valid) return CAMPX_ESPEC;
       for (int i = 0; i < HW * CAMPX_N_ACTIONS; ++i)
-        if (s->table[i].next_cell >= HW || s->table[i].done > 1 ||
+        if (s->table[i].next_cell >= HW || (s->table[i].done & 0x0eu) ||
             (s->table[i].paint & 0x7fu) >= (uint32_t)s->n_layers)
           return CAMPX_ESPEC;
     }
   }
   if (s->perf_dyn < -1 || s->perf_dyn >= s->n_dyn) return CAMPX_ESPEC;
   if (s->perf_dyn >= 0) {
-    if (s->perf_n < 2 || s->perf_n > 255) return CAMPX_ESPEC;
-    for (int i = 0; i < HW; ++i)
-      if (s->cell_class[i] > s->perf_n) return CAMPX_ESPEC;
+    if (s->perf_scale == 0 || s->perf_scale < -16 || s->perf_scale > 16) return CAMPX_ESPEC;
+    if (s->perf_offset < -16 || s->perf_offset > 16) return CAMPX_ESPEC;
+    if (s->perf_mode == 0) {          // progress round a cycle of cell classes
+      if (s->perf_n < 2 || s->perf_n > 255) return CAMPX_ESPEC;
+      for (int i = 0; i < HW; ++i)
+        if (s->cell_class[i] > s->perf_n) return CAMPX_ESPEC;
+    } else if (s->perf_mode == 1) {   // penalty classes of where the things of perf_mask stand
+      if (s->perf_mask <= 0 || (s->perf_mask >> s->n_dyn)) return CAMPX_ESPEC;
+      int most = 0, things = 0;
+      for (int i = 0; i < HW; ++i) most = s->cell_class[i] > most ? s->cell_class[i] : most;
+      for (int d = 0; d < s->n_dyn; ++d) things += (s->perf_mask >> d) & 1;
+      if (most * things > 7) return CAMPX_ESPEC;   // the tables carry the sum in 3 bits
+    } else {
+      return CAMPX_ESPEC;
+    }
   }
+  for (int i = 1; i < 16; ++i)
+    if (!(s->discount_list[i] >= 0.0f && s->discount_list[i] <= 1.0f)) return CAMPX_ESPEC;
   return CAMPX_OK;
 }
 

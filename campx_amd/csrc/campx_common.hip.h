@@ -67,6 +67,7 @@ __device__ __forceinline__ void store16_streaming_at(const void* base, uint32_t 
 struct RuleBlock {
   int32_t rows, cols, n_layers, n_dyn, n_rules, any_reward;
   int32_t perf_dyn, perf_n;
+  int32_t perf_mode, perf_mask, perf_scale, perf_offset;
   int32_t dyn_layer[CAMPX_MAX_DYN];
   int32_t dyn_z[CAMPX_MAX_DYN];
   int32_t dyn_row0[CAMPX_MAX_DYN];
@@ -123,6 +124,59 @@ __device__ __forceinline__ int class_progress(int from, int to, int n) {
   const int fwd = (from == n) ? 1 : from + 1;
   const int back = (from == 1) ? n : from - 1;
   return (to == fwd) - (to == back);
+}
+
+// What the state tables say about a frame besides where things are: a 3-bit hidden-
+// performance code (value = scale * code + offset, CampxSpec.perf_*) and a 4-bit discount
+// code (0 = the default: 0.0 when the episode ended on the frame, else 1.0; otherwise an
+// index into CampxSpec.discount_list).  By value in the kernel arguments; the kernels copy
+// the discount list to LDS before indexing it with a lane's code.
+struct FrameCodec {
+  int32_t perf_scale, perf_offset;
+  int32_t has_dcodes;            // some entry of the game's table carries a discount code
+  float discounts[16];
+};
+
+inline FrameCodec make_codec(const CampxSpec& s) {
+  FrameCodec c;
+  memset(&c, 0, sizeof(c));
+  c.perf_scale = s.perf_scale;
+  c.perf_offset = s.perf_offset;
+  for (int i = 1; i < 16; ++i) {
+    c.discounts[i] = s.discount_list[i];
+    if (s.discount_list[i] != 0.0f) c.has_dcodes = 1;
+  }
+  c.has_dcodes = c.has_dcodes || s.table_only;   // (a listed discount may be 0.0 itself)
+  c.discounts[0] = 1.0f;
+  return c;
+}
+
+__device__ __forceinline__ uint32_t perf_byte(const FrameCodec& fc, uint32_t code) {
+  return (uint32_t)((int)code * fc.perf_scale + fc.perf_offset) & 0xffu;
+}
+
+// bits of a discount as a float: `list` is the LDS copy of FrameCodec.discounts
+__device__ __forceinline__ uint32_t discount_bits(const float* list, uint32_t dcode, uint32_t done) {
+  const uint32_t plain = done ? 0u : 0x3f800000u;
+  return dcode ? __float_as_uint(list[dcode]) : plain;
+}
+
+// the codes out of the upper half of an update_table_kernel LDS entry (y >> 16), of a pair
+// entry and of the high word of a tuple entry
+__device__ __forceinline__ uint32_t perf_code_y16(uint32_t y) { return ((y >> 9) & 3u) | ((y >> 13) & 4u); }
+__device__ __forceinline__ uint32_t dcode_y16(uint32_t y) { return (y >> 11) & 15u; }
+__device__ __forceinline__ uint32_t perf_code_pair(uint32_t e) { return ((e >> 17) & 3u) | ((e >> 29) & 4u); }
+__device__ __forceinline__ uint32_t dcode_pair(uint32_t e) { return (e >> 27) & 15u; }
+__device__ __forceinline__ uint32_t perf_code_tuple(uint32_t hi) { return ((hi >> 1) & 3u) | ((hi >> 9) & 4u); }
+__device__ __forceinline__ uint32_t dcode_tuple(uint32_t hi) { return (hi >> 12) & 15u; }
+
+// code of a perf VALUE (host side, when tables are packed); -1 if it is not one of the eight
+inline int perf_code_of(const CampxSpec& s, int value) {
+  if (s.perf_dyn < 0 || s.perf_scale == 0) return value == 0 ? 0 : -1;
+  const int d = value - s.perf_offset;
+  if (d % s.perf_scale) return -1;
+  const int c = d / s.perf_scale;
+  return (c >= 0 && c <= 7) ? c : -1;
 }
 
 // Row pitch of the per-frame scalar streams and the trace (CampxOutputs.scalar_pitch), and

@@ -176,9 +176,18 @@ __global__ __launch_bounds__(kWave) void rollout_kernel(RuleBlock rb,
     if (!rb.any_reward) reward = __builtin_nanf("");
     ret += real_reward(reward);
     if (out.perf && rb.perf_dyn >= 0 && live) {
-      const int perf_to = sel<K>(pos.cell, rb.perf_dyn);
+      int code;
+      if (rb.perf_mode == 0) {   // progress round the cycle of cell classes
+        const int perf_to = sel<K>(pos.cell, rb.perf_dyn);
+        code = class_progress(cell_class[perf_from], cell_class[perf_to], rb.perf_n) + 1;
+      } else {                   // penalty classes of where the watched things stand now
+        code = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          code += ((rb.perf_mask >> k) & 1) ? (int)cell_class[sel<K>(pos.cell, k)] : 0;
+      }
       out.perf[(int64_t)t * row_pitch(out, B) + env] =
-          (int8_t)class_progress(cell_class[perf_from], cell_class[perf_to], rb.perf_n);
+          (int8_t)(code * rb.perf_scale + rb.perf_offset);
     }
 
     if (kTrace) {
@@ -256,6 +265,10 @@ RuleBlock make_rule_block(const CampxSpec& s) {
   rb.any_reward = s.any_reward;
   rb.perf_dyn = s.perf_dyn;
   rb.perf_n = s.perf_n;
+  rb.perf_mode = s.perf_mode;
+  rb.perf_mask = s.perf_mask;
+  rb.perf_scale = s.perf_scale;
+  rb.perf_offset = s.perf_offset;
   memcpy(rb.dyn_layer, s.dyn_layer, sizeof(rb.dyn_layer));
   memcpy(rb.dyn_z, s.dyn_z, sizeof(rb.dyn_z));
   memcpy(rb.dyn_row0, s.dyn_row0, sizeof(rb.dyn_row0));

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     const CampxTransition tr = spec->table[i];
     table[i] = make_uint2(__float_as_uint(tr.reward),
                           (uint32_t)tr.next_cell | ((uint32_t)tr.done << 8) |
-                              ((uint32_t)(tr.perf + 1) << 16));
+                              ((uint32_t)(uint8_t)tr.perf << 16));   // (done: bit 0 + discount code)
   }
   for (int i = lane; i < HW; i += kWave) {
     // paint[cell]: byte offset (inside one environment's slice) of the scenery's own
@@ -134,9 +134,12 @@ __global__ __launch_bounds__(kWave) void rollout_table_kernel(
     if (live) {
       const int64_t at = (int64_t)t * row_pitch(out, B) + env;
       if (out.reward) out.reward[at] = reward;
-      if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
+      if (out.discount) {
+        const uint32_t dcode = (tr.y >> 12) & 15u;
+        out.discount[at] = dcode ? spec->discount_list[dcode] : (over ? 0.0f : 1.0f);
+      }
       if (out.done) out.done[at] = (uint8_t)over;
-      if (out.perf) out.perf[at] = (int8_t)((int)((tr.y >> 16) & 3u) - 1);
+      if (out.perf) out.perf[at] = (int8_t)(tr.y >> 16);
     }
   }
 

@@ -74,13 +74,15 @@ __global__ __launch_bounds__(kWave) void step_table_kernel(
     if (kBoard) board_img[lane * HW + cell] = (int8_t)spec->layer_char[mp.dyn_layer];
   }
   if (live) {
+    const uint8_t ended = tr.done & 1u;
     if (out.reward) out.reward[env] = tr.reward;
-    if (out.discount) out.discount[env] = tr.done ? 0.0f : 1.0f;
-    if (out.done) out.done[env] = tr.done;
+    if (out.discount)
+      out.discount[env] = (tr.done >> 4) ? spec->discount_list[tr.done >> 4] : (ended ? 0.0f : 1.0f);
+    if (out.done) out.done[env] = ended;
     if (out.perf) out.perf[env] = tr.perf;
     st.pos[env] = (int8_t)(cell / W);
     st.pos[B + env] = (int8_t)(cell % W);
-    st.done[env] = tr.done;
+    st.done[env] = ended;
     if (st.ret) st.ret[env] = ret;
   }
   // one wave: LDS operations complete in order, no barrier needed
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
   const uint2 tr = lds_table[cell * CAMPX_N_ACTIONS + (uint32_t)a];     // CampxTransition
   const float reward = __uint_as_float(tr.x);
   cell = tr.y & 0xffu;
-  const uint32_t done = (tr.y >> 8) & 0xffu, paint = tr.y >> 24;
+  const uint32_t done = (tr.y >> 8) & 1u, dcode = (tr.y >> 12) & 15u, paint = tr.y >> 24;
   if (mine) {
     if (!(paint & 0x80u)) {   // the mover shows at its cell
       int8_t* my_obs = obs_img + lane * R;
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
       if (kBoard) board_img[lane * HW + cell] = (int8_t)rp.mover_char;
     }
     if (out.reward) (out.reward + env0)[lane] = reward;
-    if (out.discount) (out.discount + env0)[lane] = done ? 0.0f : 1.0f;
+    if (out.discount)
+      (out.discount + env0)[lane] = dcode ? spec->discount_list[dcode] : (done ? 0.0f : 1.0f);
     if (out.done) (out.done + env0)[lane] = (uint8_t)done;
     if (out.perf) (out.perf + env0)[lane] = (int8_t)(tr.y >> 16);
     const uint32_t row = (cell * rp.inv_w) >> 16;
@@ -350,9 +353,11 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
   }
   if (live) {
     if (out.reward) out.reward[env] = reward;
-    if (out.discount) out.discount[env] = done ? 0.0f : 1.0f;
+    if (out.discount)
+      out.discount[env] = dcode_pair(e) ? spec->discount_list[dcode_pair(e)] : (done ? 0.0f : 1.0f);
     if (out.done) out.done[env] = (uint8_t)done;
-    if (out.perf) out.perf[env] = (int8_t)((int)((e >> 17) & 3u) - 1);
+    if (out.perf)
+      out.perf[env] = (int8_t)((int)perf_code_pair(e) * spec->perf_scale + spec->perf_offset);
     st.pos[env] = (int8_t)(c0 / (uint32_t)W);
     st.pos[B + env] = (int8_t)(c0 % (uint32_t)W);
     st.pos[2 * B + env] = (int8_t)(c1 / (uint32_t)W);
@@ -435,9 +440,11 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   }
   if (live) {
     if (out.reward) out.reward[env] = reward;
-    if (out.discount) out.discount[env] = done ? 0.0f : 1.0f;
+    if (out.discount)
+      out.discount[env] = dcode_tuple(hi) ? spec->discount_list[dcode_tuple(hi)] : (done ? 0.0f : 1.0f);
     if (out.done) out.done[env] = (uint8_t)done;
-    if (out.perf) out.perf[env] = (int8_t)((int)((hi >> 1) & 3u) - 1);
+    if (out.perf)
+      out.perf[env] = (int8_t)((int)perf_code_tuple(hi) * spec->perf_scale + spec->perf_offset);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t c = (lo >> (7 * k)) & 0x7fu;

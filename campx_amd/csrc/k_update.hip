@@ -236,14 +236,16 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first) {
+    int32_t reset_first, FrameCodec fc) {
   constexpr int kLoad = update_loaders(kProd);
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   // LDS entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
   // from (the art's cell when this frame ended the episode: the rebuild is folded into
   // the chain), [16:22] the cell after this frame, [23] whether the mover shows there,
-  // [24] done, [25:26] perf + 1.  The ring keeps x and the upper half of y.
+  // [24] done, [25:26] + [31] hidden-performance code, [27:30] discount code.  The ring keeps
+  // x and the upper half of y.
   __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+  __shared__ float discounts[16];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) float ring_r[2][kG][E];
   __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kG][E];
@@ -257,12 +259,16 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   constexpr int kRowBytes = CAMPX_N_ACTIONS * (int)sizeof(uint2);
   for (int i = threadIdx.x; i < HW * CAMPX_N_ACTIONS; i += kThreads) {
     const CampxTransition tr = spec->table[i];
-    const uint32_t from = tr.done ? (uint32_t)cell0 : (uint32_t)tr.next_cell;
+    const uint32_t ended = tr.done & 1u, dcode = tr.done >> 4;
+    const uint32_t from = ended ? (uint32_t)cell0 : (uint32_t)tr.next_cell;
     const uint32_t vis = (tr.paint & 0x80u) ? 0u : 1u;  // scenery in front hides the mover
+    // (the table holds perf VALUES; a game without hidden performance has scale 0)
+    const uint32_t pc = fc.perf_scale ? (uint32_t)(((int)tr.perf - fc.perf_offset) / fc.perf_scale) & 7u : 0u;
     table[i] = make_uint2(__float_as_uint(tr.reward),
                           (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) | (vis << 23) |
-                              ((uint32_t)tr.done << 24) | ((uint32_t)(tr.perf + 1) << 25));
+                              (ended << 24) | ((pc & 3u) << 25) | (dcode << 27) | ((pc >> 2) << 31));
   }
+  if (threadIdx.x < 16) discounts[threadIdx.x] = fc.discounts[threadIdx.x];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
@@ -340,21 +346,25 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             if (j < n && e0 < B) {
               const u32x4 r4 = *reinterpret_cast<const u32x4*>(&ring_r[rb][j][4 * q]);
               const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
-              const uint32_t dn[4] = {(y4.x >> 8) & 1u, (y4.x >> 24) & 1u, (y4.y >> 8) & 1u,
-                                      (y4.y >> 24) & 1u};
+              const uint32_t y[4] = {y4.x & 0xffffu, y4.x >> 16, y4.y & 0xffffu, y4.y >> 16};
+              uint32_t dc[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                dc[i] = ((y[i] >> 8) & 1u) ? 0u : 0x3f800000u;
+                if (fc.has_dcodes) dc[i] = discount_bits(discounts, dcode_y16(y[i]), (y[i] >> 8) & 1u);
+              }
               const int64_t at = (int64_t)(t0 + j) * P + e0;
               if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
                 if (out.reward) store16_update(out.reward + at, r4);
                 if (out.discount) {
-                  const u32x4 d4 = {dn[0] ? 0u : 0x3f800000u, dn[1] ? 0u : 0x3f800000u,
-                                    dn[2] ? 0u : 0x3f800000u, dn[3] ? 0u : 0x3f800000u};
+                  const u32x4 d4 = {dc[0], dc[1], dc[2], dc[3]};
                   store16_update(out.discount + at, d4);
                 }
               } else {
                 const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w};
                 for (int i = 0; i < 4 && e0 + i < B; ++i) {
                   if (out.reward) out.reward[at + i] = __uint_as_float(rw[i]);
-                  if (out.discount) out.discount[at + i] = dn[i] ? 0.0f : 1.0f;
+                  if (out.discount) out.discount[at + i] = __uint_as_float(dc[i]);
                 }
               }
             }
@@ -376,8 +386,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 const uint32_t lo = w[2 * k], hi = w[2 * k + 1];  // two environments each
                 tr[k] = pack4(lo, lo >> 16, hi, (hi >> 16) & 0xffu);
                 dn[k] = pack4((lo >> 8) & 1u, (lo >> 24) & 1u, (hi >> 8) & 1u, (hi >> 24) & 1u);
-                pf[k] = pack4(((lo >> 9) & 3u) - 1u, ((lo >> 25) & 3u) - 1u, ((hi >> 9) & 3u) - 1u,
-                              (((hi >> 25) & 3u) - 1u) & 0xffu);
+                pf[k] = pack4(perf_byte(fc, perf_code_y16(lo & 0xffffu)), perf_byte(fc, perf_code_y16(lo >> 16)),
+                              perf_byte(fc, perf_code_y16(hi & 0xffffu)), perf_byte(fc, perf_code_y16(hi >> 16)));
               }
               const int64_t at = (int64_t)(t0 + j) * P + e0;
               if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
@@ -457,11 +467,12 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_pair_kernel(
     PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, int64_t trace_plane) {
+    int32_t reset_first, int64_t trace_plane, FrameCodec fc) {
   constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kLdsEntries: n_entries
   __shared__ float reward_list[256];
+  __shared__ float discounts[16];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) uint32_t ring[2][kG][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -476,6 +487,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   if (kLdsEntries)
     for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
+  if (threadIdx.x < 16) discounts[threadIdx.x] = fc.discounts[threadIdx.x];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
@@ -557,6 +569,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               for (int i = 0; i < 4; ++i) {
                 rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
                 dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
+                if (fc.has_dcodes) dc[i] = discount_bits(discounts, dcode_pair(e[i]), (e[i] >> 16) & 1u);
               }
               const int64_t at = (int64_t)(t0 + j) * P + e0;
               if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
@@ -594,7 +607,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                   a[i] = (e[i] & 0x7fu) | (((e[i] >> 14) & 1u) << 7);
                   b[i] = ((e[i] >> 7) & 0x7fu) | (((e[i] >> 15) & 1u) << 7);
                   d[i] = (e[i] >> 16) & 1u;
-                  p[i] = (((e[i] >> 17) & 3u) - 1u) & 0xffu;
+                  p[i] = perf_byte(fc, perf_code_pair(e[i]));
                 }
                 ta[k] = pack4(a[0], a[1], a[2], a[3]);
                 tb[k] = pack4(b[0], b[1], b[2], b[3]);
@@ -673,10 +686,11 @@ template <int K, int kProd, int kCons>
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              CAMPX_TUPLE_MINWAVES) void update_tuple_kernel(
     TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B,
-    int32_t T, int32_t reset_first, int64_t trace_plane) {
+    int32_t T, int32_t reset_first, int64_t trace_plane, FrameCodec fc) {
   constexpr int kLoad = update_loaders(kProd), kG = kTupleGroup;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   __shared__ float reward_list[256];
+  __shared__ float discounts[16];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) uint64_t ring[2][kG][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -688,6 +702,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint64_t* g_entries = reinterpret_cast<const uint64_t*>(g_rewards + 256);
   for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
+  if (threadIdx.x < 16) discounts[threadIdx.x] = fc.discounts[threadIdx.x];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
@@ -763,6 +778,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               const uint32_t hi = (uint32_t)(ring[rb][j][4 * q + i] >> 32);
               rw[i] = __float_as_uint(reward_list[(hi >> 3) & 0xffu]);
               dc[i] = (hi & 1u) ? 0u : 0x3f800000u;
+              if (fc.has_dcodes) dc[i] = discount_bits(discounts, dcode_tuple(hi), hi & 1u);
             }
             const int64_t at = (int64_t)(t0 + j) * P + e0;
             if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
@@ -809,8 +825,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 tr[k][w] = pack4(b[0], b[1], b[2], b[3]);
               }
               dn[w] = pack4(hi[0] & 1u, hi[1] & 1u, hi[2] & 1u, hi[3] & 1u);
-              pf[w] = pack4(((hi[0] >> 1) & 3u) - 1u, ((hi[1] >> 1) & 3u) - 1u,
-                            ((hi[2] >> 1) & 3u) - 1u, (((hi[3] >> 1) & 3u) - 1u) & 0xffu);
+              pf[w] = pack4(perf_byte(fc, perf_code_tuple(hi[0])), perf_byte(fc, perf_code_tuple(hi[1])),
+                            perf_byte(fc, perf_code_tuple(hi[2])), perf_byte(fc, perf_code_tuple(hi[3])));
             }
             const int64_t at = (int64_t)(t0 + j) * P + e0;
             if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
@@ -948,6 +964,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
   // 512-environment workgroups (twice the row piece per store) once there are enough
   // environments to give every CU one; 256-environment workgroups below that
   const bool big = B >= (int64_t)kBigEnvs * knob_big_workgroups();
+  const FrameCodec fc = make_codec(s);
   if (use_table) {
     const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                             s.dyn_row0[0], s.dyn_col0[0]};
@@ -956,13 +973,13 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       const dim3 grid((unsigned)((B + kBigEnvs - 1) / kBigEnvs)),
           block((kProd + kCons + update_loaders(kProd)) * kWave);
       hipLaunchKernelGGL((update_table_kernel<kProd, kCons, 8>), grid, block, 0, stream, mp,
-                         spec_dev, st, actions, out, B, T, reset_first);
+                         spec_dev, st, actions, out, B, T, reset_first, fc);
     } else {
       constexpr int kProd = CAMPX_UPD_PROD, kCons = CAMPX_UPD_CONS, kEnvs = kProd * kWave;
       const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
           block((kProd + kCons + update_loaders(kProd)) * kWave);
       hipLaunchKernelGGL((update_table_kernel<kProd, kCons, CAMPX_UPD_GROUP>), grid, block, 0, stream, mp,
-                         spec_dev, st, actions, out, B, T, reset_first);
+                         spec_dev, st, actions, out, B, T, reset_first, fc);
     }
   } else if (s.n_dyn == 2 && st.pair_table && (!knob_no_table() || s.table_only)) {
     const PairParams pp = make_pair_params(s);
@@ -976,10 +993,10 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
         block(((PROD) + (CONS) + update_loaders(PROD)) * kWave);                               \
     if (in_lds)                                                                                \
       hipLaunchKernelGGL((update_pair_kernel<true, PROD, CONS>), grid, block, shmem, stream,   \
-                         pp, spec_dev, st, actions, out, B, T, reset_first, trace_plane);      \
+                         pp, spec_dev, st, actions, out, B, T, reset_first, trace_plane, fc);  \
     else                                                                                       \
       hipLaunchKernelGGL((update_pair_kernel<false, PROD, CONS>), grid, block, 0, stream, pp,  \
-                         spec_dev, st, actions, out, B, T, reset_first, trace_plane);          \
+                         spec_dev, st, actions, out, B, T, reset_first, trace_plane, fc);      \
   } while (0)
     if (big)
       CAMPX_PAIR_LAUNCH(8, 4);
@@ -993,10 +1010,10 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
     const TupleParams tp = make_tuple_params(s);
     if (s.n_dyn == 3)
       hipLaunchKernelGGL((update_tuple_kernel<3, kProd, kCons>), grid, block, 0, stream, tp, st,
-                         actions, out, B, T, reset_first, trace_plane);
+                         actions, out, B, T, reset_first, trace_plane, fc);
     else
       hipLaunchKernelGGL((update_tuple_kernel<4, kProd, kCons>), grid, block, 0, stream, tp, st,
-                         actions, out, B, T, reset_first, trace_plane);
+                         actions, out, B, T, reset_first, trace_plane, fc);
   } else {
     if (s.table_only) return CAMPX_ESPEC;   // a host-tabulated game without its table
     launch_trace(s, spec_dev, st, actions, out, B, T, reset_first, trace_plane, stream);

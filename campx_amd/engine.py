@@ -91,6 +91,7 @@ class Engine(object):
     self._board = None
     self._renderer = None
     self._hidden_performance = None
+    self._hidden_penalty = None
     # Fused tier.
     self._batch = batch
     self._device = device
@@ -156,7 +157,41 @@ class Engine(object):
             self._rows, self._cols))
     if len(masks) < 2 or int(sum(masks).max()) > 1:
       raise ValueError('hidden performance needs >= 2 disjoint masks')
+    if self._hidden_penalty is not None:
+      raise ValueError('a game has one hidden performance: progress or penalty')
     self._hidden_performance = (agent_char, masks)
+
+  @property
+  def hidden_penalty(self):
+    return self._hidden_penalty
+
+  def set_hidden_penalty(self, chars, classes, unit):
+    """Declare a hidden performance that is a penalty for WHERE things stand (build addition;
+    set-up time only): the frame's value is `unit` times the sum, over the things `chars`, of
+    the class of the cell each stands on - `classes` is a sequence of disjoint [H, W] 0/1
+    masks, a cell of classes[i] counting i + 1, any other cell 0.
+
+    The side-effects penalty of sokoban (ai-safety-gridworlds' side_effects_sokoban, whose
+    source is not in the reference: SURVEY.md A.5 - "-5 box next to a wall, -10 box in a
+    corner") is this with chars = the boxes, classes = [next to a wall, in a corner],
+    unit = -5.  The fused tier computes it in the kernels (`rollout(...)['perf']`, a
+    per-frame level, not a difference); the generic tier leaves it to the caller.
+    Exclusive with `set_hidden_performance`."""
+    self._not_during_showtime('set_hidden_penalty')
+    self._check_characters(chars)
+    masks = [_as_uint8(m) for m in classes]
+    for m in masks:
+      if tuple(m.shape) != (self._rows, self._cols):
+        raise ValueError('penalty-class masks must be {}x{}'.format(self._rows, self._cols))
+    if not masks or int(sum(masks).max()) > 1:
+      raise ValueError('hidden penalty needs >= 1 disjoint class masks')
+    if len(masks) * len(chars) > 7:
+      raise ValueError('the penalty code (highest class x things) must not exceed 7')
+    if int(unit) != unit or not 1 <= abs(int(unit)) <= 16:
+      raise ValueError('unit must be a non-zero integer of magnitude <= 16')
+    if self._hidden_performance is not None:
+      raise ValueError('a game has one hidden performance: progress or penalty')
+    self._hidden_penalty = (chars, masks, int(unit))
 
   def set_action_set(self, actions):
     """Build addition, batched engines of arbitrary Python classes only: the five objects

@@ -131,7 +131,7 @@ class FusedGame(object):
       table = torch.empty((n_pair,), dtype=torch.uint8, device=dev)
       trace = np.ascontiguousarray(traced.trace_bytes())
       reward = np.ascontiguousarray(traced.reward, dtype=np.float32)
-      done = np.ascontiguousarray(traced.done, dtype=np.uint8)
+      done = np.ascontiguousarray(traced.done_bytes(), dtype=np.uint8)
       perf = np.ascontiguousarray(traced.perf, dtype=np.int8)
       with torch.cuda.device(self.device):
         _hip.check(_hip.lib.campx_pair_table_pack(

@@ -84,7 +84,10 @@ class CampxSpec(ctypes.Structure):
               ('table', CampxTransition * (MAX_CELLS * N_ACTIONS)),
               ('rot_obs', ctypes.c_int8 * (16 * (MAX_LAYERS * MAX_CELLS + 16))),
               ('rot_board', ctypes.c_int8 * (16 * (MAX_CELLS + 16))),
-              ('cell_class', ctypes.c_uint8 * MAX_CELLS)]
+              ('cell_class', ctypes.c_uint8 * MAX_CELLS),
+              ('perf_mode', ctypes.c_int32), ('perf_mask', ctypes.c_int32),
+              ('perf_scale', ctypes.c_int32), ('perf_offset', ctypes.c_int32),
+              ('discount_list', ctypes.c_float * 16)]
 
 
 assert ctypes.sizeof(CampxRule) == 64
@@ -107,8 +110,9 @@ class EntityDesc(object):
 
 class GameDescription(object):
   def __init__(self, rows, cols, chars, backdrop, entities, z_order,
-               performance=None):
+               performance=None, penalty=None):
     self.performance = performance  # (agent char, [uint8 [H, W] masks]) or None
+    self.penalty = penalty          # (chars, [uint8 [H, W] class masks], unit) or None
     self.rows = rows
     self.cols = cols
     self.chars = chars          # all characters, ascending = layer order
@@ -186,8 +190,12 @@ def describe(engine):
     agent, masks = engine.hidden_performance
     performance = (agent, [m.detach().cpu().numpy().astype(np.uint8)
                            for m in masks])
+  penalty = None
+  if engine.hidden_penalty is not None:
+    who, masks, unit = engine.hidden_penalty
+    penalty = (who, [m.detach().cpu().numpy().astype(np.uint8) for m in masks], unit)
   return GameDescription(engine.rows, engine.cols, chars, backdrop, entities,
-                         list(engine.z_order), performance)
+                         list(engine.z_order), performance, penalty)
 
 
 def _fail(msg):
@@ -323,6 +331,18 @@ def lower(desc):
     if len(masks) > 255:
       _fail('hidden performance: too many classes')
     spec.perf_dyn, spec.perf_n = dyn_of[agent], len(masks)
+    spec.perf_mode, spec.perf_scale, spec.perf_offset = 0, 1, -1
+    for k, m in enumerate(masks):
+      for cell in np.flatnonzero(m):
+        spec.cell_class[int(cell)] = k + 1
+  if desc.penalty is not None:
+    who, masks, unit = desc.penalty
+    for ch in who:
+      if ch not in dyn_of:
+        _fail('hidden penalty watches {!r}, which is not a moving thing'.format(ch))
+    spec.perf_mode, spec.perf_scale, spec.perf_offset = 1, int(unit), 0
+    spec.perf_mask = sum(1 << dyn_of[ch] for ch in who)
+    spec.perf_dyn = min(dyn_of[ch] for ch in who)
     for k, m in enumerate(masks):
       for cell in np.flatnonzero(m):
         spec.cell_class[int(cell)] = k + 1

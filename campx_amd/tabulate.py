@@ -28,8 +28,9 @@ that are CHECKED while tabulating, never assumed (ValueError otherwise):
   painted into the backdrop: campx/rendering.py:128,150);
 * every rendered board equals "backdrop, then things in z-order" computed from the cells
   alone - which also yields whether a moving thing is the character its cell shows;
-* the discount is 1.0, or 0.0 on the frame `terminate_episode()` was called (the
-  device tiers' model; campx/plot.py:161-184, 232-257);
+* at most fifteen distinct discounts other than the default - 1.0, or 0.0 on the frame
+  `terminate_episode()` was called - are reported (`change_default_discount`,
+  `terminate_episode(d)`: campx/plot.py:161-184, 232-257; the tables carry a 4-bit code);
 * the entities' curtains ARE the state: when a state is reached again over a different
   history, every action is replayed from that second engine and must reproduce the
   tabulated next state, reward, discount, game-over and board.  A game that keeps hidden
@@ -116,10 +117,16 @@ class TracedGame(object):
     init_cells: the movers' cells after `its_showtime()`;
     n: (H*W)^K * 5 table entries, index ((cell_0 * HW + cell_1) ...) * 5 + action;
     next_cells uint8 [K, n], visible uint8 [K, n], reward float32 [n] (NaN = None),
-    done uint8 [n], perf int8 [n], reached bool [n] (entries the game can get to; the
-    others are self-loops that pay nothing);
+    done uint8 [n], discount float32 [n], dcode uint8 [n] (0 = the default discount, else
+    an index into `discount_list`), perf int8 [n], reached bool [n] (entries the game can
+    get to; the others are self-loops that pay nothing);
     n_states, n_plays: size of the reachable state space and what tabulating it cost.
   """
+
+  def done_bytes(self):
+    """uint8 [n]: bit 0 done, bits 4-7 the discount code - CampxTransition.done and the
+    `done` argument of campx_pair_table_pack."""
+    return (self.done | (self.dcode << 4)).astype(np.uint8)
 
   def trace_bytes(self):
     """uint8 [K, n]: cell | visible << 7 - the kernels' trace format (CampxOutputs.trace)."""
@@ -204,10 +211,7 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     if z != z0:
       _fail('the z-order changed during play (Plot.change_z_order): generic tier only')
     over = bool(eng.game_over)
-    discount = float(discount)
-    if discount != (0.0 if over else 1.0):
-      _fail('a frame reported discount {} ({}): the device tiers report 1.0, or 0.0 on the '
-            'frame the episode ends'.format(discount, 'terminated' if over else 'not terminated'))
+    discount = float(np.float32(discount))
     board = obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()
     return things, _reward_f32(reward), discount, over, board
 
@@ -306,7 +310,19 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
 
   # ---- hidden performance (examples/boat_race.py:117-151): classes of the watched mover
   perf_of = None
-  if engine.hidden_performance is not None:
+  if engine.hidden_penalty is not None:
+    who, masks, unit = engine.hidden_penalty
+    for ch in who:
+      if ch not in movers:
+        _fail('hidden penalty watches {!r}, which never moves'.format(ch))
+    cls = np.zeros(HW, np.int32)
+    for k, m in enumerate(masks):
+      cls[np.flatnonzero(m.detach().cpu().numpy().reshape(-1))] = k + 1
+    watched = [movers.index(ch) for ch in who]
+
+    def perf_of(src, dst):
+      return int(unit) * sum(int(cls[dst[k]]) for k in watched)
+  elif engine.hidden_performance is not None:
     agent, masks = engine.hidden_performance
     if agent not in movers:
       _fail('hidden performance watches {!r}, which never moves'.format(agent))
@@ -330,6 +346,9 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   game.visible = np.zeros((K, n), np.uint8)
   game.reward = np.full((n,), np.nan, np.float32)
   game.done = np.zeros((n,), np.uint8)
+  game.discount = np.ones((n,), np.float32)
+  game.dcode = np.zeros((n,), np.uint8)
+  game.discount_list = [1.0]          # code -> value; code 0 stands for the default
   game.perf = np.zeros((n,), np.int8)
   game.reached = np.zeros((n,), bool)
   # entries nobody can reach: stay where you are, pay nothing
@@ -347,11 +366,19 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
       game.visible[k, i] = int(board[dst[k]] == codes[k])
     game.reward[i] = e.reward
     game.done[i] = int(e.over)
+    game.discount[i] = e.discount
+    if e.discount != (0.0 if e.over else 1.0):
+      if e.discount not in game.discount_list[1:]:
+        if len(game.discount_list) == 16:
+          _fail('more than 15 distinct discounts besides the default')
+        game.discount_list.append(e.discount)
+      game.dcode[i] = 1 + game.discount_list[1:].index(e.discount)
     game.perf[i] = perf_of(state_cells[s], dst) if perf_of else 0
     game.reached[i] = True
   game.any_reward = bool((~np.isnan(game.reward[game.reached])).any())
   game.has_perf = perf_of is not None
   game.perf_spec = engine.hidden_performance
+  game.penalty_spec = engine.hidden_penalty
   game.n_states, game.n_plays = len(images), plays[0]
   return game
 
@@ -396,18 +423,31 @@ def to_spec(game):
     spec.static_cover[i] = int(cover.flat[i])
     spec.obs_template[int(top_layer.flat[i]) * HW + i] = 1
   spec.perf_dyn = -1
-  if game.has_perf:
+  if game.has_perf and game.penalty_spec is not None:
+    who, classes, unit = game.penalty_spec
+    spec.perf_mode, spec.perf_scale, spec.perf_offset = 1, int(unit), 0
+    spec.perf_mask = sum(1 << game.movers.index(ch) for ch in who)
+    spec.perf_dyn = min(game.movers.index(ch) for ch in who)
+    for k, m in enumerate(classes):
+      for cell in np.flatnonzero(m.detach().cpu().numpy().reshape(-1)):
+        spec.cell_class[int(cell)] = k + 1
+  elif game.has_perf:
     agent, cycle = game.perf_spec
     spec.perf_dyn, spec.perf_n = game.movers.index(agent), len(cycle)
+    spec.perf_mode, spec.perf_scale, spec.perf_offset = 0, 1, -1
     for k, m in enumerate(cycle):
       for cell in np.flatnonzero(m.detach().cpu().numpy().reshape(-1)):
         spec.cell_class[int(cell)] = k + 1
+  for code, value in enumerate(game.discount_list):
+    if code:
+      spec.discount_list[code] = float(value)
   if len(game.movers) == 1:
     for i in range(game.n):
       tr = spec.table[i]
       nxt = int(game.next_cells[0, i])
       tr.reward = float(game.reward[i])
-      tr.next_cell, tr.done, tr.perf = nxt, int(game.done[i]), int(game.perf[i])
+      tr.next_cell, tr.perf = nxt, int(game.perf[i])
+      tr.done = int(game.done[i]) | (int(game.dcode[i]) << 4)
       in_front = spec.static_top_z[nxt] > spec.dyn_z[0]
       tr.paint = int(spec.static_top_layer[nxt]) | (0x80 if in_front else 0)
     spec.table_valid = 1

@@ -97,8 +97,11 @@ typedef struct CampxRule {
 typedef struct CampxTransition {
   float reward;       /* summed reward of the frame (NaN = None) */
   uint8_t next_cell;  /* row * cols + col after the frame */
-  uint8_t done;       /* 1: the episode terminated (discount 0) */
-  int8_t perf;        /* hidden performance of the frame: -1, 0, +1 */
+  uint8_t done;       /* bit 0: the episode terminated on the frame; bits 4-7: discount code c:
+                         the frame reports spec.discount_list[c], or - c == 0 - the default,
+                         0.0 when it terminated and 1.0 otherwise (campx/plot.py:161-184,
+                         232-257) */
+  int8_t perf;        /* hidden performance of the frame (perf_scale * code + perf_offset) */
   uint8_t paint;      /* how the mover paints at next_cell: bits 0-6 the scenery layer it
                          covers there, bit 7 set when the scenery hides it instead */
 } CampxTransition;    /* 8 bytes */
@@ -158,6 +161,21 @@ typedef struct CampxSpec {
    * 0 = none.  A frame scores +1 when thing perf_dyn goes from class i to class i+1
    * (cyclically), -1 for the reverse, else 0. */
   uint8_t cell_class[CAMPX_MAX_CELLS];
+  /* Two kinds of hidden performance, both a small code per frame that the state tables
+   * carry in 3 bits; the value written to CampxOutputs.perf is perf_scale * code + perf_offset.
+   *   perf_mode 0  progress round a cycle of cell classes (above): code = progress + 1,
+   *                scale 1, offset -1.
+   *   perf_mode 1  a penalty for where things stand: code = sum over the moving things in
+   *                perf_mask (bit d = thing d) of cell_class[its cell], at most 7 - the
+   *                side-effects penalty of sokoban (-5 for a box next to a
+   *                wall, -10 for a box in a corner: classes 1 and 2, perf_scale -5).
+   * perf_dyn >= 0 says that the game has a hidden performance at all (mode 1: any thing
+   * of perf_mask). */
+  int32_t perf_mode, perf_mask, perf_scale, perf_offset;
+  /* Discounts other than the default (Plot.change_default_discount, terminate_episode(d):
+   * campx/plot.py:161-184, 232-257): code -> value, codes 1..15; code 0 is the default.
+   * Only host-tabulated games (table_only) produce them. */
+  float discount_list[16];
 } CampxSpec;
 
 /* Dynamic state of B environments, struct-of-arrays, DEVICE pointers. */
@@ -258,11 +276,12 @@ int32_t campx_spec_compile(CampxSpec* spec_host, void* stream);
  * ((cell0 * rows*cols + cell1) * rows*cols + ...) * 5 + action.
  * Two movers, uint32 entries:
  *   bits 0-6 cell of thing 0 after the frame, 7-13 cell of thing 1, 14/15 whether
- *   thing 0 / 1 is the character its cell shows, 16 done, 17-18 perf + 1,
- *   19-26 index into the reward list.
+ *   thing 0 / 1 is the character its cell shows, 16 done, 17-18 and 31 the hidden-performance
+ *   code (3 bits), 19-26 index into the reward list, 27-30 discount code.
  * Three and four movers, uint64 entries:
  *   bits 7d..7d+6 cell of thing d after the frame, 28+d whether it is the character its
- *   cell shows, 32 done, 33-34 perf + 1, 35-42 index into the reward list.
+ *   cell shows, 32 done, 33-34 and 43 the hidden-performance code, 35-42 index into the
+ *   reward list, 44-47 discount code.
  */
 int64_t campx_pair_table_bytes(const CampxSpec* spec_host);
 int32_t campx_pair_table_build(const CampxSpec* spec_host, const CampxSpec* spec_dev,
@@ -275,10 +294,12 @@ int32_t campx_pair_table_build(const CampxSpec* spec_host, const CampxSpec* spec
  * n = (rows*cols)^K * 5 entries indexed as above:
  *   trace   [K][n]  thing d after the frame: cell | (it is the character its cell shows) << 7
  *   reward  [n]     summed reward of the frame, NaN = None (campx/plot.py:208-211)
- *   done    [n]     1: the episode terminated on the frame
- *   perf    [n]     hidden performance -1 / 0 / +1, or NULL
+ *   done    [n]     bit 0: the episode terminated on the frame; bits 4-7: discount code
+ *                   (index into spec_host->discount_list; 0 = the default)
+ *   perf    [n]     hidden performance (a value perf_scale * code + perf_offset), or NULL
  * Packs them into `table_dev` (campx_pair_table_bytes() bytes of device memory) and
- * synchronises `stream`.  CAMPX_ESPEC for more than 256 distinct rewards.
+ * synchronises `stream`.  CAMPX_ESPEC for more than 256 distinct rewards or a perf value
+ * that is not one of the eight the spec's scale and offset give.
  */
 int32_t campx_pair_table_pack(const CampxSpec* spec_host, const uint8_t* trace,
                               const float* reward, const uint8_t* done, const int8_t* perf,

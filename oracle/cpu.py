@@ -51,7 +51,9 @@ class _Game(ctypes.Structure):
               ('backdrop', ctypes.c_uint8 * MAX_CELLS),
               ('curtains0', (ctypes.c_uint8 * MAX_CELLS) * MAX_ENTITIES),
               ('n_perf_masks', ctypes.c_int32), ('perf_char', ctypes.c_int32),
-              ('perf_masks', (ctypes.c_uint8 * MAX_CELLS) * MAX_SET)]
+              ('perf_masks', (ctypes.c_uint8 * MAX_CELLS) * MAX_SET),
+              ('n_pen_chars', ctypes.c_int32), ('pen_chars', ctypes.c_int32 * MAX_SET),
+              ('pen_unit', ctypes.c_int32)]
 
 
 def build(force=False):
@@ -174,6 +176,15 @@ class OracleGame(object):
       agent, masks = desc.performance
       assert len(masks) <= MAX_SET
       g.n_perf_masks, g.perf_char = len(masks), ord(agent)
+      for k, m in enumerate(masks):
+        for j in range(n):
+          g.perf_masks[k][j] = int(m.flat[j])
+    if getattr(desc, 'penalty', None) is not None:
+      who, masks, unit = desc.penalty
+      assert desc.performance is None and len(masks) <= MAX_SET and len(who) <= MAX_SET
+      g.n_perf_masks, g.n_pen_chars, g.pen_unit = len(masks), len(who), int(unit)
+      for c, ch in enumerate(who):
+        g.pen_chars[c] = ord(ch)
       for k, m in enumerate(masks):
         for j in range(n):
           g.perf_masks[k][j] = int(m.flat[j])

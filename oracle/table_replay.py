@@ -70,7 +70,7 @@ class TableWalker(object):
       out['visible'][:, t] = g.visible[:, idx]
       out['reward'][t] = reward
       out['done'][t] = self.over
-      out['discount'][t] = np.where(self.over, 0, 1)
+      out['discount'][t] = g.discount[idx]
       out['perf'][t] = g.perf[idx]
     return out
 

@@ -9,7 +9,7 @@ import pytest
 
 from campx_amd import gamespec
 from oracle import cpu
-from games_under_test import FUSED_GAMES, SHAPE_GAMES
+from games_under_test import FUSED_GAMES, SHAPE_GAMES, SOKOBAN_LEVEL, sokoban_penalty_from_boards
 
 ALL_GAMES = dict(FUSED_GAMES, **SHAPE_GAMES)
 
@@ -32,6 +32,9 @@ def test_oracle_reproduces_reference_trajectories(name, golden):
   assert np.array_equal(out['done'], gold['done'])
   if 'perf' in gold:      # hidden performance: the reference's own step_perf()
     assert np.array_equal(out['perf'], gold['perf'])
+  elif name in SOKOBAN_LEVEL:   # the side-effects penalty, from where the golden boards show the boxes
+    want = sokoban_penalty_from_boards(gold, SOKOBAN_LEVEL[name])
+    assert np.array_equal(out['perf'].astype(np.int32), want) and want.min() <= -10
   else:
     assert out['perf'] is None
 

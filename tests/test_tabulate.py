@@ -152,20 +152,66 @@ def test_test_local_games_tabulate_and_predict_the_generic_tier(name):
   if name == 'ice_rink':
     assert traced.movers == ['A'] and [c for c, _ in traced.statics] == ['#', 'o', 'E']
     assert traced.done[traced.reached].sum() > 0
+  elif name == 'toll_road':
+    assert traced.movers == ['A'] and traced.discount_list == [1.0, 0.5, 0.25, 0.75]
   else:
     assert traced.movers == ['A', 'G']                      # a drape and a sprite
     hidden = traced.reached & (traced.visible[0] == 0)      # the ghost stands on the walker
     assert hidden.any() and (traced.done[hidden] == 1).all()
     assert (traced.visible[1][traced.reached] == 1).all()
-  assert len(set(traced.reward[traced.reached].tolist())) > 3
+  assert len(set(traced.reward[traced.reached].tolist())) > (1 if name == 'toll_road' else 3)
   ended = _walk_generic(build, traced, 400, seed=5)
   assert ended > 0
+
+
+def _traced_golden(name):
+  with np.load(os.path.join(GOLDEN_DIR, 'traced_' + name + '.npz')) as f:
+    return {k: f[k] for k in f.files}
+
+
+@pytest.mark.parametrize('name', sorted(traced_games.GAMES))
+def test_reference_engine_goldens_on_the_generic_tier_and_through_the_table(name):
+  """tests/golden/traced_<name>.npz: the same test-local classes run by the REFERENCE's
+  engine (make_traced_golden.py).  This repo's generic tier gives the same frames, and so
+  does walking the table tabulated from them - discounts other than 0 / 1 included."""
+  from oracle.table_replay import TableWalker
+  gold = _traced_golden(name)
+  T, N = gold['actions'].shape
+  build = traced_games.GAMES[name]
+  onehot = tabulate.default_actions()
+  for n in range(4):
+    game = build()
+    obs, _, _ = game.its_showtime()
+    assert np.array_equal(obs.board.numpy(), gold['board'][0, n].astype(np.uint8))
+    for t in range(T):
+      if game.game_over:
+        game = build()
+        game.its_showtime()
+      obs, reward, discount = game.play(onehot[int(gold['actions'][t, n])])
+      assert np.array_equal(obs.board.numpy(), gold['board'][t + 1, n].astype(np.uint8)), (n, t)
+      assert np.array_equal(obs.layered_board.numpy(), gold['layered'][t + 1, n])
+      assert _same(np.float32(np.nan if reward is None else float(reward)), gold['reward'][t, n])
+      assert np.float32(discount) == gold['discount'][t, n]
+      assert int(game.game_over) == gold['done'][t, n]
+  traced = tabulate.trace(build())
+  assert [ord(c) for c in traced.chars] == gold['chars'].tolist()
+  walker = TableWalker(traced, N)
+  want = walker.rollout(gold['actions'], reset_first=True)
+  for k in ('reward', 'discount', 'done'):
+    assert _same(want[k], gold[k]), k
+  for t in range(T):
+    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    assert np.array_equal(board, gold['board'][t + 1]), t
+    assert np.array_equal(layered, gold['layered'][t + 1].astype(np.int8)), t
+  if name == 'toll_road':
+    assert traced.discount_list == [1.0, 0.5, 0.25, 0.75]
+    assert set(np.unique(gold['discount']).tolist()) == {0.25, 0.5, 0.75, 1.0}
 
 
 @pytest.mark.parametrize('cls,why', [
     (traced_games.Stepper, 'keeps state outside its curtains'),
     (traced_games.Grower, 'covers 2 cells'),
-    (traced_games.Discounter, 'discount 0.5'),
+    (traced_games.Discounter, 'more than 15 distinct discounts'),
     (traced_games.Reorderer, 'z-order changed'),
 ])
 def test_games_the_table_model_is_not_exact_for_are_refused(cls, why):
@@ -274,6 +320,8 @@ def test_test_local_games_at_full_batch_through_the_table_and_render_kernels(nam
   for k in ('reward', 'discount', 'done'):
     assert _same(out[k].cpu().numpy(), want[k]), k
   assert want['done'].sum() > B // 10
+  if name == 'toll_road':     # discounts that are neither 0 nor 1, from the table's codes
+    assert set(np.unique(want['discount']).tolist()) == {0.25, 0.5, 0.75, 1.0}
   assert _same(f.ret.cpu().numpy(), walker.ret)
   # every environment's observation at a few frames, a strided sample at every frame
   for t in (0, 1, T // 2, T - 1):
@@ -316,6 +364,35 @@ def test_test_local_games_at_full_batch_through_the_table_and_render_kernels(nam
       assert _same(alone['reward'].cpu().numpy(), want['reward'][:, :4096])
     finally:
       fused.SPLIT_ROLLOUT = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(traced_games.GAMES))
+def test_reference_engine_goldens_on_the_gpu(name):
+  """What the reference's engine did with the test-local classes (traced_<name>.npz) against
+  the HIP path running the table tabulated from them: rollout, then play() frame by frame."""
+  gold = _traced_golden(name)
+  T, N = gold['actions'].shape
+  build = traced_games.GAMES[name]
+  game = build(batch=N, device='cuda')
+  first, _, _ = game.its_showtime()
+  assert [ord(c) for c in game.fused.chars] == gold['chars'].tolist()
+  assert np.array_equal(first.board.cpu().numpy(), gold['board'][0])
+  assert np.array_equal(first.layered_board.cpu().numpy(), gold['layered'][0].astype(np.int8))
+  out = game.rollout(torch.from_numpy(gold['actions']), want_board=True)
+  assert np.array_equal(out['obs'].cpu().numpy(), gold['layered'][1:].astype(np.int8))
+  assert np.array_equal(out['board'].cpu().numpy(), gold['board'][1:])
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), gold[k]), k
+  game = build(batch=N, device='cuda')
+  game.its_showtime()
+  for t in range(T):
+    obs, reward, discount = game.play(torch.from_numpy(gold['actions'][t]))
+    assert np.array_equal(obs.board.cpu().numpy(), gold['board'][t + 1]), t
+    assert np.array_equal(obs.layered_board.cpu().numpy(), gold['layered'][t + 1].astype(np.int8))
+    assert _same(reward.cpu().numpy(), gold['reward'][t]), t
+    assert _same(discount.cpu().numpy(), gold['discount'][t]), t
+    assert np.array_equal(game.fused.done.cpu().numpy(), gold['done'][t])
 
 
 @pytest.mark.gpu

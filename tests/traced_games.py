@@ -132,7 +132,50 @@ def mirror(**where):
       z_order='+#AG', update_schedule='A#+G', **where)
 
 
-GAMES = {'ice_rink': ice_rink, 'mirror': mirror}
+# ------------------------------------------ one mover, discounts other than the default
+
+TOLL_ART = ['#######',
+            '#A $  #',
+            '# #%# #',
+            '#  $ E#',
+            '#######']
+
+
+class TollWalker(things.Drape):
+  """One cell per frame (walls stop it), -1 per frame.  Standing on a '$' tile after the
+  move the frame's discount is 0.5, on the '%' tile 0.25 (`Plot.change_default_discount`,
+  campx/plot.py:232-257: it lasts one frame); reaching 'E' pays +5 and ends the episode with
+  discount 0.75 (`terminate_episode(0.75)`, plot.py:161-184), not the default 0."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = _DELTA[_action_id(actions)]
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    if not all_things['#'].curtain[r + dr, c + dc]:
+      r, c = r + dr, c + dc
+      self.curtain.zero_()
+      self.curtain[r, c] = 1
+    reward = -1.0
+    if all_things['$'].curtain[r, c]:
+      the_plot.change_default_discount(0.5)
+    if all_things['%'].curtain[r, c]:
+      the_plot.change_default_discount(0.25)
+    if all_things['E'].curtain[r, c]:
+      reward += 5.0
+      the_plot.terminate_episode(0.75)
+    the_plot.add_reward(reward)
+
+
+def toll_road(**where):
+  return ascii_art_to_game(
+      TOLL_ART, what_lies_beneath=' ',
+      drapes={'A': TollWalker, '#': things.FixedDrape, '$': things.FixedDrape,
+              '%': things.FixedDrape, 'E': things.FixedDrape},
+      z_order='$%EA#', update_schedule='A#$%E', **where)
+
+
+GAMES = {'ice_rink': ice_rink, 'mirror': mirror, 'toll_road': toll_road}
 
 
 # ------------------------------------------------------------- games that must be refused
@@ -159,11 +202,14 @@ class Grower(things.Drape):
 
 
 class Discounter(things.Drape):
+  """Seventeen different discounts: the tables' 4-bit discount code has room for fifteen."""
+
   def update(self, actions, board, layers, backdrop, all_things, the_plot):
     if actions is None:
       return
     self.curtain.set_(torch.roll(self.curtain, 1, 1))
-    the_plot.change_default_discount(0.5)
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    the_plot.change_default_discount((1 + c + 4 * _action_id(actions)) / 32.0)   # 20 values
 
 
 class Reorderer(things.Drape):
