@@ -348,7 +348,7 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
                    Tensor& obs, const OptTensor& board, const OptTensor& reward,
                    const OptTensor& discount, const OptTensor& step_done,
                    const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first,
-                   bool emit_first) {
+                   bool emit_first, const OptTensor& trace) {
   TORCH_CHECK(spec_host.device().is_cpu() && spec_host.scalar_type() == at::kByte &&
                   spec_host.is_contiguous() && spec_host.numel() == (int64_t)sizeof(CampxShapeSpec),
               "campx: spec_host must be the CampxShapeSpec blob as a CPU uint8 tensor");
@@ -401,6 +401,10 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
   out.done = opt_ptr<uint8_t>(step_done);
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, dev);
+  if (trace.has_value() && frames) {   // scratch of the two-kernel path: int32 [4, T, B]
+    want(*trace, "trace", at::kInt, dev, {4, T, B});
+    out.trace = reinterpret_cast<uint8_t*>(trace->data_ptr());
+  }
   CampxState state{reinterpret_cast<int8_t*>(pos.data_ptr()), reinterpret_cast<uint8_t*>(done.data_ptr()),
                    opt_ptr<float>(ret), nullptr};
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
@@ -462,7 +466,7 @@ void render_meta(const Tensor&, const Tensor&, const Tensor&, Tensor&, const Opt
 void shape_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
-                        const OptTensor&, bool, bool) {}
+                        const OptTensor&, bool, bool, const OptTensor&) {}
 void onehot_to_ids_meta(const Tensor&, Tensor&, Tensor&) {}
 void check_actions_meta(const Tensor&, Tensor&) {}
 
@@ -516,7 +520,8 @@ TORCH_LIBRARY(campx, m) {
       "shape_rollout(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, "
       "Tensor(c!)? ret, Tensor(d!)? backdrop_state, Tensor? actions, Tensor(e!) obs, "
       "Tensor(f!)? board, Tensor(g!)? reward, Tensor(h!)? discount, Tensor(i!)? step_done, "
-      "Tensor(j!)? bad_count, Tensor(k!)? bad_flag, bool reset_first, bool emit_first) -> ()");
+      "Tensor(j!)? bad_count, Tensor(k!)? bad_flag, bool reset_first, bool emit_first, "
+      "Tensor(l!)? trace=None) -> ()");
   m.def("onehot_to_ids(Tensor onehot, Tensor(a!) ids, Tensor(b!) bad_count) -> ()");
   m.def("check_actions(Tensor actions, Tensor(a!) bad_count) -> ()");
 }

@@ -15,12 +15,21 @@ the backdrop itself.
 """
 
 import ctypes
+import os
 
 import torch
 
 from . import _hip
 from . import gamespec
 from .rendering import Observation
+
+
+# Games without trails can run rollouts as two kernels (update pass -> offset trace ->
+# frame-major render with memory-aligned stores, csrc/k_shape.hip).  Built, parity-tested
+# and MEASURED SLOWER than the single serial kernel (Hello World's art without trails,
+# B = 32 768: 4.0-4.2 against 4.9 TB/s; DESIGN.md 3.7, profiles/r03_shape_rocprofv3.txt), so
+# it is off by default; CAMPX_SHAPE_SPLIT=1 (or setting this flag) turns it on.
+SPLIT_TRAIL_FREE = os.environ.get('CAMPX_SHAPE_SPLIT', '0') == '1'
 
 
 class ShapeGame(object):
@@ -51,6 +60,9 @@ class ShapeGame(object):
     self.any_reward = bool(self.spec.any_reward)
     self.has_perf = False
     self.uses_table = False
+    # no visible sprite is painted before the first drape: the backdrop never changes, and
+    # rollouts can take the two-kernel path (csrc/k_shape.hip shape_render_kernel)
+    self.trail_free = not any(self.spec.things[k].visible for k in range(self.spec.first_drape))
     B, dev = self.batch, self.device
     blob = ctypes.string_at(ctypes.addressof(self.spec), ctypes.sizeof(self.spec))
     self._spec_host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
@@ -143,12 +155,16 @@ class ShapeGame(object):
       if want_board:
         board = (torch.empty((T, B, H, W), dtype=torch.int8, device=dev) if keep_obs
                  else self._board)
+    # Games without trails: the scratch of the two-kernel path (the things' offsets per
+    # frame, 16 bytes per environment-frame); the library ignores it for other games / calls
+    trace = (torch.empty((4, T, B), dtype=torch.int32, device=dev)
+             if SPLIT_TRAIL_FREE and self.trail_free and keep_obs and T > 0 else None)
     return dict(obs=obs, board=board,
                 reward=(torch.empty((T, B), dtype=torch.float32, device=dev)
                         if self.any_reward else None),
                 discount=torch.empty((T, B), dtype=torch.float32, device=dev),
                 done=torch.empty((T, B), dtype=torch.uint8, device=dev),
-                perf=None, trace=None)
+                perf=None, trace=trace)
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True, reset_first=False,
               want_board=False, obs_dtype=torch.int8, out=None, pipelined=False):
@@ -167,7 +183,7 @@ class ShapeGame(object):
     self._op(self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self.backdrop,
              ids, out['obs'], out['board'], out['reward'], out['discount'], out['done'],
              self._bad if validate else None, self._bad_flag if validate else None,
-             bool(reset_first), False)
+             bool(reset_first), False, out.get('trace'))
     self.frame = T if reset_first else self.frame + T
     if validate:
       self._after_launch()

@@ -413,6 +413,11 @@ int32_t campx_shape_spec_validate(const CampxShapeSpec* spec_host);
  * drape).  Outputs: out.obs (int8 only), out.board, out.reward, out.discount, out.done,
  * out.bad_count / bad_flag; frames at base + t * stride as for campx_rollout_launch.
  * Action ids outside 0..4 move nothing, end nothing and are counted as bad.
+ * out.trace (optional, 4-byte aligned, 16 * T * B bytes): scratch for the things' offsets per
+ * frame, uint32 [4][T][B].  Given it, a game without trails (no visible sprite before the
+ * first drape) whose frames are kept back to back runs as two kernels - update pass, then
+ * a frame-major render with memory-aligned stores - which streams the observations faster
+ * (DESIGN.md 3.7); other games and calls ignore it.
  */
 int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxShapeSpec* spec_dev,
                                    CampxState state, int8_t* backdrop_state,

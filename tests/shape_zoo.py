@@ -71,6 +71,27 @@ ZOO = {
         drapes={'@': dict(move_reward=2)},
         fixed='#',
         z_order='12#@3', update_schedule='@#123'),
+    # Hello World's own art (13x36 = 468 cells, 3 276-byte observations), the letters a
+    # static thing, the drape painted FIRST: no trails - the two-kernel path at the size the
+    # shape tier is measured at
+    'zoo4': dict(
+        art=['                                    ',
+             '  #   #  ### #    #     ###         ',
+             '  #   # #    #    #    #   #        ',
+             '  ##### #### #    #    #   #        ',
+             '  #   # #    #    #    #   #        ',
+             '  #   #  ###  ###  ###  ###         ',
+             '                                    ',
+             '     @   @  @@@   @@@  @    @@@@  1 ',
+             '     @   @ @   @ @   @ @    @   @ 2 ',
+             '     @ @ @ @   @ @@@@  @    @   @ 3 ',
+             '     @ @ @ @   @ @   @ @    @   @   ',
+             '      @@@   @@@  @   @  @@@ @@@@  4 ',
+             '                                    '],
+        sprites={'1': 0, '2': 1, '3': 2, '4': 3},
+        drapes={'@': dict()},
+        fixed='#',
+        z_order='@#1234', update_schedule='1234@#'),
 }
 
 

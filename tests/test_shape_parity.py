@@ -88,6 +88,56 @@ def test_zoo_random_streams_vs_oracle(name, batch):
       assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
 
 
+@pytest.mark.parametrize('batch', [4, 64, 1000, 4096])
+def test_two_kernel_path_for_games_without_trails(batch):
+  """shape_zoo4 (Hello World's art, the drape painted first: no trails) takes the update pass +
+  frame-major render kernels when a rollout keeps every frame: against the oracle, several
+  launches with the state carried over, with the flat board, and against the single serial
+  kernel (the same buffers without the offset-trace scratch)."""
+  from campx_amd import shapes
+  name = 'shape_zoo4'
+  game, _ = _game(batch, name)
+  assert game.fused.trail_free
+  serial, _ = _game(batch, name)
+  shapes.SPLIT_TRAIL_FREE = True       # (off by default: it measured slower than the serial kernel)
+  og = cpu.OracleGame.from_description(gamespec.describe(SHAPE_GAMES[name]()))
+  rng = np.random.RandomState(batch)
+  for launch, T in enumerate([1, 70, 33]):
+    actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
+    acts = torch.from_numpy(actions)
+    out = game.rollout(acts, want_board=True)
+    shapes.SPLIT_TRAIL_FREE = False
+    assert out['trace'] is not None
+    bufs = None
+    bufs = serial.fused.rollout_buffers(T, want_board=True)
+    assert bufs['trace'] is None
+    alone = serial.rollout(acts, out=bufs)
+    shapes.SPLIT_TRAIL_FREE = True
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'board', 'reward', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
+      assert _same(out[k].cpu().numpy(), alone[k].cpu().numpy()), (launch, k)
+    assert torch.equal(game.fused.pos, serial.fused.pos)
+    assert _same(game.fused.ret.cpu().numpy(), serial.fused.ret.cpu().numpy())
+  shapes.SPLIT_TRAIL_FREE = False
+  # play() in between uses the serial kernel on the same state
+  obs, _, _ = game.play(torch.zeros(batch, dtype=torch.int8))
+  obs2, _, _ = serial.play(torch.zeros(batch, dtype=torch.int8))
+  assert torch.equal(obs.layered_board, obs2.layered_board)
+  assert ref['done'].sum() > 0 or batch < 64
+
+
+def test_games_with_trails_never_take_the_two_kernel_path():
+  from campx_amd import shapes
+  game, _ = _game(64)                       # Hello World: sprites 1 and 2 behind the drape
+  assert not game.fused.trail_free
+  shapes.SPLIT_TRAIL_FREE = True
+  try:
+    assert game.fused.rollout_buffers(10)['trace'] is None
+  finally:
+    shapes.SPLIT_TRAIL_FREE = False
+
+
 def test_golden_rollout(golden):
   """The notebook's own classes on the reference engine -> same frames, incl. the
   trails sprites 1 and 2 leave in the backdrop and the quit at frame 25 of env 0."""

@@ -4,10 +4,22 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from campx_amd.games import hello_world
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import shape_zoo
 
-for B in (4096, 32768):
+from campx_amd import shapes
+
+# hello_world: trails (serial kernel); shape_zoo4: the same art without trails, on the serial
+# kernel (the default) and on the two-kernel path (`split`: shapes.SPLIT_TRAIL_FREE)
+for which, B in (('hello_world', 4096), ('hello_world', 32768), ('shape_zoo4', 4096),
+                 ('shape_zoo4', 32768), ('shape_zoo4 split', 4096), ('shape_zoo4 split', 32768)):
+  shapes.SPLIT_TRAIL_FREE = which.endswith('split')
   T = 100
-  game, _, _, _ = hello_world.make_game(batch=B, device='cuda')
+  if which == 'hello_world':
+    game, _, _, _ = hello_world.make_game(batch=B, device='cuda')
+  else:
+    game = shape_zoo.library_builders()['shape_zoo4'](batch=B, device='cuda')
+    game.its_showtime()
   game.fused.validate_actions = False
   acts = torch.randint(0, 4, (T, B), dtype=torch.int8, device='cuda')
   bufs = game.fused.rollout_buffers(T)
@@ -26,8 +38,8 @@ for B in (4096, 32768):
   print('  per launch: min %.3f median %.3f max %.3f ms' % (per[0], per[n // 2], per[-1]))
   L, H, W = game.fused.n_layers, game.fused.rows, game.fused.cols
   gb = B * T * (L * H * W + 9) / 1e9
-  print('hello_world B=%d T=%d: %.3f ms per launch, %.2e env-steps/s, %.2f TB/s of observations'
-        % (B, T, ms, B * T / ms * 1e3, gb / ms))
+  print('%s B=%d T=%d: %.3f ms per launch, %.2e env-steps/s, %.2f TB/s of observations'
+        % (which, B, T, ms, B * T / ms * 1e3, gb / ms))
   t0 = time.perf_counter()
   for t in range(200):
     game.play(acts[t % T])
