@@ -54,7 +54,7 @@ WORKLOADS = {
     'sokoban_l2': ('sokoban 6x8 with three boxes (build-authored level 2)', 131072),
 }
 HEADLINE_METRIC = 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X'
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r02_traffic.json')
+TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r03_traffic.json')
 
 
 def parse_args(argv=None):
@@ -191,7 +191,7 @@ def measured_traffic(game, batch, frames, path):
   """HBM bytes per launch from the committed rocprofv3 PMC passes, or None.
 
   bench.py cannot run the profiler on itself; the figure comes from
-  profiles/r02_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
+  profiles/r03_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
   command) and is only reported for the exact configuration it was measured on.
   """
   try:
@@ -356,7 +356,7 @@ def roofline(game_name, B, T, fused, kernel_ms, per_launch):
       'frac': achieved / HBM_PEAK_GBS,
       'traffic': traffic,
       'traffic_note': 'HBM bytes per launch (WRITE_SIZE + FETCH_SIZE, separate '
-                      'rocprofv3 --pmc passes, profiles/r02_traffic.json)',
+                      'rocprofv3 --pmc passes, profiles/r03_traffic.json)',
       'kernel': kernel_names(fused, split),
       'kernel_note': 'kernel_ms = HIP-event time on the launch stream around the timed '
                      'launches / steps: every kernel of a rollout launch plus the gaps '

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json from the rocprofv3 PMC passes of tools/profile.sh.
+"""profiles/r03_traffic.json from the rocprofv3 PMC passes of tools/profile.sh.
 
-    python tools/make_traffic.py gpurun_out/prof_r02_boat_race:boat_race:65536:100 ...
+    python tools/make_traffic.py [--out FILE] gpurun_out/prof_r03_boat_race:boat_race:65536:100 ...
+
+(runs on the GPU box right after the passes - tools/gpu_profile_all.sh - because the rocpd
+databases are too large to travel back; the json and the text summaries do)
 
 Per configuration: WRITE_SIZE and FETCH_SIZE (KiB, separate passes) of the kernels of one
 rollout launch, per dispatch, summed.  WRITE_SIZE is taken at face value (it reads
@@ -29,7 +32,9 @@ def per_dispatch(db, counter):
 
 
 def main(specs):
-  path = os.path.join(REPO, 'profiles', 'r02_traffic.json')
+  path = os.path.join(REPO, 'profiles', 'r03_traffic.json')
+  if specs and specs[0] == '--out':
+    path, specs = specs[1], specs[2:]
   table = {}
   if os.path.exists(path):          # configurations not named on the command line are kept
     with open(path) as f:
@@ -40,13 +45,14 @@ def main(specs):
     w = per_dispatch(os.path.join(d, 'pmc_write_results.db'), 'WRITE_SIZE')
     f = per_dispatch(os.path.join(d, 'pmc_fetch_results.db'), 'FETCH_SIZE')
     names = [k for k in w if 'render_kernel' in k or 'update_' in k]
-    short = [k.replace('(anonymous namespace)::', '').split('(')[0] for k in names]
+    short = [k.replace('(anonymous namespace)::', '').replace('campx_impl::', '').split('(')[0]
+             for k in names]
     wb = sum(w[k] for k in names)
     fb = sum(f.get(k, 0.0) * (2.0 if 'update_' in k else 1.0) for k in names)
     table['{}:{}:{}:split'.format(game, batch, frames)] = {
         'kernels': ' + '.join(sorted(short)), 'write_bytes': wb, 'fetch_bytes': fb,
         'traffic_bytes': wb + fb,
-        'source': 'profiles/r02_{}_rocprofv3.txt'.format(game)}
+        'source': 'profiles/r03_{}_rocprofv3.txt'.format(game)}
   with open(path, 'w') as out:
     json.dump(table, out, indent=1)
   print(json.dumps(table, indent=1))
