@@ -77,15 +77,10 @@ struct ActionLoader {
   u32x4 pend[2 * kPairs];
 
   // 16-byte loads (byte-aligned unless B % 16 == 0: unaligned 16-byte accesses are legal on
-  // this stack, tools/probes/unaligned_probe.hip), no branch between them.  Rows past T are
-  // clamped to the last row and neutralised in land().  The batch's last, PARTIAL group of
-  // 16 environments is loaded like any other - its upper bytes are then the first
-  // environments of the next row, masked to "stay" in land() - except where that would read
-  // past the buffer's T * B bytes (the last row: a C-ABI caller may have allocated exactly
-  // that): there the load moves back to the buffer's last 16 bytes and land() shifts the
-  // wanted bytes down.  (Until round 3 the partial group went byte by byte: one lane's chain
-  // of thirty dependent loads per chunk, 20 us on top of every launch whose batch size is
-  // not a multiple of 16.)
+  // this stack, tools/probes/unaligned_probe.hip), no branch between them; rows past T and
+  // groups of 16 environments that are not wholly below B are clamped to valid addresses
+  // inside the buffer's T * B bytes (a C-ABI caller may have allocated exactly that) and
+  // redone or neutralised in land().
   // `lane` counts over all loader waves: 0 .. kLanes-1
   __device__ __forceinline__ void issue(const int8_t* __restrict__ actions, int64_t B, int32_t T,
                                         int t0, int64_t env0, int lane) {
@@ -100,13 +95,13 @@ struct ActionLoader {
       const int v = lane + i * kLanes;
       const int rp = v / kVecPerRow, q = v % kVecPerRow;
       int64_t e = env0 + 16 * q;
-      e = e < B ? e : 0;               // a group wholly past the batch: any valid address
+      e = e + 16 <= B ? e : 0;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int row = t0 + 2 * rp + h;
         row = row < T ? row : T - 1;
         int64_t at = (int64_t)row * B + e;
-        at = at <= last ? at : last;
+        at = at <= last ? at : last;   // (only ever changes a clamped, ignored load)
         pend[2 * i + h] = *reinterpret_cast<const u32x4*>(actions + at);
       }
     }
@@ -153,40 +148,59 @@ struct ActionLoader {
       const int v = lane + i * kLanes;
       const int rp = v / kVecPerRow, q = v % kVecPerRow;
       const int64_t e = env0 + 16 * q;
-      const int n_env = (B - e >= 16) ? 16 : (B - e <= 0 ? 0 : (int)(B - e));   // environments of the group
-      u32x4 both[2];
+      const bool here = e + 16 <= B;
+      const bool real0 = here && (t0 + 2 * rp < T), real1 = here && (t0 + 2 * rp + 1 < T);
+      u32x4 lo = pend[2 * i], hi = pend[2 * i + 1];
+      if (!here && e < B) {
+        // The batch's last, PARTIAL group of 16 environments (one lane per row pair of the
+        // last workgroup).  Loaded like any other group - its upper bytes are then the first
+        // environments of the next row, masked to "stay" - except where that would pass the
+        // end of the buffer (the last row): there the load moves back to the buffer's last
+        // 16 bytes and the wanted bytes are shifted down.  (Until round 3 this went byte by
+        // byte: one lane's chain of thirty dependent loads per chunk, 20 us on top of every
+        // launch whose batch size is not a multiple of 16.)
+        const int n_env = (int)(B - e);
+        u32x4 x[2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = t0 + 2 * rp + h;
-        u32x4 x = pend[2 * i + h];
-        if (last < 0) {
-          // (uniform) the whole buffer is shorter than one load: byte by byte
-          uint32_t w[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
-          if (row < T)
-            for (int k = 0; k < n_env; ++k) {
-              const uint32_t a = (uint8_t)actions[(int64_t)row * B + e + k];
-              w[k >> 2] = (w[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (a << (8 * (k & 3)));
+        for (int h = 0; h < 2; ++h) {
+          const int row = t0 + 2 * rp + h;
+          x[h] = u32x4{0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+          if (row < T && last >= 0) {
+            const int64_t at = (int64_t)row * B + e;
+            x[h] = *reinterpret_cast<const u32x4*>(actions + (at <= last ? at : last));
+            if (at > last) x[h] = shift_down(x[h], (uint32_t)(at - last));
+            x[h] = keep_low(x[h], n_env);
+          } else if (row < T) {
+            // (uniform) the whole buffer is shorter than one load: byte by byte, static
+            // indices only - a dynamically indexed private array lives in scratch
+            uint32_t w[4] = {0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              if (k < n_env) {
+                const uint32_t a = (uint8_t)actions[(int64_t)row * B + e + k];
+                w[k >> 2] = (w[k >> 2] & ~(0xffu << (8 * (k & 3)))) | (a << (8 * (k & 3)));
+              }
             }
-          x = u32x4{w[0], w[1], w[2], w[3]};
-        } else if (n_env < 16 && n_env > 0) {
-          // the batch's partial group: where the load had to move back from the buffer's end,
-          // bring the wanted bytes down; then everything past the batch becomes "stay"
-          const int64_t at = (int64_t)(row < T ? row : T - 1) * B + e;
-          if (at > last) x = shift_down(x, (uint32_t)(at - last));
-          x = keep_low(x, n_env);
+            x[h] = u32x4{w[0], w[1], w[2], w[3]};
+          }
         }
-        const bool real = row < T && n_env > 0;
-        if (!real) x = u32x4{0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
-        bad += count_bad16(x);        // (neutralised bytes are 4: never counted)
-        both[h] = x;
+        const uint32_t l[4] = {x[0].x, x[0].y, x[0].z, x[0].w}, h4[4] = {x[1].x, x[1].y, x[1].z, x[1].w};
+        uint32_t out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = clamp_ids(l[k]) | (clamp_ids(h4[k]) << 4);
+        const u32x4 packed = {out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
+        bad += count_bad16(x[0]) + count_bad16(x[1]);   // (neutralised bytes are 4: never counted)
+        continue;
       }
-      const uint32_t l[4] = {both[0].x, both[0].y, both[0].z, both[0].w};
-      const uint32_t h4[4] = {both[1].x, both[1].y, both[1].z, both[1].w};
+      const uint32_t l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
       uint32_t out[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) out[k] = clamp_ids(l[k]) | (clamp_ids(h4[k]) << 4);
+      for (int k = 0; k < 4; ++k)
+        out[k] = (real0 ? clamp_ids(l[k]) : 0x04040404u) | ((real1 ? clamp_ids(h[k]) : 0x04040404u) << 4);
       const u32x4 packed = {out[0], out[1], out[2], out[3]};
       *reinterpret_cast<u32x4*>(staged + rp * kEnvs + 16 * q) = packed;
+      bad += (real0 ? count_bad16(lo) : 0) + (real1 ? count_bad16(hi) : 0);
     }
     return bad;
   }

@@ -154,6 +154,10 @@ def test_test_local_games_tabulate_and_predict_the_generic_tier(name):
     assert traced.done[traced.reached].sum() > 0
   elif name == 'toll_road':
     assert traced.movers == ['A'] and traced.discount_list == [1.0, 0.5, 0.25, 0.75]
+  elif name == 'trio':
+    assert traced.movers == ['A', 'L', 'T'] and traced.n == 35 ** 3 * 5   # 64-bit tuple entries
+    both = traced.reached & (traced.next_cells[0] == traced.next_cells[1])
+    assert both.any() and (traced.visible[0][both] == 0).all()   # the lift hides the walker
   else:
     assert traced.movers == ['A', 'G']                      # a drape and a sprite
     hidden = traced.reached & (traced.visible[0] == 0)      # the ghost stands on the walker

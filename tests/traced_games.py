@@ -175,7 +175,63 @@ def toll_road(**where):
       z_order='$%EA#', update_schedule='A#$%E', **where)
 
 
-GAMES = {'ice_rink': ice_rink, 'mirror': mirror, 'toll_road': toll_road}
+# --------------------------------------------- three movers: a walker, a lift and a tram
+
+TRIO_ART = ['#######',
+            '#A  T #',
+            '#  L  #',
+            '#    $#',
+            '#######']
+
+
+class Lift(things.Drape):
+  """Goes up on 'up' and down on 'down' in its own column, whatever the walker does."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    a = _action_id(actions)
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    dr = -1 if a == 2 else (1 if a == 3 else 0)
+    if dr and not all_things['#'].curtain[r + dr, c]:
+      self.curtain.zero_()
+      self.curtain[r + dr, c] = 1
+
+
+class Tram(things.Sprite):
+  """A sprite in the top row: left on 'left', right on 'right'.  The frame pays -0.5, +2 when
+  the walker stands on '$', +1 when the walker shares a cell with the lift and +4 when all
+  three are in one column; the walker riding the tram's cell ends the episode."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    a = _action_id(actions)
+    dc = -1 if a == 0 else (1 if a == 1 else 0)
+    r, c = self.position.row, self.position.col + dc
+    if not all_things['#'].curtain[r, c]:
+      self._position = self.Position(r, c)
+    walker, lift = all_things['A'].curtain.numpy(), all_things['L'].curtain.numpy()
+    (wr,), (wc,) = np.nonzero(walker)
+    (lr,), (lc,) = np.nonzero(lift)
+    reward = -0.5 + 2.0 * float(all_things['$'].curtain[wr, wc])
+    reward += 1.0 * float((wr, wc) == (lr, lc))
+    reward += 4.0 * float(wc == lc == self.position.col)
+    the_plot.add_reward(reward)
+    if (wr, wc) == (self.position.row, self.position.col):
+      the_plot.terminate_episode()
+
+
+def trio(**where):
+  """z-order: the lift in front of the walker, the tram in front of both."""
+  return ascii_art_to_game(
+      TRIO_ART, what_lies_beneath=' ',
+      sprites={'T': Tram},
+      drapes={'A': Walker, 'L': Lift, '#': things.FixedDrape, '$': things.FixedDrape},
+      z_order='$#ALT', update_schedule='AL#$T', **where)
+
+
+GAMES = {'ice_rink': ice_rink, 'mirror': mirror, 'toll_road': toll_road, 'trio': trio}
 
 
 # ------------------------------------------------------------- games that must be refused

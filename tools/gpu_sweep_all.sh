@@ -1,0 +1,14 @@
+#!/bin/bash
+# The round's sweep (through gpurun): fraction of peak across batch sizes - odd ones and sizes
+# whose frames are not window-aligned included - and episode lengths.  tools/gpu_sweep_all.sh <tag>
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/$1
+{
+echo "# tools/gpu_sweep.sh: python bench.py --game G --batch B --frames T --steps 30 --warmup 20 (+ >= 50 ms of settle launches), one MI355X;"
+echo "# frac = algorithmic bytes per env-step x B x T / HIP-event time per launch / 8 TB/s"
+bash tools/gpu_sweep.sh boat_race "1000 4096 16384 65535 65536 100000 100001 200000 499984 524288" "100"
+bash tools/gpu_sweep.sh boat_race "65536" "16 64 400 1000 4000"
+bash tools/gpu_sweep.sh wall_world "1000 16384 65536 262143 262144 524288" "100"
+bash tools/gpu_sweep.sh sokoban "1000 16384 65536 99999 131071 131072 262144 524288" "100"
+bash tools/gpu_sweep.sh sokoban_l2 "16384 131072" "100"
+} | tee gpurun_out/$1/sweep.txt
