@@ -224,6 +224,11 @@ class FusedGame(object):
 
   def _action_ids(self, actions, expect):
     """Normalise to int8 ids on the device; one-hot floats go through a kernel."""
+    if (isinstance(actions, (list, tuple)) and len(actions) == gamespec.N_ACTIONS and len(expect) == 1
+        and all(isinstance(x, (int, float)) and x in (0, 1) for x in actions) and sum(actions) == 1):
+      # the reference's plain one-hot LIST, `game.play([1, 0, 0, 0, 0])` (Demo 1 cell 6): one
+      # action for every environment.  (Five ENVIRONMENTS' ids go in as a tensor.)
+      actions = torch.tensor(actions, dtype=torch.float32)
     if not torch.is_tensor(actions):
       actions = torch.as_tensor(actions)
     actions = actions.to(self.device)

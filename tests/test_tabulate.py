@@ -84,28 +84,88 @@ engine.Engine.its_showtime = held
 assert type(game.things['A']).__module__ == 'boat_race'
 game.set_hidden_performance('A', performance_masks())     # the driver's masks a, b, c, d
 t = tabulate.trace(game)
-np.savez(%(out)r, next_cells=t.next_cells, visible=t.visible, reward=t.reward, done=t.done,
-         perf=t.perf, reached=t.reached, init=np.array(t.init_cells), n_states=t.n_states,
-         n_plays=t.n_plays, movers=np.array([ord(c) for c in t.movers]),
-         backdrop=t.backdrop, statics=np.array([ord(c) for c, _ in t.statics]),
-         static_masks=np.array([m for _, m in t.statics]),
-         z=np.array([ord(c) for c in t.z_order]), chars=np.array([ord(c) for c in t.chars]))
-''' % dict(repo=REPO, ref=REFERENCE_EXAMPLES, out=str(tmp_path / 'table.npz'))
+%(save)s
+save_table(t, %(out)r)
+''' % dict(repo=REPO, ref=REFERENCE_EXAMPLES, save=_SAVE_TABLE, out=str(tmp_path / 'table.npz'))
   subprocess.run([sys.executable, '-c', code], check=True)
-  with np.load(tmp_path / 'table.npz') as f:
+  game, got = _traced_from_npz(tmp_path / 'table.npz', 5, 5)
+  assert int(got['n_states']) == 8 and int(got['n_plays']) == 80    # 8 x 5, each twice
+  _check_against_fixture(game, _table_fixture())
+
+
+def _traced_from_npz(path, rows, cols):
+  with np.load(path) as f:
     got = {k: f[k] for k in f.files}
   game = tabulate.TracedGame()
-  game.rows, game.cols = 5, 5
+  game.rows, game.cols = rows, cols
   game.movers = [chr(c) for c in got['movers']]
   game.init_cells = tuple(int(c) for c in got['init'])
   game.z_order = [chr(c) for c in got['z']]
   game.chars = [chr(c) for c in got['chars']]
   game.backdrop = got['backdrop']
   game.statics = [(chr(c), m) for c, m in zip(got['statics'], got['static_masks'])]
-  for k in ('next_cells', 'visible', 'reward', 'done', 'perf', 'reached'):
+  for k in ('next_cells', 'visible', 'reward', 'done', 'discount', 'perf', 'reached'):
     setattr(game, k, got[k])
-  assert int(got['n_states']) == 8 and int(got['n_plays']) == 80    # 8 x 5, each twice
-  _check_against_fixture(game, _table_fixture())
+  return game, got
+
+
+_SAVE_TABLE = r'''
+def save_table(t, path):
+  import numpy as np
+  np.savez(path, next_cells=t.next_cells, visible=t.visible, reward=t.reward, done=t.done,
+           discount=t.discount, perf=t.perf, reached=t.reached, init=np.array(t.init_cells),
+           n_states=t.n_states, n_plays=t.n_plays, movers=np.array([ord(c) for c in t.movers]),
+           backdrop=t.backdrop, statics=np.array([ord(c) for c, _ in t.statics]),
+           static_masks=np.array([m for _, m in t.statics]).reshape(len(t.statics), t.rows, t.cols),
+           z=np.array([ord(c) for c in t.z_order]), chars=np.array([ord(c) for c in t.chars]))
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_EXAMPLES),
+                    reason='reference tree not present (GPU box)')
+@pytest.mark.parametrize('name', ['demo1', 'demo2', 'demo3', 'demo4'])
+def test_unmodified_notebook_classes_tabulate_to_their_goldens(name, golden, tmp_path):
+  """The Demo 1-4 notebooks' own classes (cells exec'd unchanged from the .ipynb under
+  /root/reference, against this repo's `campx` alias), tabulated - Demo 1-3 with the plain
+  one-hot LISTS those notebooks pass to play() - and the table walked over the golden
+  action streams: the frames the REFERENCE engine produced (tests/golden/demoN.npz)."""
+  from oracle.table_replay import TableWalker
+  from test_generic_golden import NOTEBOOK_GAMES
+  notebook, cells, build = NOTEBOOK_GAMES[name]
+  code = r'''
+import json, sys, collections, itertools
+import numpy as np, torch, six
+sys.path.insert(0, %(repo)r)                       # this repo: `campx` -> campx_amd
+from campx import things
+from campx.ascii_art import ascii_art_to_game, Partial
+from campx import engine
+from campx_amd import tabulate
+nb = json.load(open(%(ref)r + '/' + %(notebook)r))
+ns = dict(globals())
+for i in %(cells)r:
+    exec(compile(''.join(nb['cells'][i]['source']), 'cell %%d' %% i, 'exec'), ns)
+game = eval(%(build)r, ns)
+assert type(game.things['A']).__module__ == '__main__'    # the notebook's own class
+if %(name)r != 'demo4':     # Demo 1-3 call play([1, 0, 0, 0, 0])
+    game.set_action_set([[int(i == a) for i in range(5)] for a in range(5)])
+%(save)s
+save_table(tabulate.trace(game, actions=game._action_set), %(out)r)
+''' % dict(repo=REPO, ref=REFERENCE_EXAMPLES, notebook=notebook, cells=cells, build=build,
+           name=name, save=_SAVE_TABLE, out=str(tmp_path / 'table.npz'))
+  subprocess.run([sys.executable, '-c', code], check=True)
+  gold = golden(name)
+  H, W = gold['board'].shape[-2:]
+  traced, _ = _traced_from_npz(tmp_path / 'table.npz', H, W)
+  assert [ord(c) for c in traced.chars] == gold['chars'].tolist() and traced.movers == ['A']
+  T, N = gold['actions'].shape
+  walker = TableWalker(traced, N)
+  want = walker.rollout(gold['actions'], reset_first=True)
+  for k in ('reward', 'discount', 'done'):
+    assert _same(want[k], gold[k]), k
+  for t in range(T):
+    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    assert np.array_equal(board, gold['board'][t + 1]), t
+    assert np.array_equal(layered, gold['layered'][t + 1].astype(np.int8)), t
 
 
 def test_library_boat_race_tabulates_to_the_reference_table():
@@ -422,6 +482,10 @@ def test_zero_argument_make_game_runs_batched_with_a_default_batch():
     assert np.array_equal(obs.board[4095].cpu().numpy(), ref_obs.board.numpy())
     assert float(reward[7]) == float(ref_reward) and float(discount[7]) == float(ref_discount)
   assert single.game_over and bool(game.fused.done.all())
+  obs, reward, _ = game.play([0, 1, 0, 0, 0])            # the notebooks' plain one-hot list
+  assert float(reward[0]) == -0.125 and bool((reward == reward[0]).all())
+  obs, reward, _ = game.play(4)                          # ... or one id
+  assert bool((reward == -0.125).all())
 
 
 @pytest.mark.gpu
