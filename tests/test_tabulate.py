@@ -482,8 +482,11 @@ def test_zero_argument_make_game_runs_batched_with_a_default_batch():
     assert np.array_equal(obs.board[4095].cpu().numpy(), ref_obs.board.numpy())
     assert float(reward[7]) == float(ref_reward) and float(discount[7]) == float(ref_discount)
   assert single.game_over and bool(game.fused.done.all())
+  fresh = traced_games.ice_rink()                        # (every environment starts over)
+  fresh.its_showtime()
+  _, want, _ = fresh.play(torch.tensor([0., 1., 0., 0., 0.]))
   obs, reward, _ = game.play([0, 1, 0, 0, 0])            # the notebooks' plain one-hot list
-  assert float(reward[0]) == -0.125 and bool((reward == reward[0]).all())
+  assert float(reward[0]) == float(want) and bool((reward == reward[0]).all())
   obs, reward, _ = game.play(4)                          # ... or one id
   assert bool((reward == -0.125).all())
 
