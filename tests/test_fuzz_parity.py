@@ -115,3 +115,52 @@ def test_random_games(seed, mode):
       assert _same(discount.cpu().numpy(), ref['discount'][t])
   finally:
     fused.SPLIT_ROLLOUT, fused.COMPILE_TABLE = saved
+
+
+def _small_random_game(rng):
+  """A random game whose reachable state space the host can tabulate in seconds."""
+  while True:
+    build, rows = random_game(rng)
+    cells = len(rows) * len(rows[0])
+    boxes = sum(ch in ''.join(rows) for ch in 'XYZ')
+    if (boxes == 0 and cells <= 64) or (boxes == 1 and cells <= 16):
+      return build, rows, boxes
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_FUZZ_TABLE_SEEDS', '30'))))
+def test_device_built_tables_equal_tables_from_running_the_python_rules(seed):
+  """Two independent derivations of a game's state table: the rule INTERPRETER KERNEL run over
+  every (cell[, cell], action) on the device (campx_spec_compile / campx_pair_table_build),
+  and campx_amd.tabulate running the rule classes' ordinary Python update() bodies on the
+  generic tier over every reachable state on the host.  Every entry the game can reach must
+  agree: next cells, who shows, reward, game-over."""
+  from campx_amd import tabulate
+  rng = np.random.RandomState(5000 + seed)
+  build, rows, boxes = _small_random_game(rng)
+  traced = tabulate.trace(build())
+  game = build(batch=64, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  assert f.traced is None and f.uses_table          # rule classes: device-built tables
+  movers = [f.chars[f.spec.dyn_layer[d]] for d in range(f.n_dyn)]
+  assert movers == traced.movers, (rows, movers, traced.movers)
+  idx = np.flatnonzero(traced.reached)
+  assert len(idx) >= 5
+  if f.n_dyn == 1:
+    for i in idx:
+      tr = f.spec.table[int(i)]
+      assert tr.next_cell == traced.next_cells[0, i], (rows, i)
+      assert (0 if tr.paint & 0x80 else 1) == traced.visible[0, i], (rows, i)
+      assert (tr.done & 1) == traced.done[i] and (tr.done >> 4) == 0
+      assert _same(np.float32(tr.reward), traced.reward[i]), (rows, i)
+  else:
+    raw = f._pair_table.cpu().numpy()
+    rewards = raw[:1024].view(np.float32)
+    entries = raw[1024:].view(np.uint32)
+    e = entries[idx]
+    assert np.array_equal(e & 0x7f, traced.next_cells[0, idx]), rows
+    assert np.array_equal((e >> 7) & 0x7f, traced.next_cells[1, idx]), rows
+    assert np.array_equal((e >> 14) & 1, traced.visible[0, idx]), rows
+    assert np.array_equal((e >> 15) & 1, traced.visible[1, idx]), rows
+    assert np.array_equal((e >> 16) & 1, traced.done[idx]), rows
+    assert _same(rewards[(e >> 19) & 0xff], traced.reward[idx]), rows
