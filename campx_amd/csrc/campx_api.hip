@@ -302,7 +302,9 @@ int32_t campx_spec_validate(const CampxSpec* s) {
   if (s->n_rules < 0 || s->n_rules > CAMPX_MAX_RULES) return CAMPX_ESPEC;
   for (int d = 0; d < s->n_dyn; ++d) {
     if (s->dyn_layer[d] < 0 || s->dyn_layer[d] >= s->n_layers) return CAMPX_ESPEC;
-    if (s->dyn_z[d] < 1 || s->dyn_z[d] > 255) return CAMPX_ESPEC;
+    // (z rank 0 = behind the backdrop: a tracked value that is never painted - the z-order
+    // mode of a host-tabulated game that re-orders its things, campx_amd/tabulate.py)
+    if (s->dyn_z[d] < (s->table_only == 1 && d > 0 ? 0 : 1) || s->dyn_z[d] > 255) return CAMPX_ESPEC;
     if (s->dyn_row0[d] < 0 || s->dyn_row0[d] >= s->rows) return CAMPX_ESPEC;
     if (s->dyn_col0[d] < 0 || s->dyn_col0[d] >= s->cols) return CAMPX_ESPEC;
   }

@@ -18,16 +18,24 @@ the game can reach:
 
 A state is identified by the byte image of every curtain, sprite position and the
 z-order.  Afterwards the moving things are the entities whose image differs between two
-reached states; everything else is scenery.  The tabulation is exact under conditions
+reached states; everything else is scenery.  A game that re-orders its things at run time
+(`Plot.change_z_order`, campx/plot.py:121-159, applied by campx/engine.py:242-281) has one
+more piece of state, WHICH of the z-orders it has reached is in force: that "mode" is
+tabulated like the cell of one more moving thing that is never painted (the kernels index
+their tables by up to four cells and care about nothing else), and what an order changes
+on the screen - which of two things on one cell shows - is already in the table entries'
+"is the character its cell shows" bits.  The tabulation is exact under conditions
 that are CHECKED while tabulating, never assumed (ValueError otherwise):
 
 * every moving thing occupies exactly one cell in every reached state (a drape's curtain
-  has exactly one 1; a sprite keeps its `visible` flag), there are at most four of them,
+  has exactly one 1; a sprite keeps its `visible` flag), there are at most four of them -
+  the mode of a re-ordering game counts as one, and it has at most rows*cols values -,
   the board has at most 128 cells and 16 characters;
-* the Backdrop's curtain and the z-order never change (no `change_z_order`, no sprite
-  painted into the backdrop: campx/rendering.py:128,150);
-* every rendered board equals "backdrop, then things in z-order" computed from the cells
-  alone - which also yields whether a moving thing is the character its cell shows;
+* the Backdrop's curtain never changes (no sprite painted into the backdrop:
+  campx/rendering.py:128,150), and no reached z-order changes how the SCENERY paints (two
+  overlapping static drapes swapping places);
+* every rendered board equals "backdrop, then things in the state's z-order" computed from
+  the cells alone - which also yields whether a moving thing is the character its cell shows;
 * at most fifteen distinct discounts other than the default - 1.0, or 0.0 on the frame
   `terminate_episode()` was called - are reported (`change_default_discount`,
   `terminate_episode(d)`: campx/plot.py:161-184, 232-257; the tables carry a 4-bit code);
@@ -71,9 +79,10 @@ def _fail(msg):
 
 
 def _image(engine):
-  """(per-thing byte images in z-order, backdrop image, z-order string)."""
+  """(per-thing byte images by ascending character, backdrop image, z-order string)."""
   parts = []
-  for ch, ent in engine.things.items():
+  for ch in sorted(engine.things.keys()):
+    ent = engine.things[ch]
     if isinstance(ent, _things.Sprite):
       parts.append(bytes((ent.position.row & 0xff, ent.position.col & 0xff,
                           1 if ent.visible else 0)))
@@ -120,8 +129,17 @@ class TracedGame(object):
     done uint8 [n], discount float32 [n], dcode uint8 [n] (0 = the default discount, else
     an index into `discount_list`), perf int8 [n], reached bool [n] (entries the game can
     get to; the others are self-loops that pay nothing);
+    mode_orders: the z-orders the game reaches (lists of characters back to front; the
+      first is `z_order`, the one after `its_showtime()`).  With more than one, the tables
+      track one more "thing" after the movers - K = len(movers) + 1 = `n_tracked` - whose
+      "cell" is the index of the order in force and which is never visible;
     n_states, n_plays: size of the reachable state space and what tabulating it cost.
   """
+
+  @property
+  def n_tracked(self):
+    """Things the tables are indexed by: the movers, plus the z-order mode if there is one."""
+    return len(self.movers) + (1 if len(self.mode_orders) > 1 else 0)
 
   def done_bytes(self):
     """uint8 [n]: bit 0 done, bits 4-7 the discount code - CampxTransition.done and the
@@ -133,7 +151,7 @@ class TracedGame(object):
     return (self.next_cells | (self.visible << 7)).astype(np.uint8)
 
   def cells_of(self, index):
-    HW, K = self.rows * self.cols, len(self.movers)
+    HW, K = self.rows * self.cols, self.n_tracked
     rest, cells = index // N_ACTIONS, []
     for _ in range(K):
       cells.append(rest % HW)
@@ -146,14 +164,18 @@ class TracedGame(object):
       idx = idx * HW + int(c)
     return idx * N_ACTIONS + action
 
-  def model_board(self, cells):
-    """The flat board (character codes) when the movers stand at `cells`: backdrop, then
-    every thing in z-order (campx/engine.py:306-324)."""
+  def model_board(self, cells, movers=True):
+    """The flat board (character codes) when the movers stand at `cells` (followed by the
+    z-order mode, if the game has more than one): backdrop, then every thing in that
+    z-order (campx/engine.py:306-324).  `movers=False`: the scenery alone."""
     board = self.backdrop.copy().reshape(-1)
     static = dict(self.statics)
     where = {ch: c for ch, c in zip(self.movers, cells)}
-    for ch in self.z_order:
+    mode = cells[len(self.movers)] if len(self.mode_orders) > 1 else 0
+    for ch in self.mode_orders[mode]:
       if ch in where:
+        if not movers:
+          continue
         board[where[ch]] = ord(ch)
       else:
         board[static[ch].reshape(-1) != 0] = ord(ch)
@@ -188,8 +210,9 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
 
   things0, backdrop0, z0 = _image(probe)
   # state bookkeeping
-  index_of = {things0: 0}
+  index_of = {(things0, z0): 0}
   images = [things0]
+  orders = [z0]              # per state: the z-order in force (characters back to front)
   engines = [probe]          # an engine standing in that state, or None (only seen ended)
   second = {}                # state -> an engine that arrived there over another history
   boards = [obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()]
@@ -208,12 +231,10 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     if backdrop != backdrop0:
       _fail('the Backdrop changed during play (a Backdrop.update(), or a sprite painted '
             'before the first drape in z-order writes into it: campx/rendering.py:128,150)')
-    if z != z0:
-      _fail('the z-order changed during play (Plot.change_z_order): generic tier only')
     over = bool(eng.game_over)
     discount = float(np.float32(discount))
     board = obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()
-    return things, _reward_f32(reward), discount, over, board
+    return (things, z), _reward_f32(reward), discount, over, board
 
   while queue:
     s = queue.popleft()
@@ -223,7 +244,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
       t = index_of.get(things)
       if t is None:
         t = index_of[things] = len(images)
-        images.append(things)
+        images.append(things[0])
+        orders.append(things[1])
         boards.append(board)
         engines.append(None)
       elif boards[t] != board:
@@ -243,21 +265,31 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
       things, reward, discount, over, board = step(eng, a)
       got = _Edge(index_of.get(things), reward, discount, over, board)
       if not got.same(edges[(t, a)]):
-        _fail('the game keeps state outside its curtains and sprite positions (the Plot, the '
-              'frame number, attributes of an entity): the same board reached over two '
-              'histories answered action {} differently'.format(a))
+        _fail('the game keeps state outside its curtains, sprite positions and z-order (the '
+              'Plot, the frame number, attributes of an entity): the same board reached over '
+              'two histories answered action {} differently'.format(a))
 
   # ---- who moves
-  order = list(probe.things.keys())                       # z-order
+  order = sorted(probe.things.keys())                     # the order of _image()'s parts
   varying = [i for i in range(len(order))
              if any(img[i] != things0[i] for img in images)]
   schedule = []
   for _, members in probe._update_groups:
     schedule.extend(ent.character for ent in members)
   movers = [ch for ch in schedule if order.index(ch) in varying]
-  if not 1 <= len(movers) <= gamespec.MAX_DYN:
-    _fail('needs between 1 and {} moving things, found {} ({})'.format(
-        gamespec.MAX_DYN, len(movers), ''.join(movers) or 'nothing moves'))
+  # the z-orders reached (Plot.change_z_order): the one in force is one more tracked "cell"
+  modes = []
+  for z in orders:
+    if z not in modes:
+      modes.append(z)
+  n_tracked = len(movers) + (1 if len(modes) > 1 else 0)
+  if not 1 <= len(movers) or n_tracked > gamespec.MAX_DYN:
+    _fail('needs between 1 and {} moving things{}, found {} ({})'.format(
+        gamespec.MAX_DYN, ' (the z-order in force counts as one)' if len(modes) > 1 else '',
+        len(movers), ''.join(movers) or 'nothing moves'))
+  if len(modes) > HW:
+    _fail('{} different z-orders are reached; the tables have room for rows*cols = {}'.format(
+        len(modes), HW))
   K = len(movers)
 
   def cell_of(img, ch):
@@ -278,7 +310,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
 
   game = TracedGame()
   game.rows, game.cols, game.chars = H, W, chars
-  game.z_order = order
+  game.z_order = list(z0)
+  game.mode_orders = [list(z) for z in modes]
   game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
   game.movers = movers
   game.statics = []
@@ -298,8 +331,18 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   if len(game.statics) > gamespec.MAX_STATIC:
     _fail('more than {} static things'.format(gamespec.MAX_STATIC))
 
-  state_cells = [tuple(cell_of(img, ch) for ch in movers) for img in images]
+  state_cells = [tuple(cell_of(img, ch) for ch in movers) +
+                 ((modes.index(z),) if len(modes) > 1 else ())
+                 for img, z in zip(images, orders)]
   game.init_cells = state_cells[0]
+
+  # ---- the render kernels lay ONE scenery row under the movers: no order may change it
+  for m in range(1, len(modes)):
+    probe_cells = tuple(state_cells[0][:K]) + (m,)
+    if (game.model_board(probe_cells, movers=False).tobytes() !=
+        game.model_board(state_cells[0], movers=False).tobytes()):
+      _fail('a z-order change re-orders overlapping static things (the scenery itself changes); '
+            'only moving things may change places')
 
   # ---- every reached board is "backdrop + things in z-order" of the cells alone
   for cells, board in zip(state_cells, boards):
@@ -340,10 +383,11 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
       return int(b == fwd) - int(b == back)
 
   # ---- the dense table
-  n = HW ** K * N_ACTIONS
+  Kt = n_tracked
+  n = HW ** Kt * N_ACTIONS
   game.n = n
-  game.next_cells = np.zeros((K, n), np.uint8)
-  game.visible = np.zeros((K, n), np.uint8)
+  game.next_cells = np.zeros((Kt, n), np.uint8)
+  game.visible = np.zeros((Kt, n), np.uint8)
   game.reward = np.full((n,), np.nan, np.float32)
   game.done = np.zeros((n,), np.uint8)
   game.discount = np.ones((n,), np.float32)
@@ -353,7 +397,7 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   game.reached = np.zeros((n,), bool)
   # entries nobody can reach: stay where you are, pay nothing
   idx = np.arange(n) // N_ACTIONS
-  for k in range(K - 1, -1, -1):
+  for k in range(Kt - 1, -1, -1):
     game.next_cells[k] = idx % HW
     idx = idx // HW
   codes = [ord(ch) for ch in movers]
@@ -364,6 +408,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     for k in range(K):
       game.next_cells[k, i] = dst[k]
       game.visible[k, i] = int(board[dst[k]] == codes[k])
+    if Kt > K:
+      game.next_cells[K, i] = dst[K]            # the mode: never visible
     game.reward[i] = e.reward
     game.done[i] = int(e.over)
     game.discount[i] = e.discount
@@ -396,7 +442,7 @@ def to_spec(game):
   spec.magic, spec.version = gamespec.SPEC_MAGIC, gamespec.SPEC_VERSION
   spec.rows, spec.cols = H, W
   spec.n_layers = len(game.chars)
-  spec.n_dyn, spec.n_static = len(game.movers), len(game.statics)
+  spec.n_dyn, spec.n_static = game.n_tracked, len(game.statics)
   spec.n_rules = 0
   spec.table_only = 1
   spec.any_reward = int(game.any_reward)
@@ -406,6 +452,12 @@ def to_spec(game):
     spec.dyn_layer[d] = layer_of[ch]
     spec.dyn_z[d] = z_of[ch]
     spec.dyn_row0[d], spec.dyn_col0[d] = divmod(int(game.init_cells[d]), W)
+  if game.n_tracked > len(game.movers):
+    # the z-order mode: a "thing" of z rank 0 - behind the backdrop, never painted - whose
+    # cell is the index of the order in force (0 after its_showtime())
+    d = len(game.movers)
+    spec.dyn_layer[d], spec.dyn_z[d] = spec.dyn_layer[0], 0
+    spec.dyn_row0[d], spec.dyn_col0[d] = 0, 0
   top_layer = np.array([[layer_of[chr(c)] for c in row] for row in game.backdrop], np.uint8)
   top_z = np.zeros((H, W), np.uint8)
   cover = np.zeros((H, W), np.uint16)
@@ -441,7 +493,7 @@ def to_spec(game):
   for code, value in enumerate(game.discount_list):
     if code:
       spec.discount_list[code] = float(value)
-  if len(game.movers) == 1:
+  if game.n_tracked == 1:
     for i in range(game.n):
       tr = spec.table[i]
       nxt = int(game.next_cells[0, i])

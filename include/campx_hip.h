@@ -133,7 +133,13 @@ typedef struct CampxSpec {
   int32_t reserved0[2];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_MAX_DYN];     /* layer painted by dynamic thing d */
-  int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop) */
+  int32_t dyn_z[CAMPX_MAX_DYN];         /* its z rank, 1 = rearmost thing (0 = backdrop).  A
+                                           host-tabulated game (table_only) may give its LAST
+                                           things rank 0: values the tables are indexed by that
+                                           are never painted - the z-order in force of a game
+                                           that calls Plot.change_z_order (campx/plot.py:121-159),
+                                           whose effect on the screen is in the table entries'
+                                           "is the character its cell shows" bits */
   int32_t dyn_row0[CAMPX_MAX_DYN];      /* position in the art */
   int32_t dyn_col0[CAMPX_MAX_DYN];
   CampxRule rules[CAMPX_MAX_RULES];     /* update-schedule order */

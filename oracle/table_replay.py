@@ -9,7 +9,7 @@ indexing, one frame at a time, with the batched engine's episode rule: an enviro
 whose episode ended is rebuilt from the start state before its next action (what the
 reference's driver does with `make_game()` per episode, examples/reinforce.py:122).
 Observations are rendered the way the reference renders them - backdrop, then every
-thing in z-order onto a flat board, layers by equality with the board
+thing in (the environment's current) z-order onto a flat board, layers by equality with the board
 (campx/engine.py:306-324, campx/rendering.py:204-215) - from the cells alone.
 
 It shares no code with the HIP path; that the table itself is right is pinned elsewhere
@@ -28,7 +28,7 @@ class TableWalker(object):
   def __init__(self, game, batch):
     self.game = game
     self.B = int(batch)
-    self.K = len(game.movers)
+    self.K = game.n_tracked          # the movers, plus the z-order mode of a re-ordering game
     self.HW = game.rows * game.cols
     self.cells = np.tile(np.array(game.init_cells, np.int64)[:, None], (1, self.B))
     self.over = np.zeros(self.B, bool)
@@ -75,18 +75,22 @@ class TableWalker(object):
     return out
 
   def render(self, cells):
-    """cells [K, N] -> (board int8 [N, H, W], layered int8 [N, L, H, W])."""
+    """cells [K, N] -> (board int8 [N, H, W], layered int8 [N, L, H, W]).  A game that
+    re-orders its things (campx/engine.py:242-281) is painted in each environment's own
+    order, the one its last tracked value names."""
     g = self.game
     N = cells.shape[1]
     board = np.tile(g.backdrop.reshape(1, -1).astype(np.int16), (N, 1))
     static = dict(g.statics)
     who = {ch: k for k, ch in enumerate(g.movers)}
-    rows = np.arange(N)
-    for ch in g.z_order:                              # back to front
-      if ch in who:
-        board[rows, cells[who[ch]]] = ord(ch)
-      else:
-        board[:, np.flatnonzero(static[ch].reshape(-1))] = ord(ch)
+    modes = cells[len(g.movers)] if len(g.mode_orders) > 1 else np.zeros(N, np.int64)
+    for m, order in enumerate(g.mode_orders):
+      rows = np.flatnonzero(modes == m)
+      for ch in order:                                # back to front
+        if ch in who:
+          board[rows, cells[who[ch]][rows]] = ord(ch)
+        else:
+          board[np.ix_(rows, np.flatnonzero(static[ch].reshape(-1)))] = ord(ch)
     layered = np.stack([(board == ord(ch)) for ch in g.chars], axis=1).astype(np.int8)
     return (board.astype(np.int8).reshape(N, g.rows, g.cols),
             layered.reshape(N, len(g.chars), g.rows, g.cols))

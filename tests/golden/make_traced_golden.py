@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate `traced_<game>.npz`: what the REFERENCE engine does with the test-local games of
 tests/traced_games.py (arbitrary Python classes: a skater that slides many cells, a sprite
-that mirrors a walker, a walker whose tiles change the frame's discount).
+that mirrors a walker, a walker whose tiles change the frame's discount, a mole that
+changes its place in the z-order).
 
 Run in the build container only (needs /root/reference):
 
@@ -83,8 +84,9 @@ def run(build, actions):
 
 
 def main():
-  for i, name in enumerate(sorted(traced_games.GAMES)):
-    actions = np.random.RandomState(300 + i).randint(0, 5, size=(80, 24))
+  seeds = dict(ice_rink=300, mirror=301, toll_road=302, trio=303, burrow=304)
+  for name in sorted(traced_games.GAMES):
+    actions = np.random.RandomState(seeds[name]).randint(0, 5, size=(80, 24))
     data = run(traced_games.GAMES[name], actions)
     path = os.path.join(HERE, 'traced_' + name + '.npz')
     np.savez_compressed(path, **data)

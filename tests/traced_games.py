@@ -231,7 +231,54 @@ def trio(**where):
       z_order='$#ALT', update_schedule='AL#$T', **where)
 
 
-GAMES = {'ice_rink': ice_rink, 'mirror': mirror, 'toll_road': toll_road, 'trio': trio}
+# ------------------------------- one mover that changes the z-order: a mole and its lawn
+
+BURROW_ART = ['#########',
+              '#A ===  #',
+              '# d===u #',
+              '#  === $#',
+              '#########']
+
+
+class Mole(things.Drape):
+  """One cell per frame (walls stop it).  Stepping on the 'd' tile it digs in - the Plot is
+  told to move it behind everything (`change_z_order('A', None)`, campx/plot.py:121-159) -
+  and from then on the lawn '=' and the tiles hide it; stepping on 'u' it comes up again, in
+  front of the lawn (`change_z_order('A', '=')`).  -0.25 per frame; +0.5 when the previous
+  render did not show it (layers['A'] is the occluded layer, campx/rendering.py:204-209);
+  +3 and the end of the episode on '$', but only above ground."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = _DELTA[_action_id(actions)]
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    was_shown = bool(layers['A'].sum())
+    if not all_things['#'].curtain[r + dr, c + dc]:
+      r, c = r + dr, c + dc
+      self.curtain.zero_()
+      self.curtain[r, c] = 1
+    reward = -0.25 + (0.0 if was_shown else 0.5)
+    if all_things['d'].curtain[r, c]:
+      the_plot.change_z_order('A', None)
+    if all_things['u'].curtain[r, c]:
+      the_plot.change_z_order('A', '=')
+    if all_things['$'].curtain[r, c] and was_shown:
+      reward += 3.0
+      the_plot.terminate_episode()
+    the_plot.add_reward(reward)
+
+
+def burrow(**where):
+  return ascii_art_to_game(
+      BURROW_ART, what_lies_beneath=' ',
+      drapes={'A': Mole, '#': things.FixedDrape, '=': things.FixedDrape,
+              'd': things.FixedDrape, 'u': things.FixedDrape, '$': things.FixedDrape},
+      z_order='du$=A#', update_schedule='A#=du$', **where)
+
+
+GAMES = {'ice_rink': ice_rink, 'mirror': mirror, 'toll_road': toll_road, 'trio': trio,
+         'burrow': burrow}
 
 
 # ------------------------------------------------------------- games that must be refused
@@ -269,11 +316,31 @@ class Discounter(things.Drape):
 
 
 class Reorderer(things.Drape):
+  """Swaps two overlapping STATIC drapes: the scenery itself changes."""
+
   def update(self, actions, board, layers, backdrop, all_things, the_plot):
     if actions is None:
       return
     self.curtain.set_(torch.roll(self.curtain, 1, 1))
-    the_plot.change_z_order('A', None)
+    the_plot.change_z_order('#', None)
+
+
+def refused_scenery(**where):
+  return ascii_art_to_game(['A   ', '  # '], what_lies_beneath=' ',
+                           drapes={'A': Reorderer, '#': things.FixedDrape,
+                                   'o': Partial(Patch, 1, 2)},
+                           z_order='o#A', update_schedule='A#o', **where)
+
+
+class Patch(things.Drape):
+  """A static one-cell drape placed by its arguments (not in the art): here under a '#'."""
+
+  def __init__(self, curtain, character, row, col):
+    super(Patch, self).__init__(curtain, character)
+    self.curtain[row, col] = 1
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    pass
 
 
 def refused(cls, **where):
