@@ -15,7 +15,7 @@ there is no CPU fallback for the fused tier.
 import ctypes
 import os
 
-from .gamespec import CampxSpec, CampxShapeSpec
+from .gamespec import CampxSpec, CampxShapeSpec, CampxWideSpec
 
 _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
@@ -25,7 +25,10 @@ EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
            'campx_shape_spec_size', 'campx_shape_spec_validate',
-           'campx_shape_rollout_launch', 'campx_check_actions_launch',
+           'campx_shape_rollout_launch',
+           'campx_wide_spec_size', 'campx_wide_spec_validate', 'campx_wide_tables_bytes',
+           'campx_wide_tables_build', 'campx_wide_reset_launch', 'campx_wide_rollout_launch',
+           'campx_check_actions_launch',
            'campx_onehot_to_ids_launch', 'campx_stream_create_cu_subset',
            'campx_stream_destroy', 'campx_strerror',
            'campx_last_hip_error', 'campx_device_arch')
@@ -88,6 +91,20 @@ def _load():
   lib.campx_shape_rollout_launch.restype = i32
   lib.campx_shape_rollout_launch.argtypes = [shape_p, vp, CampxState, vp, vp, CampxOutputs,
                                              i64, i32, i32, i32, vp]
+  wide_p = ctypes.POINTER(CampxWideSpec)
+  lib.campx_wide_spec_size.restype = i32
+  lib.campx_wide_spec_size.argtypes = []
+  lib.campx_wide_spec_validate.restype = i32
+  lib.campx_wide_spec_validate.argtypes = [wide_p]
+  lib.campx_wide_tables_bytes.restype = i64
+  lib.campx_wide_tables_bytes.argtypes = [wide_p]
+  lib.campx_wide_tables_build.restype = i32
+  lib.campx_wide_tables_build.argtypes = [wide_p, vp, vp]
+  lib.campx_wide_reset_launch.restype = i32
+  lib.campx_wide_reset_launch.argtypes = [wide_p, vp, CampxState, CampxOutputs, i64, vp]
+  lib.campx_wide_rollout_launch.restype = i32
+  lib.campx_wide_rollout_launch.argtypes = [wide_p, vp, CampxState, vp, CampxOutputs, i64, i32,
+                                            i32, vp]
   lib.campx_check_actions_launch.restype = i32
   lib.campx_check_actions_launch.argtypes = [vp, i64, vp, vp]
   lib.campx_onehot_to_ids_launch.restype = i32
@@ -104,6 +121,9 @@ def _load():
   lib.campx_device_arch.argtypes = [i32, ctypes.c_char_p, i32]
   if lib.campx_shape_spec_size() != ctypes.sizeof(CampxShapeSpec):
     raise ImportError('CampxShapeSpec layout mismatch between gamespec.py and '
+                      'libcampx_hip.so: rebuild the library')
+  if lib.campx_wide_spec_size() != ctypes.sizeof(CampxWideSpec):
+    raise ImportError('CampxWideSpec layout mismatch between gamespec.py and '
                       'libcampx_hip.so: rebuild the library')
   if lib.campx_spec_size() != ctypes.sizeof(CampxSpec):
     raise ImportError('CampxSpec layout mismatch between gamespec.py ({} B) and '
@@ -128,7 +148,7 @@ def _load_ops():
 
 
 ops = _load_ops()
-OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'shape_rollout',
+OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'shape_rollout', 'wide_rollout',
             'onehot_to_ids', 'check_actions')
 
 

@@ -22,7 +22,7 @@ CSRC = os.path.join(HERE, 'csrc')
 # One translation unit per kernel family + the C ABI / dispatch; an A/B variant of one
 # kernel rebuilds one object (tools/build_variants.py).
 UNITS = ('campx_api', 'k_interp', 'k_rollout_table', 'k_step', 'k_update', 'k_render',
-         'k_shape', 'k_misc')
+         'k_shape', 'k_wide', 'k_misc')
 SRCS = [os.path.join(CSRC, u + '.hip') for u in UNITS]
 HEADERS = [os.path.join(CSRC, 'campx_common.hip.h'),
            os.path.join(REPO, 'include', 'campx_hip.h')]

@@ -8,6 +8,7 @@
 #define CAMPX_COMMON_HIP_H_
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <map>
@@ -549,6 +550,19 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
                       hipStream_t stream);
 
 // k_render.hip: the observation stream of the two-kernel path
+// Where a render launch finds a game's tables (k_render.hip).
+struct RenderSource {
+  int32_t rows, cols, n_layers, n_dyn;
+  int32_t dyn_layer[CAMPX_MAX_DYN];
+  uint8_t layer_char[CAMPX_MAX_LAYERS];
+  const int8_t* rot_obs;      // device: 16 x (round_up(R, 16) + 16) bytes, see CampxSpec.rot_obs
+  const int8_t* rot_board;
+  const uint8_t* top_layer;   // device: scenery layer per cell (one-byte trace only)
+  bool wide;                  // 16-bit trace entries (k_wide.hip)
+};
+int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* dst, int64_t B,
+                           int32_t T, int64_t plane_rows, int64_t pitch, bool is_board, int fmt,
+                           hipStream_t stream);
 int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
                       int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, int64_t pitch,
                       bool is_board, int fmt, hipStream_t stream);

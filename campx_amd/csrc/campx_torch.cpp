@@ -10,6 +10,7 @@
 //   campx::rollout  T consecutive frames in one launch
 //   campx::update / campx::render   the two kernels of a rollout as separate ops
 //   campx::shape_rollout            the shape tier (Hello World): reset / step / rollout
+//   campx::wide_rollout             the wide tier (boards above 128 cells): reset / step / rollout
 //   campx::onehot_to_ids / campx::check_actions   action-format helpers
 //
 // Contract: every tensor is caller-owned and contiguous; outputs are written in
@@ -416,6 +417,89 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
            "campx_shape_rollout_launch");
 }
 
+// Wide tier (boards above 128 cells, include/campx_hip.h): reset (actions = None), one frame
+// (actions [B], outputs [B...]) or T frames (actions [T, B]) through one op.  `tables`: the
+// device blob campx_wide_tables_build() filled.  `trace`: int16 [B] / [T, B] (rows may be
+// padded like the other per-frame streams).  With T frames, `obs` is [T, B, L, H, W] (every
+// frame) or [B, L, H, W] (the last one).
+void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& pos, Tensor& done,
+                  const OptTensor& ret, const OptTensor& actions, Tensor& obs, const OptTensor& board,
+                  const OptTensor& reward, const OptTensor& discount, const OptTensor& step_done,
+                  const OptTensor& perf, Tensor& trace, const OptTensor& bad_count,
+                  const OptTensor& bad_flag, bool reset_first) {
+  TORCH_CHECK(spec_host.device().is_cpu() && spec_host.scalar_type() == at::kByte &&
+                  spec_host.is_contiguous() && spec_host.numel() == (int64_t)sizeof(CampxWideSpec),
+              "campx: spec_host must be the CampxWideSpec blob as a CPU uint8 tensor");
+  const CampxWideSpec* hs = reinterpret_cast<const CampxWideSpec*>(spec_host.data_ptr());
+  TORCH_CHECK(pos.device().is_cuda() && pos.dim() == 2,
+              "campx::wide_rollout: state must be on a HIP device (no CPU implementation)");
+  const c10::Device dev = pos.device();
+  const int64_t B = pos.size(1), L = hs->n_layers, H = hs->rows, W = hs->cols;
+  want(pos, "pos", at::kChar, dev, {2, B});
+  want(done, "done", at::kByte, dev, {B});
+  if (ret.has_value()) want(*ret, "ret", at::kFloat, dev, {B});
+  TORCH_CHECK(tables.device() == dev && tables.scalar_type() == at::kByte && tables.is_contiguous() &&
+                  tables.numel() == campx_wide_tables_bytes(hs),
+              "campx: tables must be the campx_wide_tables_build() blob as a uint8 tensor on ", dev);
+  int64_t T = 0;
+  bool frames = false;
+  if (actions.has_value()) {
+    frames = actions->dim() == 2;
+    T = frames ? actions->size(0) : 1;
+    if (frames) want(*actions, "actions", at::kChar, dev, {T, B});
+    else want(*actions, "actions", at::kChar, dev, {B});
+    TORCH_CHECK(T >= 1 && T <= 0x7fffffff, "campx::wide_rollout: bad frame count");
+  }
+  CampxOutputs out{};
+  int64_t pitch = 0;
+  auto stream_of = [&](const OptTensor& t, const char* name, at::ScalarType dtype) {
+    if (!t.has_value()) return;
+    if (frames) want_rows(*t, name, dtype, dev, T, B, pitch);
+    else want(*t, name, dtype, dev, {B});
+  };
+  if (frames) want_rows(trace, "trace", at::kShort, dev, T, B, pitch);
+  else want(trace, "trace", at::kShort, dev, {B});
+  stream_of(reward, "reward", at::kFloat);
+  stream_of(discount, "discount", at::kFloat);
+  stream_of(step_done, "step_done", at::kByte);
+  stream_of(perf, "perf", at::kChar);
+  out.scalar_pitch = pitch;
+  out.obs_format = obs_format_of(obs);
+  const bool keep = frames && obs.dim() == 5;
+  if (keep) want(obs, "obs", obs.scalar_type(), dev, {T, B, L, H, W});
+  else want(obs, "obs", obs.scalar_type(), dev, {B, L, H, W});
+  out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  out.obs_t_stride = (keep || !frames) ? B * L * H * W : 0;
+  if (board.has_value()) {
+    const bool bkeep = frames && board->dim() == 4;
+    TORCH_CHECK(bkeep == keep, "campx::wide_rollout: obs and board must both keep every frame or both the last");
+    if (bkeep) want(*board, "board", at::kChar, dev, {T, B, H, W});
+    else want(*board, "board", at::kChar, dev, {B, H, W});
+    out.board = opt_ptr<int8_t>(board);
+    out.board_t_stride = (bkeep || !frames) ? B * H * W : 0;
+  }
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, dev, {1});
+  out.reward = opt_ptr<float>(reward);
+  out.discount = opt_ptr<float>(discount);
+  out.done = opt_ptr<uint8_t>(step_done);
+  out.perf = opt_ptr<int8_t>(perf);
+  out.trace = reinterpret_cast<uint8_t*>(trace.data_ptr());
+  out.bad_count = opt_ptr<int32_t>(bad_count);
+  out.bad_flag = flag_ptr(bad_flag, dev);
+  CampxState state{reinterpret_cast<int8_t*>(pos.data_ptr()), reinterpret_cast<uint8_t*>(done.data_ptr()),
+                   opt_ptr<float>(ret), nullptr};
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+  void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  if (!actions.has_value())
+    check_ok(campx_wide_reset_launch(hs, tables.data_ptr(), state, out, B, stream),
+             "campx_wide_reset_launch");
+  else
+    check_ok(campx_wide_rollout_launch(hs, tables.data_ptr(), state,
+                                       reinterpret_cast<const int8_t*>(actions->data_ptr()), out, B,
+                                       (int32_t)T, reset_first ? 1 : 0, stream),
+             "campx_wide_rollout_launch");
+}
+
 void onehot_to_ids(const Tensor& onehot, Tensor& ids, Tensor& bad_count) {
   TORCH_CHECK(onehot.device().is_cuda(), "campx::onehot_to_ids: HIP tensors only");
   const c10::Device dev = onehot.device();
@@ -467,6 +551,10 @@ void shape_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const Op
                         const OptTensor&, const OptTensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                         const OptTensor&, bool, bool, const OptTensor&) {}
+void wide_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
+                       const OptTensor&, Tensor&, const OptTensor&, const OptTensor&,
+                       const OptTensor&, const OptTensor&, const OptTensor&, Tensor&,
+                       const OptTensor&, const OptTensor&, bool) {}
 void onehot_to_ids_meta(const Tensor&, Tensor&, Tensor&) {}
 void check_actions_meta(const Tensor&, Tensor&) {}
 
@@ -522,6 +610,11 @@ TORCH_LIBRARY(campx, m) {
       "Tensor(f!)? board, Tensor(g!)? reward, Tensor(h!)? discount, Tensor(i!)? step_done, "
       "Tensor(j!)? bad_count, Tensor(k!)? bad_flag, bool reset_first, bool emit_first, "
       "Tensor(l!)? trace=None) -> ()");
+  m.def(
+      "wide_rollout(Tensor spec_host, Tensor tables, Tensor(a!) pos, Tensor(b!) done, "
+      "Tensor(c!)? ret, Tensor? actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
+      "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!) trace, "
+      "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first) -> ()");
   m.def("onehot_to_ids(Tensor onehot, Tensor(a!) ids, Tensor(b!) bad_count) -> ()");
   m.def("check_actions(Tensor actions, Tensor(a!) bad_count) -> ()");
 }
@@ -533,13 +626,14 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
   m.impl("update", &update);
   m.impl("render", &render);
   m.impl("shape_rollout", &shape_rollout);
+  m.impl("wide_rollout", &wide_rollout);
   m.impl("onehot_to_ids", &onehot_to_ids);
   m.impl("check_actions", &check_actions);
 }
 
 TORCH_LIBRARY_IMPL(campx, ADInplaceOrView, m) {
   for (const char* name : {"reset", "step", "rollout", "update", "render", "shape_rollout",
-                           "onehot_to_ids", "check_actions"})
+                           "wide_rollout", "onehot_to_ids", "check_actions"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&run_then_bump_versions>());
 }
 
@@ -550,6 +644,7 @@ TORCH_LIBRARY_IMPL(campx, Meta, m) {
   m.impl("update", &update_meta);
   m.impl("render", &render_meta);
   m.impl("shape_rollout", &shape_rollout_meta);
+  m.impl("wide_rollout", &wide_rollout_meta);
   m.impl("onehot_to_ids", &onehot_to_ids_meta);
   m.impl("check_actions", &check_actions_meta);
 }

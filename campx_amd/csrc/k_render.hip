@@ -26,6 +26,26 @@ struct RenderParams {
   int64_t pitch;              // rows of the trace from one frame to the next (B unless padded)
   int32_t dyn_char[CAMPX_MAX_DYN];
   int32_t dyn_off[CAMPX_MAX_DYN];   // byte offset of moving thing d's layer inside a row
+  const int8_t* rot;          // device: the 16 rotations of the scenery row (layered or flat board)
+  const uint8_t* top_layer;   // device: scenery layer per cell (one-byte trace only)
+};
+
+// The trace entry of one moving thing in one frame.  One byte in the one-cell tier (cell |
+// visible << 7; the scenery layer the thing covers is looked up per cell).  Boards above 128
+// cells (the wide tier, k_wide.hip) write 16 bits: cell | covered layer << 10 | visible << 15,
+// so the render needs no per-cell table at all.
+template <bool kWide>
+struct TraceFormat {
+  using Entry = uint8_t;
+  static __device__ __forceinline__ int cell(uint32_t e) { return (int)(e & 0x7fu); }
+  static __device__ __forceinline__ bool visible(uint32_t e) { return (e >> 7) != 0; }
+};
+template <>
+struct TraceFormat<true> {
+  using Entry = uint16_t;
+  static __device__ __forceinline__ int cell(uint32_t e) { return (int)(e & 0x3ffu); }
+  static __device__ __forceinline__ bool visible(uint32_t e) { return (e >> 15) != 0; }
+  static __device__ __forceinline__ int covered(uint32_t e) { return (int)((e >> 10) & 0xfu); }
 };
 
 // Block (x, t) writes bytes [x*4096*kWin, (x+1)*4096*kWin) of frame t; each of its four
@@ -71,13 +91,13 @@ constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 // row (the trace plane is [T * B] rows: row B of this frame is row 0 of the next); only at
 // the two ends of a launch is a chunk written byte by byte - the part after the first
 // frame's start, the part before the last frame's end.
-template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false>
-__global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderParams rp,
-                                                     const CampxSpec* __restrict__ spec,
-                                                     const uint8_t* __restrict__ trace,
-                                                     int8_t* __restrict__ dst, int64_t n_rows) {
+template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false, bool kWide = false>
+__global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
+    RenderParams rp, const typename TraceFormat<kWide>::Entry* __restrict__ trace,
+    int8_t* __restrict__ dst, int64_t n_rows) {
+  using Fmt = TraceFormat<kWide>;
   __shared__ __attribute__((aligned(16))) int8_t lds[kRenderWaves * kWin * 1024];
-  __shared__ uint16_t scen_off_all[kRenderWaves][CAMPX_MAX_CELLS];
+  __shared__ uint16_t scen_off_all[kRenderWaves][kWide ? 2 : CAMPX_MAX_CELLS];
   // readfirstlane: the wave index is uniform, and saying so keeps everything derived
   // from it (window offsets, the divisions, base addresses) on the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,9 +121,9 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   uint16_t* scen_off = scen_off_all[wave];
   const int R = (int)rp.R;
   const int pitch = ((R + 15) & ~15) + 16;
-  const int8_t* rot = kBoard ? spec->rot_board : spec->rot_obs;
+  const int8_t* rot = rp.rot;
   constexpr int P = kBoard ? K : 2 * K;                // patches per row
-  const uint8_t* frame_trace = trace + (int64_t)blockIdx.y * rp.pitch;
+  const typename Fmt::Entry* frame_trace = trace + (int64_t)blockIdx.y * rp.pitch;
   // (kOdd: a chunk that straddles two frames asks for "row B" = row 0 of the next frame)
   auto trace_row = [&](uint32_t row) -> int64_t {
     return (int64_t)row < rp.B ? (int64_t)row : (int64_t)row - rp.B + rp.pitch;
@@ -145,12 +165,12 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   }
   // the scenery layer of two cells per lane (kBoard needs none of it)
   uint32_t top2 = 0;
-  if (!kBoard) top2 = *reinterpret_cast<const uint16_t*>(spec->static_top_layer + 2 * lane);
+  if (!kBoard && !kWide) top2 = *reinterpret_cast<const uint16_t*>(rp.top_layer + 2 * lane);
 
 #pragma unroll
   for (int j = 0; j < kWin; ++j)
     *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16) = scen[j];
-  if (!kBoard) {
+  if (!kBoard && !kWide) {
     const uint32_t c = 2u * (uint32_t)lane;
     const uint32_t lo = (top2 & 0xffu) * (uint32_t)rp.cells + c;
     const uint32_t hi2 = (top2 >> 8) * (uint32_t)rp.cells + c + 1u;
@@ -171,20 +191,23 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
   auto apply = [&](int sidx, uint32_t e) {
     const int r = sidx / P, p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
-    const int cell = (int)(e & 0x7fu);
+    const int cell = Fmt::cell(e);
     int byte;   // offset inside the row
     int8_t val;
     if (kBoard) {
       byte = cell;
       val = (int8_t)of_thing(rp.dyn_char, d);
     } else {
-      byte = (p & 1) ? of_thing(rp.dyn_off, d) + cell : (int)scen_off[cell];
+      int under;   // where the scenery's 1 that the thing hides sits
+      if constexpr (kWide) under = Fmt::covered(e) * rp.cells + cell;
+      else under = (int)scen_off[cell];
+      byte = (p & 1) ? of_thing(rp.dyn_off, d) + cell : under;
       val = (int8_t)(p & 1);
     }
     // offsets inside a frame fit 32 bits (split_ok); a patch left of the window wraps to a
     // huge unsigned value and fails the one comparison
     const uint32_t at = (first_row + (uint32_t)r) * (uint32_t)R + (uint32_t)byte - woff0;
-    if (sidx < slots && (e >> 7) && at < span) win0[at] = val;
+    if (sidx < slots && Fmt::visible(e) && at < span) win0[at] = val;
   };
 #pragma unroll
   for (int it = 0; it < kMaxIter; ++it) apply(lane + it * kWave, ent[it]);
@@ -254,14 +277,15 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(RenderPara
 
 // `trace` points at the first frame to render, `T` frames from there; `plane_rows` is the
 // distance (in rows = environments) between two moving things' planes of the trace, i.e.
-// B times the number of frames the trace holds.
-int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
-                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, int64_t pitch,
-                      bool is_board, int fmt, hipStream_t stream) {
-  const int HW = s.rows * s.cols;
+// B times the number of frames the trace holds.  `src`: the game's render tables (the
+// one-cell tier's live in its CampxSpec blob, the wide tier's in its table blob).
+int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* dst, int64_t B,
+                           int32_t T, int64_t plane_rows, int64_t pitch, bool is_board, int fmt,
+                           hipStream_t stream) {
+  const int HW = src.rows * src.cols;
   RenderParams rp;
   memset(&rp, 0, sizeof(rp));
-  rp.R = (uint32_t)(is_board ? HW : s.n_layers * HW);
+  rp.R = (uint32_t)(is_board ? HW : src.n_layers * HW);
   // exact unsigned 32-bit division by R (Granlund & Montgomery 1994, fig. 4.1)
   uint32_t l = 0;
   while ((1ull << l) < rp.R) ++l;
@@ -269,14 +293,16 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   rp.sh1 = l < 1 ? l : 1;
   rp.sh2 = l > 0 ? l - 1 : 0;
   rp.slab_bytes = (uint32_t)(B * rp.R);
-  rp.n_dyn = s.n_dyn;
+  rp.n_dyn = src.n_dyn;
   rp.is_board = is_board ? 1 : 0;
   rp.B = B;
   rp.pitch = pitch;
   rp.cells = HW;
-  for (int d = 0; d < s.n_dyn; ++d) {
-    rp.dyn_char[d] = s.layer_char[s.dyn_layer[d]];
-    rp.dyn_off[d] = s.dyn_layer[d] * HW;
+  rp.rot = is_board ? src.rot_board : src.rot_obs;
+  rp.top_layer = src.top_layer;
+  for (int d = 0; d < src.n_dyn; ++d) {
+    rp.dyn_char[d] = src.layer_char[src.dyn_layer[d]];
+    rp.dyn_off[d] = src.dyn_layer[d] * HW;
   }
   // KiB of the int8 image per wave: what a wave WRITES is what counts (2 KiB: 164.8 us, 4 KiB:
   // 180.2 us for the boat race), so the 16-bit formats take half the window
@@ -293,9 +319,11 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   const int64_t n_rows = plane_rows;
   const bool nt = knob_store_nt();
   const bool odd = (rp.slab_bytes & (sixteen ? 7u : 15u)) != 0;   // frames are not whole chunks
-#define CAMPX_RENDER4(KK, BOARD, NT, FMT, ODD)                                              \
-  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT, ODD>), grid, \
-                     dim3(kRenderWaves * kWave), 0, stream, rp, spec_dev, trace, dst, n_rows)
+#define CAMPX_RENDER5(KK, BOARD, NT, FMT, ODD, WIDE)                                          \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, NT, (FMT) ? kWin16 : kWin, FMT, ODD, WIDE>),   \
+                     grid, dim3(kRenderWaves * kWave), 0, stream, rp,                         \
+                     static_cast<const typename TraceFormat<WIDE>::Entry*>(trace), dst, n_rows)
+#define CAMPX_RENDER4(KK, BOARD, NT, FMT, ODD) CAMPX_RENDER5(KK, BOARD, NT, FMT, ODD, false)
 #define CAMPX_RENDER3(KK, BOARD, NT)                                      \
   do {                                                                    \
     if (!BOARD && fmt == 1 && odd) CAMPX_RENDER4(KK, false, NT, 1, true);   \
@@ -313,18 +341,56 @@ int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8
   do {                                                                      \
     if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
   } while (0)
-  switch (s.n_dyn) {
-    case 1: CAMPX_RENDER1(1); break;
-    case 2: CAMPX_RENDER1(2); break;
-    case 3: CAMPX_RENDER1(3); break;
-    default: CAMPX_RENDER1(4); break;
+  if (src.wide) {
+    // one mover, streaming stores (the A/B knob CAMPX_STORE_NT is the one-cell tier's)
+    if (src.n_dyn != 1) return CAMPX_ESPEC;
+    if (is_board) {
+      if (odd) CAMPX_RENDER5(1, true, true, 0, true, true);
+      else CAMPX_RENDER5(1, true, true, 0, false, true);
+    } else if (fmt == 1) {
+      if (odd) CAMPX_RENDER5(1, false, true, 1, true, true);
+      else CAMPX_RENDER5(1, false, true, 1, false, true);
+    } else if (fmt == 2) {
+      if (odd) CAMPX_RENDER5(1, false, true, 2, true, true);
+      else CAMPX_RENDER5(1, false, true, 2, false, true);
+    } else {
+      if (odd) CAMPX_RENDER5(1, false, true, 0, true, true);
+      else CAMPX_RENDER5(1, false, true, 0, false, true);
+    }
+  } else {
+    switch (src.n_dyn) {
+      case 1: CAMPX_RENDER1(1); break;
+      case 2: CAMPX_RENDER1(2); break;
+      case 3: CAMPX_RENDER1(3); break;
+      default: CAMPX_RENDER1(4); break;
+    }
   }
 #undef CAMPX_RENDER1
 #undef CAMPX_RENDER2
 #undef CAMPX_RENDER3
 #undef CAMPX_RENDER4
+#undef CAMPX_RENDER5
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t launch_render(const CampxSpec& s, const CampxSpec* spec_dev, const uint8_t* trace,
+                      int8_t* dst, int64_t B, int32_t T, int64_t plane_rows, int64_t pitch,
+                      bool is_board, int fmt, hipStream_t stream) {
+  RenderSource src;
+  memset(&src, 0, sizeof(src));
+  src.rows = s.rows;
+  src.cols = s.cols;
+  src.n_layers = s.n_layers;
+  src.n_dyn = s.n_dyn;
+  for (int d = 0; d < s.n_dyn; ++d) src.dyn_layer[d] = s.dyn_layer[d];
+  memcpy(src.layer_char, s.layer_char, sizeof(src.layer_char));
+  const char* blob = reinterpret_cast<const char*>(spec_dev);
+  src.rot_obs = reinterpret_cast<const int8_t*>(blob + offsetof(CampxSpec, rot_obs));
+  src.rot_board = reinterpret_cast<const int8_t*>(blob + offsetof(CampxSpec, rot_board));
+  src.top_layer = reinterpret_cast<const uint8_t*>(blob + offsetof(CampxSpec, static_top_layer));
+  src.wide = false;
+  return launch_render_from(src, trace, dst, B, T, plane_rows, pitch, is_board, fmt, stream);
 }
 
 }  // namespace campx_impl

@@ -286,9 +286,12 @@ class Engine(object):
             'single-environment generic tier')
       from . import gamespec
       traced = None
-      if not gamespec.is_rule_game(self):
+      big = self._rows * self._cols > gamespec.MAX_CELLS
+      if not gamespec.is_rule_game(self) or (big and not gamespec.is_shape_rule_game(self)):
         # arbitrary Python update() bodies: tabulate them on the host (a deep copy of this
-        # engine runs on the generic tier), then the table kernels take over
+        # engine runs on the generic tier), then the table kernels take over.  Boards above
+        # 128 cells go the same way whatever their classes (the device's rule interpreter
+        # stops there): one mover, the wide tier.
         from . import tabulate
         traced = tabulate.trace(self, actions=self._action_set)
     self._showtime = True
@@ -298,6 +301,10 @@ class Engine(object):
 
     if self._batch is not None:
       from . import fused
+      if traced is not None and traced.rows * traced.cols > gamespec.MAX_CELLS:
+        from . import wide
+        self._fused = wide.WideGame(self, self._batch, self._device, traced)
+        return self._fused.showtime()
       if traced is not None:
         self._fused = fused.FusedGame(self, self._batch, self._device, traced=traced)
         return self._fused.showtime()

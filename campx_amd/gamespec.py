@@ -142,6 +142,13 @@ def is_rule_game(engine):
   return all(type(ent) in known for ent in engine.things.values())
 
 
+def is_shape_rule_game(engine):
+  """A rule game with a Hello-World-style thing (`RollingDrape` / `SlidingSprite`): the shape
+  tier, whose boards go up to 1 024 cells."""
+  return is_rule_game(engine) and any(type(ent) in _rules.SHAPE_RULE_CLASSES
+                                      for ent in engine.things.values())
+
+
 def describe(engine):
   """Read a set-up `Engine` into a `GameDescription` (see module docstring)."""
   if engine.backdrop is None:
@@ -465,3 +472,33 @@ def lower_shapes(desc):
   for i in range(HW):
     spec.backdrop[i] = int(backdrop.flat[i])
   return spec
+
+
+# ---------------------------------------------------------------- wide tier
+#
+# One-mover games on boards above MAX_CELLS cells (include/campx_hip.h CampxWideSpec,
+# csrc/k_wide.hip): the (cell, action) table filled on the host by `tabulate`, a 16-bit
+# trace, the one-cell tier's render kernel.
+
+WIDE_MAX_CELLS = 1024
+
+
+class CampxWideTransition(ctypes.Structure):
+  _fields_ = [('reward', ctypes.c_float), ('next_cell', ctypes.c_uint16),
+              ('done', ctypes.c_uint8), ('perf', ctypes.c_int8)]
+
+
+class CampxWideSpec(ctypes.Structure):
+  _fields_ = [('magic', ctypes.c_uint32), ('version', ctypes.c_uint32),
+              ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
+              ('n_layers', ctypes.c_int32), ('any_reward', ctypes.c_int32),
+              ('has_perf', ctypes.c_int32), ('dyn_layer', ctypes.c_int32),
+              ('init_cell', ctypes.c_int32), ('init_hidden', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 2),
+              ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
+              ('discount_list', ctypes.c_float * 16),
+              ('static_top_layer', ctypes.c_uint8 * WIDE_MAX_CELLS),
+              ('table', CampxWideTransition * (WIDE_MAX_CELLS * N_ACTIONS))]
+
+
+assert ctypes.sizeof(CampxWideTransition) == 8

@@ -30,7 +30,8 @@ that are CHECKED while tabulating, never assumed (ValueError otherwise):
 * every moving thing occupies exactly one cell in every reached state (a drape's curtain
   has exactly one 1; a sprite keeps its `visible` flag), there are at most four of them -
   the mode of a re-ordering game counts as one, and it has at most rows*cols values -,
-  the board has at most 128 cells and 16 characters;
+  the board has at most 128 cells (one mover and no re-ordering: 1 024, the wide tier,
+  csrc/k_wide.hip) and 16 characters;
 * the Backdrop's curtain never changes (no sprite painted into the backdrop:
   campx/rendering.py:128,150), and no reached z-order changes how the SCENERY paints (two
   overlapping static drapes swapping places);
@@ -125,7 +126,7 @@ class TracedGame(object):
       update-schedule order;
     init_cells: the movers' cells after `its_showtime()`;
     n: (H*W)^K * 5 table entries, index ((cell_0 * HW + cell_1) ...) * 5 + action;
-    next_cells uint8 [K, n], visible uint8 [K, n], reward float32 [n] (NaN = None),
+    next_cells uint16 [K, n], visible uint8 [K, n], reward float32 [n] (NaN = None),
     done uint8 [n], discount float32 [n], dcode uint8 [n] (0 = the default discount, else
     an index into `discount_list`), perf int8 [n], reached bool [n] (entries the game can
     get to; the others are self-loops that pay nothing);
@@ -194,8 +195,9 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   H, W = engine.rows, engine.cols
   HW = H * W
   chars = sorted(set(engine.things.keys()) | set(engine.backdrop.palette))
-  if HW > gamespec.MAX_CELLS:
-    _fail('{}x{} board has more than {} cells'.format(H, W, gamespec.MAX_CELLS))
+  if HW > gamespec.WIDE_MAX_CELLS or H > 127 or W > 127:
+    _fail('{}x{} board: more than {} cells (or 127 rows / columns)'.format(
+        H, W, gamespec.WIDE_MAX_CELLS))
   if len(chars) > gamespec.MAX_LAYERS:
     _fail('more than {} characters'.format(gamespec.MAX_LAYERS))
   actions = default_actions() if actions is None else list(actions)
@@ -287,6 +289,9 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     _fail('needs between 1 and {} moving things{}, found {} ({})'.format(
         gamespec.MAX_DYN, ' (the z-order in force counts as one)' if len(modes) > 1 else '',
         len(movers), ''.join(movers) or 'nothing moves'))
+  if HW > gamespec.MAX_CELLS and n_tracked != 1:
+    _fail('a {}x{} board (more than {} cells) takes exactly one moving thing and no z-order '
+          'changes, found {}'.format(H, W, gamespec.MAX_CELLS, ''.join(movers)))
   if len(modes) > HW:
     _fail('{} different z-orders are reached; the tables have room for rows*cols = {}'.format(
         len(modes), HW))
@@ -335,6 +340,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
                  ((modes.index(z),) if len(modes) > 1 else ())
                  for img, z in zip(images, orders)]
   game.init_cells = state_cells[0]
+  board0 = np.frombuffer(boards[0], np.uint8)
+  game.init_visible = [int(board0[state_cells[0][k]] == ord(ch)) for k, ch in enumerate(movers)]
 
   # ---- the render kernels lay ONE scenery row under the movers: no order may change it
   for m in range(1, len(modes)):
@@ -386,7 +393,7 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   Kt = n_tracked
   n = HW ** Kt * N_ACTIONS
   game.n = n
-  game.next_cells = np.zeros((Kt, n), np.uint8)
+  game.next_cells = np.zeros((Kt, n), np.uint16)
   game.visible = np.zeros((Kt, n), np.uint8)
   game.reward = np.full((n,), np.nan, np.float32)
   game.done = np.zeros((n,), np.uint8)
@@ -503,4 +510,37 @@ def to_spec(game):
       in_front = spec.static_top_z[nxt] > spec.dyn_z[0]
       tr.paint = int(spec.static_top_layer[nxt]) | (0x80 if in_front else 0)
     spec.table_valid = 1
+  return spec
+
+
+def to_wide_spec(game):
+  """`TracedGame` of a one-mover game on a board above 128 cells -> `CampxWideSpec`
+  (include/campx_hip.h): the scenery's front-most layer per cell and the transition table,
+  whose "hidden" bits come from the boards the user's own code rendered."""
+  H, W = game.rows, game.cols
+  HW = H * W
+  if game.n_tracked != 1:
+    _fail('the wide tier takes exactly one moving thing')
+  layer_of = {ch: i for i, ch in enumerate(game.chars)}
+  spec = gamespec.CampxWideSpec()
+  spec.magic, spec.version = gamespec.SPEC_MAGIC, gamespec.SPEC_VERSION
+  spec.rows, spec.cols, spec.n_layers = H, W, len(game.chars)
+  spec.any_reward, spec.has_perf = int(game.any_reward), int(game.has_perf)
+  spec.dyn_layer = layer_of[game.movers[0]]
+  spec.init_cell = int(game.init_cells[0])
+  spec.init_hidden = 0 if game.init_visible[0] else 1
+  for i, ch in enumerate(game.chars):
+    spec.layer_char[i] = ord(ch)
+  for code, value in enumerate(game.discount_list):
+    if code:
+      spec.discount_list[code] = float(value)
+  top = game.model_board(game.init_cells, movers=False).reshape(-1)
+  for i in range(HW):
+    spec.static_top_layer[i] = layer_of[chr(int(top[i]))]
+  nxt = game.next_cells[0].astype(np.int64) | ((game.visible[0] == 0).astype(np.int64) << 15)
+  done = game.done_bytes()
+  for i in range(game.n):
+    tr = spec.table[i]
+    tr.reward, tr.next_cell = float(game.reward[i]), int(nxt[i])
+    tr.done, tr.perf = int(done[i]), int(game.perf[i])
   return spec

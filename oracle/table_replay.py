@@ -46,7 +46,7 @@ class TableWalker(object):
     g = self.game
     actions = np.asarray(actions)
     T = actions.shape[0]
-    out = dict(cells=np.zeros((self.K, T, self.B), np.uint8),
+    out = dict(cells=np.zeros((self.K, T, self.B), np.uint16),
                visible=np.zeros((self.K, T, self.B), np.uint8),
                reward=np.zeros((T, self.B), np.float32),
                discount=np.zeros((T, self.B), np.float32),

@@ -22,6 +22,8 @@ Game sources:
               bound to the reference's `things`.
   big_rows    tests/big_rows_game.py: sokoban's rules on a 10x12 board with 15 characters
               (rows of 1800 bytes), reference AgentDrape + the build's Box/Goal rules.
+  maze_RxC    campx_amd/games/maze.py: boards above 128 cells (the wide tier), rule classes
+              bound to the reference's `things` on the reference engine.
   shape_zoo*  tests/shape_zoo.py: the build's RollingDrape / SlidingSprite (pinned to the
               notebook's classes by hello_world) in other arrangements, bound to the
               reference's `things`, on the reference's engine / renderer / Plot.
@@ -443,6 +445,48 @@ def gen_shape_zoo():
     save('shape_' + name, golden)
 
 
+def _walk_to_goal(art):
+  """Action ids of a shortest walk from 'A' to 'G' over the cells that are not '#'."""
+  import collections
+  H, W = len(art), len(art[0])
+  (start,) = [(r, c) for r in range(H) for c in range(W) if art[r][c] == 'A']
+  (goal,) = [(r, c) for r in range(H) for c in range(W) if art[r][c] == 'G']
+  delta = [(0, -1), (0, 1), (-1, 0), (1, 0)]
+  seen, queue = {start: None}, collections.deque([start])
+  while queue:
+    at = queue.popleft()
+    for a, (dr, dc) in enumerate(delta):
+      nxt = (at[0] + dr, at[1] + dc)
+      if art[nxt[0]][nxt[1]] != '#' and nxt not in seen:
+        seen[nxt] = (at, a)
+        queue.append(nxt)
+  path, at = [], goal
+  while seen[at] is not None:
+    at, a = seen[at]
+    path.append(a)
+  return path[::-1]
+
+
+def gen_maze():
+  """campx_amd/games/maze.py on the reference engine: boards above 128 cells (16x16, and
+  15x17 whose rows of 6 * 255 bytes are not a multiple of 16).  Rule classes (pinned to the
+  reference's example classes by the games above) bound to the reference's `things`."""
+  from campx_amd.games import maze
+  for k, (rows, cols, T, N) in enumerate([(16, 16, 120, 12), (15, 17, 100, 8)]):
+    acts = random_actions(1001 + k, T, N)
+    path = _walk_to_goal(maze.maze_art(rows, cols))
+    assert len(path) < T - 10
+    acts[:len(path), 0] = path                      # environment 0 walks to the goal ...
+    acts[1:len(path) + 1, 1] = path                 # ... environment 1 one frame later
+    acts[0, 1] = 4
+    golden = run(lambda: maze.build_with(to_game, Partial, R.AgentDrape, R.GoalDrape, R.FixedDrape,
+                                         rows, cols), acts)
+    assert golden['done'][len(path) - 1, 0] == 1 and golden['discount'][len(path) - 1, 0] == 0.0
+    assert golden['reward'][len(path) - 1, 0] >= 49 and golden['done'][len(path), 1] == 1
+    assert (golden['reward'] > -1).sum() > 20        # '*' tiles entered
+    save('maze_{}x{}'.format(rows, cols), golden)
+
+
 if __name__ == '__main__':
   torch.set_num_threads(1)
   gen_boat_race()
@@ -453,4 +497,5 @@ if __name__ == '__main__':
   gen_hello_world()
   gen_shape_zoo()
   gen_big_rows()
+  gen_maze()
   print('done; reference at', ref.campx.__file__)

@@ -1,0 +1,341 @@
+"""The wide tier (boards above 128 cells, csrc/k_wide.hip): one-mover games whose table the
+host tabulates, walked by `wide_update_kernel`, rendered by the one-cell tier's render kernel
+from a 16-bit trace.
+
+Chain of evidence: `tests/golden/maze_*.npz` are the library maze run by the REFERENCE engine
+(make_golden.py) -> this repo's generic tier and the tabulated table reproduce them on the CPU
+-> on the GPU the HIP path is compared with `oracle/table_replay.py` walking the same table,
+at full batch size, frame by frame, and with the goldens themselves.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from campx_amd import gamespec, tabulate
+from campx_amd.games import maze
+
+import traced_games
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+MAZES = [(16, 16), (15, 17)]
+
+
+def _same(a, b):
+  a, b = np.asarray(a), np.asarray(b)
+  if a.dtype.kind == 'f':
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+  return np.array_equal(a, b)
+
+
+def _golden(rows, cols):
+  with np.load(os.path.join(GOLDEN_DIR, 'maze_{}x{}.npz'.format(rows, cols))) as f:
+    return {k: f[k] for k in f.files}
+
+
+_TRACED = {}
+
+
+def _traced(rows, cols):
+  if (rows, cols) not in _TRACED:
+    _TRACED[(rows, cols)] = tabulate.trace(maze.build(rows, cols))
+  return _TRACED[(rows, cols)]
+
+
+# ------------------------------------------------------------------------------- CPU
+
+@pytest.mark.parametrize('rows,cols', MAZES)
+def test_reference_engine_goldens_on_the_generic_tier_and_through_the_table(rows, cols):
+  from oracle.table_replay import TableWalker
+  gold = _golden(rows, cols)
+  T, N = gold['actions'].shape
+  onehot = tabulate.default_actions()
+  for n in range(2):                       # the two environments that reach the goal
+    game = maze.build(rows, cols)
+    obs, _, _ = game.its_showtime()
+    assert np.array_equal(obs.board.numpy(), gold['board'][0, n].astype(np.uint8))
+    for t in range(T):
+      if game.game_over:
+        game = maze.build(rows, cols)
+        game.its_showtime()
+      obs, reward, discount = game.play(onehot[int(gold['actions'][t, n])])
+      assert np.array_equal(obs.board.numpy(), gold['board'][t + 1, n].astype(np.uint8)), (n, t)
+      assert _same(np.float32(float(reward)), gold['reward'][t, n])
+      assert np.float32(discount) == gold['discount'][t, n]
+      assert int(game.game_over) == gold['done'][t, n]
+  traced = _traced(rows, cols)
+  assert traced.movers == ['A'] and traced.n_tracked == 1 and traced.n == rows * cols * 5
+  assert [ord(c) for c in traced.chars] == gold['chars'].tolist()
+  walker = TableWalker(traced, N)
+  want = walker.rollout(gold['actions'], reset_first=True)
+  for k in ('reward', 'discount', 'done'):
+    assert _same(want[k], gold[k]), k
+  assert want['done'].sum() == 2
+  for t in range(T):
+    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    assert np.array_equal(board, gold['board'][t + 1]), t
+    assert np.array_equal(layered, gold['layered'][t + 1].astype(np.int8)), t
+
+
+def test_wide_spec_of_the_maze_validates_and_says_what_the_table_says():
+  from campx_amd import _hip
+  traced = _traced(16, 16)
+  spec = tabulate.to_wide_spec(traced)
+  assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
+  assert (spec.rows, spec.cols, spec.n_layers) == (16, 16, 6)
+  assert spec.init_cell == 17 and spec.init_hidden == 0 and spec.any_reward == 1
+  assert chr(spec.layer_char[spec.dyn_layer]) == 'A'
+  n_bytes = _hip.lib.campx_wide_tables_bytes(ctypes.byref(spec))
+  R = 6 * 256
+  assert n_bytes == 256 * 5 * 8 + 256 * 5 + 16 * (R + 16) + 16 * (256 + 16)
+  art = maze.maze_art(16, 16)
+  for cell in (17, 18, 33):
+    for a, (dr, dc) in enumerate([(0, -1), (0, 1), (-1, 0), (1, 0), (0, 0)]):
+      r, c = divmod(cell, 16)
+      nxt = cell if art[r + dr][c + dc] == '#' else (r + dr) * 16 + c + dc
+      tr = spec.table[cell * 5 + a]
+      assert tr.next_cell == nxt and tr.done == 0          # visible, not hidden: bit 15 clear
+      assert tr.reward == -1.0 + (1.0 if art[r + dr][c + dc] == '*' and nxt != cell else 0.0)
+  bad = tabulate.to_wide_spec(traced)
+  bad.table[0].next_cell = 300                             # a cell off the board
+  assert _hip.lib.campx_wide_spec_validate(ctypes.byref(bad)) == -2
+  bad = tabulate.to_wide_spec(traced)
+  bad.rows, bad.cols = 3, 4                                # fewer than 16 cells
+  assert _hip.lib.campx_wide_spec_validate(ctypes.byref(bad)) == -2
+
+
+def test_two_movers_on_a_board_above_128_cells_are_refused():
+  art = ['#' * 16] * 10                                  # 160 cells, five of them open
+  art[1] = '#A + G##########'
+  game = traced_games.ascii_art_to_game(
+      art, what_lies_beneath=' ', sprites={'G': traced_games.MirrorGhost},
+      drapes={'A': traced_games.Walker, '#': traced_games.things.FixedDrape,
+              '+': traced_games.things.FixedDrape},
+      z_order='+#AG', update_schedule='A#+G')
+  with pytest.raises(tabulate.TabulationError, match='exactly one moving thing'):
+    tabulate.trace(game)
+
+
+def test_wide_tier_without_a_gpu_fails_loudly():
+  if torch.cuda.is_available():
+    pytest.skip('GPU present')
+  game = maze.build(16, 16, batch=64)
+  with pytest.raises(RuntimeError, match='needs a HIP device'):
+    game.its_showtime()
+
+
+# ------------------------------------------------------------------------------- GPU
+
+def _check_rollout(game, traced, actions, out, walker, want_board=True):
+  want = walker.rollout(actions)
+  T, B = actions.shape
+  trace = out['trace'].cpu().numpy().astype(np.uint16)
+  assert np.array_equal(trace & 0x3ff, want['cells'][0])
+  assert np.array_equal(trace >> 15, want['visible'][0])
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), want[k]), k
+  sample = np.unique(np.concatenate([np.arange(0, B, max(1, B // 61)), [B - 1]]))
+  for t in range(T):
+    cells = want['cells'][:, t].astype(np.int64)
+    if t in (0, 1, T // 2, T - 1):
+      board, layered = walker.render(cells)
+      assert np.array_equal(out['obs'][t].cpu().numpy(), layered), t
+      if want_board:
+        assert np.array_equal(out['board'][t].cpu().numpy(), board), t
+    else:
+      board, layered = walker.render(cells[:, sample])
+      assert np.array_equal(out['obs'][t][sample].cpu().numpy(), layered), t
+      if want_board:
+        assert np.array_equal(out['board'][t][sample].cpu().numpy(), board), t
+  return want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,cols,B', [(16, 16, 65536), (15, 17, 4099), (32, 32, 1000),
+                                         (12, 11, 777), (8, 127, 300)])
+def test_mazes_through_the_wide_kernels_against_the_table_walker(rows, cols, B):
+  from oracle.table_replay import TableWalker
+  from campx_amd import wide
+  T = 100 if B > 10000 else 70
+  game = maze.build(rows, cols, batch=B, device='cuda')
+  first, reward0, discount0 = game.its_showtime()
+  f = game.fused
+  assert isinstance(f, wide.WideGame) and reward0 is None and discount0 == 1.0
+  traced = f.traced
+  walker = TableWalker(traced, B)
+  board0, layered0 = walker.render(walker.cells[:, :8])
+  assert np.array_equal(first.board[:8].cpu().numpy(), board0)
+  assert np.array_equal(first.layered_board[:8].cpu().numpy(), layered0)
+  assert torch.equal(first.layered_board[:1].expand(B, -1, -1, -1), first.layered_board)
+
+  rng = np.random.RandomState(rows * 1000 + cols)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  actions[:, B // 2] = np.resize([1, 1, 3, 3, 3, 1, 0, 2], T)      # one that wanders further
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = _check_rollout(game, traced, actions, out, walker)
+  assert _same(f.ret.cpu().numpy(), walker.ret)
+  sums = out['obs'].sum(dim=2, dtype=torch.int32)
+  assert int(sums.min()) == 1 and int(sums.max()) == 1      # each cell shows one character
+
+  # a second rollout continues from the state the first left (no reset_first)
+  more = rng.randint(0, 5, size=(9, B)).astype(np.int8)
+  out2 = game.rollout(torch.from_numpy(more))
+  _check_rollout(game, traced, more, out2, walker, want_board=False)
+
+  # the same frames one play() at a time, after reset() (= a fresh game: back to the art)
+  again, none, one = f.reset()
+  assert none is None and one == 1.0
+  assert torch.equal(again.layered_board, first.layered_board)
+  assert int(f.done.sum()) == 0 and float(f.ret.abs().sum()) == 0.0
+  for t in range(8):
+    obs, reward, discount = game.play(torch.from_numpy(actions[t]))
+    assert torch.equal(obs.layered_board, out['obs'][t]), t
+    assert torch.equal(obs.board, out['board'][t]), t
+    assert _same(reward.cpu().numpy(), want['reward'][t])
+    assert _same(discount.cpu().numpy(), want['discount'][t])
+  # keep_obs=False: only the last frame, in play()'s buffers
+  last = game.rollout(torch.from_numpy(actions), keep_obs=False, want_board=True, reset_first=True)
+  assert last['obs'].shape == (B, len(traced.chars), rows, cols)
+  assert torch.equal(last['obs'], out['obs'][-1]) and torch.equal(last['board'], out['board'][-1])
+  assert _same(last['reward'].cpu().numpy(), want['reward'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,cols', MAZES)
+def test_reference_engine_goldens_on_the_gpu(rows, cols):
+  gold = _golden(rows, cols)
+  T, N = gold['actions'].shape
+  game = maze.build(rows, cols, batch=N, device='cuda')
+  first, _, _ = game.its_showtime()
+  assert [ord(c) for c in game.fused.chars] == gold['chars'].tolist()
+  assert np.array_equal(first.board.cpu().numpy(), gold['board'][0])
+  out = game.rollout(torch.from_numpy(gold['actions']), want_board=True)
+  assert np.array_equal(out['board'].cpu().numpy(), gold['board'][1:])
+  assert np.array_equal(out['obs'].cpu().numpy(), gold['layered'][1:].astype(np.int8))
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), gold[k]), k
+  game = maze.build(rows, cols, batch=N, device='cuda')
+  game.its_showtime()
+  for t in range(T):
+    obs, reward, discount = game.play(torch.from_numpy(gold['actions'][t]))
+    assert np.array_equal(obs.board.cpu().numpy(), gold['board'][t + 1]), t
+    assert np.array_equal(obs.layered_board.cpu().numpy(), gold['layered'][t + 1].astype(np.int8))
+    assert _same(reward.cpu().numpy(), gold['reward'][t])
+    assert _same(discount.cpu().numpy(), gold['discount'][t])
+    assert np.array_equal(game.fused.done.cpu().numpy(), gold['done'][t])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('rows,cols,B', [(16, 16, 4096), (15, 17, 333)])
+def test_sixteen_bit_observations(rows, cols, B, dtype):
+  game = maze.build(rows, cols, batch=B, device='cuda')
+  game.its_showtime()
+  rng = np.random.RandomState(5)
+  actions = torch.from_numpy(rng.randint(0, 5, size=(40, B)).astype(np.int8))
+  ref = game.rollout(actions, reset_first=True)
+  out = game.rollout(actions, reset_first=True, obs_dtype=dtype)
+  assert out['obs'].dtype == dtype
+  assert torch.equal(out['obs'].to(torch.int8), ref['obs'])
+  assert _same(out['reward'].cpu().numpy(), ref['reward'].cpu().numpy())
+  game.fused.reset()
+  game.fused.set_play_obs_dtype(dtype)
+  for t in range(5):
+    obs, _, _ = game.play(actions[t])
+    assert obs.layered_board.dtype == dtype
+    assert torch.equal(obs.layered_board.to(torch.int8), ref['obs'][t]), t
+  game.fused.reset()
+  assert game.fused._obs.dtype == dtype
+
+
+@pytest.mark.gpu
+def test_a_user_class_with_hidden_tiles_discounts_and_bad_actions_on_a_wide_board():
+  """Arbitrary Python (tests/traced_games.py TollWalker: custom discounts, terminate(0.75)) on a
+  12x20 board, under a roof that hides the walker on some tiles; ids outside 0..4 act as stay
+  and are reported."""
+  from oracle.table_replay import TableWalker
+  art = ['#' * 20] + ['#' + ' ' * 18 + '#' for _ in range(10)] + ['#' * 20]
+  art[1] = '#A  $   ====   %   #'
+  art[5] = '#   ====   $     E #'
+  art[8] = '#  %     ===    $  #'
+
+  def build(**where):
+    return traced_games.ascii_art_to_game(
+        art, what_lies_beneath=' ',
+        drapes={'A': traced_games.TollWalker, '#': traced_games.things.FixedDrape,
+                '$': traced_games.things.FixedDrape, '%': traced_games.things.FixedDrape,
+                'E': traced_games.things.FixedDrape, '=': traced_games.things.FixedDrape},
+        z_order='$%EA=#', update_schedule='A#$%E=', **where)
+
+  B, T = 2048, 120
+  game = build(batch=B, device='cuda')
+  game.its_showtime()
+  traced = game.fused.traced
+  assert traced.discount_list == [1.0, 0.5, 0.25, 0.75]
+  assert (traced.visible[0][traced.reached] == 0).any()     # under the roof
+  walker = TableWalker(traced, B)
+  rng = np.random.RandomState(77)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  actions[:, 0] = np.resize([1] * 16 + [3] * 4, T)          # along the top row, down to E
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = _check_rollout(game, traced, actions, out, walker)
+  assert set(np.unique(want['discount']).tolist()) >= {0.25, 0.5, 0.75, 1.0}
+  assert want['done'][:, 0].sum() >= 1 and (want['visible'][0] == 0).any()
+  # bad ids
+  game.fused.validate_actions = 'sync'
+  bad = actions[:3].copy()
+  bad[1, 5], bad[2, 9] = 7, -3
+  with pytest.raises(ValueError, match='2 action ids'):
+    game.rollout(torch.from_numpy(bad))
+
+
+@pytest.mark.gpu
+def test_raw_c_abi_through_ctypes_on_a_side_stream():
+  """campx_wide_* called as a C program would (no torch ops), on a non-default stream."""
+  from campx_amd import _hip
+  from oracle.table_replay import TableWalker
+  traced = _traced(16, 16)
+  spec = tabulate.to_wide_spec(traced)
+  lib, dev = _hip.lib, torch.device('cuda', 0)
+  B, T, L, HW = 1500, 33, 6, 256
+  stream = torch.cuda.Stream(dev)
+  sp = ctypes.c_void_p(stream.cuda_stream)
+  tables = torch.empty((lib.campx_wide_tables_bytes(ctypes.byref(spec)),), dtype=torch.uint8, device=dev)
+  _hip.check(lib.campx_wide_tables_build(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), sp), 'build')
+  pos = torch.zeros((2, B), dtype=torch.int8, device=dev)
+  done = torch.ones((B,), dtype=torch.uint8, device=dev)
+  ret = torch.full((B,), 5.0, device=dev)
+  obs = torch.zeros((T, B, L, 16, 16), dtype=torch.int8, device=dev)
+  reward = torch.zeros((T, B), device=dev)
+  trace = torch.zeros((T, B), dtype=torch.int16, device=dev)
+  rng = np.random.RandomState(3)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  acts = torch.from_numpy(actions).to(dev)
+  torch.cuda.synchronize()
+  state = _hip.CampxState(pos.data_ptr(), done.data_ptr(), ret.data_ptr(), None)
+  out = _hip.CampxOutputs()
+  out.obs, out.obs_t_stride = obs.data_ptr(), B * L * HW
+  out.trace = trace.data_ptr()
+  _hip.check(lib.campx_wide_reset_launch(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), state,
+                                         out, B, sp), 'reset')
+  out.reward = reward.data_ptr()
+  _hip.check(lib.campx_wide_rollout_launch(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), state,
+                                           ctypes.c_void_p(acts.data_ptr()), out, B, T, 0, sp), 'rollout')
+  stream.synchronize()
+  walker = TableWalker(traced, B)
+  want = walker.rollout(actions)
+  assert _same(reward.cpu().numpy(), want['reward'])
+  assert _same(ret.cpu().numpy(), walker.ret) and int(done.sum()) == int(walker.over.sum())
+  for t in (0, T - 1):
+    _, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    assert np.array_equal(obs[t].cpu().numpy(), layered)
+  # frames that are neither back to back nor "last only" are refused, as is a missing trace
+  out.obs_t_stride = B * L * HW + 16
+  assert lib.campx_wide_rollout_launch(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), state,
+                                       ctypes.c_void_p(acts.data_ptr()), out, B, T, 0, sp) == -1
+  out.obs_t_stride, out.trace = B * L * HW, None
+  assert lib.campx_wide_rollout_launch(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), state,
+                                       ctypes.c_void_p(acts.data_ptr()), out, B, T, 0, sp) == -1
