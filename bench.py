@@ -44,7 +44,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 # L*H*W obs + 4 reward + 1 action + 2*S state.
 BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194,
                       # 6x8 boards, 6 / 7 characters, 3 / 4 moving things (S = 6 / 8)
-                      'sokoban_l1': 288 + 4 + 1 + 12 + 1, 'sokoban_l2': 336 + 4 + 1 + 16 + 1}
+                      'sokoban_l1': 288 + 4 + 1 + 12 + 1, 'sokoban_l2': 336 + 4 + 1 + 16 + 1,
+                      # wide tier: 6 characters, one mover (S = 2) + the done byte
+                      'maze16': 6 * 256 + 4 + 1 + 4 + 1, 'maze32': 6 * 1024 + 4 + 1 + 4 + 1}
 WORKLOADS = {
     'boat_race': ('boat_race 5x5', 65536),
     'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
@@ -52,7 +54,22 @@ WORKLOADS = {
     # not BASELINE configs: games with 3 and 4 moving things (rule interpreter path)
     'sokoban_l1': ('sokoban 6x8 with two boxes (build-authored level 1)', 131072),
     'sokoban_l2': ('sokoban 6x8 with three boxes (build-authored level 2)', 131072),
+    # not BASELINE configs: boards above 128 cells (the wide tier, campx_amd/games/maze.py)
+    'maze16': ('maze 16x16, 6 characters (build-authored, wide tier)', 65536),
+    'maze32': ('maze 32x32, 6 characters (build-authored, wide tier)', 16384),
 }
+
+
+def build_game(game_name, **where):
+  """The library game behind a --game name (set up, not started)."""
+  from campx_amd import games
+  if game_name.startswith('sokoban_l'):
+    return games.sokoban.build(level=int(game_name[-1]), **where)
+  if game_name.startswith('maze'):
+    from campx_amd.games import maze
+    n = int(game_name[4:])
+    return maze.build(n, n, **where)
+  return getattr(games, game_name).build(**where)
 HEADLINE_METRIC = 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X'
 TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r03_traffic.json')
 
@@ -133,13 +150,12 @@ def cpu_baseline(game_name, frames, seconds, batch=65536):
   that the timed part takes about `seconds`.
   """
   import numpy as np
-  from campx_amd import games, gamespec
+  from campx_amd import gamespec
   from oracle import cpu as oracle_cpu
-  build = getattr(games, game_name).build
   cores = oracle_cpu.set_threads(os.cpu_count() or 1)
   rng = np.random.RandomState(7)
   actions = rng.randint(0, 5, size=(frames, batch)).astype(np.int8)
-  og = oracle_cpu.OracleGame.from_description(gamespec.describe(build()))
+  og = oracle_cpu.OracleGame.from_description(gamespec.describe(build_game(game_name)))
   og.rollout(actions[:2], reset_first=True, keep_obs=False, want_board=False)
   t0 = time.perf_counter()
   og.rollout(actions, reset_first=True, keep_obs=False, want_board=False)
@@ -203,6 +219,8 @@ def measured_traffic(game, batch, frames, path):
 
 
 def kernel_names(fused, split):
+  if type(fused).__name__ == 'WideGame':
+    return 'wide_update_kernel + render_kernel'
   if split:
     first = ('update_table_kernel' if fused.n_dyn == 1 else
              'update_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
@@ -226,11 +244,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   import torch
   on_gpu = standin is None
   if on_gpu:
-    from campx_amd import games
-    if game_name.startswith('sokoban_l'):
-      game = games.sokoban.build(batch=B, device=device, level=int(game_name[-1]))
-    else:
-      game = getattr(games, game_name).build(batch=B, device=device)
+    game = build_game(game_name, batch=B, device=device)
   else:
     game = standin(game_name, B)
   game.its_showtime()
@@ -542,7 +556,8 @@ def run_rank(args):
                                   m['per_launch_ms'])
     solo = world == 1 and standin is None and not args.force_dist
     if solo and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds)
+      line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds,
+                                          batch=4096 if args.game.startswith('maze') else 65536)
       line['cpu_baseline']['generic_b1'] = generic_b1()
       line['cpu_baseline']['reference_b1_build_container'] = {
           'value': 954.8, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference',
@@ -555,7 +570,8 @@ def run_rank(args):
       torch.cuda.empty_cache()
       line['play_mode'] = play_mode(device)
       also = []
-      for other in ('wall_world', 'sokoban'):
+      # (maze16: not a BASELINE config - the wide tier, boards above 128 cells)
+      for other in ('wall_world', 'sokoban', 'maze16'):
         oname, ob = WORKLOADS[other]
         steps = args.steps
         om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
@@ -569,7 +585,8 @@ def run_rank(args):
             'roofline': roofline(other, ob, T, om['fused'], om['kernel_ms'],
                                  om['per_launch_ms']),
             'cpu_baseline': None if args.no_cpu_baseline else
-                            cpu_baseline(other, T, args.cpu_seconds / 2, batch=ob)})
+                            cpu_baseline(other, T, args.cpu_seconds / 2,
+                                         batch=4096 if other.startswith('maze') else ob)})
         del om
         torch.cuda.empty_cache()
       line['also'] = also

@@ -25,6 +25,12 @@ import shape_zoo  # noqa: E402  (tests/shape_zoo.py: more games of the same two 
 SHAPE_GAMES.update(shape_zoo.library_builders())
 
 
+# Games of the wide tier (boards above 128 cells, one mover): campx_amd/games/maze.py
+from campx_amd.games import maze  # noqa: E402
+WIDE_GAMES = {'maze_16x16': functools.partial(maze.build, 16, 16),
+              'maze_15x17': functools.partial(maze.build, 15, 17)}
+
+
 SOKOBAN_LEVEL = {'sokoban': 0, 'sokoban_l1': 1, 'sokoban_l2': 2}
 
 

@@ -9,9 +9,11 @@ import pytest
 
 from campx_amd import gamespec
 from oracle import cpu
-from games_under_test import FUSED_GAMES, SHAPE_GAMES, SOKOBAN_LEVEL, sokoban_penalty_from_boards
+from games_under_test import (FUSED_GAMES, SHAPE_GAMES, WIDE_GAMES, SOKOBAN_LEVEL,
+                              sokoban_penalty_from_boards)
 
 ALL_GAMES = dict(FUSED_GAMES, **SHAPE_GAMES)
+ALL_GAMES.update(WIDE_GAMES)
 
 
 @pytest.mark.parametrize('name', sorted(ALL_GAMES))

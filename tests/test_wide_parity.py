@@ -204,6 +204,36 @@ def test_mazes_through_the_wide_kernels_against_the_table_walker(rows, cols, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('rows,cols,B', [(16, 16, 8192), (15, 17, 2001), (32, 32, 1024)])
+def test_mazes_against_the_c_oracle(rows, cols, B):
+  """oracle/campx_oracle.c - the literal restatement of the reference engine (full curtains,
+  cyclic shifts, z-order paint; pinned on maze_*.npz by test_oracle_golden.py) - runs the
+  maze's RULES; the HIP path walks the table tabulated from the Python classes.  Every byte
+  of every frame."""
+  from oracle import cpu as oracle_cpu
+  T = 100
+  game = maze.build(rows, cols, batch=B, device='cuda')
+  first, _, _ = game.its_showtime()
+  og = oracle_cpu.OracleGame.from_description(gamespec.describe(maze.build(rows, cols)))
+  obs0, board0 = og.first_frame()
+  assert np.array_equal(first.layered_board[B - 1].cpu().numpy(), obs0)
+  assert np.array_equal(first.board[B - 1].cpu().numpy(), board0)
+  rng = np.random.RandomState(rows + cols)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  gold = _golden(16, 16) if (rows, cols) == (16, 16) else None
+  if gold is not None:      # environments 0 and 1 walk to the goal as in the golden
+    actions[:, :2] = gold['actions'][:T, :2]
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = og.rollout(actions, reset_first=True)
+  assert np.array_equal(out['obs'].cpu().numpy(), want['obs'])
+  assert np.array_equal(out['board'].cpu().numpy(), want['board'])
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), want[k]), k
+  if gold is not None:
+    assert want['done'][:, :2].sum() == 2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('rows,cols', MAZES)
 def test_reference_engine_goldens_on_the_gpu(rows, cols):
   gold = _golden(rows, cols)

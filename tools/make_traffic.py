@@ -7,7 +7,7 @@
 databases are too large to travel back; the json and the text summaries do)
 
 Per configuration: WRITE_SIZE and FETCH_SIZE (KiB, separate passes) of the kernels of one
-rollout launch, per dispatch, summed.  WRITE_SIZE is taken at face value (it reads
+rollout launch, per dispatch (median over the run's dispatches), summed.  WRITE_SIZE is taken at face value (it reads
 1146.9 MB for the render kernel's exactly 1146.88 MB of stores).  FETCH_SIZE follows
 MI355X_MICROARCH.md: it reports half the bytes of a wide (16 B/lane) coalesced stream,
 which is what the update kernels' action loads are (3.34 MB reported for 6.55 MB of
@@ -23,12 +23,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_dispatch(db, counter):
+  """kernel -> bytes per dispatch: the MEDIAN over its dispatches (a run also holds one-off
+  dispatches of the same kernel - the one-frame render of its_showtime() - that an average
+  would mix in), for kernels dispatched at least half as often as the busiest one."""
   cur = sqlite3.connect(db).cursor()
   rows = cur.execute(
-      'select kernel_name, avg(v) from (select kernel_name, dispatch_id, sum(value) as v '
-      'from counters_collection where counter_name = ? group by kernel_name, dispatch_id) '
-      'group by kernel_name', (counter,)).fetchall()
-  return {k: v * 1024.0 for k, v in rows}
+      'select kernel_name, dispatch_id, sum(value) from counters_collection '
+      'where counter_name = ? group by kernel_name, dispatch_id', (counter,)).fetchall()
+  per = {}
+  for k, _, v in rows:
+    per.setdefault(k, []).append(v)
+  most = max(len(v) for v in per.values()) if per else 0
+  return {k: sorted(v)[len(v) // 2] * 1024.0 for k, v in per.items() if 2 * len(v) >= most}
 
 
 def main(specs):
