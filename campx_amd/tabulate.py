@@ -27,8 +27,11 @@ on the screen - which of two things on one cell shows - is already in the table 
 "is the character its cell shows" bits.  The tabulation is exact under conditions
 that are CHECKED while tabulating, never assumed (ValueError otherwise):
 
-* every moving thing occupies exactly one cell in every reached state (a drape's curtain
-  has exactly one 1; a sprite keeps its `visible` flag), there are at most four of them -
+* every moving thing occupies exactly one cell in every reached state - or NONE: a drape
+  whose curtain is empty (a key that was picked up, a door that opened) and a sprite that
+  is not `visible` (campx/things.py:294-296, 391-392; engine.py:314 skips it) are "absent",
+  tabulated as standing on a cell index the thing never occupies and never shown -, there
+  are at most four of them -
   the mode of a re-ordering game counts as one, and it has at most rows*cols values -,
   the board has at most 128 cells (one mover and no re-ordering: 1 024, the wide tier,
   csrc/k_wide.hip) and 16 characters;
@@ -130,6 +133,8 @@ class TracedGame(object):
     done uint8 [n], discount float32 [n], dcode uint8 [n] (0 = the default discount, else
     an index into `discount_list`), perf int8 [n], reached bool [n] (entries the game can
     get to; the others are self-loops that pay nothing);
+    absent_cells: per mover, the tracked values that stand for "not on the board" (an empty
+      curtain, an invisible sprite) - cell indices the thing never occupies; usually empty;
     mode_orders: the z-orders the game reaches (lists of characters back to front; the
       first is `z_order`, the one after `its_showtime()`).  With more than one, the tables
       track one more "thing" after the movers - K = len(movers) + 1 = `n_tracked` - whose
@@ -165,15 +170,24 @@ class TracedGame(object):
       idx = idx * HW + int(c)
     return idx * N_ACTIONS + action
 
+  def is_absent(self, k, cell):
+    """Mover k's tracked value `cell` stands for "nowhere" (an empty curtain, an invisible
+    sprite): an index it never occupies while on the board."""
+    return int(cell) in self.absent_cells[k]
+
   def model_board(self, cells, movers=True):
     """The flat board (character codes) when the movers stand at `cells` (followed by the
     z-order mode, if the game has more than one): backdrop, then every thing in that
     z-order (campx/engine.py:306-324).  `movers=False`: the scenery alone."""
     board = self.backdrop.copy().reshape(-1)
     static = dict(self.statics)
-    where = {ch: c for ch, c in zip(self.movers, cells)}
+    where = {ch: c for k, (ch, c) in enumerate(zip(self.movers, cells))
+             if not self.is_absent(k, c)}
+    gone = set(self.movers) - set(where)
     mode = cells[len(self.movers)] if len(self.mode_orders) > 1 else 0
     for ch in self.mode_orders[mode]:
+      if ch in gone:
+        continue
       if ch in where:
         if not movers:
           continue
@@ -297,21 +311,45 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
         len(modes), HW))
   K = len(movers)
 
-  def cell_of(img, ch):
+  def where_is(img, ch):
+    """('at', cell) or ('absent', key): the one cell a moving thing occupies, or - an empty
+    curtain, an invisible sprite (its position still counts as state) - nowhere."""
     part = img[order.index(ch)]
     ent = probe.things[ch]
     if isinstance(ent, _things.Sprite):
       if not part[2]:
-        _fail('sprite {!r} moves while invisible'.format(ch))
-      return part[0] * W + part[1]
+        return ('absent', part)
+      return ('at', part[0] * W + part[1])
     mask = np.frombuffer(part, np.uint8)
     if mask.max() > 1:
       _fail('the curtain of {!r} holds values other than 0 and 1'.format(ch))
     cells = np.flatnonzero(mask)
+    if len(cells) == 0:
+      return ('absent', b'')
     if len(cells) != 1:
       _fail('moving drape {!r} covers {} cells in a reachable state; the table kernels '
             'track a moving thing by the one cell it occupies'.format(ch, len(cells)))
-    return int(cells[0])
+    return ('at', int(cells[0]))
+
+  # absent states take cell indices the thing never stands on
+  places = [[where_is(img, ch) for img in images] for ch in movers]
+  absent_alias, absent_cells = [], []
+  for ch, seen in zip(movers, places):
+    used = {c for kind, c in seen if kind == 'at'}
+    keys = []
+    for kind, key in seen:
+      if kind == 'absent' and key not in keys:
+        keys.append(key)
+    free = [c for c in range(HW) if c not in used]
+    if len(keys) > len(free):
+      _fail('{!r} has {} different states in which it is not on the board; there is room '
+            'for {}'.format(ch, len(keys), len(free)))
+    absent_alias.append({key: free[j] for j, key in enumerate(keys)})
+    absent_cells.append(set(free[:len(keys)]))
+
+  def cell_of(s, k):
+    kind, what = places[k][s]
+    return what if kind == 'at' else absent_alias[k][what]
 
   game = TracedGame()
   game.rows, game.cols, game.chars = H, W, chars
@@ -319,6 +357,7 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   game.mode_orders = [list(z) for z in modes]
   game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
   game.movers = movers
+  game.absent_cells = absent_cells
   game.statics = []
   for ch in schedule:
     if ch in movers:
@@ -336,12 +375,15 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   if len(game.statics) > gamespec.MAX_STATIC:
     _fail('more than {} static things'.format(gamespec.MAX_STATIC))
 
-  state_cells = [tuple(cell_of(img, ch) for ch in movers) +
+  state_cells = [tuple(cell_of(s, k) for k in range(K)) +
                  ((modes.index(z),) if len(modes) > 1 else ())
-                 for img, z in zip(images, orders)]
+                 for s, z in enumerate(orders)]
   game.init_cells = state_cells[0]
   board0 = np.frombuffer(boards[0], np.uint8)
-  game.init_visible = [int(board0[state_cells[0][k]] == ord(ch)) for k, ch in enumerate(movers)]
+  game.init_visible = [int(places[k][0][0] == 'at' and board0[state_cells[0][k]] == ord(ch))
+                       for k, ch in enumerate(movers)]
+  if places[0][0][0] != 'at':
+    _fail('the first moving thing ({!r}) is not on the board after its_showtime()'.format(movers[0]))
 
   # ---- the render kernels lay ONE scenery row under the movers: no order may change it
   for m in range(1, len(modes)):
@@ -365,6 +407,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     for ch in who:
       if ch not in movers:
         _fail('hidden penalty watches {!r}, which never moves'.format(ch))
+      if absent_cells[movers.index(ch)]:
+        _fail('hidden penalty watches {!r}, which leaves the board'.format(ch))
     cls = np.zeros(HW, np.int32)
     for k, m in enumerate(masks):
       cls[np.flatnonzero(m.detach().cpu().numpy().reshape(-1))] = k + 1
@@ -376,6 +420,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     agent, masks = engine.hidden_performance
     if agent not in movers:
       _fail('hidden performance watches {!r}, which never moves'.format(agent))
+    if absent_cells[movers.index(agent)]:
+      _fail('hidden performance watches {!r}, which leaves the board'.format(agent))
     cls = np.zeros(HW, np.int32)
     for k, m in enumerate(masks):
       cls[np.flatnonzero(m.detach().cpu().numpy().reshape(-1))] = k + 1
@@ -414,7 +460,7 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     board = np.frombuffer(e.board, np.uint8)
     for k in range(K):
       game.next_cells[k, i] = dst[k]
-      game.visible[k, i] = int(board[dst[k]] == codes[k])
+      game.visible[k, i] = int(not game.is_absent(k, dst[k]) and board[dst[k]] == codes[k])
     if Kt > K:
       game.next_cells[K, i] = dst[K]            # the mode: never visible
     game.reward[i] = e.reward
@@ -459,6 +505,8 @@ def to_spec(game):
     spec.dyn_layer[d] = layer_of[ch]
     spec.dyn_z[d] = z_of[ch]
     spec.dyn_row0[d], spec.dyn_col0[d] = divmod(int(game.init_cells[d]), W)
+    if game.is_absent(d, game.init_cells[d]):
+      spec.dyn_z[d] = 0          # not on the board at the start: its_showtime() paints nothing
   if game.n_tracked > len(game.movers):
     # the z-order mode: a "thing" of z rank 0 - behind the backdrop, never painted - whose
     # cell is the index of the order in force (0 after its_showtime())
@@ -508,6 +556,8 @@ def to_spec(game):
       tr.next_cell, tr.perf = nxt, int(game.perf[i])
       tr.done = int(game.done[i]) | (int(game.dcode[i]) << 4)
       in_front = spec.static_top_z[nxt] > spec.dyn_z[0]
+      if game.reached[i]:        # (from the boards the user's own code rendered)
+        in_front = not game.visible[0, i]
       tr.paint = int(spec.static_top_layer[nxt]) | (0x80 if in_front else 0)
     spec.table_valid = 1
   return spec

@@ -88,7 +88,9 @@ class TableWalker(object):
       rows = np.flatnonzero(modes == m)
       for ch in order:                                # back to front
         if ch in who:
-          board[rows, cells[who[ch]][rows]] = ord(ch)
+          k = who[ch]
+          here = rows[~np.isin(cells[k][rows], sorted(g.absent_cells[k]))]   # (on the board)
+          board[here, cells[k][here]] = ord(ch)
         else:
           board[np.ix_(rows, np.flatnonzero(static[ch].reshape(-1)))] = ord(ch)
     layered = np.stack([(board == ord(ch)) for ch in g.chars], axis=1).astype(np.int8)

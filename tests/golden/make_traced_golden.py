@@ -2,7 +2,7 @@
 """Generate `traced_<game>.npz`: what the REFERENCE engine does with the test-local games of
 tests/traced_games.py (arbitrary Python classes: a skater that slides many cells, a sprite
 that mirrors a walker, a walker whose tiles change the frame's discount, a mole that
-changes its place in the z-order).
+changes its place in the z-order, a key, a door and a gem that leave and enter the board).
 
 Run in the build container only (needs /root/reference):
 
@@ -84,7 +84,7 @@ def run(build, actions):
 
 
 def main():
-  seeds = dict(ice_rink=300, mirror=301, toll_road=302, trio=303, burrow=304)
+  seeds = dict(ice_rink=300, mirror=301, toll_road=302, trio=303, burrow=304, vault=305)
   for name in sorted(traced_games.GAMES):
     actions = np.random.RandomState(seeds[name]).randint(0, 5, size=(80, 24))
     data = run(traced_games.GAMES[name], actions)

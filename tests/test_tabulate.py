@@ -102,6 +102,7 @@ def _traced_from_npz(path, rows, cols):
   game.init_cells = tuple(int(c) for c in got['init'])
   game.z_order = [chr(c) for c in got['z']]
   game.mode_orders = [game.z_order]
+  game.absent_cells = [set() for _ in game.movers]
   game.chars = [chr(c) for c in got['chars']]
   game.backdrop = got['backdrop']
   game.statics = [(chr(c), m) for c, m in zip(got['statics'], got['static_masks'])]
@@ -219,6 +220,14 @@ def test_test_local_games_tabulate_and_predict_the_generic_tier(name):
     assert traced.movers == ['A', 'L', 'T'] and traced.n == 35 ** 3 * 5   # 64-bit tuple entries
     both = traced.reached & (traced.next_cells[0] == traced.next_cells[1])
     assert both.any() and (traced.visible[0][both] == 0).all()   # the lift hides the walker
+  elif name == 'vault':
+    # walker, key, door, gem: four tracked things; three of them leave / enter the board
+    assert traced.movers == ['A', 'k', 'D', '$'] and traced.absent_cells == [set(), {0}, {0}, {0}]
+    assert traced.init_visible == [1, 1, 1, 0]               # the gem starts hidden
+    gone = traced.reached & (traced.next_cells[1] == 0)      # key picked up
+    assert gone.any() and (traced.visible[1][gone] == 0).all()
+    shown = traced.reached & (traced.visible[3] == 1)        # the gem shows: the door is open
+    assert shown.any() and (traced.next_cells[2][shown] == 0).all()
   elif name == 'burrow':
     assert traced.movers == ['A'] and len(traced.mode_orders) == 2    # above / under ground
     under = traced.reached & (traced.next_cells[1] == 1)

@@ -277,8 +277,80 @@ def burrow(**where):
       z_order='du$=A#', update_schedule='A#=du$', **where)
 
 
+# ------------------- things that leave the board: a key, the door it opens, a hidden gem
+
+VAULT_ART = ['########',
+             '#A k#$ #',
+             '#   D  #',
+             '########']
+
+
+class Key(things.Drape):
+  """Picked up when the walker stands on it: +1 and the curtain is EMPTY from then on."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    if (self.curtain * all_things['A'].curtain).sum():
+      self.curtain.zero_()
+      the_plot.add_reward(1.0)
+
+
+class Door(things.Drape):
+  """Blocks the walker (see VaultWalker) until the key is gone; then it is gone too."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    if self.curtain.sum() and not all_things['k'].curtain.sum():
+      self.curtain.zero_()
+      the_plot.add_reward(0.5)
+
+
+class VaultWalker(things.Drape):
+  """One cell per frame, stopped by walls and by the door while it stands; -0.25 per frame."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = _DELTA[_action_id(actions)]
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    if not all_things['#'].curtain[r + dr, c + dc] and not all_things['D'].curtain[r + dr, c + dc]:
+      self.curtain.zero_()
+      self.curtain[r + dr, c + dc] = 1
+    the_plot.add_reward(-0.25)
+
+
+class Gem(things.Sprite):
+  """A sprite that shows itself only while the door is open and the walker is not on it
+  (`_visible`, campx/things.py:294-296); the walker reaching it ends the episode with +10."""
+
+  def __init__(self, corner, position, character):
+    super(Gem, self).__init__(corner, position, character)
+    self._visible = False
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    on_it = bool(all_things['A'].curtain[self.position.row, self.position.col])
+    self._visible = (not all_things['D'].curtain.sum()) and not on_it
+    if on_it:
+      the_plot.add_reward(10.0)
+      the_plot.terminate_episode()
+
+
+def vault(**where):
+  """Update order: walker, key, door, gem - four things whose state changes (the gem only in
+  whether it shows)."""
+  return ascii_art_to_game(
+      VAULT_ART, what_lies_beneath=' ',
+      sprites={'$': Gem},
+      drapes={'A': VaultWalker, 'k': Key, 'D': Door, '#': things.FixedDrape},
+      z_order='k$DA#', update_schedule='AkD$#', **where)
+
+
 GAMES = {'ice_rink': ice_rink, 'mirror': mirror, 'toll_road': toll_road, 'trio': trio,
-         'burrow': burrow}
+         'burrow': burrow, 'vault': vault}
 
 
 # ------------------------------------------------------------- games that must be refused
