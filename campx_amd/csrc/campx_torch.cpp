@@ -417,12 +417,13 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
            "campx_shape_rollout_launch");
 }
 
-// Wide tier (boards above 128 cells, include/campx_hip.h): reset (actions = None), one frame
-// (actions [B], outputs [B...]) or T frames (actions [T, B]) through one op.  `tables`: the
-// device blob campx_wide_tables_build() filled.  `trace`: int16 [B] / [T, B] (rows may be
+// Wide tier (state-table games: boards above 128 cells, include/campx_hip.h): reset
+// (actions = None), one frame (actions [B], outputs [B...]) or T frames (actions [T, B])
+// through one op.  `tables`: the device blob campx_wide_tables_build() filled.  `state`:
+// int32 [B], the environments' state indices.  `trace`: int16 [K, B] / [K, T, B] (rows may be
 // padded like the other per-frame streams).  With T frames, `obs` is [T, B, L, H, W] (every
 // frame) or [B, L, H, W] (the last one).
-void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& pos, Tensor& done,
+void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& state, Tensor& done,
                   const OptTensor& ret, const OptTensor& actions, Tensor& obs, const OptTensor& board,
                   const OptTensor& reward, const OptTensor& discount, const OptTensor& step_done,
                   const OptTensor& perf, Tensor& trace, const OptTensor& bad_count,
@@ -431,11 +432,11 @@ void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& pos, Te
                   spec_host.is_contiguous() && spec_host.numel() == (int64_t)sizeof(CampxWideSpec),
               "campx: spec_host must be the CampxWideSpec blob as a CPU uint8 tensor");
   const CampxWideSpec* hs = reinterpret_cast<const CampxWideSpec*>(spec_host.data_ptr());
-  TORCH_CHECK(pos.device().is_cuda() && pos.dim() == 2,
+  TORCH_CHECK(state.device().is_cuda() && state.dim() == 1,
               "campx::wide_rollout: state must be on a HIP device (no CPU implementation)");
-  const c10::Device dev = pos.device();
-  const int64_t B = pos.size(1), L = hs->n_layers, H = hs->rows, W = hs->cols;
-  want(pos, "pos", at::kChar, dev, {2, B});
+  const c10::Device dev = state.device();
+  const int64_t B = state.size(0), K = hs->n_dyn, L = hs->n_layers, H = hs->rows, W = hs->cols;
+  want(state, "state", at::kInt, dev, {B});
   want(done, "done", at::kByte, dev, {B});
   if (ret.has_value()) want(*ret, "ret", at::kFloat, dev, {B});
   TORCH_CHECK(tables.device() == dev && tables.scalar_type() == at::kByte && tables.is_contiguous() &&
@@ -452,13 +453,29 @@ void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& pos, Te
   }
   CampxOutputs out{};
   int64_t pitch = 0;
+  // the trace first: with one frame only its planes tell the row pitch
+  TORCH_CHECK(trace.device() == dev && trace.scalar_type() == at::kShort,
+              "campx: trace must be an int16 tensor on ", dev);
+  if (frames) {
+    TORCH_CHECK(trace.dim() == 3 && trace.size(0) == K && trace.size(1) == T && trace.size(2) == B &&
+                    (B == 1 || trace.stride(2) == 1),
+                "campx: trace must be int16 [", K, ", ", T, ", ", B, "], contiguous within a row");
+    if (T > 1) pitch = trace.stride(1);
+    else if (K > 1) pitch = trace.stride(0);
+    TORCH_CHECK(pitch == 0 || (pitch >= B && (K == 1 || trace.stride(0) == T * pitch)),
+                "campx: trace rows must be >= B apart and its planes T * pitch apart");
+  } else {
+    TORCH_CHECK(trace.dim() == 2 && trace.size(0) == K && trace.size(1) == B &&
+                    (B == 1 || trace.stride(1) == 1),
+                "campx: trace must be int16 [", K, ", ", B, "], contiguous within a row");
+    if (K > 1) pitch = trace.stride(0);
+    TORCH_CHECK(pitch == 0 || pitch >= B, "campx: trace rows must be >= B apart");
+  }
   auto stream_of = [&](const OptTensor& t, const char* name, at::ScalarType dtype) {
     if (!t.has_value()) return;
     if (frames) want_rows(*t, name, dtype, dev, T, B, pitch);
     else want(*t, name, dtype, dev, {B});
   };
-  if (frames) want_rows(trace, "trace", at::kShort, dev, T, B, pitch);
-  else want(trace, "trace", at::kShort, dev, {B});
   stream_of(reward, "reward", at::kFloat);
   stream_of(discount, "discount", at::kFloat);
   stream_of(step_done, "step_done", at::kByte);
@@ -486,15 +503,15 @@ void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& pos, Te
   out.trace = reinterpret_cast<uint8_t*>(trace.data_ptr());
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, dev);
-  CampxState state{reinterpret_cast<int8_t*>(pos.data_ptr()), reinterpret_cast<uint8_t*>(done.data_ptr()),
-                   opt_ptr<float>(ret), nullptr};
+  CampxState st{reinterpret_cast<int8_t*>(state.data_ptr()), reinterpret_cast<uint8_t*>(done.data_ptr()),
+                opt_ptr<float>(ret), nullptr};
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   if (!actions.has_value())
-    check_ok(campx_wide_reset_launch(hs, tables.data_ptr(), state, out, B, stream),
+    check_ok(campx_wide_reset_launch(hs, tables.data_ptr(), st, out, B, stream),
              "campx_wide_reset_launch");
   else
-    check_ok(campx_wide_rollout_launch(hs, tables.data_ptr(), state,
+    check_ok(campx_wide_rollout_launch(hs, tables.data_ptr(), st,
                                        reinterpret_cast<const int8_t*>(actions->data_ptr()), out, B,
                                        (int32_t)T, reset_first ? 1 : 0, stream),
              "campx_wide_rollout_launch");
@@ -611,7 +628,7 @@ TORCH_LIBRARY(campx, m) {
       "Tensor(j!)? bad_count, Tensor(k!)? bad_flag, bool reset_first, bool emit_first, "
       "Tensor(l!)? trace=None) -> ()");
   m.def(
-      "wide_rollout(Tensor spec_host, Tensor tables, Tensor(a!) pos, Tensor(b!) done, "
+      "wide_rollout(Tensor spec_host, Tensor tables, Tensor(a!) state, Tensor(b!) done, "
       "Tensor(c!)? ret, Tensor? actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
       "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!) trace, "
       "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first) -> ()");

@@ -342,21 +342,30 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
     if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
   } while (0)
   if (src.wide) {
-    // one mover, streaming stores (the A/B knob CAMPX_STORE_NT is the one-cell tier's)
-    if (src.n_dyn != 1) return CAMPX_ESPEC;
-    if (is_board) {
-      if (odd) CAMPX_RENDER5(1, true, true, 0, true, true);
-      else CAMPX_RENDER5(1, true, true, 0, false, true);
-    } else if (fmt == 1) {
-      if (odd) CAMPX_RENDER5(1, false, true, 1, true, true);
-      else CAMPX_RENDER5(1, false, true, 1, false, true);
-    } else if (fmt == 2) {
-      if (odd) CAMPX_RENDER5(1, false, true, 2, true, true);
-      else CAMPX_RENDER5(1, false, true, 2, false, true);
-    } else {
-      if (odd) CAMPX_RENDER5(1, false, true, 0, true, true);
-      else CAMPX_RENDER5(1, false, true, 0, false, true);
+    // streaming stores (the A/B knob CAMPX_STORE_NT is the one-cell tier's)
+#define CAMPX_RENDER_WIDE(KK)                                             \
+  do {                                                                    \
+    if (is_board) {                                                       \
+      if (odd) CAMPX_RENDER5(KK, true, true, 0, true, true);              \
+      else CAMPX_RENDER5(KK, true, true, 0, false, true);                 \
+    } else if (fmt == 1) {                                                \
+      if (odd) CAMPX_RENDER5(KK, false, true, 1, true, true);             \
+      else CAMPX_RENDER5(KK, false, true, 1, false, true);                \
+    } else if (fmt == 2) {                                                \
+      if (odd) CAMPX_RENDER5(KK, false, true, 2, true, true);             \
+      else CAMPX_RENDER5(KK, false, true, 2, false, true);                \
+    } else {                                                              \
+      if (odd) CAMPX_RENDER5(KK, false, true, 0, true, true);             \
+      else CAMPX_RENDER5(KK, false, true, 0, false, true);                \
+    }                                                                     \
+  } while (0)
+    switch (src.n_dyn) {
+      case 1: CAMPX_RENDER_WIDE(1); break;
+      case 2: CAMPX_RENDER_WIDE(2); break;
+      case 3: CAMPX_RENDER_WIDE(3); break;
+      default: CAMPX_RENDER_WIDE(4); break;
     }
+#undef CAMPX_RENDER_WIDE
   } else {
     switch (src.n_dyn) {
       case 1: CAMPX_RENDER1(1); break;

@@ -1,6 +1,8 @@
-// k_wide.hip - the wide tier: one-mover games on boards above 128 cells (up to 1 024).
+// k_wide.hip - the wide tier: games run from their STATE table ((state, action) -> state,
+// one row per reachable state), which has no board-size limit: boards above 128 cells (up to
+// 1 024), up to four things that show, hidden values behind them.
 //
-// The update pass is a walk through the game's (cell, action) table, which the HOST filled
+// The update pass is a walk through that table, which the HOST filled
 // (campx_amd/tabulate.py); the observation stream is k_render.hip's render kernel reading a
 // 16-bit trace.  A frame row is L*rows*cols bytes - 1 280 for a 16x16 board with five
 // characters - against 2 bytes of trace, 4 of reward and 1 of action, so the update kernel
@@ -14,49 +16,63 @@ namespace campx_impl {
 
 constexpr int kWideThreads = 256;
 constexpr int kWideAhead = 8;     // frames whose actions are fetched before their chain runs
+constexpr size_t kWideLdsMax = 144 * 1024;   // tables up to this size are staged in LDS
 
 struct WideParams {
-  int32_t cols, cells, init_cell;
+  int32_t n_states, n_dyn;
   float discounts[16];
 };
 
-// LDS / table-blob entry: x = reward; y = [0:9] the cell the NEXT frame starts from (the
-// art's cell when this frame ended the episode: the rebuild is folded into the chain),
-// [10:19] the cell after this frame, [20] whether the mover shows there, [21] done,
-// [22:25] discount code, [26:29] the scenery layer it covers there.
-__host__ __device__ __forceinline__ uint32_t wide_pack(uint32_t from, uint32_t next, uint32_t vis,
-                                                       uint32_t done, uint32_t dcode, uint32_t cover) {
-  return from | (next << 10) | (vis << 20) | (done << 21) | (dcode << 22) | (cover << 26);
+// Table-blob entry of (state, action): x = reward; y = [0:19] the state after the frame,
+// [20] done, [21:24] discount code.  (The state the NEXT frame starts from is state 0 when
+// the frame ended the episode: the rebuild is one select on the chain.)
+__host__ __device__ __forceinline__ uint32_t wide_pack(uint32_t next, uint32_t done, uint32_t dcode) {
+  return next | (done << 20) | (dcode << 21);
 }
 
-template <bool kPerf>
+// kLds: the state table (entries, per-state trace entries, perf bytes) sits in LDS; else it
+// is read through L1 / L2 (games with thousands of states).
+template <bool kLds, bool kPerf>
 __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
-    WideParams wp, const uint2* __restrict__ entries, const int8_t* __restrict__ perf_tab,
-    CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    WideParams wp, const uint2* __restrict__ g_entries, const uint2* __restrict__ g_cells,
+    const int8_t* __restrict__ g_perf, int32_t* __restrict__ state, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
-  extern __shared__ __attribute__((aligned(16))) uint2 table[];   // cells * 5 (+ perf bytes)
+  extern __shared__ __attribute__((aligned(16))) uint2 lds_tables[];
   __shared__ float discounts[16];
-  const int n_entries = wp.cells * CAMPX_N_ACTIONS;
-  int8_t* perf_lds = reinterpret_cast<int8_t*>(table + n_entries);
-  for (int i = threadIdx.x; i < n_entries; i += kWideThreads) table[i] = entries[i];
-  if (kPerf)
-    for (int i = threadIdx.x; i < n_entries; i += kWideThreads) perf_lds[i] = perf_tab[i];
+  const int S = wp.n_states, n_entries = S * CAMPX_N_ACTIONS, K = wp.n_dyn;
+  const uint2* entries = g_entries;
+  const uint2* cells = g_cells;
+  const int8_t* perf_tab = g_perf;
+  if (kLds) {
+    uint2* l_entries = lds_tables;
+    uint2* l_cells = l_entries + n_entries;
+    int8_t* l_perf = reinterpret_cast<int8_t*>(l_cells + S);
+    for (int i = threadIdx.x; i < n_entries; i += kWideThreads) l_entries[i] = g_entries[i];
+    for (int i = threadIdx.x; i < S; i += kWideThreads) l_cells[i] = g_cells[i];
+    if (kPerf)
+      for (int i = threadIdx.x; i < n_entries; i += kWideThreads) l_perf[i] = g_perf[i];
+    entries = l_entries;
+    cells = l_cells;
+    perf_tab = l_perf;
+  }
   if (threadIdx.x < 16) discounts[threadIdx.x] = wp.discounts[threadIdx.x];
   __syncthreads();
 
   const int64_t env = (int64_t)blockIdx.x * kWideThreads + threadIdx.x;
   if (env >= B) return;
-  const int W = wp.cols;
-  int cell = wp.init_cell, over = 0;
+  uint32_t now = 0;
+  int over = 0;
   float ret = 0.0f;
   if (!reset_first) {
-    cell = (int)st.pos[env] * W + (int)st.pos[B + env];
+    now = (uint32_t)state[env];
+    now = now < (uint32_t)S ? now : 0u;      // (a state index from outside: start over)
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
   }
-  uint32_t from = (uint32_t)(over ? wp.init_cell : cell);
+  uint32_t from = over ? 0u : now;
   uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
-  const int64_t P = row_pitch(out, B);
+  const int64_t P = row_pitch(out, B), plane = (int64_t)T * P;
   int bad = 0;
   for (int t0 = 0; t0 < T; t0 += kWideAhead) {
     uint32_t a[kWideAhead];
@@ -70,53 +86,59 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
       if (t0 + j < T) {
         bad += a[j] > 4u;
         const uint32_t idx = from * CAMPX_N_ACTIONS + (a[j] > 4u ? 4u : a[j]);
-        const uint2 e = table[idx];
-        from = e.y & 0x3ffu;                       // the chain: cell -> entry -> cell
-        const uint32_t done = (e.y >> 21) & 1u, dcode = (e.y >> 22) & 15u;
+        const uint2 e = entries[idx];
+        now = e.y & 0xfffffu;
+        const uint32_t done = (e.y >> 20) & 1u, dcode = (e.y >> 21) & 15u;
+        from = done ? 0u : now;                      // the chain: state -> entry -> state
+        const uint2 c = cells[now];                  // where things show in the state reached
         const int64_t at = (int64_t)(t0 + j) * P + env;
-        trace[at] = (uint16_t)(((e.y >> 10) & 0x3ffu) | (((e.y >> 26) & 15u) << 10) |
-                               (((e.y >> 20) & 1u) << 15));
+        trace[at] = (uint16_t)c.x;
+        if (K > 1) trace[plane + at] = (uint16_t)(c.x >> 16);
+        if (K > 2) trace[2 * plane + at] = (uint16_t)c.y;
+        if (K > 3) trace[3 * plane + at] = (uint16_t)(c.y >> 16);
         if (out.reward) out.reward[at] = __uint_as_float(e.x);
-        if (out.discount)
-          out.discount[at] = __uint_as_float(discount_bits(discounts, dcode, done));
+        if (out.discount) out.discount[at] = __uint_as_float(discount_bits(discounts, dcode, done));
         if (out.done) out.done[at] = (uint8_t)done;
-        if (kPerf && out.perf) out.perf[at] = perf_lds[idx];
+        if (kPerf && out.perf) out.perf[at] = perf_tab[idx];
         ret = (over ? 0.0f : ret) + real_reward(__uint_as_float(e.x));
         over = (int)done;
-        cell = (int)((e.y >> 10) & 0x3ffu);
       }
     }
   }
-  st.pos[env] = (int8_t)(cell / W);
-  st.pos[B + env] = (int8_t)(cell % W);
+  state[env] = (int32_t)now;
   st.done[env] = (uint8_t)over;
   if (st.ret) st.ret[env] = ret;
   report_bad_actions(out, bad);
 }
 
-// its_showtime(): state from the art and the trace row of the first observation.
-__global__ void wide_reset_kernel(int32_t row0, int32_t col0, uint32_t entry, CampxState st,
-                                  uint16_t* __restrict__ trace, int64_t B) {
+// its_showtime(): state 0 and the trace rows of the first observation.
+__global__ void wide_reset_kernel(const uint2* __restrict__ cells, int32_t K, int32_t* __restrict__ state,
+                                  CampxState st, uint16_t* __restrict__ trace, int64_t P, int64_t B) {
   const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= B) return;
-  st.pos[env] = (int8_t)row0;
-  st.pos[B + env] = (int8_t)col0;
+  const uint2 c = cells[0];
+  state[env] = 0;
   st.done[env] = 0;
   if (st.ret) st.ret[env] = 0.0f;
-  trace[env] = (uint16_t)entry;
+  trace[env] = (uint16_t)c.x;
+  if (K > 1) trace[P + env] = (uint16_t)(c.x >> 16);
+  if (K > 2) trace[2 * P + env] = (uint16_t)c.y;
+  if (K > 3) trace[3 * P + env] = (uint16_t)(c.y >> 16);
 }
 
-// ---- the table blob: [entries uint2 x n][perf int8 x n, padded to 16][rot_obs][rot_board]
+// ---- the table blob: [entries uint2 x 5S][cells uint2 x S][perf int8 x 5S, padded to 16]
+// [rot_obs][rot_board]
 struct WideLayout {
-  int64_t n_entries, perf_off, rot_obs_off, rot_board_off, total;
+  int64_t n_entries, cells_off, perf_off, rot_obs_off, rot_board_off, total;
   int pitch_obs, pitch_board;
 };
 
 WideLayout wide_layout(const CampxWideSpec& s) {
   WideLayout w;
-  const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
-  w.n_entries = HW * CAMPX_N_ACTIONS;
-  w.perf_off = w.n_entries * (int64_t)sizeof(uint2);
+  const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers, S = s.n_states;
+  w.n_entries = S * CAMPX_N_ACTIONS;
+  w.cells_off = w.n_entries * (int64_t)sizeof(uint2);
+  w.perf_off = w.cells_off + S * (int64_t)sizeof(uint2);
   w.rot_obs_off = (w.perf_off + w.n_entries + 15) & ~(int64_t)15;
   w.pitch_obs = (int)(((R + 15) & ~(int64_t)15) + 16);
   w.rot_board_off = w.rot_obs_off + 16ll * w.pitch_obs;
@@ -132,8 +154,8 @@ RenderSource wide_render_source(const CampxWideSpec& s, const void* tables_dev) 
   src.rows = s.rows;
   src.cols = s.cols;
   src.n_layers = s.n_layers;
-  src.n_dyn = 1;
-  src.dyn_layer[0] = s.dyn_layer;
+  src.n_dyn = s.n_dyn;
+  for (int d = 0; d < s.n_dyn; ++d) src.dyn_layer[d] = s.dyn_layer[d];
   memcpy(src.layer_char, s.layer_char, sizeof(src.layer_char));
   const char* blob = static_cast<const char*>(tables_dev);
   src.rot_obs = reinterpret_cast<const int8_t*>(blob + w.rot_obs_off);
@@ -149,15 +171,34 @@ bool wide_last_only(const CampxOutputs& out) {
          out.obs_format == CAMPX_OBS_INT8;
 }
 
+// The plain fields of a spec (what a launch relies on).
+int32_t wide_validate_plain(const CampxWideSpec* s) {
+  if (!s) return CAMPX_EINVAL;
+  if (s->magic != CAMPX_SPEC_MAGIC || s->version != CAMPX_SPEC_VERSION) return CAMPX_ESPEC;
+  if (s->rows < 1 || s->cols < 1 || s->rows > 127 || s->cols > 127) return CAMPX_ESPEC;
+  const int HW = s->rows * s->cols;
+  if (HW < 16 || HW > CAMPX_WIDE_MAX_CELLS) return CAMPX_ESPEC;
+  if (s->n_layers < 1 || s->n_layers > CAMPX_MAX_LAYERS) return CAMPX_ESPEC;
+  if (s->n_dyn < 1 || s->n_dyn > CAMPX_MAX_DYN) return CAMPX_ESPEC;
+  if (s->n_states < 1 || s->n_states > CAMPX_WIDE_MAX_STATES) return CAMPX_ESPEC;
+  for (int d = 0; d < s->n_dyn; ++d)
+    if (s->dyn_layer[d] < 0 || s->dyn_layer[d] >= s->n_layers) return CAMPX_ESPEC;
+  if ((s->has_perf | s->any_reward) & ~1) return CAMPX_ESPEC;
+  for (int i = 0; i < HW; ++i)
+    if (s->static_top_layer[i] >= s->n_layers) return CAMPX_ESPEC;
+  return CAMPX_OK;
+}
+
 int32_t wide_check(const CampxWideSpec* s, const void* tables, const CampxState& st,
                    const CampxOutputs& out, int64_t B, int32_t T) {
   if (!s || !tables || !st.pos || !st.done || !out.obs || !out.trace || B <= 0 || T < 0)
     return CAMPX_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(out.obs) & 15) || (reinterpret_cast<uintptr_t>(out.trace) & 1))
+  if ((reinterpret_cast<uintptr_t>(out.obs) & 15) || (reinterpret_cast<uintptr_t>(out.trace) & 1) ||
+      (reinterpret_cast<uintptr_t>(st.pos) & 3))
     return CAMPX_EINVAL;
   if (out.scalar_pitch && out.scalar_pitch < B) return CAMPX_EINVAL;
   if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
-  const int32_t v = campx_wide_spec_validate(s);
+  const int32_t v = wide_validate_plain(s);
   if (v != CAMPX_OK) return v;
   if (out.perf && !s->has_perf) return CAMPX_EINVAL;
   const int64_t HW = (int64_t)s->rows * s->cols, LHW = HW * s->n_layers;
@@ -167,8 +208,9 @@ int32_t wide_check(const CampxWideSpec* s, const void* tables, const CampxState&
   return CAMPX_OK;
 }
 
+// `plane`: distance between two things' planes of the trace, in entries.
 int32_t wide_renders(const CampxWideSpec& s, const void* tables_dev, const uint16_t* trace,
-                     CampxOutputs out, int64_t B, int32_t T, hipStream_t stream) {
+                     CampxOutputs out, int64_t B, int32_t T, int64_t plane, hipStream_t stream) {
   const RenderSource src = wide_render_source(s, tables_dev);
   const int64_t pitch = row_pitch(out, B);
   const int64_t elem = out.obs_format == CAMPX_OBS_INT8 ? 1 : 2;
@@ -180,11 +222,11 @@ int32_t wide_renders(const CampxWideSpec& s, const void* tables_dev, const uint1
   for (int64_t t0 = 0; t0 < T; t0 += 65520) {
     const int32_t n = (int32_t)(T - t0 < 65520 ? T - t0 : 65520);
     int32_t rc = launch_render_from(src, trace + t0 * pitch, out.obs + t0 * out.obs_t_stride * elem,
-                                    B, n, 0, pitch, false, out.obs_format, stream);
+                                    B, n, plane, pitch, false, out.obs_format, stream);
     if (rc != CAMPX_OK) return rc;
     if (out.board) {
-      rc = launch_render_from(src, trace + t0 * pitch, out.board + t0 * out.board_t_stride, B, n, 0,
-                              pitch, true, 0, stream);
+      rc = launch_render_from(src, trace + t0 * pitch, out.board + t0 * out.board_t_stride, B, n,
+                              plane, pitch, true, 0, stream);
       if (rc != CAMPX_OK) return rc;
     }
   }
@@ -200,50 +242,55 @@ extern "C" {
 int32_t campx_wide_spec_size(void) { return (int32_t)sizeof(CampxWideSpec); }
 
 int32_t campx_wide_spec_validate(const CampxWideSpec* s) {
-  if (!s) return CAMPX_EINVAL;
-  if (s->magic != CAMPX_SPEC_MAGIC || s->version != CAMPX_SPEC_VERSION) return CAMPX_ESPEC;
-  if (s->rows < 1 || s->cols < 1 || s->rows > 127 || s->cols > 127) return CAMPX_ESPEC;
-  const int HW = s->rows * s->cols;
-  if (HW < 16 || HW > CAMPX_WIDE_MAX_CELLS) return CAMPX_ESPEC;
-  if (s->n_layers < 1 || s->n_layers > CAMPX_MAX_LAYERS) return CAMPX_ESPEC;
-  if (s->dyn_layer < 0 || s->dyn_layer >= s->n_layers) return CAMPX_ESPEC;
-  if (s->init_cell < 0 || s->init_cell >= HW) return CAMPX_ESPEC;
-  if ((s->init_hidden | s->has_perf | s->any_reward) & ~1) return CAMPX_ESPEC;
-  for (int i = 0; i < HW; ++i)
-    if (s->static_top_layer[i] >= s->n_layers) return CAMPX_ESPEC;
-  for (int i = 0; i < HW * CAMPX_N_ACTIONS; ++i) {
-    const CampxWideTransition& tr = s->table[i];
-    if ((tr.next_cell & 0x3ffu) >= (uint32_t)HW || (tr.next_cell & 0x7c00u) || (tr.done & 0x0eu))
-      return CAMPX_ESPEC;
-  }
+  const int32_t v = wide_validate_plain(s);
+  if (v != CAMPX_OK) return v;
+  const int HW = s->rows * s->cols, S = s->n_states, K = s->n_dyn;
+  if (s->state_cells)
+    for (int64_t i = 0; i < (int64_t)S * K; ++i)
+      if ((s->state_cells[i] & 0x3ffu) >= (uint32_t)HW || (s->state_cells[i] & 0x7c00u)) return CAMPX_ESPEC;
+  if (s->next_state)
+    for (int64_t i = 0; i < (int64_t)S * CAMPX_N_ACTIONS; ++i)
+      if (s->next_state[i] < 0 || s->next_state[i] >= S) return CAMPX_ESPEC;
+  if (s->done)
+    for (int64_t i = 0; i < (int64_t)S * CAMPX_N_ACTIONS; ++i)
+      if (s->done[i] & 0x0eu) return CAMPX_ESPEC;
   return CAMPX_OK;
 }
 
 int64_t campx_wide_tables_bytes(const CampxWideSpec* s) {
-  if (campx_wide_spec_validate(s) != CAMPX_OK) return 0;
+  if (wide_validate_plain(s) != CAMPX_OK) return 0;
   return wide_layout(*s).total;
 }
 
 int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* stream) {
   if (!s || !tables_dev) return CAMPX_EINVAL;
+  if (!s->state_cells || !s->next_state || !s->reward || !s->done) return CAMPX_EINVAL;
+  if (s->has_perf && !s->perf) return CAMPX_EINVAL;
   const int32_t v = campx_wide_spec_validate(s);
   if (v != CAMPX_OK) return v;
   const WideLayout w = wide_layout(*s);
-  const int HW = s->rows * s->cols, R = HW * s->n_layers;
+  const int HW = s->rows * s->cols, R = HW * s->n_layers, S = s->n_states, K = s->n_dyn;
   char* blob = static_cast<char*>(calloc(1, (size_t)w.total));
   if (!blob) return CAMPX_ENOMEM;
   uint2* entries = reinterpret_cast<uint2*>(blob);
+  uint2* cells = reinterpret_cast<uint2*>(blob + w.cells_off);
   int8_t* perf = reinterpret_cast<int8_t*>(blob + w.perf_off);
-  for (int i = 0; i < HW * CAMPX_N_ACTIONS; ++i) {
-    const CampxWideTransition& tr = s->table[i];
-    const uint32_t next = tr.next_cell & 0x3ffu, hidden = tr.next_cell >> 15;
-    const uint32_t done = tr.done & 1u, dcode = tr.done >> 4;
+  for (int64_t i = 0; i < (int64_t)S * CAMPX_N_ACTIONS; ++i) {
     uint32_t bits;
-    memcpy(&bits, &tr.reward, 4);
+    memcpy(&bits, &s->reward[i], 4);
     entries[i].x = bits;
-    entries[i].y = wide_pack(done ? (uint32_t)s->init_cell : next, next, hidden ? 0u : 1u, done, dcode,
-                             s->static_top_layer[next]);
-    perf[i] = tr.perf;
+    entries[i].y = wide_pack((uint32_t)s->next_state[i], s->done[i] & 1u, (uint32_t)(s->done[i] >> 4));
+    perf[i] = s->perf ? s->perf[i] : 0;
+  }
+  for (int st = 0; st < S; ++st) {
+    uint32_t e[4] = {0u, 0u, 0u, 0u};
+    for (int d = 0; d < K; ++d) {
+      const uint32_t c = s->state_cells[(int64_t)st * K + d];
+      const uint32_t cell = c & 0x3ffu;
+      e[d] = cell | ((uint32_t)s->static_top_layer[cell] << 10) | ((c >> 15) ? 0u : 0x8000u);
+    }
+    cells[st].x = e[0] | (e[1] << 16);
+    cells[st].y = e[2] | (e[3] << 16);
   }
   // the scenery's row (layers by equality, campx/rendering.py:204-215) and its rotations
   int8_t* row = static_cast<int8_t*>(calloc(1, (size_t)R + HW));
@@ -276,17 +323,18 @@ int32_t campx_wide_reset_launch(const CampxWideSpec* s, const void* tables_dev, 
   if (rc != CAMPX_OK) return rc;
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  const uint32_t entry = (uint32_t)s->init_cell | ((uint32_t)s->static_top_layer[s->init_cell] << 10) |
-                         (s->init_hidden ? 0u : 0x8000u);
+  const WideLayout w = wide_layout(*s);
+  const uint2* cells = reinterpret_cast<const uint2*>(static_cast<const char*>(tables_dev) + w.cells_off);
   uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
-  hipLaunchKernelGGL(wide_reset_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, hs,
-                     s->init_cell / s->cols, s->init_cell % s->cols, entry, st, trace, B);
+  const int64_t P = row_pitch(out, B);
+  hipLaunchKernelGGL(wide_reset_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, hs, cells,
+                     s->n_dyn, reinterpret_cast<int32_t*>(st.pos), st, trace, P, B);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
   CampxOutputs one = out;     // one frame, written to slot 0 of each buffer
   one.obs_t_stride = 0;
   one.board_t_stride = 0;
-  return wide_renders(*s, tables_dev, trace, one, B, 1, hs);
+  return wide_renders(*s, tables_dev, trace, one, B, 1, P, hs);
 }
 
 int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev, CampxState st,
@@ -300,28 +348,35 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   const WideLayout w = wide_layout(*s);
   WideParams wp;
   memset(&wp, 0, sizeof(wp));
-  wp.cols = s->cols;
-  wp.cells = s->rows * s->cols;
-  wp.init_cell = s->init_cell;
+  wp.n_states = s->n_states;
+  wp.n_dyn = s->n_dyn;
   wp.discounts[0] = 1.0f;
   for (int i = 1; i < 16; ++i) wp.discounts[i] = s->discount_list[i];
   const char* blob = static_cast<const char*>(tables_dev);
   const uint2* entries = reinterpret_cast<const uint2*>(blob);
+  const uint2* cells = reinterpret_cast<const uint2*>(blob + w.cells_off);
   const int8_t* perf = reinterpret_cast<const int8_t*>(blob + w.perf_off);
-  const size_t lds = (size_t)w.n_entries * sizeof(uint2) + (out.perf ? (size_t)w.n_entries : 0);
+  int32_t* state = reinterpret_cast<int32_t*>(st.pos);
+  const size_t want = (size_t)w.n_entries * sizeof(uint2) + (size_t)s->n_states * sizeof(uint2) +
+                      (out.perf ? (size_t)w.n_entries : 0);
+  const bool in_lds = want <= kWideLdsMax;
+  const size_t lds = in_lds ? want : 0;
   const dim3 grid((unsigned)((B + kWideThreads - 1) / kWideThreads));
-  if (out.perf) {
-    CAMPX_ALLOW_LDS(wide_update_kernel<true>, lds);
-    hipLaunchKernelGGL(wide_update_kernel<true>, grid, dim3(kWideThreads), lds, hs, wp, entries, perf,
-                       st, actions, out, B, T, reset_first);
-  } else {
-    CAMPX_ALLOW_LDS(wide_update_kernel<false>, lds);
-    hipLaunchKernelGGL(wide_update_kernel<false>, grid, dim3(kWideThreads), lds, hs, wp, entries, perf,
-                       st, actions, out, B, T, reset_first);
-  }
+#define CAMPX_WIDE_LAUNCH(LDS, PERF)                                                              \
+  do {                                                                                            \
+    CAMPX_ALLOW_LDS((wide_update_kernel<LDS, PERF>), lds);                                        \
+    hipLaunchKernelGGL((wide_update_kernel<LDS, PERF>), grid, dim3(kWideThreads), lds, hs, wp,    \
+                       entries, cells, perf, state, st, actions, out, B, T, reset_first);         \
+  } while (0)
+  if (in_lds && out.perf) CAMPX_WIDE_LAUNCH(true, true);
+  else if (in_lds) CAMPX_WIDE_LAUNCH(true, false);
+  else if (out.perf) CAMPX_WIDE_LAUNCH(false, true);
+  else CAMPX_WIDE_LAUNCH(false, false);
+#undef CAMPX_WIDE_LAUNCH
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
-  return wide_renders(*s, tables_dev, reinterpret_cast<const uint16_t*>(out.trace), out, B, T, hs);
+  return wide_renders(*s, tables_dev, reinterpret_cast<const uint16_t*>(out.trace), out, B, T,
+                      (int64_t)T * row_pitch(out, B), hs);
 }
 
 }  // extern "C"

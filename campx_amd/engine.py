@@ -301,7 +301,9 @@ class Engine(object):
 
     if self._batch is not None:
       from . import fused
-      if traced is not None and traced.rows * traced.cols > gamespec.MAX_CELLS:
+      if traced is not None and traced.dense_reason is not None:
+        # (more than 128 cells, or more tracked values than the cell-indexed tables take:
+        # the game runs from its state table)
         from . import wide
         self._fused = wide.WideGame(self, self._batch, self._device, traced)
         return self._fused.showtime()

@@ -476,29 +476,27 @@ def lower_shapes(desc):
 
 # ---------------------------------------------------------------- wide tier
 #
-# One-mover games on boards above MAX_CELLS cells (include/campx_hip.h CampxWideSpec,
-# csrc/k_wide.hip): the (cell, action) table filled on the host by `tabulate`, a 16-bit
-# trace, the one-cell tier's render kernel.
+# Games run from their state table (include/campx_hip.h CampxWideSpec, csrc/k_wide.hip):
+# one row per reachable state, filled on the host by `tabulate`; a 16-bit trace; the
+# one-cell tier's render kernel.  Boards up to WIDE_MAX_CELLS cells.
 
 WIDE_MAX_CELLS = 1024
 
 
-class CampxWideTransition(ctypes.Structure):
-  _fields_ = [('reward', ctypes.c_float), ('next_cell', ctypes.c_uint16),
-              ('done', ctypes.c_uint8), ('perf', ctypes.c_int8)]
+WIDE_MAX_STATES = 1 << 20
 
 
 class CampxWideSpec(ctypes.Structure):
   _fields_ = [('magic', ctypes.c_uint32), ('version', ctypes.c_uint32),
               ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
-              ('n_layers', ctypes.c_int32), ('any_reward', ctypes.c_int32),
-              ('has_perf', ctypes.c_int32), ('dyn_layer', ctypes.c_int32),
-              ('init_cell', ctypes.c_int32), ('init_hidden', ctypes.c_int32),
-              ('reserved0', ctypes.c_int32 * 2),
+              ('n_layers', ctypes.c_int32), ('n_dyn', ctypes.c_int32),
+              ('n_states', ctypes.c_int32), ('any_reward', ctypes.c_int32),
+              ('has_perf', ctypes.c_int32), ('reserved0', ctypes.c_int32 * 3),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
+              ('dyn_layer', ctypes.c_int32 * MAX_DYN),
               ('discount_list', ctypes.c_float * 16),
               ('static_top_layer', ctypes.c_uint8 * WIDE_MAX_CELLS),
-              ('table', CampxWideTransition * (WIDE_MAX_CELLS * N_ACTIONS))]
-
-
-assert ctypes.sizeof(CampxWideTransition) == 8
+              # host arrays, read at validation / table-build time only
+              ('state_cells', ctypes.c_void_p), ('next_state', ctypes.c_void_p),
+              ('reward', ctypes.c_void_p), ('done', ctypes.c_void_p),
+              ('perf', ctypes.c_void_p)]

@@ -54,6 +54,7 @@ uploads the result.
 
 import collections
 import copy
+import hashlib
 
 import numpy as np
 import torch
@@ -66,6 +67,9 @@ N_ACTIONS = gamespec.N_ACTIONS
 # deep copy + a frame of Python, ~2 ms): beyond it the game is refused with a pointer to
 # campx_amd.rules, whose tables are built on the device.
 MAX_PLAYS = 60000
+# Largest dense (cell, ..., cell, action) table built on the host (entries); games beyond it
+# run from their state table (the wide tier).
+DENSE_MAX_ENTRIES = 8 << 20
 
 
 class TabulationError(ValueError):
@@ -197,13 +201,105 @@ class TracedGame(object):
     return board.reshape(self.rows, self.cols)
 
 
-def trace(engine, actions=None, max_plays=MAX_PLAYS):
+class _NoFingerprint(Exception):
+  pass
+
+
+def _feed(h, x, depth=0):
+  """Hash plain data - numbers, strings, tensors, arrays, containers of those, objects
+  through their class and __dict__ - into h; anything else has no fingerprint."""
+  if depth > 6:
+    raise _NoFingerprint()
+  if x is None or isinstance(x, (bool, int, float, str, bytes)):
+    h.update(repr(x).encode())
+  elif torch.is_tensor(x):
+    a = x.detach().cpu().numpy()
+    h.update(str((a.dtype, a.shape)).encode())
+    h.update(a.tobytes())
+  elif isinstance(x, np.ndarray):
+    h.update(str((x.dtype, x.shape)).encode())
+    h.update(np.ascontiguousarray(x).tobytes())
+  elif isinstance(x, (list, tuple)):
+    h.update(b'[')
+    for item in x:
+      _feed(h, item, depth + 1)
+    h.update(b']')
+  elif isinstance(x, (set, frozenset)):
+    h.update(b'<')
+    for item in sorted(x, key=repr):
+      _feed(h, item, depth + 1)
+    h.update(b'>')
+  elif isinstance(x, dict):
+    h.update(b'{')
+    for key in sorted(x, key=repr):
+      _feed(h, key, depth + 1)
+      _feed(h, x[key], depth + 1)
+    h.update(b'}')
+  elif isinstance(x, type):
+    h.update('{}.{}@{}'.format(x.__module__, x.__qualname__, id(x)).encode())
+  elif hasattr(x, '__dict__') and not callable(x):
+    _feed(h, type(x), depth + 1)
+    _feed(h, vars(x), depth + 1)
+  else:
+    raise _NoFingerprint()
+
+
+def fingerprint(engine, actions):
+  """A key under which the tabulation of a set-up engine can be reused: every entity's class
+  (by identity) and attributes, the backdrop, the update groups and z-order, the hidden-
+  performance declarations, the action set.  None when something in there is not plain data
+  (the game is then tabulated afresh every time)."""
+  h = hashlib.sha1()
+  try:
+    _feed(h, (engine.rows, engine.cols, list(engine.things.keys())))
+    groups = engine._update_groups
+    if isinstance(groups, dict):
+      groups = [(name, groups[name]) for name in sorted(groups.keys())]
+    _feed(h, [(name, [ent.character for ent in members]) for name, members in groups])
+    for ch, ent in engine.things.items():
+      _feed(h, ch)
+      _feed(h, ent)
+    _feed(h, engine.backdrop)
+    _feed(h, (engine.hidden_performance, engine.hidden_penalty))
+    _feed(h, actions)
+  except _NoFingerprint:
+    return None
+  return h.hexdigest()
+
+
+_CACHE = collections.OrderedDict()
+CACHE_SIZE = 16
+
+
+def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
   """Tabulate a set-up (not yet started) `Engine`; returns a `TracedGame`.
 
   `engine` itself is not touched: a deep copy of it is put through `its_showtime()` on
   the generic tier.  `actions`: the five objects handed to `play()` for action ids
   0..4 (default: the reference's one-hot float vectors).
+
+  The reference's driver builds a new game per episode (`make_game()`,
+  examples/reinforce.py:122): the tabulation of an engine whose entities, attributes and
+  set-up are the same as an earlier one's is reused (`cache`; the `TracedGame` is shared and
+  must be treated as read-only).
   """
+  key = None
+  if cache and engine.backdrop is not None:
+    key = fingerprint(engine, default_actions() if actions is None else list(actions))
+    if key is not None:
+      key = (key, max_plays)
+      if key in _CACHE:
+        _CACHE.move_to_end(key)
+        return _CACHE[key]
+  game = _trace(engine, actions, max_plays)
+  if key is not None:
+    _CACHE[key] = game
+    while len(_CACHE) > CACHE_SIZE:
+      _CACHE.popitem(last=False)
+  return game
+
+
+def _trace(engine, actions, max_plays):
   if engine.backdrop is None:
     raise ValueError('the Engine has no Backdrop yet')
   H, W = engine.rows, engine.cols
@@ -299,17 +395,24 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
     if z not in modes:
       modes.append(z)
   n_tracked = len(movers) + (1 if len(modes) > 1 else 0)
-  if not 1 <= len(movers) or n_tracked > gamespec.MAX_DYN:
-    _fail('needs between 1 and {} moving things{}, found {} ({})'.format(
-        gamespec.MAX_DYN, ' (the z-order in force counts as one)' if len(modes) > 1 else '',
-        len(movers), ''.join(movers) or 'nothing moves'))
-  if HW > gamespec.MAX_CELLS and n_tracked != 1:
-    _fail('a {}x{} board (more than {} cells) takes exactly one moving thing and no z-order '
-          'changes, found {}'.format(H, W, gamespec.MAX_CELLS, ''.join(movers)))
-  if len(modes) > HW:
-    _fail('{} different z-orders are reached; the tables have room for rows*cols = {}'.format(
-        len(modes), HW))
+  if not 1 <= len(movers) <= gamespec.MAX_DYN:
+    _fail('needs between 1 and {} moving things, found {} ({})'.format(
+        gamespec.MAX_DYN, len(movers), ''.join(movers) or 'nothing moves'))
   K = len(movers)
+  # Two table forms come out of a tabulation.  The STATE table - one row per reachable
+  # state, (state, action) -> state - always exists.  The DENSE table the one-cell tier's
+  # kernels index by the things' cells, (cell, ..., cell, action), only when it fits them:
+  dense_reason = None
+  if HW > gamespec.MAX_CELLS:
+    dense_reason = 'the board has more than {} cells'.format(gamespec.MAX_CELLS)
+  elif n_tracked > gamespec.MAX_DYN:
+    dense_reason = ('{} moving things plus the z-order in force are more than {} tracked '
+                    'values'.format(K, gamespec.MAX_DYN))
+  elif len(modes) > HW:
+    dense_reason = '{} different z-orders are reached, more than rows*cols'.format(len(modes))
+  elif HW ** n_tracked * N_ACTIONS > DENSE_MAX_ENTRIES:
+    dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
+        HW, n_tracked, DENSE_MAX_ENTRIES)
 
   def where_is(img, ch):
     """('at', cell) or ('absent', key): the one cell a moving thing occupies, or - an empty
@@ -382,8 +485,9 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
   board0 = np.frombuffer(boards[0], np.uint8)
   game.init_visible = [int(places[k][0][0] == 'at' and board0[state_cells[0][k]] == ord(ch))
                        for k, ch in enumerate(movers)]
-  if places[0][0][0] != 'at':
-    _fail('the first moving thing ({!r}) is not on the board after its_showtime()'.format(movers[0]))
+  if places[0][0][0] != 'at' and dense_reason is None:
+    dense_reason = ('the first moving thing ({!r}) is not on the board after its_showtime()'
+                    .format(movers[0]))
 
   # ---- the render kernels lay ONE scenery row under the movers: no order may change it
   for m in range(1, len(modes)):
@@ -435,50 +539,79 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS):
       back = n_cls if a == 1 else a - 1
       return int(b == fwd) - int(b == back)
 
-  # ---- the dense table
-  Kt = n_tracked
-  n = HW ** Kt * N_ACTIONS
-  game.n = n
-  game.next_cells = np.zeros((Kt, n), np.uint16)
-  game.visible = np.zeros((Kt, n), np.uint8)
-  game.reward = np.full((n,), np.nan, np.float32)
-  game.done = np.zeros((n,), np.uint8)
-  game.discount = np.ones((n,), np.float32)
-  game.dcode = np.zeros((n,), np.uint8)
-  game.discount_list = [1.0]          # code -> value; code 0 stands for the default
-  game.perf = np.zeros((n,), np.int8)
-  game.reached = np.zeros((n,), bool)
-  # entries nobody can reach: stay where you are, pay nothing
-  idx = np.arange(n) // N_ACTIONS
-  for k in range(Kt - 1, -1, -1):
-    game.next_cells[k] = idx % HW
-    idx = idx // HW
+  # ---- the state table: one row per reachable state
+  S = len(images)
   codes = [ord(ch) for ch in movers]
+  game.dense_reason = dense_reason
+  game.st_cells = np.array([cells[:K] for cells in state_cells], np.uint16).reshape(S, K)
+  game.st_present = np.array([[places[k][s][0] == 'at' for k in range(K)] for s in range(S)],
+                             bool).reshape(S, K)
+  game.st_board = np.stack([np.frombuffer(b, np.uint8) for b in boards])
+  game.st_shows = np.zeros((S, K), np.uint8)
+  for k in range(K):
+    game.st_shows[:, k] = (game.st_present[:, k] &
+                           (game.st_board[np.arange(S), game.st_cells[:, k]] == codes[k]))
+  game.st_mode = np.array([modes.index(z) for z in orders], np.int32)
+  game.st_next = np.tile(np.arange(S, dtype=np.int32)[:, None], (1, N_ACTIONS))
+  game.st_reward = np.full((S, N_ACTIONS), np.nan, np.float32)
+  game.st_done = np.zeros((S, N_ACTIONS), np.uint8)
+  game.st_discount = np.ones((S, N_ACTIONS), np.float32)
+  game.st_dcode = np.zeros((S, N_ACTIONS), np.uint8)
+  game.st_perf = np.zeros((S, N_ACTIONS), np.int8)
+  game.st_reached = np.zeros((S, N_ACTIONS), bool)
+  game.discount_list = [1.0]          # code -> value; code 0 stands for the default
   for (s, a), e in edges.items():
-    i = game.index_of(state_cells[s], a)
-    dst = state_cells[e.next]
-    board = np.frombuffer(e.board, np.uint8)
-    for k in range(K):
-      game.next_cells[k, i] = dst[k]
-      game.visible[k, i] = int(not game.is_absent(k, dst[k]) and board[dst[k]] == codes[k])
-    if Kt > K:
-      game.next_cells[K, i] = dst[K]            # the mode: never visible
-    game.reward[i] = e.reward
-    game.done[i] = int(e.over)
-    game.discount[i] = e.discount
+    game.st_next[s, a] = e.next
+    game.st_reward[s, a] = e.reward
+    game.st_done[s, a] = int(e.over)
+    game.st_discount[s, a] = e.discount
     if e.discount != (0.0 if e.over else 1.0):
       if e.discount not in game.discount_list[1:]:
         if len(game.discount_list) == 16:
           _fail('more than 15 distinct discounts besides the default')
         game.discount_list.append(e.discount)
-      game.dcode[i] = 1 + game.discount_list[1:].index(e.discount)
-    game.perf[i] = perf_of(state_cells[s], dst) if perf_of else 0
-    game.reached[i] = True
-  game.any_reward = bool((~np.isnan(game.reward[game.reached])).any())
+      game.st_dcode[s, a] = 1 + game.discount_list[1:].index(e.discount)
+    game.st_perf[s, a] = perf_of(state_cells[s], state_cells[e.next]) if perf_of else 0
+    game.st_reached[s, a] = True
+  game.any_reward = bool((~np.isnan(game.st_reward[game.st_reached])).any())
   game.has_perf = perf_of is not None
   game.perf_spec = engine.hidden_performance
   game.penalty_spec = engine.hidden_penalty
-  game.n_states, game.n_plays = len(images), plays[0]
+  game.n_states, game.n_plays = S, plays[0]
+
+  # ---- the dense table (one-cell tier), when the game fits it
+  game.n = None
+  if dense_reason is None:
+    Kt = n_tracked
+    n = HW ** Kt * N_ACTIONS
+    game.n = n
+    game.next_cells = np.zeros((Kt, n), np.uint16)
+    game.visible = np.zeros((Kt, n), np.uint8)
+    game.reward = np.full((n,), np.nan, np.float32)
+    game.done = np.zeros((n,), np.uint8)
+    game.discount = np.ones((n,), np.float32)
+    game.dcode = np.zeros((n,), np.uint8)
+    game.perf = np.zeros((n,), np.int8)
+    game.reached = np.zeros((n,), bool)
+    # entries nobody can reach: stay where you are, pay nothing
+    idx = np.arange(n) // N_ACTIONS
+    for k in range(Kt - 1, -1, -1):
+      game.next_cells[k] = idx % HW
+      idx = idx // HW
+    for (s, a), e in edges.items():
+      i = game.index_of(state_cells[s], a)
+      dst = state_cells[e.next]
+      for k in range(K):
+        game.next_cells[k, i] = dst[k]
+        game.visible[k, i] = game.st_shows[e.next, k]
+      if Kt > K:
+        game.next_cells[K, i] = dst[K]            # the mode: never visible
+      game.reward[i] = game.st_reward[s, a]
+      game.done[i] = game.st_done[s, a]
+      game.discount[i] = game.st_discount[s, a]
+      game.dcode[i] = game.st_dcode[s, a]
+      game.perf[i] = game.st_perf[s, a]
+      game.reached[i] = True
   return game
 
 
@@ -489,6 +622,8 @@ def to_spec(game):
   campx_pair_table_pack)."""
   H, W = game.rows, game.cols
   HW = H * W
+  if game.dense_reason is not None:
+    _fail('the one-cell tier cannot take this game: ' + game.dense_reason)
   layer_of = {ch: i for i, ch in enumerate(game.chars)}
   z_of = {ch: i + 1 for i, ch in enumerate(game.z_order)}
   spec = gamespec.CampxSpec()
@@ -564,33 +699,42 @@ def to_spec(game):
 
 
 def to_wide_spec(game):
-  """`TracedGame` of a one-mover game on a board above 128 cells -> `CampxWideSpec`
-  (include/campx_hip.h): the scenery's front-most layer per cell and the transition table,
-  whose "hidden" bits come from the boards the user's own code rendered."""
+  """`TracedGame` -> (`CampxWideSpec`, arrays): the game as its STATE table
+  (include/campx_hip.h).  `arrays` are the numpy arrays the spec's host pointers point at:
+  keep them alive until campx_wide_tables_build() has run.  "Shows" bits come from the boards
+  the user's own code rendered."""
   H, W = game.rows, game.cols
   HW = H * W
-  if game.n_tracked != 1:
-    _fail('the wide tier takes exactly one moving thing')
+  K, S = len(game.movers), game.n_states
+  if HW < 16:
+    _fail('the state-table tier needs a board of at least 16 cells')
+  if S > gamespec.WIDE_MAX_STATES:
+    _fail('{} reachable states; the state table takes {}'.format(S, gamespec.WIDE_MAX_STATES))
   layer_of = {ch: i for i, ch in enumerate(game.chars)}
   spec = gamespec.CampxWideSpec()
   spec.magic, spec.version = gamespec.SPEC_MAGIC, gamespec.SPEC_VERSION
   spec.rows, spec.cols, spec.n_layers = H, W, len(game.chars)
+  spec.n_dyn, spec.n_states = K, S
   spec.any_reward, spec.has_perf = int(game.any_reward), int(game.has_perf)
-  spec.dyn_layer = layer_of[game.movers[0]]
-  spec.init_cell = int(game.init_cells[0])
-  spec.init_hidden = 0 if game.init_visible[0] else 1
   for i, ch in enumerate(game.chars):
     spec.layer_char[i] = ord(ch)
+  for d, ch in enumerate(game.movers):
+    spec.dyn_layer[d] = layer_of[ch]
   for code, value in enumerate(game.discount_list):
     if code:
       spec.discount_list[code] = float(value)
   top = game.model_board(game.init_cells, movers=False).reshape(-1)
   for i in range(HW):
     spec.static_top_layer[i] = layer_of[chr(int(top[i]))]
-  nxt = game.next_cells[0].astype(np.int64) | ((game.visible[0] == 0).astype(np.int64) << 15)
-  done = game.done_bytes()
-  for i in range(game.n):
-    tr = spec.table[i]
-    tr.reward, tr.next_cell = float(game.reward[i]), int(nxt[i])
-    tr.done, tr.perf = int(done[i]), int(game.perf[i])
-  return spec
+  cells = np.where(game.st_present, game.st_cells, 0).astype(np.uint16)
+  arrays = dict(        # (copies: a TracedGame may be shared through the tabulation cache)
+      state_cells=np.array(cells | ((game.st_shows == 0).astype(np.uint16) << 15), np.uint16, order='C'),
+      next_state=np.array(game.st_next, np.int32, order='C'),
+      reward=np.array(game.st_reward, np.float32, order='C'),
+      done=np.array(game.st_done | (game.st_dcode << 4), np.uint8, order='C'),
+      perf=np.array(game.st_perf, np.int8, order='C'))
+  for name, a in arrays.items():
+    setattr(spec, name, a.ctypes.data)
+  if not game.has_perf:
+    spec.perf = None
+  return spec, arrays

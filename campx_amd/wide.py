@@ -1,14 +1,18 @@
-"""The wide tier: one-mover games on boards above 128 cells, B environments per launch.
+"""The wide tier: games run from their STATE table, B environments per launch.
 
-PyColab-sized boards (16x16 mazes and up, campx/engine.py:31 sets no limit) do not fit the
-one-cell tier's 7-bit cells and LDS-resident per-cell tables.  For a game with ONE moving
-thing the update pass is still a (cell, action) table - `tabulate.trace()` fills it on the
-host by running the game's own `update()` classes (rule classes included) over every
-reachable state - and the observation stream is the same render kernel, fed by a 16-bit trace
-(csrc/k_wide.hip, include/campx_hip.h CampxWideSpec).  `WideGame` is what a batched `Engine`
-delegates to; same surface as `fused.FusedGame` (showtime / reset / play / rollout /
-rollout_buffers / check_actions, `pos`, `done`, `ret`, `perf`), through the torch op
-`campx::wide_rollout`.  No CPU path: constructing one without a HIP device raises.
+The one-cell tier's kernels index their tables by the things' cells - (rows*cols)^K * 5
+entries, 7-bit cells - which stops at 128 cells and grows fast with K.  `tabulate.trace()`
+enumerates the states a game can actually reach (by running its own `update()` classes,
+rule classes included), and the table over THOSE - one row per state, (state, action) ->
+state - has no such limits: PyColab-sized boards (16x16 mazes and up; campx/engine.py:31
+sets none), up to four things that show, and whatever hidden values stand behind them (the
+z-order in force, keys picked up, doors opened).  The observation stream is the same render
+kernel, fed by a 16-bit trace (csrc/k_wide.hip, include/campx_hip.h CampxWideSpec).
+`WideGame` is what a batched `Engine` delegates to for games the one-cell tier cannot take;
+same surface as `fused.FusedGame` (showtime / reset / play / rollout / rollout_buffers /
+check_actions, `done`, `ret`, `perf`; the dynamic state is `state`, int32 [B] state indices),
+through the torch op `campx::wide_rollout`.  No CPU path: constructing one without a HIP
+device raises.
 """
 
 import ctypes
@@ -38,13 +42,13 @@ class WideGame(fused.FusedGame):
       raise ValueError('batch must be >= 1')
     self.traced = traced
     self.description = None
-    self.spec = tabulate.to_wide_spec(traced)
+    self.spec, self._arrays = tabulate.to_wide_spec(traced)
     self.chars = list(traced.chars)
     _hip.check(_hip.lib.campx_wide_spec_validate(ctypes.byref(self.spec)),
                'campx_wide_spec_validate')
     self.rows, self.cols = engine.rows, engine.cols
     self.n_layers = len(self.chars)
-    self.n_dyn = 1
+    self.n_dyn = len(traced.movers)
     self.uses_table = True
     self.any_reward = bool(self.spec.any_reward)
     self.has_perf = bool(self.spec.has_perf)
@@ -62,7 +66,8 @@ class WideGame(fused.FusedGame):
           ctypes.byref(self.spec), ctypes.c_void_p(self._tables.data_ptr()),
           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
           'campx_wide_tables_build')
-    self.pos = torch.zeros((2, B), dtype=torch.int8, device=dev)
+    self.state = torch.zeros((B,), dtype=torch.int32, device=dev)   # index into traced.st_*
+    self.pos = None                   # (positions: see the trace)
     self.done = torch.zeros((B,), dtype=torch.uint8, device=dev)
     self.ret = torch.zeros((B,), dtype=torch.float32, device=dev)
     self._obs = torch.empty((B, self.n_layers, self.rows, self.cols), dtype=torch.int8, device=dev)
@@ -70,7 +75,7 @@ class WideGame(fused.FusedGame):
     self._reward = torch.empty((B,), dtype=torch.float32, device=dev)
     self._discount = torch.empty((B,), dtype=torch.float32, device=dev)
     self._step_done = torch.empty((B,), dtype=torch.uint8, device=dev)
-    self._step_trace = torch.empty((B,), dtype=torch.int16, device=dev)
+    self._step_trace = self._trace_rows(None)
     self.perf = torch.zeros((B,), dtype=torch.int8, device=dev)
     self._perf_arg = self.perf if self.has_perf else None
     self._bad = torch.zeros((1,), dtype=torch.int32, device=dev)
@@ -82,6 +87,13 @@ class WideGame(fused.FusedGame):
     self._observation_cache = self._observation(self._obs, self._board)
     self._wide = _hip.ops.wide_rollout.default
 
+  def _trace_rows(self, T):
+    """int16 [K, B] (one frame) or [K, T, B] trace buffer, rows padded like the other streams."""
+    B = self.batch
+    pitch = (B + 15) // 16 * 16 if fused.PAD_ROWS else B
+    shape = (self.n_dyn, pitch) if T is None else (self.n_dyn, T, pitch)
+    return torch.empty(shape, dtype=torch.int16, device=self.device)[..., :B]
+
   # --------------------------------------------------------------------- API
 
   def showtime(self):
@@ -89,7 +101,7 @@ class WideGame(fused.FusedGame):
     first = self._obs
     if first.dtype != torch.int8:       # set_play_obs_dtype(): the first frame is rendered as int8
       first = torch.empty(self._obs.shape, dtype=torch.int8, device=self.device)
-    self._wide(self._spec_host, self._tables, self.pos, self.done, self.ret, None, first,
+    self._wide(self._spec_host, self._tables, self.state, self.done, self.ret, None, first,
                self._board, None, None, None, None, self._step_trace, None, None, False)
     if first is not self._obs:
       self._obs.copy_(first)
@@ -106,7 +118,7 @@ class WideGame(fused.FusedGame):
     else:
       ids = self._action_ids(actions, (self.batch,))
     validate = self.validate_actions
-    self._wide(self._spec_host, self._tables, self.pos, self.done, self.ret, ids, self._obs,
+    self._wide(self._spec_host, self._tables, self.state, self.done, self.ret, ids, self._obs,
                self._board, self._reward, self._discount, self._step_done, self._perf_arg,
                self._step_trace, self._bad if validate else None,
                self._bad_flag if validate else None, False)
@@ -117,15 +129,13 @@ class WideGame(fused.FusedGame):
 
   def rollout_buffers(self, T, keep_obs=True, want_board=False, obs_dtype=torch.int8, share=None):
     out = super(WideGame, self).rollout_buffers(T, keep_obs, want_board, obs_dtype, share)
-    B = self.batch
-    pitch = (B + 15) // 16 * 16 if fused.PAD_ROWS else B
-    out['trace'] = torch.empty((T, pitch), dtype=torch.int16, device=self.device)[:, :B]
+    out['trace'] = self._trace_rows(T)
     return out
 
   def rollout(self, actions, obs=None, board=None, keep_obs=True, reset_first=False,
               want_board=False, obs_dtype=torch.int8, out=None, pipelined=False):
     """T frames in one call (see `fused.FusedGame.rollout`; `pipelined` is not offered here).
-    'trace' in the result is int16 [T, B]: cell | covered scenery layer << 10 | visible << 15."""
+    'trace' in the result is int16 [K, T, B]: cell | covered scenery layer << 10 | shows << 15."""
     if pipelined:
       raise ValueError('wide tier: pipelined rollouts are not offered')
     T = int(actions.shape[0])
@@ -146,7 +156,7 @@ class WideGame(fused.FusedGame):
       if board is not None:
         out['board'] = board
     validate = self.validate_actions
-    self._wide(self._spec_host, self._tables, self.pos, self.done, self.ret, ids, out['obs'],
+    self._wide(self._spec_host, self._tables, self.state, self.done, self.ret, ids, out['obs'],
                out['board'], out['reward'], out['discount'], out['done'], out['perf'],
                out['trace'], self._bad if validate else None,
                self._bad_flag if validate else None, bool(reset_first))

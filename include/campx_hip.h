@@ -431,62 +431,72 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
                                    int32_t reset_first, int32_t emit_first, void* stream);
 
 /*
- * Wide tier: one-mover games on boards ABOVE 128 cells (PyColab-sized mazes: 16x16, 20x20,
- * 32x32 ...; campx/engine.py:31 has no size limit).  The update pass is the game's
- * (cell, action) transition table - the caller fills it (campx_amd/tabulate.py runs the
- * game's own update() classes over every reachable state; 1 024 cells x 5 actions at most) -
- * and the observation stream is the same render kernel as the one-cell tier's, fed by a
- * 16-bit trace:
- *     entry = cell | (scenery layer the mover covers there) << 10 | visible << 15.
- * A frame of B environments is B rows of L*rows*cols bytes (1 280 B for 16x16 with five
- * characters, 8 KiB for 32x32 with eight), so the path is even more purely a write stream
- * than the one-cell tier's: 2 bytes of trace per row.
+ * Wide tier: games whose update pass is a STATE table - one row per state the game can
+ * reach, (state, action) -> state - instead of a table indexed by the things' cells.  That
+ * form has no board-size limit and no (rows*cols)^K blow-up, so it takes what the one-cell
+ * tier cannot: boards ABOVE 128 cells (PyColab-sized mazes: 16x16, 20x20, 32x32 ...;
+ * campx/engine.py:31 sets no limit), up to four things that show, any number of hidden
+ * values behind them (the z-order in force after Plot.change_z_order, keys that were
+ * picked up, doors that opened).  The caller enumerates the states (campx_amd/tabulate.py runs
+ * the game's own update() classes breadth-first from its_showtime()); state 0 is the
+ * its_showtime() state.  The observation stream is the one-cell tier's render kernel, fed
+ * by a 16-bit trace:
+ *     entry = cell | (scenery layer the thing covers there) << 10 | shows << 15.
+ * A frame of B environments is B rows of L*rows*cols bytes (1 536 B for 16x16 with six
+ * characters, 6 KiB for 32x32), so the path is even more purely a write stream than the
+ * one-cell tier's.
  */
-#define CAMPX_WIDE_MAX_CELLS 1024 /* rows * cols; rows, cols <= 127 */
-
-typedef struct CampxWideTransition {
-  float reward;        /* summed reward of the frame (NaN = None) */
-  uint16_t next_cell;  /* bits 0-9: row * cols + col after the frame; bit 15: scenery in front
-                          hides the mover there */
-  uint8_t done;        /* as CampxTransition.done: bit 0 terminated, bits 4-7 discount code */
-  int8_t perf;         /* hidden performance of the frame (the VALUE, written as it is) */
-} CampxWideTransition; /* 8 bytes */
+#define CAMPX_WIDE_MAX_CELLS 1024        /* rows * cols; rows, cols <= 127 */
+#define CAMPX_WIDE_MAX_STATES (1 << 20)
 
 typedef struct CampxWideSpec {
   uint32_t magic, version;
   int32_t rows, cols;
   int32_t n_layers;
+  int32_t n_dyn;                   /* K: things that move / come and go, 1 .. CAMPX_MAX_DYN */
+  int32_t n_states;                /* S: reachable states, 1 .. CAMPX_WIDE_MAX_STATES */
   int32_t any_reward;
-  int32_t has_perf;                /* the table's perf column means something */
-  int32_t dyn_layer;               /* layer the mover paints */
-  int32_t init_cell;               /* its cell after its_showtime() */
-  int32_t init_hidden;             /* 1: the scenery hides it there */
-  int32_t reserved0[2];
+  int32_t has_perf;                /* `perf` below means something */
+  int32_t reserved0[3];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
-  float discount_list[16];         /* as CampxSpec.discount_list */
+  int32_t dyn_layer[CAMPX_MAX_DYN];        /* layer thing d paints */
+  float discount_list[16];                 /* as CampxSpec.discount_list */
   uint8_t static_top_layer[CAMPX_WIDE_MAX_CELLS];  /* front-most scenery layer per cell */
-  CampxWideTransition table[CAMPX_WIDE_MAX_CELLS * CAMPX_N_ACTIONS];  /* cell * 5 + action */
+  /* HOST arrays, read by campx_wide_spec_validate(full) / campx_wide_tables_build() only -
+   * the launch calls never touch them, they may be gone by then: */
+  const uint16_t* state_cells;     /* [S][K]: bits 0-9 the cell thing d is on in state s; bit 15
+                                      set when it does NOT show there (hidden by something in
+                                      front, or not on the board at all) */
+  const int32_t* next_state;       /* [S][5]: the state after (state, action) */
+  const float* reward;             /* [S][5]: summed reward of the frame, NaN = None */
+  const uint8_t* done;             /* [S][5]: as CampxTransition.done (bit 0 terminated, bits
+                                      4-7 discount code) */
+  const int8_t* perf;              /* [S][5] hidden performance (the value), or NULL */
 } CampxWideSpec;
 
 int32_t campx_wide_spec_size(void);
+/* Checks the plain fields; the host arrays too when they are non-NULL. */
 int32_t campx_wide_spec_validate(const CampxWideSpec* spec_host);
 
 /*
  * Once per game: campx_wide_tables_bytes() of DEVICE memory, filled by
- * campx_wide_tables_build() from the host spec (host arithmetic + one copy; synchronises
- * `stream`): the transition table in the update kernel's packed form and the 16 byte-rotations
- * of the scenery's row for the render kernel (CampxSpec.rot_obs / rot_board explain them).
+ * campx_wide_tables_build() from the host spec and its arrays (host arithmetic + one copy;
+ * synchronises `stream`): the state table in the update kernel's packed form and the 16
+ * byte-rotations of the scenery's row for the render kernel (CampxSpec.rot_obs / rot_board
+ * explain them).
  */
 int64_t campx_wide_tables_bytes(const CampxWideSpec* spec_host);
 int32_t campx_wide_tables_build(const CampxWideSpec* spec_host, void* tables_dev, void* stream);
 
 /*
- * campx_reset_launch / campx_rollout_launch for a wide game.  state.pos is [2, B] (row, col),
- * state.pair_table is ignored.  out.trace is REQUIRED and holds uint16 entries, [T, pitch]
- * (reset: [pitch]) with pitch = out.scalar_pitch or B, 2-byte aligned; frames are kept back to
- * back (obs_t_stride == B*L*rows*cols, board_t_stride == B*rows*cols) or, with strides of 0,
- * only the last one.  B * L*rows*cols must stay below 2^32 - 2^16.  16-bit observation
- * formats as for campx_rollout_launch.  T = 1 is Engine.play().
+ * campx_reset_launch / campx_rollout_launch for a wide game.  The dynamic state of an
+ * environment is its STATE INDEX: state.pos points at int32 [B] (4-byte aligned; the
+ * positions, if wanted, are in the trace), state.pair_table is ignored.  out.trace is REQUIRED
+ * and holds uint16 entries, [K, T, pitch] (reset: [K, pitch]) with pitch = out.scalar_pitch or
+ * B, 2-byte aligned; frames are kept back to back (obs_t_stride == B*L*rows*cols,
+ * board_t_stride == B*rows*cols) or, with strides of 0, only the last one.  B * L*rows*cols
+ * must stay below 2^32 - 2^16.  16-bit observation formats as for campx_rollout_launch.
+ * T = 1 is Engine.play().
  */
 int32_t campx_wide_reset_launch(const CampxWideSpec* spec_host, const void* tables_dev,
                                 CampxState state, CampxOutputs out, int64_t B, void* stream);

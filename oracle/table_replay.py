@@ -96,3 +96,62 @@ class TableWalker(object):
     layered = np.stack([(board == ord(ch)) for ch in g.chars], axis=1).astype(np.int8)
     return (board.astype(np.int8).reshape(N, g.rows, g.cols),
             layered.reshape(N, len(g.chars), g.rows, g.cols))
+
+
+class StateWalker(object):
+  """B environments of a `tabulate.TracedGame` walked through its STATE table
+  ((state, action) -> state; state 0 is the `its_showtime()` state), the checker of the wide
+  tier.  What a state looks like is not recomputed: `game.st_board[s]` is the board the user's
+  own classes rendered when the tabulator stood in state s on the generic tier (and checked
+  against "backdrop, then things in z-order"), and the layers are that board compared with
+  each character (campx/rendering.py:204-215)."""
+
+  def __init__(self, game, batch):
+    self.game = game
+    self.B = int(batch)
+    self.state = np.zeros(self.B, np.int64)
+    self.over = np.zeros(self.B, bool)
+    self.ret = np.zeros(self.B, np.float32)
+
+  def rollout(self, actions, reset_first=False):
+    """actions int8 [T, B] -> dict(state [T, B], cells / shows [K, T, B], reward, discount,
+    done, perf [T, B])."""
+    g = self.game
+    actions = np.asarray(actions)
+    T, K = actions.shape[0], len(g.movers)
+    out = dict(state=np.zeros((T, self.B), np.int64),
+               cells=np.zeros((K, T, self.B), np.uint16),
+               shows=np.zeros((K, T, self.B), np.uint8),
+               reward=np.zeros((T, self.B), np.float32),
+               discount=np.zeros((T, self.B), np.float32),
+               done=np.zeros((T, self.B), np.uint8),
+               perf=np.zeros((T, self.B), np.int8))
+    if reset_first:
+      self.over[:] = True
+    for t in range(T):
+      a = actions[t].astype(np.int64)
+      a = np.where((a < 0) | (a > 4), 4, a)          # an id outside 0..4 acts as "stay"
+      s = np.where(self.over, 0, self.state)
+      self.ret = np.where(self.over, np.float32(0), self.ret).astype(np.float32)
+      assert g.st_reached[s, a].all(), 'the walk left the tabulated (reachable) entries'
+      self.state = g.st_next[s, a].astype(np.int64)
+      reward = g.st_reward[s, a]
+      self.ret = (self.ret + np.where(np.isnan(reward), np.float32(0), reward)).astype(np.float32)
+      self.over = g.st_done[s, a] != 0
+      out['state'][t] = self.state
+      out['cells'][:, t] = np.where(g.st_present[self.state], g.st_cells[self.state], 0).T
+      out['shows'][:, t] = g.st_shows[self.state].T
+      out['reward'][t] = reward
+      out['done'][t] = self.over
+      out['discount'][t] = g.st_discount[s, a]
+      out['perf'][t] = g.st_perf[s, a]
+    return out
+
+  def render(self, states):
+    """state indices [N] -> (board int8 [N, H, W], layered int8 [N, L, H, W])."""
+    g = self.game
+    board = g.st_board[np.asarray(states, np.int64)]
+    layered = np.stack([(board == ord(ch)) for ch in g.chars], axis=1).astype(np.int8)
+    n = board.shape[0]
+    return (board.astype(np.int8).reshape(n, g.rows, g.cols),
+            layered.reshape(n, len(g.chars), g.rows, g.cols))

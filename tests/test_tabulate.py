@@ -318,6 +318,36 @@ def test_z_order_modes_are_tabulated_as_one_more_tracked_value():
   assert traced.reached[j] and traced.visible[0, j] == 1
 
 
+def test_a_second_make_game_of_the_same_game_reuses_the_tabulation():
+  """The reference's driver calls make_game() per episode (examples/reinforce.py:122): the
+  tabulation is keyed by a fingerprint of the set-up engine (classes by identity, every
+  attribute, curtains, groups, z-order, action set) and reused."""
+  import time
+  tabulate._CACHE.clear()
+  first = tabulate.trace(traced_games.mirror())
+  t0 = time.perf_counter()
+  again = tabulate.trace(traced_games.mirror())
+  assert again is first and time.perf_counter() - t0 < 0.5
+  assert tabulate.trace(traced_games.mirror(), cache=False) is not first
+  other = traced_games.toll_road()
+  other.things['A'].bonus = 3                        # any attribute that differs: another key
+  assert (tabulate.fingerprint(other, tabulate.default_actions()) !=
+          tabulate.fingerprint(traced_games.toll_road(), tabulate.default_actions()))
+  # different action objects are a different game as far as the table goes
+  ints = [torch.eye(5)[a] * 1.0 for a in range(5)]
+  assert tabulate.fingerprint(other, ints) == tabulate.fingerprint(other, tabulate.default_actions())
+  assert tabulate.fingerprint(other, list(range(5))) != tabulate.fingerprint(other, ints)
+
+  class Opaque(traced_games.Walker):                 # state the fingerprint cannot read
+    def __init__(self, curtain, character):
+      super(Opaque, self).__init__(curtain, character)
+      self.fn = lambda: 0
+
+  game = traced_games.ascii_art_to_game(['#####', '#A  #', '#####'], what_lies_beneath=' ',
+                                        drapes={'A': Opaque, '#': traced_games.things.FixedDrape})
+  assert tabulate.fingerprint(game, tabulate.default_actions()) is None
+
+
 def test_too_large_a_state_space_is_refused_with_a_pointer_to_the_rule_library():
   with pytest.raises(tabulate.TabulationError, match='campx_amd.rules'):
     tabulate.trace(traced_games.mirror(), max_plays=50)

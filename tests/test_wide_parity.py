@@ -1,11 +1,12 @@
-"""The wide tier (boards above 128 cells, csrc/k_wide.hip): one-mover games whose table the
-host tabulates, walked by `wide_update_kernel`, rendered by the one-cell tier's render kernel
-from a 16-bit trace.
+"""The wide tier (csrc/k_wide.hip): games run from their STATE table - boards above 128 cells,
+up to four things that show, hidden values behind them - walked by `wide_update_kernel`,
+rendered by the one-cell tier's render kernel from a 16-bit trace.
 
-Chain of evidence: `tests/golden/maze_*.npz` are the library maze run by the REFERENCE engine
-(make_golden.py) -> this repo's generic tier and the tabulated table reproduce them on the CPU
--> on the GPU the HIP path is compared with `oracle/table_replay.py` walking the same table,
-at full batch size, frame by frame, and with the goldens themselves.
+Chain of evidence: `tests/golden/maze_*.npz` / `traced_*.npz` are the games run by the
+REFERENCE engine (make_golden.py, make_traced_golden.py) -> this repo's generic tier and the
+tabulated tables reproduce them on the CPU -> on the GPU the HIP path is compared with
+`oracle/table_replay.py` walking the same table and with `oracle/campx_oracle.c` running the
+rules, at full batch size, frame by frame, and with the goldens themselves.
 """
 
 import ctypes
@@ -49,7 +50,7 @@ def _traced(rows, cols):
 
 @pytest.mark.parametrize('rows,cols', MAZES)
 def test_reference_engine_goldens_on_the_generic_tier_and_through_the_table(rows, cols):
-  from oracle.table_replay import TableWalker
+  from oracle.table_replay import StateWalker
   gold = _golden(rows, cols)
   T, N = gold['actions'].shape
   onehot = tabulate.default_actions()
@@ -67,15 +68,16 @@ def test_reference_engine_goldens_on_the_generic_tier_and_through_the_table(rows
       assert np.float32(discount) == gold['discount'][t, n]
       assert int(game.game_over) == gold['done'][t, n]
   traced = _traced(rows, cols)
-  assert traced.movers == ['A'] and traced.n_tracked == 1 and traced.n == rows * cols * 5
+  assert traced.movers == ['A'] and traced.n_tracked == 1
+  assert traced.dense_reason is not None and traced.n is None      # no cell-indexed table
   assert [ord(c) for c in traced.chars] == gold['chars'].tolist()
-  walker = TableWalker(traced, N)
+  walker = StateWalker(traced, N)
   want = walker.rollout(gold['actions'], reset_first=True)
   for k in ('reward', 'discount', 'done'):
     assert _same(want[k], gold[k]), k
   assert want['done'].sum() == 2
   for t in range(T):
-    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    board, layered = walker.render(want['state'][t])
     assert np.array_equal(board, gold['board'][t + 1]), t
     assert np.array_equal(layered, gold['layered'][t + 1].astype(np.int8)), t
 
@@ -83,40 +85,102 @@ def test_reference_engine_goldens_on_the_generic_tier_and_through_the_table(rows
 def test_wide_spec_of_the_maze_validates_and_says_what_the_table_says():
   from campx_amd import _hip
   traced = _traced(16, 16)
-  spec = tabulate.to_wide_spec(traced)
+  spec, arrays = tabulate.to_wide_spec(traced)
   assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
-  assert (spec.rows, spec.cols, spec.n_layers) == (16, 16, 6)
-  assert spec.init_cell == 17 and spec.init_hidden == 0 and spec.any_reward == 1
-  assert chr(spec.layer_char[spec.dyn_layer]) == 'A'
+  S = traced.n_states
+  assert (spec.rows, spec.cols, spec.n_layers, spec.n_dyn, spec.n_states) == (16, 16, 6, 1, S)
+  assert spec.any_reward == 1 and chr(spec.layer_char[spec.dyn_layer[0]]) == 'A'
+  assert arrays['state_cells'][0, 0] == 17                  # state 0: 'A' at (1, 1), showing
   n_bytes = _hip.lib.campx_wide_tables_bytes(ctypes.byref(spec))
   R = 6 * 256
-  assert n_bytes == 256 * 5 * 8 + 256 * 5 + 16 * (R + 16) + 16 * (256 + 16)
+  assert n_bytes == (S * 5 * 8 + S * 8 + S * 5 + 15) // 16 * 16 + 16 * (R + 16) + 16 * (256 + 16)
+  # the table says what the art says: walls stop, '*' tiles pay +1 on entering
   art = maze.maze_art(16, 16)
+  where = {int(c): s for s, c in enumerate(traced.st_cells[:, 0])}
   for cell in (17, 18, 33):
     for a, (dr, dc) in enumerate([(0, -1), (0, 1), (-1, 0), (1, 0), (0, 0)]):
       r, c = divmod(cell, 16)
       nxt = cell if art[r + dr][c + dc] == '#' else (r + dr) * 16 + c + dc
-      tr = spec.table[cell * 5 + a]
-      assert tr.next_cell == nxt and tr.done == 0          # visible, not hidden: bit 15 clear
-      assert tr.reward == -1.0 + (1.0 if art[r + dr][c + dc] == '*' and nxt != cell else 0.0)
-  bad = tabulate.to_wide_spec(traced)
-  bad.table[0].next_cell = 300                             # a cell off the board
+      s = where[cell]
+      assert traced.st_cells[traced.st_next[s, a], 0] == nxt and traced.st_done[s, a] == 0
+      assert traced.st_reward[s, a] == -1.0 + (1.0 if art[r + dr][c + dc] == '*' and nxt != cell else 0.0)
+  bad, keep = tabulate.to_wide_spec(traced)
+  keep['next_state'][0, 0] = S                             # a state that does not exist
   assert _hip.lib.campx_wide_spec_validate(ctypes.byref(bad)) == -2
-  bad = tabulate.to_wide_spec(traced)
+  bad, keep = tabulate.to_wide_spec(traced)
+  keep['state_cells'][3, 0] = 300                          # a cell off the board
+  assert _hip.lib.campx_wide_spec_validate(ctypes.byref(bad)) == -2
+  bad, keep = tabulate.to_wide_spec(traced)
   bad.rows, bad.cols = 3, 4                                # fewer than 16 cells
   assert _hip.lib.campx_wide_spec_validate(ctypes.byref(bad)) == -2
 
 
-def test_two_movers_on_a_board_above_128_cells_are_refused():
-  art = ['#' * 16] * 10                                  # 160 cells, five of them open
-  art[1] = '#A + G##########'
-  game = traced_games.ascii_art_to_game(
-      art, what_lies_beneath=' ', sprites={'G': traced_games.MirrorGhost},
-      drapes={'A': traced_games.Walker, '#': traced_games.things.FixedDrape,
-              '+': traced_games.things.FixedDrape},
-      z_order='+#AG', update_schedule='A#+G')
-  with pytest.raises(tabulate.TabulationError, match='exactly one moving thing'):
-    tabulate.trace(game)
+def _big_vault(**where):
+  """tests/traced_games.py vault (walker, key, door, hidden gem: four things that show, three
+  of which come and go) on a 12x16 board."""
+  art = ['#' * 16] + ['#' + ' ' * 14 + '#' for _ in range(10)] + ['#' * 16]
+  art[1] = '#A    k #     $#'
+  for r in range(2, 11):
+    art[r] = art[r][:8] + '#' + art[r][9:]
+  art[6] = art[6][:8] + 'D' + art[6][9:]
+  return traced_games.ascii_art_to_game(
+      art, what_lies_beneath=' ', sprites={'$': traced_games.Gem},
+      drapes={'A': traced_games.VaultWalker, 'k': traced_games.Key, 'D': traced_games.Door,
+              '#': traced_games.things.FixedDrape},
+      z_order='k$DA#', update_schedule='AkD$#', **where)
+
+
+def _big_burrow(**where):
+  """tests/traced_games.py burrow (a mole that changes its place in the z-order) on 10x20."""
+  art = ['#' * 20] + ['#' + ' ' * 18 + '#' for _ in range(8)] + ['#' * 20]
+  art[1] = '#A   ======   $    #'
+  art[3] = '#  d ======  u     #'
+  art[5] = '#    ======        #'
+  return traced_games.ascii_art_to_game(
+      art, what_lies_beneath=' ',
+      drapes={'A': traced_games.Mole, '#': traced_games.things.FixedDrape,
+              '=': traced_games.things.FixedDrape, 'd': traced_games.things.FixedDrape,
+              'u': traced_games.things.FixedDrape, '$': traced_games.things.FixedDrape},
+      z_order='du$=A#', update_schedule='A#=du$', **where)
+
+
+BIG_GAMES = {'vault': _big_vault, 'burrow': _big_burrow}
+
+
+@pytest.mark.parametrize('name', sorted(BIG_GAMES))
+def test_many_tracked_values_on_a_big_board_tabulate_to_a_state_table(name):
+  """Four things that come and go, or a z-order that changes, on more than 128 cells: no
+  cell-indexed table exists; the state table predicts the generic tier frame by frame."""
+  from oracle.table_replay import StateWalker
+  build = BIG_GAMES[name]
+  traced = tabulate.trace(build())
+  assert traced.dense_reason is not None and traced.n is None
+  if name == 'vault':
+    assert traced.movers == ['A', 'k', 'D', '$'] and not traced.st_present[0, 3]
+    assert (~traced.st_present[:, 1]).any() and (~traced.st_present[:, 2]).any()
+  else:
+    assert traced.movers == ['A'] and len(traced.mode_orders) == 2
+    assert (traced.st_mode == 1).any() and (traced.st_shows[traced.st_mode == 1, 0] == 0).any()
+  spec, arrays = tabulate.to_wide_spec(traced)
+  assert spec.n_dyn == len(traced.movers) and spec.n_states == traced.n_states
+  rng = np.random.RandomState(11)
+  T = 300
+  actions = rng.randint(0, 5, size=(T, 1)).astype(np.int8)
+  walker = StateWalker(traced, 1)
+  want = walker.rollout(actions, reset_first=True)
+  game = build()
+  game.its_showtime()
+  onehot = tabulate.default_actions()
+  for t in range(T):
+    if game.game_over:
+      game = build()
+      game.its_showtime()
+    obs, reward, discount = game.play(onehot[int(actions[t, 0])])
+    board, layered = walker.render(want['state'][t])
+    assert np.array_equal(obs.board.numpy(), board[0].astype(np.uint8)), t
+    assert np.array_equal(obs.layered_board.numpy(), layered[0]), t
+    assert _same(np.float32(float(reward)), want['reward'][t, 0]), t
+    assert float(discount) == want['discount'][t, 0] and int(game.game_over) == want['done'][t, 0]
 
 
 def test_wide_tier_without_a_gpu_fails_loudly():
@@ -133,20 +197,20 @@ def _check_rollout(game, traced, actions, out, walker, want_board=True):
   want = walker.rollout(actions)
   T, B = actions.shape
   trace = out['trace'].cpu().numpy().astype(np.uint16)
-  assert np.array_equal(trace & 0x3ff, want['cells'][0])
-  assert np.array_equal(trace >> 15, want['visible'][0])
+  assert np.array_equal(trace >> 15, want['shows'])
+  assert np.array_equal(trace & 0x3ff, want['cells'])
   for k in ('reward', 'discount', 'done'):
     assert _same(out[k].cpu().numpy(), want[k]), k
+  assert np.array_equal(game.fused.state.cpu().numpy(), walker.state)
   sample = np.unique(np.concatenate([np.arange(0, B, max(1, B // 61)), [B - 1]]))
   for t in range(T):
-    cells = want['cells'][:, t].astype(np.int64)
     if t in (0, 1, T // 2, T - 1):
-      board, layered = walker.render(cells)
+      board, layered = walker.render(want['state'][t])
       assert np.array_equal(out['obs'][t].cpu().numpy(), layered), t
       if want_board:
         assert np.array_equal(out['board'][t].cpu().numpy(), board), t
     else:
-      board, layered = walker.render(cells[:, sample])
+      board, layered = walker.render(want['state'][t][sample])
       assert np.array_equal(out['obs'][t][sample].cpu().numpy(), layered), t
       if want_board:
         assert np.array_equal(out['board'][t][sample].cpu().numpy(), board), t
@@ -157,7 +221,7 @@ def _check_rollout(game, traced, actions, out, walker, want_board=True):
 @pytest.mark.parametrize('rows,cols,B', [(16, 16, 65536), (15, 17, 4099), (32, 32, 1000),
                                          (12, 11, 777), (8, 127, 300)])
 def test_mazes_through_the_wide_kernels_against_the_table_walker(rows, cols, B):
-  from oracle.table_replay import TableWalker
+  from oracle.table_replay import StateWalker
   from campx_amd import wide
   T = 100 if B > 10000 else 70
   game = maze.build(rows, cols, batch=B, device='cuda')
@@ -165,8 +229,8 @@ def test_mazes_through_the_wide_kernels_against_the_table_walker(rows, cols, B):
   f = game.fused
   assert isinstance(f, wide.WideGame) and reward0 is None and discount0 == 1.0
   traced = f.traced
-  walker = TableWalker(traced, B)
-  board0, layered0 = walker.render(walker.cells[:, :8])
+  walker = StateWalker(traced, B)
+  board0, layered0 = walker.render(walker.state[:8])
   assert np.array_equal(first.board[:8].cpu().numpy(), board0)
   assert np.array_equal(first.layered_board[:8].cpu().numpy(), layered0)
   assert torch.equal(first.layered_board[:1].expand(B, -1, -1, -1), first.layered_board)
@@ -201,6 +265,97 @@ def test_mazes_through_the_wide_kernels_against_the_table_walker(rows, cols, B):
   assert last['obs'].shape == (B, len(traced.chars), rows, cols)
   assert torch.equal(last['obs'], out['obs'][-1]) and torch.equal(last['board'], out['board'][-1])
   assert _same(last['reward'].cpu().numpy(), want['reward'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,B', [('vault', 65536), ('vault', 1001), ('burrow', 32768)])
+def test_many_tracked_values_on_a_big_board_through_the_wide_kernels(name, B):
+  """Four things that show (three come and go) / a changing z-order on more than 128 cells:
+  K trace planes, the render kernel with up to eight patches per row."""
+  from oracle.table_replay import StateWalker
+  from campx_amd import wide
+  build = BIG_GAMES[name]
+  game = build(batch=B, device='cuda')
+  first, _, _ = game.its_showtime()
+  f = game.fused
+  assert isinstance(f, wide.WideGame) and f.n_dyn == len(f.traced.movers)
+  walker = StateWalker(f.traced, B)
+  board0, layered0 = walker.render(walker.state[:4])
+  assert np.array_equal(first.board[:4].cpu().numpy(), board0)
+  assert np.array_equal(first.layered_board[:4].cpu().numpy(), layered0)
+  T = 120
+  rng = np.random.RandomState(B)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  if name == 'vault':     # environment 0: to the key, through the door, up to the gem
+    actions[:, 0] = np.resize([1] * 5 + [3] * 5 + [1] * 3 + [2] * 5 + [1] * 5, T)
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = _check_rollout(game, f.traced, actions, out, walker)
+  assert (want['shows'] == 0).any() and want['done'].sum() >= 1
+  sums = out['obs'].sum(dim=2, dtype=torch.int32)
+  assert int(sums.min()) == 1 and int(sums.max()) == 1
+  # the user's classes themselves, on the generic tier, for two environments
+  onehot = tabulate.default_actions()
+  for env in (0, B - 1):
+    g = build()
+    g.its_showtime()
+    for t in range(T):
+      if g.game_over:
+        g = build()
+        g.its_showtime()
+      obs, reward, _ = g.play(onehot[int(actions[t, env])])
+      assert np.array_equal(out['board'][t, env].cpu().numpy(), obs.board.numpy().astype(np.int8)), (env, t)
+      assert _same(out['reward'][t, env].cpu().numpy(), np.float32(float(reward)))
+  # play() frame by frame after reset()
+  f.reset()
+  for t in range(10):
+    obs, reward, discount = game.play(torch.from_numpy(actions[t]))
+    assert torch.equal(obs.layered_board, out['obs'][t]), t
+    assert _same(reward.cpu().numpy(), want['reward'][t])
+
+
+@pytest.mark.gpu
+def test_a_small_game_with_too_many_tracked_values_for_the_cell_tables_takes_the_state_table():
+  """tests/traced_games.py vault plus a z-order change would be five tracked values; here:
+  burrow's mole AND three vanishing coins on a 6x9 board (54 cells: the one-cell tier's size) -
+  four movers + the z-order mode = five tracked values, so the engine picks the wide tier."""
+  from oracle.table_replay import StateWalker
+  from campx_amd import wide
+  art = ['#########',
+         '#A ===  #',
+         '# d===u #',
+         '# 1 2 3 #',
+         '#      $#',
+         '#########']
+
+  class Coin(traced_games.things.Drape):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is None:
+        return
+      if (self.curtain * all_things['A'].curtain).sum():
+        self.curtain.zero_()
+        the_plot.add_reward(2.0)
+
+  def build(**where):
+    return traced_games.ascii_art_to_game(
+        art, what_lies_beneath=' ',
+        drapes={'A': traced_games.Mole, '#': traced_games.things.FixedDrape,
+                '=': traced_games.things.FixedDrape, 'd': traced_games.things.FixedDrape,
+                'u': traced_games.things.FixedDrape, '$': traced_games.things.FixedDrape,
+                '1': Coin, '2': Coin, '3': Coin},
+        z_order='du$=123A#', update_schedule='A123#=du$', **where)
+
+  B, T = 4096, 150
+  game = build(batch=B, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  assert isinstance(f, wide.WideGame) and f.traced.movers == ['A', '1', '2', '3']
+  assert 'tracked values' in f.traced.dense_reason
+  walker = StateWalker(f.traced, B)
+  rng = np.random.RandomState(4)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = _check_rollout(game, f.traced, actions, out, walker)
+  assert (want['reward'] > 1).sum() > B // 4           # coins collected
 
 
 @pytest.mark.gpu
@@ -286,7 +441,7 @@ def test_a_user_class_with_hidden_tiles_discounts_and_bad_actions_on_a_wide_boar
   """Arbitrary Python (tests/traced_games.py TollWalker: custom discounts, terminate(0.75)) on a
   12x20 board, under a roof that hides the walker on some tiles; ids outside 0..4 act as stay
   and are reported."""
-  from oracle.table_replay import TableWalker
+  from oracle.table_replay import StateWalker
   art = ['#' * 20] + ['#' + ' ' * 18 + '#' for _ in range(10)] + ['#' * 20]
   art[1] = '#A  $   ====   %   #'
   art[5] = '#   ====   $     E #'
@@ -305,15 +460,15 @@ def test_a_user_class_with_hidden_tiles_discounts_and_bad_actions_on_a_wide_boar
   game.its_showtime()
   traced = game.fused.traced
   assert traced.discount_list == [1.0, 0.5, 0.25, 0.75]
-  assert (traced.visible[0][traced.reached] == 0).any()     # under the roof
-  walker = TableWalker(traced, B)
+  assert (traced.st_shows[:, 0] == 0).any()                 # under the roof
+  walker = StateWalker(traced, B)
   rng = np.random.RandomState(77)
   actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
   actions[:, 0] = np.resize([1] * 16 + [3] * 4, T)          # along the top row, down to E
   out = game.rollout(torch.from_numpy(actions), want_board=True)
   want = _check_rollout(game, traced, actions, out, walker)
   assert set(np.unique(want['discount']).tolist()) >= {0.25, 0.5, 0.75, 1.0}
-  assert want['done'][:, 0].sum() >= 1 and (want['visible'][0] == 0).any()
+  assert want['done'][:, 0].sum() >= 1 and (want['shows'][0] == 0).any()
   # bad ids
   game.fused.validate_actions = 'sync'
   bad = actions[:3].copy()
@@ -326,16 +481,16 @@ def test_a_user_class_with_hidden_tiles_discounts_and_bad_actions_on_a_wide_boar
 def test_raw_c_abi_through_ctypes_on_a_side_stream():
   """campx_wide_* called as a C program would (no torch ops), on a non-default stream."""
   from campx_amd import _hip
-  from oracle.table_replay import TableWalker
+  from oracle.table_replay import StateWalker
   traced = _traced(16, 16)
-  spec = tabulate.to_wide_spec(traced)
+  spec, arrays = tabulate.to_wide_spec(traced)
   lib, dev = _hip.lib, torch.device('cuda', 0)
   B, T, L, HW = 1500, 33, 6, 256
   stream = torch.cuda.Stream(dev)
   sp = ctypes.c_void_p(stream.cuda_stream)
   tables = torch.empty((lib.campx_wide_tables_bytes(ctypes.byref(spec)),), dtype=torch.uint8, device=dev)
   _hip.check(lib.campx_wide_tables_build(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), sp), 'build')
-  pos = torch.zeros((2, B), dtype=torch.int8, device=dev)
+  pos = torch.full((B,), 7, dtype=torch.int32, device=dev)      # the state indices
   done = torch.ones((B,), dtype=torch.uint8, device=dev)
   ret = torch.full((B,), 5.0, device=dev)
   obs = torch.zeros((T, B, L, 16, 16), dtype=torch.int8, device=dev)
@@ -355,12 +510,13 @@ def test_raw_c_abi_through_ctypes_on_a_side_stream():
   _hip.check(lib.campx_wide_rollout_launch(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), state,
                                            ctypes.c_void_p(acts.data_ptr()), out, B, T, 0, sp), 'rollout')
   stream.synchronize()
-  walker = TableWalker(traced, B)
+  walker = StateWalker(traced, B)
   want = walker.rollout(actions)
   assert _same(reward.cpu().numpy(), want['reward'])
   assert _same(ret.cpu().numpy(), walker.ret) and int(done.sum()) == int(walker.over.sum())
+  assert np.array_equal(pos.cpu().numpy(), walker.state)
   for t in (0, T - 1):
-    _, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    _, layered = walker.render(want['state'][t])
     assert np.array_equal(obs[t].cpu().numpy(), layered)
   # frames that are neither back to back nor "last only" are refused, as is a missing trace
   out.obs_t_stride = B * L * HW + 16
