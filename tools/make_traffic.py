@@ -23,9 +23,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_dispatch(db, counter):
-  """kernel -> bytes per dispatch: the MEDIAN over its dispatches (a run also holds one-off
-  dispatches of the same kernel - the one-frame render of its_showtime() - that an average
-  would mix in), for kernels dispatched at least half as often as the busiest one."""
+  """kernel -> (bytes per dispatch, dispatches): the MEDIAN over its dispatches (a run also
+  holds one-off dispatches of the same kernel - the one-frame render of its_showtime() - that
+  an average would mix in)."""
   cur = sqlite3.connect(db).cursor()
   rows = cur.execute(
       'select kernel_name, dispatch_id, sum(value) from counters_collection '
@@ -33,8 +33,7 @@ def per_dispatch(db, counter):
   per = {}
   for k, _, v in rows:
     per.setdefault(k, []).append(v)
-  most = max(len(v) for v in per.values()) if per else 0
-  return {k: sorted(v)[len(v) // 2] * 1024.0 for k, v in per.items() if 2 * len(v) >= most}
+  return {k: (sorted(v)[len(v) // 2] * 1024.0, len(v)) for k, v in per.items()}
 
 
 def main(specs):
@@ -51,6 +50,11 @@ def main(specs):
     w = per_dispatch(os.path.join(d, 'pmc_write_results.db'), 'WRITE_SIZE')
     f = per_dispatch(os.path.join(d, 'pmc_fetch_results.db'), 'FETCH_SIZE')
     names = [k for k in w if 'render_kernel' in k or 'update_' in k]
+    # (kernels of the rollout launches only: not the one-off board render of its_showtime())
+    most = max([w[k][1] for k in names] or [0])
+    names = [k for k in names if 2 * w[k][1] >= most]
+    w = {k: v[0] for k, v in w.items()}
+    f = {k: v[0] for k, v in f.items()}
     short = [k.replace('(anonymous namespace)::', '').replace('campx_impl::', '').split('(')[0]
              for k in names]
     wb = sum(w[k] for k in names)
