@@ -201,6 +201,37 @@ class TracedGame(object):
     return board.reshape(self.rows, self.cols)
 
 
+def _copy_tensor(x, memo):
+  """deepcopy of a plain CPU tensor, as torch's own `Tensor.__deepcopy__` does it - a clone of
+  the STORAGE, shared by every tensor that shared the original (the reference's renderer
+  relies on such sharing: `board.set_(curtain)`, campx/rendering.py:128) - minus the checks
+  for the kinds of tensor a game's state never is; those take the slow path."""
+  if (type(x) is not torch.Tensor or x.requires_grad or x.device.type != 'cpu' or x.is_sparse
+      or x.is_quantized or x.grad is not None):
+    return x.__deepcopy__(memo)
+  storage = x.untyped_storage()
+  shared = memo.setdefault('torch', {})          # (the key torch's own storage copy uses)
+  fresh = shared.get(storage._cdata)
+  if fresh is None:
+    fresh = shared[storage._cdata] = storage.clone()
+  return torch.empty(0, dtype=x.dtype).set_(fresh, x.storage_offset(), x.size(), x.stride())
+
+
+def _clone_engine(engine):
+  """`copy.deepcopy(engine)` with the lean tensor copy above (a tabulation makes thousands of
+  copies of an engine that holds a dozen small tensors: 70 % of its time was here)."""
+  dispatch = copy._deepcopy_dispatch
+  had = dispatch.get(torch.Tensor)
+  dispatch[torch.Tensor] = _copy_tensor
+  try:
+    return copy.deepcopy(engine)
+  finally:
+    if had is None:
+      del dispatch[torch.Tensor]
+    else:
+      dispatch[torch.Tensor] = had
+
+
 class _NoFingerprint(Exception):
   pass
 
@@ -314,7 +345,7 @@ def _trace(engine, actions, max_plays):
   if len(actions) != N_ACTIONS:
     raise ValueError('exactly {} actions are needed'.format(N_ACTIONS))
 
-  probe = copy.deepcopy(engine)
+  probe = _clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None
   obs, _, _ = probe.its_showtime()
   if probe.game_over:
@@ -351,7 +382,8 @@ def _trace(engine, actions, max_plays):
   while queue:
     s = queue.popleft()
     for a in range(N_ACTIONS):
-      eng = copy.deepcopy(engines[s])
+      # (the last action is played on the state's own engine: nobody needs it afterwards)
+      eng = _clone_engine(engines[s]) if a < N_ACTIONS - 1 else engines[s]
       things, reward, discount, over, board = step(eng, a)
       t = index_of.get(things)
       if t is None:
@@ -373,7 +405,7 @@ def _trace(engine, actions, max_plays):
   # ---- the curtains are the whole state: replay every action over a second history
   for t, eng0 in second.items():
     for a in range(N_ACTIONS):
-      eng = copy.deepcopy(eng0)
+      eng = _clone_engine(eng0) if a < N_ACTIONS - 1 else eng0
       things, reward, discount, over, board = step(eng, a)
       got = _Edge(index_of.get(things), reward, discount, over, board)
       if not got.same(edges[(t, a)]):
