@@ -359,7 +359,11 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   int32_t* state = reinterpret_cast<int32_t*>(st.pos);
   const size_t want = (size_t)w.n_entries * sizeof(uint2) + (size_t)s->n_states * sizeof(uint2) +
                       (out.perf ? (size_t)w.n_entries : 0);
-  const bool in_lds = want <= kWideLdsMax;
+  // (CAMPX_WIDE_LDS_MAX=bytes, read at every launch: tests run small games through the
+  // global-memory path that games with thousands of states take)
+  size_t lds_max = kWideLdsMax;
+  if (const char* v = getenv("CAMPX_WIDE_LDS_MAX")) lds_max = (size_t)atoll(v) < kWideLdsMax ? (size_t)atoll(v) : kWideLdsMax;
+  const bool in_lds = want <= lds_max;
   const size_t lds = in_lds ? want : 0;
   const dim3 grid((unsigned)((B + kWideThreads - 1) / kWideThreads));
 #define CAMPX_WIDE_LAUNCH(LDS, PERF)                                                              \

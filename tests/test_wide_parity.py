@@ -359,6 +359,27 @@ def test_a_small_game_with_too_many_tracked_values_for_the_cell_tables_takes_the
 
 
 @pytest.mark.gpu
+def test_state_tables_too_large_for_lds_are_read_through_the_caches():
+  """Games with thousands of states keep their table in global memory (wide_update_kernel<false>);
+  CAMPX_WIDE_LDS_MAX=0 sends a small game down that path: same bytes."""
+  game = _big_vault(batch=5000, device='cuda')
+  game.its_showtime()
+  rng = np.random.RandomState(9)
+  actions = torch.from_numpy(rng.randint(0, 5, size=(90, 5000)).astype(np.int8))
+  ref = game.rollout(actions, reset_first=True, want_board=True)
+  os.environ['CAMPX_WIDE_LDS_MAX'] = '0'
+  try:
+    out = game.rollout(actions, reset_first=True, want_board=True)
+  finally:
+    del os.environ['CAMPX_WIDE_LDS_MAX']
+  for k in ('obs', 'board', 'trace', 'done'):
+    assert torch.equal(out[k], ref[k]), k
+  for k in ('reward', 'discount'):
+    assert _same(out[k].cpu().numpy(), ref[k].cpu().numpy()), k
+  assert ref['done'].sum() > 0 and (ref['trace'] >= 0).any()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('rows,cols,B', [(16, 16, 8192), (15, 17, 2001), (32, 32, 1024)])
 def test_mazes_against_the_c_oracle(rows, cols, B):
   """oracle/campx_oracle.c - the literal restatement of the reference engine (full curtains,
