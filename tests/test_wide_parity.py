@@ -365,7 +365,9 @@ def test_state_tables_too_large_for_lds_are_read_through_the_caches():
   game = _big_vault(batch=5000, device='cuda')
   game.its_showtime()
   rng = np.random.RandomState(9)
-  actions = torch.from_numpy(rng.randint(0, 5, size=(90, 5000)).astype(np.int8))
+  acts = rng.randint(0, 5, size=(90, 5000)).astype(np.int8)
+  acts[:, 0] = np.resize([1] * 5 + [3] * 5 + [1] * 3 + [2] * 5 + [1] * 5, 90)   # key, door, gem
+  actions = torch.from_numpy(acts)
   ref = game.rollout(actions, reset_first=True, want_board=True)
   os.environ['CAMPX_WIDE_LDS_MAX'] = '0'
   try:
@@ -376,7 +378,7 @@ def test_state_tables_too_large_for_lds_are_read_through_the_caches():
     assert torch.equal(out[k], ref[k]), k
   for k in ('reward', 'discount'):
     assert _same(out[k].cpu().numpy(), ref[k].cpu().numpy()), k
-  assert ref['done'].sum() > 0 and (ref['trace'] >= 0).any()
+  assert ref['done'][:, 0].sum() > 0 and (ref['reward'] > 0).sum() > 100
 
 
 @pytest.mark.gpu
