@@ -3,6 +3,8 @@
 // update_tuple_kernel) and launch_update, which picks one (or the interpreter in trace mode).
 #include "campx_common.hip.h"
 
+#include <type_traits>
+
 namespace campx_impl {
 
 // ---------------------------------------------------------------------------
@@ -34,6 +36,10 @@ namespace campx_impl {
 #define CAMPX_UPD_FLAVOR 1
 #endif
 __device__ __forceinline__ void store16_update(void* p, u32x4 v) {
+#if defined(CAMPX_UPD_DEBUG) && CAMPX_UPD_DEBUG == 1
+  if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(p) = v;   // (never)
+  return;
+#endif
 #if CAMPX_UPD_FLAVOR == 0
   *reinterpret_cast<u32x4*>(p) = v;
 #elif CAMPX_UPD_FLAVOR == 1
@@ -245,6 +251,27 @@ constexpr int update_loaders(int prod) { return prod >= 4 ? prod / 2 : 1; }
 #endif
 constexpr int update_min_waves(int, int) { return CAMPX_UPD_MINWAVES; }
 
+// Where this kernel's time goes (round 3, kernel trace at B = 4 096, T = 16 .. 512:
+// 8.2 / 10.0 / 11.9 / 17.0 / 28.9 / 52.2 us): ~6 us fixed (launch, the table and the first
+// chunk of actions, the drain) + 92 ns per frame.  The per-frame part is NOT the producers'
+// dependent chain (state -> entry -> state, one LDS lookup per frame), as rounds 1-2 assumed:
+//   * CAMPX_UPD_COMPOSE == 2 halves the chain - a second table, built per workgroup from the
+//     first, maps (cell, action, action) straight to the cell TWO frames on, the per-frame
+//     entries are looked up off the chain, the three lookups of a step issued together - and
+//     changes nothing (T = 256: 29.1 against 29.0 us; B = 65 536: 16.9 against 16.6);
+//   * neither does removing the per-frame `j < n` test and its scalar branch (whole groups run
+//     branch-free now);
+//   * -DCAMPX_UPD_DEBUG=2 (consumers idle) reads 21.3 us at T = 256, =3 (producers idle) 27.3:
+//     the CONSUMER waves bound the frame (83 ns: LDS read -> unpack -> store, five dependent
+//     rounds per group), the producers come second (60 ns);
+//   * -DCAMPX_UPD_DEBUG=1 (no global stores at all) saves 0.8 us: it is not the memory system.
+// Hence 8 consumer waves instead of 4 for the 256-environment workgroups (B = 4 096: 14.9 ->
+// 12.9 us; T = 256: 29.0 -> 23.5); at B = 65 536 the kernel reads 16.3-16.7 us either way.
+// The composed chain stays as an A/B build (default off: it only adds LDS and instructions).
+#ifndef CAMPX_UPD_COMPOSE
+#define CAMPX_UPD_COMPOSE 1
+#endif
+
 template <int kProd, int kCons, int kG>   // kG: frames per group (a ring slot)
 __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                              update_min_waves(kProd, kCons)) void update_table_kernel(
@@ -259,6 +286,10 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   // [24] done, [25:26] + [31] hidden-performance code, [27:30] discount code.  The ring keeps
   // x and the upper half of y.
   __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+#if CAMPX_UPD_COMPOSE == 2
+  static_assert(kG % 2 == 0, "frames are chained in pairs");
+  __shared__ uint8_t table2[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS * CAMPX_N_ACTIONS];
+#endif
   __shared__ float discounts[16];
   __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
   __shared__ __attribute__((aligned(16))) float ring_r[2][kG][E];
@@ -301,10 +332,22 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     if (st.ret) ret = st.ret[env];
   }
   uint32_t row_off = (uint32_t)(over ? cell0 : cell) * kRowBytes;  // the chain's state
+  uint32_t last_y = ((uint32_t)cell << 16) | ((uint32_t)over << 24);  // upper half of the latest entry
   const char* table_bytes = reinterpret_cast<const char*>(table);
   const int clane = (int)threadIdx.x - kProd * kWave;  // consumers: 0 .. CL-1
   constexpr int kGroupsPerChunk = kChunk / kG;
   __syncthreads();
+#if CAMPX_UPD_COMPOSE == 2
+  constexpr int kPairs = CAMPX_N_ACTIONS * CAMPX_N_ACTIONS;
+  for (int i = threadIdx.x; i < HW * kPairs; i += kThreads) {
+    const int c = i / kPairs, p = i - c * kPairs, a1 = p / CAMPX_N_ACTIONS, a2 = p - a1 * CAMPX_N_ACTIONS;
+    const uint32_t from1 = table[c * CAMPX_N_ACTIONS + a1].y & 0xffffu;        // a row's byte offset
+    const uint32_t from2 = table[from1 / (uint32_t)sizeof(uint2) + a2].y & 0xffffu;
+    table2[i] = (uint8_t)(from2 / kRowBytes);
+  }
+  uint32_t chain = (uint32_t)(over ? cell0 : cell);   // the cell the next frame starts from
+  __syncthreads();
+#endif
 
   const int n_groups = (T + kG - 1) / kG;
   // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
@@ -320,20 +363,67 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   #pragma unroll
           for (int j = 0; j < kG; ++j)
             col_off[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le) * (uint32_t)sizeof(uint2);
+          // A frame's bookkeeping besides the chain: into the ring, and the running return
+          // (which restarts after an episode end: bit 24 of the PREVIOUS frame's entry).  Where
+          // the mover stands and whether the episode is over are read off the last entry
+          // after the loop.  `kFull`: a whole group - no per-frame test, hence no branch
+          // between frames, and the compiler overlaps one frame's bookkeeping with the next
+          // frame's lookup (with the test, every frame ended in a scalar branch and waited
+          // for its own LDS read: the kernel spent ~190 cycles per frame issuing, not waiting
+          // on the chain; round 3 measured the chain itself by halving it: no change).
+          auto frames = [&](auto full_tag) {
+            constexpr bool kFull = decltype(full_tag)::value;
+            auto book = [&](int j, uint2 e) {
+              if (kFull || j < n) {
+                ring_r[g & 1][j][le] = __uint_as_float(e.x);
+                ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
+                ret = (((last_y >> 24) & 1u) ? 0.0f : ret) + real_reward(__uint_as_float(e.x));
+                last_y = e.y;
+              }
+            };
+#if CAMPX_UPD_COMPOSE == 2
+            uint32_t pair_of[kG / 2];   // (action, action) of each pair of frames, off the chain
   #pragma unroll
-          for (int j = 0; j < kG; ++j) {
-            if (j < n) {
-              // the dependent chain: row offset -> entry -> row offset
-              const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
-              row_off = e.y & 0xffffu;
-              ring_r[g & 1][j][le] = __uint_as_float(e.x);
-              ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
-              // off the chain: the return restarts after an episode end
-              ret = (over ? 0.0f : ret) + real_reward(__uint_as_float(e.x));
-              over = (int)((e.y >> 24) & 1u);
-              cell = (int)((e.y >> 16) & 0x7fu);
+            for (int jp = 0; jp < kG / 2; ++jp)
+              pair_of[jp] = (col_off[2 * jp] * CAMPX_N_ACTIONS + col_off[2 * jp + 1]) / (uint32_t)sizeof(uint2);
+            // Software-pipelined by hand: the lookups of one step are issued together - where
+            // the pair after this one starts (the chain), that pair's first entry, this pair's
+            // second entry - so a step costs ONE LDS round trip.  Entries past the group's last
+            // frame are looked up and dropped.
+            uint32_t next_start = table2[chain * kPairs + pair_of[0]];
+            uint2 e1 = *reinterpret_cast<const uint2*>(table_bytes + chain * kRowBytes + col_off[0]);
+  #pragma unroll
+            for (int jp = 0; jp < kG / 2; ++jp) {
+              const int j = 2 * jp;
+              const uint32_t start = next_start;
+              const uint2 ea = e1;
+              if (jp + 1 < kG / 2) {
+                next_start = table2[start * kPairs + pair_of[jp + 1]];
+                e1 = *reinterpret_cast<const uint2*>(table_bytes + start * kRowBytes + col_off[j + 2]);
+              }
+              const uint2 eb = *reinterpret_cast<const uint2*>(table_bytes + (ea.y & 0xffffu) + col_off[j + 1]);
+              book(j, ea);
+              book(j + 1, eb);
+              if (kFull || j < n) chain = start;      // (where the frame after this pair starts)
             }
-          }
+#else
+  #pragma unroll
+            for (int j = 0; j < kG; ++j) {
+              if (kFull || j < n) {
+                // the dependent chain: row offset -> entry -> row offset
+                const uint2 e = *reinterpret_cast<const uint2*>(table_bytes + row_off + col_off[j]);
+                row_off = e.y & 0xffffu;
+                book(j, e);
+              }
+            }
+#endif
+          };
+#if defined(CAMPX_UPD_DEBUG) && CAMPX_UPD_DEBUG == 3
+          if (T < 0) frames(std::true_type{});
+#else
+          if (n == kG) frames(std::true_type{});
+          else frames(std::false_type{});
+#endif
         }
       
       __syncthreads();
@@ -343,7 +433,11 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     // (a padded pitch lets the batch's last group be stored whole, into the pad)
     const int64_t P = row_pitch(out, B), Bv = row_extent(out, B);
     for (int g = 0; g <= n_groups; ++g) {
+#if defined(CAMPX_UPD_DEBUG) && CAMPX_UPD_DEBUG == 2
+        if (g > 0 && T < 0) {
+#else
         if (g > 0) {
+#endif
           const int gp = g - 1, t0 = gp * kG, rb = gp & 1;
           const int n = (T - t0 < kG) ? T - t0 : kG;
           // ---- float streams: item = (frame j, 4 environments)
@@ -445,6 +539,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   }
 
   if (live) {
+    cell = (int)((last_y >> 16) & 0x7fu);
+    over = (int)((last_y >> 24) & 1u);
     st.pos[env] = (int8_t)(cell / W);
     st.pos[B + env] = (int8_t)(cell % W);
     st.done[env] = (uint8_t)over;
@@ -946,8 +1042,11 @@ PairParams make_pair_params(const CampxSpec& s) {
 #ifndef CAMPX_UPD_PROD
 #define CAMPX_UPD_PROD 4
 #endif
+// (8 consumer waves for the 256-environment workgroups: the consumers, not the producers'
+// chain, bound the kernel per frame - see the note above update_table_kernel: B = 4 096
+// 14.9 -> 12.9 us, T = 256 29.0 -> 23.5, B = 65 536 unchanged)
 #ifndef CAMPX_UPD_CONS
-#define CAMPX_UPD_CONS 4
+#define CAMPX_UPD_CONS 8
 #endif
 #ifndef CAMPX_UPD_GROUP
 // frames per group of the 256-environment one-mover workgroups; kernel us per 100 frames at
