@@ -35,6 +35,16 @@ namespace campx_impl {
 #ifndef CAMPX_UPD_FLAVOR
 #define CAMPX_UPD_FLAVOR 1
 #endif
+// (CAMPX_UPD_CLOBBER=0: the store asm without its "memory" clobber, so that the compiler may
+// move a consumer's next LDS reads above it - an A/B build)
+#ifndef CAMPX_UPD_CLOBBER
+#define CAMPX_UPD_CLOBBER 1
+#endif
+#if CAMPX_UPD_CLOBBER
+#define CAMPX_UPD_CLOBBERS : "memory"
+#else
+#define CAMPX_UPD_CLOBBERS
+#endif
 __device__ __forceinline__ void store16_update(void* p, u32x4 v) {
 #if defined(CAMPX_UPD_DEBUG) && CAMPX_UPD_DEBUG == 1
   if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(p) = v;   // (never)
@@ -43,9 +53,9 @@ __device__ __forceinline__ void store16_update(void* p, u32x4 v) {
 #if CAMPX_UPD_FLAVOR == 0
   *reinterpret_cast<u32x4*>(p) = v;
 #elif CAMPX_UPD_FLAVOR == 1
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) CAMPX_UPD_CLOBBERS);
 #else
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) CAMPX_UPD_CLOBBERS);
 #endif
 }
 
@@ -666,7 +676,10 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
           const int n = (T - t0 < kG) ? T - t0 : kG;
           const int64_t plane = trace_plane;  // from one moving thing's trace to the next's
           constexpr int QA = E / 4, kItA = (kG * QA + CL - 1) / CL;
-  #pragma unroll 1   // (unrolled, the four iterations' lookups pile up in registers and spill)
+#ifndef CAMPX_PAIR_UNROLL_A
+#define CAMPX_PAIR_UNROLL_A 1
+#endif
+  #pragma unroll CAMPX_PAIR_UNROLL_A   // (fully unrolled, the iterations' lookups pile up in registers and spill)
           for (int it = 0; it < kItA; ++it) {
             const int item = clane + it * CL;
             const int j = item / QA, q = item % QA;
@@ -1054,11 +1067,19 @@ PairParams make_pair_params(const CampxSpec& s) {
 // 32: 12.7 / 16.8 - a group costs ~0.3 us of hand-over, a longer one more fill and drain
 #define CAMPX_UPD_GROUP 16
 #endif
+#ifndef CAMPX_PAIR_BIG
+#define CAMPX_PAIR_BIG 1     // 512-environment workgroups (8 producer, 4 consumer waves) for large batches
+#endif
 #ifndef CAMPX_PAIR_PROD
 #define CAMPX_PAIR_PROD 4
 #endif
+// (6 consumer waves for the 256-environment pair workgroups, 2 until round 3: their consumers
+// bound the kernel - sokoban B = 16 384: 31.3 -> 18.7 us per 100 frames (8 waves: 18.0), B = 4 096
+// T = 256: 68.2 -> 35.8.  The three- / four-mover kernel keeps 2: 4 or 6 read 34-36 instead of
+// 38-40 us at B = 4 096 but 78-93 instead of 60-71 us at B = 131 072, where the extra waves
+// cost resident workgroups.)
 #ifndef CAMPX_PAIR_CONS
-#define CAMPX_PAIR_CONS 2
+#define CAMPX_PAIR_CONS 6
 #endif
 #ifndef CAMPX_TUPLE_PROD
 #define CAMPX_TUPLE_PROD 4
@@ -1111,7 +1132,12 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       hipLaunchKernelGGL((update_pair_kernel<false, PROD, CONS>), grid, block, 0, stream, pp,  \
                          spec_dev, st, actions, out, B, T, reset_first, trace_plane, fc);      \
   } while (0)
-    if (big)
+    // The 256-environment pair workgroup (12 waves of ~110 VGPRs) does not share a CU with a
+    // second one, so past one workgroup per CU a launch runs in two rounds (B = 99 999: 44 us
+    // against 21 at 65 536); the 512-environment workgroups take over from there (one round,
+    // ~38 us), not only from 512 environments per CU.
+    const bool big_pair = B > (int64_t)(kBigEnvs / 2) * knob_big_workgroups();
+    if ((big || big_pair) && CAMPX_PAIR_BIG)
       CAMPX_PAIR_LAUNCH(8, 4);
     else
       CAMPX_PAIR_LAUNCH(CAMPX_PAIR_PROD, CAMPX_PAIR_CONS);
