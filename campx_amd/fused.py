@@ -190,7 +190,9 @@ class FusedGame(object):
     confined to n compute units (campx_stream_create_cu_subset), so that the update pass
     cannot take workgroup slots from the render kernel it runs under."""
     if not self.aux_cus:
-      return torch.cuda.Stream(self.device)
+      # (CAMPX_AUX_PRIORITY=-1: a high-priority side stream, so that the short update pass is
+      # scheduled ahead of the render blocks it runs under - an A/B knob)
+      return torch.cuda.Stream(self.device, priority=int(os.environ.get('CAMPX_AUX_PRIORITY', '0')))
     raw = ctypes.c_void_p()
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_stream_create_cu_subset(int(self.aux_cus), ctypes.byref(raw)),

@@ -548,3 +548,48 @@ def test_raw_c_abi_through_ctypes_on_a_side_stream():
   out.obs_t_stride, out.trace = B * L * HW, None
   assert lib.campx_wide_rollout_launch(ctypes.byref(spec), ctypes.c_void_p(tables.data_ptr()), state,
                                        ctypes.c_void_p(acts.data_ptr()), out, B, T, 0, sp) == -1
+
+
+@pytest.mark.gpu
+def test_wide_op_passes_opcheck_and_is_capturable_in_a_hip_graph():
+  """campx::wide_rollout: schema / fake-tensor / functionalization checks (torch.library.opcheck),
+  and a policy-in-the-loop stretch of play() calls captured in a HIP graph and replayed."""
+  game = maze.build(16, 16, batch=128, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  acts = torch.randint(0, 5, (128,), dtype=torch.int8, device='cuda')
+  args = (f._spec_host, f._tables, f.state, f.done, f.ret, acts, f._obs, f._board, f._reward,
+          f._discount, f._step_done, None, f._step_trace, f._bad, None, False)
+  torch.library.opcheck(torch.ops.campx.wide_rollout.default, args)
+  acts = torch.randint(0, 5, (5, 128), dtype=torch.int8, device='cuda')
+  b = f.rollout_buffers(5, want_board=True)
+  args = (f._spec_host, f._tables, f.state, f.done, f.ret, acts, b['obs'], b['board'], b['reward'],
+          b['discount'], b['done'], None, b['trace'], f._bad, None, True)
+  torch.library.opcheck(torch.ops.campx.wide_rollout.default, args)
+
+  game_g, game_e = (maze.build(16, 16, batch=1024, device='cuda') for _ in range(2))
+  for g in (game_g, game_e):
+    g.its_showtime()
+    g.fused.validate_actions = False
+  w = torch.randn(6 * 256, 5, device='cuda')
+
+  def frames(g, n):
+    for _ in range(n):
+      ids = (g.fused._obs.view(g.fused.batch, -1).float() @ w).argmax(dim=1).to(torch.int8)
+      g.play(ids)
+
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):
+    frames(game_g, 2)
+  torch.cuda.current_stream().wait_stream(side)
+  frames(game_e, 2)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    frames(game_g, 5)
+  for _ in range(3):
+    graph.replay()
+  frames(game_e, 15)
+  torch.cuda.synchronize()
+  assert torch.equal(game_g.fused._obs, game_e.fused._obs)
+  assert torch.equal(game_g.fused.state, game_e.fused.state)
+  assert torch.equal(game_g.fused.ret, game_e.fused.ret)
