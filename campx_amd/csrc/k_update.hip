@@ -843,7 +843,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   float ret = 0.0f;
   if (live && !reset_first) {
     cells = 0;
-#pragma unroll
+    // (rolled: with the 2K addresses of an unrolled loop live at once the four-mover kernel,
+    // capped at 128 VGPRs for two workgroups per CU, spilled 36 bytes here)
+#pragma unroll 1
     for (int k = 0; k < K; ++k)
       cells |= (uint32_t)((int)st.pos[(int64_t)(2 * k) * B + env] * W +
                           (int)st.pos[(int64_t)(2 * k + 1) * B + env]) << (7 * k);
@@ -994,14 +996,20 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   }
 
   if (live) {
+    // (the environment's index is derived again rather than kept in two VGPRs across the frame
+    // loop: the empty asm hides `le` from common-subexpression elimination; the four-mover
+    // kernel, capped at 128 VGPRs, otherwise spills it)
+    int le_again = le;
+    asm volatile("" : "+v"(le_again));
+    const int64_t env_again = env0 + le_again;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t c = (cells >> (7 * k)) & 0x7fu;
-      st.pos[(int64_t)(2 * k) * B + env] = (int8_t)(c / (uint32_t)W);
-      st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)(c % (uint32_t)W);
+      st.pos[(int64_t)(2 * k) * B + env_again] = (int8_t)(c / (uint32_t)W);
+      st.pos[(int64_t)(2 * k + 1) * B + env_again] = (int8_t)(c % (uint32_t)W);
     }
-    st.done[env] = (uint8_t)over;
-    if (st.ret) st.ret[env] = ret;
+    st.done[env_again] = (uint8_t)over;
+    if (st.ret) st.ret[env_again] = ret;
   }
   report_bad_actions(out, bad);
 }
