@@ -553,7 +553,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
 // Where a render launch finds a game's tables (k_render.hip).
 struct RenderSource {
   int32_t rows, cols, n_layers, n_dyn;
-  int32_t dyn_layer[CAMPX_MAX_DYN];
+  int32_t dyn_layer[CAMPX_WIDE_MAX_DYN];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   const int8_t* rot_obs;      // device: 16 x (round_up(R, 16) + 16) bytes, see CampxSpec.rot_obs
   const int8_t* rot_board;

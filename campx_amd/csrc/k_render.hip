@@ -24,8 +24,8 @@ struct RenderParams {
   int32_t n_dyn, is_board, cells;
   int64_t B;
   int64_t pitch;              // rows of the trace from one frame to the next (B unless padded)
-  int32_t dyn_char[CAMPX_MAX_DYN];
-  int32_t dyn_off[CAMPX_MAX_DYN];   // byte offset of moving thing d's layer inside a row
+  int32_t dyn_char[CAMPX_WIDE_MAX_DYN];
+  int32_t dyn_off[CAMPX_WIDE_MAX_DYN];   // byte offset of moving thing d's layer inside a row
   const int8_t* rot;          // device: the 16 rotations of the scenery row (layered or flat board)
   const uint8_t* top_layer;   // device: scenery layer per cell (one-byte trace only)
 };
@@ -122,7 +122,10 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
   const int R = (int)rp.R;
   const int pitch = ((R + 15) & ~15) + 16;
   const int8_t* rot = rp.rot;
-  constexpr int P = kBoard ? K : 2 * K;                // patches per row
+  // patches per row; the K = 8 instantiation (wide tier, five to eight things) reads the
+  // count from its arguments: its surplus planes of the trace do not exist
+  constexpr bool kRuntimeK = K > CAMPX_MAX_DYN;
+  const int P = kRuntimeK ? (kBoard ? rp.n_dyn : 2 * rp.n_dyn) : (kBoard ? K : 2 * K);
   const typename Fmt::Entry* frame_trace = trace + (int64_t)blockIdx.y * rp.pitch;
   // (kOdd: a chunk that straddles two frames asks for "row B" = row 0 of the next frame)
   auto trace_row = [&](uint32_t row) -> int64_t {
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
   // segment and wait for it inside the patch branch: one more memory trip per wave)
   // (readfirstlane makes each argument an opaque scalar: from three things up the
   // optimiser otherwise turns the select chain back into the indexed load)
-  auto of_thing = [&](const int32_t (&arr)[CAMPX_MAX_DYN], int d) {
+  auto of_thing = [&](const int32_t (&arr)[CAMPX_WIDE_MAX_DYN], int d) {
     int v = __builtin_amdgcn_readfirstlane(arr[0]);
 #pragma unroll
     for (int k = 1; k < K; ++k) v = (d == k) ? __builtin_amdgcn_readfirstlane(arr[k]) : v;
@@ -363,7 +366,8 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
       case 1: CAMPX_RENDER_WIDE(1); break;
       case 2: CAMPX_RENDER_WIDE(2); break;
       case 3: CAMPX_RENDER_WIDE(3); break;
-      default: CAMPX_RENDER_WIDE(4); break;
+      case 4: CAMPX_RENDER_WIDE(4); break;
+      default: CAMPX_RENDER_WIDE(8); break;    // five to eight things: the count at run time
     }
 #undef CAMPX_RENDER_WIDE
   } else {

@@ -1,6 +1,6 @@
 // k_wide.hip - the wide tier: games run from their STATE table ((state, action) -> state,
 // one row per reachable state), which has no board-size limit: boards above 128 cells (up to
-// 1 024), up to four things that show, hidden values behind them.
+// 1 024), up to eight things that show, hidden values behind them.
 //
 // The update pass is a walk through that table, which the HOST filled
 // (campx_amd/tabulate.py); the observation stream is k_render.hip's render kernel reading a
@@ -34,7 +34,7 @@ __host__ __device__ __forceinline__ uint32_t wide_pack(uint32_t next, uint32_t d
 // is read through L1 / L2 (games with thousands of states).
 template <bool kLds, bool kPerf>
 __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
-    WideParams wp, const uint2* __restrict__ g_entries, const uint2* __restrict__ g_cells,
+    WideParams wp, const uint2* __restrict__ g_entries, const u32x4* __restrict__ g_cells,
     const int8_t* __restrict__ g_perf, int32_t* __restrict__ state, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first) {
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
   __shared__ float discounts[16];
   const int S = wp.n_states, n_entries = S * CAMPX_N_ACTIONS, K = wp.n_dyn;
   const uint2* entries = g_entries;
-  const uint2* cells = g_cells;
+  const u32x4* cells = g_cells;
   const int8_t* perf_tab = g_perf;
   if (kLds) {
     uint2* l_entries = lds_tables;
-    uint2* l_cells = l_entries + n_entries;
+    u32x4* l_cells = reinterpret_cast<u32x4*>(l_entries + n_entries + (n_entries & 1));   // 16-byte aligned
     int8_t* l_perf = reinterpret_cast<int8_t*>(l_cells + S);
     for (int i = threadIdx.x; i < n_entries; i += kWideThreads) l_entries[i] = g_entries[i];
     for (int i = threadIdx.x; i < S; i += kWideThreads) l_cells[i] = g_cells[i];
@@ -90,12 +90,16 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
         now = e.y & 0xfffffu;
         const uint32_t done = (e.y >> 20) & 1u, dcode = (e.y >> 21) & 15u;
         from = done ? 0u : now;                      // the chain: state -> entry -> state
-        const uint2 c = cells[now];                  // where things show in the state reached
+        const u32x4 c = cells[now];                  // where things show in the state reached
         const int64_t at = (int64_t)(t0 + j) * P + env;
         trace[at] = (uint16_t)c.x;
         if (K > 1) trace[plane + at] = (uint16_t)(c.x >> 16);
         if (K > 2) trace[2 * plane + at] = (uint16_t)c.y;
         if (K > 3) trace[3 * plane + at] = (uint16_t)(c.y >> 16);
+        if (K > 4) trace[4 * plane + at] = (uint16_t)c.z;
+        if (K > 5) trace[5 * plane + at] = (uint16_t)(c.z >> 16);
+        if (K > 6) trace[6 * plane + at] = (uint16_t)c.w;
+        if (K > 7) trace[7 * plane + at] = (uint16_t)(c.w >> 16);
         if (out.reward) out.reward[at] = __uint_as_float(e.x);
         if (out.discount) out.discount[at] = __uint_as_float(discount_bits(discounts, dcode, done));
         if (out.done) out.done[at] = (uint8_t)done;
@@ -112,11 +116,11 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
 }
 
 // its_showtime(): state 0 and the trace rows of the first observation.
-__global__ void wide_reset_kernel(const uint2* __restrict__ cells, int32_t K, int32_t* __restrict__ state,
+__global__ void wide_reset_kernel(const u32x4* __restrict__ cells, int32_t K, int32_t* __restrict__ state,
                                   CampxState st, uint16_t* __restrict__ trace, int64_t P, int64_t B) {
   const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= B) return;
-  const uint2 c = cells[0];
+  const u32x4 c = cells[0];
   state[env] = 0;
   st.done[env] = 0;
   if (st.ret) st.ret[env] = 0.0f;
@@ -124,9 +128,13 @@ __global__ void wide_reset_kernel(const uint2* __restrict__ cells, int32_t K, in
   if (K > 1) trace[P + env] = (uint16_t)(c.x >> 16);
   if (K > 2) trace[2 * P + env] = (uint16_t)c.y;
   if (K > 3) trace[3 * P + env] = (uint16_t)(c.y >> 16);
+  if (K > 4) trace[4 * P + env] = (uint16_t)c.z;
+  if (K > 5) trace[5 * P + env] = (uint16_t)(c.z >> 16);
+  if (K > 6) trace[6 * P + env] = (uint16_t)c.w;
+  if (K > 7) trace[7 * P + env] = (uint16_t)(c.w >> 16);
 }
 
-// ---- the table blob: [entries uint2 x 5S][cells uint2 x S][perf int8 x 5S, padded to 16]
+// ---- the table blob: [entries uint2 x 5S, padded to 16][cells 8 x uint16 x S][perf int8 x 5S, padded to 16]
 // [rot_obs][rot_board]
 struct WideLayout {
   int64_t n_entries, cells_off, perf_off, rot_obs_off, rot_board_off, total;
@@ -137,8 +145,8 @@ WideLayout wide_layout(const CampxWideSpec& s) {
   WideLayout w;
   const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers, S = s.n_states;
   w.n_entries = S * CAMPX_N_ACTIONS;
-  w.cells_off = w.n_entries * (int64_t)sizeof(uint2);
-  w.perf_off = w.cells_off + S * (int64_t)sizeof(uint2);
+  w.cells_off = (w.n_entries * (int64_t)sizeof(uint2) + 15) & ~(int64_t)15;
+  w.perf_off = w.cells_off + S * (int64_t)sizeof(u32x4);
   w.rot_obs_off = (w.perf_off + w.n_entries + 15) & ~(int64_t)15;
   w.pitch_obs = (int)(((R + 15) & ~(int64_t)15) + 16);
   w.rot_board_off = w.rot_obs_off + 16ll * w.pitch_obs;
@@ -179,7 +187,7 @@ int32_t wide_validate_plain(const CampxWideSpec* s) {
   const int HW = s->rows * s->cols;
   if (HW < 16 || HW > CAMPX_WIDE_MAX_CELLS) return CAMPX_ESPEC;
   if (s->n_layers < 1 || s->n_layers > CAMPX_MAX_LAYERS) return CAMPX_ESPEC;
-  if (s->n_dyn < 1 || s->n_dyn > CAMPX_MAX_DYN) return CAMPX_ESPEC;
+  if (s->n_dyn < 1 || s->n_dyn > CAMPX_WIDE_MAX_DYN) return CAMPX_ESPEC;
   if (s->n_states < 1 || s->n_states > CAMPX_WIDE_MAX_STATES) return CAMPX_ESPEC;
   for (int d = 0; d < s->n_dyn; ++d)
     if (s->dyn_layer[d] < 0 || s->dyn_layer[d] >= s->n_layers) return CAMPX_ESPEC;
@@ -273,7 +281,7 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
   char* blob = static_cast<char*>(calloc(1, (size_t)w.total));
   if (!blob) return CAMPX_ENOMEM;
   uint2* entries = reinterpret_cast<uint2*>(blob);
-  uint2* cells = reinterpret_cast<uint2*>(blob + w.cells_off);
+  u32x4* cells = reinterpret_cast<u32x4*>(blob + w.cells_off);
   int8_t* perf = reinterpret_cast<int8_t*>(blob + w.perf_off);
   for (int64_t i = 0; i < (int64_t)S * CAMPX_N_ACTIONS; ++i) {
     uint32_t bits;
@@ -283,7 +291,7 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
     perf[i] = s->perf ? s->perf[i] : 0;
   }
   for (int st = 0; st < S; ++st) {
-    uint32_t e[4] = {0u, 0u, 0u, 0u};
+    uint32_t e[CAMPX_WIDE_MAX_DYN] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     for (int d = 0; d < K; ++d) {
       const uint32_t c = s->state_cells[(int64_t)st * K + d];
       const uint32_t cell = c & 0x3ffu;
@@ -291,6 +299,8 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
     }
     cells[st].x = e[0] | (e[1] << 16);
     cells[st].y = e[2] | (e[3] << 16);
+    cells[st].z = e[4] | (e[5] << 16);
+    cells[st].w = e[6] | (e[7] << 16);
   }
   // the scenery's row (layers by equality, campx/rendering.py:204-215) and its rotations
   int8_t* row = static_cast<int8_t*>(calloc(1, (size_t)R + HW));
@@ -324,7 +334,7 @@ int32_t campx_wide_reset_launch(const CampxWideSpec* s, const void* tables_dev, 
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const WideLayout w = wide_layout(*s);
-  const uint2* cells = reinterpret_cast<const uint2*>(static_cast<const char*>(tables_dev) + w.cells_off);
+  const u32x4* cells = reinterpret_cast<const u32x4*>(static_cast<const char*>(tables_dev) + w.cells_off);
   uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
   const int64_t P = row_pitch(out, B);
   hipLaunchKernelGGL(wide_reset_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, hs, cells,
@@ -354,10 +364,10 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   for (int i = 1; i < 16; ++i) wp.discounts[i] = s->discount_list[i];
   const char* blob = static_cast<const char*>(tables_dev);
   const uint2* entries = reinterpret_cast<const uint2*>(blob);
-  const uint2* cells = reinterpret_cast<const uint2*>(blob + w.cells_off);
+  const u32x4* cells = reinterpret_cast<const u32x4*>(blob + w.cells_off);
   const int8_t* perf = reinterpret_cast<const int8_t*>(blob + w.perf_off);
   int32_t* state = reinterpret_cast<int32_t*>(st.pos);
-  const size_t want = (size_t)w.n_entries * sizeof(uint2) + (size_t)s->n_states * sizeof(uint2) +
+  const size_t want = (size_t)(w.cells_off) + (size_t)s->n_states * sizeof(u32x4) +
                       (out.perf ? (size_t)w.n_entries : 0);
   // (CAMPX_WIDE_LDS_MAX=bytes, read at every launch: tests run small games through the
   // global-memory path that games with thousands of states take)

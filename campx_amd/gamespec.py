@@ -484,6 +484,7 @@ WIDE_MAX_CELLS = 1024
 
 
 WIDE_MAX_STATES = 1 << 20
+WIDE_MAX_DYN = 8
 
 
 class CampxWideSpec(ctypes.Structure):
@@ -493,7 +494,7 @@ class CampxWideSpec(ctypes.Structure):
               ('n_states', ctypes.c_int32), ('any_reward', ctypes.c_int32),
               ('has_perf', ctypes.c_int32), ('reserved0', ctypes.c_int32 * 3),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
-              ('dyn_layer', ctypes.c_int32 * MAX_DYN),
+              ('dyn_layer', ctypes.c_int32 * WIDE_MAX_DYN),
               ('discount_list', ctypes.c_float * 16),
               ('static_top_layer', ctypes.c_uint8 * WIDE_MAX_CELLS),
               # host arrays, read at validation / table-build time only

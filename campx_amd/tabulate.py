@@ -427,9 +427,9 @@ def _trace(engine, actions, max_plays):
     if z not in modes:
       modes.append(z)
   n_tracked = len(movers) + (1 if len(modes) > 1 else 0)
-  if not 1 <= len(movers) <= gamespec.MAX_DYN:
+  if not 1 <= len(movers) <= gamespec.WIDE_MAX_DYN:
     _fail('needs between 1 and {} moving things, found {} ({})'.format(
-        gamespec.MAX_DYN, len(movers), ''.join(movers) or 'nothing moves'))
+        gamespec.WIDE_MAX_DYN, len(movers), ''.join(movers) or 'nothing moves'))
   K = len(movers)
   # Two table forms come out of a tabulation.  The STATE table - one row per reachable
   # state, (state, action) -> state - always exists.  The DENSE table the one-cell tier's
@@ -438,8 +438,8 @@ def _trace(engine, actions, max_plays):
   if HW > gamespec.MAX_CELLS:
     dense_reason = 'the board has more than {} cells'.format(gamespec.MAX_CELLS)
   elif n_tracked > gamespec.MAX_DYN:
-    dense_reason = ('{} moving things plus the z-order in force are more than {} tracked '
-                    'values'.format(K, gamespec.MAX_DYN))
+    dense_reason = ('{} moving things{} are more than {} tracked values'.format(
+        K, ' plus the z-order in force' if len(modes) > 1 else '', gamespec.MAX_DYN))
   elif len(modes) > HW:
     dense_reason = '{} different z-orders are reached, more than rows*cols'.format(len(modes))
   elif HW ** n_tracked * N_ACTIONS > DENSE_MAX_ENTRIES:

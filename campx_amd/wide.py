@@ -5,7 +5,7 @@ entries, 7-bit cells - which stops at 128 cells and grows fast with K.  `tabulat
 enumerates the states a game can actually reach (by running its own `update()` classes,
 rule classes included), and the table over THOSE - one row per state, (state, action) ->
 state - has no such limits: PyColab-sized boards (16x16 mazes and up; campx/engine.py:31
-sets none), up to four things that show, and whatever hidden values stand behind them (the
+sets none), up to eight things that show, and whatever hidden values stand behind them (the
 z-order in force, keys picked up, doors opened).  The observation stream is the same render
 kernel, fed by a 16-bit trace (csrc/k_wide.hip, include/campx_hip.h CampxWideSpec).
 `WideGame` is what a batched `Engine` delegates to for games the one-cell tier cannot take;

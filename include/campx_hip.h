@@ -435,7 +435,7 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
  * reach, (state, action) -> state - instead of a table indexed by the things' cells.  That
  * form has no board-size limit and no (rows*cols)^K blow-up, so it takes what the one-cell
  * tier cannot: boards ABOVE 128 cells (PyColab-sized mazes: 16x16, 20x20, 32x32 ...;
- * campx/engine.py:31 sets no limit), up to four things that show, any number of hidden
+ * campx/engine.py:31 sets no limit), up to eight things that show, any number of hidden
  * values behind them (the z-order in force after Plot.change_z_order, keys that were
  * picked up, doors that opened).  The caller enumerates the states (campx_amd/tabulate.py runs
  * the game's own update() classes breadth-first from its_showtime()); state 0 is the
@@ -448,18 +448,19 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
  */
 #define CAMPX_WIDE_MAX_CELLS 1024        /* rows * cols; rows, cols <= 127 */
 #define CAMPX_WIDE_MAX_STATES (1 << 20)
+#define CAMPX_WIDE_MAX_DYN 8             /* things that move / come and go */
 
 typedef struct CampxWideSpec {
   uint32_t magic, version;
   int32_t rows, cols;
   int32_t n_layers;
-  int32_t n_dyn;                   /* K: things that move / come and go, 1 .. CAMPX_MAX_DYN */
+  int32_t n_dyn;                   /* K: things that move / come and go, 1 .. CAMPX_WIDE_MAX_DYN */
   int32_t n_states;                /* S: reachable states, 1 .. CAMPX_WIDE_MAX_STATES */
   int32_t any_reward;
   int32_t has_perf;                /* `perf` below means something */
   int32_t reserved0[3];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
-  int32_t dyn_layer[CAMPX_MAX_DYN];        /* layer thing d paints */
+  int32_t dyn_layer[CAMPX_WIDE_MAX_DYN];   /* layer thing d paints */
   float discount_list[16];                 /* as CampxSpec.discount_list */
   uint8_t static_top_layer[CAMPX_WIDE_MAX_CELLS];  /* front-most scenery layer per cell */
   /* HOST arrays, read by campx_wide_spec_validate(full) / campx_wide_tables_build() only -

@@ -93,7 +93,8 @@ def test_wide_spec_of_the_maze_validates_and_says_what_the_table_says():
   assert arrays['state_cells'][0, 0] == 17                  # state 0: 'A' at (1, 1), showing
   n_bytes = _hip.lib.campx_wide_tables_bytes(ctypes.byref(spec))
   R = 6 * 256
-  assert n_bytes == (S * 5 * 8 + S * 8 + S * 5 + 15) // 16 * 16 + 16 * (R + 16) + 16 * (256 + 16)
+  tables = (S * 5 * 8 + 15) // 16 * 16 + S * 16                # entries, eight trace entries per state
+  assert n_bytes == (tables + S * 5 + 15) // 16 * 16 + 16 * (R + 16) + 16 * (256 + 16)
   # the table says what the art says: walls stop, '*' tiles pay +1 on entering
   art = maze.maze_art(16, 16)
   where = {int(c): s for s, c in enumerate(traced.st_cells[:, 0])}
@@ -356,6 +357,85 @@ def test_a_small_game_with_too_many_tracked_values_for_the_cell_tables_takes_the
   out = game.rollout(torch.from_numpy(actions), want_board=True)
   want = _check_rollout(game, f.traced, actions, out, walker)
   assert (want['reward'] > 1).sum() > B // 4           # coins collected
+
+
+def _coin_field(**where):
+  """Six things that show: a walker and five coins that vanish when collected (each +2; the
+  fifth ends the episode).  6x9 board - small, but six tracked values are two more than the
+  cell-indexed tables take."""
+  art = ['#########',
+         '#A 1 2  #',
+         '#  ##   #',
+         '# 3  4 5#',
+         '#########']
+
+  class Coin(traced_games.things.Drape):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is None:
+        return
+      if (self.curtain * all_things['A'].curtain).sum():
+        self.curtain.zero_()
+        the_plot.add_reward(2.0)
+        if not any(all_things[c].curtain.sum() for c in '12345' if c != self.character):
+          the_plot.terminate_episode()
+
+  return traced_games.ascii_art_to_game(
+      art, what_lies_beneath=' ',
+      drapes={'A': traced_games.Walker, '#': traced_games.things.FixedDrape,
+              '1': Coin, '2': Coin, '3': Coin, '4': Coin, '5': Coin},
+      z_order='12345A#', update_schedule='A12345#', **where)
+
+
+def test_six_things_that_show_tabulate_to_a_state_table():
+  traced = tabulate.trace(_coin_field())
+  assert traced.movers == ['A', '1', '2', '3', '4', '5']
+  assert 'more than 4 tracked values' in traced.dense_reason
+  spec, arrays = tabulate.to_wide_spec(traced)
+  assert spec.n_dyn == 6 and arrays['state_cells'].shape == (traced.n_states, 6)
+  from campx_amd import _hip
+  assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
+  assert traced.st_done.sum() > 0                     # the last coin ends the episode
+
+
+@pytest.mark.gpu
+def test_six_things_that_show_through_the_wide_kernels():
+  """Five to eight things take the render kernel's run-time-K instantiation and uint4 trace
+  entries per state: against the state walker and, for two environments, the classes
+  themselves on the generic tier."""
+  from oracle.table_replay import StateWalker
+  B, T = 20001, 160
+  game = _coin_field(batch=B, device='cuda')
+  first, _, _ = game.its_showtime()
+  f = game.fused
+  assert f.n_dyn == 6
+  walker = StateWalker(f.traced, B)
+  board0, layered0 = walker.render(walker.state[:3])
+  assert np.array_equal(first.board[:3].cpu().numpy(), board0)
+  rng = np.random.RandomState(21)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  # environment 0 collects everything: right along the top, down the right side, back left
+  actions[:, 0] = np.resize([1] * 6 + [3] * 2 + [0] * 6 + [2] * 2, T)
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  want = _check_rollout(game, f.traced, actions, out, walker)
+  assert out['trace'].shape == (6, T, B)
+  assert (want['reward'] == 2.0).sum() > B and want['done'][:, 0].sum() >= 1
+  onehot = tabulate.default_actions()
+  for env in (0, B - 1):
+    g = _coin_field()
+    g.its_showtime()
+    for t in range(T):
+      if g.game_over:
+        g = _coin_field()
+        g.its_showtime()
+      obs, reward, _ = g.play(onehot[int(actions[t, env])])
+      assert np.array_equal(out['board'][t, env].cpu().numpy(), obs.board.numpy().astype(np.int8)), (env, t)
+      got = np.float32(np.nan) if reward is None else np.float32(float(reward))
+      assert _same(out['reward'][t, env].cpu().numpy(), got)
+  f.reset()
+  for t in range(12):
+    obs, reward, discount = game.play(torch.from_numpy(actions[t]))
+    assert torch.equal(obs.layered_board, out['obs'][t]), t
+    assert torch.equal(obs.board, out['board'][t]), t
 
 
 @pytest.mark.gpu
