@@ -2,7 +2,7 @@
 
 Seeded, so failures reproduce.  Covers what the fixed games do not: arbitrary wall /
 coin / hover-tile / box placements, boards of every aspect ratio up to 128 cells, one- to
-four-mover games (with and without their state tables), batches that are not multiples of 4 / 16 / 64 / 256 and episode
+four-mover games (with and without their state tables), random one-mover games on boards of 130 to 560 cells (the wide tier), batches that are not multiples of 4 / 16 / 64 / 256 and episode
 lengths that are not multiples of the kernels' 16-frame groups and 64-frame chunks."""
 
 import os
@@ -164,3 +164,82 @@ def test_device_built_tables_equal_tables_from_running_the_python_rules(seed):
     assert np.array_equal((e >> 15) & 1, traced.visible[1, idx]), rows
     assert np.array_equal((e >> 16) & 1, traced.done[idx]), rows
     assert _same(rewards[(e >> 19) & 0xff], traced.reward[idx]), rows
+
+
+def random_big_game(rng):
+  """A random one-mover rule game on a board ABOVE 128 cells (the wide tier): random walls
+  (the agent wraps round the edges where there is none), coin tiles, directional hover
+  tiles, maybe a goal - the rule classes of `random_game`, no boxes."""
+  H, W = int(rng.randint(9, 28)), int(rng.randint(9, 28))
+  while not 130 <= H * W <= 560:
+    H, W = int(rng.randint(9, 28)), int(rng.randint(9, 28))
+  art = np.full((H, W), ' ', dtype='<U1')
+  art[rng.rand(H, W) < rng.choice([0.0, 0.1, 0.25])] = '#'
+  free = list(zip(*np.where(art == ' ')))
+  rng.shuffle(free)
+  art[free.pop()] = 'A'
+  coins = rng.rand() < 0.6
+  hover = rng.rand() < 0.5
+  for _ in range(int(rng.randint(3, 30)) if coins else 0):
+    art[free.pop()] = '*'
+  for _ in range(int(rng.randint(2, 12)) if hover else 0):
+    art[free.pop()] = '>'
+  goal = rng.rand() < 0.5
+  if goal:
+    art[free.pop()] = 'G'
+  rows = [''.join(r) for r in art]
+  step_reward = None if hover else float(rng.choice([-1, 0, 0.5]))
+  dctns = [float(x) for x in rng.choice([0, 1, 2, 3], size=5)]
+  base = float(rng.choice([-0.25, 0, 0.5]))
+
+  def build(batch=None, device=None):
+    present = set(''.join(rows))
+    drapes = {'A': Partial(rules.AgentDrape, blocking_chars='#' if '#' in present else '',
+                           step_reward=step_reward, reward_chars='*' if '*' in present else '')}
+    for ch in '#*':
+      if ch in present:
+        drapes[ch] = rules.FixedDrape
+    if '>' in present:
+      drapes['>'] = Partial(rules.DirectionalHoverRewardDrape, dctns=torch.tensor(dctns),
+                            base_reward=base)
+    if 'G' in present:
+      drapes['G'] = Partial(rules.GoalDrape, agent_char='A', step_reward=-1, goal_reward=7)
+    back = ''.join(c for c in '*>G' if c in drapes)
+    return ascii_art_to_game(rows, what_lies_beneath=' ', drapes=drapes,
+                             update_schedule=[['A'] + [c for c in '>G*#' if c in drapes]],
+                             z_order=back + 'A' + ('#' if '#' in drapes else ''),
+                             batch=batch, device=device)
+  return build, rows
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_FUZZ_BIG_SEEDS', '6'))))
+def test_random_big_boards(seed):
+  """The wide tier (state table tabulated on the host from the rule classes' Python) against
+  the C oracle (the rules restated in C): every byte of every frame, two launches and play()."""
+  from campx_amd import wide
+  rng = np.random.RandomState(5000 + seed)
+  build, rows = random_big_game(rng)
+  batch = int(rng.choice([1, 7, 48, 257, 512]))
+  game = build(batch=batch, device='cuda')
+  first, _, _ = game.its_showtime()
+  assert isinstance(game.fused, wide.WideGame)
+  og = cpu.OracleGame.from_description(gamespec.describe(build()))
+  obs0, board0 = og.first_frame()
+  assert np.array_equal(first.layered_board[batch - 1].cpu().numpy(), obs0), rows
+  for launch, T in enumerate([int(rng.randint(1, 40)), int(rng.randint(1, 150))]):
+    actions = rng.randint(0, 5, size=(T, batch)).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), want_board=True)
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'board', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (rows, batch, T, k)
+    if out['reward'] is None:
+      assert np.isnan(ref['reward']).all()
+    else:
+      assert _same(out['reward'].cpu().numpy(), ref['reward']), (rows, batch, T)
+  acts = rng.randint(0, 5, size=(5, batch)).astype(np.int8)
+  ref = og.rollout(acts)
+  for t in range(5):
+    obs, reward, discount = game.play(torch.from_numpy(acts[t]))
+    assert _same(obs.layered_board.cpu().numpy(), ref['obs'][t]), (rows, batch, t)
+    assert _same(obs.board.cpu().numpy(), ref['board'][t]), (rows, batch, t)
+    assert _same(discount.cpu().numpy(), ref['discount'][t])
