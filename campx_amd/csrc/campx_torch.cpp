@@ -382,8 +382,9 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
     return v;
   };
   const bool keep = frames && obs.dim() == 5;
-  if (keep || !frames) want(obs, "obs", at::kChar, dev, shape({L, H, W}));
-  else want(obs, "obs", at::kChar, dev, {B, L, H, W});
+  out.obs_format = obs_format_of(obs);       // int8, or f16 / bf16 for a policy network
+  if (keep || !frames) want(obs, "obs", obs.scalar_type(), dev, shape({L, H, W}));
+  else want(obs, "obs", obs.scalar_type(), dev, {B, L, H, W});
   out.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
   out.obs_t_stride = keep ? B * L * H * W : 0;
   if (board.has_value()) {

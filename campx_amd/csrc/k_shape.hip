@@ -56,7 +56,9 @@ __device__ __forceinline__ uint32_t swar_add_wrap(uint32_t r, uint32_t d, uint32
 #define CAMPX_SHAPE_MINWAVES 1
 #endif
 
-template <bool kBoard>
+// kFmt: CAMPX_OBS_INT8, or f16 / bf16 observations (0.0 / 1.0) for a policy network - the
+// eight cells a lane expands per layer plane then go out as one 16-byte store of eight halves.
+template <bool kBoard, int kFmt = 0>
 __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void shape_rollout_kernel(
     ShapeParams sp, const CampxShapeSpec* __restrict__ spec, CampxState st,
     int8_t* __restrict__ backdrop_state, const int8_t* __restrict__ actions, CampxOutputs out,
@@ -177,6 +179,21 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
         const uint32_t b0 = *reinterpret_cast<const uint32_t*>(board + at);
         const uint32_t b1 = *reinterpret_cast<const uint32_t*>(board + at + 4);
         int8_t* plane = obs_dst;   // uniform: the stores take it as their scalar base
+        // one layer's eight cells (bytes 0 / 1 in e0, e1) to memory, in the observation format
+        auto put = [&](uint32_t e0, uint32_t e1) {
+          if (kFmt == 0) {
+            *reinterpret_cast<uint2*>(plane + at) = make_uint2(e0, e1);
+          } else {
+            constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+            u32x4 v;
+            v.x = ((e0 & 0xffu) | ((e0 << 8) & 0x00ff0000u)) * kOne;
+            v.y = (((e0 >> 16) & 0xffu) | ((e0 >> 8) & 0x00ff0000u)) * kOne;
+            v.z = ((e1 & 0xffu) | ((e1 << 8) & 0x00ff0000u)) * kOne;
+            v.w = (((e1 >> 16) & 0xffu) | ((e1 >> 8) & 0x00ff0000u)) * kOne;
+            *reinterpret_cast<u32x4*>(plane + 2 * (int64_t)at) = v;   // `plane` counts bytes
+          }
+        };
+        constexpr int kElem = kFmt ? 2 : 1;
         if (L <= 8) {
           // v_perm_b32 as a byte-wise table lookup: a board byte b (a layer index 0..7)
           // selects byte b of the 64-bit constant 1 << 8 l, which is (b == l) - one
@@ -185,8 +202,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
           for (int l = 0; l < L; ++l) {
             const uint32_t e0 = __builtin_amdgcn_perm(hi, lo, b0);
             const uint32_t e1 = __builtin_amdgcn_perm(hi, lo, b1);
-            *reinterpret_cast<uint2*>(plane + at) = make_uint2(e0, e1);
-            plane += HW;
+            put(e0, e1);
+            plane += kElem * HW;
             hi = (l == 3) ? 1u : hi << 8;
             lo = lo << 8;                // (0 after the fourth layer)
           }
@@ -196,8 +213,8 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
             // bytes < 0x80: 0x80 - (b ^ l) has bit 7 set iff they are equal
             const uint32_t e0 = ((0x80808080u - (b0 ^ lc)) & 0x80808080u) >> 7;
             const uint32_t e1 = ((0x80808080u - (b1 ^ lc)) & 0x80808080u) >> 7;
-            *reinterpret_cast<uint2*>(plane + at) = make_uint2(e0, e1);
-            plane += HW;
+            put(e0, e1);
+            plane += kElem * HW;
             lc += 0x01010101u;
           }
         }
@@ -213,7 +230,13 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     } else {
       for (int i = lane; i < HW; i += kWave) {
         const int b = board[i];
-        for (int l = 0; l < L; ++l) obs_dst[(int64_t)l * HW + i] = (int8_t)(b == l);
+        for (int l = 0; l < L; ++l) {
+          if (kFmt == 0)
+            obs_dst[(int64_t)l * HW + i] = (int8_t)(b == l);
+          else
+            reinterpret_cast<uint16_t*>(obs_dst)[(int64_t)l * HW + i] =
+                (uint16_t)(b == l ? ((kFmt == 1) ? 0x3C00u : 0x3F80u) : 0u);
+        }
         if (kBoard) board_dst[i] = (int8_t)reinterpret_cast<const uint8_t*>(lds_char)[b];
       }
     }
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(kShapeWaves * kWave, CAMPX_SHAPE_MINWAVES) void sha
     // NaN for the frame and leaves the running return alone)
     if (valid && (sp.act[a_raw].flags & 2u)) ret += reward;
     const int64_t slot = showtime ? 0 : t;
-    paint_and_emit(out.obs + slot * out.obs_t_stride + env * LHW,
+    paint_and_emit(out.obs + (slot * out.obs_t_stride + env * LHW) * (kFmt ? 2 : 1),
                    kBoard ? out.board + slot * out.board_t_stride + env * HW : nullptr,
                    !last_only || t == T - 1);
     if (!showtime) {
@@ -699,7 +722,7 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
   if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
-  if (out.obs_format != CAMPX_OBS_INT8 || out.perf) return CAMPX_EINVAL;
+  if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16 || out.perf) return CAMPX_EINVAL;
   if (out.trace && (reinterpret_cast<uintptr_t>(out.trace) & 3)) return CAMPX_EINVAL;
   if ((reinterpret_cast<uintptr_t>(out.obs) | reinterpret_cast<uintptr_t>(out.board) |
        reinterpret_cast<uintptr_t>(backdrop_state)) & 3)
@@ -712,7 +735,9 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
   const dim3 grid((unsigned)((B + kShapeWaves - 1) / kShapeWaves)), block(kShapeWaves * kWave);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const ShapeParams sp = make_shape_params(*spec_host);
-  if (shape_split_ok(*spec_host, out, B, T, emit_first)) {
+  // (the 16-bit formats: the serial kernel only; its 16-byte stores of eight halves are 8-byte
+  // aligned when rows*cols is 4 modulo 8 - legal on this stack, tools/probes/unaligned_probe.hip)
+  if (out.obs_format == CAMPX_OBS_INT8 && shape_split_ok(*spec_host, out, B, T, emit_first)) {
     // games without trails, every frame kept: update pass -> shape trace -> frame-major render
     uint32_t* trace = reinterpret_cast<uint32_t*>(out.trace);
     hipLaunchKernelGGL(shape_update_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, sp, st,
@@ -725,12 +750,17 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CAMPX_OK : hip_failed(e);
   }
-  if (out.board)
-    hipLaunchKernelGGL(shape_rollout_kernel<true>, grid, block, 0, s, sp, spec_dev, st,
-                       backdrop_state, actions, out, B, T, reset_first, emit_first);
-  else
-    hipLaunchKernelGGL(shape_rollout_kernel<false>, grid, block, 0, s, sp, spec_dev, st,
-                       backdrop_state, actions, out, B, T, reset_first, emit_first);
+#define CAMPX_SHAPE_LAUNCH(BOARD, FMT)                                                         \
+  hipLaunchKernelGGL((shape_rollout_kernel<BOARD, FMT>), grid, block, 0, s, sp, spec_dev, st,  \
+                     backdrop_state, actions, out, B, T, reset_first, emit_first)
+  if (out.obs_format == CAMPX_OBS_F16) {
+    if (out.board) CAMPX_SHAPE_LAUNCH(true, 1); else CAMPX_SHAPE_LAUNCH(false, 1);
+  } else if (out.obs_format == CAMPX_OBS_BF16) {
+    if (out.board) CAMPX_SHAPE_LAUNCH(true, 2); else CAMPX_SHAPE_LAUNCH(false, 2);
+  } else {
+    if (out.board) CAMPX_SHAPE_LAUNCH(true, 0); else CAMPX_SHAPE_LAUNCH(false, 0);
+  }
+#undef CAMPX_SHAPE_LAUNCH
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }

@@ -120,13 +120,24 @@ class ShapeGame(object):
 
   def showtime(self):
     self._op(self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self.backdrop,
-             None, self._obs, self._board, None, None, None, None, None, True, True)
+             None, self._obs, self._board, None, None, None, None, None, True, True)   # (in play()'s format)
     self.frame = 0
     return self._observation_cache, None, 1.0
 
   def reset(self):
     """A new episode for every environment (see `FusedGame.reset`)."""
     return self.showtime()
+
+  def set_play_obs_dtype(self, dtype):
+    """Make `play()` return `layered_board` in `dtype` (torch.int8, float16 or bfloat16): the
+    policy-network input of examples/reinforce.py:149, written by the kernel itself."""
+    if dtype not in (torch.int8, torch.float16, torch.bfloat16):
+      raise ValueError('obs dtype must be torch.int8, float16 or bfloat16')
+    if dtype != self._obs.dtype:
+      self._obs = self._obs.to(dtype)        # keep the frame currently shown
+      layers = {ch: self._obs[:, i] for i, ch in enumerate(self.chars)}
+      self._observation_cache = Observation(board=self._board, layers=layers,
+                                            layered_board=self._obs)
 
   def play(self, actions):
     ids = self._ids(actions, (self.batch,))
@@ -143,13 +154,15 @@ class ShapeGame(object):
 
   def rollout_buffers(self, T, keep_obs=True, want_board=False, obs_dtype=torch.int8,
                       share=None):
-    if obs_dtype != torch.int8:
-      raise ValueError('the shape tier writes int8 observations only')
+    if obs_dtype not in (torch.int8, torch.float16, torch.bfloat16):
+      raise ValueError('obs_dtype must be torch.int8, float16 or bfloat16')
+    if obs_dtype != torch.int8 and not keep_obs:
+      raise ValueError('16-bit observations need keep_obs=True')
     B, L, H, W, dev = self.batch, self.n_layers, self.rows, self.cols, self.device
     if share is not None:
       obs, board = share['obs'], share['board']
     else:
-      obs = (torch.empty((T, B, L, H, W), dtype=torch.int8, device=dev) if keep_obs
+      obs = (torch.empty((T, B, L, H, W), dtype=obs_dtype, device=dev) if keep_obs
              else self._obs)
       board = None
       if want_board:
@@ -158,7 +171,8 @@ class ShapeGame(object):
     # Games without trails: the scratch of the two-kernel path (the things' offsets per
     # frame, 16 bytes per environment-frame); the library ignores it for other games / calls
     trace = (torch.empty((4, T, B), dtype=torch.int32, device=dev)
-             if SPLIT_TRAIL_FREE and self.trail_free and keep_obs and T > 0 else None)
+             if SPLIT_TRAIL_FREE and self.trail_free and keep_obs and T > 0
+             and obs_dtype == torch.int8 else None)
     return dict(obs=obs, board=board,
                 reward=(torch.empty((T, B), dtype=torch.float32, device=dev)
                         if self.any_reward else None),

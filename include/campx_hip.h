@@ -416,7 +416,7 @@ int32_t campx_shape_spec_validate(const CampxShapeSpec* spec_host);
  * offset of each thing from its art position, state.done, state.ret as for
  * campx_rollout_launch, and `backdrop_state` [B, rows*cols] int8 layer per cell (the
  * per-environment Backdrop; may be NULL when no visible sprite precedes the first
- * drape).  Outputs: out.obs (int8 only), out.board, out.reward, out.discount, out.done,
+ * drape).  Outputs: out.obs (any out.obs_format), out.board, out.reward, out.discount, out.done,
  * out.bad_count / bad_flag; frames at base + t * stride as for campx_rollout_launch.
  * Action ids outside 0..4 move nothing, end nothing and are counted as bad.
  * out.trace (optional, 4-byte aligned, 16 * T * B bytes): scratch for the things' offsets per

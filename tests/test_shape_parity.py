@@ -268,3 +268,30 @@ def test_boards_at_the_tier_limit(H, W):
     ref = og.rollout(actions, reset_first=(launch == 0))
     for k in ('obs', 'board', 'reward', 'discount', 'done'):
       assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('name,B', [('hello_world', 777), ('shape_zoo2', 64), ('shape_zoo4', 1000)])
+def test_sixteen_bit_observations(name, B, dtype):
+  """f16 / bf16 layered boards straight from the shape kernel (rollouts and play()): the
+  int8 frames, converted."""
+  build = SHAPE_GAMES[name]
+  game = build(batch=B, device='cuda')
+  game.its_showtime()
+  rng = np.random.RandomState(31)
+  actions = torch.from_numpy(rng.randint(0, 4, size=(25, B)).astype(np.int8))
+  ref = game.rollout(actions, reset_first=True, want_board=True)
+  out = game.rollout(actions, reset_first=True, want_board=True, obs_dtype=dtype)
+  assert out['obs'].dtype == dtype
+  assert torch.equal(out['obs'].to(torch.int8), ref['obs']) and torch.equal(out['board'], ref['board'])
+  assert set(out['obs'].unique().tolist()) == {0.0, 1.0}
+  game.fused.reset()
+  game.fused.set_play_obs_dtype(dtype)
+  first, _, _ = game.fused.reset()
+  assert first.layered_board.dtype == dtype
+  for t in range(6):
+    obs, _, _ = game.play(actions[t])
+    assert obs.layered_board.dtype == dtype
+    assert torch.equal(obs.layered_board.to(torch.int8), ref['obs'][t]), t
+    assert torch.equal(obs.layers[game.fused.chars[0]], obs.layered_board[:, 0])
