@@ -18,7 +18,12 @@ fused tier  (`batch=B`, or a process-wide default: `set_default_batch`, CAMPX_BA
     * ANY OTHER Python classes - the unmodified `examples/boat_race.py` classes,
       the Demo notebooks' classes, a user's own - are tabulated on the host by
       running their `update()` on the generic tier over every reachable state
-      (`tabulate`), and the same table + render kernels run the result.
+      (`tabulate`), and the same table + render kernels run the result;
+    * games the cell-indexed tables cannot take - boards above 128 cells (up to 1 024),
+      more than four tracked values (up to eight things that show) - run from their
+      STATE table, one row per reachable state (`wide`, csrc/k_wide.hip);
+    * Hello-World-style games of rigidly moving multi-cell things take the shape tier
+      (`shapes`, csrc/k_shape.hip).
     There is no CPU fallback: without the HIP library or a GPU this tier raises.
 
 Error behaviour kept from the reference: `RuntimeError` for `play()` before
