@@ -351,6 +351,10 @@ def _trace(engine, actions, max_plays):
   if probe.game_over:
     _fail('the episode is over after its_showtime()')
 
+  # (the rule library's own classes keep nothing outside their curtains - the Plot entries they
+  # make are the renderer's live layers, campx/rendering.py:209 - so their games skip the
+  # second-history replays, which are half of a tabulation's frames)
+  check_histories = not gamespec.is_rule_game(engine)
   things0, backdrop0, z0 = _image(probe)
   # state bookkeeping
   index_of = {(things0, z0): 0}
@@ -399,7 +403,7 @@ def _trace(engine, actions, max_plays):
         if engines[t] is None:
           engines[t] = eng
           queue.append(t)
-        elif t not in second:    # (every (s, a) is played once: this is another history)
+        elif check_histories and t not in second:    # (every (s, a) is played once: another history)
           second[t] = eng
 
   # ---- the curtains are the whole state: replay every action over a second history
