@@ -673,3 +673,40 @@ def test_wide_op_passes_opcheck_and_is_capturable_in_a_hip_graph():
   assert torch.equal(game_g.fused._obs, game_e.fused._obs)
   assert torch.equal(game_g.fused.state, game_e.fused.state)
   assert torch.equal(game_g.fused.ret, game_e.fused.ret)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(traced_games.GAMES))
+def test_the_two_table_forms_of_a_game_give_the_same_frames(name, monkeypatch):
+  """Every test-local game through BOTH tiers: its cell-indexed tables on the one-cell tier's
+  kernels (FusedGame) and its state table on the wide tier's (WideGame; forced by allowing no
+  dense table at all) - the same observations, boards, scalars, frame by frame."""
+  from campx_amd import fused, wide
+  build = traced_games.GAMES[name]
+  B, T = 3001, 90
+  rng = np.random.RandomState(len(name))
+  actions = torch.from_numpy(rng.randint(0, 5, size=(T, B)).astype(np.int8))
+  tabulate._CACHE.clear()
+  game_a = build(batch=B, device='cuda')
+  first_a, _, _ = game_a.its_showtime()
+  assert type(game_a.fused) is fused.FusedGame
+  monkeypatch.setattr(tabulate, 'DENSE_MAX_ENTRIES', 0)
+  tabulate._CACHE.clear()
+  game_b = build(batch=B, device='cuda')
+  first_b, _, _ = game_b.its_showtime()
+  tabulate._CACHE.clear()
+  assert type(game_b.fused) is wide.WideGame
+  assert torch.equal(first_a.layered_board, first_b.layered_board)
+  assert torch.equal(first_a.board, first_b.board)
+  a = game_a.rollout(actions, want_board=True)
+  b = game_b.rollout(actions, want_board=True)
+  for k in ('obs', 'board', 'done'):
+    assert torch.equal(a[k], b[k]), k
+  for k in ('reward', 'discount'):
+    assert _same(a[k].cpu().numpy(), b[k].cpu().numpy()), k
+  assert _same(game_a.fused.ret.cpu().numpy(), game_b.fused.ret.cpu().numpy())
+  for t in range(6):
+    oa, ra, da = game_a.play(actions[t])
+    ob, rb, db = game_b.play(actions[t])
+    assert torch.equal(oa.layered_board, ob.layered_board) and torch.equal(oa.board, ob.board), t
+    assert _same(ra.cpu().numpy(), rb.cpu().numpy()) and _same(da.cpu().numpy(), db.cpu().numpy())
