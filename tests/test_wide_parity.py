@@ -710,3 +710,54 @@ def test_the_two_table_forms_of_a_game_give_the_same_frames(name, monkeypatch):
     ob, rb, db = game_b.play(actions[t])
     assert torch.equal(oa.layered_board, ob.layered_board) and torch.equal(oa.board, ob.board), t
     assert _same(ra.cpu().numpy(), rb.cpu().numpy()) and _same(da.cpu().numpy(), db.cpu().numpy())
+
+
+def _maze_with_quadrants(**where):
+  """The 16x16 maze with a hidden performance: progress round the four quadrants, clockwise
+  (`Engine.set_hidden_performance`, the boat race's measure - examples/boat_race.py:117-151)."""
+  game = maze.build(16, 16, **where)
+  q = torch.zeros((4, 16, 16), dtype=torch.uint8)
+  q[0, :8, :8] = 1
+  q[1, :8, 8:] = 1
+  q[2, 8:, 8:] = 1
+  q[3, 8:, :8] = 1
+  game.set_hidden_performance('A', list(q))
+  return game, q.numpy()
+
+
+def test_hidden_performance_on_a_wide_board_is_in_the_state_table():
+  game, q = _maze_with_quadrants()
+  traced = tabulate.trace(game)
+  assert traced.has_perf and set(np.unique(traced.st_perf).tolist()) == {-1, 0, 1}
+  cls = (q * np.arange(1, 5)[:, None, None]).sum(0).reshape(-1)        # quadrant 1..4 per cell
+  for s in range(traced.n_states):
+    for a in range(5):
+      if not traced.st_reached[s, a]:
+        continue
+      x, y = cls[traced.st_cells[s, 0]], cls[traced.st_cells[traced.st_next[s, a], 0]]
+      want = 1 if y == x % 4 + 1 else (-1 if x == y % 4 + 1 else 0)
+      assert traced.st_perf[s, a] == want, (s, a)
+
+
+@pytest.mark.gpu
+def test_hidden_performance_on_a_wide_board_through_the_kernels():
+  from oracle.table_replay import StateWalker
+  B, T = 9000, 110
+  game, _ = _maze_with_quadrants(batch=B, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  assert f.has_perf
+  walker = StateWalker(f.traced, B)
+  rng = np.random.RandomState(8)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  actions[:, 0] = np.resize([1] * 9 + [3] * 9 + [0] * 9 + [2] * 9, T)     # round the quadrants
+  out = game.rollout(torch.from_numpy(actions))
+  want = walker.rollout(actions)
+  assert out['perf'] is not None
+  assert np.array_equal(out['perf'].cpu().numpy(), want['perf'])
+  assert (want['perf'] == 1).sum() > 0 and (want['perf'] == -1).sum() > 0
+  assert np.array_equal(out['obs'][-1].cpu().numpy(), walker.render(want['state'][-1])[1])
+  f.reset()
+  for t in range(10):
+    game.play(torch.from_numpy(actions[t]))
+    assert np.array_equal(f.perf.cpu().numpy(), want['perf'][t]), t
