@@ -57,8 +57,6 @@ class WideGame(fused.FusedGame):
     if B * row >= (1 << 32) - 65536:
       raise ValueError('wide tier: a frame of {} environments x {} bytes does not fit 32-bit '
                        'offsets; use a smaller batch'.format(B, row))
-    self._spec_host = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
-                                       dtype=torch.uint8)
     n = int(_hip.lib.campx_wide_tables_bytes(ctypes.byref(self.spec)))
     self._tables = torch.empty((n,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -66,6 +64,12 @@ class WideGame(fused.FusedGame):
           ctypes.byref(self.spec), ctypes.c_void_p(self._tables.data_ptr()),
           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
           'campx_wide_tables_build')
+    # The launches read the spec's plain fields only; the blob they get carries no pointers
+    # to the host arrays (which stay alive in self._arrays anyway).
+    for name in ('state_cells', 'next_state', 'reward', 'done', 'perf'):
+      setattr(self.spec, name, None)
+    self._spec_host = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
+                                       dtype=torch.uint8)
     self.state = torch.zeros((B,), dtype=torch.int32, device=dev)   # index into traced.st_*
     self.pos = None                   # (positions: see the trace)
     self.done = torch.zeros((B,), dtype=torch.uint8, device=dev)
