@@ -116,6 +116,120 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
   report_bad_actions(out, bad);
 }
 
+// ---------------------------------------------------------------------------
+// Engine.play() in ONE launch (T == 1, int8 observations, rows that are whole 16-byte chunks).
+// A wave owns n consecutive environments - state, scalars and the n rows of the frame - so
+// nothing it reads is written by another wave (the update + render pair needs the trace in
+// between for exactly that reason).  Lanes 0 .. n-1 walk the table for one environment each
+// and write its scalars; every lane then builds 16-byte chunks of the wave's span of the
+// frame in registers: the scenery's chunk (rotation 0 of the render tables: rows start on
+// 16-byte boundaries) with, per thing that shows, one byte set and one cleared.  No LDS image,
+// no second kernel: 12.9 -> ~7 us per call at small batches, where the three launches of the
+// two-kernel path were what a call cost.
+struct WideStepParams {
+  int32_t n_states, n_dyn, cells, R, n_env;     // n_env: environments per wave
+  uint32_t inv_r;                                // ceil(2^32 / R): x / R for x < 2^16 * ...
+  int32_t dyn_off[CAMPX_WIDE_MAX_DYN];           // byte offset of thing d's layer inside a row
+  int32_t dyn_char[CAMPX_WIDE_MAX_DYN];
+  float discounts[16];
+};
+
+constexpr int kStepEnvMax = 16;    // environments per wave at most
+
+// One byte of a 16-byte chunk (chunk starts at byte `base` of the row; `at` is the byte's
+// offset in the row): set to `val` when it falls inside.
+__device__ __forceinline__ void poke(u32x4& v, int base, int at, uint32_t val) {
+  const uint32_t rel = (uint32_t)(at - base);
+  if (rel < 16u) {
+    const uint32_t sh = (rel & 3u) * 8u, m = ~(0xffu << sh), b = val << sh;
+    const uint32_t w = rel >> 2;
+    v.x = w == 0u ? (v.x & m) | b : v.x;
+    v.y = w == 1u ? (v.y & m) | b : v.y;
+    v.z = w == 2u ? (v.z & m) | b : v.z;
+    v.w = w == 3u ? (v.w & m) | b : v.w;
+  }
+}
+
+template <bool kBoard, bool kPerf>
+__global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
+    WideStepParams sp, const uint2* __restrict__ entries, const u32x4* __restrict__ cells,
+    const int8_t* __restrict__ perf_tab, const int8_t* __restrict__ rot_obs,
+    const int8_t* __restrict__ rot_board, int32_t* __restrict__ state, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B) {
+  __shared__ u32x4 shown[kWideThreads / kWave][kStepEnvMax];   // per wave: its environments' trace entries
+  // (readfirstlane: the wave index is uniform, and saying so keeps the span's base address
+  // in scalar registers for the stores)
+  const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = sp.n_env, K = sp.n_dyn;
+  const int64_t env0 = ((int64_t)blockIdx.x * (kWideThreads / kWave) + wave) * n;
+  if (env0 >= B) return;                          // (wave-uniform; no workgroup barrier below)
+  const int n_here = (B - env0 < n) ? (int)(B - env0) : n;
+  // ---- update pass: lane i < n_here owns environment env0 + i
+  int bad = 0;
+  if (lane < n_here) {
+    const int64_t env = env0 + lane;
+    uint32_t now = (uint32_t)state[env];
+    now = now < (uint32_t)sp.n_states ? now : 0u;
+    const int over = st.done[env];
+    const uint32_t a = (uint8_t)actions[env];
+    bad = a > 4u;
+    const uint32_t idx = (over ? 0u : now) * CAMPX_N_ACTIONS + (a > 4u ? 4u : a);
+    const uint2 e = entries[idx];
+    now = e.y & 0xfffffu;
+    const uint32_t done = (e.y >> 20) & 1u, dcode = (e.y >> 21) & 15u;
+    const u32x4 c = cells[now];
+    shown[wave][lane] = c;
+    state[env] = (int32_t)now;
+    st.done[env] = (uint8_t)done;
+    if (st.ret) st.ret[env] = (over ? 0.0f : st.ret[env]) + real_reward(__uint_as_float(e.x));
+    if (out.reward) out.reward[env] = __uint_as_float(e.x);
+    if (out.discount)
+      out.discount[env] = __uint_as_float(dcode ? __float_as_uint(sp.discounts[dcode])
+                                                : (done ? 0u : 0x3f800000u));
+    if (out.done) out.done[env] = (uint8_t)done;
+    if (kPerf && out.perf) out.perf[env] = perf_tab[idx];
+    uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
+    const int64_t P = row_pitch(out, B);
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d)
+      if (d < K) trace[(int64_t)d * P + env] = (uint16_t)(w[d >> 1] >> (16 * (d & 1)));
+  }
+  report_bad_actions(out, bad);
+  // (the wave's own LDS writes are visible to its own later reads: one wave, in order)
+
+  // ---- render: the wave's span of the frame, 16 bytes per lane per round
+  auto rows = [&](int8_t* dst, const int8_t* rot, int R, bool board) {
+    const int span = n_here * R;                  // bytes, a multiple of 16
+    for (int byte = lane * 16; byte < span; byte += kWave * 16) {
+      const int el = (int)(((uint64_t)(uint32_t)byte * sp.inv_r) >> 32);   // byte / R (R = sp.R)
+      const int e_local = board ? byte / R : el;
+      const int off = byte - e_local * R;
+      u32x4 v = *reinterpret_cast<const u32x4*>(rot + off);
+      const u32x4 c = shown[wave][e_local];
+      const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d) {
+        if (d < K) {
+          const uint32_t t = (w[d >> 1] >> (16 * (d & 1))) & 0xffffu;
+          if (t >> 15) {
+            const int cell = (int)(t & 0x3ffu);
+            if (board) {
+              poke(v, off, cell, (uint32_t)(uint8_t)sp.dyn_char[d]);
+            } else {
+              poke(v, off, (int)((t >> 10) & 15u) * sp.cells + cell, 0u);
+              poke(v, off, sp.dyn_off[d] + cell, 1u);
+            }
+          }
+        }
+      }
+      store16_streaming(reinterpret_cast<u32x4*>(dst + byte), v);
+    }
+  };
+  rows(out.obs + env0 * sp.R, rot_obs, sp.R, false);
+  if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true);
+}
+
 // its_showtime(): state 0 and the trace rows of the first observation.
 __global__ void wide_reset_kernel(const u32x4* __restrict__ cells, int32_t K, int32_t* __restrict__ state,
                                   CampxState st, uint16_t* __restrict__ trace, int64_t P, int64_t B) {
@@ -357,6 +471,62 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   if (!actions) return CAMPX_EINVAL;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const WideLayout w = wide_layout(*s);
+  {
+    // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
+    const int HW = s->rows * s->cols, R = HW * s->n_layers;
+    static const bool no_step = [] {
+      const char* v = getenv("CAMPX_NO_WIDE_STEP");
+      return v && v[0] == '1';
+    }();
+    if (T == 1 && !reset_first && out.obs_format == CAMPX_OBS_INT8 && (R & 15) == 0 &&
+        (!out.board || (HW & 15) == 0) && !no_step &&
+        (int64_t)kStepEnvMax * R < (1ll << 24)) {
+      WideStepParams sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.n_states = s->n_states;
+      sp.n_dyn = s->n_dyn;
+      sp.cells = HW;
+      sp.R = R;
+      // environments per wave: a span of about 2 KiB, whole KiB when the row allows
+      int n_env = 1;
+      if (R < 2048) {
+        n_env = 2048 / R;
+        for (int c = 1; c <= kStepEnvMax; ++c)
+          if (((int64_t)c * R) % 1024 == 0) {
+            n_env = c;
+            break;
+          }
+        n_env = n_env > kStepEnvMax ? kStepEnvMax : (n_env < 1 ? 1 : n_env);
+      }
+      sp.n_env = n_env;
+      sp.inv_r = (uint32_t)(((1ull << 32) + R - 1) / R);
+      for (int d = 0; d < s->n_dyn; ++d) {
+        sp.dyn_off[d] = s->dyn_layer[d] * HW;
+        sp.dyn_char[d] = s->layer_char[s->dyn_layer[d]];
+      }
+      sp.discounts[0] = 1.0f;
+      for (int i = 1; i < 16; ++i) sp.discounts[i] = s->discount_list[i];
+      const char* blob = static_cast<const char*>(tables_dev);
+      const uint2* entries = reinterpret_cast<const uint2*>(blob);
+      const u32x4* cells = reinterpret_cast<const u32x4*>(blob + w.cells_off);
+      const int8_t* perf = reinterpret_cast<const int8_t*>(blob + w.perf_off);
+      const int8_t* rot_obs = reinterpret_cast<const int8_t*>(blob + w.rot_obs_off);
+      const int8_t* rot_board = reinterpret_cast<const int8_t*>(blob + w.rot_board_off);
+      const int64_t n_waves = (B + n_env - 1) / n_env;
+      const dim3 grid((unsigned)((n_waves + kWideThreads / kWave - 1) / (kWideThreads / kWave)));
+      int32_t* state = reinterpret_cast<int32_t*>(st.pos);
+#define CAMPX_WIDE_STEP(BOARD, PERF)                                                            \
+  hipLaunchKernelGGL((wide_step_kernel<BOARD, PERF>), grid, dim3(kWideThreads), 0, hs, sp,      \
+                     entries, cells, perf, rot_obs, rot_board, state, st, actions, out, B)
+      if (out.board && out.perf) CAMPX_WIDE_STEP(true, true);
+      else if (out.board) CAMPX_WIDE_STEP(true, false);
+      else if (out.perf) CAMPX_WIDE_STEP(false, true);
+      else CAMPX_WIDE_STEP(false, false);
+#undef CAMPX_WIDE_STEP
+      const hipError_t e = hipGetLastError();
+      return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+    }
+  }
   WideParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.n_states = s->n_states;
