@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Engine.play() in ONE launch (T == 1, int8 observations, rows that are whole 16-byte chunks).
+// Engine.play() in ONE launch (T == 1, rows that are whole 16-byte chunks).
 // A wave owns n consecutive environments - state, scalars and the n rows of the frame - so
 // nothing it reads is written by another wave (the update + render pair needs the trace in
 // between for exactly that reason).  Lanes 0 .. n-1 walk the table for one environment each
@@ -150,7 +150,9 @@ __device__ __forceinline__ void poke(u32x4& v, int base, int at, uint32_t val) {
   }
 }
 
-template <bool kBoard, bool kPerf>
+// kFmt: CAMPX_OBS_INT8, or f16 / bf16 observations (a chunk's sixteen cells leave as two
+// 16-byte stores of eight halves each); the flat board is always int8.
+template <bool kBoard, bool kPerf, int kFmt>
 __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
     WideStepParams sp, const uint2* __restrict__ entries, const u32x4* __restrict__ cells,
     const int8_t* __restrict__ perf_tab, const int8_t* __restrict__ rot_obs,
@@ -223,10 +225,25 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
           }
         }
       }
-      store16_streaming(reinterpret_cast<u32x4*>(dst + byte), v);
+      if (kFmt == 0 || board) {
+        store16_streaming(reinterpret_cast<u32x4*>(dst + byte), v);
+      } else {
+        constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+        u32x4 h[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          h[i].x = ((b[2 * i] & 0xffu) | ((b[2 * i] << 8) & 0x00ff0000u)) * kOne;
+          h[i].y = (((b[2 * i] >> 16) & 0xffu) | ((b[2 * i] >> 8) & 0x00ff0000u)) * kOne;
+          h[i].z = ((b[2 * i + 1] & 0xffu) | ((b[2 * i + 1] << 8) & 0x00ff0000u)) * kOne;
+          h[i].w = (((b[2 * i + 1] >> 16) & 0xffu) | ((b[2 * i + 1] >> 8) & 0x00ff0000u)) * kOne;
+        }
+        store16_streaming(reinterpret_cast<u32x4*>(dst + 2 * (int64_t)byte), h[0]);
+        store16_streaming(reinterpret_cast<u32x4*>(dst + 2 * (int64_t)byte + 16), h[1]);
+      }
     }
   };
-  rows(out.obs + env0 * sp.R, rot_obs, sp.R, false);
+  rows(out.obs + env0 * sp.R * (kFmt ? 2 : 1), rot_obs, sp.R, false);
   if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true);
 }
 
@@ -478,7 +495,7 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
       const char* v = getenv("CAMPX_NO_WIDE_STEP");
       return v && v[0] == '1';
     }();
-    if (T == 1 && !reset_first && out.obs_format == CAMPX_OBS_INT8 && (R & 15) == 0 &&
+    if (T == 1 && !reset_first && (R & 15) == 0 &&
         (!out.board || (HW & 15) == 0) && !no_step &&
         (int64_t)kStepEnvMax * R < (1ll << 24)) {
       WideStepParams sp;
@@ -515,14 +532,21 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
       const int64_t n_waves = (B + n_env - 1) / n_env;
       const dim3 grid((unsigned)((n_waves + kWideThreads / kWave - 1) / (kWideThreads / kWave)));
       int32_t* state = reinterpret_cast<int32_t*>(st.pos);
-#define CAMPX_WIDE_STEP(BOARD, PERF)                                                            \
-  hipLaunchKernelGGL((wide_step_kernel<BOARD, PERF>), grid, dim3(kWideThreads), 0, hs, sp,      \
+#define CAMPX_WIDE_STEP2(BOARD, PERF, FMT)                                                       \
+  hipLaunchKernelGGL((wide_step_kernel<BOARD, PERF, FMT>), grid, dim3(kWideThreads), 0, hs, sp,  \
                      entries, cells, perf, rot_obs, rot_board, state, st, actions, out, B)
+#define CAMPX_WIDE_STEP(BOARD, PERF)                                      \
+  do {                                                                    \
+    if (out.obs_format == CAMPX_OBS_F16) CAMPX_WIDE_STEP2(BOARD, PERF, 1);      \
+    else if (out.obs_format == CAMPX_OBS_BF16) CAMPX_WIDE_STEP2(BOARD, PERF, 2); \
+    else CAMPX_WIDE_STEP2(BOARD, PERF, 0);                                \
+  } while (0)
       if (out.board && out.perf) CAMPX_WIDE_STEP(true, true);
       else if (out.board) CAMPX_WIDE_STEP(true, false);
       else if (out.perf) CAMPX_WIDE_STEP(false, true);
       else CAMPX_WIDE_STEP(false, false);
 #undef CAMPX_WIDE_STEP
+#undef CAMPX_WIDE_STEP2
       const hipError_t e = hipGetLastError();
       return e == hipSuccess ? CAMPX_OK : hip_failed(e);
     }
