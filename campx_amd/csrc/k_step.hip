@@ -285,13 +285,16 @@ __global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
 }
 
 // The same for two-mover games with a pair table (campx_pair_table_build): one more
-// dependent round trip for the reward list and the scenery layers the movers cover.
+// dependent round trip for the table entry (the reward list and the scenery layers the movers
+// cover come along in the first).
 template <bool kBoard>
 __global__ __launch_bounds__(kWave) void step_pair_kernel(
     MoverParams mp, int32_t layer1, int32_t row1, int32_t col1,
     const CampxSpec* __restrict__ spec, CampxState st, const int8_t* __restrict__ actions,
     CampxOutputs out, int64_t B, int32_t reset_first) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  __shared__ __attribute__((aligned(16))) float lds_rewards[256];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_top[CAMPX_MAX_CELLS];
   const int lane = threadIdx.x;
   const int W = mp.cols, HW = mp.rows * mp.cols, LHW = mp.n_layers * HW;
   const int64_t env0 = (int64_t)blockIdx.x * kWave;
@@ -320,6 +323,11 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
   int k_obs = (lane * 16) % LHW, k_board = (lane * 16) % HW;
   fill_issue<kStepObsLoads>(v_obs, spec->rot_obs, LHW, k_obs);
   if (kBoard) fill_issue<kStepBoardLoads>(v_board, spec->rot_board, HW, k_board);
+  // The reward list (256 floats) and the scenery's top layer per cell (128 bytes) ride in
+  // this first round trip - four floats and two cells per lane, parked in LDS - so that what
+  // the table entry points at is an LDS read, not a third trip to memory.
+  const u32x4 rw4 = reinterpret_cast<const u32x4*>(g_rewards)[lane];
+  const uint16_t top2 = reinterpret_cast<const uint16_t*>(spec->static_top_layer)[lane];
 
   const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
   a = ((unsigned)a > 4u) ? 4 : a;
@@ -329,6 +337,8 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
     ret = 0.0f;
   }
   const uint32_t e = g_entries[pair_index(c0, c1, HW) + (uint32_t)a];
+  reinterpret_cast<u32x4*>(lds_rewards)[lane] = rw4;
+  reinterpret_cast<uint16_t*>(lds_top)[lane] = top2;
   fill_land<kStepObsLoads>(v_obs, obs_img, kWave * LHW, 0, lane);
   fill_rest<kStepObsLoads>(obs_img, kWave * LHW, LHW, spec->rot_obs, k_obs, lane);
   if (kBoard) {
@@ -337,17 +347,17 @@ __global__ __launch_bounds__(kWave) void step_pair_kernel(
   }
   c0 = e & 0x7fu;
   c1 = (e >> 7) & 0x7fu;
-  const float reward = g_rewards[(e >> 19) & 0xffu];
+  const float reward = lds_rewards[(e >> 19) & 0xffu];
   const int done = (int)((e >> 16) & 1u);
   ret += real_reward(reward);
   int8_t* my_obs = obs_img + lane * LHW;
   if ((e >> 14) & 1u) {
-    my_obs[(int)spec->static_top_layer[c0] * HW + (int)c0] = 0;
+    my_obs[(int)lds_top[c0] * HW + (int)c0] = 0;
     my_obs[mp.dyn_layer * HW + (int)c0] = 1;
     if (kBoard) board_img[lane * HW + (int)c0] = (int8_t)spec->layer_char[mp.dyn_layer];
   }
   if ((e >> 15) & 1u) {
-    my_obs[(int)spec->static_top_layer[c1] * HW + (int)c1] = 0;
+    my_obs[(int)lds_top[c1] * HW + (int)c1] = 0;
     my_obs[layer1 * HW + (int)c1] = 1;
     if (kBoard) board_img[lane * HW + (int)c1] = (int8_t)spec->layer_char[layer1];
   }
@@ -377,6 +387,8 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
     TupleParams tp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t reset_first) {
   extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  __shared__ __attribute__((aligned(16))) float lds_rewards[256];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_top[CAMPX_MAX_CELLS];
   const int lane = threadIdx.x;
   const int W = tp.cols, HW = tp.rows * tp.cols, LHW = tp.n_layers * HW;
   const int64_t env0 = (int64_t)blockIdx.x * kWave;
@@ -410,6 +422,9 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   int k_obs = (lane * 16) % LHW, k_board = (lane * 16) % HW;
   fill_issue<kStepObsLoads>(v_obs, spec->rot_obs, LHW, k_obs);
   if (kBoard) fill_issue<kStepBoardLoads>(v_board, spec->rot_board, HW, k_board);
+  // (reward list and scenery top layers in the first round trip, as in step_pair_kernel)
+  const u32x4 rw4 = reinterpret_cast<const u32x4*>(g_rewards)[lane];
+  const uint16_t top2 = reinterpret_cast<const uint16_t*>(spec->static_top_layer)[lane];
 
   const int bad = (live && (unsigned)a > 4u) ? 1 : 0;
   a = ((unsigned)a > 4u) ? 4 : a;
@@ -418,6 +433,8 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
     ret = 0.0f;
   }
   const uint64_t e = g_entries[tuple_index<K>(cells, (uint32_t)HW) + (uint32_t)a];
+  reinterpret_cast<u32x4*>(lds_rewards)[lane] = rw4;
+  reinterpret_cast<uint16_t*>(lds_top)[lane] = top2;
   fill_land<kStepObsLoads>(v_obs, obs_img, kWave * LHW, 0, lane);
   fill_rest<kStepObsLoads>(obs_img, kWave * LHW, LHW, spec->rot_obs, k_obs, lane);
   if (kBoard) {
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
     fill_rest<kStepBoardLoads>(board_img, kWave * HW, HW, spec->rot_board, k_board, lane);
   }
   const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
-  const float reward = g_rewards[(hi >> 3) & 0xffu];
+  const float reward = lds_rewards[(hi >> 3) & 0xffu];
   const int done = (int)(hi & 1u);
   ret += real_reward(reward);
   int8_t* my_obs = obs_img + lane * LHW;
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   for (int k = 0; k < K; ++k) {
     const int c = (int)((lo >> (7 * k)) & 0x7fu);
     if ((lo >> (28 + k)) & 1u) {   // it is the character its cell shows
-      my_obs[(int)spec->static_top_layer[c] * HW + c] = 0;
+      my_obs[(int)lds_top[c] * HW + c] = 0;
       my_obs[tp.dyn_layer[k] * HW + c] = 1;
       if (kBoard) board_img[lane * HW + c] = (int8_t)spec->layer_char[tp.dyn_layer[k]];
     }
