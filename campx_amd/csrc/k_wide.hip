@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
 // and write its scalars; every lane then builds 16-byte chunks of the wave's span of the
 // frame in registers: the scenery's chunk (rotation 0 of the render tables: rows start on
 // 16-byte boundaries) with, per thing that shows, one byte set and one cleared.  No LDS image,
-// no second kernel: 12.9 -> ~7 us per call at small batches, where the three launches of the
+// no second kernel: 13-17 -> 6.5-7 us per call at small batches, where the three launches of the
 // two-kernel path were what a call cost.
 struct WideStepParams {
   int32_t n_states, n_dyn, cells, R, n_env;     // n_env: environments per wave
