@@ -7,11 +7,13 @@
 // 16-bit trace.  A frame row is L*rows*cols bytes - 1 536 for a 16x16 board with six
 // characters - against 2 bytes of trace per thing, 4 of reward and 1 of action, so the update
 // kernel here is the plain one (a lane per environment, the table in LDS, the frame's
-// scalars stored as they come): it moves 1-2 % of the launch's bytes and takes under 3 % of
-// its time (41 us of 1 446 at 16x16, B = 65 536).  What bounds the tier is the render kernel's
+// scalars stored as they come): it moves 1-2 % of the launch's bytes and takes 1.4 % of
+// its time (20 us of 1 430 at 16x16, B = 65 536).  What bounds the tier is the render kernel's
 // write stream (7.2 TB/s).
 
 #include "campx_common.hip.h"
+
+#include <type_traits>
 
 namespace campx_impl {
 
@@ -21,6 +23,7 @@ constexpr size_t kWideLdsMax = 144 * 1024;   // tables up to this size are stage
 
 struct WideParams {
   int32_t n_states, n_dyn;
+  int32_t has_dcodes;          // some entry of the table carries a discount code
   float discounts[16];
 };
 
@@ -75,16 +78,29 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
   uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
   const int64_t P = row_pitch(out, B), plane = (int64_t)T * P;
   int bad = 0;
-  for (int t0 = 0; t0 < T; t0 += kWideAhead) {
-    uint32_t a[kWideAhead];
+  int64_t at = env;                                // element (frame, env) of the [T, P] streams
+  // The actions of a chunk of frames are loaded ONE CHUNK AHEAD, before the previous chunk's
+  // stores are issued: vector memory operations complete in order, so a load issued after a
+  // chunk's forty stores would wait for all of them (that was 28 us per 100 frames at
+  // B = 4 096; this way the wait only covers what was issued before the loads).
+  auto fetch = [&](int t0, uint32_t (&dst)[kWideAhead]) {
 #pragma unroll
     for (int j = 0; j < kWideAhead; ++j) {
       const int t = t0 + j < T ? t0 + j : T - 1;   // (clamped: a load that is ignored)
-      a[j] = (uint8_t)actions[(int64_t)t * B + env];
+      dst[j] = (uint8_t)actions[(int64_t)t * B + env];
     }
+  };
+  uint32_t a_next[kWideAhead];
+  fetch(0, a_next);
+  // One chunk of frames.  `kPlain`: a whole chunk of a game with one thing, no discount codes
+  // and the usual output streams - no test inside, so the frames' table reads overlap (with
+  // the tests every frame made three dependent LDS round trips and ten scalar branches:
+  // 275 ns per frame, 28 us per 100 frames at B = 4 096).
+  auto chunk = [&](auto plain_tag, int t0, const uint32_t (&a)[kWideAhead]) {
+    constexpr bool kPlain = decltype(plain_tag)::value;
 #pragma unroll
     for (int j = 0; j < kWideAhead; ++j) {
-      if (t0 + j < T) {
+      if (kPlain || t0 + j < T) {
         bad += a[j] > 4u;
         const uint32_t idx = from * CAMPX_N_ACTIONS + (a[j] > 4u ? 4u : a[j]);
         const uint2 e = entries[idx];
@@ -92,23 +108,42 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
         const uint32_t done = (e.y >> 20) & 1u, dcode = (e.y >> 21) & 15u;
         from = done ? 0u : now;                      // the chain: state -> entry -> state
         const u32x4 c = cells[now];                  // where things show in the state reached
-        const int64_t at = (int64_t)(t0 + j) * P + env;
         trace[at] = (uint16_t)c.x;
-        if (K > 1) trace[plane + at] = (uint16_t)(c.x >> 16);
-        if (K > 2) trace[2 * plane + at] = (uint16_t)c.y;
-        if (K > 3) trace[3 * plane + at] = (uint16_t)(c.y >> 16);
-        if (K > 4) trace[4 * plane + at] = (uint16_t)c.z;
-        if (K > 5) trace[5 * plane + at] = (uint16_t)(c.z >> 16);
-        if (K > 6) trace[6 * plane + at] = (uint16_t)c.w;
-        if (K > 7) trace[7 * plane + at] = (uint16_t)(c.w >> 16);
-        if (out.reward) out.reward[at] = __uint_as_float(e.x);
-        if (out.discount) out.discount[at] = __uint_as_float(discount_bits(discounts, dcode, done));
-        if (out.done) out.done[at] = (uint8_t)done;
+        if (!kPlain && K > 1) {
+          uint16_t* tk = trace + at + plane;
+          tk[0] = (uint16_t)(c.x >> 16);
+          if (K > 2) tk[plane] = (uint16_t)c.y;
+          if (K > 3) tk[2 * plane] = (uint16_t)(c.y >> 16);
+          if (K > 4) tk[3 * plane] = (uint16_t)c.z;
+          if (K > 5) tk[4 * plane] = (uint16_t)(c.z >> 16);
+          if (K > 6) tk[5 * plane] = (uint16_t)c.w;
+          if (K > 7) tk[6 * plane] = (uint16_t)(c.w >> 16);
+        }
+        if (kPlain) {
+          out.reward[at] = __uint_as_float(e.x);
+          out.discount[at] = done ? 0.0f : 1.0f;
+          out.done[at] = (uint8_t)done;
+        } else {
+          if (out.reward) out.reward[at] = __uint_as_float(e.x);
+          if (out.discount) out.discount[at] = __uint_as_float(discount_bits(discounts, dcode, done));
+          if (out.done) out.done[at] = (uint8_t)done;
+        }
         if (kPerf && out.perf) out.perf[at] = perf_tab[idx];
         ret = (over ? 0.0f : ret) + real_reward(__uint_as_float(e.x));
         over = (int)done;
+        at += P;
       }
     }
+  };
+  const bool plain = K == 1 && !wp.has_dcodes && out.reward && out.discount && out.done &&
+                     (!kPerf || out.perf);
+  for (int t0 = 0; t0 < T; t0 += kWideAhead) {
+    uint32_t a[kWideAhead];
+#pragma unroll
+    for (int j = 0; j < kWideAhead; ++j) a[j] = a_next[j];
+    if (t0 + kWideAhead < T) fetch(t0 + kWideAhead, a_next);
+    if (plain && t0 + kWideAhead <= T) chunk(std::true_type{}, t0, a);
+    else chunk(std::false_type{}, t0, a);
   }
   state[env] = (int32_t)now;
   st.done[env] = (uint8_t)over;
@@ -323,7 +358,7 @@ int32_t wide_validate_plain(const CampxWideSpec* s) {
   if (s->n_states < 1 || s->n_states > CAMPX_WIDE_MAX_STATES) return CAMPX_ESPEC;
   for (int d = 0; d < s->n_dyn; ++d)
     if (s->dyn_layer[d] < 0 || s->dyn_layer[d] >= s->n_layers) return CAMPX_ESPEC;
-  if ((s->has_perf | s->any_reward) & ~1) return CAMPX_ESPEC;
+  if ((s->has_perf | s->any_reward | s->any_dcode) & ~1) return CAMPX_ESPEC;
   for (int i = 0; i < HW; ++i)
     if (s->static_top_layer[i] >= s->n_layers) return CAMPX_ESPEC;
   return CAMPX_OK;
@@ -393,7 +428,7 @@ int32_t campx_wide_spec_validate(const CampxWideSpec* s) {
       if (s->next_state[i] < 0 || s->next_state[i] >= S) return CAMPX_ESPEC;
   if (s->done)
     for (int64_t i = 0; i < (int64_t)S * CAMPX_N_ACTIONS; ++i)
-      if (s->done[i] & 0x0eu) return CAMPX_ESPEC;
+      if ((s->done[i] & 0x0eu) || ((s->done[i] >> 4) && !s->any_dcode)) return CAMPX_ESPEC;
   return CAMPX_OK;
 }
 
@@ -557,6 +592,7 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   wp.n_dyn = s->n_dyn;
   wp.discounts[0] = 1.0f;
   for (int i = 1; i < 16; ++i) wp.discounts[i] = s->discount_list[i];
+  wp.has_dcodes = s->any_dcode;
   const char* blob = static_cast<const char*>(tables_dev);
   const uint2* entries = reinterpret_cast<const uint2*>(blob);
   const u32x4* cells = reinterpret_cast<const u32x4*>(blob + w.cells_off);

@@ -492,7 +492,8 @@ class CampxWideSpec(ctypes.Structure):
               ('rows', ctypes.c_int32), ('cols', ctypes.c_int32),
               ('n_layers', ctypes.c_int32), ('n_dyn', ctypes.c_int32),
               ('n_states', ctypes.c_int32), ('any_reward', ctypes.c_int32),
-              ('has_perf', ctypes.c_int32), ('reserved0', ctypes.c_int32 * 3),
+              ('has_perf', ctypes.c_int32), ('any_dcode', ctypes.c_int32),
+              ('reserved0', ctypes.c_int32 * 2),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * WIDE_MAX_DYN),
               ('discount_list', ctypes.c_float * 16),

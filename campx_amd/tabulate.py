@@ -299,7 +299,7 @@ def fingerprint(engine, actions):
 
 
 _CACHE = collections.OrderedDict()
-CACHE_SIZE = 16
+CACHE_SIZE = 8
 
 
 def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
@@ -752,6 +752,7 @@ def to_wide_spec(game):
   spec.rows, spec.cols, spec.n_layers = H, W, len(game.chars)
   spec.n_dyn, spec.n_states = K, S
   spec.any_reward, spec.has_perf = int(game.any_reward), int(game.has_perf)
+  spec.any_dcode = int((game.st_dcode != 0).any())
   for i, ch in enumerate(game.chars):
     spec.layer_char[i] = ord(ch)
   for d, ch in enumerate(game.movers):

@@ -458,7 +458,9 @@ typedef struct CampxWideSpec {
   int32_t n_states;                /* S: reachable states, 1 .. CAMPX_WIDE_MAX_STATES */
   int32_t any_reward;
   int32_t has_perf;                /* `perf` below means something */
-  int32_t reserved0[3];
+  int32_t any_dcode;               /* 1: some entry of `done` carries a discount code (0: the
+                                      update kernel need not look the discount up) */
+  int32_t reserved0[2];
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_WIDE_MAX_DYN];   /* layer thing d paints */
   float discount_list[16];                 /* as CampxSpec.discount_list */
