@@ -646,22 +646,27 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
           uint32_t act[kG];
   #pragma unroll
           for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+          // (whole groups run without the per-frame test, like update_table_kernel's: no scalar
+          // branch between frames, so a frame's reward lookup overlaps the next frame's chain read)
+          auto frames = [&](auto full_tag) {
+            constexpr bool kFull = decltype(full_tag)::value;
   #pragma unroll
-          for (int j = 0; j < kG; ++j) {
-            if (j < n) {
-              if (over) {  // rebuilt from the art before its next action
-                c0 = init0;
-                c1 = init1;
+            for (int j = 0; j < kG; ++j) {
+              if (kFull || j < n) {
+                c0 = over ? init0 : c0;   // rebuilt from the art before its next action
+                c1 = over ? init1 : c1;
+                const uint32_t idx = pair_index(c0, c1, HW) + act[j];
+                const uint32_t e = kLdsEntries ? lds_entries[idx] : g_entries[idx];   // the chain
+                c0 = e & 0x7fu;
+                c1 = (e >> 7) & 0x7fu;
+                ring[g & 1][j][le] = e;
+                ret = (over ? 0.0f : ret) + real_reward(reward_list[(e >> 19) & 0xffu]);
+                over = (int)((e >> 16) & 1u);
               }
-              const uint32_t idx = pair_index(c0, c1, HW) + act[j];
-              const uint32_t e = kLdsEntries ? lds_entries[idx] : g_entries[idx];   // the chain
-              c0 = e & 0x7fu;
-              c1 = (e >> 7) & 0x7fu;
-              ring[g & 1][j][le] = e;
-              ret = (over ? 0.0f : ret) + real_reward(reward_list[(e >> 19) & 0xffu]);
-              over = (int)((e >> 16) & 1u);
             }
-          }
+          };
+          if (n == kG) frames(std::true_type{});
+          else frames(std::false_type{});
         }
       
       __syncthreads();
@@ -866,17 +871,22 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
         uint32_t act[kG];
 #pragma unroll
         for (int j = 0; j < kG; ++j) act[j] = staged_action<E>(chunk, t0 & (kChunk - 1), j, le);
+        auto frames = [&](auto full_tag) {      // (whole groups: no per-frame test, see above)
+          constexpr bool kFull = decltype(full_tag)::value;
 #pragma unroll
-        for (int j = 0; j < kG; ++j) {
-          if (j < n) {
-            cells = over ? init : cells;  // rebuilt from the art before its next action
-            const uint64_t e = g_entries[tuple_index<K>(cells, HW) + act[j]];  // the chain
-            cells = (uint32_t)e & 0x0fffffffu;
-            ring[g & 1][j][le] = e;
-            ret = (over ? 0.0f : ret) + real_reward(reward_list[(uint32_t)(e >> 35) & 0xffu]);
-            over = (int)((e >> 32) & 1u);
+          for (int j = 0; j < kG; ++j) {
+            if (kFull || j < n) {
+              cells = over ? init : cells;  // rebuilt from the art before its next action
+              const uint64_t e = g_entries[tuple_index<K>(cells, HW) + act[j]];  // the chain
+              cells = (uint32_t)e & 0x0fffffffu;
+              ring[g & 1][j][le] = e;
+              ret = (over ? 0.0f : ret) + real_reward(reward_list[(uint32_t)(e >> 35) & 0xffu]);
+              over = (int)((e >> 32) & 1u);
+            }
           }
-        }
+        };
+        if (n == kG) frames(std::true_type{});
+        else frames(std::false_type{});
       }
       __syncthreads();
     }
