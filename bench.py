@@ -88,6 +88,9 @@ def parse_args(argv=None):
   p.add_argument('--frames', type=int, default=100,
                  help='Engine.play() frames per launch (episode length)')
   p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--no-group', action='store_true',
+                 help='N = 1 only, for A/B measurements: no process group (the episode-return '
+                      'log is copied locally instead of all-gathered)')
   p.add_argument('--no-extras', action='store_true',
                  help='skip play()-mode and the wall_world / sokoban side measurements')
   p.add_argument('--pipeline', action='store_true',
@@ -270,8 +273,10 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     # rollout kernels ever runs on the rollout's stream.  (Without a process group -
     # RCCL could not be initialised on a one-GPU run - the "gather" is a local copy.)
     from campx_amd.distributed import ReturnLog
-    # (never rarer than once per timed region, so that a short run still exercises it)
-    gather_every = max(1, min(gather_every, steps))
+    # (never rarer than once per timed region, so that a short run still exercises the gather -
+    # and then two thirds into it, with launches still to come as in a long run, not at its
+    # very end, where the whole all-gather would sit exposed in front of the closing fence)
+    gather_every = max(1, min(gather_every, (2 * steps + 2) // 3))
     log = ReturnLog(B, gather_every, device, dist)
 
   def one_step(i):
@@ -457,7 +462,7 @@ def run_rank(args):
   # so that the N = 1 line times the same protocol as the ranks of an N > 1 run (the driver
   # computes scaling efficiency from those lines).
   dist, group_note = None, None
-  if world > 1 or args.force_dist or standin is None:
+  if (world > 1 or args.force_dist or standin is None) and not (args.no_group and world == 1):
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', str(_free_port()))

@@ -92,7 +92,7 @@ def test_one_rank_times_the_same_protocol_as_the_ranks_of_a_sharded_run():
             '--gather-every', '64', '--standin', 'bench_standin:make'])
   assert r.returncode == 0, r.stderr[-3000:]
   line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-  assert line['n_gpus'] == 1 and line['config']['gather_every'] == 4      # clamped to --steps
+  assert line['n_gpus'] == 1 and line['config']['gather_every'] == 3      # clamped: two thirds of --steps
   assert line['config']['gathered_log_matches_local'] is True
   assert line['config']['per_rank_ms_per_step'] == [line['ms_per_step']]
 

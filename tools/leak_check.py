@@ -2,7 +2,7 @@
 import os, sys, gc
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch
-from campx_amd.games import sokoban, boat_race, hello_world
+from campx_amd.games import sokoban, boat_race, hello_world, maze
 def rss():
   with open('/proc/self/status') as f:
     for l in f:
@@ -13,7 +13,9 @@ for i in range(12):
   a = torch.randint(0, 5, (20, 4096), dtype=torch.int8, device='cuda')
   g.rollout(a); g.play(a[0])
   h = hello_world.build(batch=512, device='cuda'); h.its_showtime(); h.play(a[0, :512].clamp(0, 3))
-  del g, h, a
+  w = maze.build(16, 16, batch=4096, device='cuda'); w.its_showtime()     # wide tier (tabulation cached)
+  w.rollout(a); w.play(a[0])
+  del g, h, w, a
   gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
   free, total = torch.cuda.mem_get_info()
   if free0 is None: free0 = free
