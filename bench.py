@@ -288,6 +288,9 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
       log.episode_done()
     return out
 
+  # (A host-side barrier - a gloo group beside the RCCL one - was tried for the fence: 196-242 us
+  # at the end of a timed window on one rank against 70-96 us for the RCCL barrier; a tight loop
+  # of either reads ~20 us, tools/barrier_cost.py, but the window's closing barrier is a cold one.)
   def fence():
     if on_gpu:
       torch.cuda.synchronize(device)
@@ -327,10 +330,19 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     out = one_step(i)
   if on_gpu:
     ev1.record()
+  t_loop = time.perf_counter()
   if log is not None:
     log.wait()
+  t_wait = time.perf_counter()
+  if on_gpu:
+    torch.cuda.synchronize(device)
+  t_sync = time.perf_counter()
   fence()
   elapsed = time.perf_counter() - t0
+  if os.environ.get('CAMPX_BENCH_DEBUG'):
+    sys.stderr.write('TIMED WINDOW: loop (host) %.1f us, log.wait %.1f, synchronize %.1f, fence %.1f, total %.1f\n' % (
+        (t_loop - t0) * 1e6, (t_wait - t_loop) * 1e6, (t_sync - t_wait) * 1e6,
+        (time.perf_counter() - t_sync) * 1e6, elapsed * 1e6))
   own_elapsed = elapsed               # this rank's; `elapsed` becomes the max over ranks
   gc.enable()
   if dist is not None:
