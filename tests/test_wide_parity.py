@@ -761,3 +761,30 @@ def test_hidden_performance_on_a_wide_board_through_the_kernels():
   for t in range(10):
     game.play(torch.from_numpy(actions[t]))
     assert np.array_equal(f.perf.cpu().numpy(), want['perf'][t]), t
+
+
+@pytest.mark.gpu
+def test_a_launch_of_more_than_65520_frames_is_rendered_in_pieces(monkeypatch):
+  """A render launch has one grid row per frame (at most 65 535): a 70 000-frame rollout of a
+  small game on the wide tier goes out in two render launches over one update pass."""
+  from oracle.table_replay import StateWalker
+  from campx_amd import wide
+  monkeypatch.setattr(tabulate, 'DENSE_MAX_ENTRIES', 0)
+  tabulate._CACHE.clear()
+  B, T = 16, 70000
+  game = traced_games.toll_road(batch=B, device='cuda')
+  game.its_showtime()
+  tabulate._CACHE.clear()
+  f = game.fused
+  assert isinstance(f, wide.WideGame)
+  rng = np.random.RandomState(2)
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  out = game.rollout(torch.from_numpy(actions))
+  walker = StateWalker(f.traced, B)
+  want = walker.rollout(actions)
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), want[k]), k
+  for t in (0, 65519, 65520, 65521, T - 1):
+    assert np.array_equal(out['obs'][t].cpu().numpy(), walker.render(want['state'][t])[1]), t
+  sums = out['obs'].sum(dim=2, dtype=torch.int32)
+  assert int(sums.min()) == 1 and int(sums.max()) == 1
