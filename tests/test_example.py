@@ -22,3 +22,31 @@ def test_batched_reinforce_example_runs(tmp_path):
   assert len(rows) == 4 and [r[1] for r in rows[1:]] == ['20', '40', '60']
   # 20 frames at -1 .. +2 per frame
   assert all(-20.0 <= float(r[5]) <= 40.0 for r in rows[1:])
+
+
+def test_own_game_example_runs_on_the_generic_tier():
+  """examples/own_game_batched.py: its classes are ordinary CampX classes - one environment,
+  no GPU: walk to the key, through the door it opens, to the gem."""
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import torch
+  import own_game_batched as ex
+  game = ex.make_game()
+  obs, reward, discount = game.its_showtime()
+  assert reward is None and chr(int(obs.board[1, 1])) == 'A' and chr(int(obs.board[1, 14])) == ' '
+  total = 0.0
+  for a in [1] * 5 + [3] * 5 + [1] * 3 + [2] * 5 + [1] * 5:
+    obs, reward, discount = game.play(torch.eye(5)[a])
+    total += float(reward)
+  assert game.game_over and discount == 0.0
+  assert total == -0.25 * 23 + 1.0 + 0.5 + 10.0
+
+
+@pytest.mark.gpu
+def test_own_game_example_runs_batched():
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import own_game_batched as ex
+  from campx_amd import wide
+  got = ex.run(batch=2048, frames=60, launches=2)
+  f = got['game'].fused
+  assert isinstance(f, wide.WideGame) and f.traced.movers == ['A', 'k', 'D', '$']
+  assert got['rate'] > 1e6 and got['out']['obs'].shape == (60, 2048, 6, 12, 16)
