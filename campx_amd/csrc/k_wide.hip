@@ -92,12 +92,14 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
   };
   uint32_t a_next[kWideAhead];
   fetch(0, a_next);
-  // One chunk of frames.  `kPlain`: a whole chunk of a game with one thing, no discount codes
-  // and the usual output streams - no test inside, so the frames' table reads overlap (with
+  // One chunk of frames.  `kPlain`: a whole chunk of a game without discount codes and with
+  // the usual output streams - no test inside, so the frames' table reads overlap (with
   // the tests every frame made three dependent LDS round trips and ten scalar branches:
   // 275 ns per frame, 28 us per 100 frames at B = 4 096).
+  // (`plain_tag`: 0 = the general chunk; k = 1 .. 8 = a plain chunk of a game with k things)
   auto chunk = [&](auto plain_tag, int t0, const uint32_t (&a)[kWideAhead]) {
-    constexpr bool kPlain = decltype(plain_tag)::value;
+    constexpr int kThings = decltype(plain_tag)::value;
+    constexpr bool kPlain = kThings > 0;
 #pragma unroll
     for (int j = 0; j < kWideAhead; ++j) {
       if (kPlain || t0 + j < T) {
@@ -109,6 +111,12 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
         from = done ? 0u : now;                      // the chain: state -> entry -> state
         const u32x4 c = cells[now];                  // where things show in the state reached
         trace[at] = (uint16_t)c.x;
+        if (kPlain) {
+          const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int d = 1; d < kThings; ++d)
+            trace[at + d * plane] = (uint16_t)(w[d >> 1] >> (16 * (d & 1)));
+        }
         if (!kPlain && K > 1) {
           uint16_t* tk = trace + at + plane;
           tk[0] = (uint16_t)(c.x >> 16);
@@ -135,15 +143,27 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
       }
     }
   };
-  const bool plain = K == 1 && !wp.has_dcodes && out.reward && out.discount && out.done &&
+  const bool plain = !wp.has_dcodes && out.reward && out.discount && out.done &&
                      (!kPerf || out.perf);
   for (int t0 = 0; t0 < T; t0 += kWideAhead) {
     uint32_t a[kWideAhead];
 #pragma unroll
     for (int j = 0; j < kWideAhead; ++j) a[j] = a_next[j];
     if (t0 + kWideAhead < T) fetch(t0 + kWideAhead, a_next);
-    if (plain && t0 + kWideAhead <= T) chunk(std::true_type{}, t0, a);
-    else chunk(std::false_type{}, t0, a);
+    if (plain && t0 + kWideAhead <= T) {
+      switch (K) {      // (one uniform branch per chunk of eight frames)
+        case 1: chunk(std::integral_constant<int, 1>{}, t0, a); break;
+        case 2: chunk(std::integral_constant<int, 2>{}, t0, a); break;
+        case 3: chunk(std::integral_constant<int, 3>{}, t0, a); break;
+        case 4: chunk(std::integral_constant<int, 4>{}, t0, a); break;
+        case 5: chunk(std::integral_constant<int, 5>{}, t0, a); break;
+        case 6: chunk(std::integral_constant<int, 6>{}, t0, a); break;
+        case 7: chunk(std::integral_constant<int, 7>{}, t0, a); break;
+        default: chunk(std::integral_constant<int, 8>{}, t0, a); break;
+      }
+    } else {
+      chunk(std::integral_constant<int, 0>{}, t0, a);
+    }
   }
   state[env] = (int32_t)now;
   st.done[env] = (uint8_t)over;
