@@ -243,3 +243,85 @@ def test_random_big_boards(seed):
     assert _same(obs.layered_board.cpu().numpy(), ref['obs'][t]), (rows, batch, t)
     assert _same(obs.board.cpu().numpy(), ref['board'][t]), (rows, batch, t)
     assert _same(discount.cpu().numpy(), ref['discount'][t])
+
+
+def random_python_game(rng):
+  """A random game of plain Python classes (tests/traced_games.py: a walker whose tiles change
+  the frame's discount and end the episode, plus up to two coins that vanish when collected)
+  on a random walled board of 40 to 200 cells: host tabulation, then whichever tier takes it
+  (cell-indexed tables, or the state table above 128 cells)."""
+  import traced_games
+  H, W = int(rng.randint(5, 13)), int(rng.randint(6, 18))
+  while not 40 <= H * W <= 200:
+    H, W = int(rng.randint(5, 13)), int(rng.randint(6, 18))
+  art = np.full((H, W), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = '#'
+  art[:, 0] = art[:, -1] = '#'
+  inner = art[1:-1, 1:-1]
+  inner[rng.rand(H - 2, W - 2) < 0.12] = '#'
+  free = list(zip(*np.where(art == ' ')))
+  rng.shuffle(free)
+  art[free.pop()] = 'A'
+  for ch, count in (('$', rng.randint(0, 4)), ('%', rng.randint(0, 3)), ('E', rng.randint(0, 2))):
+    for _ in range(int(count)):
+      art[free.pop()] = ch
+  coins = '12'[:int(rng.randint(0, 3))]
+  for ch in coins:
+    art[free.pop()] = ch
+  rows = [''.join(r) for r in art]
+
+  class Coin(traced_games.things.Drape):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is None:
+        return
+      if (self.curtain * all_things['A'].curtain).sum():
+        self.curtain.zero_()
+        the_plot.add_reward(2.0)
+
+  def build(**where):
+    drapes = {'A': traced_games.TollWalker, '#': traced_games.things.FixedDrape,
+              '$': traced_games.things.FixedDrape, '%': traced_games.things.FixedDrape,
+              'E': traced_games.things.FixedDrape}
+    for ch in coins:
+      drapes[ch] = Coin
+    return traced_games.ascii_art_to_game(
+        rows, what_lies_beneath=' ', drapes=drapes, z_order='$%E' + coins + 'A#',
+        update_schedule='A' + coins + '#$%E', **where)
+  return build, rows
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_FUZZ_PYTHON_SEEDS', '6'))))
+def test_random_python_class_games(seed):
+  """Host-tabulated games against the classes themselves (the generic tier, three environments,
+  every frame) and the state walker (every environment's scalars, sampled frames)."""
+  from campx_amd import tabulate
+  from oracle.table_replay import StateWalker
+  rng = np.random.RandomState(7000 + seed)
+  build, rows = random_python_game(rng)
+  B, T = int(rng.choice([3, 64, 257, 1000])), int(rng.randint(20, 90))
+  game = build(batch=B, device='cuda')
+  game.its_showtime()
+  traced = game.fused.traced
+  actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+  out = game.rollout(torch.from_numpy(actions), want_board=True)
+  walker = StateWalker(traced, B)
+  want = walker.rollout(actions)
+  for k in ('reward', 'discount', 'done'):
+    assert _same(out[k].cpu().numpy(), want[k]), (rows, k)
+  for t in (0, T // 2, T - 1):
+    board, layered = walker.render(want['state'][t])
+    assert np.array_equal(out['obs'][t].cpu().numpy(), layered), (rows, t)
+    assert np.array_equal(out['board'][t].cpu().numpy(), board), (rows, t)
+  onehot = tabulate.default_actions()
+  for env in range(min(3, B)):
+    g = build()
+    g.its_showtime()
+    for t in range(T):
+      if g.game_over:
+        g = build()
+        g.its_showtime()
+      obs, reward, discount = g.play(onehot[int(actions[t, env])])
+      assert np.array_equal(out['board'][t, env].cpu().numpy(), obs.board.numpy().astype(np.int8)), (rows, env, t)
+      got = np.float32(np.nan) if reward is None else np.float32(float(reward))
+      assert _same(out['reward'][t, env].cpu().numpy(), got), (rows, env, t)
+      assert float(out['discount'][t, env]) == float(discount)
