@@ -236,6 +236,16 @@ class _NoFingerprint(Exception):
   pass
 
 
+def _feed_code(h, code):
+  h.update(code.co_code)
+  h.update(repr(code.co_names).encode())
+  for const in code.co_consts:
+    if hasattr(const, 'co_code'):
+      _feed_code(h, const)                             # nested functions, comprehensions
+    else:
+      h.update(repr(const).encode())
+
+
 def _feed(h, x, depth=0):
   """Hash plain data - numbers, strings, tensors, arrays, containers of those, objects
   through their class and __dict__ - into h; anything else has no fingerprint."""
@@ -267,7 +277,38 @@ def _feed(h, x, depth=0):
       _feed(h, x[key], depth + 1)
     h.update(b'}')
   elif isinstance(x, type):
-    h.update('{}.{}@{}'.format(x.__module__, x.__qualname__, id(x)).encode())
+    # a class by what it DOES, not by where it lives (ids are recycled when classes defined
+    # inside functions are collected): name + the code, constants and closure of every
+    # function it and its bases define, down to this package's own base classes
+    for klass in x.__mro__:
+      h.update('{}.{}'.format(klass.__module__, klass.__qualname__).encode())
+      if (klass.__module__.startswith(('campx_amd.', 'builtins', 'abc', 'collections', 'typing'))
+          and '<locals>' not in klass.__qualname__):
+        continue
+      for name in sorted(vars(klass)):
+        if name.startswith('_abc_'):
+          continue                                     # (abc's bookkeeping)
+        member = vars(klass)[name]
+        fn = getattr(member, '__func__', member)       # static / class methods
+        fn = getattr(fn, 'fget', fn)                   # properties
+        code = getattr(fn, '__code__', None)
+        if code is None:
+          if not name.startswith('__'):
+            _feed(h, name, depth + 1)
+            _feed(h, member, depth + 1)                # a class attribute: plain data or nothing
+          continue
+        h.update(name.encode())
+        _feed_code(h, code)
+        for cell in (fn.__closure__ or ()):
+          try:
+            inside = cell.cell_contents
+          except ValueError:                           # an empty cell
+            h.update(b'<empty>')
+            continue
+          if isinstance(inside, type):                 # (`__class__`, for super(): by name)
+            h.update('{}.{}'.format(inside.__module__, inside.__qualname__).encode())
+          else:
+            _feed(h, inside, depth + 1)
   elif hasattr(x, '__dict__') and not callable(x):
     _feed(h, type(x), depth + 1)
     _feed(h, vars(x), depth + 1)
@@ -277,7 +318,7 @@ def _feed(h, x, depth=0):
 
 def fingerprint(engine, actions):
   """A key under which the tabulation of a set-up engine can be reused: every entity's class
-  (by identity) and attributes, the backdrop, the update groups and z-order, the hidden-
+  (by the code of its methods) and attributes, the backdrop, the update groups and z-order, the hidden-
   performance declarations, the action set.  None when something in there is not plain data
   (the game is then tabulated afresh every time)."""
   h = hashlib.sha1()
