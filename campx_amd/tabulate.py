@@ -320,7 +320,9 @@ def fingerprint(engine, actions):
   """A key under which the tabulation of a set-up engine can be reused: every entity's class
   (by the code of its methods) and attributes, the backdrop, the update groups and z-order, the hidden-
   performance declarations, the action set.  None when something in there is not plain data
-  (the game is then tabulated afresh every time)."""
+  (the game is then tabulated afresh every time).  Module-level globals that a method reads
+  are taken not to change between two set-ups of the same game; `trace(..., cache=False)`
+  is there for code that does change them."""
   h = hashlib.sha1()
   try:
     _feed(h, (engine.rows, engine.cols, list(engine.things.keys())))

@@ -320,8 +320,8 @@ def test_z_order_modes_are_tabulated_as_one_more_tracked_value():
 
 def test_a_second_make_game_of_the_same_game_reuses_the_tabulation():
   """The reference's driver calls make_game() per episode (examples/reinforce.py:122): the
-  tabulation is keyed by a fingerprint of the set-up engine (classes by identity, every
-  attribute, curtains, groups, z-order, action set) and reused."""
+  tabulation is keyed by a fingerprint of the set-up engine (classes by the code of their
+  methods, every attribute, curtains, groups, z-order, action set) and reused."""
   import time
   tabulate._CACHE.clear()
   first = tabulate.trace(traced_games.mirror())
