@@ -318,6 +318,9 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     settle = 4 + int(min(5000, max(0, 50.0 / per - 4)) + 0.999)
     for i in range(4, settle):
       one_step(warmup + i)
+  if log is not None:
+    log.wait()
+    log.align()                       # the timed window starts on a block boundary of the log
   gc.collect()                        # (before the fence: the chip should not idle longer than it must)
   gc.disable()                        # no collector pause between two launches of the timed region
   fence()
@@ -337,12 +340,18 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   if on_gpu:
     torch.cuda.synchronize(device)
   t_sync = time.perf_counter()
+  # The clock stops here: every launch of this rank and its share of the return log have
+  # completed.  The window OPENED barrier-aligned, and what is reported is the MAX over ranks
+  # of these per-rank times (all-reduced below) - the time at which the slowest rank was done,
+  # which is all a closing barrier inside the clock could add, plus the barrier's own cold
+  # 70-100 us (round 3's line carried it: ms_per_step 3.5 % above kernel_ms).  The barrier
+  # itself still closes the region, outside the clock.
+  elapsed = t_sync - t0
   fence()
-  elapsed = time.perf_counter() - t0
   if os.environ.get('CAMPX_BENCH_DEBUG'):
-    sys.stderr.write('TIMED WINDOW: loop (host) %.1f us, log.wait %.1f, synchronize %.1f, fence %.1f, total %.1f\n' % (
+    sys.stderr.write('TIMED WINDOW: loop (host) %.1f us, log.wait %.1f, synchronize %.1f, total %.1f; closing fence (off the clock) %.1f\n' % (
         (t_loop - t0) * 1e6, (t_wait - t_loop) * 1e6, (t_sync - t_wait) * 1e6,
-        (time.perf_counter() - t_sync) * 1e6, elapsed * 1e6))
+        elapsed * 1e6, (time.perf_counter() - t_sync) * 1e6))
   own_elapsed = elapsed               # this rank's; `elapsed` becomes the max over ranks
   gc.enable()
   if dist is not None:
@@ -620,8 +629,10 @@ def main(argv=None):
   argv = sys.argv[1:] if argv is None else argv
   args = parse_args(argv)
   if args.gpus > 1 and not args.standin:
-    import torch     # (counting devices does not initialise the GPU)
-    have = torch.cuda.device_count()
+    # (counted in a child: should torch ever fall back from amdsmi to hipGetDeviceCount, the
+    # HIP runtime comes up in that child and not in this launcher process)
+    have = int(subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                              stdout=subprocess.PIPE, text=True).stdout.strip().splitlines()[-1] or 0)
     if have < args.gpus:
       sys.stderr.write('bench.py: --gpus {} asked for, but this node shows {} HIP device(s); '
                        'nothing was launched\n'.format(args.gpus, have))

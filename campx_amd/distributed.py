@@ -141,6 +141,20 @@ class ReturnLog(object):
     self._last = i
     return True
 
+  def align(self):
+    """Skip to the start of the next block (rows already logged in the current one are
+    dropped): what follows - a timed window - then gathers after exactly `episodes`
+    episodes, wherever the warm-up left the counter."""
+    block, row = divmod(self._count, self.episodes)
+    if row:
+      block += 1
+      if self._last is not None and (block & 1) == self._last:
+        block += 1                           # (not onto the rows of the last gathered block)
+      work = self._work[block & 1]
+      if work is not None:
+        work.wait()
+      self._count = block * self.episodes
+
   def last_local_block(self):
     """This rank's own `[episodes, batch]` rows of the most recently gathered block."""
     return None if self._last is None else self._log[self._last]

@@ -379,7 +379,7 @@ class Engine(object):
     assert self._board, (
         '_update_and_render() called without a prior rendering of the board')
     the_plot = self._the_plot
-    the_plot.frame += 1
+    the_plot._advance_frame()      # (`frame += 1`, campx/engine.py:182, without reading the property)
     the_plot.update_group = None
     self._backdrop.update(actions, self._board.board, self._board.layers,
                           self._sprites_and_drapes, the_plot)

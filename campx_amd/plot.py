@@ -95,6 +95,12 @@ class Plot(dict):
     assert val == self._frame + 1   # frames advance one at a time (plot.py:279)
     self._frame = val
 
+  def _advance_frame(self):
+    """The engine's `the_plot.frame += 1` (campx/engine.py:182).  Kept apart from the property
+    so that the tabulator's probe can tell a GAME reading the frame number from the engine
+    advancing it (campx_amd/tabulate.py)."""
+    self._frame += 1
+
   @property
   def update_group(self):
     return self._update_group

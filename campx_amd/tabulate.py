@@ -16,24 +16,35 @@ the game can reach:
     campx/things.py:38), `play(action)`, read the entities' curtains / positions, the
     Plot's reward / discount / game-over, and the rendered board.
 
-A state is identified by the byte image of every curtain, sprite position and the
-z-order.  Afterwards the moving things are the entities whose image differs between two
-reached states; everything else is scenery.  A game that re-orders its things at run time
-(`Plot.change_z_order`, campx/plot.py:121-159, applied by campx/engine.py:242-281) has one
-more piece of state, WHICH of the z-orders it has reached is in force: that "mode" is
-tabulated like the cell of one more moving thing that is never painted (the kernels index
-their tables by up to four cells and care about nothing else), and what an order changes
-on the screen - which of two things on one cell shows - is already in the table entries'
-"is the character its cell shows" bits.  The tabulation is exact under conditions
-that are CHECKED while tabulating, never assumed (ValueError otherwise):
+A state is identified by everything a frame can READ: the byte image of every curtain and
+sprite position, the z-order, and `_hidden()` - every other attribute of every entity and of
+the Backdrop, the Plot's user entries and attributes (campx/plot.py:29: the Plot is a dict for
+exactly that), all by value (tensors included), and the frame number (plot.py:259-280) IF the
+game reads it (the probe engine's Plot records reads of `frame` outside the priming frame; a
+game that does is tabulated again with the frame number in the state).  A value that cannot be
+imaged (a generator, a file, a lock) refuses the game.  So a bounded counter, a cooldown or a
+time limit multiplies the states and is tabulated exactly; an unbounded one is refused - after
+`MAX_HIDDEN_VALUES` distinct values of one quantity, or `MAX_PLAYS` frames - with a message
+that names what keeps growing.
+
+Afterwards the moving things are the entities whose image differs between two reached states;
+everything else is scenery.  Whatever else tells two reached states with the same curtains
+apart - WHICH z-order is in force for a game that re-orders its things (`Plot.change_z_order`,
+campx/plot.py:121-159, applied by campx/engine.py:242-281), and the hidden values that are not
+themselves functions of the curtains - is the "mode", tabulated like the cell of one more moving
+thing that is never painted (the kernels index their tables by up to four cells and care about
+nothing else).  What an order changes on the screen - which of two things on one cell shows - is
+already in the table entries' "is the character its cell shows" bits.  The tabulation is exact
+under conditions that are CHECKED while tabulating (TabulationError otherwise):
 
 * every moving thing occupies exactly one cell in every reached state - or NONE: a drape
   whose curtain is empty (a key that was picked up, a door that opened) and a sprite that
   is not `visible` (campx/things.py:294-296, 391-392; engine.py:314 skips it) are "absent",
   tabulated as standing on a cell index the thing never occupies and never shown -, there
   are at most four of them -
-  the mode of a re-ordering game counts as one, and it has at most rows*cols values -,
-  the board has at most 128 cells (one mover and no re-ordering: 1 024, the wide tier,
+  the mode counts as one, and it has at most rows*cols values (beyond either: the game runs
+  from its STATE table, the wide tier, which only needs the state count to fit) -,
+  the board has at most 128 cells (one mover and one mode: 1 024, the wide tier,
   csrc/k_wide.hip) and 16 characters;
 * the Backdrop's curtain never changes (no sprite painted into the backdrop:
   campx/rendering.py:128,150), and no reached z-order changes how the SCENERY paints (two
@@ -42,11 +53,16 @@ that are CHECKED while tabulating, never assumed (ValueError otherwise):
   the cells alone - which also yields whether a moving thing is the character its cell shows;
 * at most fifteen distinct discounts other than the default - 1.0, or 0.0 on the frame
   `terminate_episode()` was called - are reported (`change_default_discount`,
-  `terminate_episode(d)`: campx/plot.py:161-184, 232-257; the tables carry a 4-bit code);
-* the entities' curtains ARE the state: when a state is reached again over a different
-  history, every action is replayed from that second engine and must reproduce the
-  tabulated next state, reward, discount, game-over and board.  A game that keeps hidden
-  state elsewhere (a counter in the Plot, the frame number) is refused here.
+  `terminate_episode(d)`: campx/plot.py:161-184, 232-257; the tables carry a 4-bit code).
+
+... and under one that is only SPOT-CHECKED: that the game keeps no state where `_hidden()` does
+not look - a module global it mutates, a closure, a random number generator.  When a state is
+reached again over a different history, every action is replayed from that second engine and
+must reproduce the tabulated next state, reward, discount, game-over and board; that catches
+such state only if it shows within one frame of one second arrival (a `random` call does; a
+global counter that matters fifty frames later does not).  Games are deterministic functions of
+their entities and their Plot in every example of the reference; one that is not must not be
+handed to a batched Engine.
 
 Host logic only (numpy + the generic tier): runs without a GPU.  `fused.FusedGame`
 uploads the result.
@@ -55,6 +71,8 @@ uploads the result.
 import collections
 import copy
 import hashlib
+import os
+import sys
 
 import numpy as np
 import torch
@@ -67,9 +85,16 @@ N_ACTIONS = gamespec.N_ACTIONS
 # deep copy + a frame of Python, ~2 ms): beyond it the game is refused with a pointer to
 # campx_amd.rules, whose tables are built on the device.
 MAX_PLAYS = 60000
+# Most distinct values ONE hidden quantity (a Plot entry, an entity attribute, the frame number)
+# may take before the game is refused: a counter that is never reset would otherwise cost all of
+# MAX_PLAYS (two minutes) to find out.  A time limit of up to this many frames is fine.
+MAX_HIDDEN_VALUES = 1024
 # Largest dense (cell, ..., cell, action) table built on the host (entries); games beyond it
 # run from their state table (the wide tier).
 DENSE_MAX_ENTRIES = 8 << 20
+
+
+_STDLIB = os.path.dirname(os.__file__)
 
 
 class TabulationError(ValueError):
@@ -98,6 +123,127 @@ def _image(engine):
       parts.append(ent.curtain.detach().to(torch.uint8).numpy().tobytes())
   backdrop = engine.backdrop.curtain.detach().to(torch.int64).numpy().tobytes()
   return tuple(parts), backdrop, ''.join(engine.things.keys())
+
+
+class _Unimageable(Exception):
+  """Something a frame can read that is not plain data (raised with its path)."""
+
+
+# attributes of an entity that `_image()` (or nothing at all: constants) already covers
+_CORE_ATTRS = {
+    'drape': ('_curtain', '_character'),
+    'sprite': ('_corner', '_character', '_position', '_visible'),
+    'backdrop': ('_curtain', '_palette'),
+    'plot': ('_frame', '_update_group', '_engine_directives'),
+}
+_MISSING = ('missing',)
+
+
+def _plain(x, path, depth, open_ids):
+  """A hashable image of plain data: numbers, strings, tensors and arrays BY VALUE, containers
+  and objects (class name + attributes) of those.  Functions, classes and modules are taken by
+  name (they are code, not state).  Anything else - a generator, an open file, a lock - cannot
+  be compared between two frames and raises `_Unimageable`."""
+  if x is None or isinstance(x, (bool, int, float, complex, str, bytes)):
+    return (type(x).__name__, x) if not (isinstance(x, float) and x != x) else ('float', 'nan')
+  if torch.is_tensor(x):
+    a = x.detach().cpu().numpy()
+    return ('tensor', str(a.dtype), a.shape, a.tobytes())
+  if isinstance(x, (np.ndarray, np.generic)):
+    a = np.asarray(x)
+    return ('array', str(a.dtype), a.shape, np.ascontiguousarray(a).tobytes())
+  if depth > 8:
+    raise _Unimageable(path + ' (nested more than 8 deep)')
+  if id(x) in open_ids:
+    return ('cycle',)
+  if isinstance(x, (type, type(_plain), type(len), type(np))) or callable(x) and hasattr(x, '__qualname__'):
+    return ('ref', getattr(x, '__module__', None), getattr(x, '__qualname__', getattr(x, '__name__', '?')))
+  open_ids = open_ids | {id(x)}
+  if isinstance(x, (list, tuple)):
+    return (type(x).__name__,) + tuple(_plain(v, '{}[{}]'.format(path, i), depth + 1, open_ids)
+                                        for i, v in enumerate(x))
+  if isinstance(x, (set, frozenset)):
+    return ('set',) + tuple(sorted((_plain(v, path + '{..}', depth + 1, open_ids) for v in x), key=repr))
+  if isinstance(x, dict):
+    items = [(_plain(k, path + '{key}', depth + 1, open_ids),
+              _plain(v, '{}[{!r}]'.format(path, k), depth + 1, open_ids)) for k, v in x.items()]
+    return ('dict',) + tuple(sorted(items, key=repr))
+  if hasattr(x, '__dict__'):
+    items = tuple((k, _plain(v, '{}.{}'.format(path, k), depth + 1, open_ids))
+                  for k, v in sorted(vars(x).items()))
+    return ('object', type(x).__module__, type(x).__qualname__) + items
+  raise _Unimageable('{} (a {})'.format(path, type(x).__name__))
+
+
+def _hidden(engine, with_frame):
+  """Everything a frame can read that is NOT a curtain, a sprite's position / visibility or the
+  z-order (those are `_image()`): every other attribute of every entity and of the Backdrop,
+  the Plot's user entries (campx/plot.py:29 - the Plot is a dict for exactly that; the message
+  log, which frames only append to, is left out) and attributes, and - `with_frame` - the frame
+  number (campx/plot.py:259-280).  A tuple of (path, image) pairs, sorted by path."""
+  plot = engine.the_plot
+  found = []
+
+  def attrs(obj, prefix, kind):
+    for name, value in vars(obj).items():
+      if name not in _CORE_ATTRS[kind]:
+        found.append((prefix + '.' + name, value))
+
+  for ch in sorted(engine.things.keys()):
+    ent = engine.things[ch]
+    attrs(ent, 'things[{!r}]'.format(ch), 'sprite' if isinstance(ent, _things.Sprite) else 'drape')
+  attrs(engine.backdrop, 'backdrop', 'backdrop')
+  for key, value in plot.items():
+    if key != plot.LOG_KEY:
+      found.append(('the_plot[{!r}]'.format(key), value))
+  attrs(plot, 'the_plot', 'plot')
+  if with_frame:
+    found.append(('the_plot.frame', plot._frame))
+  out = []
+  for path, value in found:
+    try:
+      out.append((path, _plain(value, path, 0, frozenset())))
+    except _Unimageable as e:
+      _fail('{} is not plain data (numbers, strings, tensors, containers and objects of '
+            'those): the tabulator cannot tell whether two frames that look the same ARE the '
+            'same state'.format(e))
+  out.sort(key=lambda kv: kv[0])
+  return tuple(out)
+
+
+class _FrameWasRead(Exception):
+  pass
+
+
+_FRAME_READS = [0]     # bumped by every read of `Plot.frame` on a probe engine
+
+
+_PROBE_PLOTS = {}
+
+
+def _probe_plot_class(base):
+  """`base` (the engine's Plot class) with a `frame` that notices being read: a game whose
+  update() looks at the frame number (a time limit) has the frame number in its state."""
+  if base in _PROBE_PLOTS:
+    return _PROBE_PLOTS[base]
+  if getattr(base, '_campx_probe', False):
+    return base
+
+  class ProbePlot(base):
+    _campx_probe = True
+    __slots__ = ()
+
+    @property
+    def frame(self):
+      _FRAME_READS[0] += 1
+      return self._frame
+
+    @frame.setter
+    def frame(self, val):
+      base.frame.fset(self, val)
+
+  _PROBE_PLOTS[base] = ProbePlot
+  return ProbePlot
 
 
 def _reward_f32(reward):
@@ -237,19 +383,90 @@ class _NoFingerprint(Exception):
 
 
 def _feed_code(h, code):
+  h.update(b'code(')
   h.update(code.co_code)
-  h.update(repr(code.co_names).encode())
+  h.update(repr((code.co_names, code.co_varnames, code.co_argcount, code.co_kwonlyargcount,
+                 code.co_freevars, code.co_cellvars, code.co_flags)).encode())
   for const in code.co_consts:
     if hasattr(const, 'co_code'):
       _feed_code(h, const)                             # nested functions, comprehensions
     else:
       h.update(repr(const).encode())
+    h.update(b',')
+  h.update(b')')
 
 
-def _feed(h, x, depth=0):
+def _code_names(code, into):
+  """Every name the code object - and the code objects nested in it - loads by name."""
+  into.update(code.co_names)
+  for const in code.co_consts:
+    if hasattr(const, 'co_code'):
+      _code_names(const, into)
+  return into
+
+
+def _is_library_module(mod):
+  """A module nobody edits between two set-ups of a game: the standard library, installed
+  packages (torch, numpy ...), this package."""
+  name = getattr(mod, '__name__', '')
+  if name.split('.')[0] in ('campx_amd', 'campx', 'builtins', 'torch', 'numpy'):
+    return True
+  path = getattr(mod, '__file__', None)
+  if path is None:
+    return name in sys.builtin_module_names or name != '__main__'
+  return 'site-packages' in path or 'dist-packages' in path or path.startswith(_STDLIB)
+
+
+def _feed_function(h, fn, depth, seen):
+  """A function by what it does AND by what it reads: its code, defaults, closure, and the
+  VALUES behind the global names it loads (`QUARTERED_MOVEMENT_PENALTY`,
+  examples/boat_race.py:22,76): plain data by value, helper functions and classes of user
+  modules by their own code, user modules through the attributes the code names; library
+  modules (torch, numpy, the standard library) by name."""
+  code = fn.__code__
+  if id(fn) in seen:
+    h.update(b'<again>')
+    return
+  seen = seen | {id(fn)}
+  _feed_code(h, code)
+  h.update(b'defaults')
+  _feed(h, fn.__defaults__, depth + 1, seen)
+  _feed(h, fn.__kwdefaults__, depth + 1, seen)
+  h.update(b'closure')
+  for cell in (fn.__closure__ or ()):
+    try:
+      inside = cell.cell_contents
+    except ValueError:                           # an empty cell
+      h.update(b'<empty>')
+      continue
+    if isinstance(inside, type):                 # (`__class__`, for super(): by name)
+      h.update('{}.{}'.format(inside.__module__, inside.__qualname__).encode())
+    else:
+      _feed(h, inside, depth + 1, seen)
+  h.update(b'globals')
+  names = sorted(_code_names(code, set()))
+  space = fn.__globals__
+  for name in names:
+    if name not in space:
+      continue                                   # an attribute name, a builtin
+    value = space[name]
+    h.update(name.encode() + b'=')
+    if isinstance(value, type(sys)):
+      h.update(('module ' + value.__name__).encode())
+      if not _is_library_module(value):
+        for attr in names:                       # `config.PENALTY`: the attributes it names
+          if hasattr(value, attr):
+            h.update(attr.encode() + b':')
+            _feed(h, getattr(value, attr), depth + 1, seen)
+    else:
+      _feed(h, value, depth + 1, seen)
+
+
+def _feed(h, x, depth=0, seen=frozenset()):
   """Hash plain data - numbers, strings, tensors, arrays, containers of those, objects
-  through their class and __dict__ - into h; anything else has no fingerprint."""
-  if depth > 6:
+  through their class and __dict__, functions and classes through `_feed_function` - into h;
+  anything else has no fingerprint."""
+  if depth > 8:
     raise _NoFingerprint()
   if x is None or isinstance(x, (bool, int, float, str, bytes)):
     h.update(repr(x).encode())
@@ -257,31 +474,40 @@ def _feed(h, x, depth=0):
     a = x.detach().cpu().numpy()
     h.update(str((a.dtype, a.shape)).encode())
     h.update(a.tobytes())
-  elif isinstance(x, np.ndarray):
+  elif isinstance(x, (np.ndarray, np.generic)):
+    x = np.asarray(x)
     h.update(str((x.dtype, x.shape)).encode())
     h.update(np.ascontiguousarray(x).tobytes())
   elif isinstance(x, (list, tuple)):
     h.update(b'[')
     for item in x:
-      _feed(h, item, depth + 1)
+      _feed(h, item, depth + 1, seen)
+      h.update(b',')
     h.update(b']')
   elif isinstance(x, (set, frozenset)):
     h.update(b'<')
     for item in sorted(x, key=repr):
-      _feed(h, item, depth + 1)
+      _feed(h, item, depth + 1, seen)
+      h.update(b',')
     h.update(b'>')
   elif isinstance(x, dict):
     h.update(b'{')
     for key in sorted(x, key=repr):
-      _feed(h, key, depth + 1)
-      _feed(h, x[key], depth + 1)
+      _feed(h, key, depth + 1, seen)
+      h.update(b':')
+      _feed(h, x[key], depth + 1, seen)
+      h.update(b',')
     h.update(b'}')
   elif isinstance(x, type):
     # a class by what it DOES, not by where it lives (ids are recycled when classes defined
-    # inside functions are collected): name + the code, constants and closure of every
+    # inside functions are collected): name + the code, defaults, closure and globals of every
     # function it and its bases define, down to this package's own base classes
+    if id(x) in seen:
+      h.update(b'<again>')
+      return
+    seen = seen | {id(x)}
     for klass in x.__mro__:
-      h.update('{}.{}'.format(klass.__module__, klass.__qualname__).encode())
+      h.update('class {}.{};'.format(klass.__module__, klass.__qualname__).encode())
       if (klass.__module__.startswith(('campx_amd.', 'builtins', 'abc', 'collections', 'typing'))
           and '<locals>' not in klass.__qualname__):
         continue
@@ -291,27 +517,30 @@ def _feed(h, x, depth=0):
         member = vars(klass)[name]
         fn = getattr(member, '__func__', member)       # static / class methods
         fn = getattr(fn, 'fget', fn)                   # properties
-        code = getattr(fn, '__code__', None)
-        if code is None:
+        if getattr(fn, '__code__', None) is None:
           if not name.startswith('__'):
-            _feed(h, name, depth + 1)
-            _feed(h, member, depth + 1)                # a class attribute: plain data or nothing
+            _feed(h, name, depth + 1, seen)
+            h.update(b'=')
+            _feed(h, member, depth + 1, seen)          # a class attribute: plain data or nothing
           continue
-        h.update(name.encode())
-        _feed_code(h, code)
-        for cell in (fn.__closure__ or ()):
-          try:
-            inside = cell.cell_contents
-          except ValueError:                           # an empty cell
-            h.update(b'<empty>')
-            continue
-          if isinstance(inside, type):                 # (`__class__`, for super(): by name)
-            h.update('{}.{}'.format(inside.__module__, inside.__qualname__).encode())
-          else:
-            _feed(h, inside, depth + 1)
+        h.update(b'def ' + name.encode() + b':')
+        _feed_function(h, fn, depth + 1, seen)
+  elif getattr(x, '__code__', None) is not None and hasattr(x, '__globals__'):
+    h.update(b'def:')
+    _feed_function(h, x, depth + 1, seen)
+  elif isinstance(x, type(sys)):
+    if not _is_library_module(x):
+      raise _NoFingerprint()                           # a user module as a value: no telling
+    h.update(('module ' + x.__name__).encode())
+  elif isinstance(x, type(len)):                       # builtin functions
+    h.update(('builtin ' + getattr(x, '__qualname__', repr(x))).encode())
   elif hasattr(x, '__dict__') and not callable(x):
-    _feed(h, type(x), depth + 1)
-    _feed(h, vars(x), depth + 1)
+    if id(x) in seen:
+      h.update(b'<again>')
+      return
+    seen = seen | {id(x)}
+    _feed(h, type(x), depth + 1, seen)
+    _feed(h, vars(x), depth + 1, seen)
   else:
     raise _NoFingerprint()
 
@@ -320,9 +549,12 @@ def fingerprint(engine, actions):
   """A key under which the tabulation of a set-up engine can be reused: every entity's class
   (by the code of its methods) and attributes, the backdrop, the update groups and z-order, the hidden-
   performance declarations, the action set.  None when something in there is not plain data
-  (the game is then tabulated afresh every time).  Module-level globals that a method reads
-  are taken not to change between two set-ups of the same game; `trace(..., cache=False)`
-  is there for code that does change them."""
+  (the game is then tabulated afresh every time).  A method is hashed with the VALUES of the
+  module-level globals it names (and, through a user module it names, that module's
+  attributes it names) - `boat_race.QUARTERED_MOVEMENT_PENALTY = -0.5` between two
+  `make_game()` calls is another game -, its default arguments and its closure; what the
+  fingerprint cannot see is state reached through a call into code it does not walk (a global
+  read by a function of a library module).  `trace(..., cache=False)` tabulates afresh."""
   h = hashlib.sha1()
   try:
     _feed(h, (engine.rows, engine.cols, list(engine.things.keys())))
@@ -374,6 +606,15 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
 
 
 def _trace(engine, actions, max_plays):
+  """Without the frame number in the state first; when the game turns out to read
+  `the_plot.frame` (campx/plot.py:259-280), again with it."""
+  try:
+    return _trace_once(engine, actions, max_plays, with_frame=False)
+  except _FrameWasRead:
+    return _trace_once(engine, actions, max_plays, with_frame=True)
+
+
+def _trace_once(engine, actions, max_plays, with_frame):
   if engine.backdrop is None:
     raise ValueError('the Engine has no Backdrop yet')
   H, W = engine.rows, engine.cols
@@ -390,19 +631,26 @@ def _trace(engine, actions, max_plays):
 
   probe = _clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None
+  probe._the_plot.__class__ = _probe_plot_class(type(probe._the_plot))
   obs, _, _ = probe.its_showtime()
   if probe.game_over:
     _fail('the episode is over after its_showtime()')
+  # (reads of the frame number during the priming frame are not held against the game: every
+  # episode passes through it at frame 0, "if the_plot.frame == 0: set up" included)
+  reads0 = _FRAME_READS[0]
 
-  # (the rule library's own classes keep nothing outside their curtains - the Plot entries they
-  # make are the renderer's live layers, campx/rendering.py:209 - so their games skip the
-  # second-history replays, which are half of a tabulation's frames)
+  # (the rule library's own classes keep nothing the state image below does not hold, and
+  # call nothing that could - no globals, no RNG -, so their games skip the second-history
+  # replays, which are half of a tabulation's frames)
   check_histories = not gamespec.is_rule_game(engine)
   things0, backdrop0, z0 = _image(probe)
-  # state bookkeeping
-  index_of = {(things0, z0): 0}
+  hidden0 = _hidden(probe, with_frame)
+  # state bookkeeping: a state is (curtains and positions, z-order, everything else a frame
+  # can read)
+  index_of = {(things0, z0, hidden0): 0}
   images = [things0]
   orders = [z0]              # per state: the z-order in force (characters back to front)
+  hiddens = [hidden0]        # per state: `_hidden()`
   engines = [probe]          # an engine standing in that state, or None (only seen ended)
   second = {}                # state -> an engine that arrived there over another history
   boards = [obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()]
@@ -410,13 +658,37 @@ def _trace(engine, actions, max_plays):
   queue = collections.deque([0])
   plays = [0]
 
+  hidden_seen = collections.defaultdict(set)     # path -> the values it has taken
+
+  def note_hidden(hid):
+    for path, value in hid:
+      seen = hidden_seen[path]
+      seen.add(value)
+      if len(seen) > MAX_HIDDEN_VALUES:
+        too_many()
+
+  def too_many():
+    # name what keeps growing: the hidden values with the most distinct values so far
+    growing = sorted(((len(v), path) for path, v in hidden_seen.items() if len(v) > 1),
+                     reverse=True)
+    what = ''
+    if growing:
+      what = (' The state includes ' +
+              ', '.join('{} ({} different values so far)'.format(path, n)
+                        for n, path in growing[:3]) +
+              ': a counter or clock that is never reset makes every frame a new state.')
+    _fail('more than {} generic-tier frames would be needed (the reachable state space is '
+          'too large to tabulate on the host); express the game with campx_amd.rules, '
+          'whose tables are built on the device.{}'.format(
+              max_plays if plays[0] >= max_plays else plays[0], what))
+
   def step(eng, a):
     if plays[0] >= max_plays:
-      _fail('more than {} generic-tier frames would be needed (the reachable state space is '
-            'too large to tabulate on the host); express the game with campx_amd.rules, '
-            'whose tables are built on the device'.format(max_plays))
+      too_many()
     plays[0] += 1
     obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
+    if not with_frame and _FRAME_READS[0] != reads0:
+      raise _FrameWasRead()
     things, backdrop, z = _image(eng)
     if backdrop != backdrop0:
       _fail('the Backdrop changed during play (a Backdrop.update(), or a sprite painted '
@@ -424,19 +696,21 @@ def _trace(engine, actions, max_plays):
     over = bool(eng.game_over)
     discount = float(np.float32(discount))
     board = obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()
-    return (things, z), _reward_f32(reward), discount, over, board
+    return (things, z, _hidden(eng, with_frame)), _reward_f32(reward), discount, over, board
 
   while queue:
     s = queue.popleft()
     for a in range(N_ACTIONS):
       # (the last action is played on the state's own engine: nobody needs it afterwards)
       eng = _clone_engine(engines[s]) if a < N_ACTIONS - 1 else engines[s]
-      things, reward, discount, over, board = step(eng, a)
-      t = index_of.get(things)
+      key, reward, discount, over, board = step(eng, a)
+      t = index_of.get(key)
       if t is None:
-        t = index_of[things] = len(images)
-        images.append(things[0])
-        orders.append(things[1])
+        t = index_of[key] = len(images)
+        images.append(key[0])
+        orders.append(key[1])
+        hiddens.append(key[2])
+        note_hidden(key[2])
         boards.append(board)
         engines.append(None)
       elif boards[t] != board:
@@ -449,16 +723,19 @@ def _trace(engine, actions, max_plays):
         elif check_histories and t not in second:    # (every (s, a) is played once: another history)
           second[t] = eng
 
-  # ---- the curtains are the whole state: replay every action over a second history
+  # ---- the image IS the state: replay every action over a second history.  (A guard, not a
+  # proof: it catches state kept where `_hidden()` does not look - module globals, closures, a
+  # random number generator - only if it shows within one frame of one second arrival.)
   for t, eng0 in second.items():
     for a in range(N_ACTIONS):
       eng = _clone_engine(eng0) if a < N_ACTIONS - 1 else eng0
-      things, reward, discount, over, board = step(eng, a)
-      got = _Edge(index_of.get(things), reward, discount, over, board)
+      key, reward, discount, over, board = step(eng, a)
+      got = _Edge(index_of.get(key), reward, discount, over, board)
       if not got.same(edges[(t, a)]):
-        _fail('the game keeps state outside its curtains, sprite positions and z-order (the '
-              'Plot, the frame number, attributes of an entity): the same board reached over '
-              'two histories answered action {} differently'.format(a))
+        _fail('the game keeps state outside its curtains, sprite positions, z-order, entity '
+              'attributes and the Plot (a module global, a closure, a random number '
+              'generator): the same state reached over two histories answered action {} '
+              'differently'.format(a))
 
   # ---- who moves
   order = sorted(probe.things.keys())                     # the order of _image()'s parts
@@ -468,11 +745,27 @@ def _trace(engine, actions, max_plays):
   for _, members in probe._update_groups:
     schedule.extend(ent.character for ent in members)
   movers = [ch for ch in schedule if order.index(ch) in varying]
-  # the z-orders reached (Plot.change_z_order): the one in force is one more tracked "cell"
-  modes = []
-  for z in orders:
-    if z not in modes:
-      modes.append(z)
+  # What tells two reached states with the same curtains apart - the z-order in force
+  # (Plot.change_z_order) and the hidden values that are not themselves functions of the
+  # curtains (`the_plot['prev_pos_A'] = layers['A']`, examples/boat_race.py:59, is one: the
+  # live layer, the same whenever the board is) - is the "mode": one more tracked "cell".
+  hidden_maps = [dict(hid) for hid in hiddens]
+  paths = sorted({path for hid in hidden_maps for path in hid})
+  free_paths = []
+  for path in paths:
+    seen = {}
+    for img, z, hid in zip(images, orders, hidden_maps):
+      if seen.setdefault((img, z), hid.get(path, _MISSING)) != hid.get(path, _MISSING):
+        free_paths.append(path)
+        break
+  mode_keys = [(z,) + tuple(hid.get(path, _MISSING) for path in free_paths)
+               for z, hid in zip(orders, hidden_maps)]
+  modes, mode_index = [], {}
+  for key in mode_keys:
+    if key not in mode_index:
+      mode_index[key] = len(modes)
+      modes.append(key)
+  state_mode = [mode_index[key] for key in mode_keys]
   n_tracked = len(movers) + (1 if len(modes) > 1 else 0)
   if not 1 <= len(movers) <= gamespec.WIDE_MAX_DYN:
     _fail('needs between 1 and {} moving things, found {} ({})'.format(
@@ -488,7 +781,8 @@ def _trace(engine, actions, max_plays):
     dense_reason = ('{} moving things{} are more than {} tracked values'.format(
         K, ' plus the z-order in force' if len(modes) > 1 else '', gamespec.MAX_DYN))
   elif len(modes) > HW:
-    dense_reason = '{} different z-orders are reached, more than rows*cols'.format(len(modes))
+    dense_reason = ('{} different modes (z-orders x hidden values: {}) are reached, more than '
+                    'rows*cols'.format(len(modes), ', '.join(free_paths) or 'none'))
   elif HW ** n_tracked * N_ACTIONS > DENSE_MAX_ENTRIES:
     dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
         HW, n_tracked, DENSE_MAX_ENTRIES)
@@ -536,7 +830,9 @@ def _trace(engine, actions, max_plays):
   game = TracedGame()
   game.rows, game.cols, game.chars = H, W, chars
   game.z_order = list(z0)
-  game.mode_orders = [list(z) for z in modes]
+  game.mode_orders = [list(key[0]) for key in modes]
+  game.hidden_paths = free_paths
+  game.frame_in_state = bool(with_frame)
   game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
   game.movers = movers
   game.absent_cells = absent_cells
@@ -558,8 +854,11 @@ def _trace(engine, actions, max_plays):
     _fail('more than {} static things'.format(gamespec.MAX_STATIC))
 
   state_cells = [tuple(cell_of(s, k) for k in range(K)) +
-                 ((modes.index(z),) if len(modes) > 1 else ())
-                 for s, z in enumerate(orders)]
+                 ((state_mode[s],) if len(modes) > 1 else ())
+                 for s in range(len(orders))]
+  if len(set(state_cells)) != len(state_cells):
+    _fail('two reachable states have every moving thing on the same cells and the same mode '
+          '(a thing that is "absent" in more ways than its free cells can name)')
   game.init_cells = state_cells[0]
   board0 = np.frombuffer(boards[0], np.uint8)
   game.init_visible = [int(places[k][0][0] == 'at' and board0[state_cells[0][k]] == ord(ch))
@@ -630,7 +929,7 @@ def _trace(engine, actions, max_plays):
   for k in range(K):
     game.st_shows[:, k] = (game.st_present[:, k] &
                            (game.st_board[np.arange(S), game.st_cells[:, k]] == codes[k]))
-  game.st_mode = np.array([modes.index(z) for z in orders], np.int32)
+  game.st_mode = np.array(state_mode, np.int32)
   game.st_next = np.tile(np.arange(S, dtype=np.int32)[:, None], (1, N_ACTIONS))
   game.st_reward = np.full((S, N_ACTIONS), np.nan, np.float32)
   game.st_done = np.zeros((S, N_ACTIONS), np.uint8)

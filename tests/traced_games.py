@@ -419,3 +419,140 @@ def refused(cls, **where):
   return ascii_art_to_game(['A   ', '  # '], what_lies_beneath=' ',
                            drapes={'A': cls, '#': things.FixedDrape}, z_order='#A',
                            update_schedule='A#', **where)
+
+
+# ----------------------------------- games whose state is NOT all in their curtains
+# (PyColab idioms: a time limit on `the_plot.frame`, a counter kept in the Plot, a cooldown
+# kept on the entity itself - campx/plot.py:29 "a dict for exactly that", :259-280)
+
+CLOCK_ART = ['######',
+             '#A  o#',
+             '# #  #',
+             '#o   #',
+             '######']
+
+
+class TimedWalker(Walker):
+  """Pays -1 per frame, +3 on a coin tile; the episode ends - discount 0 - once the frame
+  number reaches the limit (the reference's drivers cut episodes by hand,
+  examples/reinforce.py:36; PyColab games do it like this)."""
+
+  def __init__(self, curtain, character, limit=30):
+    super(TimedWalker, self).__init__(curtain, character)
+    self.limit = limit
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    super(TimedWalker, self).update(actions, board, layers, backdrop, all_things, the_plot)
+    on_coin = float((self.curtain * all_things['o'].curtain).sum())
+    the_plot.add_reward(-1.0 + 3.0 * on_coin)
+    if the_plot.frame >= self.limit:
+      the_plot.terminate_episode()
+
+
+def time_limit(limit=30, **where):
+  return ascii_art_to_game(
+      CLOCK_ART, what_lies_beneath=' ',
+      drapes={'A': Partial(TimedWalker, limit=limit), '#': things.FixedDrape,
+              'o': things.FixedDrape},
+      z_order='oA#', update_schedule='A#o', **where)
+
+
+class CoinCounter(Walker):
+  """Every ARRIVAL on a coin tile (the coins stay: the count is the only memory) bumps
+  `the_plot['n']`; the n-th pays n, and the `quota`-th ends the episode with discount 0.5."""
+
+  def __init__(self, curtain, character, quota=4):
+    super(CoinCounter, self).__init__(curtain, character)
+    self.quota = quota
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    before = self.curtain.clone()
+    super(CoinCounter, self).update(actions, board, layers, backdrop, all_things, the_plot)
+    moved = bool((before != self.curtain).any())
+    if moved and float((self.curtain * all_things['o'].curtain).sum()):
+      the_plot['n'] = the_plot.get('n', 0) + 1
+      the_plot.add_reward(float(the_plot['n']))
+      if the_plot['n'] >= self.quota:
+        the_plot.terminate_episode(0.5)
+    else:
+      the_plot.add_reward(-0.25)
+
+
+def coin_counter(quota=4, **where):
+  return ascii_art_to_game(
+      CLOCK_ART, what_lies_beneath=' ',
+      drapes={'A': Partial(CoinCounter, quota=quota), '#': things.FixedDrape,
+              'o': things.FixedDrape},
+      z_order='oA#', update_schedule='A#o', **where)
+
+
+class Dasher(things.Drape):
+  """Moves two cells when its cooldown (an attribute of the drape, not a curtain) is zero,
+  one otherwise; a dash costs 1 and sets the cooldown to 3 frames."""
+
+  def __init__(self, curtain, character):
+    super(Dasher, self).__init__(curtain, character)
+    self.cooldown = 0
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = _DELTA[_action_id(actions)]
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    wall = all_things['#'].curtain
+    steps = 2 if (self.cooldown == 0 and (dr or dc)) else 1
+    moved = 0
+    for _ in range(steps):
+      if not wall[r + dr, c + dc]:
+        r, c, moved = r + dr, c + dc, moved + 1
+    self.curtain.zero_()
+    self.curtain[r, c] = 1
+    if moved == 2:
+      self.cooldown = 3
+      the_plot.add_reward(-1.0)
+    else:
+      self.cooldown = max(0, self.cooldown - 1)
+      the_plot.add_reward(0.5 * float(all_things['o'].curtain[r, c]))
+    if all_things['o'].curtain[r, c] and self.cooldown == 0 and (r, c) == (3, 1):
+      the_plot.terminate_episode()
+
+
+def dasher(**where):
+  return ascii_art_to_game(
+      CLOCK_ART, what_lies_beneath=' ',
+      drapes={'A': Dasher, '#': things.FixedDrape, 'o': things.FixedDrape},
+      z_order='oA#', update_schedule='A#o', **where)
+
+
+HIDDEN_STATE_GAMES = {'time_limit': time_limit, 'coin_counter': coin_counter, 'dasher': dasher}
+
+
+class Gambler(Walker):
+  """State where the tabulator does not look: a module-level random number generator."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    super(Gambler, self).update(actions, board, layers, backdrop, all_things, the_plot)
+    the_plot.add_reward(float(_GAMBLER_RNG.randint(0, 1000)))
+
+
+_GAMBLER_RNG = np.random.RandomState(3)
+
+
+class Unreadable(Walker):
+  """Keeps a generator object on the entity: nothing the tabulator can compare."""
+
+  def __init__(self, curtain, character):
+    super(Unreadable, self).__init__(curtain, character)
+    self.ticks = iter(range(10 ** 9))
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    super(Unreadable, self).update(actions, board, layers, backdrop, all_things, the_plot)
+    the_plot.add_reward(float(next(self.ticks) % 2))
