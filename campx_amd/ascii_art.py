@@ -14,7 +14,9 @@ Behaviour kept from the reference:
 * a string `update_schedule` is split into characters and a flat schedule is one
   update group (ascii_art.py:182-186); groups are named '00000', '00001', ...
   (ascii_art.py:255-258);
-* default `z_order` is the flattened schedule (ascii_art.py:204);
+* default `z_order` is the flattened schedule (ascii_art.py:204); the default schedule itself
+  is the entity characters in ascending order (the reference: in `set` order, which varies
+  from process to process);
 * entities are added in schedule order, each character is then replaced in the
   art by `what_lies_beneath`, and what remains is the backdrop, whose palette is
   the set of characters left (ascii_art.py:266-307);
@@ -92,7 +94,9 @@ def ascii_art_to_game(art,
 
   # Normalise the schedule to a list of groups, each a list of characters.
   if update_schedule is None:
-    update_schedule = list(entity_chars)
+    # (the reference takes `list(set)`, ascii_art.py:178, whose order changes with
+    # PYTHONHASHSEED; ascending characters is one of those orders, and always the same one)
+    update_schedule = sorted(entity_chars)
   if isinstance(update_schedule, str):
     update_schedule = list(update_schedule)
   if all(isinstance(item, str) for item in update_schedule):

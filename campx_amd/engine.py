@@ -290,15 +290,27 @@ class Engine(object):
             'False) and has no CPU fallback; use batch=None for the '
             'single-environment generic tier')
       from . import gamespec
-      traced = None
+      traced, recognised = None, None
       big = self._rows * self._cols > gamespec.MAX_CELLS
       if not gamespec.is_rule_game(self) or (big and not gamespec.is_shape_rule_game(self)):
         # arbitrary Python update() bodies: tabulate them on the host (a deep copy of this
         # engine runs on the generic tier), then the table kernels take over.  Boards above
         # 128 cells go the same way whatever their classes (the device's rule interpreter
-        # stops there): one mover, the wide tier.
-        from . import tabulate
-        traced = tabulate.trace(self, actions=self._action_set)
+        # stops there): one mover, the wide tier.  Games of rigidly translating multi-cell
+        # things (the Hello World notebook's own classes) cannot be enumerated; they are
+        # recognised for the shape tier instead (campx_amd/recognise.py).
+        from . import recognise, tabulate
+        actions = recognise.detect_actions(self)
+        if recognise.looks_like_shapes(self, actions):
+          recognised = recognise.shapes(self, actions)
+        else:
+          try:
+            traced = tabulate.trace(self, actions=actions)
+          except tabulate.TabulationError as refusal:
+            try:
+              recognised = recognise.shapes(self, actions)
+            except recognise.RecogniseError as other:
+              raise tabulate.TabulationError('{} (and {})'.format(refusal, other))
     self._showtime = True
     self._update_groups = [(name, self._update_groups[name])
                            for name in sorted(self._update_groups.keys())]
@@ -315,7 +327,7 @@ class Engine(object):
       if traced is not None:
         self._fused = fused.FusedGame(self, self._batch, self._device, traced=traced)
         return self._fused.showtime()
-      description = gamespec.describe(self)
+      description = recognised if recognised is not None else gamespec.describe(self)
       if description.is_shape_game:   # Hello-World-style rules: the shape tier
         from . import shapes          # needs the HIP library; raises if it is missing
         self._fused = shapes.ShapeGame(self, self._batch, self._device, description)

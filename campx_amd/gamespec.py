@@ -465,6 +465,10 @@ def lower_shapes(desc):
         if not 0 <= p['quit_action'] < N_ACTIONS:
           _fail('{!r}: quit_action outside 0..{}'.format(e.char, N_ACTIONS - 1))
         t.terminate_mask = 1 << int(p['quit_action'])
+      for a in p.get('quit_actions', ()):        # (recognise.shapes: any set of actions)
+        if not 0 <= a < N_ACTIONS:
+          _fail('{!r}: quit action outside 0..{}'.format(e.char, N_ACTIONS - 1))
+        t.terminate_mask |= 1 << int(a)
     if i < spec.first_drape and t.visible:                     # the trail quirk
       for r, c in cells:
         backdrop[r, c] = t.layer

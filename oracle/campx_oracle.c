@@ -46,7 +46,7 @@
 #define ORACLE_MAX_SET 8
 
 enum { KIND_FIXED = 0, KIND_AGENT = 1, KIND_DIR_HOVER = 2, KIND_BOX = 3, KIND_GOAL = 4,
-       KIND_ROLLING = 5, KIND_SLIDING_SPRITE = 6 };
+       KIND_ROLLING = 5, KIND_SLIDING_SPRITE = 6, KIND_TRANSLATE = 7 };
 
 /* One sprite/drape, in update-schedule order. Plain-old-data: ctypes mirrors it. */
 typedef struct {
@@ -73,6 +73,15 @@ typedef struct {
   int32_t roll_axis[4], roll_shift[4]; /* ROLLING */
   int32_t dy[4], dx[4];                /* SLIDING_SPRITE */
   int32_t quit_action;                 /* ROLLING: -1 = none */
+  /* TRANSLATE: not a class of the reference - any user-written thing (drape or sprite) whose
+   * update() is "shift every cell by (t_dy[a], t_dx[a]) modulo the board; add_reward(t_reward[a])
+   * if bit a of t_has_reward; terminate_episode() if bit a of t_ends" for actions 0..4, run by
+   * the reference's ENGINE semantics like every other kind (update order, Plot, renderer with
+   * its trails).  tests/shape_local.py holds such classes; tests/golden/parade.npz is what the
+   * reference engine does with them. */
+  int32_t t_dy[5], t_dx[5];
+  float t_reward[5];
+  int32_t t_has_reward, t_ends;
 } OracleEntity;
 
 typedef struct {
@@ -283,6 +292,27 @@ static void update_entity(const OracleGame* g, Env* e, int k, int action, Direct
         const int c2 = ((at % W + en->dx[action]) % W + W) % W;
         memset(e->curtain[k], 0, (size_t)n);
         e->curtain[k][r2 * W + c2] = 1;
+      }
+      break;
+    }
+    case KIND_TRANSLATE: {
+      /* tests/shape_local.py: every cell moves by the action's offset, cyclically */
+      const int H = g->rows, W = g->cols;
+      if (action >= 0 && action < 5) {
+        memset(b, 0, (size_t)n);
+        for (int r = 0; r < H; ++r)
+          for (int c = 0; c < W; ++c)
+            if (e->curtain[k][r * W + c]) {
+              const int r2 = ((r + en->t_dy[action]) % H + H) % H;
+              const int c2 = ((c + en->t_dx[action]) % W + W) % W;
+              b[r2 * W + c2] = 1;
+            }
+        memcpy(e->curtain[k], b, (size_t)n);
+        if ((en->t_has_reward >> action) & 1) add_reward(d, en->t_reward[action]);
+        if ((en->t_ends >> action) & 1) {  /* plot.py:183-184 */
+          d->game_over = 1;
+          d->discount = 0.0f;
+        }
       }
       break;
     }

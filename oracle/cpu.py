@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, '_build', 'libcampx_oracle.so')
 
 MAX_CELLS, MAX_ENTITIES, MAX_CHARS, MAX_SET = 1024, 16, 32, 8
 KINDS = {'fixed': 0, 'agent': 1, 'dir_hover': 2, 'box': 3, 'goal': 4,
-         'rolling': 5, 'sliding_sprite': 6}
+         'rolling': 5, 'sliding_sprite': 6, 'translate': 7}
 
 
 class _Entity(ctypes.Structure):
@@ -39,7 +39,10 @@ class _Entity(ctypes.Structure):
               ('n_moves', ctypes.c_int32),
               ('roll_axis', ctypes.c_int32 * 4), ('roll_shift', ctypes.c_int32 * 4),
               ('dy', ctypes.c_int32 * 4), ('dx', ctypes.c_int32 * 4),
-              ('quit_action', ctypes.c_int32)]
+              ('quit_action', ctypes.c_int32),
+              ('t_dy', ctypes.c_int32 * 5), ('t_dx', ctypes.c_int32 * 5),
+              ('t_reward', ctypes.c_float * 5),
+              ('t_has_reward', ctypes.c_int32), ('t_ends', ctypes.c_int32)]
 
 
 class _Game(ctypes.Structure):
@@ -124,7 +127,11 @@ class OracleGame(object):
     for i, e in enumerate(desc.entities):
       en, p = g.entities[i], e.params
       kind = e.kind
-      if kind == 'shape':      # Hello World rules: a rolling drape or a sliding sprite
+      if kind == 'shape' and 'quit_actions' in p:
+        # a user-written translating thing, as campx_amd.recognise describes it: offsets on
+        # both axes, a reward per action, any set of ending actions (KIND_TRANSLATE)
+        kind = 'translate'
+      elif kind == 'shape':    # Hello World rules: a rolling drape or a sliding sprite
         kind = 'sliding_sprite' if p['sprite'] else 'rolling'
       en.kind, en.ch, en.group = KINDS[kind], ord(e.char), e.group
       en.visible, en.quit_action = 1, -1
@@ -155,6 +162,15 @@ class OracleGame(object):
         en.n_agents, en.agents[0] = 1, ord(p['agent'])
         en.step_reward = float(p['step_reward'])
         en.goal_reward = float(p['goal_reward'])
+      elif kind == 'translate':
+        en.visible, en.is_sprite = int(p['visible']), int(p['sprite'])
+        for a in range(5):
+          en.t_dy[a], en.t_dx[a] = int(p['drow'][a]), int(p['dcol'][a])
+          if p['rewards'][a] is not None:
+            en.t_has_reward |= 1 << a
+            en.t_reward[a] = float(p['rewards'][a])
+        for a in p['quit_actions']:
+          en.t_ends |= 1 << int(a)
       elif e.kind == 'shape':
         en.n_moves = len(p['drow'])
         assert en.n_moves <= 4

@@ -445,6 +445,28 @@ def gen_shape_zoo():
     save('shape_' + name, golden)
 
 
+def gen_shape_local():
+  """tests/shape_local.py: multi-cell things with plain Python update() bodies (no rule
+  classes), run by the reference's engine: what `campx_amd.recognise` has to reproduce on the
+  shape tier.  Also the CampxShapeSpec bytes of the notebook's own Hello World as the library
+  classes lower it (pinned to the notebook by gen_hello_world): `hello_world_spec.npz`."""
+  sys.path.insert(0, os.path.join(REPO, 'tests'))
+  import shape_local
+  acts = random_actions(1201, 60, 6, n_actions=4)
+  acts[:, 1] = random_actions(1202, 60, 1, n_actions=5)[:, 0]     # with quits
+  acts[:, 2] = 0                                                  # a long trail
+  acts[30:, 3] = 4                                                # quit, then quit on frame 0
+  golden = run(lambda: shape_local.build(to_game, ref.things), acts, to_action=int)
+  assert golden['done'].sum() > 10 and np.nansum(golden['reward']) != 0
+  save('parade', golden)
+  import ctypes
+  from campx_amd import gamespec
+  from campx_amd.games import hello_world as g_hw
+  spec = gamespec.lower_shapes(gamespec.describe(g_hw.build()))
+  blob = np.frombuffer(ctypes.string_at(ctypes.addressof(spec), ctypes.sizeof(spec)), np.uint8)
+  np.savez_compressed(os.path.join(HERE, 'hello_world_spec.npz'), spec=blob)
+
+
 def _walk_to_goal(art):
   """Action ids of a shortest walk from 'A' to 'G' over the cells that are not '#'."""
   import collections
@@ -496,6 +518,7 @@ if __name__ == '__main__':
   gen_sokoban_levels()
   gen_hello_world()
   gen_shape_zoo()
+  gen_shape_local()
   gen_big_rows()
   gen_maze()
   print('done; reference at', ref.campx.__file__)
