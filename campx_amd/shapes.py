@@ -108,9 +108,12 @@ class ShapeGame(object):
   def _ids(self, actions, expect):
     if not torch.is_tensor(actions):
       actions = torch.as_tensor(actions)
-    actions = actions.to(self.device)
     if actions.is_floating_point():
       raise ValueError('shape games take integer action ids, not one-hot vectors')
+    if actions.dim() == 0 and len(expect) == 1:
+      # ONE action for every environment: `game.play(0)`, Hello World notebook cell 6
+      actions = actions.to(torch.int64).clamp(-1, gamespec.N_ACTIONS).to(torch.int8).expand(expect)
+    actions = actions.to(self.device)
     if tuple(actions.shape) != tuple(expect):
       raise ValueError('action ids must have shape {}, got {}'.format(
           tuple(expect), tuple(actions.shape)))
