@@ -84,7 +84,20 @@ void want_rows(const Tensor& t, const char* name, at::ScalarType dtype, const c1
   TORCH_CHECK(t.dim() == 2 && t.size(0) == T && t.size(1) == B, "campx: ", name,
               " must have shape [", T, ", ", B, "], it has ", t.sizes());
   TORCH_CHECK(B == 1 || t.stride(1) == 1, "campx: ", name, " must be contiguous within a row");
-  if (T == 1) return;            // one row: its pitch is never used
+  if (T == 1) {
+    // One row: its own pitch is never used, but the call's pitch (taken from the planes of the
+    // trace, want_trace() runs first) decides whether the update kernels store the row's last
+    // 16-element group whole (row_extent()): the row must then reach that far.
+    const int64_t up = (B + 15) / 16 * 16;
+    if (pitch >= up) {
+      const int64_t room = static_cast<int64_t>(t.storage().nbytes() / t.element_size()) -
+                           t.storage_offset();
+      TORCH_CHECK(room >= up, "campx: ", name, " is a [1, ", B, "] row with room for ", room,
+                  " elements, but the call's trace has a padded row pitch (", pitch,
+                  "): the row must reach ", up, " elements (take every buffer from rollout_buffers())");
+    }
+    return;
+  }
   const int64_t p = t.stride(0);
   TORCH_CHECK(p >= B && (pitch == 0 || p == pitch), "campx: ", name, " has row pitch ", p,
               "; every per-frame stream of a call must have the same pitch >= B");

@@ -230,6 +230,11 @@ class FusedGame(object):
         and all(isinstance(x, (int, float)) and x in (0, 1) for x in actions) and sum(actions) == 1):
       # the reference's plain one-hot LIST, `game.play([1, 0, 0, 0, 0])` (Demo 1 cell 6): one
       # action for every environment.  (Five ENVIRONMENTS' ids go in as a tensor.)
+      if expect[0] == gamespec.N_ACTIONS and not any(isinstance(x, float) for x in actions):
+        raise ValueError(
+            'with batch == 5 a list of five 0/1 integers is ambiguous (one one-hot action for '
+            'every environment, or five action ids): pass a float list / tensor for a one-hot '
+            'action, an integer tensor for ids')
       actions = torch.tensor(actions, dtype=torch.float32)
     if not torch.is_tensor(actions):
       actions = torch.as_tensor(actions)

@@ -411,10 +411,14 @@ int campx_oracle_rollout(const OracleGame* g, int64_t B, int32_t T, const int8_t
         memcpy(e->curtain[k], curtains + (env * g->n_entities + k) * n, (size_t)n);
       for (int i = 0; i < n; ++i) e->backdrop[i] = backdrops ? backdrops[env * n + i] : g->backdrop[i];
     }
-    if (render(g, e) != 0) bad = 1;  /* the board the first frame's updates read */
+    if (render(g, e) != 0) {  /* the board the first frame's updates read */
+#pragma omp atomic write
+      bad = 1;
+    }
     for (int t = 0; t < T; ++t) {
       const int action = actions[(int64_t)t * B + env];
       if (action < 0 || action > 4) {
+#pragma omp atomic write
         bad = 1;
         break;
       }

@@ -106,3 +106,46 @@ def test_more_gpus_than_the_node_has_fails_fast_with_a_clear_message():
   assert r.returncode == 2
   assert '--gpus 2 asked for' in r.stderr and 'nothing was launched' in r.stderr
   assert not r.stdout.strip()
+
+
+# ------------------------------------------------------------------------------- GPU
+
+import pytest  # noqa: E402
+
+
+def _hip_devices():
+  import torch
+  return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_hip_devices() < 2, reason='needs two HIP devices (RCCL with more than one rank)')
+def test_two_rccl_ranks_through_the_real_launcher():
+  """BASELINE config 5's protocol on the smallest sharded world: `bench.py --gpus 2` starts two
+  ranks (one per GPU, RCCL over xGMI), each steps its own shard and the episode-return log is
+  all-gathered.  Skips on one-GPU boxes; the first lease of a multi-GPU node turns it into
+  evidence.  No scaling claim is made from it."""
+  r = _run(['--gpus', '2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-extras'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  cfg = line['config']
+  assert line['n_gpus'] == 2 and cfg['world'] == 2 and cfg['rccl_world'] == 2
+  assert cfg['global_batch'] == 2 * 65536 and line['scaling'] == 'weak'
+  assert cfg['per_rank_gathered_log_matches_local'] == [True, True]
+  assert cfg['gathered_log_matches_local'] is True
+  a, b = cfg['per_rank_ms_per_step']
+  assert abs(a - b) <= 0.10 * max(a, b), (a, b)
+  assert abs(max(a, b) - line['ms_per_step']) < 1e-6 * line['ms_per_step']
+  assert line['roofline']['frac'] > 0.3
+
+
+@pytest.mark.gpu
+def test_one_rccl_rank_through_the_real_launcher():
+  """What a one-GPU box CAN show of that path: the launcher, an RCCL group of one, the gather."""
+  r = _run(['--gpus', '1', '--force-dist', '--steps', '5', '--warmup', '2', '--no-cpu-baseline',
+            '--no-extras'])
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  assert line['config']['rccl_world'] == 1 and line['config']['gathered_log_matches_local'] is True
+  # the closing barrier is off the clock: the step time is the kernels' plus the host's share
+  assert line['ms_per_step'] < 1.10 * line['roofline']['kernel_ms']

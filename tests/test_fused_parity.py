@@ -11,6 +11,7 @@ import torch
 from campx_amd import gamespec
 from oracle import cpu
 from games_under_test import FUSED_GAMES
+from campx_amd.games import boat_race
 
 pytestmark = pytest.mark.gpu
 
@@ -144,6 +145,42 @@ def test_one_hot_actions_and_validation():
   bad[3] = 0.5
   with pytest.raises(ValueError):
     game.play(bad)
+
+@pytest.mark.gpu
+def test_five_environments_and_a_list_of_five_zero_one_integers_is_ambiguous():
+  """[0, 1, 0, 0, 0] with batch == 5: one one-hot action for all, or five ids?  Refused."""
+  game, _, _, _ = boat_race.make_game(batch=5, device='cuda')
+  with pytest.raises(ValueError, match='ambiguous'):
+    game.play([0, 1, 0, 0, 0])
+  _, reward, _ = game.play([0., 1., 0., 0., 0.])              # floats: a one-hot action
+  assert reward.shape == (5,)
+  game.play(torch.tensor([0, 1, 0, 0, 0]))                    # a tensor: five ids
+  other, _, _, _ = boat_race.make_game(batch=6, device='cuda')
+  other.play([0, 1, 0, 0, 0])                                 # any other batch: the one-hot list
+
+
+@pytest.mark.gpu
+def test_one_frame_rows_must_reach_the_padded_pitch_of_the_trace():
+  """A caller's own contiguous [1, B] reward beside a padded trace (B % 16 != 0): the update
+  kernels would store the row's last 16-element group whole - refused instead of written past
+  the end (the advisor's round-3 finding)."""
+  from campx_amd import _hip
+  from campx_amd.games import sokoban
+  B = 100
+  game = sokoban.build(batch=B, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  out = f.rollout_buffers(1)
+  if out['trace'] is None:
+    pytest.skip('the single fused kernel keeps no trace (no padded pitch to disagree with)')
+  assert out['trace'].stride(0) == 112
+  acts = torch.zeros((1, B), dtype=torch.int8, device='cuda')
+  f.rollout(acts, out=out)                                    # its own buffers: fine
+  tight = dict(out)
+  tight['reward'] = torch.empty((1, B), dtype=torch.float32, device='cuda')
+  with pytest.raises(RuntimeError, match='must reach 112 elements'):
+    f.rollout(acts, out=tight)
+
 
 
 def test_lazy_validation_of_one_hot_rows():
