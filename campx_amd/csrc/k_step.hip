@@ -125,6 +125,72 @@ constexpr int kRowsTableLoads = 5;   // the whole table: 5 KiB = 5 chunks per la
 #endif
 constexpr int kStepWaves = CAMPX_STEP_WAVES;
 
+// The wave's span of the frame out of its LDS image: 16 bytes per lane per store (a partial
+// group - the batch's last - element by element).  Shared by the row-group-major kernels.
+template <int kMaxChunks, int kBoardChunks, bool kBoard, int kFmt, bool kNT>
+__device__ __forceinline__ void rows_stream_out(const int8_t* obs_img, const int8_t* board_img,
+                                                const CampxOutputs& out, int64_t env0, uint32_t n,
+                                                uint32_t n_live, uint32_t R, uint32_t HW,
+                                                uint32_t n_obs, uint32_t lane) {
+  const uint32_t span = n * R;
+  constexpr uint32_t kElem = kFmt ? 2u : 1u;
+  int8_t* obs_dst = out.obs + env0 * (int64_t)(R * kElem);
+  int8_t* board_dst = kBoard ? out.board + env0 * (int64_t)HW : nullptr;
+  if (n_live == n) {           // (every wave but, perhaps, the batch's last)
+    if (kFmt == 0) {
+#pragma unroll
+      for (int j = 0; j < kMaxChunks; ++j) {
+        const uint32_t o = ((uint32_t)j * kWave + lane) * 16u;
+        if ((uint32_t)j < n_obs && o < span) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(obs_img + o);
+          if (kNT) store16_streaming_at(obs_dst, o, v);
+          else *reinterpret_cast<u32x4*>(obs_dst + o) = v;
+        }
+      }
+    } else {
+      // 16-bit observations (0.0 / 1.0 in f16 or bf16): 8 image bytes -> 16 output bytes
+      constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+#pragma unroll
+      for (int j = 0; j < 2 * kMaxChunks; ++j) {
+        const uint32_t o = ((uint32_t)j * kWave + lane) * 8u;
+        if ((uint32_t)j < 2u * n_obs && o < span) {
+          const uint2 b = *reinterpret_cast<const uint2*>(obs_img + o);
+          u32x4 v;
+          v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * kOne;
+          v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * kOne;
+          v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * kOne;
+          v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * kOne;
+          if (kNT) store16_streaming_at(obs_dst, 2u * o, v);
+          else *reinterpret_cast<u32x4*>(obs_dst + 2u * o) = v;
+        }
+      }
+    }
+    if (kBoard) {
+#pragma unroll
+      for (int j = 0; j < kBoardChunks; ++j) {
+        const uint32_t o = ((uint32_t)j * kWave + lane) * 16u;
+        if (o < n * HW)
+          *reinterpret_cast<u32x4*>(board_dst + o) = *reinterpret_cast<const u32x4*>(board_img + o);
+      }
+    }
+  } else {                     // a partial group: element by element
+    const uint32_t live = n_live * R;
+    if (kFmt == 0) {
+#pragma unroll 1
+      for (uint32_t i = lane; i < live; i += kWave) obs_dst[i] = obs_img[i];
+    } else {
+      const uint16_t one = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+#pragma unroll 1
+      for (uint32_t i = lane; i < live; i += kWave)
+        reinterpret_cast<uint16_t*>(obs_dst)[i] = obs_img[i] ? one : (uint16_t)0;
+    }
+    if (kBoard) {
+#pragma unroll 1
+      for (uint32_t i = lane; i < n_live * HW; i += kWave) board_dst[i] = board_img[i];
+    }
+  }
+}
+
 template <bool kBoard, int kFmt, bool kNT>
 __global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
     RowsParams rp, const CampxSpec* __restrict__ spec, CampxState st,
@@ -139,7 +205,7 @@ __global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
   const int64_t env0 = (int64_t)(blk * (uint32_t)kStepWaves + wave) * n;
   if (env0 >= B) return;   // (uniform per wave; waves share nothing)
   const uint32_t n_live = (B - env0 < (int64_t)n) ? (uint32_t)(B - env0) : n;
-  const uint32_t span = n * R, n_obs = (uint32_t)rp.n_obs, n_tab = (uint32_t)rp.n_tab;
+  const uint32_t n_obs = (uint32_t)rp.n_obs, n_tab = (uint32_t)rp.n_tab;
   int8_t* obs_img = lds + wave * ((n_obs + n_tab + (kBoard ? 1u : 0u)) << 10);
   int8_t* board_img = obs_img + (n_obs << 10);
   const uint2* lds_table = reinterpret_cast<const uint2*>(board_img + (kBoard ? 1024 : 0));
@@ -229,58 +295,190 @@ __global__ __launch_bounds__(kStepWaves * kWave) void step_rows_kernel(
     done_base[lane] = (uint8_t)done;
     if (st.ret) (st.ret + env0)[lane] = ret + real_reward(reward);
   }
-  // ---- out: the wave's span, 16 bytes per lane per store
-  constexpr uint32_t kElem = kFmt ? 2u : 1u;
-  int8_t* obs_dst = out.obs + env0 * (int64_t)(R * kElem);
-  int8_t* board_dst = kBoard ? out.board + env0 * (int64_t)HW : nullptr;
-  if (n_live == n) {           // (every wave but, perhaps, the batch's last)
-    if (kFmt == 0) {
+  rows_stream_out<kRowsMaxChunks, 1, kBoard, kFmt, kNT>(obs_img, board_img, out, env0, n, n_live, R, HW, n_obs, lane);
+  report_bad_actions(out, bad);
+}
+
+// ---------------------------------------------------------------------------
+// Row-group-major for games with two to four movers (and, as an A/B, one): the shape of
+// step_rows_kernel - a wave owns n consecutive environments with n * R about 3 KiB, every
+// independent load issued before the first wait - around the ONE dependent trip a K-mover
+// game cannot avoid: its (cell, ..., cell, action) table is megabytes, so the entry is a
+// gather from L2, issued as soon as the state has landed (the state loads go first, so that
+// waiting for them - vmcnt counts in order - does not wait for the scenery), and the scenery
+// chunks, the reward list (1 KiB) and the scenery's top layers (128 B) land in LDS under it.
+// Round 2's step_pair_kernel / step_tuple_kernel gave a wave 64 environments (18-21 KiB of
+// image: eight waves per CU, four launches' worth of serial stream per wave).
+struct DepParams {
+  int32_t dyn_layer[CAMPX_MAX_DYN], cell0[CAMPX_MAX_DYN], mover_char[CAMPX_MAX_DYN];
+  int32_t perf_scale, perf_offset;
+  uint32_t step_hw;     // 1024 % cells
+};
+
+constexpr int kDepMaxChunks = 8;     // a wave's observation span is at most 8 KiB (kChunks: 4, 6 or 8 loads per lane) ...
+constexpr int kDepBoardChunks = 2;   // ... and its flat boards 2 KiB
+
+template <int K, int kChunks, bool kBoard, int kFmt>
+__global__ __launch_bounds__(kWave) void step_rows_dep_kernel(
+    RowsParams rp, DepParams dp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t reset_first) {
+  extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t W = (uint32_t)rp.cols, HW = (uint32_t)rp.cells, R = (uint32_t)rp.R;
+  const uint32_t n = (uint32_t)rp.n;
+  // (block b runs on XCD b % 8: each XCD sweeps its own contiguous eighth of the frame)
+  const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t env0 = (int64_t)blk * n;
+  if (env0 >= B) return;
+  const uint32_t n_live = (B - env0 < (int64_t)n) ? (uint32_t)(B - env0) : n;
+  const uint32_t n_obs = (uint32_t)rp.n_obs;
+  int8_t* obs_img = lds;
+  int8_t* board_img = obs_img + (n_obs << 10);
+  float* lds_rewards = reinterpret_cast<float*>(board_img + (kBoard ? kDepBoardChunks * 1024 : 0));   // K > 1
+  uint8_t* lds_top = reinterpret_cast<uint8_t*>(lds_rewards + 256);                // K > 1
+
+  // ---- the state first (what the table index needs) ...
+  const bool mine = lane < n_live;
+  const uint32_t ln = mine ? lane : n_live - 1u;    // surplus lanes reload the last environment
+  uint8_t* done_base = st.done + env0;
+  const float* ret_src = st.ret ? st.ret + env0 : reinterpret_cast<const float*>(spec) - ln;
+  int a = (actions + env0)[ln];
+  int over = done_base[ln];
+  uint32_t cells[K];
+  int rr[K], cc[K];
 #pragma unroll
-      for (int j = 0; j < kRowsMaxChunks; ++j) {
-        const uint32_t o = ((uint32_t)j * kWave + lane) * 16u;
-        if ((uint32_t)j < n_obs && o < span) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(obs_img + o);
-          if (kNT) store16_streaming_at(obs_dst, o, v);
-          else *reinterpret_cast<u32x4*>(obs_dst + o) = v;
-        }
-      }
-    } else {
-      // 16-bit observations (0.0 / 1.0 in f16 or bf16): 8 image bytes -> 16 output bytes
-      constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+  for (int k = 0; k < K; ++k) {
+    rr[k] = (st.pos + (int64_t)(2 * k) * B + env0)[ln];
+    cc[k] = (st.pos + (int64_t)(2 * k + 1) * B + env0)[ln];
+  }
+  float ret = ret_src[ln];
+  // ---- ... then everything that does not depend on it
+  u32x4 v_obs[kChunks], v_board[kDepBoardChunks], rw4, top4;
+  {
+    const uint32_t pitch = ((R + 15u) & ~15u) + 16u;
+    const uint32_t x = lane * 16u;
+    uint32_t k = x - ((x * rp.inv_r) >> 24) * R;   // x % R
 #pragma unroll
-      for (int j = 0; j < 2 * kRowsMaxChunks; ++j) {
-        const uint32_t o = ((uint32_t)j * kWave + lane) * 8u;
-        if ((uint32_t)j < 2u * n_obs && o < span) {
-          const uint2 b = *reinterpret_cast<const uint2*>(obs_img + o);
-          u32x4 v;
-          v.x = ((b.x & 0xffu) | ((b.x << 8) & 0x00ff0000u)) * kOne;
-          v.y = (((b.x >> 16) & 0xffu) | ((b.x >> 8) & 0x00ff0000u)) * kOne;
-          v.z = ((b.y & 0xffu) | ((b.y << 8) & 0x00ff0000u)) * kOne;
-          v.w = (((b.y >> 16) & 0xffu) | ((b.y >> 8) & 0x00ff0000u)) * kOne;
-          if (kNT) store16_streaming_at(obs_dst, 2u * o, v);
-          else *reinterpret_cast<u32x4*>(obs_dst + 2u * o) = v;
-        }
+    for (int j = 0; j < kChunks; ++j) {
+      v_obs[j] = *reinterpret_cast<const u32x4*>(spec->rot_obs + ((k & 15u) * pitch + (k & ~15u)));
+      k += rp.step_r;
+      k = k >= R ? k - R : k;
+    }
+    if (kBoard) {   // n * HW <= 2 KiB (launcher)
+      const uint32_t bpitch = ((HW + 15u) & ~15u) + 16u;
+      uint32_t kb = x - ((x * rp.inv_hw) >> 24) * HW;
+#pragma unroll
+      for (int j = 0; j < kDepBoardChunks; ++j) {
+        v_board[j] = *reinterpret_cast<const u32x4*>(spec->rot_board + ((kb & 15u) * bpitch + (kb & ~15u)));
+        kb += dp.step_hw;
+        kb = kb >= HW ? kb - HW : kb;
       }
     }
-    if (kBoard && lane * 16u < n * HW)
-      *reinterpret_cast<u32x4*>(board_dst + lane * 16u) =
-          *reinterpret_cast<const u32x4*>(board_img + lane * 16u);
-  } else {                     // a partial group: element by element
-    const uint32_t live = n_live * R;
-    if (kFmt == 0) {
-#pragma unroll 1
-      for (uint32_t i = lane; i < live; i += kWave) obs_dst[i] = obs_img[i];
-    } else {
-      const uint16_t one = (kFmt == 1) ? 0x3C00u : 0x3F80u;
-#pragma unroll 1
-      for (uint32_t i = lane; i < live; i += kWave)
-        reinterpret_cast<uint16_t*>(obs_dst)[i] = obs_img[i] ? one : (uint16_t)0;
-    }
-    if (kBoard) {
-#pragma unroll 1
-      for (uint32_t i = lane; i < n_live * HW; i += kWave) board_dst[i] = board_img[i];
+    if (K > 1) {
+      rw4 = static_cast<const u32x4*>(st.pair_table)[lane];
+      top4 = reinterpret_cast<const u32x4*>(spec->static_top_layer)[lane & 7u];
     }
   }
+  // ---- the table entry: the one dependent trip.  (The empty asm statements pin the state
+  // loads where they were written - hipcc otherwise sinks some of them into the branch that
+  // uses them, behind a full wait; needing their values HERE costs a wait for them alone,
+  // vmcnt counts in order and they were issued first.)
+  asm volatile("" : "+v"(a), "+v"(over));
+#pragma unroll
+  for (int k = 0; k < K; ++k) asm volatile("" : "+v"(rr[k]), "+v"(cc[k]));
+  const int bad = (mine && (unsigned)a > 4u) ? 1 : 0;
+  a = ((unsigned)a > 4u) ? 4 : a;
+  over = reset_first ? 1 : over;       // a finished episode is rebuilt from the art first
+  ret = over ? 0.0f : ret;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    cells[k] = over ? (uint32_t)dp.cell0[k] : (uint32_t)rr[k] * W + (uint32_t)cc[k];
+  uint32_t idx = cells[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) idx = idx * HW + cells[k];
+  idx = idx * CAMPX_N_ACTIONS + (uint32_t)a;
+  uint32_t e_lo, e_hi = 0;     // K = 1: CampxTransition {reward bits, cell | done | perf | paint}
+  if (K == 1) {
+    const uint2 tr = reinterpret_cast<const uint2*>(spec->table)[idx];
+    e_lo = tr.y;
+    e_hi = tr.x;
+  } else if (K == 2) {
+    e_lo = (reinterpret_cast<const uint32_t*>(static_cast<const float*>(st.pair_table) + 256))[idx];
+  } else {
+    const uint2 e = (reinterpret_cast<const uint2*>(static_cast<const float*>(st.pair_table) + 256))[idx];
+    e_lo = e.x;
+    e_hi = e.y;
+  }
+  // ---- land the scenery under it (LDS operations of a wave complete in order: no barrier)
+#pragma unroll
+  for (int j = 0; j < kChunks; ++j) asm volatile("" : "+v"(v_obs[j]));
+  u32x4* img_dst = reinterpret_cast<u32x4*>(obs_img) + lane;
+#pragma unroll
+  for (int j = 0; j < kChunks; ++j)
+    if ((uint32_t)j < n_obs) img_dst[j * kWave] = v_obs[j];             // uniform condition
+  if (kBoard) {
+#pragma unroll
+    for (int j = 0; j < kDepBoardChunks; ++j)
+      reinterpret_cast<u32x4*>(board_img)[j * kWave + lane] = v_board[j];
+  }
+  if (K > 1) {
+    reinterpret_cast<u32x4*>(lds_rewards)[lane] = rw4;
+    if (lane < 8u) reinterpret_cast<u32x4*>(lds_top)[lane] = top4;
+  }
+  // ---- decode, patch this lane's environment, scalars and state
+  float reward;
+  uint32_t done, dcode, perf_byte_v, shows = 0;
+  if (K == 1) {
+    reward = __uint_as_float(e_hi);
+    cells[0] = e_lo & 0xffu;
+    done = (e_lo >> 8) & 1u;
+    dcode = (e_lo >> 12) & 15u;
+    perf_byte_v = (e_lo >> 16) & 0xffu;
+    shows = ((e_lo >> 31) & 1u) ^ 1u;
+  } else if (K == 2) {
+    cells[0] = e_lo & 0x7fu;
+    cells[1] = (e_lo >> 7) & 0x7fu;
+    shows = (e_lo >> 14) & 3u;
+    done = (e_lo >> 16) & 1u;
+    dcode = dcode_pair(e_lo);
+    perf_byte_v = (uint32_t)((int)perf_code_pair(e_lo) * dp.perf_scale + dp.perf_offset);
+    reward = lds_rewards[(e_lo >> 19) & 0xffu];
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) cells[k] = (e_lo >> (7 * k)) & 0x7fu;
+    shows = (e_lo >> 28) & 15u;
+    done = e_hi & 1u;
+    dcode = dcode_tuple(e_hi);
+    perf_byte_v = (uint32_t)((int)perf_code_tuple(e_hi) * dp.perf_scale + dp.perf_offset);
+    reward = lds_rewards[(e_hi >> 3) & 0xffu];
+  }
+  if (mine) {
+    int8_t* my_obs = obs_img + lane * R;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if ((shows >> k) & 1u) {   // it is the character its cell shows
+        const uint32_t c = cells[k];
+        const uint32_t under = (K == 1) ? ((e_lo >> 24) & 0x7fu) : (uint32_t)lds_top[c];
+        my_obs[under * HW + c] = 0;
+        my_obs[(uint32_t)dp.dyn_layer[k] * HW + c] = 1;
+        if (kBoard) board_img[lane * HW + c] = (int8_t)dp.mover_char[k];
+      }
+    }
+    if (out.reward) (out.reward + env0)[lane] = reward;
+    if (out.discount)
+      (out.discount + env0)[lane] = dcode ? spec->discount_list[dcode] : (done ? 0.0f : 1.0f);
+    if (out.done) (out.done + env0)[lane] = (uint8_t)done;
+    if (out.perf) (out.perf + env0)[lane] = (int8_t)perf_byte_v;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t row = (cells[k] * rp.inv_w) >> 16;
+      (st.pos + (int64_t)(2 * k) * B + env0)[lane] = (int8_t)row;
+      (st.pos + (int64_t)(2 * k + 1) * B + env0)[lane] = (int8_t)(cells[k] - row * W);
+    }
+    done_base[lane] = (uint8_t)done;
+    if (st.ret) (st.ret + env0)[lane] = ret + real_reward(reward);
+  }
+  rows_stream_out<kChunks, kDepBoardChunks, kBoard, kFmt, false>(obs_img, board_img, out, env0, n, n_live, R, HW, n_obs, lane);
   report_bad_actions(out, bad);
 }
 
@@ -476,10 +674,24 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   report_bad_actions(out, bad);
 }
 
+// A/B: bytes of observation a wave of the row-group-major kernels aims at (default 3072)
+static const int g_step_span = [] {
+  const char* v = getenv("CAMPX_STEP_SPAN");
+  const int x = (v && *v) ? atoi(v) : 0;      // 0: each kernel's own default
+  return x <= 0 ? 0 : (x < 256 ? 256 : x);
+}();
+// A/B: one-mover games through step_rows_kernel (round 3: the table copied to LDS) instead of
+// step_rows_dep_kernel (a dependent trip for the table entry)
+static const bool g_step_tab1 = [] {
+  const char* v = getenv("CAMPX_STEP_LDS_TABLE");
+  return v && v[0] == '1';
+}();
+
 // Environments per wave of step_rows_kernel for this game, or 0 when its rows do not fit the
 // kernel's shape: n * R and (with a board) n * HW must be multiples of 16 bytes - 8 for the
 // 16-bit formats -, n <= 64, the observation span at most 4 KiB and the board span 1 KiB.
-int rows_per_wave(const CampxSpec& s, bool board, int fmt) {
+int rows_per_wave(const CampxSpec& s, bool board, int fmt, int max_chunks = kRowsMaxChunks,
+                  int board_chunks = 1, int target = 0) {
   const int HW = s.rows * s.cols, R = s.n_layers * HW;
   auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
   const int unit = fmt ? 8 : 16;
@@ -488,11 +700,14 @@ int rows_per_wave(const CampxSpec& s, bool board, int fmt) {
     const int nb = 16 / gcd(HW, 16);
     n0 = n0 / gcd(n0, nb) * nb;   // lcm
   }
-  if (n0 > kWave || n0 * R > kRowsMaxChunks * 1024 || (board && n0 * HW > 1024) || R < 16 || HW < 4)
+  if (n0 > kWave || n0 * R > max_chunks * 1024 || (board && n0 * HW > board_chunks * 1024) ||
+      R < 16 || HW < 4)
     return 0;
-  // about 3 KiB of observation per wave, in whole multiples of n0
-  int n = n0 * (3072 / (n0 * R) > 0 ? 3072 / (n0 * R) : 1);
-  while (n > n0 && (n > kWave || (board && n * HW > 1024))) n -= n0;
+  // about `target` bytes of observation per wave, in whole multiples of n0
+  if (target <= 0) target = g_step_span > 0 ? g_step_span : 3072;
+  if (target > max_chunks * 1024) target = max_chunks * 1024;
+  int n = n0 * (target / (n0 * R) > 0 ? target / (n0 * R) : 1);
+  while (n > n0 && (n > kWave || (board && n * HW > board_chunks * 1024))) n -= n0;
   return n;
 }
 
@@ -565,12 +780,92 @@ int32_t launch_step_rows(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
+// Environments per wave of step_rows_dep_kernel: spans of up to 8 KiB (measured, B = 65 536,
+// kernel us at spans of 3 / 4 / 8 KiB on one box: wall world 11.5 / 10.5 / 10.6, sokoban with
+// three boxes 10.0 / 9.3 / 8.2, with two 8.3 / 7.7 / 7.7, boat race 6.5 / 6.4 / 6.4;
+// profiles/r04_play_rocprofv3.txt).
+int dep_rows_per_wave(const CampxSpec& s, bool board, int fmt) {
+  return rows_per_wave(s, board, fmt, kDepMaxChunks, kDepBoardChunks, g_step_span > 0 ? g_step_span : 8192);
+}
+
+int32_t launch_step_rows_dep(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                             const int8_t* actions, CampxOutputs out, int64_t B,
+                             int32_t reset_first, int n, hipStream_t stream) {
+  const int HW = s.rows * s.cols, R = s.n_layers * HW, K = s.n_dyn;
+  const bool board = out.board != nullptr;
+  RowsParams rp;
+  rp.cols = s.cols;
+  rp.cells = HW;
+  rp.R = R;
+  rp.dyn_layer = s.dyn_layer[0];
+  rp.cell0 = s.dyn_row0[0] * s.cols + s.dyn_col0[0];
+  rp.mover_char = s.layer_char[s.dyn_layer[0]];
+  rp.n = n;
+  rp.n_tab = 0;
+  rp.n_obs = (n * R + 1023) / 1024;
+  rp.inv_w = (65536u + (uint32_t)s.cols - 1u) / (uint32_t)s.cols;
+  rp.inv_r = ((1u << 24) + (uint32_t)R - 1u) / (uint32_t)R;
+  rp.inv_hw = ((1u << 24) + (uint32_t)HW - 1u) / (uint32_t)HW;
+  rp.step_r = 1024u % (uint32_t)R;
+  DepParams dp;
+  memset(&dp, 0, sizeof(dp));
+  for (int d = 0; d < K; ++d) {
+    dp.dyn_layer[d] = s.dyn_layer[d];
+    dp.cell0[d] = s.dyn_row0[d] * s.cols + s.dyn_col0[d];
+    dp.mover_char[d] = s.layer_char[s.dyn_layer[d]];
+  }
+  dp.perf_scale = s.perf_scale;
+  dp.perf_offset = s.perf_offset;
+  dp.step_hw = 1024u % (uint32_t)HW;
+  size_t shmem = 1024 * (size_t)(rp.n_obs + (board ? kDepBoardChunks : 0)) + (K > 1 ? 1024 + 128 : 0);
+  if (g_step_lds_kb * 1024 > shmem) shmem = g_step_lds_kb * 1024;
+  const int64_t waves = (B + n - 1) / n;
+  const dim3 grid((unsigned)((waves + 7) & ~(int64_t)7)), block(kWave);
+#define CAMPX_DEP4(KK, CH, BOARD, FMT)                                                             \
+  do {                                                                                             \
+    CAMPX_ALLOW_LDS((step_rows_dep_kernel<KK, CH, BOARD, FMT>), shmem);                            \
+    hipLaunchKernelGGL((step_rows_dep_kernel<KK, CH, BOARD, FMT>), grid, block, shmem, stream, rp, \
+                       dp, spec_dev, st, actions, out, B, reset_first);                            \
+  } while (0)
+#define CAMPX_DEP3(KK, BOARD, FMT)                                                     \
+  do {                                                                                 \
+    if (rp.n_obs <= 4) CAMPX_DEP4(KK, 4, BOARD, FMT);                                  \
+    else if (rp.n_obs <= 6) CAMPX_DEP4(KK, 6, BOARD, FMT);                             \
+    else CAMPX_DEP4(KK, 8, BOARD, FMT);                                                \
+  } while (0)
+#define CAMPX_DEP2(KK, BOARD)                                            \
+  do {                                                                   \
+    if (out.obs_format == CAMPX_OBS_F16) CAMPX_DEP3(KK, BOARD, 1);       \
+    else if (out.obs_format == CAMPX_OBS_BF16) CAMPX_DEP3(KK, BOARD, 2); \
+    else CAMPX_DEP3(KK, BOARD, 0);                                       \
+  } while (0)
+#define CAMPX_DEP(KK)                                     \
+  do {                                                    \
+    if (board) CAMPX_DEP2(KK, true); else CAMPX_DEP2(KK, false); \
+  } while (0)
+  if (K == 1) CAMPX_DEP(1);
+  else if (K == 2) CAMPX_DEP(2);
+  else if (K == 3) CAMPX_DEP(3);
+  else CAMPX_DEP(4);
+#undef CAMPX_DEP
+#undef CAMPX_DEP2
+#undef CAMPX_DEP3
+#undef CAMPX_DEP4
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
 int32_t launch_step_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                           const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
                           hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
   if (!g_no_rows_kernel) {
+    if (!g_step_tab1) {
+      const int nd = dep_rows_per_wave(s, board, out.obs_format);
+      if (nd > 0)
+        return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, nd, stream);
+    }
     const int n = rows_per_wave(s, board, out.obs_format);
     if (n > 0) return launch_step_rows(s, spec_dev, st, actions, out, B, reset_first, n, stream);
   }
@@ -596,6 +891,10 @@ int32_t launch_step_pair(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
                          hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
+  if (!g_no_rows_kernel) {
+    const int n = dep_rows_per_wave(s, board, out.obs_format);
+    if (n > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, n, stream);
+  }
   const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
@@ -618,6 +917,10 @@ int32_t launch_step_tuple(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
                           hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
+  if (!g_no_rows_kernel) {
+    const int n = dep_rows_per_wave(s, board, out.obs_format);
+    if (n > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, n, stream);
+  }
   const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const TupleParams tp = make_tuple_params(s);

@@ -215,8 +215,7 @@ def _thing_mask(ent, H, W):
 
 def looks_like_shapes(engine, actions):
   """One frame of every action from the start: True when the cell-indexed / state tables
-  cannot be the right home for this game - a DRAPE that moves covers more or less than one
-  cell, or a visible sprite is painted before the first drape (it writes into the backdrop,
+  cannot be the right home for this game - a DRAPE that moves covers more than one cell, or a visible sprite is painted before the first drape (it writes into the backdrop,
   campx/rendering.py:128,150) - so that a batched Engine asks `shapes()` first instead of
   walking `tabulate.trace()` into its refusal."""
   H, W = engine.rows, engine.cols
@@ -236,7 +235,8 @@ def looks_like_shapes(engine, actions):
         if isinstance(ent, _things.Sprite):
           continue
         after = _thing_mask(ent, H, W)
-        if not np.array_equal(after, before[ch]) and (before[ch].sum() != 1 or after.sum() != 1):
+        # (a drape that empties - a coin collected - is the tabulator's "absent" thing)
+        if not np.array_equal(after, before[ch]) and (before[ch].sum() > 1 or after.sum() > 1):
           return True
   except Exception:       # noqa: BLE001 - let the tabulator report what is wrong with the game
     return False

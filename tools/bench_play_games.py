@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch
 from campx_amd.games import boat_race, sokoban, wall_world
 for name, build in (('boat_race', boat_race.build), ('sokoban', sokoban.build), ('sokoban_l1', lambda **k: sokoban.build(level=1, **k)), ('sokoban_l2', lambda **k: sokoban.build(level=2, **k)), ('wall_world', wall_world.build)):
-  for B in (1024, 65536):
+  for B in (1024, 65536, 131072):
     game = build(batch=B, device='cuda'); game.its_showtime()
     f = game.fused; f.validate_actions = False
     acts = torch.randint(0, 5, (8, B), dtype=torch.int8, device='cuda')
