@@ -46,7 +46,8 @@ class CampxOutputs(ctypes.Structure):
               ('done', ctypes.c_void_p), ('perf', ctypes.c_void_p),
               ('trace', ctypes.c_void_p), ('obs_format', ctypes.c_int32),
               ('bad_count', ctypes.c_void_p), ('bad_flag', ctypes.c_void_p),
-              ('scalar_pitch', ctypes.c_int64)]
+              ('scalar_pitch', ctypes.c_int64),
+              ('overlap_ctl', ctypes.c_void_p), ('overlap_ctl_bytes', ctypes.c_int64)]
 
 
 class CampxError(RuntimeError):
@@ -62,6 +63,8 @@ def _load():
   spec_p = ctypes.POINTER(CampxSpec)
   i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
   lib.campx_spec_size.restype = i32
+  lib.campx_overlap_ctl_bytes.restype = i64
+  lib.campx_overlap_ctl_bytes.argtypes = [i64]
   lib.campx_spec_size.argtypes = []
   lib.campx_spec_validate.restype = i32
   lib.campx_spec_validate.argtypes = [spec_p]

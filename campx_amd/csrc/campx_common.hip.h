@@ -549,6 +549,13 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
                       int32_t reset_first, bool use_table, int64_t trace_plane,
                       hipStream_t stream);
 
+// k_update.hip: update pass and render of a small-batch rollout in one persistent launch
+bool overlap_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table);
+int64_t overlap_ctl_bytes(int64_t B);
+int32_t launch_overlap(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                       const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                       int32_t reset_first, int64_t trace_plane, hipStream_t stream);
+
 // k_render.hip: the observation stream of the two-kernel path
 // Where a render launch finds a game's tables (k_render.hip).
 struct RenderSource {

@@ -210,7 +210,8 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
              const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions, Tensor& obs,
              const OptTensor& board, const OptTensor& reward, const OptTensor& discount,
              const OptTensor& step_done, const OptTensor& perf, const OptTensor& trace,
-             const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first) {
+             const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first,
+             const OptTensor& scratch) {
   const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
   TORCH_CHECK(actions.dim() == 2, "campx::rollout: actions must be int8 [T, B]");
   const int64_t T = actions.size(0);
@@ -249,6 +250,14 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
   out.trace = opt_ptr<uint8_t>(trace);
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, g.dev);
+  if (scratch.has_value()) {   // CampxOutputs.overlap_ctl: zeroed once by its owner
+    TORCH_CHECK(scratch->device() == g.dev && scratch->scalar_type() == at::kInt &&
+                    scratch->is_contiguous() && scratch->numel() * 4 >= campx_overlap_ctl_bytes(g.B),
+                "campx::rollout: scratch must be a contiguous int32 tensor on ", g.dev, " of at least ",
+                campx_overlap_ctl_bytes(g.B), " bytes");
+    out.overlap_ctl = reinterpret_cast<uint32_t*>(scratch->data_ptr());
+    out.overlap_ctl_bytes = scratch->numel() * 4;
+  }
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
   check_ok(campx_rollout_launch(g.spec_host, g.spec_dev, g.state, reinterpret_cast<const int8_t*>(actions.data_ptr()),
                                 out, g.B, (int32_t)T, reset_first ? 1 : 0,
@@ -570,7 +579,7 @@ void reset_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&
 void rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
                   const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                   const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
-                  const OptTensor&, bool) {}
+                  const OptTensor&, bool, const OptTensor&) {}
 void step_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
                const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&) {}
@@ -626,7 +635,7 @@ TORCH_LIBRARY(campx, m) {
       "rollout(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
       "Tensor? pair_table, Tensor actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
       "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!)? trace, "
-      "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first) -> ()");
+      "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first, Tensor(m!)? scratch=None) -> ()");
   m.def(
       "update(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
       "Tensor? pair_table, Tensor actions, Tensor(d!)? reward, Tensor(e!)? discount, "

@@ -3,6 +3,7 @@
 // update_tuple_kernel) and launch_update, which picks one (or the interpreter in trace mode).
 #include "campx_common.hip.h"
 
+#include <stdio.h>
 #include <type_traits>
 
 namespace campx_impl {
@@ -277,38 +278,43 @@ constexpr int update_min_waves(int, int) { return CAMPX_UPD_MINWAVES; }
 //   * -DCAMPX_UPD_DEBUG=1 (no global stores at all) saves 0.8 us: it is not the memory system.
 // Hence 8 consumer waves instead of 4 for the 256-environment workgroups (B = 4 096: 14.9 ->
 // 12.9 us; T = 256: 29.0 -> 23.5); at B = 65 536 the kernel reads 16.3-16.7 us either way.
-// The composed chain stays as an A/B build (default off: it only adds LDS and instructions).
-#ifndef CAMPX_UPD_COMPOSE
-#define CAMPX_UPD_COMPOSE 1
-#endif
+// (The composed chain was an A/B build through round 3; round 4 removed it with its knob.)
 
-template <int kProd, int kCons, int kG>   // kG: frames per group (a ring slot)
-__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
-                             update_min_waves(kProd, kCons)) void update_table_kernel(
-    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
-    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, FrameCodec fc) {
-  constexpr int kLoad = update_loaders(kProd);
-  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
-  // LDS entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
+// LDS of an update workgroup of the one-mover kernel (a struct, so that the overlapped
+// rollout kernel - k_overlap: this body as one role of a persistent launch - can lay its other
+// role's windows over the same bytes).
+template <int kProd, int kG>
+struct UpdateTableLds {
+  // entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
   // from (the art's cell when this frame ended the episode: the rebuild is folded into
   // the chain), [16:22] the cell after this frame, [23] whether the mover shows there,
   // [24] done, [25:26] + [31] hidden-performance code, [27:30] discount code.  The ring keeps
   // x and the upper half of y.
-  __shared__ uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
-#if CAMPX_UPD_COMPOSE == 2
-  static_assert(kG % 2 == 0, "frames are chained in pairs");
-  __shared__ uint8_t table2[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS * CAMPX_N_ACTIONS];
-#endif
-  __shared__ float discounts[16];
-  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
-  __shared__ __attribute__((aligned(16))) float ring_r[2][kG][E];
-  __shared__ __attribute__((aligned(16))) uint16_t ring_y[2][kG][E];
+  uint2 table[CAMPX_MAX_CELLS * CAMPX_N_ACTIONS];
+  float discounts[16];
+  __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * kProd * kWave];
+  __attribute__((aligned(16))) float ring_r[2][kG][kProd * kWave];
+  __attribute__((aligned(16))) uint16_t ring_y[2][kG][kProd * kWave];
+};
+
+// The body of update_table_kernel.  `wg`: which kEnvs environments this workgroup owns.
+// `progress` (overlapped rollouts only, else null): after every group of kG frames whose
+// streams - the trace among them - have been written AND acknowledged (the stores are
+// write-through), the number of complete groups is published there with an agent-scope store:
+// what a render wave of the same launch polls before it reads those rows of the trace.
+template <int kProd, int kCons, int kG, bool kPublish>
+__device__ __forceinline__ void update_table_body(
+    UpdateTableLds<kProd, kG>& L, uint32_t wg, uint32_t* progress,
+    const MoverParams& mp, const CampxSpec* __restrict__ spec, const CampxState& st,
+    const int8_t* __restrict__ actions, const CampxOutputs& out, int64_t B, int32_t T,
+    int32_t reset_first, const FrameCodec& fc) {
+  constexpr int kLoad = update_loaders(kProd);
+  constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave >= kProd + kCons;
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
   const int W = mp.cols, HW = mp.rows * mp.cols;
-  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
+  const int64_t env0 = (int64_t)wg * E;
 
   const int cell0 = mp.row0 * W + mp.col0;
   constexpr int kRowBytes = CAMPX_N_ACTIONS * (int)sizeof(uint2);
@@ -319,16 +325,16 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     const uint32_t vis = (tr.paint & 0x80u) ? 0u : 1u;  // scenery in front hides the mover
     // (the table holds perf VALUES; a game without hidden performance has scale 0)
     const uint32_t pc = fc.perf_scale ? (uint32_t)(((int)tr.perf - fc.perf_offset) / fc.perf_scale) & 7u : 0u;
-    table[i] = make_uint2(__float_as_uint(tr.reward),
+    L.table[i] = make_uint2(__float_as_uint(tr.reward),
                           (from * kRowBytes) | ((uint32_t)tr.next_cell << 16) | (vis << 23) |
                               (ended << 24) | ((pc & 3u) << 25) | (dcode << 27) | ((pc >> 2) << 31));
   }
-  if (threadIdx.x < 16) discounts[threadIdx.x] = fc.discounts[threadIdx.x];
+  if (threadIdx.x < 16) L.discounts[threadIdx.x] = fc.discounts[threadIdx.x];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
     ld.issue(actions, B, T, 0, env0, llane);
-    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
+    bad += ld.land(L.staged[0], actions, B, T, 0, env0, llane);
   }
 
   const int le = wave * kWave + lane;  // producers: this lane's environment in the workgroup
@@ -343,21 +349,10 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   }
   uint32_t row_off = (uint32_t)(over ? cell0 : cell) * kRowBytes;  // the chain's state
   uint32_t last_y = ((uint32_t)cell << 16) | ((uint32_t)over << 24);  // upper half of the latest entry
-  const char* table_bytes = reinterpret_cast<const char*>(table);
+  const char* table_bytes = reinterpret_cast<const char*>(L.table);
   const int clane = (int)threadIdx.x - kProd * kWave;  // consumers: 0 .. CL-1
   constexpr int kGroupsPerChunk = kChunk / kG;
   __syncthreads();
-#if CAMPX_UPD_COMPOSE == 2
-  constexpr int kPairs = CAMPX_N_ACTIONS * CAMPX_N_ACTIONS;
-  for (int i = threadIdx.x; i < HW * kPairs; i += kThreads) {
-    const int c = i / kPairs, p = i - c * kPairs, a1 = p / CAMPX_N_ACTIONS, a2 = p - a1 * CAMPX_N_ACTIONS;
-    const uint32_t from1 = table[c * CAMPX_N_ACTIONS + a1].y & 0xffffu;        // a row's byte offset
-    const uint32_t from2 = table[from1 / (uint32_t)sizeof(uint2) + a2].y & 0xffffu;
-    table2[i] = (uint8_t)(from2 / kRowBytes);
-  }
-  uint32_t chain = (uint32_t)(over ? cell0 : cell);   // the cell the next frame starts from
-  __syncthreads();
-#endif
 
   const int n_groups = (T + kG - 1) / kG;
   // Each kind of wave runs its own loop (one s_barrier per group in each, so the counts
@@ -367,7 +362,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     for (int g = 0; g <= n_groups; ++g) {
         if (g < n_groups) {
           const int t0 = g * kG;
-          const int8_t* chunk = staged[(t0 / kChunk) & 1];
+          const int8_t* chunk = L.staged[(t0 / kChunk) & 1];
           const int n = (T - t0 < kG) ? T - t0 : kG;
           uint32_t col_off[kG];  // action * sizeof(entry), off the dependent chain
   #pragma unroll
@@ -385,38 +380,12 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             constexpr bool kFull = decltype(full_tag)::value;
             auto book = [&](int j, uint2 e) {
               if (kFull || j < n) {
-                ring_r[g & 1][j][le] = __uint_as_float(e.x);
-                ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
+                L.ring_r[g & 1][j][le] = __uint_as_float(e.x);
+                L.ring_y[g & 1][j][le] = (uint16_t)(e.y >> 16);
                 ret = (((last_y >> 24) & 1u) ? 0.0f : ret) + real_reward(__uint_as_float(e.x));
                 last_y = e.y;
               }
             };
-#if CAMPX_UPD_COMPOSE == 2
-            uint32_t pair_of[kG / 2];   // (action, action) of each pair of frames, off the chain
-  #pragma unroll
-            for (int jp = 0; jp < kG / 2; ++jp)
-              pair_of[jp] = (col_off[2 * jp] * CAMPX_N_ACTIONS + col_off[2 * jp + 1]) / (uint32_t)sizeof(uint2);
-            // Software-pipelined by hand: the lookups of one step are issued together - where
-            // the pair after this one starts (the chain), that pair's first entry, this pair's
-            // second entry - so a step costs ONE LDS round trip.  Entries past the group's last
-            // frame are looked up and dropped.
-            uint32_t next_start = table2[chain * kPairs + pair_of[0]];
-            uint2 e1 = *reinterpret_cast<const uint2*>(table_bytes + chain * kRowBytes + col_off[0]);
-  #pragma unroll
-            for (int jp = 0; jp < kG / 2; ++jp) {
-              const int j = 2 * jp;
-              const uint32_t start = next_start;
-              const uint2 ea = e1;
-              if (jp + 1 < kG / 2) {
-                next_start = table2[start * kPairs + pair_of[jp + 1]];
-                e1 = *reinterpret_cast<const uint2*>(table_bytes + start * kRowBytes + col_off[j + 2]);
-              }
-              const uint2 eb = *reinterpret_cast<const uint2*>(table_bytes + (ea.y & 0xffffu) + col_off[j + 1]);
-              book(j, ea);
-              book(j + 1, eb);
-              if (kFull || j < n) chain = start;      // (where the frame after this pair starts)
-            }
-#else
   #pragma unroll
             for (int j = 0; j < kG; ++j) {
               if (kFull || j < n) {
@@ -426,7 +395,6 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 book(j, e);
               }
             }
-#endif
           };
 #if defined(CAMPX_UPD_DEBUG) && CAMPX_UPD_DEBUG == 3
           if (T < 0) frames(std::true_type{});
@@ -462,14 +430,14 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             const int j = item / QA, q = item % QA;
             const int64_t e0 = env0 + 4 * q;
             if (j < n && e0 < B) {
-              const u32x4 r4 = *reinterpret_cast<const u32x4*>(&ring_r[rb][j][4 * q]);
-              const uint2 y4 = *reinterpret_cast<const uint2*>(&ring_y[rb][j][4 * q]);
+              const u32x4 r4 = *reinterpret_cast<const u32x4*>(&L.ring_r[rb][j][4 * q]);
+              const uint2 y4 = *reinterpret_cast<const uint2*>(&L.ring_y[rb][j][4 * q]);
               const uint32_t y[4] = {y4.x & 0xffffu, y4.x >> 16, y4.y & 0xffffu, y4.y >> 16};
               uint32_t dc[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 dc[i] = ((y[i] >> 8) & 1u) ? 0u : 0x3f800000u;
-                if (fc.has_dcodes) dc[i] = discount_bits(discounts, dcode_y16(y[i]), (y[i] >> 8) & 1u);
+                if (fc.has_dcodes) dc[i] = discount_bits(L.discounts, dcode_y16(y[i]), (y[i] >> 8) & 1u);
               }
               const int64_t at = (int64_t)(t0 + j) * P + e0;
               if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
@@ -495,8 +463,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             const int j = item / QB, q = item % QB;
             const int64_t e0 = env0 + 16 * q;
             if (item < kG * QB && j < n && e0 < B) {
-              const u32x4 ya = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q]);
-              const u32x4 yb = *reinterpret_cast<const u32x4*>(&ring_y[rb][j][16 * q + 8]);
+              const u32x4 ya = *reinterpret_cast<const u32x4*>(&L.ring_y[rb][j][16 * q]);
+              const u32x4 yb = *reinterpret_cast<const u32x4*>(&L.ring_y[rb][j][16 * q + 8]);
               const uint32_t w[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
               uint32_t tr[4], dn[4], pf[4];
   #pragma unroll
@@ -530,8 +498,14 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             }
           }
         }
-      
+      if (kPublish) {
+        // every stream of the group stored above has been acknowledged (write-through stores):
+        // +2.3 us per 100 frames on the kernel alone (B = 4 096: 12.9 -> 15.3 us)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __syncthreads();
+      if (kPublish && g > 0 && clane == 0)
+        __hip_atomic_store(progress, (uint32_t)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     for (int g = 0; g <= n_groups; ++g) {
@@ -541,7 +515,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
         if (t_next < T) {
           if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
           if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+            bad += ld.land(L.staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
         }
       
       __syncthreads();
@@ -557,6 +531,19 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     if (st.ret) st.ret[env] = ret;
   }
   report_bad_actions(out, bad);
+}
+
+
+template <int kProd, int kCons, int kG>   // kG: frames per group (a ring slot)
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             update_min_waves(kProd, kCons)) void update_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, FrameCodec fc) {
+  __shared__ UpdateTableLds<kProd, kG> L;
+  update_table_body<kProd, kCons, kG, false>(L, tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD),
+                                             nullptr, mp, spec, st, actions, out, B, T,
+                                             reset_first, fc);
 }
 
 // ---------------------------------------------------------------------------
@@ -1178,6 +1165,355 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
   return CAMPX_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Overlapped rollouts for small and middle batches (round 4).  Below ~32 K environments the
+// update pass is a latency chain that leaves the chip almost empty (B = 4 096: 16 workgroups
+// for 12.9 us, whatever the batch size) and the render kernel behind it cannot start before
+// it ends: two dependent launches, ~25 us of which nothing streams (profiles/r03_sweep.txt:
+// boat race 0.33 of peak at B = 4 096, 0.62 at 16 384).  Here both run in ONE persistent
+// launch of 2 workgroups per CU:
+//   * a workgroup takes a TICKET when it starts; the first U tickets are the update
+//     workgroups (update_table_body, unchanged but for publishing), the others render;
+//   * an update workgroup publishes, after each group of 16 frames, how many groups of its
+//     256 environments' trace are complete in memory: write-through (`sc0 sc1`) stores,
+//     `s_waitcnt vmcnt(0)`, workgroup barrier, agent-scope flag store
+//     (/opt/skills/guides/MI355X_MICROARCH.md, valid producer forms);
+//   * a render wave owns 2 KiB windows of the observation stream, frame-major (item i of
+//     render workgroup r: r + i * R_n), and before it reads a window's rows of the trace it
+//     polls the flag(s) of the update workgroup(s) those rows belong to (relaxed agent-scope
+//     loads, `s_sleep` between polls); the trace itself is read with agent-scope loads
+//     (`sc1`: not from this CU's L1, which may hold a line whose other half was written later).
+// No workgroup ever waits for one that has not started (tickets are handed out to RUNNING
+// workgroups, update workgroups wait for nobody), so the launch cannot deadlock whatever the
+// dispatch order.  The last workgroup to leave zeroes the control block for the next launch.
+// Scope: one-mover table games, int8 observations kept for every frame, frames that are whole
+// 16-byte chunks; the flat board (if asked for) is rendered by the ordinary kernel afterwards.
+// Anything else takes the two-launch path.
+constexpr int kOvProd = 4, kOvCons = 8, kOvGroup = 16;
+constexpr int kOvWaves = kOvProd + kOvCons + update_loaders(kOvProd);     // 14
+constexpr int kOvEnvs = kOvProd * kWave;                                   // 256
+constexpr int kOvChunks = 4;                                               // KiB per wave and step
+constexpr uint32_t kOvSpan = 1024u * kOvChunks;                            // a wave's window
+constexpr int kOvMaxUpdate = 1024;    // update workgroups of one launch (B <= 262 144)
+
+struct OverlapRender {
+  uint32_t R, m, sh1, sh2, slab_bytes, shift_base, shift_slab;
+  int32_t cells, dyn_off;
+  int64_t pitch;               // rows of the trace from one frame to the next
+  const int8_t* rot;
+  const uint8_t* top_layer;
+  const uint8_t* trace;
+  int8_t* dst;
+  int32_t T;
+  uint32_t per_frame;          // workgroup-items (kOvWaves windows) per frame
+  uint32_t U;                  // update workgroups
+  uint32_t* ctl;               // [0] tickets, [1] finished, [4 + u] groups complete of workgroup u
+};
+
+__global__ __launch_bounds__(kOvWaves * kWave) void overlap_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, FrameCodec fc, OverlapRender rr) {
+  __shared__ UpdateTableLds<kOvProd, kOvGroup> L;
+  __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_known[kOvMaxUpdate];
+  static_assert(sizeof(L) >= kOvWaves * (kOvSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&rr.ctl[0], 1u);
+  __syncthreads();
+  const uint32_t ticket = s_ticket;
+  if (ticket < rr.U) {
+    update_table_body<kOvProd, kOvCons, kOvGroup, true>(L, ticket, rr.ctl + 4 + ticket, mp, spec, st,
+                                                        actions, out, B, T, reset_first, fc);
+  } else {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int8_t* win0 = reinterpret_cast<int8_t*>(&L) + wave * (kOvSpan + 2 * CAMPX_MAX_CELLS);
+    uint16_t* scen_off = reinterpret_cast<uint16_t*>(win0 + kOvSpan);
+    // what this workgroup knows of the update workgroups' progress: polled from memory by wave
+    // 0 only, read from LDS by the others (7 000 waves polling one line each on their own
+    // slowed the whole launch fourfold)
+    for (uint32_t u = threadIdx.x; u < rr.U; u += kOvWaves * kWave) s_known[u] = 0u;
+    const uint32_t R = rr.R;
+    const uint32_t rot_pitch = ((R + 15u) & ~15u) + 16u;
+    {   // where the scenery's 1 that the mover hides sits, per cell (once per wave)
+      const uint32_t top2 = *reinterpret_cast<const uint16_t*>(rr.top_layer + 2u * lane);
+      const uint32_t c = 2u * lane;
+      const uint32_t lo = (top2 & 0xffu) * (uint32_t)rr.cells + c;
+      const uint32_t hi2 = (top2 >> 8) * (uint32_t)rr.cells + c + 1u;
+      *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
+    }
+    __syncthreads();
+    const uint32_t n_render = gridDim.x - rr.U;
+    const uint32_t n_items = rr.per_frame ? (uint32_t)rr.T * rr.per_frame : 0u;
+    const uint32_t* progress = rr.ctl + 4;
+    // (one KiB per workgroup: every wave of the launch storing into ONE KiB cost 30 us at B = 1 024)
+    int8_t* sink = reinterpret_cast<int8_t*>(rr.ctl + ((4u + rr.U + 3u) & ~3u)) + (size_t)(blockIdx.x & 1023u) * 1024u;
+    const uint32_t last_env = (uint32_t)(B - 1);
+
+    // One window of one item: where it is, which rows of which frame it needs.
+    struct Win {
+      uint32_t t, woff0, first_row, last_row, slots;
+      bool live;
+    };
+    auto locate = [&](uint32_t item) {
+      Win w;
+      w.t = item / rr.per_frame;
+      const uint32_t wx = item - w.t * rr.per_frame;
+      // windows are aligned in MEMORY (see render_kernel): `shift` bytes before the frame
+      const uint32_t shift = (rr.shift_base + w.t * rr.shift_slab) & (kOvSpan - 1u);
+      const uint32_t base = wx * (uint32_t)kOvWaves;
+      // ---- progress: the rows of ALL the item's windows (wave 0 polls for everybody)
+      {
+        const uint64_t lo64 = (uint64_t)base * kOvSpan, hi64 = (uint64_t)(base + kOvWaves) * kOvSpan - 1u;
+        const uint32_t blo = lo64 < shift ? 0u : (uint32_t)(lo64 - shift);
+        uint32_t bhi = hi64 < shift ? 0u : (uint32_t)(hi64 - shift);
+        bhi = bhi < rr.slab_bytes ? bhi : rr.slab_bytes - 1u;
+        const uint32_t h1 = __umulhi(rr.m, blo), h2 = __umulhi(rr.m, bhi);
+        const uint32_t r_lo = (((blo - h1) >> rr.sh1) + h1) >> rr.sh2;
+        uint32_t r_hi = (((bhi - h2) >> rr.sh1) + h2) >> rr.sh2;
+        r_hi = r_hi < last_env ? r_hi : last_env;
+        const uint32_t need = w.t / (uint32_t)kOvGroup + 1u;
+        if (blo <= bhi && lo64 < (uint64_t)rr.slab_bytes + shift) {
+          for (uint32_t u = r_lo / (uint32_t)kOvEnvs; u <= r_hi / (uint32_t)kOvEnvs; ++u) {
+            if (wave == 0u) {
+              uint32_t seen = __hip_atomic_load(&s_known[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              while (seen < need) {
+                seen = __hip_atomic_load(progress + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen < need) {
+                  // (a group takes the update pass ~1.5-2 us; one poller per workgroup: a few
+                  // hundred polls per us chip-wide)
+                  if (need - seen > 1u) __builtin_amdgcn_s_sleep(64);
+                  else __builtin_amdgcn_s_sleep(16);
+                }
+              }
+              __hip_atomic_store(&s_known[u], seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              while (__hip_atomic_load(&s_known[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                __builtin_amdgcn_s_sleep(16);
+            }
+          }
+        }
+      }
+      const uint32_t widx = base + wave;
+      w.live = (uint64_t)widx * kOvSpan < (uint64_t)rr.slab_bytes + shift;
+      w.woff0 = widx * kOvSpan - shift;
+      const uint32_t wlo = widx * kOvSpan < shift ? 0u : w.woff0;
+      const uint32_t whi = __umulhi(rr.m, wlo);
+      w.first_row = (((wlo - whi) >> rr.sh1) + whi) >> rr.sh2;
+      const uint32_t wend = (w.woff0 + kOvSpan - 1u < rr.slab_bytes) ? w.woff0 + kOvSpan - 1u : rr.slab_bytes - 1u;
+      const uint32_t ehi = __umulhi(rr.m, wend);
+      w.last_row = (((wend - ehi) >> rr.sh1) + ehi) >> rr.sh2;
+      w.slots = (w.last_row - w.first_row + 1u) * 2u;     // (row) x (set | clear)
+      // (a window past the frame's end goes through the motions: its stores land in the sink)
+      if (!w.live) { w.first_row = 0; w.last_row = 0; w.slots = 0; w.woff0 = 0xffff0000u; }
+      return w;
+    };
+    // The loads of a window: two trace bytes (agent scope: not from L1) and two scenery chunks.
+    auto issue = [&](const Win& w, uint32_t (&ent)[2], u32x4 (&scen)[kOvChunks]) {
+      const uint8_t* frame_trace = rr.trace + (int64_t)w.t * rr.pitch;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        uint32_t row = w.first_row + ((lane + (uint32_t)it * kWave) >> 1);
+        row = row <= w.last_row ? row : w.last_row;
+        // (the aligned dword the byte sits in: a byte-sized atomic load comes with a mask
+        // instruction that hipcc places right behind it, i.e. a wait for the load just issued)
+        ent[it] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(frame_trace + (row & ~3u)),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int j = 0; j < kOvChunks; ++j) {
+        const uint32_t off = w.woff0 + (uint32_t)j * 1024u + lane * 16u;
+        const uint32_t hi = __umulhi(rr.m, off);
+        const uint32_t row = (((off - hi) >> rr.sh1) + hi) >> rr.sh2;
+        const uint32_t k = off - row * R;
+        scen[j] = *reinterpret_cast<const u32x4*>(rr.rot + (k & 15u) * rot_pitch + (k & ~15u));
+      }
+    };
+
+    auto finish = [&](const Win& w, const uint32_t (&ent)[2], const u32x4 (&scen)[kOvChunks]) {
+#pragma unroll
+      for (int j = 0; j < kOvChunks; ++j)
+        *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16u) = scen[j];
+      auto apply = [&](uint32_t sidx, uint32_t e) {
+        const uint32_t r = sidx >> 1, p = sidx & 1u;
+        const uint32_t cell = e & 0x7fu;
+        const uint32_t byte = p ? (uint32_t)rr.dyn_off + cell : (uint32_t)scen_off[cell];
+        const uint32_t at = (w.first_row + r) * R + byte - w.woff0;
+        if (sidx < w.slots && (e >> 7) && at < kOvSpan) win0[at] = (int8_t)p;
+      };
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        uint32_t row = w.first_row + ((lane + (uint32_t)it * kWave) >> 1);
+        row = row <= w.last_row ? row : w.last_row;
+        apply(lane + (uint32_t)it * kWave, (ent[it] >> ((row & 3u) * 8u)) & 0xffu);
+      }
+      const uint8_t* frame_trace = rr.trace + (int64_t)w.t * rr.pitch;
+      for (uint32_t sidx = lane + 2u * kWave; sidx < w.slots; sidx += kWave)     // tiny rows only
+        apply(sidx, (uint32_t)__hip_atomic_load(frame_trace + w.first_row + (sidx >> 1),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      // ---- out: aligned, contiguous KiB stores
+      const int8_t* frame = rr.dst + (int64_t)w.t * rr.slab_bytes;
+#pragma unroll
+      for (int j = 0; j < kOvChunks; ++j) {
+        // UNCONDITIONAL (a lane outside the frame stores into the control block's sink): a
+        // store under a branch is one hipcc cannot count, and the next wait for loads would
+        // then wait for this window's stores as well
+        const uint32_t off = w.woff0 + (uint32_t)j * 1024u + lane * 16u;
+        const bool inside = off < rr.slab_bytes;
+        int8_t* at = inside ? const_cast<int8_t*>(frame) + off : sink + lane * 16u;
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16u),
+                                    reinterpret_cast<u32x4*>(at));
+      }
+    };
+
+    // Software-pipelined over the workgroup's items, two register sets taking turns (no copy
+    // between them: a copy would wait for the loads it copies): the loads of item i + 1 are
+    // issued BEFORE the stores of item i, so that waiting for them (vmcnt counts in order)
+    // never waits for those stores to be acknowledged.
+    uint32_t item = ticket - rr.U;
+    Win wa, wb;
+    uint32_t ea[2], eb[2];
+    u32x4 sa[kOvChunks], sb[kOvChunks];
+    if (item < n_items) {
+      wa = locate(item);
+      issue(wa, ea, sa);
+      if (item + n_render < n_items) {
+        wb = locate(item + n_render);
+        issue(wb, eb, sb);
+        finish(wa, ea, sa);
+        item += n_render;
+        // Invariant: set B holds the loads of `item`, behind the stores of the window before
+        // it.  The steady state has no conditional issue and no conditional store, and the
+        // loop is entered in the state its back edge leaves: hipcc then counts what is in
+        // flight exactly (`s_waitcnt vmcnt(7)` / `vmcnt(6)`) and a wait for loads never
+        // includes the stores issued before them.
+        while (item + 2u * n_render < n_items) {
+          wa = locate(item + n_render);
+          issue(wa, ea, sa);
+          finish(wb, eb, sb);
+          wb = locate(item + 2u * n_render);
+          issue(wb, eb, sb);
+          finish(wa, ea, sa);
+          item += 2u * n_render;
+        }
+        if (item + n_render < n_items) {
+          wa = locate(item + n_render);
+          issue(wa, ea, sa);
+          finish(wb, eb, sb);
+          finish(wa, ea, sa);
+        } else {
+          finish(wb, eb, sb);
+        }
+      } else {
+        finish(wa, ea, sa);
+      }
+    }
+  }
+  // ---- the last workgroup out resets the control block
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t gone = atomicAdd(&rr.ctl[1], 1u);
+    if (gone == gridDim.x - 1u) {
+      for (uint32_t u = 0; u < rr.U; ++u)
+        __hip_atomic_store(rr.ctl + 4 + u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rr.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rr.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// OFF by default: measured SLOWER than the two launches at every batch size (round 4, boat
+// race, us per 100-frame rollout, two launches / overlapped: B = 1 024 21 / 30, 4 096 28 / 41,
+// 8 192 38 / 50, 16 384 61 / 75; profiles/r04_overlap_ab.txt).  The update role runs at its
+// stand-alone speed inside the launch (16 us), but the render role's long-lived waves - one
+// 14-wave workgroup per CU, all the update body's 106 VGPRs allow - stream at 3-4 TB/s where the
+// one-shot render kernel's 32 short waves per CU reach 6.4, which costs more than hiding the
+// update pass saves.  CAMPX_OVERLAP=1 turns it on (CAMPX_OVERLAP_MAX_B: the largest batch it
+// takes, default 16 384); tests/test_overlap.py keeps it bit-exact.
+static const int64_t g_overlap_max_b = [] {
+  const char* on = getenv("CAMPX_OVERLAP");
+  if (!on || on[0] != '1') return (int64_t)0;
+  const char* v = getenv("CAMPX_OVERLAP_MAX_B");
+  return (int64_t)(v && *v ? atoll(v) : 16384);
+}();
+
+int64_t overlap_ctl_bytes(int64_t B) {
+  // header (16 bytes), one progress word per update workgroup, padding, the render role's sink
+  return 16 + 4 * ((B + kOvEnvs - 1) / kOvEnvs) + 16 + 1024 * 1024;   // (1 024 workgroups' sinks)
+}
+
+// Whether launch_overlap() takes this rollout (one-mover table game; see the kernel's scope).
+bool overlap_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table) {
+  const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
+  if (!use_table || s.n_dyn != 1 || !out.overlap_ctl || B > g_overlap_max_b) return false;
+  if (B > (int64_t)kOvMaxUpdate * kOvEnvs) return false;     // (the progress table's LDS copy)
+  if (B > (int64_t)64 * kOvEnvs) return false;   // update workgroups take at most a quarter of the CUs
+  if (out.overlap_ctl_bytes < overlap_ctl_bytes(B) || (reinterpret_cast<uintptr_t>(out.overlap_ctl) & 15)) return false;
+  if (out.obs_format != CAMPX_OBS_INT8 || out.obs_t_stride != B * R) return false;
+  if ((B * R) % 16 != 0 || T < 2 * kOvGroup || T > 65535) return false;
+  // (the render role reads the trace as aligned dwords)
+  if (row_pitch(out, B) % 4 != 0 || (reinterpret_cast<uintptr_t>(out.trace) & 3)) return false;
+  return true;
+}
+
+int32_t launch_overlap(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                       const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                       int32_t reset_first, int64_t trace_plane, hipStream_t stream) {
+  // workgroups of this kernel the device holds at once (per CU: 1 with today's 106 VGPRs):
+  // the grid is exactly that many, so that every render workgroup is running from the start
+  // (one that started only after another had left would hold EARLY items and render them late)
+  static const int n_resident = [] {
+    int dev = 0, n = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, overlap_table_kernel, kOvWaves * kWave, 0) !=
+            hipSuccess || per_cu < 1)
+      per_cu = 1;
+    return (n > 0 ? n : 256) * per_cu;
+  }();
+  const int HW = s.rows * s.cols;
+  const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                          s.dyn_row0[0], s.dyn_col0[0]};
+  const FrameCodec fc = make_codec(s);
+  OverlapRender rr;
+  memset(&rr, 0, sizeof(rr));
+  rr.R = (uint32_t)(s.n_layers * HW);
+  uint32_t l = 0;
+  while ((1ull << l) < rr.R) ++l;
+  rr.m = (uint32_t)(((1ull << 32) * ((1ull << l) - rr.R)) / rr.R + 1);   // as launch_render_from
+  rr.sh1 = l < 1 ? l : 1;
+  rr.sh2 = l > 0 ? l - 1 : 0;
+  rr.slab_bytes = (uint32_t)(B * rr.R);
+  rr.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(out.obs) & (kOvSpan - 1u));
+  rr.shift_slab = rr.slab_bytes & (kOvSpan - 1u);
+  rr.cells = HW;
+  rr.dyn_off = s.dyn_layer[0] * HW;
+  rr.pitch = row_pitch(out, B);
+  const char* blob = reinterpret_cast<const char*>(spec_dev);
+  rr.rot = reinterpret_cast<const int8_t*>(blob + offsetof(CampxSpec, rot_obs));
+  rr.top_layer = reinterpret_cast<const uint8_t*>(blob + offsetof(CampxSpec, static_top_layer));
+  rr.trace = out.trace;
+  rr.dst = out.obs;
+  rr.T = T;
+  const uint64_t reach = (uint64_t)rr.slab_bytes + ((rr.shift_base | rr.shift_slab) ? kOvSpan - 1u : 0u);
+  const uint64_t block_span = (uint64_t)kOvSpan * kOvWaves;
+  rr.per_frame = (uint32_t)((reach + block_span - 1) / block_span);
+  rr.U = (uint32_t)((B + kOvEnvs - 1) / kOvEnvs);
+  rr.ctl = out.overlap_ctl;
+  (void)trace_plane;
+  const uint64_t items = (uint64_t)T * rr.per_frame;
+  if ((int64_t)rr.U * 2 > n_resident) return CAMPX_EINVAL;   // (overlap_ok keeps such batches away)
+  uint64_t n_render = (uint64_t)n_resident - rr.U;
+  if (n_render > items && items > 0) n_render = items;
+  if (n_render < 1) n_render = 1;
+  const dim3 grid((unsigned)(rr.U + n_render)), block(kOvWaves * kWave);
+  hipLaunchKernelGGL(overlap_table_kernel, grid, block, 0, stream, mp, spec_dev, st, actions, out, B,
+                     T, reset_first, fc, rr);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
 }  // namespace campx_impl

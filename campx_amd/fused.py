@@ -172,6 +172,13 @@ class FusedGame(object):
     self.validate_actions = True
     self.frame = -1
     self._observation_cache = self._observation(self._obs, self._board)
+    # control block of overlapped small-batch rollouts (CampxOutputs.overlap_ctl; an A/B path,
+    # measured slower than two launches and off unless CAMPX_OVERLAP=1): zeroed once here,
+    # left zeroed by every launch; this game's own (its rollouts are ordered anyway)
+    self._overlap_ctl = None
+    if os.environ.get('CAMPX_OVERLAP', '0') == '1':
+      self._overlap_ctl = torch.zeros((int(_hip.lib.campx_overlap_ctl_bytes(B)) + 3) // 4,
+                                      dtype=torch.int32, device=dev)
     self._step = _hip.ops.step.default
     self._rollout = _hip.ops.rollout.default
     self._update = _hip.ops.update.default
@@ -477,7 +484,7 @@ class FusedGame(object):
                     self._pair_table, ids, out['obs'], out['board'], out['reward'],
                     out['discount'], out['done'], out['perf'], out['trace'],
                     self._bad if validate else None,
-                    self._bad_flag if validate else None, bool(reset_first))
+                    self._bad_flag if validate else None, bool(reset_first), self._overlap_ctl)
     self.frame = T if reset_first else self.frame + T
     if validate:
       self._after_launch()

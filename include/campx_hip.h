@@ -250,7 +250,21 @@ typedef struct CampxOutputs {
                          row used: every row then starts aligned and the kernels write whole
                          16-byte groups (the pad holds unspecified values).  `actions` and the
                          observation / board frames are never padded. */
+  uint32_t* overlap_ctl; /* optional device scratch of campx_overlap_ctl_bytes(B) bytes, 16-byte
+                         aligned, ZEROED ONCE by the caller and then left to the library (every
+                         launch leaves its control words zeroed).  An A/B path, used only when the
+                         environment says CAMPX_OVERLAP=1: a rollout of a one-mover game at a
+                         small batch then runs its update pass and its observation render in
+                         ONE persistent launch, the render following the update pass group by
+                         group (csrc/k_update.hip overlap_table_kernel).  Measured slower than
+                         the two launches at every batch size in round 4, hence off.
+                         Two launches that may run concurrently must not share a block.
+                         NULL: two launches. */
+  int64_t overlap_ctl_bytes;
 } CampxOutputs;
+
+/* Size of CampxOutputs.overlap_ctl for a batch of B environments. */
+int64_t campx_overlap_ctl_bytes(int64_t B);
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */
 int32_t campx_spec_size(void);
