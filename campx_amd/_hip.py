@@ -20,7 +20,7 @@ from .gamespec import CampxSpec, CampxShapeSpec, CampxWideSpec
 _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
 
-EXPORTS = ('campx_spec_size', 'campx_spec_validate', 'campx_spec_compile',
+EXPORTS = ('campx_spec_size', 'campx_overlap_ctl_bytes', 'campx_spec_validate', 'campx_spec_compile',
            'campx_pair_table_bytes', 'campx_pair_table_build', 'campx_pair_table_pack',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
