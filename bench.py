@@ -46,7 +46,9 @@ BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194,
                       # 6x8 boards, 6 / 7 characters, 3 / 4 moving things (S = 6 / 8)
                       'sokoban_l1': 288 + 4 + 1 + 12 + 1, 'sokoban_l2': 336 + 4 + 1 + 16 + 1,
                       # wide tier: 6 characters, one mover (S = 2) + the done byte
-                      'maze16': 6 * 256 + 4 + 1 + 4 + 1, 'maze32': 6 * 1024 + 4 + 1 + 4 + 1}
+                      'maze16': 6 * 256 + 4 + 1 + 4 + 1, 'maze32': 6 * 1024 + 4 + 1 + 4 + 1,
+                      # 16x16 sokoban, two boxes: 6 characters, three movers (S = 6)
+                      'sokoban16': 6 * 256 + 4 + 1 + 12 + 1}
 WORKLOADS = {
     'boat_race': ('boat_race 5x5', 65536),
     'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
@@ -57,6 +59,9 @@ WORKLOADS = {
     # not BASELINE configs: boards above 128 cells (the wide tier, campx_amd/games/maze.py)
     'maze16': ('maze 16x16, 6 characters (build-authored, wide tier)', 65536),
     'maze32': ('maze 32x32, 6 characters (build-authored, wide tier)', 16384),
+    # not a BASELINE config: a multi-mover rule game above 128 cells - 4.4 million states
+    # enumerated on the device (campx_amd/enumerate_states.py), run by the wide tier
+    'sokoban16': ('sokoban 16x16 with two boxes (build-authored level 3, wide tier)', 65536),
 }
 
 
@@ -65,6 +70,8 @@ def build_game(game_name, **where):
   from campx_amd import games
   if game_name.startswith('sokoban_l'):
     return games.sokoban.build(level=int(game_name[-1]), **where)
+  if game_name == 'sokoban16':
+    return games.sokoban.build(level=3, **where)
   if game_name.startswith('maze'):
     from campx_amd.games import maze
     n = int(game_name[4:])
@@ -583,7 +590,7 @@ def run_rank(args):
     solo = world == 1 and standin is None and not args.force_dist
     if solo and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds,
-                                          batch=4096 if args.game.startswith('maze') else 65536)
+                                          batch=4096 if args.game.startswith(('maze', 'sokoban16')) else 65536)
       line['cpu_baseline']['generic_b1'] = generic_b1()
       line['cpu_baseline']['reference_b1_build_container'] = {
           'value': 954.8, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference',

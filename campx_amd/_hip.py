@@ -28,6 +28,7 @@ EXPORTS = ('campx_spec_size', 'campx_overlap_ctl_bytes', 'campx_spec_validate', 
            'campx_shape_rollout_launch',
            'campx_wide_spec_size', 'campx_wide_spec_validate', 'campx_wide_tables_bytes',
            'campx_wide_tables_build', 'campx_wide_reset_launch', 'campx_wide_rollout_launch',
+           'campx_wide_rules_size', 'campx_wide_enumerate_launch',
            'campx_check_actions_launch',
            'campx_onehot_to_ids_launch', 'campx_stream_create_cu_subset',
            'campx_stream_destroy', 'campx_strerror',
@@ -108,6 +109,10 @@ def _load():
   lib.campx_wide_rollout_launch.restype = i32
   lib.campx_wide_rollout_launch.argtypes = [wide_p, vp, CampxState, vp, CampxOutputs, i64, i32,
                                             i32, vp]
+  lib.campx_wide_rules_size.restype = i32
+  lib.campx_wide_rules_size.argtypes = []
+  lib.campx_wide_enumerate_launch.restype = i32
+  lib.campx_wide_enumerate_launch.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp]
   lib.campx_check_actions_launch.restype = i32
   lib.campx_check_actions_launch.argtypes = [vp, i64, vp, vp]
   lib.campx_onehot_to_ids_launch.restype = i32

@@ -27,11 +27,11 @@ struct WideParams {
   float discounts[16];
 };
 
-// Table-blob entry of (state, action): x = reward; y = [0:19] the state after the frame,
-// [20] done, [21:24] discount code.  (The state the NEXT frame starts from is state 0 when
+// Table-blob entry of (state, action): x = reward; y = [0:23] the state after the frame,
+// [24] done, [25:28] discount code.  (The state the NEXT frame starts from is state 0 when
 // the frame ended the episode: the rebuild is one select on the chain.)
 __host__ __device__ __forceinline__ uint32_t wide_pack(uint32_t next, uint32_t done, uint32_t dcode) {
-  return next | (done << 20) | (dcode << 21);
+  return next | (done << 24) | (dcode << 25);
 }
 
 // kLds: the state table (entries, per-state trace entries, perf bytes) sits in LDS; else it
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
         bad += a[j] > 4u;
         const uint32_t idx = from * CAMPX_N_ACTIONS + (a[j] > 4u ? 4u : a[j]);
         const uint2 e = entries[idx];
-        now = e.y & 0xfffffu;
-        const uint32_t done = (e.y >> 20) & 1u, dcode = (e.y >> 21) & 15u;
+        now = e.y & 0xffffffu;
+        const uint32_t done = (e.y >> 24) & 1u, dcode = (e.y >> 25) & 15u;
         from = done ? 0u : now;                      // the chain: state -> entry -> state
         const u32x4 c = cells[now];                  // where things show in the state reached
         trace[at] = (uint16_t)c.x;
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
     bad = a > 4u;
     const uint32_t idx = (over ? 0u : now) * CAMPX_N_ACTIONS + (a > 4u ? 4u : a);
     const uint2 e = entries[idx];
-    now = e.y & 0xfffffu;
-    const uint32_t done = (e.y >> 20) & 1u, dcode = (e.y >> 21) & 15u;
+    now = e.y & 0xffffffu;
+    const uint32_t done = (e.y >> 24) & 1u, dcode = (e.y >> 25) & 15u;
     const u32x4 c = cells[now];
     shown[wave][lane] = c;
     state[env] = (int32_t)now;
@@ -426,6 +426,184 @@ int32_t wide_renders(const CampxWideSpec& s, const void* tables_dev, const uint1
     }
   }
   return CAMPX_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// One frame of a RULE game's update pass for N given states under each of the five actions:
+// the building block of the device-side state enumeration (include/campx_hip.h
+// campx_wide_enumerate_launch).  The rules are rollout_kernel's (k_interp.hip: same CampxRule
+// records, same order of reads and writes, `shown` = where things stood at the latest repaint,
+// campx/engine.py:195-208) with cells of up to ten bits and the scenery tables in global memory:
+// one thread per (state, action), nothing shared, nothing kept.
+struct EnumParams {
+  int32_t rows, cols, n_rules, any_reward;
+  int32_t perf_dyn, perf_n, perf_mode, perf_mask, perf_scale, perf_offset;
+  int32_t dyn_layer[CAMPX_MAX_DYN], dyn_z[CAMPX_MAX_DYN];
+  CampxRule rules[CAMPX_MAX_RULES];
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void wide_enumerate_kernel(
+    EnumParams ep, const uint8_t* __restrict__ top_layer, const uint8_t* __restrict__ top_z,
+    const uint16_t* __restrict__ cover, const uint8_t* __restrict__ cell_class,
+    const uint16_t* __restrict__ cells_in, int64_t N, uint16_t* __restrict__ next_cells,
+    float* __restrict__ reward_out, uint8_t* __restrict__ done_out, uint8_t* __restrict__ shows_out,
+    int8_t* __restrict__ perf_out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * CAMPX_N_ACTIONS) return;
+  const int64_t s = idx / CAMPX_N_ACTIONS;
+  const int a = (int)(idx - s * CAMPX_N_ACTIONS);
+  const int H = ep.rows, W = ep.cols;
+  int pr[K], pc[K], sr[K], sc[K];   // now / at the latest repaint (indexed through select chains)
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int cell = cells_in[s * K + k];
+    pr[k] = sr[k] = cell / W;
+    pc[k] = sc[k] = cell - (cell / W) * W;
+  }
+  auto get = [&](const int (&v)[K], int d) {
+    int x = v[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) x = (d == k) ? v[k] : x;
+    return x;
+  };
+  auto put2 = [&](int d, int r, int c) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pr[k] = (d == k) ? r : pr[k];
+      pc[k] = (d == k) ? c : pc[k];
+    }
+  };
+  // layer shown at `cell` when the things stand at (r, c): engine.py:306-324
+  auto shown_at = [&](int cell, const int (&r)[K], const int (&c)[K]) {
+    int layer = top_layer[cell], z = top_z[cell];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const bool here = (r[k] * W + c[k] == cell) && (ep.dyn_z[k] > z);
+      layer = here ? ep.dyn_layer[k] : layer;
+      z = here ? ep.dyn_z[k] : z;
+    }
+    return layer;
+  };
+  const int perf_from = ep.perf_dyn >= 0 ? get(pr, ep.perf_dyn) * W + get(pc, ep.perf_dyn) : 0;
+  float reward = 0.0f;
+  bool first = true;
+  int over = 0;
+  auto add_reward = [&](float r) {  // plot.py:208-211: r + total
+    reward = first ? r : r + reward;
+    first = false;
+  };
+  for (int i = 0; i < ep.n_rules; ++i) {
+    const CampxRule& R = ep.rules[i];
+    const int d = R.dyn;
+    switch (R.op) {
+      case CAMPX_OP_AGENT: {
+        int r2, c2;
+        moved(a, H, W, get(pr, d), get(pc, d), r2, c2);
+        const int target = shown_at(r2 * W + c2, sr, sc);
+        const bool blocked = (R.block_layers >> target) & 1u;
+        r2 = blocked ? get(sr, d) : r2;
+        c2 = blocked ? get(sc, d) : c2;
+        put2(d, r2, c2);
+        if (R.has_reward) {
+          float r = R.base;
+          if (R.reward_layers) r += (float)((R.reward_layers >> shown_at(r2 * W + c2, sr, sc)) & 1u);
+          add_reward(r);
+        }
+        break;
+      }
+      case CAMPX_OP_DIR_HOVER: {
+        const int under = shown_at(get(pr, d) * W + get(pc, d), sr, sc);
+        add_reward(R.base + ((under == R.aux) ? 1.0f : 0.0f) * R.bonus[a]);
+        break;
+      }
+      case CAMPX_OP_BOX: {
+        int ar, ac, br, bc;
+        moved(a, H, W, get(sr, R.aux), get(sc, R.aux), ar, ac);
+        const int box_r = get(pr, d), box_c = get(pc, d);
+        moved(a, H, W, box_r, box_c, br, bc);
+        const int beyond = shown_at(br * W + bc, sr, sc);
+        const bool go = (ar == box_r) && (ac == box_c) && !((R.block_layers >> beyond) & 1u);
+        put2(d, go ? br : box_r, go ? bc : box_c);
+        break;
+      }
+      case CAMPX_OP_GOAL: {
+        const int arrived = (cover[get(pr, d) * W + get(pc, d)] >> R.aux) & 1;
+        add_reward(R.base + (float)arrived * R.bonus[0]);
+        if (arrived) over = 1;  // plot.py:183-184
+        break;
+      }
+      default:
+        break;
+    }
+    if (R.end_group) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        sr[k] = pr[k];
+        sc[k] = pc[k];
+      }
+    }
+  }
+  if (!ep.any_reward) reward = __builtin_nanf("");
+  uint32_t shows = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int cell = pr[k] * W + pc[k];
+    next_cells[idx * K + k] = (uint16_t)cell;
+    shows |= (uint32_t)(shown_at(cell, pr, pc) == ep.dyn_layer[k]) << k;
+  }
+  reward_out[idx] = reward;
+  done_out[idx] = (uint8_t)over;
+  shows_out[idx] = (uint8_t)shows;
+  if (perf_out) {
+    int code = 0;
+    if (ep.perf_dyn >= 0) {
+      if (ep.perf_mode == 0) {
+        const int to = get(pr, ep.perf_dyn) * W + get(pc, ep.perf_dyn);
+        code = class_progress(cell_class[perf_from], cell_class[to], ep.perf_n) + 1;
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          code += ((ep.perf_mask >> k) & 1) ? (int)cell_class[pr[k] * W + pc[k]] : 0;
+      }
+    }
+    perf_out[idx] = (int8_t)(code * ep.perf_scale + ep.perf_offset);
+  }
+}
+
+int32_t launch_wide_enumerate(const CampxWideRules& r, const uint16_t* cells_in, int64_t N,
+                              uint16_t* next_cells, float* reward, uint8_t* done, uint8_t* shows,
+                              int8_t* perf, hipStream_t stream) {
+  EnumParams ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.rows = r.rows;
+  ep.cols = r.cols;
+  ep.n_rules = r.n_rules;
+  ep.any_reward = r.any_reward;
+  ep.perf_dyn = r.perf_dyn;
+  ep.perf_n = r.perf_n;
+  ep.perf_mode = r.perf_mode;
+  ep.perf_mask = r.perf_mask;
+  ep.perf_scale = r.perf_scale;
+  ep.perf_offset = r.perf_offset;
+  memcpy(ep.dyn_layer, r.dyn_layer, sizeof(ep.dyn_layer));
+  memcpy(ep.dyn_z, r.dyn_z, sizeof(ep.dyn_z));
+  memcpy(ep.rules, r.rules, sizeof(ep.rules));
+  const int64_t threads = N * CAMPX_N_ACTIONS;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+#define CAMPX_ENUM(KK)                                                                          \
+  hipLaunchKernelGGL((wide_enumerate_kernel<KK>), grid, block, 0, stream, ep, r.top_layer,      \
+                     r.top_z, r.cover, r.cell_class, cells_in, N, next_cells, reward, done, shows, perf)
+  switch (r.n_dyn) {
+    case 1: CAMPX_ENUM(1); break;
+    case 2: CAMPX_ENUM(2); break;
+    case 3: CAMPX_ENUM(3); break;
+    default: CAMPX_ENUM(4); break;
+  }
+#undef CAMPX_ENUM
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
 }  // namespace campx_impl
@@ -642,6 +820,30 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   if (e != hipSuccess) return hip_failed(e);
   return wide_renders(*s, tables_dev, reinterpret_cast<const uint16_t*>(out.trace), out, B, T,
                       (int64_t)T * row_pitch(out, B), hs);
+}
+
+int32_t campx_wide_rules_size(void) { return (int32_t)sizeof(CampxWideRules); }
+
+int32_t campx_wide_enumerate_launch(const CampxWideRules* r, const uint16_t* cells_in, int64_t N,
+                                    uint16_t* next_cells, float* reward, uint8_t* done,
+                                    uint8_t* shows, int8_t* perf, void* stream) {
+  if (!r || !cells_in || !next_cells || !reward || !done || !shows || N < 0) return CAMPX_EINVAL;
+  if (r->magic != CAMPX_SPEC_MAGIC || r->version != CAMPX_SPEC_VERSION) return CAMPX_ESPEC;
+  if (r->rows < 1 || r->cols < 1 || r->rows > 127 || r->cols > 127 ||
+      r->rows * r->cols > CAMPX_WIDE_MAX_CELLS)
+    return CAMPX_ESPEC;
+  if (r->n_dyn < 1 || r->n_dyn > CAMPX_MAX_DYN || r->n_rules < 0 || r->n_rules > CAMPX_MAX_RULES)
+    return CAMPX_ESPEC;
+  if (!r->top_layer || !r->top_z || !r->cover || !r->cell_class) return CAMPX_EINVAL;
+  for (int i = 0; i < r->n_rules; ++i) {
+    const CampxRule& R = r->rules[i];
+    if (R.dyn < 0 || R.dyn >= r->n_dyn) return CAMPX_ESPEC;
+    if (R.op == CAMPX_OP_BOX && (R.aux < 0 || R.aux >= r->n_dyn)) return CAMPX_ESPEC;
+  }
+  if (N == 0) return CAMPX_OK;
+  if (N > (int64_t)0x7fffffff * 256 / CAMPX_N_ACTIONS) return CAMPX_EINVAL;
+  return launch_wide_enumerate(*r, cells_in, N, next_cells, reward, done, shows, perf,
+                               static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -292,13 +292,16 @@ class Engine(object):
       from . import gamespec
       traced, recognised = None, None
       big = self._rows * self._cols > gamespec.MAX_CELLS
-      if not gamespec.is_rule_game(self) or (big and not gamespec.is_shape_rule_game(self)):
-        # arbitrary Python update() bodies: tabulate them on the host (a deep copy of this
-        # engine runs on the generic tier), then the table kernels take over.  Boards above
-        # 128 cells go the same way whatever their classes (the device's rule interpreter
-        # stops there): one mover, the wide tier.  Games of rigidly translating multi-cell
-        # things (the Hello World notebook's own classes) cannot be enumerated; they are
-        # recognised for the shape tier instead (campx_amd/recognise.py).
+      n_movers = 0
+      if big and gamespec.is_rule_game(self) and not gamespec.is_shape_rule_game(self):
+        n_movers = sum(1 for e in gamespec.describe(self).entities if e.moves)
+      if n_movers >= 2:
+        # a multi-mover rule game above 128 cells: millions of reachable states, enumerated by
+        # the rules themselves on the device (the host tabulator below spends a frame of Python
+        # per state and action); the wide tier runs the table
+        from . import enumerate_states
+        traced = enumerate_states.enumerate_rule_game(self, self._device)
+      elif not gamespec.is_rule_game(self) or (big and not gamespec.is_shape_rule_game(self)):
         from . import recognise, tabulate
         actions = recognise.detect_actions(self)
         if recognise.looks_like_shapes(self, actions):

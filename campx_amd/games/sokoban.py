@@ -34,6 +34,24 @@ LEVELS = {
         '#      #',
         '#   G  #',
         '########'],
+    # 16x16 (256 cells: beyond the one-cell tier's 7-bit cells) with two boxes: its state table
+    # is enumerated on the device (campx_amd/enumerate_states.py) and run by the wide tier
+    3: ['################',
+        '#   #      #   #',
+        '# A #  X   #   #',
+        '#   #      #   #',
+        '#       ####   #',
+        '#              #',
+        '####   #       #',
+        '#      #   Y   #',
+        '#      #       #',
+        '#   ####    ####',
+        '#              #',
+        '#      #       #',
+        '#   #  #   #   #',
+        '#   #      # G #',
+        '#   #      #   #',
+        '################'],
 }
 
 MOVEMENT_REWARD = -1

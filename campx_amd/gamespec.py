@@ -209,11 +209,34 @@ def _fail(msg):
   raise ValueError('fused tier: ' + msg)
 
 
-def lower(desc):
-  """`GameDescription` -> `CampxSpec` (ctypes structure, host memory)."""
+class _WideLowered(object):
+  """What `lower(desc, wide=True)` fills instead of a CampxSpec: the same fields, the
+  per-cell tables as numpy arrays of rows*cols entries (boards up to WIDE_MAX_CELLS)."""
+
+  def __init__(self, n_cells):
+    self.rules = (CampxRule * MAX_RULES)()
+    self.layer_char = np.zeros(MAX_LAYERS, np.uint8)
+    self.dyn_layer = np.zeros(MAX_DYN, np.int32)
+    self.dyn_z = np.zeros(MAX_DYN, np.int32)
+    self.dyn_row0 = np.zeros(MAX_DYN, np.int32)
+    self.dyn_col0 = np.zeros(MAX_DYN, np.int32)
+    self.static_top_layer = np.zeros(n_cells, np.uint8)
+    self.static_top_z = np.zeros(n_cells, np.uint8)
+    self.static_cover = np.zeros(n_cells, np.uint16)
+    self.obs_template = np.zeros(MAX_LAYERS * n_cells, np.int8)
+    self.cell_class = np.zeros(n_cells, np.uint8)
+    self.perf_mode = self.perf_mask = self.perf_scale = self.perf_offset = 0
+
+
+def lower(desc, wide=False):
+  """`GameDescription` -> `CampxSpec` (ctypes structure, host memory).  `wide`: the same
+  lowering - rules, moving things, scenery tables - for boards of up to WIDE_MAX_CELLS cells,
+  into a `_WideLowered` (what `enumerate_states` hands to the device)."""
   H, W = desc.rows, desc.cols
   HW = H * W
-  if HW > MAX_CELLS:
+  if wide and (HW > WIDE_MAX_CELLS or H > 127 or W > 127):
+    _fail('{}x{} board has more than {} cells (or 127 rows / columns)'.format(H, W, WIDE_MAX_CELLS))
+  if not wide and HW > MAX_CELLS:
     _fail('{}x{} board has more than {} cells'.format(H, W, MAX_CELLS))
   if len(desc.chars) > MAX_LAYERS:
     _fail('more than {} characters'.format(MAX_LAYERS))
@@ -239,7 +262,7 @@ def lower(desc):
   dyn_of = {e.char: i for i, e in enumerate(dynamic)}
   static_of = {e.char: i for i, e in enumerate(static)}
 
-  spec = CampxSpec()
+  spec = _WideLowered(HW) if wide else CampxSpec()
   spec.magic, spec.version = SPEC_MAGIC, SPEC_VERSION
   spec.rows, spec.cols = H, W
   spec.n_layers = len(desc.chars)
@@ -487,8 +510,22 @@ def lower_shapes(desc):
 WIDE_MAX_CELLS = 1024
 
 
-WIDE_MAX_STATES = 1 << 20
+WIDE_MAX_STATES = 1 << 24
 WIDE_MAX_DYN = 8
+
+
+class CampxWideRules(ctypes.Structure):
+  """include/campx_hip.h CampxWideRules: what campx_wide_enumerate_launch() interprets."""
+  _fields_ = [('magic', ctypes.c_uint32), ('version', ctypes.c_uint32),
+              ('rows', ctypes.c_int32), ('cols', ctypes.c_int32), ('n_layers', ctypes.c_int32),
+              ('n_dyn', ctypes.c_int32), ('n_rules', ctypes.c_int32), ('any_reward', ctypes.c_int32),
+              ('perf_dyn', ctypes.c_int32), ('perf_n', ctypes.c_int32),
+              ('perf_mode', ctypes.c_int32), ('perf_mask', ctypes.c_int32),
+              ('perf_scale', ctypes.c_int32), ('perf_offset', ctypes.c_int32),
+              ('dyn_layer', ctypes.c_int32 * MAX_DYN), ('dyn_z', ctypes.c_int32 * MAX_DYN),
+              ('rules', CampxRule * MAX_RULES),
+              ('top_layer', ctypes.c_void_p), ('top_z', ctypes.c_void_p),
+              ('cover', ctypes.c_void_p), ('cell_class', ctypes.c_void_p)]
 
 
 class CampxWideSpec(ctypes.Structure):

@@ -461,7 +461,7 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
  * one-cell tier's.
  */
 #define CAMPX_WIDE_MAX_CELLS 1024        /* rows * cols; rows, cols <= 127 */
-#define CAMPX_WIDE_MAX_STATES (1 << 20)
+#define CAMPX_WIDE_MAX_STATES (1 << 24)
 #define CAMPX_WIDE_MAX_DYN 8             /* things that move / come and go */
 
 typedef struct CampxWideSpec {
@@ -504,6 +504,44 @@ int32_t campx_wide_spec_validate(const CampxWideSpec* spec_host);
  */
 int64_t campx_wide_tables_bytes(const CampxWideSpec* spec_host);
 int32_t campx_wide_tables_build(const CampxWideSpec* spec_host, void* tables_dev, void* stream);
+
+/*
+ * State enumeration on the device for RULE games (campx_amd.rules classes, lowered to
+ * CampxRule as for CampxSpec) on boards the one-cell tier cannot take (more than 128 cells): the
+ * wide tier runs any state table, and for games of arbitrary Python classes the host fills it by
+ * running them on the generic tier (campx_amd/tabulate.py: a frame of Python per (state,
+ * action)); a multi-mover rule game on a PyColab-sized board (campx/engine.py:31 sets no size
+ * limit) has millions of reachable states.  campx_wide_enumerate_launch() applies one frame of
+ * the rules - the update pass of campx/engine.py:168-208 as rollout_kernel interprets it - to
+ * N given states under each of the five actions; the caller (campx_amd/enumerate_states.py)
+ * drives a breadth-first enumeration with it and fills CampxWideSpec's arrays from the last pass.
+ *   cells_in    DEVICE uint16 [N][K]   the cell of every moving thing (row * cols + col)
+ *   next_cells  DEVICE uint16 [N][5][K]
+ *   reward      DEVICE float  [N][5]   NaN = None        done   DEVICE uint8 [N][5]
+ *   shows       DEVICE uint8  [N][5]   bit d: thing d is the character its cell shows AFTER the frame
+ *   perf        DEVICE int8   [N][5]   hidden performance of the frame, or NULL
+ * The tables of CampxWideRules are DEVICE arrays of rows*cols entries (CampxSpec.static_* and
+ * cell_class explain them).  Nothing is allocated; no host synchronisation.
+ */
+typedef struct CampxWideRules {
+  uint32_t magic, version;         /* CAMPX_SPEC_MAGIC, CAMPX_SPEC_VERSION */
+  int32_t rows, cols, n_layers;
+  int32_t n_dyn;                   /* K: 1 .. CAMPX_MAX_DYN */
+  int32_t n_rules, any_reward;
+  int32_t perf_dyn, perf_n, perf_mode, perf_mask, perf_scale, perf_offset;
+  int32_t dyn_layer[CAMPX_MAX_DYN];
+  int32_t dyn_z[CAMPX_MAX_DYN];
+  CampxRule rules[CAMPX_MAX_RULES];
+  const uint8_t* top_layer;        /* DEVICE [rows*cols] front-most scenery layer per cell */
+  const uint8_t* top_z;            /* DEVICE its z rank (0 = backdrop) */
+  const uint16_t* cover;           /* DEVICE bit s = static drape s covers the cell */
+  const uint8_t* cell_class;       /* DEVICE hidden-performance class per cell (all 0 without one) */
+} CampxWideRules;
+
+int32_t campx_wide_rules_size(void);
+int32_t campx_wide_enumerate_launch(const CampxWideRules* rules_host, const uint16_t* cells_in,
+                                    int64_t N, uint16_t* next_cells, float* reward, uint8_t* done,
+                                    uint8_t* shows, int8_t* perf, void* stream);
 
 /*
  * campx_reset_launch / campx_rollout_launch for a wide game.  The dynamic state of an

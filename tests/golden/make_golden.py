@@ -366,11 +366,19 @@ def gen_sokoban():
 def gen_sokoban_levels():
   """Two and three boxes (K = 3, 4 moving things), reference AgentDrape + the
   build's Box/Goal rules on the reference engine."""
-  for level in (1, 2):
+  for level in (1, 2, 3):
     art = g_sk.LEVELS[level]
     boxes = [ch for ch in 'XYZ' if any(ch in row for row in art)]
-    acts = random_actions(410 + level, 80, 32)
-    acts[:6, 0] = [3, 0, 3, 3, 1, 1]       # walk round a box and to the goal row
+    if level == 3:
+      # the 16x16 level (device-enumerated state table): pushes of both boxes, a walk to the goal
+      acts = random_actions(413, 100, 12)
+      acts[:5, 0] = [1, 1, 1, 1, 1]                         # push X right (against the wall)
+      walk = [3] * 11 + [1] * 11                            # down the left side, along the bottom
+      acts[:len(walk), 1] = walk
+      acts[:40, 2] = ([3] * 3 + [1] * 9 + [3] * 2) * 2 + [1] * 12   # towards Y, push it
+    else:
+      acts = random_actions(410 + level, 80, 32)
+      acts[:6, 0] = [3, 0, 3, 3, 1, 1]       # walk round a box and to the goal row
 
     def game(agent_cls, box_cls, goal_cls, fixed_cls):
       def make():
@@ -389,6 +397,10 @@ def gen_sokoban_levels():
                       ref.things.FixedDrape), acts)
     lib = run(game(R.AgentDrape, R.BoxDrape, R.GoalDrape, R.FixedDrape), acts)
     assert_same(golden, lib, 'sokoban level {} library agent'.format(level))
+    if level == 3:
+      moved = [(golden['board'][:, n] == ord(ch)).reshape(golden['board'].shape[0], -1).argmax(1)
+               for n in range(3) for ch in 'XY']
+      assert sum(len(set(m.tolist())) > 1 for m in moved) >= 2, 'no box was pushed'
     save('sokoban_l{}'.format(level), golden)
 
 
