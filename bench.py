@@ -78,7 +78,9 @@ def build_game(game_name, **where):
     return maze.build(n, n, **where)
   return getattr(games, game_name).build(**where)
 HEADLINE_METRIC = 'env-steps/sec at batch=65536, boat_race 5x5, 1/2/4/8 MI355X'
-TRAFFIC_FILE = os.path.join(REPO, 'profiles', 'r03_traffic.json')
+# the latest round's counter passes (tools/gpu_profile_all.sh -> tools/make_traffic.py)
+TRAFFIC_FILE = max([os.path.join(REPO, 'profiles', f) for f in os.listdir(os.path.join(REPO, 'profiles'))
+                    if f.endswith('_traffic.json')] or [os.path.join(REPO, 'profiles', 'none')])
 
 
 def parse_args(argv=None):
@@ -217,8 +219,8 @@ def measured_traffic(game, batch, frames, path):
   """HBM bytes per launch from the committed rocprofv3 PMC passes, or None.
 
   bench.py cannot run the profiler on itself; the figure comes from
-  profiles/r03_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
-  command) and is only reported for the exact configuration it was measured on.
+  profiles/rNN_traffic.json (tools/profile.sh + tools/rocpd_summary.py on this same
+  command; the latest round's file) and is only reported for the exact configuration it was measured on.
   """
   try:
     with open(TRAFFIC_FILE) as f:
@@ -403,7 +405,7 @@ def roofline(game_name, B, T, fused, kernel_ms, per_launch):
       'frac': achieved / HBM_PEAK_GBS,
       'traffic': traffic,
       'traffic_note': 'HBM bytes per launch (WRITE_SIZE + FETCH_SIZE, separate '
-                      'rocprofv3 --pmc passes, profiles/r03_traffic.json)',
+                      'rocprofv3 --pmc passes, profiles/' + os.path.basename(TRAFFIC_FILE) + ')',
       'kernel': kernel_names(fused, split),
       'kernel_note': 'kernel_ms = HIP-event time on the launch stream around the timed '
                      'launches / steps: every kernel of a rollout launch plus the gaps '

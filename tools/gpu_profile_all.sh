@@ -19,6 +19,6 @@ for g in $games; do
   specs="$specs $d:$g:$b:100"
   grep "render_kernel\|update_" $O/${g}_rocprofv3.txt | head -3 | cut -c1-140
 done
-python3 tools/make_traffic.py --out $O/traffic.json $specs > /dev/null 2>$O/traffic.err
+python3 tools/make_traffic.py --round $(echo $tag | cut -c1-3) --out $O/traffic.json $specs > /dev/null 2>$O/traffic.err
 cat $O/traffic.json | head -40
 rm -rf gpurun_out/prof_${tag}_*

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r03_traffic.json from the rocprofv3 PMC passes of tools/profile.sh.
+"""profiles/<round>_traffic.json from the rocprofv3 PMC passes of tools/profile.sh.
 
-    python tools/make_traffic.py [--out FILE] gpurun_out/prof_r03_boat_race:boat_race:65536:100 ...
+    python tools/make_traffic.py [--round r04] [--out FILE] gpurun_out/prof_r04_boat_race:boat_race:65536:100 ...
 
 (runs on the GPU box right after the passes - tools/gpu_profile_all.sh - because the rocpd
 databases are too large to travel back; the json and the text summaries do)
@@ -37,7 +37,10 @@ def per_dispatch(db, counter):
 
 
 def main(specs):
-  path = os.path.join(REPO, 'profiles', 'r03_traffic.json')
+  rnd = 'r04'
+  if specs and specs[0] == '--round':
+    rnd, specs = specs[1], specs[2:]
+  path = os.path.join(REPO, 'profiles', rnd + '_traffic.json')
   if specs and specs[0] == '--out':
     path, specs = specs[1], specs[2:]
   table = {}
@@ -49,7 +52,7 @@ def main(specs):
     d, game, batch, frames = spec.split(':')
     w = per_dispatch(os.path.join(d, 'pmc_write_results.db'), 'WRITE_SIZE')
     f = per_dispatch(os.path.join(d, 'pmc_fetch_results.db'), 'FETCH_SIZE')
-    names = [k for k in w if 'render_kernel' in k or 'update_' in k]
+    names = [k for k in w if 'render_kernel' in k or 'update_' in k or 'rollout_kernel' in k]
     # (kernels of the rollout launches only: not the one-off board render of its_showtime())
     most = max([w[k][1] for k in names] or [0])
     names = [k for k in names if 2 * w[k][1] >= most]
@@ -62,7 +65,7 @@ def main(specs):
     table['{}:{}:{}:split'.format(game, batch, frames)] = {
         'kernels': ' + '.join(sorted(short)), 'write_bytes': wb, 'fetch_bytes': fb,
         'traffic_bytes': wb + fb,
-        'source': 'profiles/r03_{}_rocprofv3.txt'.format(game)}
+        'source': 'profiles/{}_{}_rocprofv3.txt'.format(rnd, game)}
   with open(path, 'w') as out:
     json.dump(table, out, indent=1)
   print(json.dumps(table, indent=1))
