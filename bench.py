@@ -88,7 +88,7 @@ def parse_args(argv=None):
   p.add_argument('--gpus', type=int, default=1)
   # defaults: the timed region pays a fixed ~0.2 ms after the synchronise that opens it (the
   # chip idles during the fence and ramps back): 30 timed launches read 0.186-0.193 ms per
-  # step, 100 read 0.181-0.183, whatever the warm-up (tools/gpu_warm_ab.sh)
+  # step, 100 read 0.181-0.183, whatever the warm-up (tools/gpu_warm_ab.sh, NOTES.md section 5)
   p.add_argument('--steps', type=int, default=100)
   p.add_argument('--warmup', type=int, default=50)
   p.add_argument('--game', default='boat_race', choices=sorted(WORKLOADS))
@@ -105,7 +105,7 @@ def parse_args(argv=None):
   p.add_argument('--pipeline', action='store_true',
                  help='A/B: issue the update pass of each rollout on a side stream so that '
                       'it overlaps the previous launch (measured SLOWER: the two kernels '
-                      'contend for CU slots; DESIGN.md "Kernels")')
+                      'contend for CU slots; NOTES.md "Kernels")')
   p.add_argument('--gather-every', type=int, default=32,
                  help='episodes per RCCL all-gather of the episode-return log')
   p.add_argument('--episode-csv', default=None,

@@ -9,7 +9,7 @@
 // discount / game-over bookkeeping (campx/plot.py:161-211, engine.py:285-292) and
 // the occluded layered-board render (campx/rendering.py:104-219).
 //
-// Kernels (DESIGN.md section 3 has the numbers):
+// Kernels (NOTES.md section 3 has the numbers):
 //   rollout_kernel        rule interpreter + render, fused.  One lane = one
 //                         environment, one wave = one workgroup = 64 environments;
 //                         rules arrive in the kernarg segment (scalar loads/branches),

@@ -381,7 +381,7 @@ ShapeParams make_shape_params(const CampxShapeSpec& s) {
 // so - as for the one-cell games - the update pass can run ahead and the observation stream
 // can be written frame-major by one-shot blocks with memory-aligned stores, the store pattern
 // that reaches the chip's write ceiling (the serial kernel's "every wave streams its own row
-// per frame" stays at 4.1-4.4 TB/s whatever its instruction count: DESIGN.md 3.7).
+// per frame" stays at 4.1-4.4 TB/s whatever its instruction count: NOTES.md 3.7).
 //
 //   shape_update_kernel  one lane per environment, T frames: offsets += delta[action]
 //                        (the same SWAR words as the serial kernel), the frame's offsets

@@ -51,7 +51,7 @@ from .rendering import Observation
 # exercise the rule interpreter on the same games.
 COMPILE_TABLE = True
 # Rollouts that keep every frame run the update pass and the render as two kernels
-# (needs a [K, T, B] uint8 trace buffer; DESIGN.md "Kernels", profiles/): faster for
+# (needs a [K, T, B] uint8 trace buffer; NOTES.md "Kernels", profiles/): faster for
 # every game, tabulated update pass or interpreted.  CAMPX_SPLIT=0 keeps everything in
 # the single fused kernel; parity tests run both.
 SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') != '0'

@@ -27,7 +27,7 @@ from .rendering import Observation
 # Games without trails can run rollouts as two kernels (update pass -> offset trace ->
 # frame-major render with memory-aligned stores, csrc/k_shape.hip).  Built, parity-tested
 # and MEASURED SLOWER than the single serial kernel (Hello World's art without trails,
-# B = 32 768: 4.0-4.2 against 4.9 TB/s; DESIGN.md 3.7, profiles/r03_shape_rocprofv3.txt), so
+# B = 32 768: 4.0-4.2 against 4.9 TB/s; NOTES.md 3.7, profiles/r03_shape_rocprofv3.txt), so
 # it is off by default; CAMPX_SHAPE_SPLIT=1 (or setting this flag) turns it on.
 SPLIT_TRAIL_FREE = os.environ.get('CAMPX_SHAPE_SPLIT', '0') == '1'
 

@@ -6,7 +6,7 @@ environments on the MI355X.
 The vault: a walker 'A', a key 'k', a door 'D' the key opens, a gem '$' behind the door,
 on a 12x16 board.  Four things come and go, the board has more than 128 cells: the engine
 tabulates the classes on the host (every reachable state, by running them) and the wide
-tier's kernels walk the resulting state table.  The classes are
+tier's kernels walk the resulting state table (NOTES.md 1a, 3.9).  The classes are
 ordinary: they also run, unchanged, on the single-environment generic tier and on the
 reference's own engine.
 

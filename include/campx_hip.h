@@ -23,7 +23,7 @@
  *     CAMPX_E* code; campx_strerror() names it.
  *   - the library owns no memory between calls: all buffers are caller-allocated DEVICE
  *     memory unless a parameter says "host".  The only process-wide state is read-only
- *     after first use: measurement knobs read once from the environment
+ *     after first use: measurement knobs read once from the environment (NOTES.md 3.8)
  *     and, per device, its CU count and the dynamic-LDS limit already granted to a kernel.
  *   - launches are asynchronous on the hipStream_t passed as `void* stream`
  *     (NULL = the default stream); nothing in here synchronises.
@@ -257,7 +257,7 @@ typedef struct CampxOutputs {
                          small batch then runs its update pass and its observation render in
                          ONE persistent launch, the render following the update pass group by
                          group (csrc/k_update.hip overlap_table_kernel).  Measured slower than
-                         the two launches at every batch size in round 4, hence off.
+                         the two launches at every batch size in round 4 (NOTES.md, round 4), hence off.
                          Two launches that may run concurrently must not share a block.
                          NULL: two launches. */
   int64_t overlap_ctl_bytes;
@@ -437,7 +437,7 @@ int32_t campx_shape_spec_validate(const CampxShapeSpec* spec_host);
  * frame, uint32 [4][T][B].  Given it, a game without trails (no visible sprite before the
  * first drape) whose frames are kept back to back runs as two kernels - update pass, then
  * a frame-major render with memory-aligned stores - which streams the observations faster
- * (DESIGN.md 3.7); other games and calls ignore it.
+ * (NOTES.md 3.7); other games and calls ignore it.
  */
 int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxShapeSpec* spec_dev,
                                    CampxState state, int8_t* backdrop_state,
