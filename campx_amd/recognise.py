@@ -20,8 +20,10 @@ This module gives the notebook's OWN classes - any user classes of that kind - t
 2. that model - offsets, rewards summed in update order as `r + total`, termination, and the
    reference renderer's treatment of sprites painted before the first drape, which are written
    into the backdrop for good (campx/rendering.py:128,150: trails) - must then predict every
-   frame of a set of walks on the generic tier: all 25 two-action openings and `WALKS` random
-   walks of `WALK_FRAMES` frames: every thing's curtain / position, the reward bit for bit,
+   frame of a set of walks on the generic tier: all 25 two-action openings, every action
+   repeated max(rows, cols) + 2 times (once round the board: wrap-around is exercised for every
+   direction) and `WALKS` random walks of `WALK_FRAMES` frames: every thing's curtain /
+   position, the reward bit for bit,
    discount, game-over and the rendered board.  Nothing else a frame can read may change
    (`tabulate._hidden`: entity attributes, the Plot's entries), the z-order must stay put, and
    the frame number must not be read.
@@ -360,8 +362,12 @@ def shapes(engine, actions=None):
   for a in range(N_ACTIONS):
     for b in range(N_ACTIONS):
       follow(tabulate._clone_engine(probe), (a, b), 'opening {}{},'.format(a, b))
-  rng = np.random.RandomState(20260401)
   live = [a for a in range(N_ACTIONS) if not any(model.ends[ch][a] for ch in order)]
+  # every action repeated until whatever it moves has been once round the board: a thing that
+  # stops at an edge instead of wrapping (or bounces) shows here, wherever it starts
+  for a in live:
+    follow(tabulate._clone_engine(probe), [a] * (max(H, W) + 2), 'action {} repeated,'.format(a))
+  rng = np.random.RandomState(20260401)
   for w in range(WALKS):
     # (mostly actions that do not end the episode, so that walks get somewhere)
     seq = [int(rng.choice(live)) if live and rng.rand() < 0.97 else int(rng.randint(N_ACTIONS))

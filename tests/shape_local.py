@@ -93,9 +93,19 @@ def bind(things):
       if not (rolled * all_things['#'].curtain).sum():
         self.curtain.set_(rolled)
 
+  class Clamper(things.Sprite):
+    """NOT a shape either, and only an edge shows it: moves like a shape in the open, but
+    stops at the board's last column instead of wrapping."""
+
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is None or int(actions) != 1:
+        return
+      col = min(self._position.col + 1, self.corner.col - 1)
+      self._position = self.Position(self._position.row, col)
+
   import types
   return types.SimpleNamespace(Wave=Wave, Zigzag=Zigzag, Bouncer=Bouncer, Hiker=Hiker,
-                               Loner=Loner)
+                               Loner=Loner, Clamper=Clamper)
 
 
 def build(to_game, things, **engine_kwargs):
@@ -111,6 +121,16 @@ def parade(**where):
   from campx import things
   from campx.ascii_art import ascii_art_to_game
   return build(ascii_art_to_game, things, **where)
+
+
+def clamps_at_the_edge(**where):
+  """36 columns: no random walk of the recogniser gets a sprite from column 2 to the edge."""
+  from campx import things
+  from campx.ascii_art import ascii_art_to_game
+  C = bind(things)
+  art = [' ' * 36, '  c' + ' ' * 33, ' ' * 18 + 'WW' + ' ' * 16, ' ' * 36]
+  return ascii_art_to_game(art, what_lies_beneath=' ', sprites={'c': C.Clamper},
+                           drapes={'W': C.Wave}, z_order='Wc', update_schedule='cW', **where)
 
 
 def not_a_shape(**where):

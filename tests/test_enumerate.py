@@ -99,7 +99,10 @@ def test_sokoban_16x16_is_enumerated_on_the_device_and_matches_the_golden():
   from campx_amd import wide
   gold = _golden()
   T, N = gold['actions'].shape
-  torch.zeros(1, device='cuda')
+  # (a fresh box pages torch's sort / unique / searchsorted code objects in on first use - a
+  # minute, once per process, nothing to do with the enumeration: touch them before the clock)
+  warm = torch.randint(0, 1000, (4096,), device='cuda')
+  torch.searchsorted(torch.sort(torch.unique(warm)).values, warm)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   game = sokoban.build(batch=N, device='cuda', level=3)
@@ -156,6 +159,32 @@ def test_sokoban_16x16_at_full_batch_against_the_oracle():
   ref = og_sub.rollout(np.ascontiguousarray(actions[:, sub]), want_board=False)
   assert _same(out['obs'][:, torch.from_numpy(sub).cuda()].cpu().numpy(), ref['obs'])
   assert int(out['obs'].sum(dim=2, dtype=torch.int32).min()) == 1     # one character per cell
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['boat_race', 'wall_world', 'demo3', 'demo4'])
+def test_enumerate_kernel_on_the_other_rule_kinds(name):
+  """Directional hover rewards, reward characters, the hidden-performance cycle: one-mover
+  library games (never enumerated in production: the host tabulator takes them) put through
+  the enumerate kernel and the wide tier, against the one-cell tier on the same actions."""
+  from campx_amd import enumerate_states, wide
+  from games_under_test import FUSED_GAMES
+  build = FUSED_GAMES[name]
+  B, T = 1024, 150
+  a_game = build(batch=B, device='cuda')
+  a_game.its_showtime()
+  traced = enumerate_states.enumerate_rule_game(build(), 'cuda')
+  assert traced.n_states >= 4
+  b = wide.WideGame(build(batch=B, device='cuda'), B, 'cuda', traced)
+  b.showtime()
+  actions = torch.from_numpy(np.random.RandomState(7).randint(0, 5, size=(T, B)).astype(np.int8))
+  x = a_game.rollout(actions, want_board=True)
+  y = b.rollout(actions, want_board=True)
+  for k in ('obs', 'board', 'reward', 'discount', 'done', 'perf'):
+    if x[k] is None:
+      assert y[k] is None or k == 'perf'
+      continue
+    assert _same(x[k].cpu().numpy(), y[k].cpu().numpy()), k
 
 
 @pytest.mark.gpu

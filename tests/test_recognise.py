@@ -127,6 +127,10 @@ def test_recognised_parade_replays_the_reference_engines_frames_through_the_orac
 def test_games_that_are_not_shape_games_are_refused_with_the_frame_that_shows_it():
   with pytest.raises(recognise.RecogniseError, match=r"'L' is not where its per-action offsets"):
     recognise.shapes(shape_local.not_a_shape(), list(range(5)))
+  # a sprite that stops at the right edge instead of wrapping: 34 columns away from where it
+  # starts - found by the "every action repeated once round the board" walks
+  with pytest.raises(recognise.RecogniseError, match=r"action 1 repeated, frame 3[0-9].*'c' is not where"):
+    recognise.shapes(shape_local.clamps_at_the_edge(), list(range(5)))
   import traced_games
   # a one-cell walker stopped by walls: the tabulator's game, not this module's
   game = traced_games.mirror()
