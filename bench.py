@@ -605,8 +605,9 @@ def run_rank(args):
       torch.cuda.empty_cache()
       line['play_mode'] = play_mode(device)
       also = []
-      # (maze16: not a BASELINE config - the wide tier, boards above 128 cells)
-      for other in ('wall_world', 'sokoban', 'maze16'):
+      # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
+      # second one's 4.4 M-state table is enumerated on the device during its_showtime())
+      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16'):
         oname, ob = WORKLOADS[other]
         steps = args.steps
         om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
@@ -621,7 +622,7 @@ def run_rank(args):
                                  om['per_launch_ms']),
             'cpu_baseline': None if args.no_cpu_baseline else
                             cpu_baseline(other, T, args.cpu_seconds / 2,
-                                         batch=4096 if other.startswith('maze') else ob)})
+                                         batch=4096 if other.startswith(('maze', 'sokoban16')) else ob)})
         del om
         torch.cuda.empty_cache()
       line['also'] = also

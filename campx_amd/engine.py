@@ -302,6 +302,11 @@ class Engine(object):
         from . import enumerate_states
         traced = enumerate_states.enumerate_rule_game(self, self._device)
       elif not gamespec.is_rule_game(self) or (big and not gamespec.is_shape_rule_game(self)):
+        # arbitrary Python update() bodies: tabulate them on the host (a deep copy of this
+        # engine runs on the generic tier), then the table kernels take over.  One-mover rule
+        # games above 128 cells go the same way (hundreds of states).  Games of rigidly
+        # translating multi-cell things (the Hello World notebook's own classes) cannot be
+        # enumerated; they are recognised for the shape tier instead (campx_amd/recognise.py).
         from . import recognise, tabulate
         actions = recognise.detect_actions(self)
         if recognise.looks_like_shapes(self, actions):

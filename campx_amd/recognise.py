@@ -25,7 +25,7 @@ This module gives the notebook's OWN classes - any user classes of that kind - t
    direction) and `WALKS` random walks of `WALK_FRAMES` frames: every thing's curtain /
    position, the reward bit for bit,
    discount, game-over and the rendered board.  Nothing else a frame can read may change
-   (`tabulate._hidden`: entity attributes, the Plot's entries), the z-order must stay put, and
+   (`tabulate.hidden_image`: entity attributes, the Plot's entries), the z-order must stay put, and
    the frame number must not be read.
 
 A game that passes is a shape game AS FAR AS THOSE FRAMES SHOW - the check is a sample, not an
@@ -121,12 +121,12 @@ def detect_actions(engine):
   errors = []
   for name, actions in (('one-hot float vectors', tabulate.default_actions()),
                         ('integers', list(range(N_ACTIONS)))):
-    probe = tabulate._clone_engine(engine)
+    probe = tabulate.clone_engine(engine)
     probe._batch, probe._device, probe._fused = None, None, None
     try:
       probe.its_showtime()
       for a in range(N_ACTIONS):
-        trial = tabulate._clone_engine(probe)
+        trial = tabulate.clone_engine(probe)
         trial.play(copy.deepcopy(actions[a]))
       return actions
     except Exception as e:      # noqa: BLE001 - whatever the user's classes raise
@@ -221,7 +221,7 @@ def looks_like_shapes(engine, actions):
   campx/rendering.py:128,150) - so that a batched Engine asks `shapes()` first instead of
   walking `tabulate.trace()` into its refusal."""
   H, W = engine.rows, engine.cols
-  probe = tabulate._clone_engine(engine)
+  probe = tabulate.clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None
   try:
     probe.its_showtime()
@@ -231,7 +231,7 @@ def looks_like_shapes(engine, actions):
       return True
     before = {ent.character: _thing_mask(ent, H, W) for ent in order}
     for a in range(N_ACTIONS):
-      eng = tabulate._clone_engine(probe)
+      eng = tabulate.clone_engine(probe)
       eng.play(copy.deepcopy(actions[a]))
       for ch, ent in eng.things.items():
         if isinstance(ent, _things.Sprite):
@@ -258,9 +258,9 @@ def shapes(engine, actions=None):
   if len(actions) != N_ACTIONS:
     raise ValueError('exactly {} actions are needed'.format(N_ACTIONS))
 
-  probe = tabulate._clone_engine(engine)
+  probe = tabulate.clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None
-  probe._the_plot.__class__ = _watched_plot(tabulate._probe_plot_class(type(probe._the_plot)))
+  probe._the_plot.__class__ = _watched_plot(tabulate.probe_plot_class(type(probe._the_plot)))
   for ent in probe.things.values():
     try:
       ent.__class__ = _watched_class(type(ent))
@@ -271,7 +271,7 @@ def shapes(engine, actions=None):
   obs, _, _ = probe.its_showtime()
   if probe.game_over:
     _fail('the episode is over after its_showtime()')
-  reads0 = tabulate._FRAME_READS[0]
+  reads0 = tabulate.FRAME_READS[0]
   order = list(probe.things.keys())                      # z-order, back to front
   schedule, group_of = [], {}
   for gi, (_, members) in enumerate(probe._update_groups):
@@ -290,7 +290,7 @@ def shapes(engine, actions=None):
       _fail('{!r} moves during its_showtime()'.format(ch))
     if masks[ch].max() > 1:
       _fail('the curtain of {!r} holds values other than 0 and 1'.format(ch))
-  hidden0 = tabulate._hidden(probe, False)
+  hidden0 = tabulate.hidden_image(probe, False)
   model = _Model(H, W, order, schedule, masks, is_sprite, visible, backdrop_art)
   if not np.array_equal(model.board(), obs.board.detach().cpu().numpy().astype(np.uint8)):
     _fail('the first observation is not "backdrop, then every thing in z-order"')
@@ -299,13 +299,13 @@ def shapes(engine, actions=None):
   def play(eng, a):
     del _CALLS[:]
     obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
-    if tabulate._FRAME_READS[0] != reads0:
+    if tabulate.FRAME_READS[0] != reads0:
       _fail('the game reads the_plot.frame')
-    return obs, tabulate._reward_f32(reward), float(np.float32(discount)), list(_CALLS)
+    return obs, tabulate.reward_f32(reward), float(np.float32(discount)), list(_CALLS)
 
   # ---- 1. one frame of every action from the start: offsets, rewards, who ends the episode
   for a in range(N_ACTIONS):
-    eng = tabulate._clone_engine(probe)
+    eng = tabulate.clone_engine(probe)
     play(eng, a)
     calls = list(_CALLS)
     for ch, ent in eng.things.items():
@@ -329,7 +329,7 @@ def shapes(engine, actions=None):
           _fail('{!r} adds more than one reward in a frame'.format(who))
         # (as float32, summed in float32: that this equals the generic tier's own sum for
         # every action is part of what the walks below check)
-        model.reward[who][a] = tabulate._reward_f32(value)
+        model.reward[who][a] = tabulate.reward_f32(value)
 
   # ---- 2. the model predicts the generic tier, frame by frame
   def follow(eng, seq, what):
@@ -354,25 +354,25 @@ def shapes(engine, actions=None):
       if not np.array_equal(obs.board.detach().cpu().numpy().astype(np.uint8), model.board()):
         _fail(where + ': the rendered board is not backdrop (with the trails of the sprites '
               'behind the first drape) + things in z-order')
-      if tabulate._hidden(eng, False) != hidden0:
+      if tabulate.hidden_image(eng, False) != hidden0:
         _fail(where + ': state outside the curtains changed (an entity attribute, a Plot entry)')
       if eng.game_over:
         return
 
   for a in range(N_ACTIONS):
     for b in range(N_ACTIONS):
-      follow(tabulate._clone_engine(probe), (a, b), 'opening {}{},'.format(a, b))
+      follow(tabulate.clone_engine(probe), (a, b), 'opening {}{},'.format(a, b))
   live = [a for a in range(N_ACTIONS) if not any(model.ends[ch][a] for ch in order)]
   # every action repeated until whatever it moves has been once round the board: a thing that
   # stops at an edge instead of wrapping (or bounces) shows here, wherever it starts
   for a in live:
-    follow(tabulate._clone_engine(probe), [a] * (max(H, W) + 2), 'action {} repeated,'.format(a))
+    follow(tabulate.clone_engine(probe), [a] * (max(H, W) + 2), 'action {} repeated,'.format(a))
   rng = np.random.RandomState(20260401)
   for w in range(WALKS):
     # (mostly actions that do not end the episode, so that walks get somewhere)
     seq = [int(rng.choice(live)) if live and rng.rand() < 0.97 else int(rng.randint(N_ACTIONS))
            for _ in range(WALK_FRAMES)]
-    follow(tabulate._clone_engine(probe), seq, 'walk {},'.format(w))
+    follow(tabulate.clone_engine(probe), seq, 'walk {},'.format(w))
 
   # ---- the description `gamespec.lower_shapes()` takes
   entities = []

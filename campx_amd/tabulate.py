@@ -17,7 +17,7 @@ the game can reach:
     Plot's reward / discount / game-over, and the rendered board.
 
 A state is identified by everything a frame can READ: the byte image of every curtain and
-sprite position, the z-order, and `_hidden()` - every other attribute of every entity and of
+sprite position, the z-order, and `hidden_image()` - every other attribute of every entity and of
 the Backdrop, the Plot's user entries and attributes (campx/plot.py:29: the Plot is a dict for
 exactly that), all by value (tensors included), and the frame number (plot.py:259-280) IF the
 game reads it (the probe engine's Plot records reads of `frame` outside the priming frame; a
@@ -55,7 +55,7 @@ under conditions that are CHECKED while tabulating (TabulationError otherwise):
   `terminate_episode()` was called - are reported (`change_default_discount`,
   `terminate_episode(d)`: campx/plot.py:161-184, 232-257; the tables carry a 4-bit code).
 
-... and under one that is only SPOT-CHECKED: that the game keeps no state where `_hidden()` does
+... and under one that is only SPOT-CHECKED: that the game keeps no state where `hidden_image()` does
 not look - a module global it mutates, a closure, a random number generator.  When a state is
 reached again over a different history, every action is replayed from that second engine and
 must reproduce the tabulated next state, reward, discount, game-over and board; that catches
@@ -175,7 +175,7 @@ def _plain(x, path, depth, open_ids):
   raise _Unimageable('{} (a {})'.format(path, type(x).__name__))
 
 
-def _hidden(engine, with_frame):
+def hidden_image(engine, with_frame):
   """Everything a frame can read that is NOT a curtain, a sprite's position / visibility or the
   z-order (those are `_image()`): every other attribute of every entity and of the Backdrop,
   the Plot's user entries (campx/plot.py:29 - the Plot is a dict for exactly that; the message
@@ -215,13 +215,13 @@ class _FrameWasRead(Exception):
   pass
 
 
-_FRAME_READS = [0]     # bumped by every read of `Plot.frame` on a probe engine
+FRAME_READS = [0]     # bumped by every read of `Plot.frame` on a probe engine
 
 
 _PROBE_PLOTS = {}
 
 
-def _probe_plot_class(base):
+def probe_plot_class(base):
   """`base` (the engine's Plot class) with a `frame` that notices being read: a game whose
   update() looks at the frame number (a time limit) has the frame number in its state."""
   if base in _PROBE_PLOTS:
@@ -235,7 +235,7 @@ def _probe_plot_class(base):
 
     @property
     def frame(self):
-      _FRAME_READS[0] += 1
+      FRAME_READS[0] += 1
       return self._frame
 
     @frame.setter
@@ -246,7 +246,7 @@ def _probe_plot_class(base):
   return ProbePlot
 
 
-def _reward_f32(reward):
+def reward_f32(reward):
   if reward is None:
     return np.float32(np.nan)
   if torch.is_tensor(reward):
@@ -363,7 +363,7 @@ def _copy_tensor(x, memo):
   return torch.empty(0, dtype=x.dtype).set_(fresh, x.storage_offset(), x.size(), x.stride())
 
 
-def _clone_engine(engine):
+def clone_engine(engine):
   """`copy.deepcopy(engine)` with the lean tensor copy above (a tabulation makes thousands of
   copies of an engine that holds a dozen small tensors: 70 % of its time was here)."""
   dispatch = copy._deepcopy_dispatch
@@ -629,28 +629,28 @@ def _trace_once(engine, actions, max_plays, with_frame):
   if len(actions) != N_ACTIONS:
     raise ValueError('exactly {} actions are needed'.format(N_ACTIONS))
 
-  probe = _clone_engine(engine)
+  probe = clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None
-  probe._the_plot.__class__ = _probe_plot_class(type(probe._the_plot))
+  probe._the_plot.__class__ = probe_plot_class(type(probe._the_plot))
   obs, _, _ = probe.its_showtime()
   if probe.game_over:
     _fail('the episode is over after its_showtime()')
   # (reads of the frame number during the priming frame are not held against the game: every
   # episode passes through it at frame 0, "if the_plot.frame == 0: set up" included)
-  reads0 = _FRAME_READS[0]
+  reads0 = FRAME_READS[0]
 
   # (the rule library's own classes keep nothing the state image below does not hold, and
   # call nothing that could - no globals, no RNG -, so their games skip the second-history
   # replays, which are half of a tabulation's frames)
   check_histories = not gamespec.is_rule_game(engine)
   things0, backdrop0, z0 = _image(probe)
-  hidden0 = _hidden(probe, with_frame)
+  hidden0 = hidden_image(probe, with_frame)
   # state bookkeeping: a state is (curtains and positions, z-order, everything else a frame
   # can read)
   index_of = {(things0, z0, hidden0): 0}
   images = [things0]
   orders = [z0]              # per state: the z-order in force (characters back to front)
-  hiddens = [hidden0]        # per state: `_hidden()`
+  hiddens = [hidden0]        # per state: `hidden_image()`
   engines = [probe]          # an engine standing in that state, or None (only seen ended)
   second = {}                # state -> an engine that arrived there over another history
   boards = [obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()]
@@ -687,7 +687,7 @@ def _trace_once(engine, actions, max_plays, with_frame):
       too_many()
     plays[0] += 1
     obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
-    if not with_frame and _FRAME_READS[0] != reads0:
+    if not with_frame and FRAME_READS[0] != reads0:
       raise _FrameWasRead()
     things, backdrop, z = _image(eng)
     if backdrop != backdrop0:
@@ -696,13 +696,13 @@ def _trace_once(engine, actions, max_plays, with_frame):
     over = bool(eng.game_over)
     discount = float(np.float32(discount))
     board = obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()
-    return (things, z, _hidden(eng, with_frame)), _reward_f32(reward), discount, over, board
+    return (things, z, hidden_image(eng, with_frame)), reward_f32(reward), discount, over, board
 
   while queue:
     s = queue.popleft()
     for a in range(N_ACTIONS):
       # (the last action is played on the state's own engine: nobody needs it afterwards)
-      eng = _clone_engine(engines[s]) if a < N_ACTIONS - 1 else engines[s]
+      eng = clone_engine(engines[s]) if a < N_ACTIONS - 1 else engines[s]
       key, reward, discount, over, board = step(eng, a)
       t = index_of.get(key)
       if t is None:
@@ -724,11 +724,11 @@ def _trace_once(engine, actions, max_plays, with_frame):
           second[t] = eng
 
   # ---- the image IS the state: replay every action over a second history.  (A guard, not a
-  # proof: it catches state kept where `_hidden()` does not look - module globals, closures, a
+  # proof: it catches state kept where `hidden_image()` does not look - module globals, closures, a
   # random number generator - only if it shows within one frame of one second arrival.)
   for t, eng0 in second.items():
     for a in range(N_ACTIONS):
-      eng = _clone_engine(eng0) if a < N_ACTIONS - 1 else eng0
+      eng = clone_engine(eng0) if a < N_ACTIONS - 1 else eng0
       key, reward, discount, over, board = step(eng, a)
       got = _Edge(index_of.get(key), reward, discount, over, board)
       if not got.same(edges[(t, a)]):
