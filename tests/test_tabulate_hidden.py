@@ -310,3 +310,59 @@ def test_hidden_state_games_at_full_batch_on_the_hip_path(name):
     assert torch.equal(obs.layered_board, out['obs'][t]), t
     assert _same(reward.cpu().numpy(), want['reward'][t]), t
     assert _same(discount.cpu().numpy(), want['discount'][t]), t
+
+
+# ------------------------------------------------------------------------- CPU fuzz
+
+def _random_hidden_state_game(rng):
+  """A random walled board of 20-48 cells with coins, and one of the three hidden-state
+  walkers with random parameters (time limit 5-40 frames, quota 2-6 coins, dasher)."""
+  H, W = int(rng.randint(4, 7)), int(rng.randint(5, 9))
+  art = np.full((H, W), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = '#'
+  art[:, 0] = art[:, -1] = '#'
+  inner = art[1:-1, 1:-1]
+  inner[rng.rand(H - 2, W - 2) < 0.1] = '#'
+  free = list(zip(*np.where(art == ' ')))
+  rng.shuffle(free)
+  art[free.pop()] = 'A'
+  for _ in range(int(rng.randint(1, 4))):
+    if free:
+      art[free.pop()] = 'o'
+  rows = [''.join(r) for r in art]
+  kind = int(rng.randint(3))
+  if kind == 0:
+    cls = traced_games.Partial(traced_games.TimedWalker, limit=int(rng.randint(5, 41)))
+  elif kind == 1:
+    cls = traced_games.Partial(traced_games.CoinCounter, quota=int(rng.randint(2, 7)))
+  else:
+    cls = traced_games.CoinCounter if 'o' not in ''.join(rows) else traced_games.Partial(
+        traced_games.TimedWalker, limit=int(rng.randint(3, 12)))
+
+  def build(**where):
+    return traced_games.ascii_art_to_game(
+        rows, what_lies_beneath=' ',
+        drapes={'A': cls, '#': traced_games.things.FixedDrape, 'o': traced_games.things.FixedDrape},
+        z_order='oA#', update_schedule='A#o', **where)
+  return build, rows, kind
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_hidden_state_games_against_the_generic_tier(seed):
+  """Whatever table form the tabulator picks (cell-indexed with a mode, or the state table),
+  walking it predicts the classes' own frames on the generic tier: 150 frames, two action
+  streams, episodes ending and restarting on the way."""
+  rng = np.random.RandomState(9100 + seed)
+  build, rows, kind = _random_hidden_state_game(rng)
+  traced = tabulate.trace(build(), cache=False)
+  assert traced.hidden_paths, rows                       # every one of these has hidden state
+  for stream in range(2):
+    actions = rng.randint(0, 5, size=(150, 1)).astype(np.int8)
+    walker, key = _walker(traced, 1)
+    want = walker.rollout(actions, reset_first=True)
+    for t, (board, layered, reward, discount, over) in enumerate(_generic_frames(build, actions[:, 0])):
+      got_board, got_layered = _render(walker, key, want, t)
+      assert np.array_equal(got_board[0], board), (rows, kind, stream, t)
+      assert np.array_equal(got_layered[0], layered), (rows, kind, stream, t)
+      assert _same(want['reward'][t, 0], reward), (rows, kind, stream, t)
+      assert want['discount'][t, 0] == discount and want['done'][t, 0] == over, (rows, kind, stream, t)
