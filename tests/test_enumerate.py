@@ -140,7 +140,6 @@ def test_sokoban_16x16_at_full_batch_against_the_oracle():
   game.its_showtime()
   desc = gamespec.describe(sokoban.build(level=3))
   og, og_sub = cpu.OracleGame.from_description(desc), cpu.OracleGame.from_description(desc)
-  cpu.set_threads(os.cpu_count() or 1)
   rng = np.random.RandomState(31)
   sub = np.arange(0, B, 16)
   for launch, T in enumerate([24, 16]):
