@@ -50,3 +50,31 @@ def test_own_game_example_runs_batched():
   f = got['game'].fused
   assert isinstance(f, wide.WideGame) and f.traced.movers == ['A', 'k', 'D', '$']
   assert got['rate'] > 1e6 and got['out']['obs'].shape == (60, 2048, 6, 12, 16)
+
+
+def test_hello_world_example_classes_are_recognised_on_the_cpu():
+  """examples/hello_world_batched.py: its make_game() (the notebook's classes as the notebook
+  types them) is recognised to the committed Hello World spec - the part that needs no GPU."""
+  import ctypes
+  import numpy as np
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import hello_world_batched as ex
+  from campx_amd import gamespec, recognise
+  game = ex.make_game()
+  assert game.batch is None and not gamespec.is_rule_game(game)
+  spec = gamespec.lower_shapes(recognise.shapes(game))
+  with np.load(os.path.join(REPO, 'tests', 'golden', 'hello_world_spec.npz')) as f:
+    assert ctypes.string_at(ctypes.addressof(spec), ctypes.sizeof(spec)) == f['spec'].tobytes()
+
+
+@pytest.mark.gpu
+def test_hello_world_example_runs_batched(capsys):
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import hello_world_batched as ex
+  from campx_amd import engine
+  try:
+    ex.main()
+  finally:
+    engine.set_default_batch(None)
+  out = capsys.readouterr().out
+  assert 'ShapeGame' in out and 'for every environment: True' in out and 'TB/s' in out
