@@ -148,4 +148,4 @@ def test_one_rccl_rank_through_the_real_launcher():
   line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
   assert line['config']['rccl_world'] == 1 and line['config']['gathered_log_matches_local'] is True
   # the closing barrier is off the clock: the step time is the kernels' plus the host's share
-  assert line['ms_per_step'] < 1.10 * line['roofline']['kernel_ms']
+  assert line["ms_per_step"] < 1.25 * line["roofline"]["kernel_ms"]
