@@ -207,3 +207,29 @@ def test_enumerate_kernel_against_the_rule_interpreter(level):
   for k in ('obs', 'board', 'reward', 'discount', 'done', 'perf'):
     assert _same(x[k].cpu().numpy(), y[k].cpu().numpy()), k
   assert int(x['done'].sum()) > 0
+
+
+def test_enumerate_entry_point_checks_its_arguments_without_a_gpu():
+  """campx_wide_enumerate_launch() refuses bad arguments before it touches the device (the
+  reference raises ValueError / RuntimeError for malformed set-up: engine.py:47-53, 332-350)."""
+  from campx_amd import _hip
+  r = gamespec.CampxWideRules()
+  fake = ctypes.c_void_p(16)                   # never dereferenced: every call below is refused
+  call = lambda rules, n=1: _hip.lib.campx_wide_enumerate_launch(
+      ctypes.byref(rules), fake, n, fake, fake, fake, fake, None, None)
+  assert ctypes.sizeof(r) == _hip.lib.campx_wide_rules_size()
+  assert call(r) != 0                          # no magic
+  r.magic, r.version = gamespec.SPEC_MAGIC, gamespec.SPEC_VERSION
+  r.rows, r.cols, r.n_dyn = 16, 16, 3
+  assert call(r) != 0                          # no scenery tables
+  r.top_layer = r.top_z = r.cover = r.cell_class = 16
+  r.rows = 200
+  assert call(r) != 0                          # more than 127 rows
+  r.rows, r.n_dyn = 16, 9
+  assert call(r) != 0                          # more than four moving things
+  r.n_dyn, r.n_rules = 3, 1
+  r.rules[0].op, r.rules[0].dyn = gamespec.OP_BOX, 7
+  assert call(r) != 0                          # a rule about a thing that does not exist
+  r.rules[0].dyn, r.rules[0].aux = 0, 1
+  assert call(r, n=0) == 0                     # nothing to do: accepted, nothing launched
+  assert call(r, n=-1) != 0
