@@ -106,6 +106,10 @@ def parse_args(argv=None):
                  help='A/B: issue the update pass of each rollout on a side stream so that '
                       'it overlaps the previous launch (measured SLOWER: the two kernels '
                       'contend for CU slots; NOTES.md "Kernels")')
+  p.add_argument('--deferred', action='store_true',
+                 help='A/B: rollouts pipelined across calls (FusedGame.rollout_deferred): one '
+                      'launch holds the update pass of rollout i+1 and the render pass of rollout '
+                      'i; every timed step still does one update pass and one render pass')
   p.add_argument('--gather-every', type=int, default=32,
                  help='episodes per RCCL all-gather of the episode-return log')
   p.add_argument('--episode-csv', default=None,
@@ -272,8 +276,13 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   # rollouts (the update pass of launch i+1 overlaps the observation stream of launch
   # i) alternate two sets of scalars / trace over one observation buffer.
   bufs = [fused.rollout_buffers(T)]
-  bufs.append(fused.rollout_buffers(T, share=bufs[0]) if pipelined else bufs[0])
-  pipelined = pipelined and bufs[0].get('trace') is not None
+  deferred = pipelined == 'deferred' and bufs[0].get('trace') is not None and hasattr(fused, 'rollout_deferred')
+  share_obs = os.environ.get('CAMPX_BENCH_OWN_OBS') != '1'    # (A/B: an observation buffer per set)
+  if deferred and not share_obs:
+    bufs.append(fused.rollout_buffers(T))
+  else:
+    bufs.append(fused.rollout_buffers(T, share=bufs[0]) if pipelined else bufs[0])
+  pipelined = 'deferred' if deferred else (pipelined is True and bufs[0].get('trace') is not None)
   log = None
   if dist is not None or with_log:
     # Episode returns are logged per rank and all-gathered every `gather_every`
@@ -288,11 +297,21 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     gather_every = max(1, min(gather_every, (2 * steps + 2) // 3))
     log = ReturnLog(B, gather_every, device, dist)
 
+  n_calls = [0]
+
   def one_step(i):
     if log is not None:
       fused.ret = log.row()
-    out = fused.rollout(streams[i & 1], out=bufs[i & 1], reset_first=True,
-                        pipelined=pipelined)
+    if deferred:
+      # update pass of this rollout + render pass of the one before it, one launch (the two
+      # buffer sets strictly alternate, whatever `i` the caller's loops restart from)
+      k = n_calls[0] & 1
+      n_calls[0] += 1
+      fused.rollout_deferred(streams[k], bufs[k], reset_first=True)
+      out = bufs[k]
+    else:
+      out = fused.rollout(streams[i & 1], out=bufs[i & 1], reset_first=True,
+                          pipelined=pipelined)
     if log is not None:
       log.episode_done()
     return out
@@ -385,6 +404,9 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     if log is not None:
       log.wait()
     fence()
+    if deferred:
+      fused.flush()                   # the last rollout's observations
+      fence()
     per = [s.elapsed_time(e) for s, e in zip(starts, stops)]
     result['per_launch_ms'] = {'median': float(np.median(per)), 'min': float(min(per)),
                                'max': float(max(per)), 'mean': float(np.mean(per))}
@@ -514,7 +536,8 @@ def run_rank(args):
   B = args.batch or default_batch
   T = args.frames
   m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
-                      args.gather_every, standin, args.pipeline, with_log=True)
+                      args.gather_every, standin, 'deferred' if args.deferred else args.pipeline,
+                      with_log=True)
   fused, elapsed = m['fused'], m['elapsed']
 
   gathered_ok = None
@@ -604,6 +627,27 @@ def run_rank(args):
       del m
       torch.cuda.empty_cache()
       line['play_mode'] = play_mode(device)
+      if not args.deferred and not args.pipeline:
+        # Rollouts pipelined across calls (FusedGame.rollout_deferred: ONE launch = the update
+        # pass of rollout i+1 + the render pass of rollout i), beside the headline's two
+        # launches per rollout, at the headline's batch and two smaller ones.  Reported, not
+        # the headline: it changes what a caller gets back when (observations one call late).
+        rows = []
+        for db in (B, 16384, 4096):
+          dm = measure_rollout(args.game, db, T, args.steps, args.warmup, device, 0, None, 0,
+                               pipelined='deferred')
+          rows.append({'batch': db, 'value': db * T * args.steps / dm['elapsed'],
+                       'unit': 'env-steps/s', 'ms_per_step': dm['elapsed'] / args.steps * 1e3,
+                       'kernel_ms': dm['kernel_ms'],
+                       'frac': BYTES_PER_ENV_STEP[args.game] * db * T / (dm['kernel_ms'] / 1e3) / 1e9
+                       / HBM_PEAK_GBS})
+          del dm
+          torch.cuda.empty_cache()
+        line['deferred_rollouts'] = {
+            'note': 'rollout_deferred(): one launch per step = update pass of rollout i+1 + '
+                    'render pass of rollout i (pipe_table_kernel); same work per step as the '
+                    'headline, observations delivered one call late',
+            'rows': rows}
       also = []
       # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
       # second one's 4.4 M-state table is enumerated on the device during its_showtime())
@@ -611,7 +655,7 @@ def run_rank(args):
         oname, ob = WORKLOADS[other]
         steps = args.steps
         om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
-                             pipelined=args.pipeline)
+                             pipelined='deferred' if args.deferred else args.pipeline)
         also.append({
             'workload': '{}, batch={}, random actions, {} frames per launch'.format(
                 oname, ob, T),

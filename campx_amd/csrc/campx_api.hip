@@ -644,6 +644,37 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
                         static_cast<hipStream_t>(stream));
 }
 
+int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
+                                   CampxState st, const int8_t* actions, CampxOutputs out,
+                                   CampxOutputs prev, int64_t B, int32_t T, int32_t reset_first,
+                                   void* stream) {
+  if (!prev.trace)
+    return campx_update_launch(spec_host, spec_dev, st, actions, out, B, T, reset_first, stream);
+  // (every check of the two calls this one stands for, before anything is launched)
+  if (!spec_host || !spec_dev || !st.pos || !st.done || !actions || !out.trace || B <= 0 || T <= 0 ||
+      T > 65535 || !prev.obs || prev.trace == out.trace)
+    return CAMPX_EINVAL;
+  if (out.perf && spec_host->perf_dyn < 0) return CAMPX_EINVAL;
+  if (reinterpret_cast<uintptr_t>(prev.obs) & 15) return CAMPX_EINVAL;
+  if (prev.obs_format < CAMPX_OBS_INT8 || prev.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
+  const int32_t v = campx_spec_validate(spec_host);
+  if (v != CAMPX_OK) return v;
+  if (!spec_host->render_valid) return CAMPX_ESPEC;
+  if ((out.scalar_pitch && out.scalar_pitch < B) || (prev.scalar_pitch && prev.scalar_pitch < B))
+    return CAMPX_EINVAL;
+  CampxOutputs probe = prev;
+  if (!split_ok(*spec_host, probe, B, T)) return CAMPX_EINVAL;
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
+                         (!knob_no_table() || spec_host->table_only);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pipe_ok(*spec_host, out, prev, B, T, use_table))
+    return launch_pipe(*spec_host, spec_dev, st, actions, out, prev, B, T, reset_first, s);
+  const int32_t rc = launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
+                                   (int64_t)T * row_pitch(out, B), s);
+  if (rc != CAMPX_OK) return rc;
+  return launch_renders(*spec_host, spec_dev, prev, B, T, (int64_t)T * row_pitch(prev, B), s);
+}
+
 int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out) {
   if (!stream_out) return CAMPX_EINVAL;
   int dev = 0, cus = 0;

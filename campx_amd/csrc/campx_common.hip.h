@@ -556,6 +556,13 @@ int32_t launch_overlap(const CampxSpec& s, const CampxSpec* spec_dev, CampxState
                        const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                        int32_t reset_first, int64_t trace_plane, hipStream_t stream);
 
+// k_update.hip: the update pass of one rollout and the render pass of the one before it in one launch
+bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& prev, int64_t B,
+             int32_t T, bool use_table);
+int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                    const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
+                    int32_t T, int32_t reset_first, hipStream_t stream);
+
 // k_render.hip: the observation stream of the two-kernel path
 // Where a render launch finds a game's tables (k_render.hip).
 struct RenderSource {

@@ -9,6 +9,7 @@
 //   campx::step     one Engine.play() frame for B environments
 //   campx::rollout  T consecutive frames in one launch
 //   campx::update / campx::render   the two kernels of a rollout as separate ops
+//   campx::update_render            update of one rollout + render of the one before it
 //   campx::shape_rollout            the shape tier (Hello World): reset / step / rollout
 //   campx::wide_rollout             the wide tier (boards above 128 cells): reset / step / rollout
 //   campx::onehot_to_ids / campx::check_actions   action-format helpers
@@ -331,6 +332,53 @@ void render(const Tensor& spec_host, const Tensor& spec_dev, const Tensor& trace
            "campx_render_launch");
 }
 
+// The update pass of one rollout and the render pass of the one before it as ONE call
+// (campx_update_render_launch: a single launch where the game and the shapes allow it).
+void update_render(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+                   const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions,
+                   const OptTensor& reward, const OptTensor& discount, const OptTensor& step_done,
+                   const OptTensor& perf, Tensor& trace, const OptTensor& bad_count,
+                   const OptTensor& bad_flag, bool reset_first, const Tensor& prev_trace,
+                   Tensor& prev_obs) {
+  const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
+  TORCH_CHECK(actions.dim() == 2, "campx::update_render: actions must be int8 [T, B]");
+  const int64_t T = actions.size(0);
+  TORCH_CHECK(T >= 1 && T <= 65535, "campx::update_render: 1 to 65535 frames");
+  want(actions, "actions", at::kChar, g.dev, {T, g.B});
+  int64_t pitch = 0, prev_pitch = 0;
+  want_trace(trace, g.dev, g.K, T, g.B, pitch);
+  want_trace(prev_trace, g.dev, g.K, T, g.B, prev_pitch);
+  TORCH_CHECK(prev_trace.data_ptr() != trace.data_ptr(),
+              "campx::update_render: the two rollouts need a trace buffer each");
+  if (reward.has_value()) want_rows(*reward, "reward", at::kFloat, g.dev, T, g.B, pitch);
+  if (discount.has_value()) want_rows(*discount, "discount", at::kFloat, g.dev, T, g.B, pitch);
+  if (step_done.has_value()) want_rows(*step_done, "step_done", at::kByte, g.dev, T, g.B, pitch);
+  if (perf.has_value()) want_rows(*perf, "perf", at::kChar, g.dev, T, g.B, pitch);
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
+  CampxOutputs out{};
+  out.scalar_pitch = pitch;
+  out.reward = opt_ptr<float>(reward);
+  out.discount = opt_ptr<float>(discount);
+  out.done = opt_ptr<uint8_t>(step_done);
+  out.perf = opt_ptr<int8_t>(perf);
+  out.trace = reinterpret_cast<uint8_t*>(trace.data_ptr());
+  out.bad_count = opt_ptr<int32_t>(bad_count);
+  out.bad_flag = flag_ptr(bad_flag, g.dev);
+  CampxOutputs prev{};
+  prev.scalar_pitch = prev_pitch;
+  prev.obs_format = obs_format_of(prev_obs);
+  want(prev_obs, "prev_obs", prev_obs.scalar_type(), g.dev, {T, g.B, g.L, g.H, g.W});
+  prev.obs = reinterpret_cast<int8_t*>(prev_obs.data_ptr());
+  prev.obs_t_stride = g.B * g.L * g.H * g.W;
+  prev.trace = reinterpret_cast<uint8_t*>(prev_trace.data_ptr());
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
+  check_ok(campx_update_render_launch(g.spec_host, g.spec_dev, g.state,
+                                      reinterpret_cast<const int8_t*>(actions.data_ptr()), out, prev,
+                                      g.B, (int32_t)T, reset_first ? 1 : 0,
+                                      c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
+           "campx_update_render_launch");
+}
+
 // One Engine.play() frame: actions [B], per-frame outputs [B].
 void step(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
           const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions, Tensor& obs,
@@ -587,6 +635,10 @@ void update_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor
                  const Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                  const OptTensor&, Tensor&, const OptTensor&, const OptTensor&, bool) {}
 void render_meta(const Tensor&, const Tensor&, const Tensor&, Tensor&, const OptTensor&) {}
+void update_render_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
+                        const OptTensor&, const Tensor&, const OptTensor&, const OptTensor&,
+                        const OptTensor&, const OptTensor&, Tensor&, const OptTensor&,
+                        const OptTensor&, bool, const Tensor&, Tensor&) {}
 void shape_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
@@ -645,6 +697,11 @@ TORCH_LIBRARY(campx, m) {
       "render(Tensor spec_host, Tensor spec_dev, Tensor trace, Tensor(a!) obs, Tensor(b!)? board) "
       "-> ()");
   m.def(
+      "update_render(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, "
+      "Tensor(c!)? ret, Tensor? pair_table, Tensor actions, Tensor(d!)? reward, Tensor(e!)? discount, "
+      "Tensor(f!)? step_done, Tensor(g!)? perf, Tensor(h!) trace, Tensor(i!)? bad_count, "
+      "Tensor(j!)? bad_flag, bool reset_first, Tensor prev_trace, Tensor(k!) prev_obs) -> ()");
+  m.def(
       "shape_rollout(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, "
       "Tensor(c!)? ret, Tensor(d!)? backdrop_state, Tensor? actions, Tensor(e!) obs, "
       "Tensor(f!)? board, Tensor(g!)? reward, Tensor(h!)? discount, Tensor(i!)? step_done, "
@@ -665,6 +722,7 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
   m.impl("rollout", &rollout);
   m.impl("update", &update);
   m.impl("render", &render);
+  m.impl("update_render", &update_render);
   m.impl("shape_rollout", &shape_rollout);
   m.impl("wide_rollout", &wide_rollout);
   m.impl("onehot_to_ids", &onehot_to_ids);
@@ -672,7 +730,7 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
 }
 
 TORCH_LIBRARY_IMPL(campx, ADInplaceOrView, m) {
-  for (const char* name : {"reset", "step", "rollout", "update", "render", "shape_rollout",
+  for (const char* name : {"reset", "step", "rollout", "update", "render", "update_render", "shape_rollout",
                            "wide_rollout", "onehot_to_ids", "check_actions"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&run_then_bump_versions>());
 }
@@ -683,6 +741,7 @@ TORCH_LIBRARY_IMPL(campx, Meta, m) {
   m.impl("rollout", &rollout_meta);
   m.impl("update", &update_meta);
   m.impl("render", &render_meta);
+  m.impl("update_render", &update_render_meta);
   m.impl("shape_rollout", &shape_rollout_meta);
   m.impl("wide_rollout", &wide_rollout_meta);
   m.impl("onehot_to_ids", &onehot_to_ids_meta);

@@ -1516,4 +1516,174 @@ int32_t launch_overlap(const CampxSpec& s, const CampxSpec* spec_dev, CampxState
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
+// ---------------------------------------------------------------------------
+// Rollouts pipelined ACROSS calls (round 4): one launch holds the update pass of rollout i + 1
+// AND the render pass of rollout i.  The two have nothing to do with each other - the render
+// role reads the trace the PREVIOUS launch left complete in memory, the update role writes
+// another trace buffer - so, unlike overlap_table_kernel above, nothing polls and nothing
+// persists: workgroups [0, U) are update workgroups (dispatched first: they are the latency
+// chain), every later one renders one 2 KiB window per wave of one frame and leaves, like a
+// render_kernel block.  What a caller pays for it: the observations of a rollout are complete
+// only after the NEXT call (or FusedGame.flush()), and the next rollout's actions must be known
+// when this one's observations are asked for - open-loop action streams (bench.py --deferred).
+// Scope as overlap_table_kernel: one-mover table games, int8 observations of every frame,
+// frames of whole 16-byte chunks; anything else runs the two passes one after the other.
+#ifndef CAMPX_PIPE_WIN
+#define CAMPX_PIPE_WIN 2
+#endif
+constexpr int kPipeWin = CAMPX_PIPE_WIN;                   // KiB per render wave
+constexpr uint32_t kPipeSpan = 1024u * kPipeWin;
+#ifndef CAMPX_PIPE_PROD
+#define CAMPX_PIPE_PROD 1
+#endif
+#ifndef CAMPX_PIPE_CONS
+#define CAMPX_PIPE_CONS 2
+#endif
+// Small workgroups - one producer wave (64 environments), two consumer waves, one loader: what
+// the render role needs is many short waves per CU that come and go one by one (as 14-wave
+// workgroups of the update kernel's own shape it streamed at two thirds of render_kernel's rate)
+constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS;
+constexpr int kPipeWaves = kPipeProd + kPipeCons + update_loaders(kPipeProd);
+constexpr int kPipeEnvs = kPipeProd * kWave;
+
+__global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
+    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, FrameCodec fc, OverlapRender rr) {
+  __shared__ UpdateTableLds<kPipeProd, kOvGroup> L;
+  static_assert(sizeof(L) >= kPipeWaves * (kPipeSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
+  if (blockIdx.x < rr.U) {
+    update_table_body<kPipeProd, kPipeCons, kOvGroup, false>(L, blockIdx.x, nullptr, mp, spec, st, actions,
+                                                         out, B, T, reset_first, fc);
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t item = blockIdx.x - rr.U;
+  const uint32_t t = item / rr.per_frame;
+  uint32_t wx = item - t * rr.per_frame;
+  wx = (wx & 7u) * (rr.per_frame >> 3) + (wx >> 3);    // per_frame is a multiple of 8: one XCD, one eighth
+  const uint32_t shift = (rr.shift_base + t * rr.shift_slab) & (kPipeSpan - 1u);
+  const uint32_t widx = wx * (uint32_t)kPipeWaves + wave;
+  if ((uint64_t)widx * kPipeSpan >= (uint64_t)rr.slab_bytes + shift) return;
+  int8_t* win0 = reinterpret_cast<int8_t*>(&L) + wave * (kPipeSpan + 2 * CAMPX_MAX_CELLS);
+  uint16_t* scen_off = reinterpret_cast<uint16_t*>(win0 + kPipeSpan);
+  const uint32_t R = rr.R;
+  const uint32_t rot_pitch = ((R + 15u) & ~15u) + 16u;
+  const uint32_t woff0 = widx * kPipeSpan - shift;
+  const uint32_t wlo = widx * kPipeSpan < shift ? 0u : woff0;
+  const uint32_t whi = __umulhi(rr.m, wlo);
+  const uint32_t first_row = (((wlo - whi) >> rr.sh1) + whi) >> rr.sh2;
+  const uint32_t wend = (woff0 + kPipeSpan - 1u < rr.slab_bytes) ? woff0 + kPipeSpan - 1u : rr.slab_bytes - 1u;
+  const uint32_t ehi = __umulhi(rr.m, wend);
+  const uint32_t last_row = (((wend - ehi) >> rr.sh1) + ehi) >> rr.sh2;
+  const uint32_t slots = (last_row - first_row + 1u) * 2u;     // (row) x (set | clear)
+  const uint8_t* frame_trace = rr.trace + (int64_t)t * rr.pitch;
+  // ---- loads first: two trace bytes, the window's scenery chunks, two cells' scenery layer
+  uint32_t ent[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    uint32_t row = first_row + ((lane + (uint32_t)it * kWave) >> 1);
+    row = row <= last_row ? row : last_row;
+    ent[it] = frame_trace[row];
+  }
+  u32x4 scen[kPipeWin];
+#pragma unroll
+  for (int j = 0; j < kPipeWin; ++j) {
+    const uint32_t off = woff0 + (uint32_t)j * 1024u + lane * 16u;
+    const uint32_t hi = __umulhi(rr.m, off);
+    const uint32_t row = (((off - hi) >> rr.sh1) + hi) >> rr.sh2;
+    const uint32_t k = off - row * R;
+    scen[j] = *reinterpret_cast<const u32x4*>(rr.rot + (k & 15u) * rot_pitch + (k & ~15u));
+  }
+  const uint32_t top2 = *reinterpret_cast<const uint16_t*>(rr.top_layer + 2u * lane);
+#pragma unroll
+  for (int j = 0; j < kPipeWin; ++j)
+    *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16u) = scen[j];
+  {
+    const uint32_t c = 2u * lane;
+    const uint32_t lo = (top2 & 0xffu) * (uint32_t)rr.cells + c;
+    const uint32_t hi2 = (top2 >> 8) * (uint32_t)rr.cells + c + 1u;
+    *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
+  }
+  // ---- patches: the mover's 1, and the scenery's 1 it hides
+  auto apply = [&](uint32_t sidx, uint32_t e) {
+    const uint32_t r = sidx >> 1, p = sidx & 1u;
+    const uint32_t cell = e & 0x7fu;
+    const uint32_t byte = p ? (uint32_t)rr.dyn_off + cell : (uint32_t)scen_off[cell];
+    const uint32_t at = (first_row + r) * R + byte - woff0;
+    if (sidx < slots && (e >> 7) && at < kPipeSpan) win0[at] = (int8_t)p;
+  };
+  apply(lane, ent[0]);
+  apply(lane + kWave, ent[1]);
+  for (uint32_t sidx = lane + 2u * kWave; sidx < slots; sidx += kWave)     // tiny rows only
+    apply(sidx, (uint32_t)frame_trace[first_row + (sidx >> 1)]);
+  // ---- out: aligned, contiguous KiB stores
+  int8_t* frame = rr.dst + (int64_t)t * rr.slab_bytes;
+#pragma unroll
+  for (int j = 0; j < kPipeWin; ++j) {
+    const uint32_t off = woff0 + (uint32_t)j * 1024u + lane * 16u;
+    if (off < rr.slab_bytes)
+      __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16u),
+                                  reinterpret_cast<u32x4*>(frame + off));
+  }
+}
+
+// Whether launch_pipe() can put these two passes in one launch (`prev`: the rollout to render).
+bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& prev, int64_t B,
+             int32_t T, bool use_table) {
+  static const bool off = [] { const char* v = getenv("CAMPX_NO_PIPE"); return v && v[0] == '1'; }();
+  const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
+  if (off || !use_table || s.n_dyn != 1 || !prev.trace || !prev.obs || prev.board) return false;
+  if (prev.obs_format != CAMPX_OBS_INT8 || prev.obs_t_stride != B * R) return false;
+  if ((B * R) % 16 != 0 || B * R >= (int64_t)1 << 31 || T > 65535) return false;
+  if (reinterpret_cast<uintptr_t>(prev.obs) & 15) return false;
+  (void)out;
+  return true;
+}
+
+int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                    const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
+                    int32_t T, int32_t reset_first, hipStream_t stream) {
+  const int HW = s.rows * s.cols;
+  const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
+                          s.dyn_row0[0], s.dyn_col0[0]};
+  const FrameCodec fc = make_codec(s);
+  OverlapRender rr;
+  memset(&rr, 0, sizeof(rr));
+  rr.R = (uint32_t)(s.n_layers * HW);
+  uint32_t l = 0;
+  while ((1ull << l) < rr.R) ++l;
+  rr.m = (uint32_t)(((1ull << 32) * ((1ull << l) - rr.R)) / rr.R + 1);   // as launch_render_from
+  rr.sh1 = l < 1 ? l : 1;
+  rr.sh2 = l > 0 ? l - 1 : 0;
+  rr.slab_bytes = (uint32_t)(B * rr.R);
+  rr.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(prev.obs) & (kPipeSpan - 1u));
+  rr.shift_slab = rr.slab_bytes & (kPipeSpan - 1u);
+  rr.cells = HW;
+  rr.dyn_off = s.dyn_layer[0] * HW;
+  rr.pitch = row_pitch(prev, B);
+  const char* blob = reinterpret_cast<const char*>(spec_dev);
+  rr.rot = reinterpret_cast<const int8_t*>(blob + offsetof(CampxSpec, rot_obs));
+  rr.top_layer = reinterpret_cast<const uint8_t*>(blob + offsetof(CampxSpec, static_top_layer));
+  rr.trace = prev.trace;
+  rr.dst = prev.obs;
+  rr.T = T;
+  const uint64_t reach = (uint64_t)rr.slab_bytes + ((rr.shift_base | rr.shift_slab) ? kPipeSpan - 1u : 0u);
+  const uint64_t block_span = (uint64_t)kPipeSpan * kPipeWaves;
+  rr.per_frame = (uint32_t)(((reach + block_span - 1) / block_span + 7) & ~7ull);
+  rr.U = (uint32_t)((B + kPipeEnvs - 1) / kPipeEnvs);
+  const uint64_t n_blocks = (uint64_t)rr.U + (uint64_t)T * rr.per_frame;
+  if (n_blocks > 0x7fffffffull) return CAMPX_EINVAL;
+  const dim3 grid((unsigned)n_blocks), block(kPipeWaves * kWave);
+  // (84 VGPRs: 20 waves per CU.  Squeezed into 80 or 72 registers - 24 / 28 waves, the update
+  // body spilling - the launch was slower from 32 768 environments up and at 4 096, level at
+  // 16 384: profiles/r04_deferred_ab.txt)
+  hipLaunchKernelGGL(pipe_table_kernel, grid, block, 0, stream, mp, spec_dev, st, actions, out, B, T,
+                     reset_first, fc, rr);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+
 }  // namespace campx_impl

@@ -183,6 +183,8 @@ class FusedGame(object):
     self._rollout = _hip.ops.rollout.default
     self._update = _hip.ops.update.default
     self._render = _hip.ops.render.default
+    self._update_render = _hip.ops.update_render.default
+    self._deferred = None      # rollout_deferred(): the dict whose observations are still owed
     # pipelined rollouts: the update pass runs on this side stream
     self._aux = None
     self._aux_event = None
@@ -489,3 +491,68 @@ class FusedGame(object):
     if validate:
       self._after_launch()
     return out
+
+  def rollout_deferred(self, actions, out, reset_first=False):
+    """Rollouts pipelined across calls: T frames of update pass now, their observations with
+    the NEXT call.
+
+    One launch holds this rollout's update pass (Engine.play() x T, campx/engine.py:145-222,
+    without rendering) and the render pass (campx/engine.py:286-324) of the rollout handed to
+    the previous `rollout_deferred()` call - two pieces of work that do not depend on each
+    other, so the latency chain of the one hides under the observation stream of the other
+    (`campx_update_render_launch`, include/campx_hip.h).  After the call `out`'s per-frame
+    scalars and trace are this rollout's; its 'obs' are written by the next call, or by
+    `flush()`.  For callers whose next actions do not wait for those observations (open-loop
+    action streams: random exploration, scripted or replayed episodes).
+
+    Args:
+      actions: int tensor [T, B] of action ids.
+      out: a dict from `rollout_buffers(T)` (every frame kept, no flat board); not the dict
+          of the previous call - alternate two of them.  They may share 'obs'
+          (`rollout_buffers(T, share=first)`): a rollout's observations are complete after the
+          next call and, shared, overwritten by the one after that.
+    Returns:
+      the previous call's dict, whose 'obs' this launch completes; None on the first call.
+    """
+    T = int(actions.shape[0])
+    if (torch.is_tensor(actions) and actions.dtype == torch.int8
+        and actions.device == self.device and actions.shape == (T, self.batch)
+        and actions.is_contiguous()):
+      ids = actions
+    else:
+      ids = self._action_ids(actions, (T, self.batch))
+    if out.get('trace') is None or out.get('board') is not None or out['obs'].dim() != 5:
+      raise ValueError('deferred rollouts need rollout_buffers(T) of the two-kernel path: every '
+                       'frame kept, a trace buffer, no flat board')
+    prev = self._deferred
+    if prev is not None and (prev is out or prev['trace'].data_ptr() == out['trace'].data_ptr()):
+      raise ValueError('`out` is the dict whose observations are still to be rendered: '
+                       'alternate two rollout_buffers() (they may share `obs`: '
+                       'rollout_buffers(T, share=first))')
+    # (a rollout of another length: its observations now, by the ordinary render kernel)
+    share = prev is not None and tuple(prev['trace'].shape) == tuple(out['trace'].shape)
+    if prev is not None and not share:
+      self.flush()
+    validate = self.validate_actions
+    self._aux_in_sync = False
+    head = (self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self._pair_table, ids,
+            out['reward'], out['discount'], out['done'], out['perf'], out['trace'],
+            self._bad if validate else None, self._bad_flag if validate else None,
+            bool(reset_first))
+    if share:
+      self._update_render(*(head + (prev['trace'], prev['obs'])))
+    else:
+      self._update(*head)
+    self._deferred = out
+    self.frame = T if reset_first else self.frame + T
+    if validate:
+      self._after_launch()
+    return prev
+
+  def flush(self):
+    """Render the rollout `rollout_deferred()` still owes its observations; returns its dict
+    (None if there is none)."""
+    prev, self._deferred = self._deferred, None
+    if prev is not None:
+      self._render(self._spec_host, self._spec_dev, prev['trace'], prev['obs'], None)
+    return prev

@@ -372,6 +372,23 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
                             int64_t B, int32_t T, void* stream);
 
 /*
+ * Rollouts pipelined across calls: the update pass of one rollout (as campx_update_launch:
+ * `actions`, `out`) together with the render pass of the rollout BEFORE it (as
+ * campx_render_launch: `prev.trace` -> `prev.obs` / `prev.board`, same B and T), for callers
+ * whose next actions do not depend on the observations they are waiting for (open-loop action
+ * streams; the reference has no such call - it is Engine.play(), campx/engine.py:145-222,
+ * T times for rollout i + 1 interleaved with the _render() calls, engine.py:286-324, of
+ * rollout i).  For one-mover table games with int8 observations of whole 16-byte chunks per
+ * frame and no flat board the two passes share ONE launch (update workgroups first, the others
+ * render); otherwise they are issued one after the other on `stream`.  prev.trace == NULL:
+ * the update pass alone.  CAMPX_NO_PIPE=1 in the environment: always one after the other.
+ */
+int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
+                                   CampxState state, const int8_t* actions, CampxOutputs out,
+                                   CampxOutputs prev, int64_t B, int32_t T, int32_t reset_first,
+                                   void* stream);
+
+/*
  * ---- Shape tier --------------------------------------------------------------------
  * Games made only of rigidly translated things that interact with nothing: the
  * reference's Hello World (examples/Hello World Example.ipynb cell 3: RollingDrape

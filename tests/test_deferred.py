@@ -1,0 +1,105 @@
+"""Rollouts pipelined across calls (FusedGame.rollout_deferred / flush: the update pass of one
+rollout and the render pass of the one before it in one launch, csrc/k_update.hip
+pipe_table_kernel behind campx_update_render_launch).  Every byte of every frame against the C
+oracle, over several calls with the state carried from one to the next: batch sizes whose last
+update workgroup is partial, whose frames are not whole 16-byte chunks (the two passes then run
+one after the other), below and above the batch from which the launch runs two workgroups per
+CU, rollouts of changing length, and a two-mover game (no shared launch at all)."""
+
+import numpy as np
+import pytest
+import torch
+
+from campx_amd import gamespec
+from campx_amd.games import boat_race, sokoban, wall_world
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(build, B, Ts, seed, build_kwargs=None):
+  kw = build_kwargs or {}
+  game = build(batch=B, device='cuda', **kw)
+  game.its_showtime()
+  fused = game.fused
+  og = cpu.OracleGame.from_description(gamespec.describe(build(**kw)))
+  rng = np.random.RandomState(seed)
+  refs, dicts = [], []
+  bufs = {}
+  for call, T in enumerate(Ts):
+    actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+    refs.append(og.rollout(actions, reset_first=(call == 0)))
+    key = (T, sum(1 for d in dicts if d['obs'].shape[0] == T) & 1)
+    if key not in bufs:
+      bufs[key] = fused.rollout_buffers(T)
+    out = bufs[key]
+    out['obs'].fill_(-7)
+    prev = fused.rollout_deferred(torch.from_numpy(actions).cuda(), out, reset_first=(call == 0))
+    assert prev is (dicts[-1] if dicts else None)
+    # this call's scalars are ready, the previous call's observations too
+    for k in ('reward', 'discount'):
+      if out[k] is not None:
+        assert np.array_equal(out[k].cpu().numpy().view(np.uint32), refs[-1][k].view(np.uint32)), (B, call, k)
+    assert np.array_equal(out['done'].cpu().numpy(), refs[-1]['done']), (B, call)
+    if prev is not None:
+      assert np.array_equal(prev['obs'].cpu().numpy(), refs[-2]['obs']), (B, call - 1)
+    dicts.append(out)
+  last = fused.flush()
+  assert last is dicts[-1]
+  assert np.array_equal(last['obs'].cpu().numpy(), refs[-1]['obs']), (B, 'flush')
+  assert fused.flush() is None
+  # ... and the engine carries on from there on the ordinary path
+  actions = rng.randint(0, 5, size=(20, B)).astype(np.int8)
+  out = game.rollout(torch.from_numpy(actions))
+  ref = og.rollout(actions)
+  assert np.array_equal(out['obs'].cpu().numpy(), ref['obs'])
+
+
+@pytest.mark.parametrize('B', [16, 1000, 1024, 4096, 5008, 16384])
+def test_boat_race_deferred_matches_oracle(B):
+  _check(boat_race.build, B, [100, 100, 33, 100, 33], seed=B)
+
+
+def test_wall_world_deferred_matches_oracle():
+  _check(wall_world.build, 2000, [64, 64, 64], seed=5)
+
+
+def test_two_mover_game_runs_the_passes_one_after_the_other():
+  _check(sokoban.build, 512, [50, 50, 50], seed=6)
+
+
+def test_deferred_rollouts_refuse_what_they_cannot_do():
+  game = boat_race.build(batch=64, device='cuda')
+  game.its_showtime()
+  fused = game.fused
+  a = torch.zeros((10, 64), dtype=torch.int8, device='cuda')
+  with pytest.raises(ValueError, match='deferred rollouts need'):
+    fused.rollout_deferred(a, fused.rollout_buffers(10, want_board=True))
+  with pytest.raises(ValueError, match='deferred rollouts need'):
+    fused.rollout_deferred(a, fused.rollout_buffers(10, keep_obs=False))
+  out = fused.rollout_buffers(10)
+  assert fused.rollout_deferred(a, out) is None
+  with pytest.raises(ValueError, match='still to be rendered'):
+    fused.rollout_deferred(a, out)
+  assert fused.flush() is out
+
+
+def test_two_buffer_sets_may_share_their_observations():
+  B, T = 1024, 50
+  game = boat_race.build(batch=B, device='cuda')
+  game.its_showtime()
+  fused = game.fused
+  og = cpu.OracleGame.from_description(gamespec.describe(boat_race.build()))
+  rng = np.random.RandomState(3)
+  first = fused.rollout_buffers(T)
+  sets = [first, fused.rollout_buffers(T, share=first)]
+  ref_prev = None
+  for call in range(5):
+    actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+    ref = og.rollout(actions, reset_first=(call == 0))
+    prev = fused.rollout_deferred(torch.from_numpy(actions).cuda(), sets[call & 1],
+                                  reset_first=(call == 0))
+    if prev is not None:
+      assert np.array_equal(prev['obs'].cpu().numpy(), ref_prev['obs']), call
+    ref_prev = ref
+  assert np.array_equal(fused.flush()['obs'].cpu().numpy(), ref_prev['obs'])
