@@ -24,7 +24,7 @@ EXPORTS = ('campx_spec_size', 'campx_overlap_ctl_bytes', 'campx_spec_validate', 
            'campx_pair_table_bytes', 'campx_pair_table_build', 'campx_pair_table_pack',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
-           'campx_update_render_launch',
+           'campx_update_render_launch', 'campx_update_render_shared',
            'campx_shape_spec_size', 'campx_shape_spec_validate',
            'campx_shape_rollout_launch',
            'campx_wide_spec_size', 'campx_wide_spec_validate', 'campx_wide_tables_bytes',
@@ -92,6 +92,8 @@ def _load():
   lib.campx_update_render_launch.argtypes = [spec_p, vp, CampxState, vp, CampxOutputs, CampxOutputs,
                                              i64, i32, i32, vp]
   lib.campx_update_render_launch.restype = i32
+  lib.campx_update_render_shared.argtypes = [spec_p, i64, i32]
+  lib.campx_update_render_shared.restype = i32
   lib.campx_shape_spec_size.restype = i32
   lib.campx_shape_spec_size.argtypes = []
   lib.campx_shape_spec_validate.restype = i32

@@ -675,6 +675,18 @@ int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* 
   return launch_renders(*spec_host, spec_dev, prev, B, T, (int64_t)T * row_pitch(prev, B), s);
 }
 
+int32_t campx_update_render_shared(const CampxSpec* spec_host, int64_t B, int32_t T) {
+  if (!spec_host || B <= 0 || T <= 0 || campx_spec_validate(spec_host) != CAMPX_OK) return 0;
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
+                         (!knob_no_table() || spec_host->table_only);
+  CampxOutputs prev{};       // int8 observations of every frame, back to back, 16-byte aligned
+  prev.obs = reinterpret_cast<int8_t*>(uintptr_t{4096});
+  prev.trace = reinterpret_cast<uint8_t*>(uintptr_t{4096});
+  prev.obs_t_stride = B * spec_host->n_layers * spec_host->rows * spec_host->cols;
+  prev.obs_format = CAMPX_OBS_INT8;
+  return pipe_ok(*spec_host, prev, prev, B, T, use_table) ? 1 : 0;
+}
+
 int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out) {
   if (!stream_out) return CAMPX_EINVAL;
   int dev = 0, cus = 0;

@@ -1552,14 +1552,18 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     int32_t reset_first, FrameCodec fc, OverlapRender rr) {
   __shared__ UpdateTableLds<kPipeProd, kOvGroup> L;
   static_assert(sizeof(L) >= kPipeWaves * (kPipeSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
+  // Which role: the first U workgroups update.  (Spreading them among the render ones - every
+  // 24th / 48th / 96th workgroup - was slower at every size tried: an update wave that shares
+  // its SIMD with streaming waves walks its chain more slowly, lives longer, and more of them
+  // pile up; profiles/r04_deferred_ab.txt section 5.)
   if (blockIdx.x < rr.U) {
     update_table_body<kPipeProd, kPipeCons, kOvGroup, false>(L, blockIdx.x, nullptr, mp, spec, st, actions,
                                                          out, B, T, reset_first, fc);
     return;
   }
+  const uint32_t item = blockIdx.x - rr.U;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t item = blockIdx.x - rr.U;
   const uint32_t t = item / rr.per_frame;
   uint32_t wx = item - t * rr.per_frame;
   wx = (wx & 7u) * (rr.per_frame >> 3) + (wx >> 3);    // per_frame is a multiple of 8: one XCD, one eighth
@@ -1638,6 +1642,22 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
   if (prev.obs_format != CAMPX_OBS_INT8 || prev.obs_t_stride != B * R) return false;
   if ((B * R) % 16 != 0 || B * R >= (int64_t)1 << 31 || T > 65535) return false;
   if (reinterpret_cast<uintptr_t>(prev.obs) & 15) return false;
+  // Where one launch beats two (boat race / wall world, T = 100, of HBM peak, two launches ->
+  // one; profiles/r04_deferred_ab.txt): B = 4 096 0.34 -> 0.53, 16 384 0.62 -> 0.75 / 0.77 ->
+  // 0.80, 65 536 0.82 -> 0.83-0.88 / 0.87 -> 0.83, 200 000 0.83 -> 0.57.  The render role streams
+  // ~4 % below render_kernel's rate (84 VGPRs: 20 waves per CU), which hiding ~15 us of update
+  // pass repays only while the observations of a rollout are under ~2 GB; and the update
+  // workgroups, dispatched first, must leave room for render ones in the first wave of
+  // resident workgroups (5 per CU, 1 280: at most 1 024 update workgroups, 65 536 environments).
+  static const int64_t max_b = [] {
+    const char* v = getenv("CAMPX_PIPE_MAX_B");
+    return (int64_t)(v && *v ? atoll(v) : 1024 * kPipeEnvs);
+  }();
+  static const int64_t max_bytes = [] {
+    const char* v = getenv("CAMPX_PIPE_MAX_BYTES");
+    return (int64_t)(v && *v ? atoll(v) : 2000000000ll);
+  }();
+  if (B > max_b || B * R * T > max_bytes) return false;
   (void)out;
   return true;
 }

@@ -185,6 +185,8 @@ class FusedGame(object):
     self._render = _hip.ops.render.default
     self._update_render = _hip.ops.update_render.default
     self._deferred = None      # rollout_deferred(): the dict whose observations are still owed
+    self._deferred_rendered = False    # ... unless that rollout was run whole (no shared launch)
+    self._shared_launch = {}   # T -> whether campx_update_render_launch shares one launch
     # pipelined rollouts: the update pass runs on this side stream
     self._aux = None
     self._aux_event = None
@@ -505,6 +507,12 @@ class FusedGame(object):
     `flush()`.  For callers whose next actions do not wait for those observations (open-loop
     action streams: random exploration, scripted or replayed episodes).
 
+    Where the library has no shared launch for the game or the sizes (two moving things, more
+    than 65 536 environments or ~2 GB of observations per rollout, batches whose frames are not
+    whole 16-byte chunks: `campx_update_render_shared`), the rollout is run whole at once -
+    deferring would only make its render read a trace gone cold - and `out` is simply complete
+    a call early.
+
     Args:
       actions: int tensor [T, B] of action ids.
       out: a dict from `rollout_buffers(T)` (every frame kept, no flat board); not the dict
@@ -529,12 +537,35 @@ class FusedGame(object):
       raise ValueError('`out` is the dict whose observations are still to be rendered: '
                        'alternate two rollout_buffers() (they may share `obs`: '
                        'rollout_buffers(T, share=first))')
-    # (a rollout of another length: its observations now, by the ordinary render kernel)
-    share = prev is not None and tuple(prev['trace'].shape) == tuple(out['trace'].shape)
-    if prev is not None and not share:
-      self.flush()
     validate = self.validate_actions
     self._aux_in_sync = False
+    one_launch = self._shared_launch.get(T)
+    if one_launch is None:
+      one_launch = self._shared_launch[T] = bool(_hip.lib.campx_update_render_shared(
+          ctypes.byref(self.spec), self.batch, T))
+    if not one_launch or out['obs'].dtype != torch.int8:
+      # Nothing to gain from deferring (two movers, a batch or a rollout too big for the shared
+      # launch, 16-bit observations): the whole rollout now, rendered while its trace is still
+      # cached.  `out` is complete a call early; what the caller sees is the same.
+      if (prev is not None and not self._deferred_rendered
+          and prev['obs'].data_ptr() == out['obs'].data_ptr()):
+        raise ValueError('the previous rollout still owes its observations to the buffer this '
+                         'one would overwrite at once: flush() and read them first')
+      self.flush()
+      self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                    self._pair_table, ids, out['obs'], None, out['reward'], out['discount'],
+                    out['done'], out['perf'], out['trace'], self._bad if validate else None,
+                    self._bad_flag if validate else None, bool(reset_first), self._overlap_ctl)
+      self._deferred, self._deferred_rendered = out, True
+      self.frame = T if reset_first else self.frame + T
+      if validate:
+        self._after_launch()
+      return prev
+    # (a rollout of another length: its observations now, by the ordinary render kernel)
+    share = (prev is not None and not self._deferred_rendered
+             and tuple(prev['trace'].shape) == tuple(out['trace'].shape))
+    if prev is not None and not share:
+      self.flush()
     head = (self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self._pair_table, ids,
             out['reward'], out['discount'], out['done'], out['perf'], out['trace'],
             self._bad if validate else None, self._bad_flag if validate else None,
@@ -543,7 +574,7 @@ class FusedGame(object):
       self._update_render(*(head + (prev['trace'], prev['obs'])))
     else:
       self._update(*head)
-    self._deferred = out
+    self._deferred, self._deferred_rendered = out, False
     self.frame = T if reset_first else self.frame + T
     if validate:
       self._after_launch()
@@ -553,6 +584,7 @@ class FusedGame(object):
     """Render the rollout `rollout_deferred()` still owes its observations; returns its dict
     (None if there is none)."""
     prev, self._deferred = self._deferred, None
-    if prev is not None:
+    if prev is not None and not self._deferred_rendered:
       self._render(self._spec_host, self._spec_dev, prev['trace'], prev['obs'], None)
+    self._deferred_rendered = False
     return prev

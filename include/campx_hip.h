@@ -387,6 +387,12 @@ int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* 
                                    CampxState state, const int8_t* actions, CampxOutputs out,
                                    CampxOutputs prev, int64_t B, int32_t T, int32_t reset_first,
                                    void* stream);
+/* 1 if campx_update_render_launch() puts the two passes of such rollouts (int8 observations of
+ * every frame, no flat board) in one launch, 0 if it would issue them one after the other - in
+ * which case a caller does better not to defer at all: campx_rollout_launch() renders a trace
+ * that is still cached, a deferred render reads one that a whole launch has since evicted
+ * (boat race, B = 200 000: 0.67 of peak against 0.83). */
+int32_t campx_update_render_shared(const CampxSpec* spec_host, int64_t B, int32_t T);
 
 /*
  * ---- Shape tier --------------------------------------------------------------------

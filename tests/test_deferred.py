@@ -2,14 +2,18 @@
 rollout and the render pass of the one before it in one launch, csrc/k_update.hip
 pipe_table_kernel behind campx_update_render_launch).  Every byte of every frame against the C
 oracle, over several calls with the state carried from one to the next: batch sizes whose last
-update workgroup is partial, whose frames are not whole 16-byte chunks (the two passes then run
-one after the other), below and above the batch from which the launch runs two workgroups per
-CU, rollouts of changing length, and a two-mover game (no shared launch at all)."""
+update workgroup is partial, whose frames are not whole 16-byte chunks or that are too big for
+the shared launch (the rollout is then run whole, at once), rollouts of changing length, a
+two-mover game (no shared launch at all), and the C entry point's own fallback - the two passes
+one after the other - through the torch op."""
+
+import ctypes
 
 import numpy as np
 import pytest
 import torch
 
+from campx_amd import _hip
 from campx_amd import gamespec
 from campx_amd.games import boat_race, sokoban, wall_world
 from oracle import cpu
@@ -60,6 +64,13 @@ def test_boat_race_deferred_matches_oracle(B):
   _check(boat_race.build, B, [100, 100, 33, 100, 33], seed=B)
 
 
+@pytest.mark.parametrize('B,T', [(32768, 20), (24000, 30), (66000, 10)])
+def test_big_batches(B, T):
+  # 512 and 375 update workgroups in front of the render ones; 66 000 environments are past
+  # what the shared launch takes (65 536): each rollout whole, at once
+  _check(boat_race.build, B, [T, T, T], seed=B)
+
+
 def test_wall_world_deferred_matches_oracle():
   _check(wall_world.build, 2000, [64, 64, 64], seed=5)
 
@@ -103,3 +114,34 @@ def test_two_buffer_sets_may_share_their_observations():
       assert np.array_equal(prev['obs'].cpu().numpy(), ref_prev['obs']), call
     ref_prev = ref
   assert np.array_equal(fused.flush()['obs'].cpu().numpy(), ref_prev['obs'])
+
+
+def test_the_entry_point_runs_the_passes_one_after_the_other_when_it_must():
+  # B = 1000: frames of 175 000 bytes, not whole 16-byte chunks - rollout_deferred() would not
+  # defer at all; campx_update_render_launch itself (C callers) issues update, then render
+  B, T = 1000, 40
+  game = boat_race.build(batch=B, device='cuda')
+  game.its_showtime()
+  fused = game.fused
+  assert not _hip.lib.campx_update_render_shared(ctypes.byref(fused.spec), B, T)
+  assert _hip.lib.campx_update_render_shared(ctypes.byref(fused.spec), 1024, T)
+  og = cpu.OracleGame.from_description(gamespec.describe(boat_race.build()))
+  rng = np.random.RandomState(11)
+  sets = [fused.rollout_buffers(T), fused.rollout_buffers(T)]
+  acts = [rng.randint(0, 5, size=(T, B)).astype(np.int8) for _ in range(3)]
+  refs = [og.rollout(a, reset_first=(i == 0)) for i, a in enumerate(acts)]
+
+  def head(i):
+    o = sets[i & 1]
+    return (fused._spec_host, fused._spec_dev, fused.pos, fused.done, fused.ret, fused._pair_table,
+            torch.from_numpy(acts[i]).cuda(), o['reward'], o['discount'], o['done'], o['perf'],
+            o['trace'], None, None, i == 0)
+  fused._update(*head(0))
+  for i in (1, 2):
+    prev = sets[(i - 1) & 1]
+    prev['obs'].fill_(-7)
+    fused._update_render(*(head(i) + (prev['trace'], prev['obs'])))
+    assert np.array_equal(prev['obs'].cpu().numpy(), refs[i - 1]['obs']), i
+    assert np.array_equal(sets[i & 1]['reward'].cpu().numpy(), refs[i]['reward']), i
+  with pytest.raises(RuntimeError, match='trace buffer each'):
+    fused._update_render(*(head(2) + (sets[0]['trace'], sets[0]['obs'])))

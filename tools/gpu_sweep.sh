@@ -1,11 +1,11 @@
 #!/bin/bash
 # Roofline fraction across batch sizes and episode lengths (through gpurun):
-#   tools/gpu_sweep.sh <game> "<batches>" "<frames>"
+#   [BENCH_FLAGS=--deferred] tools/gpu_sweep.sh <game> "<batches>" "<frames>"
 cd "$GRAFT_REPO_ROOT"
 game=$1
 for b in $2; do for t in $3; do
-  python bench.py --game $game --batch $b --frames $t --steps 30 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
+  python bench.py --game $game --batch $b --frames $t --steps 30 --warmup 20 --no-cpu-baseline --no-extras ${BENCH_FLAGS:-} 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('SWEEP %-10s B=%7d T=%5d  %8.4f ms  frac %.3f  %s' % ('$game', $b, $t, d['ms_per_step'], r['frac'], r['kernel']))"
+print('SWEEP %-10s B=%7d T=%5d  %8.4f ms  frac %.3f  %s' % ('$game', $b, $t, d['ms_per_step'], r['frac'], r['kernel'] if '--deferred' not in '${BENCH_FLAGS:-}' else 'pipe_table_kernel (deferred)'))"
 done; done
