@@ -18,6 +18,8 @@ from campx_amd import gamespec
 from campx_amd.games import boat_race, sokoban, wall_world
 from oracle import cpu
 
+import traced_games
+
 pytestmark = pytest.mark.gpu
 
 
@@ -145,3 +147,30 @@ def test_the_entry_point_runs_the_passes_one_after_the_other_when_it_must():
     assert np.array_equal(sets[i & 1]['reward'].cpu().numpy(), refs[i]['reward']), i
   with pytest.raises(RuntimeError, match='trace buffer each'):
     fused._update_render(*(head(2) + (sets[0]['trace'], sets[0]['obs'])))
+
+
+def test_host_tabulated_game_deferred_matches_its_ordinary_rollouts():
+  # a game of arbitrary Python classes (tabulated on the host, `table_only`): the same table
+  # kernel body, so the same shared launch - twin engines, one deferred, one not
+  B, T = 2048, 60
+  twins = [traced_games.ice_rink(batch=B, device='cuda') for _ in range(2)]
+  for g in twins:
+    g.its_showtime()
+  a, b = twins[0].fused, twins[1].fused
+  assert a.traced is not None and a.n_dyn == 1
+  assert _hip.lib.campx_update_render_shared(ctypes.byref(a.spec), B, T)
+  rng = np.random.RandomState(2)
+  sets = [a.rollout_buffers(T), a.rollout_buffers(T)]
+  want_prev = None
+  for call in range(4):
+    actions = torch.from_numpy(rng.randint(0, 5, size=(T, B)).astype(np.int8)).cuda()
+    want = b.rollout(actions, reset_first=(call == 2))
+    prev = a.rollout_deferred(actions, sets[call & 1], reset_first=(call == 2))
+    for k in ('reward', 'discount', 'done'):
+      if want[k] is not None:
+        assert torch.equal(sets[call & 1][k], want[k]), (call, k)
+    if prev is not None:
+      assert torch.equal(prev['obs'], want_prev), call
+    want_prev = want['obs']
+  assert torch.equal(a.flush()['obs'], want_prev)
+  assert torch.equal(a.pos, b.pos) and torch.equal(a.ret, b.ret)

@@ -78,3 +78,14 @@ def test_hello_world_example_runs_batched(capsys):
     engine.set_default_batch(None)
   out = capsys.readouterr().out
   assert 'ShapeGame' in out and 'for every environment: True' in out and 'TB/s' in out
+
+
+@pytest.mark.gpu
+def test_deferred_rollouts_example_runs():
+  """examples/random_rollouts_deferred.py: every episode's observations reach the consumer, in
+  order, complete (a 5x5 boat race frame shows 25 cells: one 1 per cell over the 7 layers)."""
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import random_rollouts_deferred as ex
+  got = ex.run(batch=1024, frames=40, episodes=5)
+  assert got['seen'] == [40 * 1024 * 25] * 5
+  assert -3.0 * 40 <= got['mean_return'] <= 2.0 * 40
