@@ -172,6 +172,13 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
     if (rc != CAMPX_OK || !out.board) return rc;
     return launch_render(s, spec_dev, out.trace, out.board, B, T, plane, pitch, true, 0, stream);
   }
+  if (whole && !last_frame_only(out) && flow_ok(s, out, B, T, use_table, stream)) {
+    // one-mover table games up to 65 536 environments: one launch, the render role following
+    // the update role group by group (k_update.hip flow_table launch)
+    int32_t rc = launch_flow(s, spec_dev, st, actions, out, B, T, reset_first, stream);
+    if (rc != CAMPX_OK || !out.board) return rc;
+    return launch_render(s, spec_dev, out.trace, out.board, B, T, plane, pitch, true, 0, stream);
+  }
   if (last_frame_only(out) || whole) {
     const int32_t rc = launch_update(s, spec_dev, st, actions, out, B, T, reset_first, use_table,
                                      plane, stream);
@@ -297,6 +304,10 @@ extern "C" {
 int32_t campx_spec_size(void) { return (int32_t)sizeof(CampxSpec); }
 
 int64_t campx_overlap_ctl_bytes(int64_t B) { return B > 0 ? overlap_ctl_bytes(B) : 0; }
+
+int64_t campx_flow_scratch_bytes(int64_t B, int32_t T) {
+  return B > 0 && T > 0 ? flow_scratch_bytes(B, T) : 0;
+}
 
 int32_t campx_spec_validate(const CampxSpec* s) {
   if (!s) return CAMPX_EINVAL;

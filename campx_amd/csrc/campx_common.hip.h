@@ -563,6 +563,15 @@ int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
                     const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
                     int32_t T, int32_t reset_first, hipStream_t stream);
 
+// k_update.hip: update pass and render of ONE rollout in one launch (the render role waits for
+// the update role's published progress)
+bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table,
+             hipStream_t stream);
+int64_t flow_scratch_bytes(int64_t B, int32_t T);
+int32_t launch_flow(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                    const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                    int32_t reset_first, hipStream_t stream);
+
 // k_render.hip: the observation stream of the two-kernel path
 // Where a render launch finds a game's tables (k_render.hip).
 struct RenderSource {

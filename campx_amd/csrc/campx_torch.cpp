@@ -252,10 +252,11 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, g.dev);
   if (scratch.has_value()) {   // CampxOutputs.overlap_ctl: zeroed once by its owner
+    // (how many bytes each user of it needs is the library's check: too small a block only
+    // means the launch takes another path)
     TORCH_CHECK(scratch->device() == g.dev && scratch->scalar_type() == at::kInt &&
-                    scratch->is_contiguous() && scratch->numel() * 4 >= campx_overlap_ctl_bytes(g.B),
-                "campx::rollout: scratch must be a contiguous int32 tensor on ", g.dev, " of at least ",
-                campx_overlap_ctl_bytes(g.B), " bytes");
+                    scratch->is_contiguous() && scratch->numel() >= 4,
+                "campx::rollout: scratch must be a contiguous int32 tensor on ", g.dev);
     out.overlap_ctl = reinterpret_cast<uint32_t*>(scratch->data_ptr());
     out.overlap_ctl_bytes = scratch->numel() * 4;
   }

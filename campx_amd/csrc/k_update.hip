@@ -3,6 +3,9 @@
 // update_tuple_kernel) and launch_update, which picks one (or the interpreter in trace mode).
 #include "campx_common.hip.h"
 
+#include <mutex>
+#include <unordered_map>
+
 #include <stdio.h>
 #include <type_traits>
 
@@ -302,12 +305,16 @@ struct UpdateTableLds {
 // streams - the trace among them - have been written AND acknowledged (the stores are
 // write-through), the number of complete groups is published there with an agent-scope store:
 // what a render wave of the same launch polls before it reads those rows of the trace.
-template <int kProd, int kCons, int kG, bool kPublish>
+// (`progress_base` + that number: flow_table_kernel's launches count up instead of resetting.)
+// `tagged` (one-launch rollouts, else null): a second copy of the trace as 16-bit entries,
+// byte | tag << 8 - every entry says by itself which launch wrote it, so a render wave of the
+// same launch needs no flag and this role no drain (MI355X_MICROARCH.md: data-tagged granules).
+template <int kProd, int kCons, int kG, bool kPublish, bool kTagged = false>
 __device__ __forceinline__ void update_table_body(
-    UpdateTableLds<kProd, kG>& L, uint32_t wg, uint32_t* progress,
+    UpdateTableLds<kProd, kG>& L, uint32_t wg, uint32_t* progress, uint32_t progress_base,
     const MoverParams& mp, const CampxSpec* __restrict__ spec, const CampxState& st,
     const int8_t* __restrict__ actions, const CampxOutputs& out, int64_t B, int32_t T,
-    int32_t reset_first, const FrameCodec& fc) {
+    int32_t reset_first, const FrameCodec& fc, uint16_t* tagged = nullptr, uint32_t tag = 0) {
   constexpr int kLoad = update_loaders(kProd);
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -479,6 +486,17 @@ __device__ __forceinline__ void update_table_body(
               if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
                 const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
                 store16_update(out.trace + at, t4);
+                if (kTagged) {
+                  const uint32_t tt = (tag << 8) | (tag << 24);
+                  uint32_t e[8];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) {
+                    e[2 * k] = (tr[k] & 0xffu) | ((tr[k] & 0xff00u) << 8) | tt;
+                    e[2 * k + 1] = ((tr[k] >> 16) & 0xffu) | ((tr[k] >> 8) & 0xff0000u) | tt;
+                  }
+                  store16_update(tagged + at, u32x4{e[0], e[1], e[2], e[3]});
+                  store16_update(tagged + at + 8, u32x4{e[4], e[5], e[6], e[7]});
+                }
                 if (out.done) {
                   const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
                   store16_update(out.done + at, d4);
@@ -491,6 +509,9 @@ __device__ __forceinline__ void update_table_body(
                 for (int i = 0; i < 16 && e0 + i < B; ++i) {
                   const int sh = (i & 3) * 8;
                   out.trace[at + i] = (uint8_t)(tr[i >> 2] >> sh);
+                  if (kTagged)
+                    __hip_atomic_store(tagged + at + i, (uint16_t)(((tr[i >> 2] >> sh) & 0xffu) | (tag << 8)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
                   if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
                 }
@@ -505,7 +526,7 @@ __device__ __forceinline__ void update_table_body(
       }
       __syncthreads();
       if (kPublish && g > 0 && clane == 0)
-        __hip_atomic_store(progress, (uint32_t)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(progress, progress_base + (uint32_t)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     for (int g = 0; g <= n_groups; ++g) {
@@ -542,7 +563,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     int32_t reset_first, FrameCodec fc) {
   __shared__ UpdateTableLds<kProd, kG> L;
   update_table_body<kProd, kCons, kG, false>(L, tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD),
-                                             nullptr, mp, spec, st, actions, out, B, T,
+                                             nullptr, 0u, mp, spec, st, actions, out, B, T,
                                              reset_first, fc);
 }
 
@@ -1211,6 +1232,8 @@ struct OverlapRender {
   uint32_t per_frame;          // workgroup-items (kOvWaves windows) per frame
   uint32_t U;                  // update workgroups
   uint32_t* ctl;               // [0] tickets, [1] finished, [4 + u] groups complete of workgroup u
+  uint16_t* tagged;            // one-launch rollouts: the trace's tagged copy [T, pitch], and
+  uint32_t tag;                // this launch's tag (1..255)
 };
 
 __global__ __launch_bounds__(kOvWaves * kWave) void overlap_table_kernel(
@@ -1225,7 +1248,7 @@ __global__ __launch_bounds__(kOvWaves * kWave) void overlap_table_kernel(
   __syncthreads();
   const uint32_t ticket = s_ticket;
   if (ticket < rr.U) {
-    update_table_body<kOvProd, kOvCons, kOvGroup, true>(L, ticket, rr.ctl + 4 + ticket, mp, spec, st,
+    update_table_body<kOvProd, kOvCons, kOvGroup, true>(L, ticket, rr.ctl + 4 + ticket, 0u, mp, spec, st,
                                                         actions, out, B, T, reset_first, fc);
   } else {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1546,6 +1569,9 @@ constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS;
 constexpr int kPipeWaves = kPipeProd + kPipeCons + update_loaders(kPipeProd);
 constexpr int kPipeEnvs = kPipeProd * kWave;
 
+// kFlow: the render role is THIS rollout's (flow_table_kernel below): the update role publishes
+// its progress, a render wave waits for the groups of frames it reads.
+template <bool kFlow>
 __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
@@ -1557,8 +1583,8 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
   // its SIMD with streaming waves walks its chain more slowly, lives longer, and more of them
   // pile up; profiles/r04_deferred_ab.txt section 5.)
   if (blockIdx.x < rr.U) {
-    update_table_body<kPipeProd, kPipeCons, kOvGroup, false>(L, blockIdx.x, nullptr, mp, spec, st, actions,
-                                                         out, B, T, reset_first, fc);
+    update_table_body<kPipeProd, kPipeCons, kOvGroup, false, kFlow>(L, blockIdx.x, nullptr, 0u, mp, spec, st, actions,
+                                                                out, B, T, reset_first, fc, rr.tagged, rr.tag);
     return;
   }
   const uint32_t item = blockIdx.x - rr.U;
@@ -1585,11 +1611,40 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
   const uint8_t* frame_trace = rr.trace + (int64_t)t * rr.pitch;
   // ---- loads first: two trace bytes, the window's scenery chunks, two cells' scenery layer
   uint32_t ent[2];
+  if (kFlow) {
+    // THIS rollout's trace, from its tagged copy: an entry is valid when it carries this
+    // launch's tag (agent-scope loads of the aligned dword an entry sits in; a wave whose rows
+    // are not there yet sleeps and looks again - at its own entries, so nobody polls one line)
+    const uint16_t* frame_tagged = rr.tagged + (int64_t)t * rr.pitch;
+    auto look = [&](uint32_t row) {
+      const uint32_t d = __hip_atomic_load(reinterpret_cast<const uint32_t*>(frame_tagged + (row & ~1u)),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return (d >> ((row & 1u) * 16u)) & 0xffffu;
+    };
+    uint32_t row0 = first_row + (lane >> 1), row1 = first_row + ((lane + kWave) >> 1);
+    row0 = row0 <= last_row ? row0 : last_row;
+    row1 = row1 <= last_row ? row1 : last_row;
+    ent[0] = look(row0);
+    ent[1] = look(row1);
+#ifndef CAMPX_FLOW_NOPOLL       // (=1: a TIMING experiment - never wait; results are wrong)
+    uint32_t naps = 0;
+    while (__any((ent[0] >> 8) != rr.tag || (ent[1] >> 8) != rr.tag)) {
+      if (naps < 4u) __builtin_amdgcn_s_sleep(8);
+      else __builtin_amdgcn_s_sleep(32);
+      ++naps;
+      ent[0] = look(row0);
+      ent[1] = look(row1);
+    }
+#endif
+    ent[0] &= 0xffu;
+    ent[1] &= 0xffu;
+  } else {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    uint32_t row = first_row + ((lane + (uint32_t)it * kWave) >> 1);
-    row = row <= last_row ? row : last_row;
-    ent[it] = frame_trace[row];
+    for (int it = 0; it < 2; ++it) {
+      uint32_t row = first_row + ((lane + (uint32_t)it * kWave) >> 1);
+      row = row <= last_row ? row : last_row;
+      ent[it] = frame_trace[row];
+    }
   }
   u32x4 scen[kPipeWin];
 #pragma unroll
@@ -1621,7 +1676,17 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
   apply(lane, ent[0]);
   apply(lane + kWave, ent[1]);
   for (uint32_t sidx = lane + 2u * kWave; sidx < slots; sidx += kWave)     // tiny rows only
-    apply(sidx, (uint32_t)frame_trace[first_row + (sidx >> 1)]);
+    if (kFlow) {   // (each lane waits for its own entry: rows of under 32 bytes, boards of a few cells)
+      const uint16_t* at = rr.tagged + (int64_t)t * rr.pitch + first_row + (sidx >> 1);
+      uint32_t e = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((e >> 8) != rr.tag) {
+        __builtin_amdgcn_s_sleep(8);
+        e = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      apply(sidx, e & 0xffu);
+    } else {
+      apply(sidx, (uint32_t)frame_trace[first_row + (sidx >> 1)]);
+    }
   // ---- out: aligned, contiguous KiB stores
   int8_t* frame = rr.dst + (int64_t)t * rr.slab_bytes;
 #pragma unroll
@@ -1662,9 +1727,34 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
   return true;
 }
 
-int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
-                    const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
-                    int32_t T, int32_t reset_first, hipStream_t stream) {
+// The tagged copy of the trace of one-launch rollouts lives in the caller's scratch block
+// (CampxOutputs.overlap_ctl): 16 bytes of header, then [T, pitch] 16-bit entries.
+int64_t flow_scratch_bytes(int64_t B, int32_t T) {
+  const int64_t pitch = (B + 15) / 16 * 16;       // (the widest row pitch a caller may use)
+  return 16 + 2 * (int64_t)T * pitch;
+}
+
+// A launch's tag: 1..255, counting up per scratch block (kept here, on the host).  Every launch
+// rewrites every entry of its T frames, so at its start they all carry the previous launch's tag
+// - unless the last launch on this block had another T or B, or the block is new to this
+// process: then it is zeroed first (stream-ordered; tag 0 is never used).
+static uint32_t next_flow_tag(void* block, int64_t bytes, int64_t B, int32_t T, hipStream_t stream) {
+  struct Last { uint32_t tag; int64_t B; int32_t T; };
+  static std::mutex lock;
+  static std::unordered_map<const void*, Last> blocks;
+  std::lock_guard<std::mutex> hold(lock);
+  Last& l = blocks[block];
+  if (l.tag == 0 || l.B != B || l.T != T) {
+    (void)hipMemsetAsync(block, 0, (size_t)bytes, stream);
+    l = Last{0, B, T};
+  }
+  l.tag = l.tag % 255u + 1u;
+  return l.tag;
+}
+
+static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                                   const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
+                                   int32_t T, int32_t reset_first, hipStream_t stream) {
   const int HW = s.rows * s.cols;
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
@@ -1699,10 +1789,74 @@ int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
   // (84 VGPRs: 20 waves per CU.  Squeezed into 80 or 72 registers - 24 / 28 waves, the update
   // body spilling - the launch was slower from 32 768 environments up and at 4 096, level at
   // 16 384: profiles/r04_deferred_ab.txt)
-  hipLaunchKernelGGL(pipe_table_kernel, grid, block, 0, stream, mp, spec_dev, st, actions, out, B, T,
-                     reset_first, fc, rr);
+  if (flow) {
+    rr.tagged = reinterpret_cast<uint16_t*>(out.overlap_ctl + 4);
+    rr.tag = next_flow_tag(out.overlap_ctl, 16 + 2 * (int64_t)T * rr.pitch, B, T, stream);
+    hipLaunchKernelGGL(pipe_table_kernel<true>, grid, block, 0, stream, mp, spec_dev, st, actions, out, B, T,
+                       reset_first, fc, rr);
+  } else {
+    hipLaunchKernelGGL(pipe_table_kernel<false>, grid, block, 0, stream, mp, spec_dev, st, actions, out, B, T,
+                       reset_first, fc, rr);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                    const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
+                    int32_t T, int32_t reset_first, hipStream_t stream) {
+  return launch_pipe_or_flow(false, s, spec_dev, st, actions, out, prev, B, T, reset_first, stream);
+}
+
+// ---------------------------------------------------------------------------
+// ONE rollout in one launch, the render following the update pass as it goes: the same launch
+// shape with the render role reading THIS rollout's trace - from a tagged copy, 16-bit entries
+// byte | tag << 8 that the update role's consumers store beside the trace (write-through, no drain,
+// no flag).  A render wave loads the entries of its rows with agent-scope loads and, while any of
+// them carries another launch's tag, sleeps and looks again.  Every workgroup of the grid is
+// dispatched in order, so the update ones (lowest indices, at most 1 024 <= the 1 280 resident
+// ones) all run before any render workgroup can wait for them: no tickets, no deadlock.
+// What the two earlier forms cost (tools/probes/flow_noack.sh, B = 4 096 / 16 384, two launches
+// 27 / 60 us, waits compiled out 19 / 47): progress WORDS side by side, polled by every waiting
+// wave: 38 / 71 (64 update workgroups' words in four lines of one L2 channel - everything else
+// through that channel, the update role's stores among it, queued behind the polls); the words
+// 256 bytes apart: 24 / 57 (a flag is one more dependent trip in front of each short wave's
+// loads, and a hop's price sits in the consumer CU's own memory queue: MI355X_MICROARCH.md,
+// handoff-flag against handoff-1to1).  Tagged entries are that guide's data-tagged granules.
+// Measured (boat race, T = 100, us per rollout, two launches / one; profiles/r04_flow_ab.txt):
+// B = 1 024 20.7 / 16.9, 4 096 27.9 / 23.8, 8 192 38.2 / 35.9, 16 384 60.2 / 61.8, 32 768 101 / 113,
+// 65 536 184 / 234 - the tagged copy is read from the fabric (write-through stores drop their
+// lines from L2) by every render wave, which costs more than hiding the update pass saves once
+// the render is the longer part: on for B <= 8 192 (CAMPX_FLOW_MAX_B), CAMPX_NO_FLOW=1: never.
+// Not while the stream is being captured into a graph: a replay would reuse the launch's tag.
+bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table,
+             hipStream_t stream) {
+  static const bool off = [] { const char* v = getenv("CAMPX_NO_FLOW"); return v && v[0] == '1'; }();
+  static const int64_t max_b = [] {
+    const char* v = getenv("CAMPX_FLOW_MAX_B");
+    return (int64_t)(v && *v ? atoll(v) : 8192);
+  }();
+  // (CAMPX_OVERLAP=1: the scratch block is the overlapped launch's control block)
+  if (off || g_overlap_max_b > 0 || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
+  if (out.overlap_ctl_bytes < 16 + 2 * (int64_t)T * row_pitch(out, B) ||
+      (reinterpret_cast<uintptr_t>(out.overlap_ctl) & 15))
+    return false;
+  if (row_pitch(out, B) % 2 != 0) return false;     // (entries are read as aligned dwords)
+  CampxOutputs self = out;
+  self.board = nullptr;          // (rendered by the ordinary kernel afterwards)
+  if (!pipe_ok(s, out, self, B, T, use_table)) return false;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return capturing == hipStreamCaptureStatusNone;
+}
+
+int32_t launch_flow(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
+                    const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                    int32_t reset_first, hipStream_t stream) {
+  return launch_pipe_or_flow(true, s, spec_dev, st, actions, out, out, B, T, reset_first, stream);
 }
 
 

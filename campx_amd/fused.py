@@ -175,6 +175,9 @@ class FusedGame(object):
     # control block of overlapped small-batch rollouts (CampxOutputs.overlap_ctl; an A/B path,
     # measured slower than two launches and off unless CAMPX_OVERLAP=1): zeroed once here,
     # left zeroed by every launch; this game's own (its rollouts are ordered anyway)
+    # ... and of the one-launch rollouts of one-mover games (progress words the update role
+    # publishes and the render role of the same launch polls: 4 bytes per 64 environments,
+    # zeroed once, counting up from launch to launch)
     self._overlap_ctl = None
     if os.environ.get('CAMPX_OVERLAP', '0') == '1':
       self._overlap_ctl = torch.zeros((int(_hip.lib.campx_overlap_ctl_bytes(B)) + 3) // 4,
@@ -184,6 +187,7 @@ class FusedGame(object):
     self._update = _hip.ops.update.default
     self._render = _hip.ops.render.default
     self._update_render = _hip.ops.update_render.default
+    self._flow_scratch = None
     self._deferred = None      # rollout_deferred(): the dict whose observations are still owed
     self._deferred_rendered = False    # ... unless that rollout was run whole (no shared launch)
     self._shared_launch = {}   # T -> whether campx_update_render_launch shares one launch
@@ -345,6 +349,17 @@ class FusedGame(object):
     return (self._observation_cache,
             (self._reward if self.any_reward else None), self._discount)
 
+  def _scratch(self, T):
+    """CampxOutputs.overlap_ctl for a T-frame rollout: the tagged copy of the trace that lets a
+    one-mover game's rollout run as ONE launch (campx_flow_scratch_bytes; the library decides
+    per call whether it does), or the opt-in overlapped launch's control block."""
+    if os.environ.get('CAMPX_OVERLAP', '0') == '1' or self.n_dyn != 1 or self.batch > 65536:
+      return self._overlap_ctl
+    need = (int(_hip.lib.campx_flow_scratch_bytes(self.batch, T)) + 3) // 4
+    if self._flow_scratch is None or self._flow_scratch.numel() < need:
+      self._flow_scratch = torch.zeros(need, dtype=torch.int32, device=self.device)
+    return self._flow_scratch
+
   def rollout_buffers(self, T, keep_obs=True, want_board=False,
                       obs_dtype=torch.int8, share=None):
     """Allocate the output buffers of a T-frame rollout once, for `rollout(out=...)`.
@@ -488,7 +503,7 @@ class FusedGame(object):
                     self._pair_table, ids, out['obs'], out['board'], out['reward'],
                     out['discount'], out['done'], out['perf'], out['trace'],
                     self._bad if validate else None,
-                    self._bad_flag if validate else None, bool(reset_first), self._overlap_ctl)
+                    self._bad_flag if validate else None, bool(reset_first), self._scratch(T))
     self.frame = T if reset_first else self.frame + T
     if validate:
       self._after_launch()
@@ -555,7 +570,7 @@ class FusedGame(object):
       self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
                     self._pair_table, ids, out['obs'], None, out['reward'], out['discount'],
                     out['done'], out['perf'], out['trace'], self._bad if validate else None,
-                    self._bad_flag if validate else None, bool(reset_first), self._overlap_ctl)
+                    self._bad_flag if validate else None, bool(reset_first), self._scratch(T))
       self._deferred, self._deferred_rendered = out, True
       self.frame = T if reset_first else self.frame + T
       if validate:
