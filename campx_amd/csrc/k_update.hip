@@ -1611,40 +1611,24 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
   const uint8_t* frame_trace = rr.trace + (int64_t)t * rr.pitch;
   // ---- loads first: two trace bytes, the window's scenery chunks, two cells' scenery layer
   uint32_t ent[2];
+  // kFlow: THIS rollout's trace, from its tagged copy: an entry is valid when it carries this
+  // launch's tag (agent-scope loads of the aligned dword an entry sits in).  The first look is
+  // issued here, in front of the scenery loads; whether it found this launch's tags is asked
+  // only after the scenery is staged.
+  const uint16_t* frame_tagged = kFlow ? rr.tagged + (int64_t)t * rr.pitch : nullptr;
+  auto look = [&](uint32_t row) {     // (the raw dword: shifting it here would wait for it here)
+    return __hip_atomic_load(reinterpret_cast<const uint32_t*>(frame_tagged + (row & ~1u)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  uint32_t row0 = first_row + (lane >> 1), row1 = first_row + ((lane + kWave) >> 1);
+  row0 = row0 <= last_row ? row0 : last_row;
+  row1 = row1 <= last_row ? row1 : last_row;
   if (kFlow) {
-    // THIS rollout's trace, from its tagged copy: an entry is valid when it carries this
-    // launch's tag (agent-scope loads of the aligned dword an entry sits in; a wave whose rows
-    // are not there yet sleeps and looks again - at its own entries, so nobody polls one line)
-    const uint16_t* frame_tagged = rr.tagged + (int64_t)t * rr.pitch;
-    auto look = [&](uint32_t row) {
-      const uint32_t d = __hip_atomic_load(reinterpret_cast<const uint32_t*>(frame_tagged + (row & ~1u)),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return (d >> ((row & 1u) * 16u)) & 0xffffu;
-    };
-    uint32_t row0 = first_row + (lane >> 1), row1 = first_row + ((lane + kWave) >> 1);
-    row0 = row0 <= last_row ? row0 : last_row;
-    row1 = row1 <= last_row ? row1 : last_row;
     ent[0] = look(row0);
     ent[1] = look(row1);
-#ifndef CAMPX_FLOW_NOPOLL       // (=1: a TIMING experiment - never wait; results are wrong)
-    uint32_t naps = 0;
-    while (__any((ent[0] >> 8) != rr.tag || (ent[1] >> 8) != rr.tag)) {
-      if (naps < 4u) __builtin_amdgcn_s_sleep(8);
-      else __builtin_amdgcn_s_sleep(32);
-      ++naps;
-      ent[0] = look(row0);
-      ent[1] = look(row1);
-    }
-#endif
-    ent[0] &= 0xffu;
-    ent[1] &= 0xffu;
   } else {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      uint32_t row = first_row + ((lane + (uint32_t)it * kWave) >> 1);
-      row = row <= last_row ? row : last_row;
-      ent[it] = frame_trace[row];
-    }
+    ent[0] = frame_trace[row0];
+    ent[1] = frame_trace[row1];
   }
   u32x4 scen[kPipeWin];
 #pragma unroll
@@ -1664,6 +1648,26 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     const uint32_t lo = (top2 & 0xffu) * (uint32_t)rr.cells + c;
     const uint32_t hi2 = (top2 >> 8) * (uint32_t)rr.cells + c + 1u;
     *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
+  }
+  if (kFlow) {
+#ifndef CAMPX_FLOW_NOPOLL       // (=1: a TIMING experiment - never wait; results are wrong)
+    // a wave whose rows are not there yet sleeps and looks again - at its own entries, so nobody
+    // polls one line
+    uint32_t naps = 0;
+    const uint32_t sh0 = (row0 & 1u) * 16u, sh1 = (row1 & 1u) * 16u;
+    while (__any(((ent[0] >> sh0) & 0xff00u) != (rr.tag << 8) || ((ent[1] >> sh1) & 0xff00u) != (rr.tag << 8))) {
+      if (naps < 4u) __builtin_amdgcn_s_sleep(8);
+      else __builtin_amdgcn_s_sleep(32);
+      ++naps;
+      ent[0] = look(row0);
+      ent[1] = look(row1);
+    }
+    ent[0] = (ent[0] >> sh0) & 0xffu;
+    ent[1] = (ent[1] >> sh1) & 0xffu;
+#else
+    ent[0] = (ent[0] >> ((row0 & 1u) * 16u)) & 0xffu;
+    ent[1] = (ent[1] >> ((row1 & 1u) * 16u)) & 0xffu;
+#endif
   }
   // ---- patches: the mover's 1, and the scenery's 1 it hides
   auto apply = [&](uint32_t sidx, uint32_t e) {
