@@ -1565,7 +1565,10 @@ constexpr uint32_t kPipeSpan = 1024u * kPipeWin;
 // Small workgroups - one producer wave (64 environments), two consumer waves, one loader: what
 // the render role needs is many short waves per CU that come and go one by one (as 14-wave
 // workgroups of the update kernel's own shape it streamed at two thirds of render_kernel's rate)
-constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS;
+#ifndef CAMPX_PIPE_GROUP
+#define CAMPX_PIPE_GROUP 16
+#endif
+constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS, kPipeGroup = CAMPX_PIPE_GROUP;
 constexpr int kPipeWaves = kPipeProd + kPipeCons + update_loaders(kPipeProd);
 constexpr int kPipeEnvs = kPipeProd * kWave;
 
@@ -1576,14 +1579,14 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first, FrameCodec fc, OverlapRender rr) {
-  __shared__ UpdateTableLds<kPipeProd, kOvGroup> L;
+  __shared__ UpdateTableLds<kPipeProd, kPipeGroup> L;
   static_assert(sizeof(L) >= kPipeWaves * (kPipeSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
   // Which role: the first U workgroups update.  (Spreading them among the render ones - every
   // 24th / 48th / 96th workgroup - was slower at every size tried: an update wave that shares
   // its SIMD with streaming waves walks its chain more slowly, lives longer, and more of them
   // pile up; profiles/r04_deferred_ab.txt section 5.)
   if (blockIdx.x < rr.U) {
-    update_table_body<kPipeProd, kPipeCons, kOvGroup, false, kFlow>(L, blockIdx.x, nullptr, 0u, mp, spec, st, actions,
+    update_table_body<kPipeProd, kPipeCons, kPipeGroup, false, kFlow>(L, blockIdx.x, nullptr, 0u, mp, spec, st, actions,
                                                                 out, B, T, reset_first, fc, rr.tagged, rr.tag);
     return;
   }
