@@ -634,10 +634,11 @@ def run_rank(args):
         # the headline: it changes what a caller gets back when (observations one call late).
         rows = []
         for db in (B, 16384, 4096):
-          dm = measure_rollout(args.game, db, T, args.steps, args.warmup, device, 0, None, 0,
+          dsteps = args.steps * max(1, B // db)      # (the same env-steps per timed window)
+          dm = measure_rollout(args.game, db, T, dsteps, args.warmup, device, 0, None, 0,
                                pipelined='deferred')
-          rows.append({'batch': db, 'value': db * T * args.steps / dm['elapsed'],
-                       'unit': 'env-steps/s', 'ms_per_step': dm['elapsed'] / args.steps * 1e3,
+          rows.append({'batch': db, 'steps': dsteps, 'value': db * T * dsteps / dm['elapsed'],
+                       'unit': 'env-steps/s', 'ms_per_step': dm['elapsed'] / dsteps * 1e3,
                        'kernel_ms': dm['kernel_ms'],
                        'frac': BYTES_PER_ENV_STEP[args.game] * db * T / (dm['kernel_ms'] / 1e3) / 1e9
                        / HBM_PEAK_GBS})
