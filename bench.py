@@ -647,7 +647,8 @@ def run_rank(args):
         line['deferred_rollouts'] = {
             'note': 'rollout_deferred(): one launch per step = update pass of rollout i+1 + '
                     'render pass of rollout i (pipe_table_kernel); same work per step as the '
-                    'headline, observations delivered one call late',
+                    'headline, observations delivered one call late; these rows run without the '
+                    'episode-return log of the headline (with it: tools/gpu_deferred_rep.sh)',
             'rows': rows}
       also = []
       # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
