@@ -112,6 +112,9 @@ class ReturnLog(object):
     self._out = [torch.zeros((self.world, self.episodes, batch),
                              dtype=torch.float32, device=self.device)
                  for _ in range(2)]
+    # (the rows as tensors of their own, made once: indexing a tensor costs the host ~3 us,
+    # which at small batches - one launch per 14-20 us - is what the device would wait for)
+    self._rows = [[block[r] for r in range(self.episodes)] for block in self._log]
     self._work = [None, None]
     self._count = 0
     self._last = None
@@ -119,7 +122,7 @@ class ReturnLog(object):
   def row(self):
     """The float32 [batch] buffer the next episode accumulates its returns in."""
     block, row = divmod(self._count, self.episodes)
-    return self._log[block & 1][row]
+    return self._rows[block & 1][row]
 
   def episode_done(self):
     """Call after launching an episode; gathers the block when it is complete."""
