@@ -1565,6 +1565,12 @@ constexpr uint32_t kPipeSpan = 1024u * kPipeWin;
 // Small workgroups - one producer wave (64 environments), two consumer waves, one loader: what
 // the render role needs is many short waves per CU that come and go one by one (as 14-wave
 // workgroups of the update kernel's own shape it streamed at two thirds of render_kernel's rate)
+#ifndef CAMPX_FLOW_NAP          // s_sleep units (64 clocks) between two looks at stale entries:
+#define CAMPX_FLOW_NAP 8        // the first four times,
+#endif
+#ifndef CAMPX_FLOW_NAP_LONG
+#define CAMPX_FLOW_NAP_LONG 32  // and from then on
+#endif
 #ifndef CAMPX_PIPE_GROUP
 #define CAMPX_PIPE_GROUP 16
 #endif
@@ -1659,8 +1665,8 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     uint32_t naps = 0;
     const uint32_t sh0 = (row0 & 1u) * 16u, sh1 = (row1 & 1u) * 16u;
     while (__any(((ent[0] >> sh0) & 0xff00u) != (rr.tag << 8) || ((ent[1] >> sh1) & 0xff00u) != (rr.tag << 8))) {
-      if (naps < 4u) __builtin_amdgcn_s_sleep(8);
-      else __builtin_amdgcn_s_sleep(32);
+      if (naps < 4u) __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP);
+      else __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
       ++naps;
       ent[0] = look(row0);
       ent[1] = look(row1);
