@@ -1829,7 +1829,7 @@ int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
 // them carries another launch's tag, sleeps and looks again.  Every workgroup of the grid is
 // dispatched in order, so the update ones (lowest indices, at most 1 024 <= the 1 280 resident
 // ones) all run before any render workgroup can wait for them: no tickets, no deadlock.
-// What the two earlier forms cost (tools/probes/flow_noack.sh, B = 4 096 / 16 384, two launches
+// What the two earlier forms cost (tools/gpu_flow_variants.sh, B = 4 096 / 16 384, two launches
 // 27 / 60 us, waits compiled out 19 / 47): progress WORDS side by side, polled by every waiting
 // wave: 38 / 71 (64 update workgroups' words in four lines of one L2 channel - everything else
 // through that channel, the update role's stores among it, queued behind the polls); the words
