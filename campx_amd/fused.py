@@ -67,6 +67,9 @@ def _ptr(t):
   return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+_FLOW_MAX_B = int(os.environ.get('CAMPX_FLOW_MAX_B', '8192'))
+
+
 class FusedGame(object):
 
   def __init__(self, engine, batch, device=None, traced=None):
@@ -353,8 +356,14 @@ class FusedGame(object):
     """CampxOutputs.overlap_ctl for a T-frame rollout: the tagged copy of the trace that lets a
     one-mover game's rollout run as ONE launch (campx_flow_scratch_bytes; the library decides
     per call whether it does), or the opt-in overlapped launch's control block."""
-    if os.environ.get('CAMPX_OVERLAP', '0') == '1' or self.n_dyn != 1 or self.batch > 65536:
+    if os.environ.get('CAMPX_OVERLAP', '0') == '1':
       return self._overlap_ctl
+    # (the library's own bounds, csrc/k_update.hip flow_ok / pipe_ok: no block where it would
+    # not be used - at B = 65 536, T = 4 000 it would be half a gigabyte)
+    frame = self.batch * self.n_layers * self.rows * self.cols
+    if (self.n_dyn != 1 or self.batch > _FLOW_MAX_B or frame % 16 or frame * T > 2000000000
+        or os.environ.get('CAMPX_NO_FLOW', '0') == '1'):
+      return None
     need = (int(_hip.lib.campx_flow_scratch_bytes(self.batch, T)) + 3) // 4
     if self._flow_scratch is None or self._flow_scratch.numel() < need:
       self._flow_scratch = torch.zeros(need, dtype=torch.int32, device=self.device)
