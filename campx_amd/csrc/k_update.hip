@@ -1574,6 +1574,7 @@ constexpr uint32_t kPipeSpan = 1024u * kPipeWin;
 #ifndef CAMPX_PIPE_GROUP
 #define CAMPX_PIPE_GROUP 16
 #endif
+constexpr uint32_t kFlowMaxNaps = 1u << 20;     // looks at stale entries before a render wave gives up (seconds)
 constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS, kPipeGroup = CAMPX_PIPE_GROUP;
 constexpr int kPipeWaves = kPipeProd + kPipeCons + update_loaders(kPipeProd);
 constexpr int kPipeEnvs = kPipeProd * kWave;
@@ -1667,7 +1668,10 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     while (__any(((ent[0] >> sh0) & 0xff00u) != (rr.tag << 8) || ((ent[1] >> sh1) & 0xff00u) != (rr.tag << 8))) {
       if (naps < 4u) __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP);
       else __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
-      ++naps;
+      // (seconds of waiting: the entries will never carry this launch's tag - two launches
+      // sharing one scratch block at the same time, which the header forbids; wrong frames
+      // are a better outcome than a launch that never ends)
+      if (++naps > kFlowMaxNaps) break;
       ent[0] = look(row0);
       ent[1] = look(row1);
     }
@@ -1692,8 +1696,8 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     if (kFlow) {   // (each lane waits for its own entry: rows of under 32 bytes, boards of a few cells)
       const uint16_t* at = rr.tagged + (int64_t)t * rr.pitch + first_row + (sidx >> 1);
       uint32_t e = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((e >> 8) != rr.tag) {
-        __builtin_amdgcn_s_sleep(8);
+      for (uint32_t naps = 0; (e >> 8) != rr.tag && naps < kFlowMaxNaps; ++naps) {
+        __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
         e = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       apply(sidx, e & 0xffu);

@@ -260,6 +260,7 @@ typedef struct CampxOutputs {
                          it (csrc/k_update.hip, pipe_table_kernel<true>): 17 / 24 / 36 us against
                          21 / 28 / 38 at B = 1 024 / 4 096 / 8 192.  Not while `stream` is being
                          captured into a graph.  CAMPX_NO_FLOW=1 in the environment: never.
+                         Two launches that may run at the same time must not share a block.
                          (2) campx_overlap_ctl_bytes(B) bytes (every launch leaves its control
                          words zeroed): an A/B path, used only when the
                          environment says CAMPX_OVERLAP=1: a rollout of a one-mover game at a
