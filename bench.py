@@ -630,10 +630,10 @@ def run_rank(args):
       if not args.deferred and not args.pipeline:
         # Rollouts pipelined across calls (FusedGame.rollout_deferred: ONE launch = the update
         # pass of rollout i+1 + the render pass of rollout i), beside the headline's two
-        # launches per rollout, at the headline's batch and two smaller ones.  Reported, not
+        # launches per rollout, at the batches where the library shares the launch.  Reported, not
         # the headline: it changes what a caller gets back when (observations one call late).
         rows = []
-        for db in (B, 16384, 4096):
+        for db in (32768, 16384, 4096):
           dsteps = args.steps * max(1, B // db)      # (the same env-steps per timed window)
           dm = measure_rollout(args.game, db, T, dsteps, args.warmup, device, 0, None, 0,
                                pipelined='deferred')

@@ -1726,14 +1726,16 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
   if (reinterpret_cast<uintptr_t>(prev.obs) & 15) return false;
   // Where one launch beats two (boat race / wall world, T = 100, of HBM peak, two launches ->
   // one; profiles/r04_deferred_ab.txt): B = 4 096 0.34 -> 0.53, 16 384 0.62 -> 0.75 / 0.77 ->
-  // 0.80, 65 536 0.82 -> 0.83-0.88 / 0.87 -> 0.83, 200 000 0.83 -> 0.57.  The render role streams
-  // ~4 % below render_kernel's rate (84 VGPRs: 20 waves per CU), which hiding ~15 us of update
-  // pass repays only while the observations of a rollout are under ~2 GB; and the update
-  // workgroups, dispatched first, must leave room for render ones in the first wave of
-  // resident workgroups (5 per CU, 1 280: at most 1 024 update workgroups, 65 536 environments).
+  // 0.80, 32 768 0.74 -> 0.78, 65 536 0.82 -> 0.79-0.88 / 0.87 -> 0.83, 200 000 0.83 -> 0.57.  The
+  // render role streams ~4 % below render_kernel's rate (84 VGPRs: 20 waves per CU), which
+  // hiding ~15 us of update pass repays only while the observations of a rollout are under
+  // ~2 GB; and the update workgroups, dispatched first, must leave room for render ones in the
+  // first wave of resident workgroups (5 per CU, 1 280): 1 024 of them (65 536 environments)
+  // is where the shared launch stops winning consistently - single launches then swing
+  // between 165 and 200 us - so it is taken up to 512 (32 768 environments).
   static const int64_t max_b = [] {
     const char* v = getenv("CAMPX_PIPE_MAX_B");
-    return (int64_t)(v && *v ? atoll(v) : 1024 * kPipeEnvs);
+    return (int64_t)(v && *v ? atoll(v) : 512 * kPipeEnvs);
   }();
   static const int64_t max_bytes = [] {
     const char* v = getenv("CAMPX_PIPE_MAX_BYTES");

@@ -532,7 +532,7 @@ class FusedGame(object):
     action streams: random exploration, scripted or replayed episodes).
 
     Where the library has no shared launch for the game or the sizes (two moving things, more
-    than 65 536 environments or ~2 GB of observations per rollout, batches whose frames are not
+    than 32 768 environments or ~2 GB of observations per rollout, batches whose frames are not
     whole 16-byte chunks: `campx_update_render_shared`), the rollout is run whole at once -
     deferring would only make its render read a trace gone cold - and `out` is simply complete
     a call early.

@@ -391,8 +391,9 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
  * streams; the reference has no such call - it is Engine.play(), campx/engine.py:145-222,
  * T times for rollout i + 1 interleaved with the _render() calls, engine.py:286-324, of
  * rollout i).  For one-mover table games with int8 observations of whole 16-byte chunks per
- * frame and no flat board the two passes share ONE launch (update workgroups first, the others
- * render); otherwise they are issued one after the other on `stream`.  prev.trace == NULL:
+ * frame and no flat board, up to 32 768 environments and 2 GB of observations per rollout, the
+ * two passes share ONE launch (update workgroups first, the others render); otherwise they are
+ * issued one after the other on `stream`.  prev.trace == NULL:
  * the update pass alone.  CAMPX_NO_PIPE=1 in the environment: always one after the other.
  */
 int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,

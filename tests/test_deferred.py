@@ -66,10 +66,10 @@ def test_boat_race_deferred_matches_oracle(B):
   _check(boat_race.build, B, [100, 100, 33, 100, 33], seed=B)
 
 
-@pytest.mark.parametrize('B,T', [(32768, 20), (24000, 30), (66000, 10)])
+@pytest.mark.parametrize('B,T', [(32768, 20), (24000, 30), (33024, 10)])
 def test_big_batches(B, T):
-  # 512 and 375 update workgroups in front of the render ones; 66 000 environments are past
-  # what the shared launch takes (65 536): each rollout whole, at once
+  # 512 and 375 update workgroups in front of the render ones; 33 024 environments are past
+  # what the shared launch takes (32 768): each rollout whole, at once
   _check(boat_race.build, B, [T, T, T], seed=B)
 
 
