@@ -20,7 +20,7 @@ from .gamespec import CampxSpec, CampxShapeSpec, CampxWideSpec
 _LIB_PATH = os.environ.get('CAMPX_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libcampx_hip.so')
 
-EXPORTS = ('campx_spec_size', 'campx_overlap_ctl_bytes', 'campx_flow_scratch_bytes', 'campx_spec_validate', 'campx_spec_compile',
+EXPORTS = ('campx_spec_size', 'campx_flow_scratch_bytes', 'campx_spec_validate', 'campx_spec_compile',
            'campx_pair_table_bytes', 'campx_pair_table_build', 'campx_pair_table_pack',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
@@ -65,8 +65,6 @@ def _load():
   spec_p = ctypes.POINTER(CampxSpec)
   i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
   lib.campx_spec_size.restype = i32
-  lib.campx_overlap_ctl_bytes.restype = i64
-  lib.campx_overlap_ctl_bytes.argtypes = [i64]
   lib.campx_flow_scratch_bytes.restype = i64
   lib.campx_flow_scratch_bytes.argtypes = [i64, i32]
   lib.campx_spec_size.argtypes = []

@@ -166,12 +166,6 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
   chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
   const bool whole = (per_frame * T <= knob_trace_whole_bytes() && T <= 65535) || T <= chunk;
-  if (whole && !last_frame_only(out) && overlap_ok(s, out, B, T, use_table)) {
-    // small batches: update pass and observation render in one persistent launch
-    int32_t rc = launch_overlap(s, spec_dev, st, actions, out, B, T, reset_first, plane, stream);
-    if (rc != CAMPX_OK || !out.board) return rc;
-    return launch_render(s, spec_dev, out.trace, out.board, B, T, plane, pitch, true, 0, stream);
-  }
   if (whole && !last_frame_only(out) && flow_ok(s, out, B, T, use_table, stream)) {
     // one-mover table games up to 65 536 environments: one launch, the render role following
     // the update role group by group (k_update.hip flow_table launch)
@@ -302,8 +296,6 @@ using namespace campx_impl;
 extern "C" {
 
 int32_t campx_spec_size(void) { return (int32_t)sizeof(CampxSpec); }
-
-int64_t campx_overlap_ctl_bytes(int64_t B) { return B > 0 ? overlap_ctl_bytes(B) : 0; }
 
 int64_t campx_flow_scratch_bytes(int64_t B, int32_t T) {
   return B > 0 && T > 0 ? flow_scratch_bytes(B, T) : 0;

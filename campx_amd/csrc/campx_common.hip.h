@@ -549,13 +549,6 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
                       int32_t reset_first, bool use_table, int64_t trace_plane,
                       hipStream_t stream);
 
-// k_update.hip: update pass and render of a small-batch rollout in one persistent launch
-bool overlap_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table);
-int64_t overlap_ctl_bytes(int64_t B);
-int32_t launch_overlap(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
-                       const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
-                       int32_t reset_first, int64_t trace_plane, hipStream_t stream);
-
 // k_update.hip: the update pass of one rollout and the render pass of the one before it in one launch
 bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& prev, int64_t B,
              int32_t T, bool use_table);

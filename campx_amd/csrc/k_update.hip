@@ -283,9 +283,8 @@ constexpr int update_min_waves(int, int) { return CAMPX_UPD_MINWAVES; }
 // 12.9 us; T = 256: 29.0 -> 23.5); at B = 65 536 the kernel reads 16.3-16.7 us either way.
 // (The composed chain was an A/B build through round 3; round 4 removed it with its knob.)
 
-// LDS of an update workgroup of the one-mover kernel (a struct, so that the overlapped
-// rollout kernel - k_overlap: this body as one role of a persistent launch - can lay its other
-// role's windows over the same bytes).
+// LDS of an update workgroup of the one-mover kernel (a struct, so that pipe_table_kernel - this
+// body as one role of a launch - can lay its other role's windows over the same bytes).
 template <int kProd, int kG>
 struct UpdateTableLds {
   // entry: x = reward; y = [0:15] byte offset of the table row the NEXT frame starts
@@ -301,18 +300,13 @@ struct UpdateTableLds {
 };
 
 // The body of update_table_kernel.  `wg`: which kEnvs environments this workgroup owns.
-// `progress` (overlapped rollouts only, else null): after every group of kG frames whose
-// streams - the trace among them - have been written AND acknowledged (the stores are
-// write-through), the number of complete groups is published there with an agent-scope store:
-// what a render wave of the same launch polls before it reads those rows of the trace.
-// (`progress_base` + that number: flow_table_kernel's launches count up instead of resetting.)
 // `tagged` (one-launch rollouts, else null): a second copy of the trace as 16-bit entries,
 // byte | tag << 8 - every entry says by itself which launch wrote it, so a render wave of the
 // same launch needs no flag and this role no drain (MI355X_MICROARCH.md: data-tagged granules).
-template <int kProd, int kCons, int kG, bool kPublish, bool kTagged = false>
+template <int kProd, int kCons, int kG, bool kTagged = false>
 __device__ __forceinline__ void update_table_body(
-    UpdateTableLds<kProd, kG>& L, uint32_t wg, uint32_t* progress, uint32_t progress_base,
-    const MoverParams& mp, const CampxSpec* __restrict__ spec, const CampxState& st,
+    UpdateTableLds<kProd, kG>& L, uint32_t wg, const MoverParams& mp,
+    const CampxSpec* __restrict__ spec, const CampxState& st,
     const int8_t* __restrict__ actions, const CampxOutputs& out, int64_t B, int32_t T,
     int32_t reset_first, const FrameCodec& fc, uint16_t* tagged = nullptr, uint32_t tag = 0) {
   constexpr int kLoad = update_loaders(kProd);
@@ -519,14 +513,7 @@ __device__ __forceinline__ void update_table_body(
             }
           }
         }
-      if (kPublish) {
-        // every stream of the group stored above has been acknowledged (write-through stores):
-        // +2.3 us per 100 frames on the kernel alone (B = 4 096: 12.9 -> 15.3 us)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
       __syncthreads();
-      if (kPublish && g > 0 && clane == 0)
-        __hip_atomic_store(progress, progress_base + (uint32_t)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     for (int g = 0; g <= n_groups; ++g) {
@@ -562,9 +549,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
     int32_t reset_first, FrameCodec fc) {
   __shared__ UpdateTableLds<kProd, kG> L;
-  update_table_body<kProd, kCons, kG, false>(L, tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD),
-                                             nullptr, 0u, mp, spec, st, actions, out, B, T,
-                                             reset_first, fc);
+  update_table_body<kProd, kCons, kG>(L, tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD), mp, spec, st,
+                                      actions, out, B, T, reset_first, fc);
 }
 
 // ---------------------------------------------------------------------------
@@ -1189,38 +1175,8 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
 }
 
 
-// ---------------------------------------------------------------------------
-// Overlapped rollouts for small and middle batches (round 4).  Below ~32 K environments the
-// update pass is a latency chain that leaves the chip almost empty (B = 4 096: 16 workgroups
-// for 12.9 us, whatever the batch size) and the render kernel behind it cannot start before
-// it ends: two dependent launches, ~25 us of which nothing streams (profiles/r03_sweep.txt:
-// boat race 0.33 of peak at B = 4 096, 0.62 at 16 384).  Here both run in ONE persistent
-// launch of 2 workgroups per CU:
-//   * a workgroup takes a TICKET when it starts; the first U tickets are the update
-//     workgroups (update_table_body, unchanged but for publishing), the others render;
-//   * an update workgroup publishes, after each group of 16 frames, how many groups of its
-//     256 environments' trace are complete in memory: write-through (`sc0 sc1`) stores,
-//     `s_waitcnt vmcnt(0)`, workgroup barrier, agent-scope flag store
-//     (/opt/skills/guides/MI355X_MICROARCH.md, valid producer forms);
-//   * a render wave owns 2 KiB windows of the observation stream, frame-major (item i of
-//     render workgroup r: r + i * R_n), and before it reads a window's rows of the trace it
-//     polls the flag(s) of the update workgroup(s) those rows belong to (relaxed agent-scope
-//     loads, `s_sleep` between polls); the trace itself is read with agent-scope loads
-//     (`sc1`: not from this CU's L1, which may hold a line whose other half was written later).
-// No workgroup ever waits for one that has not started (tickets are handed out to RUNNING
-// workgroups, update workgroups wait for nobody), so the launch cannot deadlock whatever the
-// dispatch order.  The last workgroup to leave zeroes the control block for the next launch.
-// Scope: one-mover table games, int8 observations kept for every frame, frames that are whole
-// 16-byte chunks; the flat board (if asked for) is rendered by the ordinary kernel afterwards.
-// Anything else takes the two-launch path.
-constexpr int kOvProd = 4, kOvCons = 8, kOvGroup = 16;
-constexpr int kOvWaves = kOvProd + kOvCons + update_loaders(kOvProd);     // 14
-constexpr int kOvEnvs = kOvProd * kWave;                                   // 256
-constexpr int kOvChunks = 4;                                               // KiB per wave and step
-constexpr uint32_t kOvSpan = 1024u * kOvChunks;                            // a wave's window
-constexpr int kOvMaxUpdate = 1024;    // update workgroups of one launch (B <= 262 144)
-
-struct OverlapRender {
+// What a render workgroup of the shared launches below needs (pipe_table_kernel).
+struct PipeRender {
   uint32_t R, m, sh1, sh2, slab_bytes, shift_base, shift_slab;
   int32_t cells, dyn_off;
   int64_t pitch;               // rows of the trace from one frame to the next
@@ -1229,327 +1185,28 @@ struct OverlapRender {
   const uint8_t* trace;
   int8_t* dst;
   int32_t T;
-  uint32_t per_frame;          // workgroup-items (kOvWaves windows) per frame
+  uint32_t per_frame;          // render workgroups per frame (a multiple of 8)
   uint32_t U;                  // update workgroups
-  uint32_t* ctl;               // [0] tickets, [1] finished, [4 + u] groups complete of workgroup u
   uint16_t* tagged;            // one-launch rollouts: the trace's tagged copy [T, pitch], and
   uint32_t tag;                // this launch's tag (1..255)
 };
 
-__global__ __launch_bounds__(kOvWaves * kWave) void overlap_table_kernel(
-    MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
-    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, FrameCodec fc, OverlapRender rr) {
-  __shared__ UpdateTableLds<kOvProd, kOvGroup> L;
-  __shared__ uint32_t s_ticket;
-  __shared__ uint32_t s_known[kOvMaxUpdate];
-  static_assert(sizeof(L) >= kOvWaves * (kOvSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&rr.ctl[0], 1u);
-  __syncthreads();
-  const uint32_t ticket = s_ticket;
-  if (ticket < rr.U) {
-    update_table_body<kOvProd, kOvCons, kOvGroup, true>(L, ticket, rr.ctl + 4 + ticket, 0u, mp, spec, st,
-                                                        actions, out, B, T, reset_first, fc);
-  } else {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int8_t* win0 = reinterpret_cast<int8_t*>(&L) + wave * (kOvSpan + 2 * CAMPX_MAX_CELLS);
-    uint16_t* scen_off = reinterpret_cast<uint16_t*>(win0 + kOvSpan);
-    // what this workgroup knows of the update workgroups' progress: polled from memory by wave
-    // 0 only, read from LDS by the others (7 000 waves polling one line each on their own
-    // slowed the whole launch fourfold)
-    for (uint32_t u = threadIdx.x; u < rr.U; u += kOvWaves * kWave) s_known[u] = 0u;
-    const uint32_t R = rr.R;
-    const uint32_t rot_pitch = ((R + 15u) & ~15u) + 16u;
-    {   // where the scenery's 1 that the mover hides sits, per cell (once per wave)
-      const uint32_t top2 = *reinterpret_cast<const uint16_t*>(rr.top_layer + 2u * lane);
-      const uint32_t c = 2u * lane;
-      const uint32_t lo = (top2 & 0xffu) * (uint32_t)rr.cells + c;
-      const uint32_t hi2 = (top2 >> 8) * (uint32_t)rr.cells + c + 1u;
-      *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
-    }
-    __syncthreads();
-    const uint32_t n_render = gridDim.x - rr.U;
-    const uint32_t n_items = rr.per_frame ? (uint32_t)rr.T * rr.per_frame : 0u;
-    const uint32_t* progress = rr.ctl + 4;
-    // (one KiB per workgroup: every wave of the launch storing into ONE KiB cost 30 us at B = 1 024)
-    int8_t* sink = reinterpret_cast<int8_t*>(rr.ctl + ((4u + rr.U + 3u) & ~3u)) + (size_t)(blockIdx.x & 1023u) * 1024u;
-    const uint32_t last_env = (uint32_t)(B - 1);
-
-    // One window of one item: where it is, which rows of which frame it needs.
-    struct Win {
-      uint32_t t, woff0, first_row, last_row, slots;
-      bool live;
-    };
-    auto locate = [&](uint32_t item) {
-      Win w;
-      w.t = item / rr.per_frame;
-      const uint32_t wx = item - w.t * rr.per_frame;
-      // windows are aligned in MEMORY (see render_kernel): `shift` bytes before the frame
-      const uint32_t shift = (rr.shift_base + w.t * rr.shift_slab) & (kOvSpan - 1u);
-      const uint32_t base = wx * (uint32_t)kOvWaves;
-      // ---- progress: the rows of ALL the item's windows (wave 0 polls for everybody)
-      {
-        const uint64_t lo64 = (uint64_t)base * kOvSpan, hi64 = (uint64_t)(base + kOvWaves) * kOvSpan - 1u;
-        const uint32_t blo = lo64 < shift ? 0u : (uint32_t)(lo64 - shift);
-        uint32_t bhi = hi64 < shift ? 0u : (uint32_t)(hi64 - shift);
-        bhi = bhi < rr.slab_bytes ? bhi : rr.slab_bytes - 1u;
-        const uint32_t h1 = __umulhi(rr.m, blo), h2 = __umulhi(rr.m, bhi);
-        const uint32_t r_lo = (((blo - h1) >> rr.sh1) + h1) >> rr.sh2;
-        uint32_t r_hi = (((bhi - h2) >> rr.sh1) + h2) >> rr.sh2;
-        r_hi = r_hi < last_env ? r_hi : last_env;
-        const uint32_t need = w.t / (uint32_t)kOvGroup + 1u;
-        if (blo <= bhi && lo64 < (uint64_t)rr.slab_bytes + shift) {
-          for (uint32_t u = r_lo / (uint32_t)kOvEnvs; u <= r_hi / (uint32_t)kOvEnvs; ++u) {
-            if (wave == 0u) {
-              uint32_t seen = __hip_atomic_load(&s_known[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              while (seen < need) {
-                seen = __hip_atomic_load(progress + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen < need) {
-                  // (a group takes the update pass ~1.5-2 us; one poller per workgroup: a few
-                  // hundred polls per us chip-wide)
-                  if (need - seen > 1u) __builtin_amdgcn_s_sleep(64);
-                  else __builtin_amdgcn_s_sleep(16);
-                }
-              }
-              __hip_atomic_store(&s_known[u], seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-              while (__hip_atomic_load(&s_known[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                __builtin_amdgcn_s_sleep(16);
-            }
-          }
-        }
-      }
-      const uint32_t widx = base + wave;
-      w.live = (uint64_t)widx * kOvSpan < (uint64_t)rr.slab_bytes + shift;
-      w.woff0 = widx * kOvSpan - shift;
-      const uint32_t wlo = widx * kOvSpan < shift ? 0u : w.woff0;
-      const uint32_t whi = __umulhi(rr.m, wlo);
-      w.first_row = (((wlo - whi) >> rr.sh1) + whi) >> rr.sh2;
-      const uint32_t wend = (w.woff0 + kOvSpan - 1u < rr.slab_bytes) ? w.woff0 + kOvSpan - 1u : rr.slab_bytes - 1u;
-      const uint32_t ehi = __umulhi(rr.m, wend);
-      w.last_row = (((wend - ehi) >> rr.sh1) + ehi) >> rr.sh2;
-      w.slots = (w.last_row - w.first_row + 1u) * 2u;     // (row) x (set | clear)
-      // (a window past the frame's end goes through the motions: its stores land in the sink)
-      if (!w.live) { w.first_row = 0; w.last_row = 0; w.slots = 0; w.woff0 = 0xffff0000u; }
-      return w;
-    };
-    // The loads of a window: two trace bytes (agent scope: not from L1) and two scenery chunks.
-    auto issue = [&](const Win& w, uint32_t (&ent)[2], u32x4 (&scen)[kOvChunks]) {
-      const uint8_t* frame_trace = rr.trace + (int64_t)w.t * rr.pitch;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        uint32_t row = w.first_row + ((lane + (uint32_t)it * kWave) >> 1);
-        row = row <= w.last_row ? row : w.last_row;
-        // (the aligned dword the byte sits in: a byte-sized atomic load comes with a mask
-        // instruction that hipcc places right behind it, i.e. a wait for the load just issued)
-        ent[it] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(frame_trace + (row & ~3u)),
-                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#pragma unroll
-      for (int j = 0; j < kOvChunks; ++j) {
-        const uint32_t off = w.woff0 + (uint32_t)j * 1024u + lane * 16u;
-        const uint32_t hi = __umulhi(rr.m, off);
-        const uint32_t row = (((off - hi) >> rr.sh1) + hi) >> rr.sh2;
-        const uint32_t k = off - row * R;
-        scen[j] = *reinterpret_cast<const u32x4*>(rr.rot + (k & 15u) * rot_pitch + (k & ~15u));
-      }
-    };
-
-    auto finish = [&](const Win& w, const uint32_t (&ent)[2], const u32x4 (&scen)[kOvChunks]) {
-#pragma unroll
-      for (int j = 0; j < kOvChunks; ++j)
-        *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16u) = scen[j];
-      auto apply = [&](uint32_t sidx, uint32_t e) {
-        const uint32_t r = sidx >> 1, p = sidx & 1u;
-        const uint32_t cell = e & 0x7fu;
-        const uint32_t byte = p ? (uint32_t)rr.dyn_off + cell : (uint32_t)scen_off[cell];
-        const uint32_t at = (w.first_row + r) * R + byte - w.woff0;
-        if (sidx < w.slots && (e >> 7) && at < kOvSpan) win0[at] = (int8_t)p;
-      };
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        uint32_t row = w.first_row + ((lane + (uint32_t)it * kWave) >> 1);
-        row = row <= w.last_row ? row : w.last_row;
-        apply(lane + (uint32_t)it * kWave, (ent[it] >> ((row & 3u) * 8u)) & 0xffu);
-      }
-      const uint8_t* frame_trace = rr.trace + (int64_t)w.t * rr.pitch;
-      for (uint32_t sidx = lane + 2u * kWave; sidx < w.slots; sidx += kWave)     // tiny rows only
-        apply(sidx, (uint32_t)__hip_atomic_load(frame_trace + w.first_row + (sidx >> 1),
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      // ---- out: aligned, contiguous KiB stores
-      const int8_t* frame = rr.dst + (int64_t)w.t * rr.slab_bytes;
-#pragma unroll
-      for (int j = 0; j < kOvChunks; ++j) {
-        // UNCONDITIONAL (a lane outside the frame stores into the control block's sink): a
-        // store under a branch is one hipcc cannot count, and the next wait for loads would
-        // then wait for this window's stores as well
-        const uint32_t off = w.woff0 + (uint32_t)j * 1024u + lane * 16u;
-        const bool inside = off < rr.slab_bytes;
-        int8_t* at = inside ? const_cast<int8_t*>(frame) + off : sink + lane * 16u;
-        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16u),
-                                    reinterpret_cast<u32x4*>(at));
-      }
-    };
-
-    // Software-pipelined over the workgroup's items, two register sets taking turns (no copy
-    // between them: a copy would wait for the loads it copies): the loads of item i + 1 are
-    // issued BEFORE the stores of item i, so that waiting for them (vmcnt counts in order)
-    // never waits for those stores to be acknowledged.
-    uint32_t item = ticket - rr.U;
-    Win wa, wb;
-    uint32_t ea[2], eb[2];
-    u32x4 sa[kOvChunks], sb[kOvChunks];
-    if (item < n_items) {
-      wa = locate(item);
-      issue(wa, ea, sa);
-      if (item + n_render < n_items) {
-        wb = locate(item + n_render);
-        issue(wb, eb, sb);
-        finish(wa, ea, sa);
-        item += n_render;
-        // Invariant: set B holds the loads of `item`, behind the stores of the window before
-        // it.  The steady state has no conditional issue and no conditional store, and the
-        // loop is entered in the state its back edge leaves: hipcc then counts what is in
-        // flight exactly (`s_waitcnt vmcnt(7)` / `vmcnt(6)`) and a wait for loads never
-        // includes the stores issued before them.
-        while (item + 2u * n_render < n_items) {
-          wa = locate(item + n_render);
-          issue(wa, ea, sa);
-          finish(wb, eb, sb);
-          wb = locate(item + 2u * n_render);
-          issue(wb, eb, sb);
-          finish(wa, ea, sa);
-          item += 2u * n_render;
-        }
-        if (item + n_render < n_items) {
-          wa = locate(item + n_render);
-          issue(wa, ea, sa);
-          finish(wb, eb, sb);
-          finish(wa, ea, sa);
-        } else {
-          finish(wb, eb, sb);
-        }
-      } else {
-        finish(wa, ea, sa);
-      }
-    }
-  }
-  // ---- the last workgroup out resets the control block
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t gone = atomicAdd(&rr.ctl[1], 1u);
-    if (gone == gridDim.x - 1u) {
-      for (uint32_t u = 0; u < rr.U; ++u)
-        __hip_atomic_store(rr.ctl + 4 + u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rr.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rr.ctl + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// OFF by default: measured SLOWER than the two launches at every batch size (round 4, boat
-// race, us per 100-frame rollout, two launches / overlapped: B = 1 024 21 / 30, 4 096 28 / 41,
-// 8 192 38 / 50, 16 384 61 / 75; profiles/r04_overlap_ab.txt).  The update role runs at its
-// stand-alone speed inside the launch (16 us), but the render role's long-lived waves - one
-// 14-wave workgroup per CU, all the update body's 106 VGPRs allow - stream at 3-4 TB/s where the
-// one-shot render kernel's 32 short waves per CU reach 6.4, which costs more than hiding the
-// update pass saves.  CAMPX_OVERLAP=1 turns it on (CAMPX_OVERLAP_MAX_B: the largest batch it
-// takes, default 16 384); tests/test_overlap.py keeps it bit-exact.
-static const int64_t g_overlap_max_b = [] {
-  const char* on = getenv("CAMPX_OVERLAP");
-  if (!on || on[0] != '1') return (int64_t)0;
-  const char* v = getenv("CAMPX_OVERLAP_MAX_B");
-  return (int64_t)(v && *v ? atoll(v) : 16384);
-}();
-
-int64_t overlap_ctl_bytes(int64_t B) {
-  // header (16 bytes), one progress word per update workgroup, padding, the render role's sink
-  return 16 + 4 * ((B + kOvEnvs - 1) / kOvEnvs) + 16 + 1024 * 1024;   // (1 024 workgroups' sinks)
-}
-
-// Whether launch_overlap() takes this rollout (one-mover table game; see the kernel's scope).
-bool overlap_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table) {
-  const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
-  if (!use_table || s.n_dyn != 1 || !out.overlap_ctl || B > g_overlap_max_b) return false;
-  if (B > (int64_t)kOvMaxUpdate * kOvEnvs) return false;     // (the progress table's LDS copy)
-  if (B > (int64_t)64 * kOvEnvs) return false;   // update workgroups take at most a quarter of the CUs
-  if (out.overlap_ctl_bytes < overlap_ctl_bytes(B) || (reinterpret_cast<uintptr_t>(out.overlap_ctl) & 15)) return false;
-  if (out.obs_format != CAMPX_OBS_INT8 || out.obs_t_stride != B * R) return false;
-  if ((B * R) % 16 != 0 || T < 2 * kOvGroup || T > 65535) return false;
-  // (the render role reads the trace as aligned dwords)
-  if (row_pitch(out, B) % 4 != 0 || (reinterpret_cast<uintptr_t>(out.trace) & 3)) return false;
-  return true;
-}
-
-int32_t launch_overlap(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
-                       const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
-                       int32_t reset_first, int64_t trace_plane, hipStream_t stream) {
-  // workgroups of this kernel the device holds at once (per CU: 1 with today's 106 VGPRs):
-  // the grid is exactly that many, so that every render workgroup is running from the start
-  // (one that started only after another had left would hold EARLY items and render them late)
-  static const int n_resident = [] {
-    int dev = 0, n = 256, per_cu = 1;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, overlap_table_kernel, kOvWaves * kWave, 0) !=
-            hipSuccess || per_cu < 1)
-      per_cu = 1;
-    return (n > 0 ? n : 256) * per_cu;
-  }();
-  const int HW = s.rows * s.cols;
-  const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
-                          s.dyn_row0[0], s.dyn_col0[0]};
-  const FrameCodec fc = make_codec(s);
-  OverlapRender rr;
-  memset(&rr, 0, sizeof(rr));
-  rr.R = (uint32_t)(s.n_layers * HW);
-  uint32_t l = 0;
-  while ((1ull << l) < rr.R) ++l;
-  rr.m = (uint32_t)(((1ull << 32) * ((1ull << l) - rr.R)) / rr.R + 1);   // as launch_render_from
-  rr.sh1 = l < 1 ? l : 1;
-  rr.sh2 = l > 0 ? l - 1 : 0;
-  rr.slab_bytes = (uint32_t)(B * rr.R);
-  rr.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(out.obs) & (kOvSpan - 1u));
-  rr.shift_slab = rr.slab_bytes & (kOvSpan - 1u);
-  rr.cells = HW;
-  rr.dyn_off = s.dyn_layer[0] * HW;
-  rr.pitch = row_pitch(out, B);
-  const char* blob = reinterpret_cast<const char*>(spec_dev);
-  rr.rot = reinterpret_cast<const int8_t*>(blob + offsetof(CampxSpec, rot_obs));
-  rr.top_layer = reinterpret_cast<const uint8_t*>(blob + offsetof(CampxSpec, static_top_layer));
-  rr.trace = out.trace;
-  rr.dst = out.obs;
-  rr.T = T;
-  const uint64_t reach = (uint64_t)rr.slab_bytes + ((rr.shift_base | rr.shift_slab) ? kOvSpan - 1u : 0u);
-  const uint64_t block_span = (uint64_t)kOvSpan * kOvWaves;
-  rr.per_frame = (uint32_t)((reach + block_span - 1) / block_span);
-  rr.U = (uint32_t)((B + kOvEnvs - 1) / kOvEnvs);
-  rr.ctl = out.overlap_ctl;
-  (void)trace_plane;
-  const uint64_t items = (uint64_t)T * rr.per_frame;
-  if ((int64_t)rr.U * 2 > n_resident) return CAMPX_EINVAL;   // (overlap_ok keeps such batches away)
-  uint64_t n_render = (uint64_t)n_resident - rr.U;
-  if (n_render > items && items > 0) n_render = items;
-  if (n_render < 1) n_render = 1;
-  const dim3 grid((unsigned)(rr.U + n_render)), block(kOvWaves * kWave);
-  hipLaunchKernelGGL(overlap_table_kernel, grid, block, 0, stream, mp, spec_dev, st, actions, out, B,
-                     T, reset_first, fc, rr);
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
-}
+// (Round 4's first attempt at one rollout in one launch - overlap_table_kernel: persistent 14-wave
+// workgroups, tickets, per-workgroup progress words polled by the render role - measured slower
+// than two launches at every batch size, profiles/r04_overlap_ab.txt, and was removed once the
+// tagged-trace form below had replaced it; NOTES.md R4.4, R4.12.)
 
 // ---------------------------------------------------------------------------
 // Rollouts pipelined ACROSS calls (round 4): one launch holds the update pass of rollout i + 1
 // AND the render pass of rollout i.  The two have nothing to do with each other - the render
 // role reads the trace the PREVIOUS launch left complete in memory, the update role writes
-// another trace buffer - so, unlike overlap_table_kernel above, nothing polls and nothing
+// another trace buffer - so nothing polls and nothing
 // persists: workgroups [0, U) are update workgroups (dispatched first: they are the latency
 // chain), every later one renders one 2 KiB window per wave of one frame and leaves, like a
 // render_kernel block.  What a caller pays for it: the observations of a rollout are complete
 // only after the NEXT call (or FusedGame.flush()), and the next rollout's actions must be known
 // when this one's observations are asked for - open-loop action streams (bench.py --deferred).
-// Scope as overlap_table_kernel: one-mover table games, int8 observations of every frame,
+// Scope: one-mover table games, int8 observations of every frame,
 // frames of whole 16-byte chunks; anything else runs the two passes one after the other.
 #ifndef CAMPX_PIPE_WIN
 #define CAMPX_PIPE_WIN 2
@@ -1579,13 +1236,13 @@ constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS, kPipeGro
 constexpr int kPipeWaves = kPipeProd + kPipeCons + update_loaders(kPipeProd);
 constexpr int kPipeEnvs = kPipeProd * kWave;
 
-// kFlow: the render role is THIS rollout's (flow_table_kernel below): the update role publishes
-// its progress, a render wave waits for the groups of frames it reads.
+// kFlow: the render role is THIS rollout's (launch_flow below): the update role stores a tagged
+// copy of the trace, a render wave waits for its entries to carry this launch's tag.
 template <bool kFlow>
 __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     MoverParams mp, const CampxSpec* __restrict__ spec, CampxState st,
     const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, FrameCodec fc, OverlapRender rr) {
+    int32_t reset_first, FrameCodec fc, PipeRender rr) {
   __shared__ UpdateTableLds<kPipeProd, kPipeGroup> L;
   static_assert(sizeof(L) >= kPipeWaves * (kPipeSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
   // Which role: the first U workgroups update.  (Spreading them among the render ones - every
@@ -1593,8 +1250,8 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
   // its SIMD with streaming waves walks its chain more slowly, lives longer, and more of them
   // pile up; profiles/r04_deferred_ab.txt section 5.)
   if (blockIdx.x < rr.U) {
-    update_table_body<kPipeProd, kPipeCons, kPipeGroup, false, kFlow>(L, blockIdx.x, nullptr, 0u, mp, spec, st, actions,
-                                                                out, B, T, reset_first, fc, rr.tagged, rr.tag);
+    update_table_body<kPipeProd, kPipeCons, kPipeGroup, kFlow>(L, blockIdx.x, mp, spec, st, actions, out, B, T,
+                                                         reset_first, fc, rr.tagged, rr.tag);
     return;
   }
   const uint32_t item = blockIdx.x - rr.U;
@@ -1778,7 +1435,7 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
                           s.dyn_row0[0], s.dyn_col0[0]};
   const FrameCodec fc = make_codec(s);
-  OverlapRender rr;
+  PipeRender rr;
   memset(&rr, 0, sizeof(rr));
   rr.R = (uint32_t)(s.n_layers * HW);
   uint32_t l = 0;
@@ -1855,8 +1512,7 @@ bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, 
     const char* v = getenv("CAMPX_FLOW_MAX_B");
     return (int64_t)(v && *v ? atoll(v) : 8192);
   }();
-  // (CAMPX_OVERLAP=1: the scratch block is the overlapped launch's control block)
-  if (off || g_overlap_max_b > 0 || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
+  if (off || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
   if (out.overlap_ctl_bytes < 16 + 2 * (int64_t)T * row_pitch(out, B) ||
       (reinterpret_cast<uintptr_t>(out.overlap_ctl) & 15))
     return false;

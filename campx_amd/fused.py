@@ -175,16 +175,6 @@ class FusedGame(object):
     self.validate_actions = True
     self.frame = -1
     self._observation_cache = self._observation(self._obs, self._board)
-    # control block of overlapped small-batch rollouts (CampxOutputs.overlap_ctl; an A/B path,
-    # measured slower than two launches and off unless CAMPX_OVERLAP=1): zeroed once here,
-    # left zeroed by every launch; this game's own (its rollouts are ordered anyway)
-    # ... and of the one-launch rollouts of one-mover games (progress words the update role
-    # publishes and the render role of the same launch polls: 4 bytes per 64 environments,
-    # zeroed once, counting up from launch to launch)
-    self._overlap_ctl = None
-    if os.environ.get('CAMPX_OVERLAP', '0') == '1':
-      self._overlap_ctl = torch.zeros((int(_hip.lib.campx_overlap_ctl_bytes(B)) + 3) // 4,
-                                      dtype=torch.int32, device=dev)
     self._step = _hip.ops.step.default
     self._rollout = _hip.ops.rollout.default
     self._update = _hip.ops.update.default
@@ -355,9 +345,7 @@ class FusedGame(object):
   def _scratch(self, T):
     """CampxOutputs.overlap_ctl for a T-frame rollout: the tagged copy of the trace that lets a
     one-mover game's rollout run as ONE launch (campx_flow_scratch_bytes; the library decides
-    per call whether it does), or the opt-in overlapped launch's control block."""
-    if os.environ.get('CAMPX_OVERLAP', '0') == '1':
-      return self._overlap_ctl
+    per call whether it does)."""
     # (the library's own bounds, csrc/k_update.hip flow_ok / pipe_ok: no block where it would
     # not be used - at B = 65 536, T = 4 000 it would be half a gigabyte)
     frame = self.batch * self.n_layers * self.rows * self.cols

@@ -250,32 +250,22 @@ typedef struct CampxOutputs {
                          row used: every row then starts aligned and the kernels write whole
                          16-byte groups (the pad holds unspecified values).  `actions` and the
                          observation / board frames are never padded. */
-  uint32_t* overlap_ctl; /* optional device scratch, 16-byte aligned, ZEROED ONCE by the caller and
-                         then left to the library; NULL: two launches per rollout.
-                         (1) campx_flow_scratch_bytes(B, T) bytes: a rollout of a one-mover game
-                         at a batch of at most 8 192 environments (int8 observations of every
-                         frame, whole 16-byte chunks per frame) then runs as ONE launch - update
-                         workgroups first, render workgroups behind them reading a tagged
-                         16-bit copy of the trace kept in this block as the update role writes
-                         it (csrc/k_update.hip, pipe_table_kernel<true>): 17 / 24 / 36 us against
-                         21 / 28 / 38 at B = 1 024 / 4 096 / 8 192.  Not while `stream` is being
-                         captured into a graph.  CAMPX_NO_FLOW=1 in the environment: never.
-                         Two launches that may run at the same time must not share a block.
-                         (2) campx_overlap_ctl_bytes(B) bytes (every launch leaves its control
-                         words zeroed): an A/B path, used only when the
-                         environment says CAMPX_OVERLAP=1: a rollout of a one-mover game at a
-                         small batch then runs its update pass and its observation render in
-                         ONE persistent launch, the render following the update pass group by
-                         group (csrc/k_update.hip overlap_table_kernel).  Measured slower than
-                         the two launches at every batch size in round 4 (NOTES.md, round 4), hence off.
-                         Two launches that may run concurrently must not share a block.
-                         NULL: two launches. */
+  uint32_t* overlap_ctl; /* optional device scratch of campx_flow_scratch_bytes(B, T) bytes, 16-byte
+                         aligned, ZEROED ONCE by the caller and then left to the library; NULL:
+                         two launches per rollout.  With it a rollout of a one-mover game at a
+                         batch of at most 8 192 environments (int8 observations of every frame,
+                         whole 16-byte chunks per frame) runs as ONE launch whose update pass and
+                         render overlap: update workgroups first, render workgroups behind them
+                         reading a tagged 16-bit copy of the trace kept in this block as the
+                         update role writes it (csrc/k_update.hip, pipe_table_kernel<true>):
+                         15 / 22 / 34 us against 20 / 27 / 38 at B = 1 024 / 4 096 / 8 192.  Not
+                         while `stream` is being captured into a graph.  CAMPX_NO_FLOW=1 in the
+                         environment: never.  Two launches that may run at the same time must
+                         not share a block. */
   int64_t overlap_ctl_bytes;
 } CampxOutputs;
 
-/* Size of CampxOutputs.overlap_ctl for a batch of B environments. */
-int64_t campx_overlap_ctl_bytes(int64_t B);
-/* ... and for the one-launch rollouts of T frames (see CampxOutputs.overlap_ctl). */
+/* Size of CampxOutputs.overlap_ctl for rollouts of T frames of B environments. */
 int64_t campx_flow_scratch_bytes(int64_t B, int32_t T);
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */

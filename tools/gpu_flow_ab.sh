@@ -6,7 +6,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; mkdir -p $O
 if [ "${5:-}" = test ]; then
-  timeout 1500 python -m pytest tests/test_fused_parity.py tests/test_tabulate.py tests/test_fuzz_parity.py tests/test_torch_ops.py tests/test_chunked_rollouts.py tests/test_deferred.py tests/test_overlap.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+  timeout 1500 python -m pytest tests/test_fused_parity.py tests/test_tabulate.py tests/test_fuzz_parity.py tests/test_torch_ops.py tests/test_chunked_rollouts.py tests/test_deferred.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 fi
 line() { python3 -c "
 import json,sys
