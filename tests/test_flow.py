@@ -142,3 +142,13 @@ def test_switched_off_the_two_launches_give_the_same_bytes():
                        timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
   assert out.stdout.strip().endswith('ok')
+
+
+@pytest.mark.parametrize('B', [4096, 8192])
+def test_back_to_back_launches_beside_a_busy_stream(B):
+  """tools/flow_stress.py: launches queued without a pause, every one compared on the device with
+  the two kernels of a twin engine, while another stream fills memory and rolls out a third game."""
+  out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'flow_stress.py'), str(B), '3000', '100', '1'],
+                       capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  assert out.stdout.strip().endswith('ok B=%d launches=3000' % B)
