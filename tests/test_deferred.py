@@ -174,3 +174,14 @@ def test_host_tabulated_game_deferred_matches_its_ordinary_rollouts():
     want_prev = want['obs']
   assert torch.equal(a.flush()['obs'], want_prev)
   assert torch.equal(a.pos, b.pos) and torch.equal(a.ret, b.ret)
+
+
+def test_calls_queued_back_to_back_over_one_observation_buffer():
+  """tools/deferred_stress.py: 1 500 calls without a pause, two buffer sets sharing their
+  observations, every rollout compared on the device with the two kernels of a twin engine."""
+  import os, subprocess, sys
+  from conftest import REPO
+  out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'deferred_stress.py'), '16384', '1500', '100'],
+                       capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  assert out.stdout.strip().endswith('ok B=16384 calls=1500')
