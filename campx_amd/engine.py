@@ -382,6 +382,27 @@ class Engine(object):
                          'been through its_showtime()')
     return self._fused.rollout(actions, **kwargs)
 
+  def rollout_buffers(self, T, **kwargs):
+    """Fused tiers only: the output buffers of a T-frame rollout, allocated once
+    (`fused.FusedGame.rollout_buffers`)."""
+    if self._fused is None:
+      raise RuntimeError('rollout_buffers() needs a batched Engine (batch=B) that has '
+                         'been through its_showtime()')
+    return self._fused.rollout_buffers(T, **kwargs)
+
+  def rollout_deferred(self, actions, out, reset_first=False):
+    """Fused tiers only: T frames whose observations may arrive with the NEXT call - for action
+    streams that do not wait for them.  Returns the previous call's buffers, complete; see
+    `fused.FusedGame.rollout_deferred` (tiers without a shared launch run the rollout whole)."""
+    if self._fused is None:
+      raise RuntimeError('rollout_deferred() needs a batched Engine (batch=B) that has '
+                         'been through its_showtime()')
+    return self._fused.rollout_deferred(actions, out, reset_first=reset_first)
+
+  def flush(self):
+    """The buffers of the last `rollout_deferred()` call, complete (None if there is none)."""
+    return self._fused.flush() if self._fused is not None else None
+
   @property
   def fused(self):
     """The `fused.FusedGame` behind a batched engine (None in the generic tier)."""

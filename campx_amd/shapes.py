@@ -183,6 +183,19 @@ class ShapeGame(object):
                 done=torch.empty((T, B), dtype=torch.uint8, device=dev),
                 perf=None, trace=trace)
 
+  def rollout_deferred(self, actions, out, reset_first=False):
+    """`FusedGame.rollout_deferred` for this tier, which has no shared launch (one kernel does
+    update and render): the rollout is run whole, at once, and `out` is simply complete a call
+    early; returns the previous call's dict (None on the first)."""
+    prev = getattr(self, '_deferred', None)
+    self.rollout(actions, out=out, reset_first=reset_first)
+    self._deferred = out
+    return prev
+
+  def flush(self):
+    prev, self._deferred = getattr(self, '_deferred', None), None
+    return prev
+
   def rollout(self, actions, obs=None, board=None, keep_obs=True, reset_first=False,
               want_board=False, obs_dtype=torch.int8, out=None, pipelined=False):
     """T frames in one launch; arguments and result as `FusedGame.rollout`."""

@@ -185,3 +185,29 @@ def test_calls_queued_back_to_back_over_one_observation_buffer():
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
   assert out.stdout.strip().endswith('ok B=16384 calls=1500')
+
+
+@pytest.mark.parametrize('tier', ['wide', 'shape'])
+def test_engine_level_calls_on_tiers_without_a_shared_launch(tier):
+  """Engine.rollout_deferred / flush on the state-table tier (16x16 maze) and the shape tier
+  (Hello World): the rollout is run whole, the calling convention is the same."""
+  from campx_amd.games import hello_world, maze
+  B, T = 512, 30
+  build = (lambda **kw: maze.build(16, 16, **kw)) if tier == 'wide' else hello_world.build
+  a, b = build(batch=B, device='cuda'), build(batch=B, device='cuda')
+  a.its_showtime()
+  b.its_showtime()
+  assert type(a.fused).__name__ == ('WideGame' if tier == 'wide' else 'ShapeGame')
+  rng = np.random.RandomState(8)
+  sets = [a.rollout_buffers(T), a.rollout_buffers(T)]
+  want_prev = None
+  for call in range(3):
+    actions = torch.from_numpy(rng.randint(0, 5, size=(T, B)).astype(np.int8)).cuda()
+    want = b.rollout(actions, reset_first=(call == 0))
+    prev = a.rollout_deferred(actions, sets[call & 1], reset_first=(call == 0))
+    assert prev is (None if call == 0 else sets[(call - 1) & 1])
+    if prev is not None:
+      assert torch.equal(prev['obs'], want_prev)
+    want_prev = want['obs'].clone()
+  assert torch.equal(a.flush()['obs'], want_prev)
+  assert a.flush() is None
