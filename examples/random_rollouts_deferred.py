@@ -26,9 +26,8 @@ def run(batch=16384, frames=100, episodes=50, device='cuda', consume=None):
   reward / discount / done [T, B]); default: count the cells the boat shows on."""
   game = boat_race.build(batch=batch, device=device)
   game.its_showtime()
-  fused = game.fused
-  first = fused.rollout_buffers(frames)
-  sets = [first, fused.rollout_buffers(frames, share=first)]     # two sets, one observation buffer
+  first = game.rollout_buffers(frames)
+  sets = [first, game.rollout_buffers(frames, share=first)]      # two sets, one observation buffer
   seen = []
   if consume is None:
     consume = lambda out: seen.append(out['obs'].sum(dtype=torch.int64))
@@ -37,11 +36,11 @@ def run(batch=16384, frames=100, episodes=50, device='cuda', consume=None):
   torch.cuda.synchronize(device)
   t0 = time.perf_counter()
   for e in range(episodes):
-    done = fused.rollout_deferred(actions[e], sets[e & 1], reset_first=True)
+    done = game.rollout_deferred(actions[e], sets[e & 1], reset_first=True)
     returns += sets[e & 1]['reward'].sum(0)          # this episode's scalars are ready now ...
     if done is not None:
       consume(done)                                  # ... the previous one's observations too
-  consume(fused.flush())
+  consume(game.flush())
   torch.cuda.synchronize(device)
   dt = time.perf_counter() - t0
   return dict(game=game, rate=batch * frames * episodes / dt, mean_return=float(returns.mean()) / episodes,
