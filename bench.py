@@ -238,6 +238,9 @@ def kernel_names(fused, split):
   if type(fused).__name__ == 'WideGame':
     return 'wide_update_kernel + render_kernel'
   if split:
+    # (one-mover games at small batches: update pass and render share ONE launch)
+    if getattr(fused, '_flow_scratch', None) is not None:
+      return 'pipe_table_kernel<true> (update pass + render in one launch)'
     first = ('update_table_kernel' if fused.n_dyn == 1 else
              'update_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
              'update_tuple_kernel' if fused.uses_table else 'rollout_kernel<trace>')
