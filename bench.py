@@ -112,6 +112,17 @@ def parse_args(argv=None):
                       'i; every timed step still does one update pass and one render pass')
   p.add_argument('--gather-every', type=int, default=32,
                  help='episodes per RCCL all-gather of the episode-return log')
+  p.add_argument('--gather-at', type=float, default=2.0 / 3.0,
+                 help='a timed window shorter than --gather-every episodes gathers once, this '
+                      'fraction of the way into it')
+  p.add_argument('--pg-priority', choices=['high', 'normal'], default='high',
+                 help='priority of the stream RCCL runs its collectives on (ProcessGroupNCCL.Options.'
+                      'is_high_priority_stream): high = the episode-return gather is dispatched '
+                      'ahead of the rollout\'s queued workgroups instead of competing with them')
+  p.add_argument('--reserve-cus', type=int, default=0,
+                 help='A/B: launch the rollouts on a stream confined to all but this many compute '
+                      'units (campx_stream_create_cu_subset), so that a collective always finds '
+                      'free ones')
   p.add_argument('--episode-csv', default=None,
                  help='rank 0: after the timed region, write the last all-gathered block of '
                       'episode returns in the reference\'s CSV format '
@@ -250,7 +261,7 @@ def kernel_names(fused, split):
 
 
 def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_every,
-                    standin=None, pipelined=False, with_log=False):
+                    standin=None, pipelined=False, with_log=False, gather_at=2.0 / 3.0):
   """Warm up, then time exactly `steps` rollout launches.  Returns a dict.
 
   Wall clock: perf_counter around the timed region, bracketed by synchronize +
@@ -297,7 +308,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     # (never rarer than once per timed region, so that a short run still exercises the gather -
     # and then two thirds into it, with launches still to come as in a long run, not at its
     # very end, where the whole all-gather would sit exposed in front of the closing fence)
-    gather_every = max(1, min(gather_every, (2 * steps + 2) // 3))
+    gather_every = max(1, min(gather_every, int(gather_at * steps + 0.67)))
     log = ReturnLog(B, gather_every, device, dist)
 
   n_calls = [0]
@@ -352,6 +363,8 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   if log is not None:
     log.wait()
     log.align()                       # the timed window starts on a block boundary of the log
+  if log is not None and on_gpu:
+    log.timing = []                   # the gathers of the timed window leave their start / end events
   gc.collect()                        # (before the fence: the chip should not idle longer than it must)
   gc.disable()                        # no collector pause between two launches of the timed region
   fence()
@@ -385,13 +398,24 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
         elapsed * 1e6, (time.perf_counter() - t_sync) * 1e6))
   own_elapsed = elapsed               # this rank's; `elapsed` becomes the max over ranks
   gc.enable()
+  # where the window's time went, on the host's clock, and when its gathers ran, on the device's
+  # (relative to the event that opens the window on the launch stream)
+  window_us = {'loop': (t_loop - t0) * 1e6, 'log_wait': (t_wait - t_loop) * 1e6,
+               'synchronize': (t_sync - t_wait) * 1e6, 'total': elapsed * 1e6}
+  gathers = None
+  if log is not None and log.timing is not None:
+    gathers = [{'after_episode': n - log.timing[0][0] + gather_every,
+                'ready_us': ev0.elapsed_time(ready) * 1e3, 'done_us': ev0.elapsed_time(done) * 1e3}
+               for n, ready, done in log.timing]
+    window_us['launches_done'] = ev0.elapsed_time(ev1) * 1e3
+    log.timing = None
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
   result = dict(fused=fused, elapsed=elapsed, own_elapsed=own_elapsed, log=log, out=out,
-                pipelined=pipelined, settle=settle,
+                pipelined=pipelined, settle=settle, window_us=window_us, gathers=gathers,
                 gather_every=gather_every if log is not None else None,
                 mean_return=float(out['reward'].sum(0).mean())
                 if out['reward'] is not None else None)
@@ -513,6 +537,14 @@ def run_rank(args):
                        .format(rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+  if args.reserve_cus and standin is None:
+    import ctypes
+    from campx_amd import _hip
+    raw = ctypes.c_void_p()
+    n_cus = torch.cuda.get_device_properties(device).multi_processor_count - args.reserve_cus
+    _hip.check(_hip.lib.campx_stream_create_cu_subset(n_cus, ctypes.byref(raw)),
+               'campx_stream_create_cu_subset')
+    torch.cuda.set_stream(torch.cuda.ExternalStream(raw.value, device=device))
   # Every run - one rank too - goes through the process group and the episode-return log,
   # so that the N = 1 line times the same protocol as the ranks of an N > 1 run (the driver
   # computes scaling efficiency from those lines).
@@ -525,7 +557,9 @@ def run_rank(args):
       if standin is not None:
         dist.init_process_group('gloo', rank=rank, world_size=world)
       else:
-        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world)
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=args.pg_priority == 'high')
+        dist.init_process_group('nccl', device_id=device, rank=rank, world_size=world,
+                                pg_options=opts)
       world = dist.get_world_size()      # as the process group reports it
     except Exception as e:               # noqa: BLE001 - one rank can do without
       if world > 1 or args.force_dist:
@@ -540,7 +574,7 @@ def run_rank(args):
   T = args.frames
   m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
                       args.gather_every, standin, 'deferred' if args.deferred else args.pipeline,
-                      with_log=True)
+                      with_log=True, gather_at=args.gather_at)
   fused, elapsed = m['fused'], m['elapsed']
 
   gathered_ok = None
@@ -606,6 +640,12 @@ def run_rank(args):
             'rccl_world': world if (dist is not None and standin is None) else None,
             'gather_every': m['gather_every'],
             'settle_launches': m['settle'],
+            # rank 0's timed window: host clock (the loop that issues the launches, the wait for
+            # the log's last gather, the synchronise that closes the window) and, on the device
+            # clock from the window's opening event, when the launches were done and when each
+            # gather of the window could start (`ready_us`) and had finished (`done_us`)
+            'window_us': m['window_us'],
+            'gathers': m['gathers'],
             'per_rank_ms_per_step': per_rank_ms,
             'gathered_log_matches_local': gathered_ok,
             'per_rank_gathered_log_matches_local': per_rank_ok,

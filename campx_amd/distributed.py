@@ -118,6 +118,11 @@ class ReturnLog(object):
     self._work = [None, None]
     self._count = 0
     self._last = None
+    # (bench.py: `timing = []` makes every gather leave a pair of events - recorded on the
+    # caller's stream when the block is complete, and on an observer stream once the
+    # collective has finished - so a line can say when its gather ran)
+    self.timing = None
+    self._observer = None
 
   def row(self):
     """The float32 [batch] buffer the next episode accumulates its returns in."""
@@ -135,12 +140,29 @@ class ReturnLog(object):
     work = self._work[nxt]
     if work is not None and not (self.on_gpu and work.is_completed()):
       work.wait()
+    timed = self.timing is not None and self.on_gpu
+    if timed:
+      ready = torch.cuda.Event(enable_timing=True)
+      ready.record()                         # the block's last episode has finished
     if self.dist is not None:
       self._work[i] = self.dist.all_gather_into_tensor(
           self._out[i].view(-1), self._log[i].view(-1), group=self.group,
           async_op=self.on_gpu)
     else:
       self._out[i][0].copy_(self._log[i])
+    if timed:
+      # the collective runs on the process group's own stream; an observer stream waits for
+      # it (never the caller's stream) and records when it was done
+      if self._observer is None:
+        self._observer = torch.cuda.Stream(self.device)
+      done = torch.cuda.Event(enable_timing=True)
+      if self.dist is not None:
+        with torch.cuda.stream(self._observer):
+          self._work[i].wait()
+          done.record()
+      else:
+        done.record()                        # (the local copy ran on the caller's stream)
+      self.timing.append((self._count, ready, done))
     self._last = i
     return True
 

@@ -3,35 +3,52 @@
 The shape tier (`shapes.ShapeGame`, csrc/k_shape.hip) runs games whose things are rigid
 shapes that translate cyclically by a per-action offset and interact with nothing: the
 reference's examples/Hello World Example.ipynb (cell 3 `RollingDrape`, `SlidingSprite`; cell 4
-`make_game()`, z-order '12@34').  Such a game has rows*cols positions PER THING, so its states
-cannot be enumerated the way `tabulate.trace()` does; `campx_amd.rules` holds re-typed classes
-that declare their offsets (`fused_rule()`), and until round 4 only those reached the device.
+`make_game()`, z-order '12@34').  Such a game has rows*cols positions PER THING, so its joint
+states cannot be enumerated the way `tabulate.trace()` does; `campx_amd.rules` holds re-typed
+classes that declare their offsets (`fused_rule()`), and until round 4 only those reached the
+device.
 
 This module gives the notebook's OWN classes - any user classes of that kind - the same
 `gamespec.GameDescription` by watching them on the generic tier (`engine.Engine` with
-`batch=None`, the reference's execution model, campx/engine.py:114-324):
+`batch=None`, the reference's execution model, campx/engine.py:114-324).  Since round 5 the
+check is a PROOF over the game's own code, not a sample of walks:
 
-1. from the state `its_showtime()` leaves, each of the five actions is played once on a deep
-   copy; for every thing the curtain (a drape) or position (a sprite, campx/things.py:294)
-   after the frame must be the one before it rolled by some (rows, cols) offset, and the
-   reward it added (campx/plot.py:186-211; at most one `add_reward` per thing and frame) and
-   whether it ended the episode (discount 0.0 only) are noted per (thing, action) - the probe's
-   Plot records WHO called;
-2. that model - offsets, rewards summed in update order as `r + total`, termination, and the
-   reference renderer's treatment of sprites painted before the first drape, which are written
-   into the backdrop for good (campx/rendering.py:128,150: trails) - must then predict every
-   frame of a set of walks on the generic tier: all 25 two-action openings, every action
-   repeated max(rows, cols) + 2 times (once round the board: wrap-around is exercised for every
-   direction) and `WALKS` random walks of `WALK_FRAMES` frames: every thing's curtain /
-   position, the reward bit for bit,
-   discount, game-over and the rendered board.  Nothing else a frame can read may change
-   (`tabulate.hidden_image`: entity attributes, the Plot's entries), the z-order must stay put, and
-   the frame number must not be read.
+1. THE MODEL.  From the state `its_showtime()` leaves, each of the five actions is played once
+   on a deep copy; for every thing the curtain (a drape) or position (a sprite,
+   campx/things.py:294) after the frame must be the one before it rolled by some (rows, cols)
+   offset, and the reward it added (campx/plot.py:186-211; at most one `add_reward` per thing
+   and frame) and whether it ended the episode (discount 0.0 only) are noted per (thing,
+   action) - the probe's Plot records WHO called.  The frame's total reward (`r + total` in
+   update order) and discount depend on the action alone, so these five frames pin them for
+   good - given step 2.
 
-A game that passes is a shape game AS FAR AS THOSE FRAMES SHOW - the check is a sample, not an
-enumeration (a thing that behaves differently only in a configuration no walk reaches would
-pass); `RecogniseError` (a ValueError) names the first frame that contradicts the model.
-Host logic only; no GPU.
+2. EVERY THING IS INDEPENDENT, EVERYWHERE IT CAN GET.  Each thing (and the Backdrop) is then
+   taken alone: its `update()` is called directly, for every position the thing can reach
+   under its own offsets (rows * cols of them for Hello World's things) times the five
+   actions - 468 x 5 x 5 calls for Hello World - with RECORDING stand-ins for everything
+   `update()` is handed besides the action (campx/engine.py:200-204): `board`, every
+   `layers[ch]`, `backdrop.curtain` and the curtains of the other `things` are tensors that
+   note any operation on them, other entries of `things` and other attributes of the backdrop
+   note being fetched, the Plot notes reads and writes of its entries, `frame` reads,
+   z-order and default-discount requests.  Any such access is a refusal: the thing's behaviour
+   could depend on (or change) something besides itself.  What is left is a function of (the
+   thing's own state, the action), and it is checked on every point of its domain: the new
+   curtain / position is the old one moved by the action's offset, the reward and termination
+   are the model's, visibility and every other attribute of the entity stay as they were.  By
+   induction over frames the model then holds for every action sequence, whatever the other
+   things do.  (One input is beyond this: module globals, closures, clocks and random number
+   generators that `update()` consults behind the engine's back.  As in `tabulate.py` those
+   are only spot-checked - by the walks of step 3.)
+
+3. CROSS-CHECK of this module's own model against the engine (rendering with the trails that
+   sprites painted before the first drape leave in the backdrop, campx/rendering.py:128,150;
+   reward summation; game over): all 25 two-action openings, every action repeated once round
+   the board, and `WALKS` random walks of `WALK_FRAMES` frames, every thing's curtain /
+   position, reward bit for bit, discount, game-over and rendered board compared frame by
+   frame.  The same recording stand-ins are in force during these frames.
+
+`RecogniseError` (a ValueError) names the first thing, position and action that contradicts
+the model.  Host logic only; no GPU.
 """
 
 import copy
@@ -60,6 +77,8 @@ def _fail(msg):
 
 _CALLS = []          # (character of the thing being updated, 'reward' | 'end', value)
 _NOW = [None]
+_RECORDING = [False]  # the engine's own update() calls get recording stand-ins too
+BACKDROP = 'the Backdrop'
 _WATCHED = {}
 _WATCHED_PLOTS = {}
 
@@ -75,8 +94,22 @@ def _watched_class(cls):
     _campx_watched = True
 
     def update(self, *args, **kwargs):
-      _NOW[0] = self.character
+      _NOW[0] = getattr(self, 'character', BACKDROP)
       try:
+        if _RECORDING[0] and len(args) == 5 and not kwargs and args[0] is not None:
+          # (the Backdrop's call, campx/engine.py:190-192)
+          actions, board, layers, all_things, the_plot = args
+          args = (actions, _watched_tensor(board, 'board'),
+                  {ch: _watched_tensor(t, 'layers[{!r}]'.format(ch)) for ch, t in layers.items()},
+                  _WatchedThings(all_things, None), the_plot)
+        elif _RECORDING[0] and len(args) == 6 and not kwargs and args[0] is not None:
+          # (the engine's call, campx/engine.py:202-204: board, layers, backdrop, things
+          # replaced by their recording twins)
+          actions, board, layers, backdrop, all_things, the_plot = args
+          args = (actions, _watched_tensor(board, 'board'),
+                  {ch: _watched_tensor(t, 'layers[{!r}]'.format(ch)) for ch, t in layers.items()},
+                  _WatchedBackdrop(backdrop), _WatchedThings(all_things, self.character),
+                  the_plot)
         return cls.update(self, *args, **kwargs)
       finally:
         _NOW[0] = None
@@ -105,8 +138,181 @@ def _watched_plot(base):
       _CALLS.append((_NOW[0], 'discount', None))
       return base.change_default_discount(self, *args, **kwargs)
 
+    def change_z_order(self, *args, **kwargs):
+      _CALLS.append((_NOW[0], 'z-order', None))
+      return base.change_z_order(self, *args, **kwargs)
+
+    # The Plot is a dict for the game's own entries (campx/plot.py:29): inside an update() any
+    # access to one is noted - an entry may alias the renderer's live layers
+    # (`the_plot['prev_pos_A'] = layers['A']`, examples/boat_race.py:59), and a written one is
+    # state outside the thing.  (`log()` appends to its own key: write-only, left alone.)
+    def _entry(self, key, how):
+      if _NOW[0] is not None and key != self.LOG_KEY:
+        _READS.append((_NOW[0], 'the_plot[{!r}] ({})'.format(key, how)))
+
+    def __getitem__(self, key):
+      self._entry(key, 'read')
+      return base.__getitem__(self, key)
+
+    def get(self, key, default=None):
+      self._entry(key, 'read')
+      return base.get(self, key, default)
+
+    def __contains__(self, key):
+      self._entry(key, 'read')
+      return base.__contains__(self, key)
+
+    def __setitem__(self, key, value):
+      self._entry(key, 'written')
+      return base.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+      self._entry(key, 'written')
+      return base.__delitem__(self, key)
+
+    def setdefault(self, key, default=None):
+      self._entry(key, 'written')
+      return base.setdefault(self, key, default)
+
+    def pop(self, key, *default):
+      self._entry(key, 'written')
+      return base.pop(self, key, *default)
+
+    def update(self, *args, **kwargs):
+      self._entry('...', 'written')
+      return base.update(self, *args, **kwargs)
+
+    def clear(self):
+      self._entry('...', 'written')
+      return base.clear(self)
+
+    def keys(self):
+      self._entry('...', 'read')
+      return base.keys(self)
+
+    def values(self):
+      self._entry('...', 'read')
+      return base.values(self)
+
+    def items(self):
+      self._entry('...', 'read')
+      return base.items(self)
+
+    def __iter__(self):
+      self._entry('...', 'read')
+      return base.__iter__(self)
+
   _WATCHED_PLOTS[base] = WatchedPlot
   return WatchedPlot
+
+
+# ---------------------------------------------------------------- what update() is handed
+
+_READS = []          # (character of the thing being updated, what it touched)
+_META = frozenset(('shape', 'size', 'dim', 'ndim', 'ndimension', 'dtype', 'device', 'numel',
+                   'nelement', 'stride', 'is_contiguous', 'is_floating_point', 'layout',
+                   'requires_grad', 'is_cuda', 'is_sparse', 'element_size', 'type', 'names'))
+
+
+def _func_name(func):
+  owner = getattr(func, '__self__', None)          # a property getter: Tensor.shape.__get__
+  if getattr(func, '__name__', '') in ('__get__', '__set__') and hasattr(owner, '__name__'):
+    return owner.__name__
+  return getattr(func, '__name__', repr(func))
+
+
+class _WatchedTensor(torch.Tensor):
+  """A tensor that notes every operation it takes part in (reading its metadata aside); the
+  operation itself runs on plain tensors and returns plain tensors."""
+
+  @classmethod
+  def __torch_function__(cls, func, types, args=(), kwargs=None):
+    kwargs = kwargs or {}
+    name = _func_name(func)
+    if name not in _META:
+      seen = []
+
+      def look(x):
+        if isinstance(x, _WatchedTensor):
+          seen.append(x)
+        elif isinstance(x, (list, tuple)):
+          for y in x:
+            look(y)
+      look(args)
+      look(list(kwargs.values()))
+      for x in seen:
+        _READS.append((_NOW[0], '{} ({})'.format(getattr(x, '_campx_label', 'a tensor'), name)))
+    with torch._C.DisableTorchFunctionSubclass():
+      return func(*args, **kwargs)
+
+
+def _watched_tensor(t, label):
+  w = torch.Tensor._make_subclass(_WatchedTensor, t.detach())
+  w._campx_label = label
+  return w
+
+
+class _WatchedThings(dict):
+  """`things` as update() gets it (campx/engine.py:203): the thing's own entry is itself;
+  fetching another one is noted."""
+
+  def __init__(self, real, own):
+    dict.__init__(self, real)
+    self._own = own
+
+  def _note(self, key):
+    if key != self._own:
+      _READS.append((_NOW[0], 'things[{!r}]'.format(key)))
+
+  def __getitem__(self, key):
+    self._note(key)
+    return dict.__getitem__(self, key)
+
+  def get(self, key, default=None):
+    self._note(key)
+    return dict.get(self, key, default)
+
+  def values(self):
+    _READS.append((_NOW[0], 'things.values()'))
+    return dict.values(self)
+
+  def items(self):
+    _READS.append((_NOW[0], 'things.items()'))
+    return dict.items(self)
+
+
+class _WatchedBackdrop(object):
+  """The Backdrop as a thing's update() gets it: the curtain is a watched tensor, the palette a
+  constant, any other attribute noted."""
+
+  def __init__(self, real):
+    object.__setattr__(self, '_real', real)
+    object.__setattr__(self, '_curtain_w', _watched_tensor(real.curtain, 'backdrop.curtain'))
+
+  @property
+  def curtain(self):
+    return self._curtain_w
+
+  @property
+  def palette(self):
+    return self._real.palette
+
+  def __getattr__(self, name):
+    _READS.append((_NOW[0], 'backdrop.' + name))
+    return getattr(self._real, name)
+
+  def __setattr__(self, name, value):
+    _READS.append((_NOW[0], 'backdrop.{} (written)'.format(name)))
+    setattr(self._real, name, value)
+
+
+def _stand_ins(eng, own):
+  """(board, layers, backdrop, things) for one `update()` call of the thing `own` (None: the
+  Backdrop) on the engine `eng`, all recording."""
+  obs = eng._board
+  board = _watched_tensor(obs.board, 'board')
+  layers = {ch: _watched_tensor(t, 'layers[{!r}]'.format(ch)) for ch, t in obs.layers.items()}
+  return board, layers, _WatchedBackdrop(eng.backdrop), _WatchedThings(eng.things, own)
 
 
 # ---------------------------------------------------------------- actions
@@ -215,6 +421,122 @@ def _thing_mask(ent, H, W):
   return ent.curtain.detach().cpu().numpy().astype(np.uint8)
 
 
+def _entity_extras(ent, kind):
+  """Image of everything an entity holds besides its curtain / position / visibility."""
+  out = []
+  for name, value in sorted(vars(ent).items()):
+    if name in tabulate._CORE_ATTRS[kind]:
+      continue
+    try:
+      out.append((name, tabulate._plain(value, name, 0, frozenset())))
+    except tabulate._Unimageable as e:
+      _fail('attribute {} of {!r} is not plain data'.format(e, getattr(ent, 'character', 'the Backdrop')))
+  return tuple(out)
+
+
+def _prove_independent(probe, model, actions, reads0):
+  """Step 2 of the module docstring.  `probe` is the watched engine right after
+  `its_showtime()`; `model` holds the per-(thing, action) offsets, rewards and terminations
+  inferred from one frame of every action.  Calls every thing's `update()` directly - on a
+  copy of the engine - for every position its own offsets can take it to x every action,
+  handing it recording stand-ins; raises `RecogniseError` on the first access to anything but
+  itself, or the first (position, action) where it does not do what the model says."""
+  H, W = model.H, model.W
+  eng = tabulate.clone_engine(probe)
+  plot = eng._the_plot
+
+  def expected_calls(ch, a):
+    want = []
+    if model.reward[ch][a] is not None:
+      want.append(('reward', np.array([model.reward[ch][a]], np.float32).view(np.uint32)[0]))
+    if model.ends[ch][a]:
+      want.append(('end', 0.0))
+    return sorted(want)
+
+  def one_call(ent, ch, a, where, backdrop_call=False):
+    del _CALLS[:]
+    del _READS[:]
+    board, layers, backdrop, all_things = _stand_ins(eng, ch)
+    action = copy.deepcopy(actions[a])
+    _RECORDING[0] = False        # (the stand-ins are handed over here)
+    if backdrop_call:
+      ent.update(action, board, layers, all_things, plot)       # campx/engine.py:190-192
+    else:
+      ent.update(action, board, layers, backdrop, all_things, plot)
+    plot._clear_engine_directives()
+    if tabulate.FRAME_READS[0] != reads0:
+      _fail(where + ' reads the_plot.frame')
+    if _READS:
+      _fail('{} looks at / touches {}: a thing of a shape game depends on nothing but itself '
+            'and the action'.format(where, _READS[0][1]))
+    got = []
+    for who, what, value in _CALLS:
+      if what == 'reward':
+        got.append(('reward', np.array([tabulate.reward_f32(value)], np.float32).view(np.uint32)[0]))
+      elif what == 'end':
+        got.append(('end', float(value)))
+      else:
+        _fail('{} asks the Plot for a {} change'.format(where, what))
+    return sorted(got)
+
+  # the Backdrop: one state, five actions; it may do nothing at all
+  bd = eng.backdrop
+  if getattr(type(bd), '_campx_watched', False):
+    art = bd.curtain.detach().clone()
+    extras = _entity_extras(bd, 'backdrop')
+    for a in range(N_ACTIONS):
+      where = BACKDROP + ', action {}:'.format(a)
+      if one_call(bd, None, a, where, backdrop_call=True):
+        _fail(where + ' it talks to the Plot')
+      if not torch.equal(bd.curtain, art) or _entity_extras(bd, 'backdrop') != extras:
+        _fail(where + ' it changes')
+
+  for ch in model.schedule:
+    ent = eng.things[ch]
+    sprite = model.is_sprite[ch]
+    kind = 'sprite' if sprite else 'drape'
+    start = model.masks[ch]
+    extras = _entity_extras(ent, kind)
+    offs = [(model.drow[ch][a], model.dcol[ch][a]) for a in range(N_ACTIONS)]
+    r0 = c0 = 0
+    if sprite:
+      r0, c0 = int(ent.position.row), int(ent.position.col)
+      if not (0 <= r0 < H and 0 <= c0 < W):
+        _fail('sprite {!r} stands outside the board'.format(ch))
+    seen = {(0, 0)}
+    frontier = [(0, 0)]
+    while frontier:
+      pos = frontier.pop()
+      for a in range(N_ACTIONS):
+        if sprite:
+          ent._position = ent.Position((r0 + pos[0]) % H, (c0 + pos[1]) % W)
+        else:
+          ent._curtain = torch.from_numpy(np.roll(start, pos, (0, 1)).copy())
+        where = '{!r} moved by (rows {}, cols {}) from its start, action {}:'.format(
+            ch, pos[0], pos[1], a)
+        got = one_call(ent, ch, a, where)
+        if got != expected_calls(ch, a):
+          _fail(where + ' its reward / termination is not the one action {} has at its '
+                'start'.format(a))
+        nxt = ((pos[0] + offs[a][0]) % H, (pos[1] + offs[a][1]) % W)
+        if sprite:
+          at = ent.position
+          ok = (int(at.row), int(at.col)) == ((r0 + nxt[0]) % H, (c0 + nxt[1]) % W) \
+              and bool(ent.visible) == model.visible[ch]
+        else:
+          now = ent.curtain.detach().cpu().numpy()
+          ok = now.shape == start.shape and np.array_equal(now, np.roll(start, nxt, (0, 1)))
+        if not ok:
+          _fail(where + ' it is not moved by the action\'s offset (rows {}, cols {}): what it '
+                'does depends on where it is'.format(offs[a][0], offs[a][1]))
+        if _entity_extras(ent, kind) != extras:
+          _fail(where + ' state outside its curtain / position changed (an attribute of the '
+                'entity)')
+        if nxt not in seen:
+          seen.add(nxt)
+          frontier.append(nxt)
+
+
 def looks_like_shapes(engine, actions):
   """One frame of every action from the start: True when the cell-indexed / state tables
   cannot be the right home for this game - a DRAPE that moves covers more than one cell, or a visible sprite is painted before the first drape (it writes into the backdrop,
@@ -261,11 +583,13 @@ def shapes(engine, actions=None):
   probe = tabulate.clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None
   probe._the_plot.__class__ = _watched_plot(tabulate.probe_plot_class(type(probe._the_plot)))
-  for ent in probe.things.values():
+  for ent in list(probe.things.values()) + [probe.backdrop]:
+    if ent is probe.backdrop and type(ent).update is _things.Backdrop.update:
+      continue
     try:
       ent.__class__ = _watched_class(type(ent))
     except TypeError as e:
-      _fail('{!r}: its class cannot be watched ({})'.format(ent.character, e))
+      _fail('{!r}: its class cannot be watched ({})'.format(getattr(ent, 'character', BACKDROP), e))
   start_masks = {ch: _thing_mask(ent, H, W) for ch, ent in probe.things.items()}
   backdrop_art = probe.backdrop.curtain.detach().cpu().numpy().astype(np.uint8).copy()
   obs, _, _ = probe.its_showtime()
@@ -296,11 +620,23 @@ def shapes(engine, actions=None):
     _fail('the first observation is not "backdrop, then every thing in z-order"')
   model.backdrop0 = model.backdrop.copy()                # (the first frame's trail cells)
 
-  def play(eng, a):
-    del _CALLS[:]
-    obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
+  def refuse_reads(where):
     if tabulate.FRAME_READS[0] != reads0:
       _fail('the game reads the_plot.frame')
+    if _READS:
+      who, what = _READS[0]
+      _fail('{}{!r} looks at / touches {}: a thing of a shape game depends on nothing but '
+            'itself and the action'.format(where, who, what))
+
+  def play(eng, a, where=''):
+    del _CALLS[:]
+    del _READS[:]
+    _RECORDING[0] = True
+    try:
+      obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
+    finally:
+      _RECORDING[0] = False
+    refuse_reads(where)
     return obs, tabulate.reward_f32(reward), float(np.float32(discount)), list(_CALLS)
 
   # ---- 1. one frame of every action from the start: offsets, rewards, who ends the episode
@@ -320,6 +656,8 @@ def shapes(engine, actions=None):
         _fail('the Backdrop (or code outside any thing\'s update) talks to the Plot')
       if what == 'discount':
         _fail('{!r} changes the default discount'.format(who))
+      if what == 'z-order':
+        _fail('{!r} asks for a z-order change'.format(who))
       if what == 'end':
         if value != 0.0:
           _fail('{!r} ends the episode with discount {}'.format(who, value))
@@ -331,13 +669,16 @@ def shapes(engine, actions=None):
         # every action is part of what the walks below check)
         model.reward[who][a] = tabulate.reward_f32(value)
 
-  # ---- 2. the model predicts the generic tier, frame by frame
+  # ---- 2. every thing alone, at every position it can reach, under every action
+  _prove_independent(probe, model, actions, reads0)
+
+  # ---- 3. the model against the engine, frame by frame (a cross-check of THIS module)
   def follow(eng, seq, what):
     model.reset()
     for t, a in enumerate(seq):
-      obs, reward, discount, _ = play(eng, a)
-      want_reward, want_discount = model.step(a)
       where = '{} frame {} (action {})'.format(what, t, a)
+      obs, reward, discount, _ = play(eng, a, where + ': ')
+      want_reward, want_discount = model.step(a)
       if list(eng.things.keys()) != order:
         _fail(where + ': the z-order changed')
       for ch, ent in eng.things.items():

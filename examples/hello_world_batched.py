@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""The Hello World notebook's game, typed the way the notebook types it, for 32 768 environments.
+"""A user's own Hello World for 32 768 environments: plain Python classes, recognised, not declared.
 
-examples/Hello World Example.ipynb (cells 3-4) defines `RollingDrape` (np.roll of a 95-cell
-mask) and `SlidingSprite` (diagonal moves) with plain Python `update()` methods and integer
-actions, and a zero-argument `make_game()`.  Nothing below tells the engine what those classes
-do: `engine.set_default_batch()` makes `make_game()` build a batched engine, and
+The game of examples/Hello World Example.ipynb (cells 3-4: the 95-cell '@' banner that rolls
+under actions 0..3 and pays a point for it, four sprites that slide diagonally, action 4 quits;
+integer actions; a zero-argument `make_game()`) written here independently of the notebook's
+code - `Scroller` rolls with `torch.roll` by a (rows, cols) pair per action, `Bishop` derives
+its four diagonal moves from the heading of action 0.  Nothing below tells the engine what
+those classes do: `engine.set_default_batch()` makes `make_game()` build a batched engine, and
 `its_showtime()` recognises the game (campx_amd/recognise.py: per-action offsets inferred on the
-single-environment tier and verified on sampled walks) and hands it to the shape tier's kernel.
+single-environment tier, then PROVED thing by thing - every reachable position x every action
+with recording stand-ins for everything but the thing itself) and hands it to the shape tier's
+kernel.  The recognised spec is byte-equal to the one the notebook's own cells recognise to
+(tests/test_recognise.py, tests/golden/hello_world_spec.npz).
 
     python examples/hello_world_batched.py          # needs an MI355X
 """
@@ -15,7 +20,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,47 +28,54 @@ from campx.ascii_art import ascii_art_to_game, Partial   # noqa: E402
 from campx_amd import engine                              # noqa: E402
 from campx_amd.games.hello_world import HELLO_ART         # noqa: E402  (the notebook's art)
 
-
-class RollingDrape(things.Drape):
-  _ROLL_AXES = [0, 0, 1, 1]
-  _ROLL_SHIFTS = [-1, 1, -1, 1]
-
-  def update(self, actions, board, layers, backdrop, all_things, the_plot):
-    if actions is None: return
-    if actions == 4: the_plot.terminate_episode()
-    if actions < 4:
-      rolled = np.roll(self.curtain.numpy(), self._ROLL_SHIFTS[actions], self._ROLL_AXES[actions])
-      self.curtain.set_(torch.from_numpy(rolled.copy()))
-      the_plot.add_reward(1)
+QUIT = 4
 
 
-class SlidingSprite(things.Sprite):
-  _DX = ([-1, 1, -1, 1], [-1, 1, -1, 1], [1, -1, 1, -1], [1, -1, 1, -1])
-  _DY = ([-1, 1, 1, -1], [1, -1, -1, 1], [1, -1, -1, 1], [-1, 1, 1, -1])
+class Scroller(things.Drape):
+  """The banner: actions 0..3 scroll it one cell up / down / left / right, wrapping, for a
+  point; QUIT ends the episode."""
 
-  def __init__(self, corner, position, character, direction_set):
-    super(SlidingSprite, self).__init__(corner, position, character)
-    self._dx = self._DX[direction_set]
-    self._dy = self._DY[direction_set]
+  SCROLL = {0: (-1, 0), 1: (1, 0), 2: (0, -1), 3: (0, 1)}     # action -> (rows, cols)
 
   def update(self, actions, board, layers, backdrop, all_things, the_plot):
-    if actions is None or actions > 3: return
-    self._position = self.Position((self._position.row + self._dy[actions]) % self.corner.row,
-                                   (self._position.col + self._dx[actions]) % self.corner.col)
+    if actions is None:
+      return
+    if actions == QUIT:
+      the_plot.terminate_episode()
+      return
+    self.curtain.copy_(torch.roll(self.curtain, self.SCROLL[int(actions)], (0, 1)))
+    the_plot.add_reward(1)
 
 
-def make_game():
+class Bishop(things.Sprite):
+  """Slides diagonally: action 0 along `heading` (rows, cols), action 1 back, actions 2 and 3
+  along the other diagonal (rows mirrored, and back)."""
+
+  def __init__(self, corner, position, character, heading):
+    super(Bishop, self).__init__(corner, position, character)
+    dr, dc = heading
+    self._moves = ((dr, dc), (-dr, -dc), (-dr, dc), (dr, -dc))
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None or actions == QUIT:
+      return
+    dr, dc = self._moves[int(actions)]
+    rows, cols = self.corner
+    self._position = self.Position((self.position.row + dr) % rows, (self.position.col + dc) % cols)
+
+
+def make_game(bishop=Bishop, scroller=Scroller):
   return ascii_art_to_game(
       HELLO_ART, what_lies_beneath=' ',
-      sprites={'1': Partial(SlidingSprite, 0), '2': Partial(SlidingSprite, 1),
-               '3': Partial(SlidingSprite, 2), '4': Partial(SlidingSprite, 3)},
-      drapes={'@': RollingDrape}, z_order='12@34')
+      sprites={'1': Partial(bishop, (-1, -1)), '2': Partial(bishop, (1, -1)),
+               '3': Partial(bishop, (1, 1)), '4': Partial(bishop, (-1, 1))},
+      drapes={'@': scroller}, z_order='12@34')
 
 
 def main():
   B, T = 32768, 100
   engine.set_default_batch(B, 'cuda')
-  game = make_game()                      # the notebook's call, unchanged
+  game = make_game()                      # a zero-argument make_game(), as the notebook calls its own
   t0 = time.perf_counter()
   board, reward, discount = game.its_showtime()
   torch.cuda.synchronize()

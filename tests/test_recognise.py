@@ -9,8 +9,12 @@ the library's re-typed classes lower to, which is also a committed fixture
 REFERENCE engine produced with the same classes (`parade.npz`, make_golden.py) through the C
 oracle; (c) games that are not shape games are refused, with the frame that shows it.
 GPU (`-m gpu`): the test-local game through `shape_rollout_kernel` against that golden and
-against the C oracle on random streams; the unmodified-notebook path for Hello World itself,
-with classes written in this file as the notebook writes them.
+against the C oracle on random streams; Hello World itself as a user's own classes
+(examples/hello_world_batched.py, written independently of the notebook) through
+`set_default_batch()` and recognition, against `hello_world.npz`.
+(d) round 5: recognition is a proof - every thing alone, at every position it can reach, under
+every action, with recording stand-ins for everything else update() is handed: a one-cell
+exception, a reward that differs on one row and a look at `layers` are all refused.
 """
 
 import ctypes
@@ -125,11 +129,12 @@ def test_recognised_parade_replays_the_reference_engines_frames_through_the_orac
 
 
 def test_games_that_are_not_shape_games_are_refused_with_the_frame_that_shows_it():
-  with pytest.raises(recognise.RecogniseError, match=r"'L' is not where its per-action offsets"):
+  with pytest.raises(recognise.RecogniseError, match=r"'L' looks at / touches things\['#'\]"):
     recognise.shapes(shape_local.not_a_shape(), list(range(5)))
-  # a sprite that stops at the right edge instead of wrapping: 34 columns away from where it
-  # starts - found by the "every action repeated once round the board" walks
-  with pytest.raises(recognise.RecogniseError, match=r"action 1 repeated, frame 3[0-9].*'c' is not where"):
+  # a sprite that stops at the right edge instead of wrapping: 33 columns away from where it
+  # starts - found by the enumeration of every position it can reach
+  with pytest.raises(recognise.RecogniseError,
+                     match=r"'c' moved by \(rows 0, cols 33\) from its start, action 1: it is not moved"):
     recognise.shapes(shape_local.clamps_at_the_edge(), list(range(5)))
   import traced_games
   # a one-cell walker stopped by walls: the tabulator's game, not this module's
@@ -150,7 +155,24 @@ def test_games_that_are_not_shape_games_are_refused_with_the_frame_that_shows_it
 
   game = ascii_art_to_game(['CC   ', '     '], what_lies_beneath=' ', drapes={'C': Counting},
                            z_order='C', update_schedule='C')
-  with pytest.raises(recognise.RecogniseError, match='state outside the curtains changed'):
+  with pytest.raises(recognise.RecogniseError, match=r"'C' looks at / touches the_plot\['n'\]"):
+    recognise.shapes(game, list(range(5)))
+
+  class Tired(things.Drape):
+    """State in an attribute of its own: after three moves it stops."""
+    def __init__(self, curtain, character):
+      super(Tired, self).__init__(curtain, character)
+      self.moves = 0
+
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is None or self.moves >= 3:
+        return
+      self.moves += 1
+      self.curtain.set_(torch.roll(self.curtain, 1, 1))
+
+  game = ascii_art_to_game(['TT   ', '     '], what_lies_beneath=' ', drapes={'T': Tired},
+                           z_order='T', update_schedule='T')
+  with pytest.raises(recognise.RecogniseError, match=r"state outside its curtain / position changed"):
     recognise.shapes(game, list(range(5)))
 
 
@@ -161,6 +183,121 @@ def test_action_format_is_detected_from_the_classes():
   game = shape_local.parade()
   game.set_action_set([4, 3, 2, 1, 0])
   assert recognise.detect_actions(game) == [4, 3, 2, 1, 0]
+
+
+# ------------------------------------------------------- recognition is a proof (round 5)
+
+def _hello(**classes):
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import hello_world_batched as ex
+  return ex, ex.make_game(**classes)
+
+
+def test_hello_world_with_one_trap_door_cell_is_refused():
+  """sprite '3' jumps to (0, 0) when it stands on (2, 3) - a cell the sampled walks
+  of round 4 never reached, so the game was accepted and would have run wrong on the device.
+  The enumeration visits every cell a thing can reach: refused, naming thing and place."""
+  ex, _ = _hello()
+
+  class TrapDoor(ex.Bishop):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is not None and self.character == '3' and tuple(self.position) == (2, 3):
+        self._position = self.Position(0, 0)
+        return
+      ex.Bishop.update(self, actions, board, layers, backdrop, all_things, the_plot)
+
+  game = ex.make_game(bishop=TrapDoor)
+  assert recognise.looks_like_shapes(game, list(range(5)))
+  with pytest.raises(recognise.RecogniseError, match=r"'3' moved by \(rows \d+, cols \d+\) from its "
+                     r"start, action \d: it is not moved by the action's offset"):
+    recognise.shapes(game)
+  # and through the engine's own front door: the tabulator cannot take it either
+  game = ex.make_game(bishop=TrapDoor)
+  game._batch, game._device = 4, 'cpu'
+  with pytest.raises(ValueError):
+    with pytest.MonkeyPatch.context() as mp:
+      mp.setattr(torch.cuda, 'is_available', lambda: True)
+      game.its_showtime()
+
+
+def test_a_drape_whose_reward_differs_on_one_row_is_refused():
+  ex, _ = _hello()
+
+  class Generous(ex.Scroller):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      ex.Scroller.update(self, actions, board, layers, backdrop, all_things, the_plot)
+      # the banner's top row (13 cells) starts on row 7; one point more whenever it stands on row 2
+      if actions is not None and actions != ex.QUIT and int(self.curtain[2].sum()) == 13 \
+          and int(self.curtain[1].sum()) == 0:
+        the_plot.add_reward(1)
+
+  game = ex.make_game(scroller=Generous)
+  with pytest.raises(recognise.RecogniseError, match=r"'@' moved by .* its reward / termination is not"):
+    recognise.shapes(game)
+
+
+def test_a_sprite_that_reads_layers_board_things_or_the_plot_is_refused():
+  ex, _ = _hello()
+
+  def bishop_that(look):
+    class Peeking(ex.Bishop):
+      def update(self, actions, board, layers, backdrop, all_things, the_plot):
+        if actions is not None:
+          look(self, board, layers, backdrop, all_things, the_plot)
+        ex.Bishop.update(self, actions, board, layers, backdrop, all_things, the_plot)
+    return Peeking
+
+  cases = [
+      (lambda self, b, l, bd, th, p: bool(l['@'][0, 0]), r"layers\['@'\]"),
+      (lambda self, b, l, bd, th, p: int(b.sum()), r"board \(sum\)"),
+      (lambda self, b, l, bd, th, p: bd.curtain.numpy(), r"backdrop\.curtain"),
+      (lambda self, b, l, bd, th, p: th['@'].curtain, r"things\['@'\]"),
+      (lambda self, b, l, bd, th, p: p.get('anything'), r"the_plot\['anything'\] \(read\)"),
+      (lambda self, b, l, bd, th, p: p.__setitem__('n', 1), r"the_plot\['n'\] \(written\)"),
+      (lambda self, b, l, bd, th, p: p.frame, r"reads the_plot\.frame"),
+      (lambda self, b, l, bd, th, p: p.change_z_order('1', '4'), r"z-order"),
+  ]
+  for look, pattern in cases:
+    with pytest.raises(recognise.RecogniseError, match=pattern):
+      recognise.shapes(ex.make_game(bishop=bishop_that(look)))
+  # what is NOT a look: the thing's own entry of `things`, shapes and dtypes, the palette, the log
+  harmless = bishop_that(lambda self, b, l, bd, th, p: (
+      th[self.character].position, b.shape, l['@'].dtype, len(l), bd.palette, p.log('moved')))
+  desc = recognise.shapes(ex.make_game(bishop=harmless))
+  assert _spec_bytes(gamespec.lower_shapes(desc)) == _golden('hello_world_spec')['spec'].tobytes()
+
+
+def test_a_backdrop_that_changes_or_looks_is_refused():
+  from campx import things
+  from campx.ascii_art import ascii_art_to_game
+  C = shape_local.bind(things)
+
+  class Tide(things.Backdrop):
+    def update(self, actions, board, layers, things_, the_plot):
+      if actions is not None and int(actions) == 2:
+        self.curtain[0, 0] = ord('~')
+
+  class Nosy(things.Backdrop):
+    def update(self, actions, board, layers, things_, the_plot):
+      if actions is not None:
+        things_['W'].curtain.sum()
+
+  art = ['        ', '  WW    ', '  W     ', '        ']
+  for backdrop, pattern in ((Tide, r'the Backdrop, action 2: it changes'),
+                            (Nosy, r"things\['W'\]")):
+    game = ascii_art_to_game(art, what_lies_beneath=' ', drapes={'W': C.Wave}, backdrop=backdrop,
+                             z_order='W', update_schedule='W')
+    with pytest.raises(recognise.RecogniseError, match=pattern):
+      recognise.shapes(game, list(range(5)))
+
+
+def test_recognising_hello_world_takes_seconds():
+  import time
+  ex, game = _hello()
+  t0 = time.perf_counter()
+  desc = recognise.shapes(game)
+  assert time.perf_counter() - t0 < 10.0
+  assert _spec_bytes(gamespec.lower_shapes(desc)) == _golden('hello_world_spec')['spec'].tobytes()
 
 
 # ------------------------------------------------------------------------------- GPU
@@ -227,55 +364,21 @@ def test_parade_random_streams_against_the_oracle_and_the_generic_tier(batch):
 
 
 @pytest.mark.gpu
-def test_notebook_style_hello_world_runs_batched_unchanged():
-  """The notebook's cells cannot travel to the GPU box, so its two classes and make_game()
-  are typed out here the way the notebook has them (integers as actions, np.roll, a
-  zero-argument make_game()); `set_default_batch` is the only addition.  Same frames as
-  `hello_world.npz`, which make_golden.py made with the notebook's cells on the reference
-  engine."""
-  from campx import things
-  from campx.ascii_art import ascii_art_to_game, Partial
+def test_user_written_hello_world_runs_batched_through_recognition():
+  """The notebook's cells cannot travel to the GPU box; examples/hello_world_batched.py holds
+  the same GAME written independently (integers as actions, a zero-argument make_game());
+  `set_default_batch` is the only addition.  Same spec as the notebook's own cells recognise to
+  (the CPU test above), same frames as `hello_world.npz`, which make_golden.py made with the
+  notebook's cells on the reference engine."""
   from campx_amd import shapes
-
-  class RollingDrape(things.Drape):
-    _ROLL_AXES = [0, 0, 1, 1]
-    _ROLL_SHIFTS = [-1, 1, -1, 1]
-
-    def update(self, actions, board, layers, backdrop, all_things, the_plot):
-      if actions is None: return
-      if actions == 4: the_plot.terminate_episode()
-      if actions < 4:
-        rolled = np.roll(self.curtain.numpy(), self._ROLL_SHIFTS[actions], self._ROLL_AXES[actions])
-        self.curtain.set_(torch.from_numpy(rolled.copy()))
-        the_plot.add_reward(1)
-
-  class SlidingSprite(things.Sprite):
-    _DX = ([-1, 1, -1, 1], [-1, 1, -1, 1], [1, -1, 1, -1], [1, -1, 1, -1])
-    _DY = ([-1, 1, 1, -1], [1, -1, -1, 1], [1, -1, -1, 1], [-1, 1, 1, -1])
-
-    def __init__(self, corner, position, character, direction_set):
-      super(SlidingSprite, self).__init__(corner, position, character)
-      self._dx = self._DX[direction_set]
-      self._dy = self._DY[direction_set]
-
-    def update(self, actions, board, layers, backdrop, all_things, the_plot):
-      if actions is None or actions > 3: return
-      new_col = (self._position.col + self._dx[actions]) % self.corner.col
-      new_row = (self._position.row + self._dy[actions]) % self.corner.row
-      self._position = self.Position(new_row, new_col)
-
-  def make_game():
-    return ascii_art_to_game(
-        hello_world.HELLO_ART, what_lies_beneath=' ',
-        sprites={'1': Partial(SlidingSprite, 0), '2': Partial(SlidingSprite, 1),
-                 '3': Partial(SlidingSprite, 2), '4': Partial(SlidingSprite, 3)},
-        drapes={'@': RollingDrape}, z_order='12@34')
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import hello_world_batched as ex
 
   gold = _golden('hello_world')
   T, N = gold['actions'].shape
   engine_mod.set_default_batch(N, 'cuda')
   try:
-    game = make_game()
+    game = ex.make_game()
   finally:
     engine_mod.set_default_batch(None)
   board, reward, discount = game.its_showtime()
