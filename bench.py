@@ -245,12 +245,14 @@ def measured_traffic(game, batch, frames, path):
     return None
 
 
-def kernel_names(fused, split):
+def kernel_names(fused, split, B=None, T=None):
   if type(fused).__name__ == 'WideGame':
     return 'wide_update_kernel + render_kernel'
   if split:
-    # (one-mover games at small batches: update pass and render share ONE launch)
-    if getattr(fused, '_flow_scratch', None) is not None:
+    # (one-mover games at small batches: update pass and render share ONE launch - asked of the
+    # library itself, campx_flow_shared: its bounds and knobs, not a copy of them)
+    one = getattr(fused, '_one_launch', None)
+    if one is not None and B is not None and one(T, (B + 15) // 16 * 16):
       return 'pipe_table_kernel<true> (update pass + render in one launch)'
     first = ('update_table_kernel' if fused.n_dyn == 1 else
              'update_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
@@ -455,7 +457,7 @@ def roofline(game_name, B, T, fused, kernel_ms, per_launch):
       'traffic': traffic,
       'traffic_note': 'HBM bytes per launch (WRITE_SIZE + FETCH_SIZE, separate '
                       'rocprofv3 --pmc passes, profiles/' + os.path.basename(TRAFFIC_FILE) + ')',
-      'kernel': kernel_names(fused, split),
+      'kernel': kernel_names(fused, split, B, T),
       'kernel_note': 'kernel_ms = HIP-event time on the launch stream around the timed '
                      'launches / steps: every kernel of a rollout launch plus the gaps '
                      'between launches (pipelined: the update pass of launch i+1 runs on '
@@ -730,8 +732,13 @@ def main(argv=None):
   if args.gpus > 1 and not args.standin:
     # (counted in a child: should torch ever fall back from amdsmi to hipGetDeviceCount, the
     # HIP runtime comes up in that child and not in this launcher process)
-    have = int(subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
-                              stdout=subprocess.PIPE, text=True).stdout.strip().splitlines()[-1] or 0)
+    child = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = child.stdout.strip().splitlines()
+    have = int(lines[-1]) if child.returncode == 0 and lines and lines[-1].strip().isdigit() else 0
+    if child.returncode != 0 or not lines:
+      sys.stderr.write('bench.py: could not count HIP devices (rc {}): {}\n'.format(
+          child.returncode, child.stderr.strip()[-400:]))
     if have < args.gpus:
       sys.stderr.write('bench.py: --gpus {} asked for, but this node shows {} HIP device(s); '
                        'nothing was launched\n'.format(args.gpus, have))

@@ -24,7 +24,7 @@ EXPORTS = ('campx_spec_size', 'campx_flow_scratch_bytes', 'campx_spec_validate',
            'campx_pair_table_bytes', 'campx_pair_table_build', 'campx_pair_table_pack',
            'campx_reset_launch',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
-           'campx_update_render_launch', 'campx_update_render_shared',
+           'campx_update_render_launch', 'campx_update_render_shared', 'campx_flow_shared',
            'campx_shape_spec_size', 'campx_shape_spec_validate',
            'campx_shape_rollout_launch',
            'campx_wide_spec_size', 'campx_wide_spec_validate', 'campx_wide_tables_bytes',
@@ -49,7 +49,18 @@ class CampxOutputs(ctypes.Structure):
               ('trace', ctypes.c_void_p), ('obs_format', ctypes.c_int32),
               ('bad_count', ctypes.c_void_p), ('bad_flag', ctypes.c_void_p),
               ('scalar_pitch', ctypes.c_int64),
-              ('overlap_ctl', ctypes.c_void_p), ('overlap_ctl_bytes', ctypes.c_int64)]
+              ('overlap_ctl', ctypes.c_void_p), ('overlap_ctl_bytes', ctypes.c_int64),
+              ('flow_state', ctypes.c_void_p), ('error_flag', ctypes.c_void_p)]
+
+
+class CampxFlowState(ctypes.Structure):
+  """include/campx_hip.h: what the library remembers about a scratch block of one-launch
+  rollouts, in the caller's (host) memory."""
+  _fields_ = [('tag', ctypes.c_int64), ('B', ctypes.c_int64), ('T', ctypes.c_int64),
+              ('pitch', ctypes.c_int64)]
+
+
+ERR_FLOW_TIMEOUT = 1
 
 
 class CampxError(RuntimeError):
@@ -94,6 +105,8 @@ def _load():
   lib.campx_update_render_launch.restype = i32
   lib.campx_update_render_shared.argtypes = [spec_p, i64, i32]
   lib.campx_update_render_shared.restype = i32
+  lib.campx_flow_shared.argtypes = [spec_p, i64, i32, i64]
+  lib.campx_flow_shared.restype = i32
   lib.campx_shape_spec_size.restype = i32
   lib.campx_shape_spec_size.argtypes = []
   lib.campx_shape_spec_validate.restype = i32

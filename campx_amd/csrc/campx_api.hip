@@ -670,7 +670,9 @@ int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* 
   const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
                          (!knob_no_table() || spec_host->table_only);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (pipe_ok(*spec_host, out, prev, B, T, use_table))
+  // (games of two to four movers share the launch too, over the caller's pair / tuple table)
+  const bool multi_table = spec_host->n_dyn >= 2 && st.pair_table && (!knob_no_table() || spec_host->table_only);
+  if (pipe_ok(*spec_host, out, prev, B, T, use_table || multi_table))
     return launch_pipe(*spec_host, spec_dev, st, actions, out, prev, B, T, reset_first, s);
   const int32_t rc = launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
                                    (int64_t)T * row_pitch(out, B), s);
@@ -687,7 +689,30 @@ int32_t campx_update_render_shared(const CampxSpec* spec_host, int64_t B, int32_
   prev.trace = reinterpret_cast<uint8_t*>(uintptr_t{4096});
   prev.obs_t_stride = B * spec_host->n_layers * spec_host->rows * spec_host->cols;
   prev.obs_format = CAMPX_OBS_INT8;
-  return pipe_ok(*spec_host, prev, prev, B, T, use_table) ? 1 : 0;
+  // (two to four movers: with their pair / tuple table in CampxState.pair_table, which this
+  // query cannot see - a caller without one gets two launches whatever this says)
+  const bool multi_table = spec_host->n_dyn >= 2 && (!knob_no_table() || spec_host->table_only);
+  return pipe_ok(*spec_host, prev, prev, B, T, use_table || multi_table) ? 1 : 0;
+}
+
+int32_t campx_flow_shared(const CampxSpec* spec_host, int64_t B, int32_t T, int64_t scalar_pitch) {
+  if (!spec_host || B <= 0 || T <= 0 || campx_spec_validate(spec_host) != CAMPX_OK) return 0;
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
+                         (!knob_no_table() || spec_host->table_only);
+  // a call as the header describes it: every output this path looks at present and aligned
+  static CampxFlowState some_state;        // (never read or written: flow_ok only asks whether there is one)
+  static int32_t some_flag;
+  CampxOutputs out{};
+  out.obs = reinterpret_cast<int8_t*>(uintptr_t{4096});
+  out.trace = reinterpret_cast<uint8_t*>(uintptr_t{4096});
+  out.obs_t_stride = B * spec_host->n_layers * spec_host->rows * spec_host->cols;
+  out.obs_format = CAMPX_OBS_INT8;
+  out.scalar_pitch = scalar_pitch;
+  out.overlap_ctl = reinterpret_cast<uint32_t*>(uintptr_t{4096});
+  out.overlap_ctl_bytes = flow_scratch_bytes(B, T);
+  out.flow_state = &some_state;
+  out.error_flag = &some_flag;
+  return flow_ok(*spec_host, out, B, T, use_table, nullptr, /*ask_stream=*/false) ? 1 : 0;
 }
 
 int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out) {

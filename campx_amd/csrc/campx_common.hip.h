@@ -559,7 +559,7 @@ int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
 // k_update.hip: update pass and render of ONE rollout in one launch (the render role waits for
 // the update role's published progress)
 bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table,
-             hipStream_t stream);
+             hipStream_t stream, bool ask_stream = true);
 int64_t flow_scratch_bytes(int64_t B, int32_t T);
 int32_t launch_flow(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                     const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,

@@ -212,7 +212,7 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
              const OptTensor& board, const OptTensor& reward, const OptTensor& discount,
              const OptTensor& step_done, const OptTensor& perf, const OptTensor& trace,
              const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first,
-             const OptTensor& scratch) {
+             const OptTensor& scratch, const OptTensor& scratch_state, const OptTensor& error_flag) {
   const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
   TORCH_CHECK(actions.dim() == 2, "campx::rollout: actions must be int8 [T, B]");
   const int64_t T = actions.size(0);
@@ -259,7 +259,18 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
                 "campx::rollout: scratch must be a contiguous int32 tensor on ", g.dev);
     out.overlap_ctl = reinterpret_cast<uint32_t*>(scratch->data_ptr());
     out.overlap_ctl_bytes = scratch->numel() * 4;
+    // the block's CampxFlowState lives with its owner, in host memory: four int64 (zeroed when
+    // the block was allocated); without it, or without an error word, the library runs two launches
+    if (scratch_state.has_value()) {
+      TORCH_CHECK(scratch_state->device().is_cpu() && scratch_state->scalar_type() == at::kLong &&
+                      scratch_state->is_contiguous() &&
+                      scratch_state->numel() * 8 == (int64_t)sizeof(CampxFlowState),
+                  "campx::rollout: scratch_state must be a contiguous CPU int64 tensor of ",
+                  sizeof(CampxFlowState) / 8, " elements");
+      out.flow_state = reinterpret_cast<CampxFlowState*>(scratch_state->data_ptr());
+    }
   }
+  out.error_flag = flag_ptr(error_flag, g.dev);
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
   check_ok(campx_rollout_launch(g.spec_host, g.spec_dev, g.state, reinterpret_cast<const int8_t*>(actions.data_ptr()),
                                 out, g.B, (int32_t)T, reset_first ? 1 : 0,
@@ -628,7 +639,7 @@ void reset_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&
 void rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
                   const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                   const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
-                  const OptTensor&, bool, const OptTensor&) {}
+                  const OptTensor&, bool, const OptTensor&, const OptTensor&, const OptTensor&) {}
 void step_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
                const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&) {}
@@ -688,7 +699,8 @@ TORCH_LIBRARY(campx, m) {
       "rollout(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
       "Tensor? pair_table, Tensor actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "
       "Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, Tensor(j!)? trace, "
-      "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first, Tensor(m!)? scratch=None) -> ()");
+      "Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first, Tensor(m!)? scratch=None, "
+      "Tensor(n!)? scratch_state=None, Tensor(o!)? error_flag=None) -> ()");
   m.def(
       "update(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, Tensor(c!)? ret, "
       "Tensor? pair_table, Tensor actions, Tensor(d!)? reward, Tensor(e!)? discount, "

@@ -4,7 +4,6 @@
 #include "campx_common.hip.h"
 
 #include <mutex>
-#include <unordered_map>
 
 #include <stdio.h>
 #include <type_traits>
@@ -61,6 +60,13 @@ __device__ __forceinline__ void store16_update(void* p, u32x4 v) {
 #else
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) CAMPX_UPD_CLOBBERS);
 #endif
+}
+
+// The tagged copy of the trace (one-launch rollouts) is read by render waves of the SAME launch,
+// on other XCDs, as it is written: always write-through, whatever CAMPX_UPD_FLAVOR an A/B build
+// gives the other streams (a plain store would sit in the writer's L2 until the kernel ends).
+__device__ __forceinline__ void store16_tagged(void* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Number of bytes >= 5 (as unsigned) among the 16 of v: the action ids outside 0..4.
@@ -488,8 +494,8 @@ __device__ __forceinline__ void update_table_body(
                     e[2 * k] = (tr[k] & 0xffu) | ((tr[k] & 0xff00u) << 8) | tt;
                     e[2 * k + 1] = ((tr[k] >> 16) & 0xffu) | ((tr[k] >> 8) & 0xff0000u) | tt;
                   }
-                  store16_update(tagged + at, u32x4{e[0], e[1], e[2], e[3]});
-                  store16_update(tagged + at + 8, u32x4{e[4], e[5], e[6], e[7]});
+                  store16_tagged(tagged + at, u32x4{e[0], e[1], e[2], e[3]});
+                  store16_tagged(tagged + at + 8, u32x4{e[4], e[5], e[6], e[7]});
                 }
                 if (out.done) {
                   const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
@@ -576,37 +582,43 @@ constexpr int kPairLdsEntries = CAMPX_PAIR_LDS_ENTRIES;  // 32 KiB of LDS for th
 #define CAMPX_PAIR_GROUP 16   // frames per ring slot group (A/B builds)
 #endif
 
+// LDS of an update workgroup of the two-mover kernel without the entries themselves (which are
+// dynamic shared memory when they are staged at all): a struct, so that pipe_multi_kernel - this
+// body as one role of a launch - can lay its other role's windows over the same bytes.
+template <int kProd, int kG>
+struct UpdatePairLds {
+  float reward_list[256];
+  float discounts[16];
+  __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * kProd * kWave];
+  __attribute__((aligned(16))) uint32_t ring[2][kG][kProd * kWave];
+};
+
+// The body of update_pair_kernel.  `wg`: which kProd * 64 environments this workgroup owns.
 template <bool kLdsEntries, int kProd, int kCons>
-__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
-                             update_min_waves(kProd, kCons)) void update_pair_kernel(
-    PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
-    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
-    int32_t reset_first, int64_t trace_plane, FrameCodec fc) {
+__device__ __forceinline__ void update_pair_body(
+    UpdatePairLds<kProd, CAMPX_PAIR_GROUP>& L, uint32_t* lds_entries, uint32_t wg, const PairParams& pp,
+    const CampxState& st, const int8_t* __restrict__ actions, const CampxOutputs& out, int64_t B, int32_t T,
+    int32_t reset_first, int64_t trace_plane, const FrameCodec& fc) {
   constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kLdsEntries: n_entries
-  __shared__ float reward_list[256];
-  __shared__ float discounts[16];
-  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
-  __shared__ __attribute__((aligned(16))) uint32_t ring[2][kG][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave >= kProd + kCons;
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;  // loaders: 0 .. 64*kLoad-1
   const int W = pp.cols, HW = pp.rows * pp.cols;
-  const int64_t env0 = (int64_t)tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD) * E;
+  const int64_t env0 = (int64_t)wg * E;
 
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint32_t* g_entries = reinterpret_cast<const uint32_t*>(g_rewards + 256);
   const int n_entries = HW * HW * CAMPX_N_ACTIONS;
   if (kLdsEntries)
     for (int i = threadIdx.x; i < n_entries; i += kThreads) lds_entries[i] = g_entries[i];
-  for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
-  if (threadIdx.x < 16) discounts[threadIdx.x] = fc.discounts[threadIdx.x];
+  for (int i = threadIdx.x; i < 256; i += kThreads) L.reward_list[i] = g_rewards[i];
+  if (threadIdx.x < 16) L.discounts[threadIdx.x] = fc.discounts[threadIdx.x];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
     ld.issue(actions, B, T, 0, env0, llane);
-    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
+    bad += ld.land(L.staged[0], actions, B, T, 0, env0, llane);
   }
 
   const int le = wave * kWave + lane;
@@ -635,7 +647,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     for (int g = 0; g <= n_groups; ++g) {
         if (g < n_groups) {
           const int t0 = g * kG;
-          const int8_t* chunk = staged[(t0 / kChunk) & 1];
+          const int8_t* chunk = L.staged[(t0 / kChunk) & 1];
           const int n = (T - t0 < kG) ? T - t0 : kG;
           uint32_t act[kG];
   #pragma unroll
@@ -653,8 +665,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
                 const uint32_t e = kLdsEntries ? lds_entries[idx] : g_entries[idx];   // the chain
                 c0 = e & 0x7fu;
                 c1 = (e >> 7) & 0x7fu;
-                ring[g & 1][j][le] = e;
-                ret = (over ? 0.0f : ret) + real_reward(reward_list[(e >> 19) & 0xffu]);
+                L.ring[g & 1][j][le] = e;
+                ret = (over ? 0.0f : ret) + real_reward(L.reward_list[(e >> 19) & 0xffu]);
                 over = (int)((e >> 16) & 1u);
               }
             }
@@ -684,14 +696,14 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             const int j = item / QA, q = item % QA;
             const int64_t e0 = env0 + 4 * q;
             if (j < n && e0 < B) {
-              const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][4 * q]);
+              const u32x4 e4 = *reinterpret_cast<const u32x4*>(&L.ring[rb][j][4 * q]);
               const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
               uint32_t rw[4], dc[4];
   #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                rw[i] = __float_as_uint(reward_list[(e[i] >> 19) & 0xffu]);
+                rw[i] = __float_as_uint(L.reward_list[(e[i] >> 19) & 0xffu]);
                 dc[i] = ((e[i] >> 16) & 1u) ? 0u : 0x3f800000u;
-                if (fc.has_dcodes) dc[i] = discount_bits(discounts, dcode_pair(e[i]), (e[i] >> 16) & 1u);
+                if (fc.has_dcodes) dc[i] = discount_bits(L.discounts, dcode_pair(e[i]), (e[i] >> 16) & 1u);
               }
               const int64_t at = (int64_t)(t0 + j) * P + e0;
               if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
@@ -721,7 +733,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               uint32_t ta[4], tb[4], dn[4], pf[4];
   #pragma unroll
               for (int k = 0; k < 4; ++k) {
-                const u32x4 e4 = *reinterpret_cast<const u32x4*>(&ring[rb][j][16 * q + 4 * k]);
+                const u32x4 e4 = *reinterpret_cast<const u32x4*>(&L.ring[rb][j][16 * q + 4 * k]);
                 const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
                 uint32_t a[4], b[4], d[4], p[4];
   #pragma unroll
@@ -771,7 +783,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
         if (t_next < T) {
           if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
           if (phase == kGroupsPerChunk - 1)
-            bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+            bad += ld.land(L.staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
         }
       
       __syncthreads();
@@ -789,6 +801,18 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
   report_bad_actions(out, bad);
 }
 
+template <bool kLdsEntries, int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             update_min_waves(kProd, kCons)) void update_pair_kernel(
+    PairParams pp, const CampxSpec* __restrict__ spec, CampxState st,
+    const int8_t* __restrict__ actions, CampxOutputs out, int64_t B, int32_t T,
+    int32_t reset_first, int64_t trace_plane, FrameCodec fc) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];  // kLdsEntries: n_entries
+  __shared__ UpdatePairLds<kProd, CAMPX_PAIR_GROUP> L;
+  update_pair_body<kLdsEntries, kProd, kCons>(L, lds_entries, tile_of_block(blockIdx.x, gridDim.x, CAMPX_UPD_XCD),
+                                              pp, st, actions, out, B, T, reset_first, trace_plane, fc);
+}
+
 // ---------------------------------------------------------------------------
 // Three- and four-mover games: the same producer / consumer / loader layout over a
 // direct-indexed (cell, cell, cell[, cell], action) table in GLOBAL memory
@@ -804,32 +828,37 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
 #define CAMPX_TUPLE_MINWAVES 4
 #endif
 
+template <int kProd>
+struct UpdateTupleLds {
+  float reward_list[256];
+  float discounts[16];
+  __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * kProd * kWave];
+  __attribute__((aligned(16))) uint64_t ring[2][kTupleGroup][kProd * kWave];
+};
+
+// The body of update_tuple_kernel.  `wg`: which kProd * 64 environments this workgroup owns.
 template <int K, int kProd, int kCons>
-__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
-                             CAMPX_TUPLE_MINWAVES) void update_tuple_kernel(
-    TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B,
-    int32_t T, int32_t reset_first, int64_t trace_plane, FrameCodec fc) {
+__device__ __forceinline__ void update_tuple_body(
+    UpdateTupleLds<kProd>& L, const uint32_t wg, const TupleParams tp, const CampxState st,
+    const int8_t* __restrict__ actions, const CampxOutputs out, const int64_t B, const int32_t T,
+    const int32_t reset_first, const int64_t trace_plane, const FrameCodec fc) {
   constexpr int kLoad = update_loaders(kProd), kG = kTupleGroup;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
-  __shared__ float reward_list[256];
-  __shared__ float discounts[16];
-  __shared__ __attribute__((aligned(16))) int8_t staged[2][(kChunk / 2) * E];
-  __shared__ __attribute__((aligned(16))) uint64_t ring[2][kG][E];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const bool producer = wave < kProd, loader = wave >= kProd + kCons;
   const int llane = (int)threadIdx.x - (kProd + kCons) * kWave;
   const int W = tp.cols;
   const uint32_t HW = (uint32_t)(tp.rows * tp.cols);
-  const int64_t env0 = (int64_t)blockIdx.x * E;
+  const int64_t env0 = (int64_t)wg * E;
   const float* g_rewards = static_cast<const float*>(st.pair_table);
   const uint64_t* g_entries = reinterpret_cast<const uint64_t*>(g_rewards + 256);
-  for (int i = threadIdx.x; i < 256; i += kThreads) reward_list[i] = g_rewards[i];
-  if (threadIdx.x < 16) discounts[threadIdx.x] = fc.discounts[threadIdx.x];
+  for (int i = threadIdx.x; i < 256; i += kThreads) L.reward_list[i] = g_rewards[i];
+  if (threadIdx.x < 16) L.discounts[threadIdx.x] = fc.discounts[threadIdx.x];
   ActionLoader<E, kLoad> ld;
   int bad = 0;
   if (loader && T > 0) {
     ld.issue(actions, B, T, 0, env0, llane);
-    bad += ld.land(staged[0], actions, B, T, 0, env0, llane);
+    bad += ld.land(L.staged[0], actions, B, T, 0, env0, llane);
   }
   const int le = wave * kWave + lane;
   const int64_t env = env0 + le;
@@ -860,7 +889,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     for (int g = 0; g <= n_groups; ++g) {
       if (g < n_groups) {
         const int t0 = g * kG;
-        const int8_t* chunk = staged[(t0 / kChunk) & 1];
+        const int8_t* chunk = L.staged[(t0 / kChunk) & 1];
         const int n = (T - t0 < kG) ? T - t0 : kG;
         uint32_t act[kG];
 #pragma unroll
@@ -873,8 +902,8 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               cells = over ? init : cells;  // rebuilt from the art before its next action
               const uint64_t e = g_entries[tuple_index<K>(cells, HW) + act[j]];  // the chain
               cells = (uint32_t)e & 0x0fffffffu;
-              ring[g & 1][j][le] = e;
-              ret = (over ? 0.0f : ret) + real_reward(reward_list[(uint32_t)(e >> 35) & 0xffu]);
+              L.ring[g & 1][j][le] = e;
+              ret = (over ? 0.0f : ret) + real_reward(L.reward_list[(uint32_t)(e >> 35) & 0xffu]);
               over = (int)((e >> 32) & 1u);
             }
           }
@@ -904,10 +933,10 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
             uint32_t rw[4], dc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const uint32_t hi = (uint32_t)(ring[rb][j][4 * q + i] >> 32);
-              rw[i] = __float_as_uint(reward_list[(hi >> 3) & 0xffu]);
+              const uint32_t hi = (uint32_t)(L.ring[rb][j][4 * q + i] >> 32);
+              rw[i] = __float_as_uint(L.reward_list[(hi >> 3) & 0xffu]);
               dc[i] = (hi & 1u) ? 0u : 0x3f800000u;
-              if (fc.has_dcodes) dc[i] = discount_bits(discounts, dcode_tuple(hi), hi & 1u);
+              if (fc.has_dcodes) dc[i] = discount_bits(L.discounts, dcode_tuple(hi), hi & 1u);
             }
             const int64_t at = (int64_t)(t0 + j) * P + e0;
             if (e0 + 4 <= Bv) {   // (dword-aligned; 16-byte aligned when the row pitch is a multiple of 4)
@@ -941,7 +970,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
               uint32_t lo[4], hi[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                const uint64_t e = ring[rb][j][16 * q + 4 * w + i];
+                const uint64_t e = L.ring[rb][j][16 * q + 4 * w + i];
                 lo[i] = (uint32_t)e;
                 hi[i] = (uint32_t)(e >> 32);
               }
@@ -993,7 +1022,7 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
       if (t_next < T) {
         if (phase == 0) ld.issue(actions, B, T, t_next, env0, llane);
         if (phase == kGroupsPerChunk - 1)
-          bad += ld.land(staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
+          bad += ld.land(L.staged[(c + 1) & 1], actions, B, T, t_next, env0, llane);
       }
       __syncthreads();
     }
@@ -1016,6 +1045,15 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
     if (st.ret) st.ret[env_again] = ret;
   }
   report_bad_actions(out, bad);
+}
+
+template <int K, int kProd, int kCons>
+__global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
+                             CAMPX_TUPLE_MINWAVES) void update_tuple_kernel(
+    TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out, int64_t B,
+    int32_t T, int32_t reset_first, int64_t trace_plane, FrameCodec fc) {
+  __shared__ UpdateTupleLds<kProd> L;
+  update_tuple_body<K, kProd, kCons>(L, blockIdx.x, tp, st, actions, out, B, T, reset_first, trace_plane, fc);
 }
 
 constexpr int kBigEnvs = 8 * kWave;   // environments of a "big" update workgroup
@@ -1189,6 +1227,11 @@ struct PipeRender {
   uint32_t U;                  // update workgroups
   uint16_t* tagged;            // one-launch rollouts: the trace's tagged copy [T, pitch], and
   uint32_t tag;                // this launch's tag (1..255)
+  int32_t dyn_offs[CAMPX_MAX_DYN];   // games of two to four movers: each one's layer offset in a row,
+  int64_t plane;               // and the rows from one mover's plane of the trace to the next's
+  uint32_t max_naps;           // looks at stale entries before a render wave gives up - loudly
+  uint32_t debug_delay;        // tests only: s_sleep rounds in front of the update role
+  int32_t* error_flag;         // CampxOutputs.error_flag
 };
 
 // (Round 4's first attempt at one rollout in one launch - overlap_table_kernel: persistent 14-wave
@@ -1232,6 +1275,12 @@ constexpr uint32_t kPipeSpan = 1024u * kPipeWin;
 #define CAMPX_PIPE_GROUP 16
 #endif
 constexpr uint32_t kFlowMaxNaps = 1u << 20;     // looks at stale entries before a render wave gives up (seconds)
+// A render wave that gives up says so: CAMPX_ERR_FLOW_TIMEOUT in the caller's error word (system
+// scope: the word may be host memory), once per wave; the frames it then writes are wrong.
+__device__ __forceinline__ void flow_gave_up(int32_t* error_flag) {
+  if (error_flag && (threadIdx.x & 63u) == 0u)
+    __hip_atomic_fetch_or(error_flag, CAMPX_ERR_FLOW_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 constexpr int kPipeProd = CAMPX_PIPE_PROD, kPipeCons = CAMPX_PIPE_CONS, kPipeGroup = CAMPX_PIPE_GROUP;
 constexpr int kPipeWaves = kPipeProd + kPipeCons + update_loaders(kPipeProd);
 constexpr int kPipeEnvs = kPipeProd * kWave;
@@ -1250,6 +1299,8 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
   // its SIMD with streaming waves walks its chain more slowly, lives longer, and more of them
   // pile up; profiles/r04_deferred_ab.txt section 5.)
   if (blockIdx.x < rr.U) {
+    if (kFlow && rr.debug_delay)     // (tests: hold the update role back so that render waves time out)
+      for (uint32_t i = 0; i < rr.debug_delay; ++i) __builtin_amdgcn_s_sleep(127);
     update_table_body<kPipeProd, kPipeCons, kPipeGroup, kFlow>(L, blockIdx.x, mp, spec, st, actions, out, B, T,
                                                          reset_first, fc, rr.tagged, rr.tag);
     return;
@@ -1326,9 +1377,13 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
       if (naps < 4u) __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP);
       else __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
       // (seconds of waiting: the entries will never carry this launch's tag - two launches
-      // sharing one scratch block at the same time, which the header forbids; wrong frames
-      // are a better outcome than a launch that never ends)
-      if (++naps > kFlowMaxNaps) break;
+      // sharing one scratch block at the same time, which the header forbids.  A launch that
+      // never ends helps nobody, so the wave goes on with what it has - and raises the
+      // caller's error word: these frames are wrong and the host is told)
+      if (++naps > rr.max_naps) {
+        flow_gave_up(rr.error_flag);
+        break;
+      }
       ent[0] = look(row0);
       ent[1] = look(row1);
     }
@@ -1353,14 +1408,130 @@ __global__ __launch_bounds__(kPipeWaves * kWave) void pipe_table_kernel(
     if (kFlow) {   // (each lane waits for its own entry: rows of under 32 bytes, boards of a few cells)
       const uint16_t* at = rr.tagged + (int64_t)t * rr.pitch + first_row + (sidx >> 1);
       uint32_t e = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (uint32_t naps = 0; (e >> 8) != rr.tag && naps < kFlowMaxNaps; ++naps) {
+      for (uint32_t naps = 0; (e >> 8) != rr.tag && naps < rr.max_naps; ++naps) {
         __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
         e = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if ((e >> 8) != rr.tag && rr.error_flag)     // (per lane here: tiny rows only)
+        __hip_atomic_fetch_or(rr.error_flag, CAMPX_ERR_FLOW_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       apply(sidx, e & 0xffu);
     } else {
       apply(sidx, (uint32_t)frame_trace[first_row + (sidx >> 1)]);
     }
+  // ---- out: aligned, contiguous KiB stores
+  int8_t* frame = rr.dst + (int64_t)t * rr.slab_bytes;
+#pragma unroll
+  for (int j = 0; j < kPipeWin; ++j) {
+    const uint32_t off = woff0 + (uint32_t)j * 1024u + lane * 16u;
+    if (off < rr.slab_bytes)
+      __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(win0 + j * 1024 + lane * 16u),
+                                  reinterpret_cast<u32x4*>(frame + off));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The shared launch for games of two to four movers (round 5): the same shape - update workgroups
+// of 64 environments first (one producer wave walking the pair / tuple table, two consumers, one
+// loader), every later workgroup four one-shot render waves of one 2 KiB window each - with the
+// render role patching up to 2K bytes per row from K planes of the PREVIOUS rollout's trace
+// (render_kernel's patch rule: a mover that shows sets its own layer's byte and clears the byte
+// of the scenery it stands in front of).  Deferred rollouts only: the two roles share nothing.
+// kLdsEntries (two movers): the pair table's entries staged in dynamic LDS - the chain is then an
+// LDS read per frame, but EVERY workgroup of the launch, the render ones too, is charged for the
+// bytes; without, the chain goes through L1 / L2 and the launch keeps 5 workgroups per CU.
+template <int K>
+using PipeMultiLds = std::conditional_t<K == 2, UpdatePairLds<kPipeProd, CAMPX_PAIR_GROUP>, UpdateTupleLds<kPipeProd>>;
+
+#ifndef CAMPX_PIPE_MULTI_MINWAVES
+#define CAMPX_PIPE_MULTI_MINWAVES 4     // (128 VGPRs: the four-mover update role would take 138 and a wave per SIMD)
+#endif
+template <int K, bool kLdsEntries>
+__global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void pipe_multi_kernel(
+    PairParams pp, TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out,
+    int64_t B, int32_t T, int32_t reset_first, int64_t trace_plane, FrameCodec fc, PipeRender rr) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_entries[];
+  __shared__ PipeMultiLds<K> L;
+  static_assert(sizeof(L) >= kPipeWaves * (kPipeSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
+  static_assert(K >= 2 && K <= CAMPX_MAX_DYN, "two to four movers");
+  if (blockIdx.x < rr.U) {
+    if constexpr (K == 2)
+      update_pair_body<kLdsEntries, kPipeProd, kPipeCons>(L, lds_entries, blockIdx.x, pp, st, actions, out, B, T,
+                                                          reset_first, trace_plane, fc);
+    else
+      update_tuple_body<K, kPipeProd, kPipeCons>(L, blockIdx.x, tp, st, actions, out, B, T, reset_first,
+                                                 trace_plane, fc);
+    return;
+  }
+  constexpr uint32_t P = 2u * K;                       // patches per row: (mover) x (set | clear)
+  const uint32_t item = blockIdx.x - rr.U;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t t = item / rr.per_frame;
+  uint32_t wx = item - t * rr.per_frame;
+  wx = (wx & 7u) * (rr.per_frame >> 3) + (wx >> 3);    // per_frame is a multiple of 8: one XCD, one eighth
+  const uint32_t shift = (rr.shift_base + t * rr.shift_slab) & (kPipeSpan - 1u);
+  const uint32_t widx = wx * (uint32_t)kPipeWaves + wave;
+  if ((uint64_t)widx * kPipeSpan >= (uint64_t)rr.slab_bytes + shift) return;
+  int8_t* win0 = reinterpret_cast<int8_t*>(&L) + wave * (kPipeSpan + 2 * CAMPX_MAX_CELLS);
+  uint16_t* scen_off = reinterpret_cast<uint16_t*>(win0 + kPipeSpan);
+  const uint32_t R = rr.R;
+  const uint32_t rot_pitch = ((R + 15u) & ~15u) + 16u;
+  const uint32_t woff0 = widx * kPipeSpan - shift;
+  const uint32_t wlo = widx * kPipeSpan < shift ? 0u : woff0;
+  const uint32_t whi = __umulhi(rr.m, wlo);
+  const uint32_t first_row = (((wlo - whi) >> rr.sh1) + whi) >> rr.sh2;
+  const uint32_t wend = (woff0 + kPipeSpan - 1u < rr.slab_bytes) ? woff0 + kPipeSpan - 1u : rr.slab_bytes - 1u;
+  const uint32_t ehi = __umulhi(rr.m, wend);
+  const uint32_t last_row = (((wend - ehi) >> rr.sh1) + ehi) >> rr.sh2;
+  const uint32_t slots = (last_row - first_row + 1u) * P;
+  const uint8_t* frame_trace = rr.trace + (int64_t)t * rr.pitch;
+  // ---- loads first: two trace bytes per lane, the window's scenery chunks, two cells' scenery layer
+  auto entry_of = [&](uint32_t sidx) {
+    const uint32_t r = sidx / P, d = (sidx - r * P) >> 1;
+    uint32_t row = first_row + r;
+    row = row <= last_row ? row : last_row;              // clamp: slot unused, entry ignored
+    return (uint32_t)frame_trace[(int64_t)d * rr.plane + row];
+  };
+  uint32_t ent[2];
+  ent[0] = entry_of(lane);
+  ent[1] = slots > kWave ? entry_of(lane + kWave) : 0u;
+  u32x4 scen[kPipeWin];
+#pragma unroll
+  for (int j = 0; j < kPipeWin; ++j) {
+    const uint32_t off = woff0 + (uint32_t)j * 1024u + lane * 16u;
+    const uint32_t hi = __umulhi(rr.m, off);
+    const uint32_t row = (((off - hi) >> rr.sh1) + hi) >> rr.sh2;
+    const uint32_t k = off - row * R;
+    scen[j] = *reinterpret_cast<const u32x4*>(rr.rot + (k & 15u) * rot_pitch + (k & ~15u));
+  }
+  const uint32_t top2 = *reinterpret_cast<const uint16_t*>(rr.top_layer + 2u * lane);
+#pragma unroll
+  for (int j = 0; j < kPipeWin; ++j)
+    *reinterpret_cast<u32x4*>(win0 + j * 1024 + lane * 16u) = scen[j];
+  {
+    const uint32_t c = 2u * lane;
+    const uint32_t lo = (top2 & 0xffu) * (uint32_t)rr.cells + c;
+    const uint32_t hi2 = (top2 >> 8) * (uint32_t)rr.cells + c + 1u;
+    *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
+  }
+  // ---- patches (a select chain over the kernel arguments, as in render_kernel)
+  auto off_of = [&](uint32_t d) {
+    int v = __builtin_amdgcn_readfirstlane(rr.dyn_offs[0]);
+#pragma unroll
+    for (int k = 1; k < K; ++k) v = (d == (uint32_t)k) ? __builtin_amdgcn_readfirstlane(rr.dyn_offs[k]) : v;
+    return (uint32_t)v;
+  };
+  auto apply = [&](uint32_t sidx, uint32_t e) {
+    const uint32_t r = sidx / P, p = sidx - r * P;
+    const uint32_t cell = e & 0x7fu;
+    const uint32_t byte = (p & 1u) ? off_of(p >> 1) + cell : (uint32_t)scen_off[cell];
+    const uint32_t at = (first_row + r) * R + byte - woff0;
+    if (sidx < slots && (e >> 7) && at < kPipeSpan) win0[at] = (int8_t)(p & 1u);
+  };
+  apply(lane, ent[0]);
+  apply(lane + kWave, ent[1]);
+  for (uint32_t sidx = lane + 2u * kWave; sidx < slots; sidx += kWave)     // short rows only
+    apply(sidx, entry_of(sidx));
   // ---- out: aligned, contiguous KiB stores
   int8_t* frame = rr.dst + (int64_t)t * rr.slab_bytes;
 #pragma unroll
@@ -1377,7 +1548,12 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
              int32_t T, bool use_table) {
   static const bool off = [] { const char* v = getenv("CAMPX_NO_PIPE"); return v && v[0] == '1'; }();
   const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
-  if (off || !use_table || s.n_dyn != 1 || !prev.trace || !prev.obs || prev.board) return false;
+  // (`use_table`: the game's table is there - the one-mover table in the spec, or, for two to
+  // four movers, the caller's pair / tuple table; CAMPX_NO_PIPE_MULTI=1: one-mover games only)
+  static const bool no_multi = [] { const char* v = getenv("CAMPX_NO_PIPE_MULTI"); return v && v[0] == '1'; }();
+  if (off || !use_table || s.n_dyn < 1 || s.n_dyn > CAMPX_MAX_DYN || (no_multi && s.n_dyn != 1) ||
+      !prev.trace || !prev.obs || prev.board)
+    return false;
   if (prev.obs_format != CAMPX_OBS_INT8 || prev.obs_t_stride != B * R) return false;
   if ((B * R) % 16 != 0 || B * R >= (int64_t)1 << 31 || T > 65535) return false;
   if (reinterpret_cast<uintptr_t>(prev.obs) & 15) return false;
@@ -1399,6 +1575,20 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
     return (int64_t)(v && *v ? atoll(v) : 2000000000ll);
   }();
   if (B > max_b || B * R * T > max_bytes) return false;
+  if (s.n_dyn >= 2) {
+    // Two to four movers (pipe_multi_kernel; sokoban levels 0 / 1 / 2, T = 100, of HBM peak, two
+    // launches -> one, profiles/r05_multimover_deferred_ab.txt): B = 4 096 0.21 -> 0.27 / 0.25 ->
+    // 0.37 / 0.29 -> 0.39, 8 192 0.41 -> 0.49 / 0.41 -> 0.58 / 0.43 -> 0.56, 16 384 0.61 -> 0.67 /
+    // 0.58 -> 0.61 / 0.61 -> 0.55, 32 768 0.73 -> 0.67 / 0.72 -> 0.64 / 0.74 -> 0.60: the update
+    // role's registers (99 / 122 / 128 VGPRs) leave the render role 16 waves per CU, which hiding
+    // the update pass repays only while that pass is a large part of the rollout.
+    static const int64_t forced = [] {
+      const char* v = getenv("CAMPX_PIPE_MULTI_MAX_B");
+      return (int64_t)(v && *v ? atoll(v) : -1);
+    }();
+    const int64_t multi_max = forced >= 0 ? forced : (s.n_dyn == 4 ? 8192 : 16384);
+    if (B > multi_max) return false;
+  }
   (void)out;
   return true;
 }
@@ -1410,22 +1600,20 @@ int64_t flow_scratch_bytes(int64_t B, int32_t T) {
   return 16 + 2 * (int64_t)T * pitch;
 }
 
-// A launch's tag: 1..255, counting up per scratch block (kept here, on the host).  Every launch
-// rewrites every entry of its T frames, so at its start they all carry the previous launch's tag
-// - unless the last launch on this block had another T or B, or the block is new to this
-// process: then it is zeroed first (stream-ordered; tag 0 is never used).
-static uint32_t next_flow_tag(void* block, int64_t bytes, int64_t B, int32_t T, hipStream_t stream) {
-  struct Last { uint32_t tag; int64_t B; int32_t T; };
-  static std::mutex lock;
-  static std::unordered_map<const void*, Last> blocks;
-  std::lock_guard<std::mutex> hold(lock);
-  Last& l = blocks[block];
-  if (l.tag == 0 || l.B != B || l.T != T) {
-    (void)hipMemsetAsync(block, 0, (size_t)bytes, stream);
-    l = Last{0, B, T};
+// A launch's tag: 1..255, counting up per scratch block - in the CALLER's CampxFlowState (the
+// library keeps nothing between calls).  Every launch rewrites every entry of its T frames, so at
+// its start they all carry the previous launch's tag - unless the last launch on this block had
+// another T, B or row pitch (entries of the pad columns or of frames past T would keep an old tag,
+// which the 255-tag wrap would make current again), or the state is fresh: then the whole block is
+// zeroed first (stream-ordered; tag 0 is never used).
+static uint32_t next_flow_tag(CampxFlowState& l, void* block, int64_t block_bytes, int64_t B, int32_t T,
+                              int64_t pitch, hipStream_t stream) {
+  if (l.tag < 1 || l.tag > 255 || l.B != B || l.T != T || l.pitch != pitch) {
+    (void)hipMemsetAsync(block, 0, (size_t)block_bytes, stream);
+    l = CampxFlowState{0, B, T, pitch};
   }
-  l.tag = l.tag % 255u + 1u;
-  return l.tag;
+  l.tag = l.tag % 255 + 1;
+  return (uint32_t)l.tag;
 }
 
 static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
@@ -1455,6 +1643,8 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
   rr.trace = prev.trace;
   rr.dst = prev.obs;
   rr.T = T;
+  for (int d = 0; d < s.n_dyn && d < CAMPX_MAX_DYN; ++d) rr.dyn_offs[d] = s.dyn_layer[d] * HW;
+  rr.plane = (int64_t)T * rr.pitch;
   const uint64_t reach = (uint64_t)rr.slab_bytes + ((rr.shift_base | rr.shift_slab) ? kPipeSpan - 1u : 0u);
   const uint64_t block_span = (uint64_t)kPipeSpan * kPipeWaves;
   rr.per_frame = (uint32_t)(((reach + block_span - 1) / block_span + 7) & ~7ull);
@@ -1465,9 +1655,41 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
   // (84 VGPRs: 20 waves per CU.  Squeezed into 80 or 72 registers - 24 / 28 waves, the update
   // body spilling - the launch was slower from 32 768 environments up and at 4 096, level at
   // 16 384: profiles/r04_deferred_ab.txt)
-  if (flow) {
+  if (s.n_dyn >= 2) {
+    // two to four movers (deferred rollouts only): pipe_multi_kernel over the caller's pair / tuple table
+    if (flow || !st.pair_table) return CAMPX_EINVAL;
+    const PairParams pp = make_pair_params(s);
+    const TupleParams tp = make_tuple_params(s);
+    const int64_t plane = (int64_t)T * row_pitch(out, B);
+    const int n_entries = HW * HW * CAMPX_N_ACTIONS;
+    // (the pair table's entries staged in LDS when they fit - charged to every workgroup of the
+    // launch, the render ones too, and still the faster form: sokoban B = 4 096 / 8 192 / 16 384
+    // 48 / 50 / 66 us through L1 / L2, 37 / 41 / 60 from LDS; CAMPX_PIPE_PAIR_LDS=0: never)
+    static const bool want_lds = [] { const char* v = getenv("CAMPX_PIPE_PAIR_LDS"); return !(v && v[0] == '0'); }();
+    const bool in_lds = s.n_dyn == 2 && want_lds && n_entries <= kPairLdsEntries;
+    const size_t shmem = in_lds ? (((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15) : 0;
+#define CAMPX_PIPE_MULTI(KK, LDS)                                                                  \
+  hipLaunchKernelGGL((pipe_multi_kernel<KK, LDS>), grid, block, shmem, stream, pp, tp, st, actions, \
+                     out, B, T, reset_first, plane, fc, rr)
+    if (s.n_dyn == 2 && in_lds) CAMPX_PIPE_MULTI(2, true);
+    else if (s.n_dyn == 2) CAMPX_PIPE_MULTI(2, false);
+    else if (s.n_dyn == 3) CAMPX_PIPE_MULTI(3, false);
+    else CAMPX_PIPE_MULTI(4, false);
+#undef CAMPX_PIPE_MULTI
+  } else if (flow) {
+    static const uint32_t max_naps = [] {
+      const char* v = getenv("CAMPX_FLOW_MAX_NAPS");
+      return (uint32_t)(v && *v ? strtoul(v, nullptr, 10) : kFlowMaxNaps);
+    }();
+    static const uint32_t debug_delay = [] {
+      const char* v = getenv("CAMPX_FLOW_DEBUG_DELAY");
+      return (uint32_t)(v && *v ? strtoul(v, nullptr, 10) : 0u);
+    }();
     rr.tagged = reinterpret_cast<uint16_t*>(out.overlap_ctl + 4);
-    rr.tag = next_flow_tag(out.overlap_ctl, 16 + 2 * (int64_t)T * rr.pitch, B, T, stream);
+    rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, stream);
+    rr.max_naps = max_naps;
+    rr.debug_delay = debug_delay;
+    rr.error_flag = out.error_flag;
     hipLaunchKernelGGL(pipe_table_kernel<true>, grid, block, 0, stream, mp, spec_dev, st, actions, out, B, T,
                        reset_first, fc, rr);
   } else {
@@ -1506,13 +1728,15 @@ int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
 // the render is the longer part: on for B <= 8 192 (CAMPX_FLOW_MAX_B), CAMPX_NO_FLOW=1: never.
 // Not while the stream is being captured into a graph: a replay would reuse the launch's tag.
 bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table,
-             hipStream_t stream) {
+             hipStream_t stream, bool ask_stream) {
   static const bool off = [] { const char* v = getenv("CAMPX_NO_FLOW"); return v && v[0] == '1'; }();
   static const int64_t max_b = [] {
     const char* v = getenv("CAMPX_FLOW_MAX_B");
     return (int64_t)(v && *v ? atoll(v) : 8192);
   }();
   if (off || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
+  // (no caller-owned tag state, or nowhere to report a render wave that gave up: two launches)
+  if (!out.flow_state || !out.error_flag) return false;
   if (out.overlap_ctl_bytes < 16 + 2 * (int64_t)T * row_pitch(out, B) ||
       (reinterpret_cast<uintptr_t>(out.overlap_ctl) & 15))
     return false;
@@ -1520,6 +1744,7 @@ bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, 
   CampxOutputs self = out;
   self.board = nullptr;          // (rendered by the ordinary kernel afterwards)
   if (!pipe_ok(s, out, self, B, T, use_table)) return false;
+  if (!ask_stream) return true;           // (campx_flow_shared: "a stream that is not being captured")
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) {
     (void)hipGetLastError();

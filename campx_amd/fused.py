@@ -67,7 +67,8 @@ def _ptr(t):
   return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-_FLOW_MAX_B = int(os.environ.get('CAMPX_FLOW_MAX_B', '8192'))
+# (A/B knob: deferred rollouts of multi-mover games past the shared launch run in order)
+_PIPELINE_DEFERRED = os.environ.get('CAMPX_NO_PIPELINE_DEFERRED', '0') != '1'
 
 
 class FusedGame(object):
@@ -181,6 +182,12 @@ class FusedGame(object):
     self._render = _hip.ops.render.default
     self._update_render = _hip.ops.update_render.default
     self._flow_scratch = None
+    self._flow_state = None    # the scratch block's CampxFlowState: host memory, ours (int64[4])
+    self._flow_shared = {}     # (T, pitch) -> whether the library runs such a rollout as one launch
+    # what a launch could not do although its call returned: bits the kernels raise in pinned
+    # host memory (include/campx_hip.h CampxOutputs.error_flag), looked at after EVERY launch
+    self._err_flag = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    self._err_flag_view = self._err_flag.numpy()
     self._deferred = None      # rollout_deferred(): the dict whose observations are still owed
     self._deferred_rendered = False    # ... unless that rollout was run whole (no shared launch)
     self._shared_launch = {}   # T -> whether campx_update_render_launch shares one launch
@@ -198,9 +205,11 @@ class FusedGame(object):
     confined to n compute units (campx_stream_create_cu_subset), so that the update pass
     cannot take workgroup slots from the render kernel it runs under."""
     if not self.aux_cus:
-      # (CAMPX_AUX_PRIORITY=-1: a high-priority side stream, so that the short update pass is
-      # scheduled ahead of the render blocks it runs under - an A/B knob)
-      return torch.cuda.Stream(self.device, priority=int(os.environ.get('CAMPX_AUX_PRIORITY', '0')))
+      # (a HIGH-priority side stream: the short update pass is scheduled ahead of the render
+      # blocks it runs under - sokoban with three boxes, B = 16 384 / 32 768: 0.53 / 0.64 of peak
+      # at normal priority, 0.70 / 0.78 at high, 0.60 / 0.72 for launches in order;
+      # profiles/r05_multimover_pipeline_ab.txt.  CAMPX_AUX_PRIORITY=0: normal)
+      return torch.cuda.Stream(self.device, priority=int(os.environ.get('CAMPX_AUX_PRIORITY', '-1')))
     raw = ctypes.c_void_p()
     with torch.cuda.device(self.device):
       _hip.check(_hip.lib.campx_stream_create_cu_subset(int(self.aux_cus), ctypes.byref(raw)),
@@ -224,6 +233,23 @@ class FusedGame(object):
     """Synchronise and raise ValueError if any consumed action id was outside 0..4."""
     torch.cuda.synchronize(self.device)
     self._raise_bad()
+
+  def check_ok(self):
+    """Raise RuntimeError if a launch reported, through the error word, that it could not do what
+    it was asked to (a plain host read; `check_ok()` after a synchronise is definitive).  Called
+    after every rollout launch, whatever `validate_actions` says."""
+    bits = int(self._err_flag_view[0])
+    if bits:
+      self._err_flag_view[0] = 0
+      what = []
+      if bits & _hip.ERR_FLOW_TIMEOUT:
+        what.append('a render wave of a one-launch rollout (pipe_table_kernel<true>) waited for '
+                    'its own launch\'s trace entries until it gave up and wrote frames from '
+                    'stale ones: the observations of that rollout are WRONG (two launches '
+                    'sharing one scratch block at the same time?)')
+      if bits & ~_hip.ERR_FLOW_TIMEOUT:
+        what.append('error bits {:#x}'.format(bits & ~_hip.ERR_FLOW_TIMEOUT))
+      raise RuntimeError('campx: ' + '; '.join(what))
 
   def _after_launch(self):
     mode = self.validate_actions
@@ -342,20 +368,31 @@ class FusedGame(object):
     return (self._observation_cache,
             (self._reward if self.any_reward else None), self._discount)
 
-  def _scratch(self, T):
-    """CampxOutputs.overlap_ctl for a T-frame rollout: the tagged copy of the trace that lets a
-    one-mover game's rollout run as ONE launch (campx_flow_scratch_bytes; the library decides
-    per call whether it does)."""
-    # (the library's own bounds, csrc/k_update.hip flow_ok / pipe_ok: no block where it would
-    # not be used - at B = 65 536, T = 4 000 it would be half a gigabyte)
-    frame = self.batch * self.n_layers * self.rows * self.cols
-    if (self.n_dyn != 1 or self.batch > _FLOW_MAX_B or frame % 16 or frame * T > 2000000000
-        or os.environ.get('CAMPX_NO_FLOW', '0') == '1'):
-      return None
+  def _one_launch(self, T, pitch):
+    """Whether the library runs a T-frame rollout of this game, rows `pitch` apart, as ONE
+    launch (campx_flow_shared: its own bounds and knobs, asked once per shape)."""
+    key = (T, pitch)
+    got = self._flow_shared.get(key)
+    if got is None:
+      got = self._flow_shared[key] = bool(_hip.lib.campx_flow_shared(
+          ctypes.byref(self.spec), self.batch, T, pitch))
+    return got
+
+  def _scratch(self, T, out):
+    """(scratch, scratch_state) = CampxOutputs.overlap_ctl / flow_state for this rollout: the
+    tagged copy of the trace that lets a one-mover game's rollout run as ONE launch, and the
+    block's tag state (host memory, ours).  (None, None) where the library would not use them -
+    at B = 65 536, T = 4 000 the block would be half a gigabyte."""
+    trace = out.get('trace')
+    if trace is None or out['obs'].dim() != 5 or out['obs'].dtype != torch.int8:
+      return None, None
+    if not self._one_launch(T, trace.stride(1)):
+      return None, None
     need = (int(_hip.lib.campx_flow_scratch_bytes(self.batch, T)) + 3) // 4
     if self._flow_scratch is None or self._flow_scratch.numel() < need:
       self._flow_scratch = torch.zeros(need, dtype=torch.int32, device=self.device)
-    return self._flow_scratch
+      self._flow_state = torch.zeros(4, dtype=torch.int64)
+    return self._flow_scratch, self._flow_state
 
   def rollout_buffers(self, T, keep_obs=True, want_board=False,
                       obs_dtype=torch.int8, share=None):
@@ -500,8 +537,10 @@ class FusedGame(object):
                     self._pair_table, ids, out['obs'], out['board'], out['reward'],
                     out['discount'], out['done'], out['perf'], out['trace'],
                     self._bad if validate else None,
-                    self._bad_flag if validate else None, bool(reset_first), self._scratch(T))
+                    self._bad_flag if validate else None, bool(reset_first),
+                    *(self._scratch(T, out) + (self._err_flag,)))
     self.frame = T if reset_first else self.frame + T
+    self.check_ok()
     if validate:
       self._after_launch()
     return out
@@ -550,11 +589,11 @@ class FusedGame(object):
                        'alternate two rollout_buffers() (they may share `obs`: '
                        'rollout_buffers(T, share=first))')
     validate = self.validate_actions
-    self._aux_in_sync = False
     one_launch = self._shared_launch.get(T)
     if one_launch is None:
-      one_launch = self._shared_launch[T] = bool(_hip.lib.campx_update_render_shared(
-          ctypes.byref(self.spec), self.batch, T))
+      one_launch = self._shared_launch[T] = bool(
+          (self.n_dyn == 1 or self._pair_table is not None) and
+          _hip.lib.campx_update_render_shared(ctypes.byref(self.spec), self.batch, T))
     if not one_launch or out['obs'].dtype != torch.int8:
       # Nothing to gain from deferring (two movers, a batch or a rollout too big for the shared
       # launch, 16-bit observations): the whole rollout now, rendered while its trace is still
@@ -564,15 +603,29 @@ class FusedGame(object):
         raise ValueError('the previous rollout still owes its observations to the buffer this '
                          'one would overwrite at once: flush() and read them first')
       self.flush()
+      if (out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
+          ((self.n_dyn >= 3 and self.batch >= 8192) or (self.n_dyn == 2 and self.batch >= 32768))):
+        # Games of two to four movers past the shared launch's bounds: the update pass on the
+        # (high-priority) side stream, under the render of the rollout before it - two kernels
+        # on two streams instead of two roles of one launch (sokoban with three boxes,
+        # B = 16 384 / 32 768: 0.70 / 0.78 of peak against 0.60 / 0.72 in order;
+        # profiles/r05_multimover_pipeline_ab.txt).  Complete a call early, like the rollout below.
+        self.rollout(ids, out=out, reset_first=reset_first, pipelined=True)
+        self._deferred, self._deferred_rendered = out, True
+        return prev
+      self._aux_in_sync = False
       self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
                     self._pair_table, ids, out['obs'], None, out['reward'], out['discount'],
                     out['done'], out['perf'], out['trace'], self._bad if validate else None,
-                    self._bad_flag if validate else None, bool(reset_first), self._scratch(T))
+                    self._bad_flag if validate else None, bool(reset_first),
+                    *(self._scratch(T, out) + (self._err_flag,)))
       self._deferred, self._deferred_rendered = out, True
       self.frame = T if reset_first else self.frame + T
+      self.check_ok()
       if validate:
         self._after_launch()
       return prev
+    self._aux_in_sync = False
     # (a rollout of another length: its observations now, by the ordinary render kernel)
     share = (prev is not None and not self._deferred_rendered
              and tuple(prev['trace'].shape) == tuple(out['trace'].shape))

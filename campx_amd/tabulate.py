@@ -605,9 +605,36 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
   return game
 
 
+LAST_WALK = ['']      # how the most recent tabulation was walked (tests, diagnostics)
+
+
 def _trace(engine, actions, max_plays):
-  """Without the frame number in the state first; when the game turns out to read
-  `the_plot.frame` (campx/plot.py:259-280), again with it."""
+  """Many states per call where the game's classes allow it (tabulate_batched.py: the user's
+  update() on lane tensors); else one frame of Python per state and action - without the frame
+  number in the state first; when the game turns out to read `the_plot.frame`
+  (campx/plot.py:259-280), again with it.  CAMPX_TABULATE=walk: never lane by lane; =batch:
+  only lane by lane (the refusal is raised)."""
+  mode = os.environ.get('CAMPX_TABULATE', 'auto')
+  if mode != 'walk':
+    from . import tabulate_batched
+    from .lanes import CannotBatch
+    device = None
+    if getattr(engine, '_device', None) is not None and torch.cuda.is_available():
+      device = engine._device
+    try:
+      game = tabulate_batched.trace(engine, actions, max_plays, device=device)
+      LAST_WALK[0] = 'lanes: {} frames for {} states'.format(game.batched_frames, game.n_states)
+      return game
+    except CannotBatch as why:
+      if mode == 'batch':
+        raise TabulationError('not a game the many-states-per-call tabulator takes: {}'.format(why))
+      LAST_WALK[0] = 'one frame per play (lanes: {})'.format(why)
+    except TabulationError:
+      raise
+    except Exception as why:         # noqa: BLE001 - whatever the user's classes raise on lane tensors
+      if mode == 'batch':
+        raise
+      LAST_WALK[0] = 'one frame per play (lanes: {}: {})'.format(type(why).__name__, str(why)[:200])
   try:
     return _trace_once(engine, actions, max_plays, with_frame=False)
   except _FrameWasRead:
@@ -737,6 +764,19 @@ def _trace_once(engine, actions, max_plays, with_frame):
               'generator): the same state reached over two histories answered action {} '
               'differently'.format(a))
 
+  return _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, images, orders,
+                 hiddens, boards, edges, plays[0])
+
+
+def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, images, orders, hiddens,
+            boards, edges, n_plays):
+  """From the walked state graph to a `TracedGame`: `images[s]` (per-thing byte images, things in
+  ascending character order), `orders[s]` (z-order string), `hiddens[s]` (`hidden_image()`),
+  `boards[s]` (the rendered board's bytes) of every reached state, state 0 the one after
+  `its_showtime()` (`things0`, `backdrop0`, `z0`), and `edges[(s, a)]` = `_Edge`.  Shared by the
+  one-frame-per-play walker above and the many-states-per-call one (tabulate_batched.py)."""
+  HW = H * W
+  plays = [n_plays]
   # ---- who moves
   order = sorted(probe.things.keys())                     # the order of _image()'s parts
   varying = [i for i in range(len(order))

@@ -1,0 +1,529 @@
+"""Tabulate a game of arbitrary Python `update()` classes MANY STATES PER CALL.
+
+`tabulate.trace()` walks a game's state graph with one generic-tier frame of Python per (state,
+action): 60 000 frames is what it will spend (`MAX_PLAYS`), so a user's own two-box sokoban -
+10^5 states and more - was refused, and only the re-typed `campx_amd.rules` classes reached the
+device-side enumerator ("what's missing" 2).  The reference's own classes are written
+in arithmetic-only tensor operations (examples/boat_race.py:40-57, README.md:3) precisely so that
+they run on other tensor types.  This module runs them on one: `lanes.Lanes`, N tensors at once.
+
+The walk is the same breadth-first one, a LEVEL at a time: the curtains of every state of the
+frontier are stacked into `[N, H, W]` lanes, the frame is rendered for all of them (the engine's
+own `_render()` on a renderer that paints lanes), and the game's unmodified `update()` methods run
+ONCE per action for the whole frontier - `Engine._update_and_render()` / `_apply_and_clear_plot()`
+themselves (campx/engine.py:168-293), on a deep copy of the user's engine whose drape curtains
+and rendered layers are `Lanes`.  Next states are keyed exactly (the cell of every one-cell
+drape; anything else is not this tier's game), deduplicated with sort / searchsorted, and numbered
+in the order the one-frame-per-play walker discovers them, so both walkers hand `tabulate._finish`
+the same graph and produce the same `TracedGame`.
+
+What this tier takes - checked, `CannotBatch` otherwise, and `tabulate.trace()` then falls back
+to the one-frame-per-play walk, which takes anything and says what is wrong with the rest:
+  * things are Drapes with 0/1 curtains (a Sprite's position is a Python tuple: one value for all
+    lanes), the Backdrop's `update()` is the base class's no-op;
+  * nothing a frame can read changes besides the curtains and what renders from them: entity
+    attributes, Plot entries (other than aliases of the renderer's live layers,
+    `the_plot['prev_pos_A'] = layers['A']`, boat_race.py:59), the z-order, the frame number;
+  * Python-level control flow never depends on a lane-varying value (`if gate:` with a tensor
+    that differs between states, `int(x)`, `.item()`, `.numpy()`); rewards are lane tensors or
+    plain numbers, termination and discounts are per action, not per state.
+A sample of the tabulated edges (every action from the first state, and `CHECK_EDGES` random
+ones) is then replayed on the ordinary generic tier - the user's code on plain tensors - and must
+agree bit for bit; a disagreement falls back as well.
+
+Host logic (torch on the CPU, or on the engine's device when there is one); no HIP kernel.
+"""
+
+import copy
+
+import numpy as np
+import torch
+
+from . import gamespec
+from . import lanes
+from . import rendering
+from . import tabulate
+from . import things as _things
+from .lanes import CannotBatch, Lanes
+
+N_ACTIONS = gamespec.N_ACTIONS
+CHECK_EDGES = 48
+MAX_STATES = 1 << 24          # the wide tier's state index
+
+
+class _LanesRenderer(object):
+  """`rendering.BaseObservationRenderer`'s interface (campx/rendering.py:104-219) over lanes: the
+  board and every `layers[ch]` are persistent `Lanes` objects re-bound per render, as the
+  reference's are persistent tensors re-bound with `set_` (rendering.py:209) - so what a game
+  stored (`the_plot['prev_pos_A'] = layers['A']`) stays live."""
+
+  def __init__(self, rows, cols, chars, device):
+    self.rows, self.cols, self.chars = rows, cols, sorted(chars)
+    self.device = device
+    self.n = 1
+    self._board = lanes.wrap(torch.zeros((1, rows, cols), dtype=torch.int64, device=device))
+    self._layers = {ch: lanes.wrap(torch.zeros((1, rows, cols), dtype=torch.uint8, device=device))
+                    for ch in self.chars}
+    self._canvas = None
+
+  def clear(self):
+    self._canvas = None
+
+  def paint_all_of(self, curtain):
+    if isinstance(curtain, Lanes):
+      raise CannotBatch('the Backdrop\'s curtain became lane-varying')
+    self._canvas = curtain.to(self.device).unsqueeze(0).expand(self.n, self.rows, self.cols).clone()
+
+  def paint_sprite(self, character, position):
+    self._canvas[:, position.row, position.col] = ord(character)
+
+  def paint_drape(self, character, curtain):
+    if isinstance(curtain, Lanes):
+      mask = lanes.plain(curtain)
+      if mask.shape[0] != self.n:
+        raise CannotBatch('a curtain of {} lanes in a frame of {}'.format(mask.shape[0], self.n))
+    else:
+      mask = curtain.to(self.device).unsqueeze(0)
+    # (board - m * board + m * ord(ch), rendering.py:176-178, for the 0/1 masks this tier checks)
+    self._canvas = torch.where(mask != 0, torch.full_like(self._canvas, ord(character)), self._canvas)
+
+  def render(self):
+    with lanes._guard():
+      torch.Tensor.set_(self._board, self._canvas)
+      for ch in self.chars:
+        torch.Tensor.set_(self._layers[ch], (self._canvas == ord(ch)).to(torch.uint8))
+    return rendering.Observation(board=self._board, layers=self._layers, layered_board=None)
+
+
+def _walk_values(obj, seen, path, out, depth=0):
+  """(path, container, key) of every tensor reachable through lists / tuples / dicts."""
+  if depth > 4 or id(obj) in seen:
+    return
+  if isinstance(obj, dict):
+    seen.add(id(obj))
+    for k, v in obj.items():
+      if torch.is_tensor(v):
+        out.append(('{}[{!r}]'.format(path, k), obj, k))
+      else:
+        _walk_values(v, seen, '{}[{!r}]'.format(path, k), out, depth + 1)
+  elif isinstance(obj, list):
+    seen.add(id(obj))
+    for i, v in enumerate(obj):
+      if torch.is_tensor(v):
+        out.append(('{}[{}]'.format(path, i), obj, i))
+      else:
+        _walk_values(v, seen, '{}[{}]'.format(path, i), out, depth + 1)
+
+
+def _tensor_slots(eng):
+  """Every place outside the curtains where the engine's entities and Plot hold a tensor."""
+  out, seen = [], set()
+  for ch, ent in eng.things.items():
+    for name, value in vars(ent).items():
+      if name == '_curtain':
+        continue
+      if torch.is_tensor(value):
+        out.append(('things[{!r}].{}'.format(ch, name), vars(ent), name))
+      else:
+        _walk_values(value, seen, 'things[{!r}].{}'.format(ch, name), out)
+  for name, value in vars(eng.backdrop).items():
+    if name != '_curtain' and torch.is_tensor(value):
+      out.append(('backdrop.' + name, vars(eng.backdrop), name))
+  plot = eng._the_plot
+  for key in list(dict.keys(plot)):
+    value = dict.__getitem__(plot, key)
+    if torch.is_tensor(value):
+      out.append(('the_plot[{!r}]'.format(key), plot, key))
+    else:
+      _walk_values(value, seen, 'the_plot[{!r}]'.format(key), out)
+  return out
+
+
+def _get(container, key):
+  return dict.__getitem__(container, key) if isinstance(container, dict) else container[key]
+
+
+def _put(container, key, value):
+  if isinstance(container, dict):
+    dict.__setitem__(container, key, value)
+  else:
+    container[key] = value
+
+
+def _plain_image(eng):
+  """`tabulate.hidden_image()` of everything that is not a `Lanes`: what must stay put."""
+  stash = []
+  for path, container, key in _tensor_slots(eng):
+    value = _get(container, key)
+    if isinstance(value, Lanes):
+      stash.append((container, key, value))
+      _put(container, key, ('lanes', path))
+  try:
+    return tabulate.hidden_image(eng, False)
+  finally:
+    for container, key, value in stash:
+      _put(container, key, value)
+
+
+class _Frontier(object):
+  """The lifted engine: one deep copy of the user's, curtains and rendered layers as lanes."""
+
+  def __init__(self, probe, actions, device):
+    self.eng = eng = tabulate.clone_engine(probe)
+    self.actions = actions
+    self.device = device
+    self.H, self.W = eng.rows, eng.cols
+    for ch, ent in eng.things.items():
+      if isinstance(ent, _things.Sprite):
+        raise CannotBatch('{!r} is a Sprite: its position is a Python tuple, one for every state'.format(ch))
+    if type(eng.backdrop).update is not _things.Backdrop.update:
+      raise CannotBatch('the Backdrop has an update() of its own')
+    self.drapes = sorted(eng.things.keys())
+    old = eng._renderer
+    chars = set(eng.things.keys()) | set(eng.backdrop.palette)
+    self.renderer = _LanesRenderer(self.H, self.W, chars, device)
+    # whatever the game kept of the old renderer's live tensors now means the new one's
+    remap = {id(old._board): self.renderer._board}
+    for ch, t in old._layers.items():
+      remap[id(t)] = self.renderer._layers[ch]
+    eng._renderer = self.renderer
+    for path, container, key in _tensor_slots(eng):
+      value = _get(container, key)
+      if id(value) in remap:
+        _put(container, key, remap[id(value)])
+    for ch in self.drapes:
+      ent = eng.things[ch]
+      ent._curtain = lanes.wrap(ent._curtain.to(device).to(torch.uint8).unsqueeze(0).clone())
+    self.slots = [(path, c, k) for path, c, k in _tensor_slots(eng)]
+    self.owned = {id(self.renderer._board)} | {id(t) for t in self.renderer._layers.values()}
+    self.image0 = _plain_image(eng)
+    self.reads0 = tabulate.FRAME_READS[0]
+    self.z0 = ''.join(eng.things.keys())
+
+  def frame(self, curtains, a):
+    """One frame of action `a` for N states (`curtains[ch]`: uint8 `[N, H, W]`).  Returns
+    (next curtains, reward f32 [N] with NaN for None, discount, over, boards uint8 [N, H*W])."""
+    eng = self.eng
+    n = int(next(iter(curtains.values())).shape[0])
+    self.renderer.n = n
+    with lanes._guard():
+      for ch in self.drapes:
+        ent = eng.things[ch]
+        if not isinstance(ent._curtain, Lanes):
+          raise CannotBatch('{!r} replaced its curtain by an ordinary tensor'.format(ch))
+        torch.Tensor.set_(ent._curtain, curtains[ch].clone())
+    eng._render()                       # the states' own rendering: what this frame's update() reads
+    eng._game_over = False
+    eng._the_plot._clear_engine_directives()
+    eng._update_and_render(copy.deepcopy(self.actions[a]))
+    reward, discount, rerender = eng._apply_and_clear_plot()
+    eng._the_plot._frame -= 1            # (one frame, over and over: its number is not part of this tier's state)
+    if tabulate.FRAME_READS[0] != self.reads0:
+      raise CannotBatch('the game reads the_plot.frame')
+    if rerender or ''.join(eng.things.keys()) != self.z0:
+      raise CannotBatch('the game changes the z-order')
+    over = bool(eng._game_over)
+    if isinstance(discount, Lanes):
+      raise CannotBatch('a discount that differs between states')
+    nxt = {}
+    for ch in self.drapes:
+      cur = eng.things[ch]._curtain
+      if not isinstance(cur, Lanes):
+        raise CannotBatch('{!r} replaced its curtain by an ordinary tensor'.format(ch))
+      p = lanes.plain(cur)
+      if tuple(p.shape) != (n, self.H, self.W):
+        raise CannotBatch('the curtain of {!r} changed its shape'.format(ch))
+      nxt[ch] = p.to(torch.uint8).clone()
+    if reward is None:
+      r = torch.full((n,), float('nan'), dtype=torch.float32, device=self.device)
+    elif isinstance(reward, Lanes):
+      p = lanes.plain(reward)
+      if p.dim() != 1 and p[0].numel() != 1:
+        raise CannotBatch('a reward that is not a number')
+      r = p.reshape(n).to(torch.float32)
+    else:
+      r = torch.full((n,), float(tabulate.reward_f32(reward)), dtype=torch.float32, device=self.device)
+    # nothing else may have moved
+    for path, container, key in _tensor_slots(eng):
+      value = _get(container, key)
+      if isinstance(value, Lanes) and id(value) not in self.owned:
+        raise CannotBatch('{} holds a lane-varying tensor of its own: state outside the curtains'.format(path))
+    if _plain_image(eng) != self.image0:
+      raise CannotBatch('something besides the curtains changed (an entity attribute, a Plot entry)')
+    board = lanes.plain(self.renderer._board).to(torch.uint8).reshape(n, self.H * self.W)
+    return nxt, r, float(np.float32(discount)), over, board
+
+
+def trace(engine, actions=None, max_plays=None, device=None):
+  """The `TracedGame` `tabulate.trace()` would return, from many-states-per-call frames; raises
+  `CannotBatch` for games this tier does not take (module docstring)."""
+  if engine.backdrop is None:
+    raise ValueError('the Engine has no Backdrop yet')
+  H, W = engine.rows, engine.cols
+  HW = H * W
+  chars = sorted(set(engine.things.keys()) | set(engine.backdrop.palette))
+  if HW > gamespec.WIDE_MAX_CELLS or H > 127 or W > 127 or len(chars) > gamespec.MAX_LAYERS:
+    raise CannotBatch('board or character set beyond every tier')       # (the walker says it properly)
+  actions = tabulate.default_actions() if actions is None else list(actions)
+  if device is None:
+    device = torch.device('cpu')
+  device = torch.device(device)
+
+  probe = tabulate.clone_engine(engine)
+  probe._batch, probe._device, probe._fused = None, None, None
+  probe._the_plot.__class__ = tabulate.probe_plot_class(type(probe._the_plot))
+  obs, _, _ = probe.its_showtime()
+  if probe.game_over:
+    raise CannotBatch('the episode is over after its_showtime()')
+  things0, backdrop0, z0 = tabulate._image(probe)
+  hidden0 = tabulate.hidden_image(probe, False)
+  front = _Frontier(probe, actions, device)
+  drapes = front.drapes                                   # ascending characters = _image()'s order
+  start = {ch: lanes.plain(front.eng.things[ch]._curtain).clone() for ch in drapes}
+  for ch in drapes:
+    if int(start[ch].max()) > 1:
+      raise CannotBatch('the curtain of {!r} holds values other than 0 and 1'.format(ch))
+
+  # ---- which drapes move at all: one frame of every action from the start
+  moving = set()
+  first = {}
+  for a in range(N_ACTIONS):
+    first[a] = front.frame(start, a)
+    for ch in drapes:
+      if not torch.equal(first[a][0][ch], start[ch]):
+        moving.add(ch)
+
+  # a state = the cells of the drapes that (ever) move; discovered lazily: a drape found moving
+  # later restarts the walk with it among the movers (rare: at most a few restarts)
+  while True:
+    try:
+      graph = _walk(front, start, sorted(moving), drapes, HW, device)
+      break
+    except _NewMover as e:
+      moving.add(e.ch)
+
+  cells, nxt, reward, over_a, disc_a, boards, n_frames = graph
+  S = cells.shape[0]
+  movers = sorted(moving)
+  cells_np = cells.cpu().numpy()
+  boards_np = boards.cpu().numpy()
+  static_bytes = {ch: start[ch][0].cpu().numpy().astype(np.uint8).tobytes() for ch in drapes}
+  plane = np.zeros(HW, np.uint8)
+
+  def image_of(s):
+    parts = []
+    for ch in drapes:
+      if ch in moving:
+        k = movers.index(ch)
+        c = int(cells_np[s, k])
+        plane[:] = 0
+        if c < HW:
+          plane[c] = 1
+        parts.append(plane.tobytes())
+      else:
+        parts.append(static_bytes[ch])
+    return tuple(parts)
+
+  images = [image_of(s) for s in range(S)]
+  if images[0] != things0:
+    raise CannotBatch('a moving drape covers more than one cell at the start')
+  orders = [z0] * S
+  hiddens = [hidden0] * S
+  board_bytes = [boards_np[s].tobytes() for s in range(S)]
+  if board_bytes[0] != obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes():
+    raise CannotBatch('the lanes renderer disagrees with the generic tier on the first board')
+  nxt_np, reward_np = nxt.cpu().numpy(), reward.cpu().numpy()
+  edges = {}
+  expanded = nxt_np[:, 0] >= 0
+  for s in np.flatnonzero(expanded):
+    for a in range(N_ACTIONS):
+      t = int(nxt_np[s, a])
+      edges[(int(s), a)] = tabulate._Edge(t, np.float32(reward_np[s, a]), disc_a[a], over_a[a], board_bytes[t])
+
+  _cross_check(probe, actions, drapes, movers, cells_np, edges, images, HW)
+  game = tabulate._finish(engine, probe, H, W, chars, False, things0, backdrop0, z0, images, orders,
+                          hiddens, board_bytes, edges, n_frames)
+  game.batched_frames = n_frames
+  return game
+
+
+class _NewMover(Exception):
+  def __init__(self, ch):
+    Exception.__init__(self, ch)
+    self.ch = ch
+
+
+def _walk(front, start, movers, drapes, HW, device):
+  """Breadth-first over levels.  Returns (cells int64 [S, K], next int64 [S, 5] (-1: never
+  expanded), reward f32 [S, 5], over per action, discount per action, boards uint8 [S, HW],
+  frames run)."""
+  K = len(movers)
+  if K == 0:
+    raise CannotBatch('nothing moves')
+  base = HW + 1
+  if base ** K >= 1 << 62:
+    raise CannotBatch('too many moving drapes for an exact key')
+  H, W = front.H, front.W
+
+  def cells_of(curtains):
+    """int64 [N, K]: the cell of every mover (HW: its curtain is empty)."""
+    cols = []
+    for ch in movers:
+      m = curtains[ch].reshape(curtains[ch].shape[0], -1)
+      if int(m.max()) > 1:
+        raise CannotBatch('the curtain of {!r} holds values other than 0 and 1'.format(ch))
+      count = m.sum(dim=1)
+      if int(count.max()) > 1:
+        raise CannotBatch('moving drape {!r} covers more than one cell in a reachable state'.format(ch))
+      cell = m.to(torch.int16).argmax(dim=1)
+      cols.append(torch.where(count == 0, torch.full_like(cell, HW), cell))
+    return torch.stack(cols, dim=1).to(torch.int64)
+
+  def key_of(cells):
+    key = torch.zeros(cells.shape[0], dtype=torch.int64, device=device)
+    for k in range(K):
+      key = key * base + cells[:, k]
+    return key
+
+  def curtains_of(cells):
+    n = cells.shape[0]
+    out = {}
+    for ch in drapes:
+      if ch in movers:
+        k = movers.index(ch)
+        m = torch.zeros((n, HW + 1), dtype=torch.uint8, device=device)
+        m.scatter_(1, cells[:, k:k + 1], 1)
+        out[ch] = m[:, :HW].reshape(n, H, W).contiguous()
+      else:
+        out[ch] = start[ch].expand(n, H, W)
+    return out
+
+  cells0 = cells_of(start)
+  cells = cells0                              # [S, K], grows
+  known_keys = key_of(cells0)                 # sorted, with the state index of each
+  known_index = torch.zeros(1, dtype=torch.int64, device=device)
+  S = 1
+  boards = [_render_states(front, start)]
+  nxt_rows, reward_rows, level_states = [], [], []
+  queued = torch.ones(1, dtype=torch.bool, device=device)       # ever put on the walk's queue
+  frontier = torch.zeros(1, dtype=torch.int64, device=device)   # state indices in QUEUE order
+  over_a, disc_a = [None] * N_ACTIONS, [None] * N_ACTIONS
+  frames = 0
+  big = 1 << 62
+
+  while frontier.numel():
+    F = frontier.numel()
+    cur = curtains_of(cells[frontier])
+    keys = torch.empty((F, N_ACTIONS), dtype=torch.int64, device=device)
+    ncell = torch.empty((F, N_ACTIONS, K), dtype=torch.int64, device=device)
+    rew = torch.empty((F, N_ACTIONS), dtype=torch.float32, device=device)
+    nboard = [None] * N_ACTIONS
+    for a in range(N_ACTIONS):
+      nxt, r, discount, over, board = front.frame(cur, a)
+      frames += 1
+      for ch in drapes:
+        if ch not in movers and not torch.equal(nxt[ch], cur[ch].expand(F, H, W)):
+          raise _NewMover(ch)
+      if over_a[a] is None:
+        over_a[a], disc_a[a] = over, discount
+      elif over_a[a] != over or disc_a[a] != discount:
+        raise CannotBatch('action {} ends the episode (or sets the discount) in some states only'.format(a))
+      c = cells_of(nxt)
+      ncell[:, a] = c
+      keys[:, a] = key_of(c)
+      rew[:, a] = r
+      nboard[a] = board
+    flat_keys = keys.reshape(-1)              # slot = state's place in the queue * 5 + action: discovery order
+    pos = torch.searchsorted(known_keys, flat_keys).clamp(max=known_keys.numel() - 1)
+    found = known_keys[pos] == flat_keys
+    target = torch.where(found, known_index[pos], torch.full_like(pos, -1))
+    if not bool(found.all()):
+      where = torch.nonzero(~found).reshape(-1)                    # ascending = discovery order
+      uniq, inverse = torch.unique(flat_keys[where], return_inverse=True)
+      # number the new states by the first slot each one appears in
+      first_at = torch.full((uniq.numel(),), big, dtype=torch.int64, device=device)
+      first_at.scatter_reduce_(0, inverse, where, reduce='amin', include_self=True)
+      order = torch.argsort(first_at)
+      rank = torch.empty_like(order)
+      rank[order] = torch.arange(order.numel(), device=device)
+      new_index = S + rank                                          # the index of each unique key
+      target[where] = new_index[inverse]
+      n_new = int(uniq.numel())
+      if S + n_new > MAX_STATES:
+        raise CannotBatch('more than {} reachable states'.format(MAX_STATES))
+      first_sorted = first_at[order]                                # slot of each new state, in index order
+      cells = torch.cat([cells, ncell.reshape(-1, K)[first_sorted]])
+      boards.append(torch.stack(nboard, dim=1).reshape(F * N_ACTIONS, HW)[first_sorted])
+      merged_keys = torch.cat([known_keys, uniq])
+      merged_index = torch.cat([known_index, new_index])
+      sort = torch.argsort(merged_keys)
+      known_keys, known_index = merged_keys[sort], merged_index[sort]
+      queued = torch.cat([queued, torch.zeros(n_new, dtype=torch.bool, device=device)])
+      S += n_new
+    target = target.reshape(F, N_ACTIONS)
+    nxt_rows.append(target)
+    reward_rows.append(rew)
+    level_states.append(frontier)
+    # the walk goes on from a state once an edge that does not end the episode reaches it, in
+    # the order those edges are played (tabulate._trace_once's queue)
+    live = [a for a in range(N_ACTIONS) if not over_a[a]]
+    if not live:
+      break
+    slots = (torch.arange(F, device=device)[:, None] * N_ACTIONS +
+             torch.tensor(live, device=device)[None, :]).reshape(-1)
+    reached = target[:, live].reshape(-1)
+    first_slot = torch.full((S,), big, dtype=torch.int64, device=device)
+    first_slot.scatter_reduce_(0, reached, slots, reduce='amin', include_self=True)
+    newly = (first_slot < big) & ~queued
+    frontier = torch.nonzero(newly).reshape(-1)
+    frontier = frontier[torch.argsort(first_slot[frontier])]
+    queued |= newly
+
+  nxt_all = torch.full((S, N_ACTIONS), -1, dtype=torch.int64, device=device)
+  rew_all = torch.full((S, N_ACTIONS), float('nan'), dtype=torch.float32, device=device)
+  for st, t, r in zip(level_states, nxt_rows, reward_rows):
+    nxt_all[st] = t
+    rew_all[st] = r
+  return cells, nxt_all, rew_all, [bool(x) for x in over_a], disc_a, torch.cat(boards), frames
+
+
+def _render_states(front, curtains):
+  """The boards (uint8 [N, H*W]) of states given by their curtains."""
+  eng = front.eng
+  n = int(next(iter(curtains.values())).shape[0])
+  front.renderer.n = n
+  with lanes._guard():
+    for ch in front.drapes:
+      torch.Tensor.set_(eng.things[ch]._curtain, curtains[ch].clone())
+  eng._render()
+  return lanes.plain(front.renderer._board).to(torch.uint8).reshape(n, front.H * front.W).clone()
+
+
+def _cross_check(probe, actions, drapes, movers, cells_np, edges, images, HW):
+  """Replay a sample of the tabulated edges with the user's code on PLAIN tensors (the generic
+  tier, one state, one action) and demand the same next state, reward, discount, game-over and
+  board: the lane-by-lane frames are the game's own frames."""
+  keys = sorted(edges.keys())
+  rng = np.random.RandomState(20261003)
+  sample = [k for k in keys if k[0] == 0]
+  if len(keys) > len(sample):
+    rest = [k for k in keys if k[0] != 0]
+    pick = rng.choice(len(rest), size=min(CHECK_EDGES, len(rest)), replace=False)
+    sample += [rest[i] for i in sorted(pick)]
+  H, W = probe.rows, probe.cols
+  for s, a in sample:
+    eng = tabulate.clone_engine(probe)
+    for i, ch in enumerate(drapes):
+      mask = np.frombuffer(images[s][i], np.uint8).reshape(H, W)
+      eng.things[ch].curtain.copy_(torch.from_numpy(mask.copy()))
+    eng._render()
+    obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
+    got_things, _, _ = tabulate._image(eng)
+    e = edges[(s, a)]
+    ok = (got_things == images[e.next] and bool(eng.game_over) == e.over and
+          float(np.float32(discount)) == e.discount and
+          obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes() == e.board and
+          np.array([tabulate.reward_f32(reward)]).view(np.uint32)[0] == np.array([e.reward]).view(np.uint32)[0])
+    if not ok:
+      raise CannotBatch('a frame run lane by lane disagrees with the same frame on the generic tier '
+                        '(state {}, action {})'.format(s, a))

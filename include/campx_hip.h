@@ -198,6 +198,17 @@ typedef struct CampxState {
 /* Per-frame outputs, DEVICE pointers; any of them except `obs` may be NULL.
  * Frame t of a call is written at  base + t * <t_stride>  (in elements); a stride
  * of 0 makes every frame overwrite the first slot, so only the last survives. */
+/* Bits of *CampxOutputs.error_flag. */
+#define CAMPX_ERR_FLOW_TIMEOUT 1
+
+/* What the library remembers about a scratch block of one-launch rollouts - in the CALLER's
+ * memory (CampxOutputs.flow_state), so that the library holds no state of its own. */
+typedef struct CampxFlowState {
+  int64_t tag;    /* 1..255, of the block's last launch; 0: none yet (the block is cleared first) */
+  int64_t B, T;   /* what the block's entries were written for */
+  int64_t pitch;  /* the row pitch they were written with */
+} CampxFlowState;
+
 typedef struct CampxOutputs {
   int8_t* obs;        /* layered_board [*, B, L, rows, cols] 0/1 (campx/rendering.py:213-215);
                          16-byte aligned */
@@ -251,22 +262,47 @@ typedef struct CampxOutputs {
                          16-byte groups (the pad holds unspecified values).  `actions` and the
                          observation / board frames are never padded. */
   uint32_t* overlap_ctl; /* optional device scratch of campx_flow_scratch_bytes(B, T) bytes, 16-byte
-                         aligned, ZEROED ONCE by the caller and then left to the library; NULL:
-                         two launches per rollout.  With it a rollout of a one-mover game at a
-                         batch of at most 8 192 environments (int8 observations of every frame,
-                         whole 16-byte chunks per frame) runs as ONE launch whose update pass and
-                         render overlap: update workgroups first, render workgroups behind them
-                         reading a tagged 16-bit copy of the trace kept in this block as the
-                         update role writes it (csrc/k_update.hip, pipe_table_kernel<true>):
-                         15 / 22 / 34 us against 20 / 27 / 38 at B = 1 024 / 4 096 / 8 192.  Not
-                         while `stream` is being captured into a graph.  CAMPX_NO_FLOW=1 in the
-                         environment: never.  Two launches that may run at the same time must
-                         not share a block. */
+                         aligned; NULL: two launches per rollout.  With it - AND `flow_state` AND
+                         `error_flag` below - a rollout of a one-mover game at a batch of at most
+                         8 192 environments (int8 observations of every frame, whole 16-byte
+                         chunks per frame) runs as ONE launch whose update pass and render
+                         overlap: update workgroups first, render workgroups behind them reading
+                         a tagged 16-bit copy of the trace kept in this block as the update role
+                         writes it (csrc/k_update.hip, pipe_table_kernel<true>): 15 / 22 / 34 us
+                         against 20 / 27 / 38 at B = 1 024 / 4 096 / 8 192.  Not while `stream` is
+                         being captured into a graph.  CAMPX_NO_FLOW=1 in the environment: never.
+                         Two launches that may run at the same time must not share a block.
+                         campx_flow_shared() says whether a call will take this path. */
   int64_t overlap_ctl_bytes;
+  struct CampxFlowState* flow_state; /* HOST memory, caller-owned, one per `overlap_ctl` block,
+                         zero-initialised by the caller when the block is allocated and from then
+                         on read and written only by the library, inside the launch call: the tag
+                         of the block's last launch and the (B, T, row pitch, bytes) its entries
+                         were written for (a launch with any of them changed first clears the
+                         block, stream-ordered).  The library itself keeps NO state between
+                         calls.  NULL: two launches per rollout. */
+  int32_t* error_flag; /* int32, device memory or host memory mapped into the device: bits OR-ed in
+                         (system scope) when a launch could not do what it was asked to, although
+                         the call returned CAMPX_OK: CAMPX_ERR_FLOW_TIMEOUT - a render wave of a
+                         one-launch rollout waited for trace entries of its own launch until it
+                         gave up (seconds; two launches sharing one block at the same time is
+                         the known way to get there) and wrote frames from stale entries: the
+                         observations of that launch are WRONG.  Never cleared by the library.
+                         Required for the one-launch path (NULL: two launches per rollout), so
+                         that this failure cannot pass unseen. */
 } CampxOutputs;
 
 /* Size of CampxOutputs.overlap_ctl for rollouts of T frames of B environments. */
 int64_t campx_flow_scratch_bytes(int64_t B, int32_t T);
+
+/* 1 when campx_rollout_launch() of T frames of B environments of this game, with a scratch
+ * block, flow state and error flag supplied, int8 observations of every frame at a 16-byte
+ * aligned address, rows of the per-frame streams `scalar_pitch` apart (0: B) and a stream that
+ * is not being captured, runs as ONE launch (pipe_table_kernel<true>); 0 when it runs as an
+ * update launch and a render launch.  The library's own bounds and environment knobs, for
+ * callers that allocate the block only where it is used and for whoever reports which kernel
+ * ran (bench.py). */
+int32_t campx_flow_shared(const CampxSpec* spec_host, int64_t B, int32_t T, int64_t scalar_pitch);
 
 /* sizeof(CampxSpec), for bindings that allocate the blob themselves. */
 int32_t campx_spec_size(void);
@@ -380,11 +416,13 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
  * whose next actions do not depend on the observations they are waiting for (open-loop action
  * streams; the reference has no such call - it is Engine.play(), campx/engine.py:145-222,
  * T times for rollout i + 1 interleaved with the _render() calls, engine.py:286-324, of
- * rollout i).  For one-mover table games with int8 observations of whole 16-byte chunks per
- * frame and no flat board, up to 32 768 environments and 2 GB of observations per rollout, the
- * two passes share ONE launch (update workgroups first, the others render); otherwise they are
- * issued one after the other on `stream`.  prev.trace == NULL:
- * the update pass alone.  CAMPX_NO_PIPE=1 in the environment: always one after the other.
+ * rollout i).  For table games of ONE TO FOUR movers (one: the table in the spec; two to four:
+ * the pair / tuple table in `state.pair_table`, round 5) with int8 observations of whole 16-byte
+ * chunks per frame and no flat board, up to 32 768 environments and 2 GB of observations per
+ * rollout, the two passes share ONE launch (update workgroups first, the others render);
+ * otherwise they are issued one after the other on `stream`.  prev.trace == NULL: the update
+ * pass alone.  CAMPX_NO_PIPE=1 in the environment: always one after the other;
+ * CAMPX_NO_PIPE_MULTI=1: only one-mover games share the launch.
  */
 int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
                                    CampxState state, const int8_t* actions, CampxOutputs out,
@@ -394,7 +432,8 @@ int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* 
  * every frame, no flat board) in one launch, 0 if it would issue them one after the other - in
  * which case a caller does better not to defer at all: campx_rollout_launch() renders a trace
  * that is still cached, a deferred render reads one that a whole launch has since evicted
- * (boat race, B = 200 000: 0.67 of peak against 0.83). */
+ * (boat race, B = 200 000: 0.67 of peak against 0.83).  For a game of two to four movers the
+ * answer assumes its table in CampxState.pair_table (without one: one after the other). */
 int32_t campx_update_render_shared(const CampxSpec* spec_host, int64_t B, int32_t T);
 
 /*

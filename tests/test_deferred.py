@@ -77,8 +77,42 @@ def test_wall_world_deferred_matches_oracle():
   _check(wall_world.build, 2000, [64, 64, 64], seed=5)
 
 
-def test_two_mover_game_runs_the_passes_one_after_the_other():
-  _check(sokoban.build, 512, [50, 50, 50], seed=6)
+def _kernels_of(fn):
+  from torch.profiler import ProfilerActivity, profile
+  with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    fn()
+    torch.cuda.synchronize()
+  return [e.key for e in prof.key_averages() if 'campx_impl' in e.key]
+
+
+@pytest.mark.parametrize('level,B,Ts', [(0, 512, [50, 50, 50]), (0, 4096, [100, 100, 33, 100]),
+                                        (0, 5008, [40, 40, 40]), (0, 16384, [30, 30, 30]),
+                                        (1, 1024, [64, 64, 17, 64]), (1, 8192, [40, 40, 40]),
+                                        (2, 1024, [64, 64, 64]), (2, 4096, [50, 50, 20, 50])])
+def test_games_of_two_to_four_movers_share_the_launch(level, B, Ts):
+  """Round 5: pipe_multi_kernel - the update role walks the pair (sokoban: two movers) or tuple
+  table (levels 1 and 2: three and four), the render role patches up to 2K bytes per row from K
+  planes of the previous rollout's trace.  Every byte against the oracle, state carried over."""
+  _check(sokoban.build, B, Ts, seed=31 * level + B, build_kwargs=dict(level=level))
+  game = sokoban.build(level=level, batch=B, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  assert f.n_dyn == level + 2
+  T = Ts[0]
+  sets = [f.rollout_buffers(T), f.rollout_buffers(T)]
+  acts = torch.randint(0, 5, (T, B), dtype=torch.int8, device='cuda')
+  f.rollout_deferred(acts, sets[0], reset_first=True)
+  names = _kernels_of(lambda: f.rollout_deferred(acts, sets[1]))
+  assert len(names) == 1 and 'pipe_multi_kernel<%d' % (level + 2) in names[0], names
+  f.flush()
+
+
+def test_multi_mover_games_past_the_shared_launch_pipeline_over_two_streams():
+  # 33 024 environments of the two-mover game, 16 384 of the four-mover one: past what the shared
+  # launch takes; rollout_deferred() then runs the update pass on the high-priority side stream
+  # under the previous rollout's render (two kernels, two streams), complete a call early
+  _check(sokoban.build, 33024, [10, 10, 10], seed=6)
+  _check(sokoban.build, 16384, [20, 20, 7, 20], seed=7, build_kwargs=dict(level=2))
 
 
 def test_deferred_rollouts_refuse_what_they_cannot_do():
