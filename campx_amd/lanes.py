@@ -226,6 +226,20 @@ def _store(dst, value):
 class Lanes(torch.Tensor):
   """See the module docstring."""
 
+  def set_(self, source=None, *rest, **kwargs):
+    """`Tensor.set_` (which does not pass through __torch_function__): these lanes now ARE
+    `source` - a `Lanes`, or one tensor for every lane - and keep their identity, as a
+    curtain re-bound with `self.curtain.set_(new)` (examples/boat_race.py:57) does."""
+    if rest or kwargs or source is None or not torch.is_tensor(source):
+      raise CannotBatch('set_ with a storage / offset / strides')
+    if isinstance(source, Lanes):
+      new = plain(source)
+    else:
+      new = source.unsqueeze(0).expand((lanes_of(self),) + tuple(source.shape)).contiguous()
+    with _guard():
+      torch.Tensor.set_(self, new)
+    return self
+
   @classmethod
   def __torch_function__(cls, func, types, args=(), kwargs=None):
     kwargs = kwargs or {}
@@ -271,19 +285,6 @@ class Lanes(torch.Tensor):
       raise CannotBatch('{}() of a tensor that stands for many states'.format(name))
 
     # ---- writes: into the lanes' own storage
-    if name == 'set_':
-      if not isinstance(first, Lanes):
-        raise CannotBatch('a lane-varying value set_ into a tensor every state shares')
-      src = args[1] if len(args) > 1 else kwargs.get('source')
-      if len(args) > 2 or src is None:
-        raise CannotBatch('set_ with a storage / offset / strides')
-      if isinstance(src, Lanes):
-        new = plain(src)
-      else:
-        new = src.unsqueeze(0).expand((lanes_of(first),) + tuple(src.shape)).contiguous()
-      with _guard():
-        torch.Tensor.set_(first, new)
-      return first
     if name == '__setitem__':
       if not isinstance(first, Lanes):
         raise CannotBatch('a lane-varying value written into a tensor every state shares')

@@ -303,47 +303,204 @@ def trace(engine, actions=None, max_plays=None, device=None):
       moving.add(e.ch)
 
   cells, nxt, reward, over_a, disc_a, boards, n_frames = graph
-  S = cells.shape[0]
-  movers = sorted(moving)
-  cells_np = cells.cpu().numpy()
-  boards_np = boards.cpu().numpy()
-  static_bytes = {ch: start[ch][0].cpu().numpy().astype(np.uint8).tobytes() for ch in drapes}
-  plane = np.zeros(HW, np.uint8)
-
-  def image_of(s):
-    parts = []
-    for ch in drapes:
-      if ch in moving:
-        k = movers.index(ch)
-        c = int(cells_np[s, k])
-        plane[:] = 0
-        if c < HW:
-          plane[c] = 1
-        parts.append(plane.tobytes())
-      else:
-        parts.append(static_bytes[ch])
-    return tuple(parts)
-
-  images = [image_of(s) for s in range(S)]
-  if images[0] != things0:
-    raise CannotBatch('a moving drape covers more than one cell at the start')
-  orders = [z0] * S
-  hiddens = [hidden0] * S
-  board_bytes = [boards_np[s].tobytes() for s in range(S)]
-  if board_bytes[0] != obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes():
-    raise CannotBatch('the lanes renderer disagrees with the generic tier on the first board')
-  nxt_np, reward_np = nxt.cpu().numpy(), reward.cpu().numpy()
-  edges = {}
-  expanded = nxt_np[:, 0] >= 0
-  for s in np.flatnonzero(expanded):
-    for a in range(N_ACTIONS):
-      t = int(nxt_np[s, a])
-      edges[(int(s), a)] = tabulate._Edge(t, np.float32(reward_np[s, a]), disc_a[a], over_a[a], board_bytes[t])
-
-  _cross_check(probe, actions, drapes, movers, cells_np, edges, images, HW)
-  game = tabulate._finish(engine, probe, H, W, chars, False, things0, backdrop0, z0, images, orders,
-                          hiddens, board_bytes, edges, n_frames)
+  game = _finish_arrays(engine, probe, chars, sorted(moving), start, cells.cpu().numpy(),
+                        nxt.cpu().numpy(), reward.cpu().numpy(), over_a, disc_a,
+                        boards.cpu().numpy(), n_frames, obs, things0, backdrop0, z0, actions)
   game.batched_frames = n_frames
+  return game
+
+
+def _fail(msg):
+  raise tabulate.TabulationError('cannot tabulate this game for the HIP tier: ' + msg)
+
+
+def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, reward, over_a, disc_a,
+                   boards, n_frames, obs0, things0, backdrop0, z0, actions):
+  """`tabulate._finish` for the many-states-per-call walk, on arrays: the same `TracedGame`,
+  field for field (tests/test_tabulate_batched.py compares the two walkers' results), without a
+  Python loop over states - one z-order, no hidden values, drapes only, which is what this tier
+  takes.  cells [S, K] (HW: the mover's curtain is empty) in `movers_sorted` order; nxt [S, 5]
+  (-1: the state was never walked on from); boards uint8 [S, HW]."""
+  H, W = probe.rows, probe.cols
+  HW = H * W
+  S = cells.shape[0]
+  drapes = sorted(probe.things.keys())
+  schedule = []
+  for _, members in probe._update_groups:
+    schedule.extend(ent.character for ent in members)
+  movers = [ch for ch in schedule if ch in movers_sorted]
+  K = len(movers)
+  if not 1 <= K <= gamespec.WIDE_MAX_DYN:
+    _fail('needs between 1 and {} moving things, found {} ({})'.format(
+        gamespec.WIDE_MAX_DYN, K, ''.join(movers) or 'nothing moves'))
+  cells = cells[:, [movers_sorted.index(ch) for ch in movers]]          # schedule order
+  if boards[0].tobytes() != obs0.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes():
+    raise CannotBatch('the lanes renderer disagrees with the generic tier on the first board')
+  start_np = {ch: start[ch][0].cpu().numpy().astype(np.uint8) for ch in drapes}
+  for k, ch in enumerate(movers):
+    if start_np[ch].sum() > 1:
+      raise CannotBatch('moving drape {!r} covers more than one cell at the start'.format(ch))
+
+  dense_reason = None
+  if HW > gamespec.MAX_CELLS:
+    dense_reason = 'the board has more than {} cells'.format(gamespec.MAX_CELLS)
+  elif K > gamespec.MAX_DYN:
+    dense_reason = '{} moving things are more than {} tracked values'.format(K, gamespec.MAX_DYN)
+  elif HW ** K * N_ACTIONS > tabulate.DENSE_MAX_ENTRIES:
+    dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
+        HW, K, tabulate.DENSE_MAX_ENTRIES)
+
+  # a mover that is nowhere (an empty curtain) stands on a cell index it never occupies
+  present = cells < HW
+  absent_cells, st_cells = [], cells.copy()
+  for k, ch in enumerate(movers):
+    gone = ~present[:, k]
+    if gone.any():
+      used = np.unique(cells[present[:, k], k])
+      free = np.setdiff1d(np.arange(HW), used)
+      if len(free) < 1:
+        _fail('{!r} has 1 different states in which it is not on the board; there is room '
+              'for 0'.format(ch))
+      st_cells[gone, k] = free[0]
+      absent_cells.append({int(free[0])})
+    else:
+      absent_cells.append(set())
+
+  game = tabulate.TracedGame()
+  game.rows, game.cols, game.chars = H, W, chars
+  game.z_order = list(z0)
+  game.mode_orders = [list(z0)]
+  game.hidden_paths = []
+  game.frame_in_state = False
+  game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
+  game.movers = movers
+  game.absent_cells = absent_cells
+  game.statics = [(ch, start_np[ch].copy()) for ch in schedule if ch not in movers]
+  if len(game.statics) > gamespec.MAX_STATIC:
+    _fail('more than {} static things'.format(gamespec.MAX_STATIC))
+  game.init_cells = tuple(int(c) for c in st_cells[0])
+  game.init_visible = [int(present[0, k] and boards[0, st_cells[0, k]] == ord(ch))
+                       for k, ch in enumerate(movers)]
+  if not present[0, 0] and dense_reason is None:
+    dense_reason = ('the first moving thing ({!r}) is not on the board after its_showtime()'
+                    .format(movers[0]))
+
+  # ---- every reached board is "backdrop + things in z-order" of the cells alone
+  model = np.broadcast_to(game.backdrop.reshape(-1), (S, HW)).copy()
+  static = dict(game.statics)
+  rows = np.arange(S)
+  for ch in z0:
+    if ch in movers:
+      k = movers.index(ch)
+      on = present[:, k]
+      model[rows[on], cells[on, k]] = ord(ch)
+    else:
+      model[:, static[ch].reshape(-1) != 0] = ord(ch)
+  if not np.array_equal(model, boards):
+    _fail('a rendered board is not "backdrop, then every thing in z-order" of the moving '
+          'things\' cells')
+
+  # ---- hidden performance (examples/boat_race.py:117-151): classes of the watched mover
+  walked = nxt[:, 0] >= 0
+  nxt_safe = np.where(nxt >= 0, nxt, np.arange(S)[:, None])
+  perf = np.zeros((S, N_ACTIONS), np.int64)
+  has_perf = False
+  if engine.hidden_penalty is not None or engine.hidden_performance is not None:
+    has_perf = True
+    if engine.hidden_penalty is not None:
+      who, masks, unit = engine.hidden_penalty
+      what = 'hidden penalty'
+    else:
+      agent, masks = engine.hidden_performance
+      who, what = [agent], 'hidden performance'
+    for ch in who:
+      if ch not in movers:
+        _fail('{} watches {!r}, which never moves'.format(what, ch))
+      if absent_cells[movers.index(ch)]:
+        _fail('{} watches {!r}, which leaves the board'.format(what, ch))
+    cls = np.zeros(HW + 1, np.int64)
+    for j, m in enumerate(masks):
+      cls[:HW][m.detach().cpu().numpy().reshape(-1) != 0] = j + 1
+    if engine.hidden_penalty is not None:
+      for ch in who:
+        perf += int(unit) * cls[st_cells[nxt_safe, movers.index(ch)]]
+    else:
+      n_cls, k = len(masks), movers.index(who[0])
+      a = cls[st_cells[:, k]][:, None]
+      b = cls[st_cells[nxt_safe, k]]
+      fwd = np.where(a == n_cls, 1, a + 1)
+      back = np.where(a == 1, n_cls, a - 1)
+      perf = np.where((a == 0) | (b == 0), 0, (b == fwd).astype(np.int64) - (b == back).astype(np.int64))
+
+  # ---- the state table
+  codes = np.array([ord(ch) for ch in movers])
+  game.dense_reason = dense_reason
+  game.st_cells = st_cells.astype(np.uint16).reshape(S, K)
+  game.st_present = present.reshape(S, K).copy()
+  game.st_board = boards
+  game.st_shows = (present & (boards[rows[:, None], st_cells] == codes[None, :])).astype(np.uint8)
+  game.st_mode = np.zeros(S, np.int32)
+  game.st_next = nxt_safe.astype(np.int32)
+  game.st_reached = np.broadcast_to(walked[:, None], (S, N_ACTIONS)).copy()
+  game.st_reward = np.where(game.st_reached, reward, np.float32(np.nan)).astype(np.float32)
+  over = np.array(over_a, bool)
+  game.st_done = (game.st_reached & over[None, :]).astype(np.uint8)
+  disc = np.array(disc_a, np.float32)
+  game.st_discount = np.where(game.st_reached, disc[None, :], np.float32(1.0)).astype(np.float32)
+  game.st_dcode = np.zeros((S, N_ACTIONS), np.uint8)
+  game.discount_list = [1.0]
+  if walked.any():
+    for a in range(N_ACTIONS):
+      d = float(disc[a])
+      if d != (0.0 if over[a] else 1.0):
+        if d not in game.discount_list[1:]:
+          if len(game.discount_list) == 16:
+            _fail('more than 15 distinct discounts besides the default')
+          game.discount_list.append(d)
+        game.st_dcode[walked, a] = 1 + game.discount_list[1:].index(d)
+  game.st_perf = np.where(game.st_reached, perf, 0).astype(np.int8)
+  game.any_reward = bool((~np.isnan(game.st_reward[game.st_reached])).any())
+  game.has_perf = has_perf
+  game.perf_spec = engine.hidden_performance
+  game.penalty_spec = engine.hidden_penalty
+  game.n_states, game.n_plays = S, n_frames
+
+  # ---- the dense table (one-cell tier), when the game fits it
+  game.n = None
+  if dense_reason is None:
+    n = HW ** K * N_ACTIONS
+    game.n = n
+    game.next_cells = np.zeros((K, n), np.uint16)
+    game.visible = np.zeros((K, n), np.uint8)
+    game.reward = np.full((n,), np.nan, np.float32)
+    game.done = np.zeros((n,), np.uint8)
+    game.discount = np.ones((n,), np.float32)
+    game.dcode = np.zeros((n,), np.uint8)
+    game.perf = np.zeros((n,), np.int8)
+    game.reached = np.zeros((n,), bool)
+    idx = np.arange(n) // N_ACTIONS
+    for k in range(K - 1, -1, -1):
+      game.next_cells[k] = idx % HW
+      idx = idx // HW
+    base = np.zeros(S, np.int64)
+    for k in range(K):
+      base = base * HW + st_cells[:, k]
+    src = np.flatnonzero(walked)
+    for a in range(N_ACTIONS):
+      i = base[src] * N_ACTIONS + a
+      t = nxt_safe[src, a]
+      for k in range(K):
+        game.next_cells[k, i] = st_cells[t, k]
+        game.visible[k, i] = game.st_shows[t, k]
+      game.reward[i] = game.st_reward[src, a]
+      game.done[i] = game.st_done[src, a]
+      game.discount[i] = game.st_discount[src, a]
+      game.dcode[i] = game.st_dcode[src, a]
+      game.perf[i] = game.st_perf[src, a]
+      game.reached[i] = True
+
+  _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, reward, over_a, disc_a,
+               boards)
   return game
 
 
@@ -499,31 +656,42 @@ def _render_states(front, curtains):
   return lanes.plain(front.renderer._board).to(torch.uint8).reshape(n, front.H * front.W).clone()
 
 
-def _cross_check(probe, actions, drapes, movers, cells_np, edges, images, HW):
+def _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, reward, over_a,
+                 disc_a, boards):
   """Replay a sample of the tabulated edges with the user's code on PLAIN tensors (the generic
   tier, one state, one action) and demand the same next state, reward, discount, game-over and
   board: the lane-by-lane frames are the game's own frames."""
-  keys = sorted(edges.keys())
-  rng = np.random.RandomState(20261003)
-  sample = [k for k in keys if k[0] == 0]
-  if len(keys) > len(sample):
-    rest = [k for k in keys if k[0] != 0]
-    pick = rng.choice(len(rest), size=min(CHECK_EDGES, len(rest)), replace=False)
-    sample += [rest[i] for i in sorted(pick)]
   H, W = probe.rows, probe.cols
+  HW = H * W
+  walked = np.flatnonzero(nxt[:, 0] >= 0)
+  rng = np.random.RandomState(20261003)
+  sample = [(0, a) for a in range(N_ACTIONS)]
+  if len(walked) > 1:
+    pick = rng.choice(len(walked), size=min(CHECK_EDGES, len(walked)), replace=False)
+    sample += [(int(walked[i]), int(rng.randint(N_ACTIONS))) for i in sorted(pick)]
+
+  def curtain_of(s, ch):
+    if ch not in movers:
+      return start_np[ch]
+    k = movers.index(ch)
+    mask = np.zeros(HW, np.uint8)
+    if present[s, k]:
+      mask[cells[s, k]] = 1
+    return mask.reshape(H, W)
+
   for s, a in sample:
     eng = tabulate.clone_engine(probe)
-    for i, ch in enumerate(drapes):
-      mask = np.frombuffer(images[s][i], np.uint8).reshape(H, W)
-      eng.things[ch].curtain.copy_(torch.from_numpy(mask.copy()))
+    for ch in drapes:
+      eng.things[ch].curtain.copy_(torch.from_numpy(curtain_of(s, ch).copy()))
     eng._render()
-    obs, reward, discount = eng.play(copy.deepcopy(actions[a]))
-    got_things, _, _ = tabulate._image(eng)
-    e = edges[(s, a)]
-    ok = (got_things == images[e.next] and bool(eng.game_over) == e.over and
-          float(np.float32(discount)) == e.discount and
-          obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes() == e.board and
-          np.array([tabulate.reward_f32(reward)]).view(np.uint32)[0] == np.array([e.reward]).view(np.uint32)[0])
+    obs, got_reward, discount = eng.play(copy.deepcopy(actions[a]))
+    t = int(nxt[s, a])
+    ok = (bool(eng.game_over) == bool(over_a[a]) and float(np.float32(discount)) == float(disc_a[a]) and
+          obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes() == boards[t].tobytes() and
+          np.array([tabulate.reward_f32(got_reward)]).view(np.uint32)[0] ==
+          np.array([np.float32(reward[s, a])]).view(np.uint32)[0])
+    for ch in drapes:
+      ok = ok and np.array_equal(eng.things[ch].curtain.detach().numpy().astype(np.uint8), curtain_of(t, ch))
     if not ok:
       raise CannotBatch('a frame run lane by lane disagrees with the same frame on the generic tier '
                         '(state {}, action {})'.format(s, a))

@@ -99,14 +99,13 @@ def warehouse(art=None, **where):
   return build(ascii_art_to_game, things, Partial, art=art, **where)
 
 
-SMALL_ART = ['#######',
-             '#P    #',
-             '# X   #',
-             '#  #Y #',
-             '# G G #',
-             '#######']
+SMALL_ART = ['######',
+             '#P   #',
+             '# X  #',
+             '# GY #',
+             '######']
 
 
 def small_warehouse(**where):
-  """The same classes on a board the one-frame-per-play walker can finish (a few thousand frames)."""
+  """The same classes on a board the one-frame-per-play walker can finish (a few thousand frames: 12 free cells, some 900 states)."""
   return warehouse(art=SMALL_ART, **where)

@@ -89,7 +89,9 @@ save_table(t, %(out)r)
 ''' % dict(repo=REPO, ref=REFERENCE_EXAMPLES, save=_SAVE_TABLE, out=str(tmp_path / 'table.npz'))
   subprocess.run([sys.executable, '-c', code], check=True)
   game, got = _traced_from_npz(tmp_path / 'table.npz', 5, 5)
-  assert int(got['n_states']) == 8 and int(got['n_plays']) == 80    # 8 x 5, each twice
+  # (round 5: the reference's classes run on lane tensors, a whole level of the state graph per
+  # frame - 25 frames; the one-frame-per-play walker, CAMPX_TABULATE=walk, spends 8 x 5, each twice = 80)
+  assert int(got['n_states']) == 8 and int(got['n_plays']) == 25
   _check_against_fixture(game, _table_fixture())
 
 
