@@ -26,7 +26,8 @@ EXPORTS = ('campx_spec_size', 'campx_flow_scratch_bytes', 'campx_spec_validate',
            'campx_rollout_launch', 'campx_update_launch', 'campx_render_launch',
            'campx_update_render_launch', 'campx_update_render_shared', 'campx_flow_shared',
            'campx_shape_spec_size', 'campx_shape_spec_validate',
-           'campx_shape_rollout_launch',
+           'campx_shape_rollout_launch', 'campx_shape_tables_bytes', 'campx_shape_tables_build',
+           'campx_shape_scratch_bytes',
            'campx_wide_spec_size', 'campx_wide_spec_validate', 'campx_wide_tables_bytes',
            'campx_wide_tables_build', 'campx_wide_reset_launch', 'campx_wide_rollout_launch',
            'campx_wide_rules_size', 'campx_wide_enumerate_launch',
@@ -112,8 +113,14 @@ def _load():
   lib.campx_shape_spec_validate.restype = i32
   lib.campx_shape_spec_validate.argtypes = [shape_p]
   lib.campx_shape_rollout_launch.restype = i32
-  lib.campx_shape_rollout_launch.argtypes = [shape_p, vp, CampxState, vp, vp, CampxOutputs,
+  lib.campx_shape_rollout_launch.argtypes = [shape_p, vp, vp, CampxState, vp, vp, CampxOutputs,
                                              i64, i32, i32, i32, vp]
+  lib.campx_shape_tables_bytes.restype = i64
+  lib.campx_shape_tables_bytes.argtypes = [shape_p]
+  lib.campx_shape_tables_build.restype = i32
+  lib.campx_shape_tables_build.argtypes = [shape_p, vp, i64]
+  lib.campx_shape_scratch_bytes.restype = i64
+  lib.campx_shape_scratch_bytes.argtypes = [shape_p, i64, i32]
   wide_p = ctypes.POINTER(CampxWideSpec)
   lib.campx_wide_spec_size.restype = i32
   lib.campx_wide_spec_size.argtypes = []

@@ -431,7 +431,7 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
                    Tensor& obs, const OptTensor& board, const OptTensor& reward,
                    const OptTensor& discount, const OptTensor& step_done,
                    const OptTensor& bad_count, const OptTensor& bad_flag, bool reset_first,
-                   bool emit_first, const OptTensor& trace) {
+                   bool emit_first, const OptTensor& trace, const OptTensor& tables) {
   TORCH_CHECK(spec_host.device().is_cpu() && spec_host.scalar_type() == at::kByte &&
                   spec_host.is_contiguous() && spec_host.numel() == (int64_t)sizeof(CampxShapeSpec),
               "campx: spec_host must be the CampxShapeSpec blob as a CPU uint8 tensor");
@@ -485,15 +485,25 @@ void shape_rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos,
   out.done = opt_ptr<uint8_t>(step_done);
   out.bad_count = opt_ptr<int32_t>(bad_count);
   out.bad_flag = flag_ptr(bad_flag, dev);
-  if (trace.has_value() && frames) {   // scratch of the two-kernel path: int32 [4, T, B]
-    want(*trace, "trace", at::kInt, dev, {4, T, B});
+  const void* tables_dev = nullptr;
+  if (trace.has_value() && tables.has_value() && frames) {
+    // the frame-major path: its scratch (campx_shape_scratch_bytes) and the game's row tables
+    const int64_t need = campx_shape_scratch_bytes(hs, B, (int32_t)T);
+    TORCH_CHECK(trace->device() == dev && trace->scalar_type() == at::kLong && trace->is_contiguous() &&
+                    need > 0 && trace->numel() * 8 >= need,
+                "campx::shape_rollout: trace must be a contiguous int64 tensor of at least ", need,
+                " bytes on ", dev);
+    TORCH_CHECK(tables->device() == dev && tables->scalar_type() == at::kLong && tables->is_contiguous() &&
+                    tables->numel() * 8 >= campx_shape_tables_bytes(hs),
+                "campx::shape_rollout: tables must hold campx_shape_tables_build()'s blob on ", dev);
     out.trace = reinterpret_cast<uint8_t*>(trace->data_ptr());
+    tables_dev = tables->data_ptr();
   }
   CampxState state{reinterpret_cast<int8_t*>(pos.data_ptr()), reinterpret_cast<uint8_t*>(done.data_ptr()),
                    opt_ptr<float>(ret), nullptr};
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
   check_ok(campx_shape_rollout_launch(
-               hs, reinterpret_cast<const CampxShapeSpec*>(spec_dev.data_ptr()), state,
+               hs, reinterpret_cast<const CampxShapeSpec*>(spec_dev.data_ptr()), tables_dev, state,
                opt_ptr<int8_t>(backdrop_state), opt_ptr<int8_t>(actions), out, B, (int32_t)T,
                reset_first ? 1 : 0, emit_first ? 1 : 0,
                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
@@ -719,7 +729,7 @@ TORCH_LIBRARY(campx, m) {
       "Tensor(c!)? ret, Tensor(d!)? backdrop_state, Tensor? actions, Tensor(e!) obs, "
       "Tensor(f!)? board, Tensor(g!)? reward, Tensor(h!)? discount, Tensor(i!)? step_done, "
       "Tensor(j!)? bad_count, Tensor(k!)? bad_flag, bool reset_first, bool emit_first, "
-      "Tensor(l!)? trace=None) -> ()");
+      "Tensor(l!)? trace=None, Tensor? tables=None) -> ()");
   m.def(
       "wide_rollout(Tensor spec_host, Tensor tables, Tensor(a!) state, Tensor(b!) done, "
       "Tensor(c!)? ret, Tensor? actions, Tensor(d!) obs, Tensor(e!)? board, Tensor(f!)? reward, "

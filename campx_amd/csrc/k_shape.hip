@@ -375,52 +375,110 @@ ShapeParams make_shape_params(const CampxShapeSpec& s) {
 
 
 // ---------------------------------------------------------------------------
-// Two-kernel path for shape games WITHOUT trails (no visible sprite is painted before the
-// first drape: campx/rendering.py:128,150,178 - the backdrop is then the same in every frame
-// of every environment).  A frame's observation is a function of the things' offsets alone,
-// so - as for the one-cell games - the update pass can run ahead and the observation stream
-// can be written frame-major by one-shot blocks with memory-aligned stores, the store pattern
-// that reaches the chip's write ceiling (the serial kernel's "every wave streams its own row
-// per frame" stays at 4.1-4.4 TB/s whatever its instruction count: NOTES.md 3.7).
+// Frame-major path (round 5): update pass + a render pass of one-shot waves with memory-aligned
+// 2 KiB windows - render_kernel's store pattern, the one that reaches the chip's write ceiling
+// (the serial kernel's "every wave streams its own row per frame" stays at 4.2-5.3 TB/s).  Round 3's
+// attempt painted whole boards in LDS per row and lost (NOTES.md 3.7); this one never paints.
 //
-//   shape_update_kernel  one lane per environment, T frames: offsets += delta[action]
-//                        (the same SWAR words as the serial kernel), the frame's offsets
-//                        as four dwords [4][T][B] - the shape trace -, reward / discount /
-//                        done, state back.
-//   shape_render_kernel  block (x, t) writes the 16 KiB window x of frame t (aligned in
-//                        MEMORY to 1 KiB).  Its four waves take the environments whose rows
-//                        overlap the window in turn: board = backdrop + things at their
-//                        offsets, in LDS; expand into the window's LDS image (8 cells per
-//                        lane, every layer: v_perm_b32 lookups), clipped to the window; then
-//                        all waves stream the image out, one aligned KiB per wave-instruction.
-//                        A row that straddles two windows is built by both blocks (one row
-//                        in six at Hello World's size).
-// A/B knobs: bytes of a frame per block and waves per block.  A row that straddles two
-// windows is built by both blocks, so small windows repeat work (16 KiB at Hello World's
-// 3 276-byte rows: 7 boards per 5 rows of output, and the whole kernel ran at 3.7 TB/s -
-// instruction-bound); 64 KiB: 22 per 20.
-#ifndef CAMPX_SHAPE_SPAN_KB
-#define CAMPX_SHAPE_SPAN_KB 64
+// An environment-frame of the observation is L planes of H rows of W bytes 0 / 1: L * H "slots"
+// of W bits.  A slot is computed ARITHMETICALLY from 64-bit row words:
+//     thing z (multi-cell): rowbits_z[dc][(r - dr) mod H] - the thing's mask, every column
+//                           rotation precomputed (the tables blob: W * H words per thing);
+//     thing z (one cell):   (r == its row) ? 1 << its column : 0;
+//     front to back: visible_z = word_z & ~covered, covered |= word_z;
+//     backdrop of layer l:  (static_l[r] & ~trails) | trail words of layer l, & ~covered.
+// A wave computes the <= 2 KiB / W + 2 slots its window overlaps (one slot per lane, into LDS),
+// then every lane takes the 16 bits of its 16-byte chunk from two neighbouring slots - output
+// byte k of the frame is bit (k mod W) of slot k / W, whatever plane or environment it falls
+// in - expands them to bytes and stores: aligned, contiguous KiB per wave-instruction.
+//
+// Trails (sprites painted before the first drape write into the backdrop for good,
+// campx/rendering.py:128,150): the update pass keeps, per environment, one W-bit word per trail
+// sprite and board row ("painted by this sprite last") and writes them out every kShapeKey-th
+// frame (a KEYFRAME, 8 * S * H bytes per environment: 1.6 % of the observation stream for Hello
+// World); a render wave starts from the keyframe at or before its frame and applies the at most
+// kShapeKey - 1 frames of sprite positions since, which the offset trace holds anyway.  A frame
+// that began with a rebuild (the episode had ended) carries a flag in the trace: trails restart.
+#ifndef CAMPX_SHAPE_KEY
+#define CAMPX_SHAPE_KEY 4
 #endif
-#ifndef CAMPX_SHAPE_RENDER_WAVES
-#define CAMPX_SHAPE_RENDER_WAVES 8
+constexpr int kShapeKey = CAMPX_SHAPE_KEY;
+constexpr uint32_t kShapeTablesMagic = 0x54485343u;   // 'CSHT'
+#ifndef CAMPX_SHAPE_SPLIT_WAVES
+#define CAMPX_SHAPE_SPLIT_WAVES 2
 #endif
-constexpr int kRenderSpan = CAMPX_SHAPE_SPAN_KB * 1024;   // bytes of a frame per block
-constexpr int kRenderBlockWaves = CAMPX_SHAPE_RENDER_WAVES;
+#ifndef CAMPX_SHAPE_SPLIT_WIN
+#define CAMPX_SHAPE_SPLIT_WIN 2
+#endif
+constexpr int kSplitWaves = CAMPX_SHAPE_SPLIT_WAVES, kSplitWin = CAMPX_SHAPE_SPLIT_WIN;
+constexpr uint32_t kSplitSpan = 1024u * kSplitWin;
+constexpr int kSplitSlots = (int)kSplitSpan / 16 + 8;      // W >= 16: span / W + 2 slots, rounded up
 
-__global__ __launch_bounds__(256) void shape_update_kernel(
-    ShapeParams sp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out,
-    uint32_t* __restrict__ trace, int64_t B, int32_t T, int32_t reset_first) {
+struct ShapeTablesHeader {       // the device blob campx_shape_tables_build() fills
+  uint32_t magic;
+  int32_t rows, cols, n_layers, n_things, first_drape;
+  uint32_t static_off;           // uint64 [L][H]: the art's backdrop, one word per layer and row
+  uint32_t rowbits_off[CAMPX_SHAPE_MAX_THINGS];   // uint64 [W][H] per multi-cell thing; 0: none
+  uint32_t bytes;
+};
+
+struct FastDiv {                 // exact n / d for 32-bit n (Granlund & Montgomery 1994, fig. 4.1)
+  uint32_t m, sh1, sh2, d;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const {
+    const uint32_t hi = __umulhi(m, n);
+    return (((n - hi) >> sh1) + hi) >> sh2;
+  }
+};
+static FastDiv make_div(uint32_t d) {
+  FastDiv f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.sh1 = l < 1 ? l : 1;
+  f.sh2 = l > 0 ? l - 1 : 0;
+  f.d = d;
+  return f;
+}
+
+struct ShapeSplitParams {
+  int32_t rows, cols, n_layers, n_things, first_drape, n_trail;
+  uint32_t R, slab_bytes, shift_base, shift_slab, n_slots;   // n_slots = B * L * H
+  FastDiv by_w, by_lh, by_h;
+  // per thing (z-order): layer | visible << 8 | one_cell << 9 | art row << 16 | art col << 24
+  uint32_t thing[CAMPX_SHAPE_MAX_THINGS];
+  uint32_t trail_z[CAMPX_SHAPE_MAX_THINGS];    // the visible sprites before the first drape
+  const uint64_t* static_rows;                 // device: [L][H]
+  const uint64_t* rowbits[CAMPX_SHAPE_MAX_THINGS];   // device: [W][H], or null
+  const uint32_t* trace;                       // [4][T][B] offsets (bit 7 of orow0: rebuilt)
+  const uint64_t* keys;                        // [ceil(T / key)][B][S][H]
+  int64_t B, plane;                            // plane = T * B
+};
+
+__device__ __forceinline__ uint32_t wrap_add(uint32_t a, uint32_t d, uint32_t n) {
+  const uint32_t t = a + d;
+  return t >= n ? t - n : t;
+}
+
+// The update pass: one lane per environment, one wave per workgroup (its 64 environments' trail
+// words in LDS: [S * H][64] uint64, 8 * S * H * 64 bytes of dynamic shared memory).
+__global__ __launch_bounds__(kWave) void shape_update_split_kernel(
+    ShapeParams sp, ShapeSplitParams pp, const CampxShapeSpec* __restrict__ spec, CampxState st,
+    int8_t* __restrict__ backdrop_state, const int8_t* __restrict__ actions, CampxOutputs out,
+    uint32_t* __restrict__ trace, uint64_t* __restrict__ keys, int64_t B, int32_t T, int32_t reset_first) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t trail[];     // [S * H][64]
   __shared__ ShapeAction act[CAMPX_N_ACTIONS];   // (indexed by a lane's action: LDS, not kernarg)
-  if (threadIdx.x < CAMPX_N_ACTIONS) act[threadIdx.x] = sp.act[threadIdx.x];
+  const int lane = threadIdx.x;
+  if (lane < CAMPX_N_ACTIONS) act[lane] = sp.act[lane];
+  const int64_t env0 = (int64_t)blockIdx.x * kWave;
+  const int64_t env = env0 + lane;
+  const bool live = env < B;
+  const int H = sp.rows, W = sp.cols, HW = H * W, N = sp.n_things, S = pp.n_trail, SH = S * H;
+  for (int i = 0; i < SH; ++i) trail[i * kWave + lane] = 0ull;
   __syncthreads();
-  const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= B) return;
-  const int H = sp.rows, W = sp.cols, N = sp.n_things;
   uint32_t orow[2] = {0u, 0u}, ocol[2] = {0u, 0u};
   int over = 0, bad = 0;
   float ret = 0.0f;
-  if (!reset_first) {
+  if (live && !reset_first) {
 #pragma unroll
     for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
       if (k < N) {
@@ -429,7 +487,32 @@ __global__ __launch_bounds__(256) void shape_update_kernel(
       }
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
+    if (S > 0 && backdrop_state) {
+      // the carried backdrop -> trail words: a cell that differs from the art's backdrop was
+      // painted by the trail sprite of that layer
+      const uint8_t* mine = reinterpret_cast<const uint8_t*>(backdrop_state) + env * HW;
+      for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+          const uint32_t v = mine[r * W + c], art = spec->backdrop[r * W + c];
+          if (v != art)
+            for (int s = 0; s < S; ++s)
+              if ((pp.thing[pp.trail_z[s]] & 0xffu) == v) trail[(s * H + r) * kWave + lane] |= 1ull << c;
+        }
+    }
   }
+  auto paint_trails = [&]() {        // every trail sprite, back to front: mine, nobody else's
+    for (int s = 0; s < S; ++s) {
+      const uint32_t z = pp.trail_z[s], th = pp.thing[z];
+      const int sh = 8 * (z & 3);
+      const uint32_t r = wrap_add(th >> 16 & 0xffu, ((z < 4 ? orow[0] : orow[1]) >> sh) & 0xffu, (uint32_t)H);
+      const uint32_t c = wrap_add(th >> 24, ((z < 4 ? ocol[0] : ocol[1]) >> sh) & 0xffu, (uint32_t)W);
+      const uint64_t bit = 1ull << c;
+      for (int q = 0; q < S; ++q) {
+        uint64_t& w = trail[(q * H + r) * kWave + lane];
+        w = q == s ? (w | bit) : (w & ~bit);
+      }
+    }
+  };
   const int64_t plane = (int64_t)T * B;
   constexpr int kAhead = 16;                    // actions in flight per lane
   for (int t0 = 0; t0 < T; t0 += kAhead) {
@@ -437,33 +520,38 @@ __global__ __launch_bounds__(256) void shape_update_kernel(
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) {
       const int t = t0 + j < T ? t0 + j : T - 1;
-      a16[j] = actions[(int64_t)t * B + env];
+      a16[j] = live ? (int)actions[(int64_t)t * B + env] : 4;
     }
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < kAhead; ++j) {
       const int t = t0 + j;
-      if (t < T) {
-        const int a = a16[j];
-        const bool valid = (unsigned)a < (unsigned)CAMPX_N_ACTIONS;
-        bad += valid ? 0 : 1;
-        if (over) {   // a fresh make_game() + its_showtime()
-          orow[0] = orow[1] = ocol[0] = ocol[1] = 0u;
-          over = 0;
-          ret = 0.0f;
-        }
-        float reward = __builtin_nanf("");
-        if (valid) {
-          const ShapeAction e = act[a];
-          orow[0] = swar_add_wrap(orow[0], e.drow[0], (uint32_t)H);
-          ocol[0] = swar_add_wrap(ocol[0], e.dcol[0], (uint32_t)W);
-          orow[1] = swar_add_wrap(orow[1], e.drow[1], (uint32_t)H);
-          ocol[1] = swar_add_wrap(ocol[1], e.dcol[1], (uint32_t)W);
-          reward = e.reward;
-          if (e.flags & 2u) ret += reward;
-          if (e.flags & 1u) over = 1;   // plot.py:183-184 (discount 0 on that frame)
-        }
+      if (t >= T) break;        // (uniform)
+      const int a = a16[j];
+      const bool valid = (unsigned)a < (unsigned)CAMPX_N_ACTIONS;
+      bad += (valid || !live) ? 0 : 1;
+      uint32_t rebuilt = 0u;
+      if (over) {   // a fresh make_game() + its_showtime()
+        orow[0] = orow[1] = ocol[0] = ocol[1] = 0u;
+        over = 0;
+        ret = 0.0f;
+        rebuilt = 0x80u;
+        for (int i = 0; i < SH; ++i) trail[i * kWave + lane] = 0ull;
+      }
+      float reward = __builtin_nanf("");
+      if (valid) {
+        const ShapeAction e = act[a];
+        orow[0] = swar_add_wrap(orow[0], e.drow[0], (uint32_t)H);
+        ocol[0] = swar_add_wrap(ocol[0], e.dcol[0], (uint32_t)W);
+        orow[1] = swar_add_wrap(orow[1], e.drow[1], (uint32_t)H);
+        ocol[1] = swar_add_wrap(ocol[1], e.dcol[1], (uint32_t)W);
+        reward = e.reward;
+        if (e.flags & 2u) ret += reward;
+        if (e.flags & 1u) over = 1;   // plot.py:183-184 (discount 0 on that frame)
+      }
+      if (S > 0) paint_trails();
+      if (live) {
         const int64_t at = (int64_t)t * B + env;
-        trace[at] = orow[0];
+        trace[at] = orow[0] | rebuilt;
         trace[plane + at] = orow[1];
         trace[2 * plane + at] = ocol[0];
         trace[3 * plane + at] = ocol[1];
@@ -471,204 +559,298 @@ __global__ __launch_bounds__(256) void shape_update_kernel(
         if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
         if (out.done) out.done[at] = (uint8_t)over;
       }
+      if (S > 0 && t % kShapeKey == 0) {
+        // keyframe: this wave's 64 environments x S * H words, contiguous in [key][B][S][H]
+        uint64_t* to = keys + ((int64_t)(t / kShapeKey) * B + env0) * SH;
+        const int64_t n_words = (B - env0 < kWave ? B - env0 : (int64_t)kWave) * SH;
+        for (int i = lane; i < n_words; i += kWave) {
+          const int e = i / SH, w = i - e * SH;
+          to[i] = trail[w * kWave + e];
+        }
+      }
     }
   }
+  if (live) {
 #pragma unroll
-  for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
-    if (k < N) {
-      st.pos[(int64_t)(2 * k) * B + env] = (int8_t)((orow[k >> 2] >> (8 * (k & 3))) & 0xffu);
-      st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)((ocol[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
+      if (k < N) {
+        st.pos[(int64_t)(2 * k) * B + env] = (int8_t)((orow[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        st.pos[(int64_t)(2 * k + 1) * B + env] = (int8_t)((ocol[k >> 2] >> (8 * (k & 3))) & 0xffu);
+      }
+    st.done[env] = (uint8_t)over;
+    if (st.ret) st.ret[env] = ret;
+    if (S > 0 && backdrop_state) {
+      uint8_t* mine = reinterpret_cast<uint8_t*>(backdrop_state) + env * HW;
+      for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) {
+          uint32_t v = spec->backdrop[r * W + c];
+          for (int s = 0; s < S; ++s)
+            if ((trail[(s * H + r) * kWave + lane] >> c) & 1ull) v = pp.thing[pp.trail_z[s]] & 0xffu;
+          mine[r * W + c] = (uint8_t)v;
+        }
     }
-  st.done[env] = (uint8_t)over;
-  if (st.ret) st.ret[env] = ret;
+  }
   report_bad_actions(out, bad);
 }
 
-struct ShapeRenderParams {
-  uint32_t R;                 // bytes of an environment's row of the stream (L*H*W, or H*W: flat board)
-  uint32_t m, sh1, sh2;       // exact n / R for 32-bit n (Granlund-Montgomery)
-  uint32_t slab_bytes;        // B * R, a multiple of 16
-  uint32_t shift_base, shift_slab;   // (address of frame 0) and slab_bytes modulo 1 KiB
-};
+// 16 bits -> 16 bytes 0 / 1 (bit i -> byte i)
+__device__ __forceinline__ u32x4 bits_to_bytes(uint32_t b) {
+  auto four = [](uint32_t n) { return ((n & 0xfu) * 0x00204081u) & 0x01010101u; };
+  return u32x4{four(b), four(b >> 4), four(b >> 8), four(b >> 12)};
+}
 
-template <bool kBoard>
-__global__ __launch_bounds__(kRenderBlockWaves * kWave) void shape_render_kernel(
-    ShapeParams sp, ShapeRenderParams rp, const CampxShapeSpec* __restrict__ spec,
-    const uint32_t* __restrict__ trace, int8_t* __restrict__ dst, int64_t B, int64_t plane) {
-  __shared__ __attribute__((aligned(16))) int8_t image[kRenderSpan];
-  __shared__ __attribute__((aligned(16))) uint8_t lds_board[kRenderBlockWaves][CAMPX_SHAPE_MAX_CELLS];
-  __shared__ __attribute__((aligned(16))) uint8_t lds_backdrop[CAMPX_SHAPE_MAX_CELLS];
-  __shared__ uint16_t lds_cells[CAMPX_SHAPE_MAX_LIST];
-  __shared__ uint32_t lds_char[CAMPX_MAX_LAYERS / 4];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int H = sp.rows, W = sp.cols, HW = H * W, L = sp.n_layers, N = sp.n_things;
-  // windows are aligned in memory: they start `shift` bytes before the frame (offsets
-  // modulo 2^32: the head window's bytes before the frame fail the one bounds test)
-  const uint32_t shift = (rp.shift_base + blockIdx.y * rp.shift_slab) & 1023u;
-  if ((uint64_t)blockIdx.x * kRenderSpan >= (uint64_t)rp.slab_bytes + shift) return;
-  const uint32_t w0 = blockIdx.x * (uint32_t)kRenderSpan - shift;          // first byte of the window
-  const uint32_t wlo = blockIdx.x == 0 ? 0u : w0;                           // ... inside the frame
-  const uint32_t whi_end = (w0 + kRenderSpan < rp.slab_bytes) ? w0 + kRenderSpan : rp.slab_bytes;
-  const uint32_t h0 = __umulhi(rp.m, wlo), h1 = __umulhi(rp.m, whi_end - 1u);
-  const uint32_t first_row = (((wlo - h0) >> rp.sh1) + h0) >> rp.sh2;
-  const uint32_t last_row = (((whi_end - 1u - h1) >> rp.sh1) + h1) >> rp.sh2;
+__global__ __launch_bounds__(kSplitWaves * kWave) void shape_render_split_kernel(
+    ShapeSplitParams pp, int8_t* __restrict__ dst) {
+  __shared__ __attribute__((aligned(16))) uint64_t slots_all[kSplitWaves][kSplitSlots];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t t = blockIdx.y;
+  uint32_t bx = blockIdx.x;
+  bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);     // gridDim.x is a multiple of 8: one XCD, one eighth
+  const uint32_t shift = (pp.shift_base + t * pp.shift_slab) & (kSplitSpan - 1u);
+  const uint32_t widx = bx * (uint32_t)kSplitWaves + wave;
+  if ((uint64_t)widx * kSplitSpan >= (uint64_t)pp.slab_bytes + shift) return;
+  const uint32_t woff0 = widx * kSplitSpan - shift;
+  const uint32_t wlo = widx * kSplitSpan < shift ? 0u : woff0;
+  const uint32_t wend = (woff0 + kSplitSpan - 1u < pp.slab_bytes) ? woff0 + kSplitSpan - 1u : pp.slab_bytes - 1u;
+  const uint32_t s_first = pp.by_w.div(wlo);
+  uint32_t s_last = pp.by_w.div(wend) + 1u;                    // (a chunk's tail reaches into the next slot)
+  s_last = s_last < pp.n_slots ? s_last : pp.n_slots - 1u;
+  uint64_t* slots = slots_all[wave];
+  const int H = pp.rows, W = pp.cols, N = pp.n_things, S = pp.n_trail, FD = pp.first_drape;
+  const uint32_t LH = (uint32_t)(pp.n_layers * H);
+  const uint32_t* frame_trace = pp.trace + (int64_t)t * pp.B;
+  const uint32_t key_frame = t - t % (uint32_t)kShapeKey;
 
-  for (int i = threadIdx.x; i < sp.n_list; i += kRenderBlockWaves * kWave) lds_cells[i] = spec->cells[i];
-  for (int i = threadIdx.x; 4 * i < HW; i += kRenderBlockWaves * kWave)
-    reinterpret_cast<uint32_t*>(lds_backdrop)[i] = reinterpret_cast<const uint32_t*>(spec->backdrop)[i];
-  if (kBoard && threadIdx.x < CAMPX_MAX_LAYERS / 4) lds_char[threadIdx.x] = sp.layer_char[threadIdx.x];
-  __syncthreads();
-
-  uint8_t* board = lds_board[wave];
-  const uint32_t* frame_trace = trace + (int64_t)blockIdx.y * B;
-  for (uint32_t row = first_row + (uint32_t)wave; row <= last_row; row += kRenderBlockWaves) {
-    // the things' offsets in environment `row` at this frame (the same address in every lane)
-    const uint32_t or0 = __builtin_amdgcn_readfirstlane(frame_trace[row]);
-    const uint32_t or1 = __builtin_amdgcn_readfirstlane(frame_trace[plane + row]);
-    const uint32_t oc0 = __builtin_amdgcn_readfirstlane(frame_trace[2 * plane + row]);
-    const uint32_t oc1 = __builtin_amdgcn_readfirstlane(frame_trace[3 * plane + row]);
-    // board = backdrop, then every thing back to front (one wave: LDS operations complete
-    // in order, no barrier)
-    for (int base = 0; base * 16 < HW; base += kWave) {
-      const int i = base + lane;
-      if (i * 16 < HW) reinterpret_cast<u32x4*>(board)[i] = reinterpret_cast<const u32x4*>(lds_backdrop)[i];
+  for (uint32_t base = s_first; base <= s_last; base += kWave) {
+    uint32_t g = base + lane;
+    g = g <= s_last ? g : s_last;                 // (surplus lanes repeat the last slot)
+    const uint32_t env = pp.by_lh.div(g);
+    const uint32_t rem = g - env * LH;
+    const uint32_t l = pp.by_h.div(rem);
+    const uint32_t r = rem - l * (uint32_t)H;
+    const uint32_t or0 = frame_trace[env] & ~0x80u, oc0 = frame_trace[2 * pp.plane + env];
+    uint32_t or1 = 0u, oc1 = 0u;
+    if (N > 4) {
+      or1 = frame_trace[pp.plane + env];
+      oc1 = frame_trace[3 * pp.plane + env];
     }
-    for (int z = 0; z < N; ++z) {
-      const uint32_t th = sp.thing[z];
-      if (!((th >> 28) & 1u)) continue;
-      const int begin = (int)(th & 0x7ffu), n = (int)((th >> 11) & 0xfffu);
-      const uint8_t layer = (uint8_t)((th >> 23) & 0x1fu);
+    // ---- things at and in front of the first drape, front to back
+    uint64_t covered = 0ull, mine = 0ull;
+    for (int z = N - 1; z >= FD; --z) {         // (uniform)
+      const uint32_t th = pp.thing[z];
+      if (!((th >> 8) & 1u)) continue;
       const int sh = 8 * (z & 3);
-      const int dr = (int)(((z < 4 ? or0 : or1) >> sh) & 0xffu);
-      const int dc = (int)(((z < 4 ? oc0 : oc1) >> sh) & 0xffu);
-      if (n == 1) {
-        const uint32_t packed = sp.one_cell[z];
-        int r = (int)(packed >> 8) + dr, c = (int)(packed & 0xffu) + dc;
-        r = r >= H ? r - H : r;
-        c = c >= W ? c - W : c;
-        if (lane == 0) board[r * W + c] = layer;
-        continue;
-      }
-      for (int base = 0; base < n; base += kWave) {
-        const int i = base + lane;
-        if (i < n) {
-          const uint32_t packed = lds_cells[begin + i];
-          int r = (int)(packed >> 8) + dr, c = (int)(packed & 0xffu) + dc;
-          r = r >= H ? r - H : r;
-          c = c >= W ? c - W : c;
-          board[r * W + c] = layer;
-        }
-      }
-    }
-    // expand into the window's image: 8 cells per lane (the launcher admits H * W % 4 == 0,
-    // H * W >= 8 only).  A row wholly inside the window - most - writes 8 bytes per layer
-    // unconditionally; the window's first and last row are clipped, two guarded 4-byte
-    // writes per layer.
-    const uint32_t row0 = row * rp.R - w0;          // the row's first byte, relative to the window
-    const bool inside = row0 <= (uint32_t)kRenderSpan - rp.R;   // (uniform; a wrapped row0 is huge)
-    if (inside && !kBoard && L <= 8) {
-      for (int qbase = 0; 8 * qbase < HW; qbase += kWave) {
-        const int q = qbase + lane;
-        if (8 * q >= HW) continue;
-        const uint32_t at = (uint32_t)(8 * q + 8 <= HW ? 8 * q : HW - 8);
-        const uint32_t b0 = *reinterpret_cast<const uint32_t*>(board + at);
-        const uint32_t b1 = *reinterpret_cast<const uint32_t*>(board + at + 4);
-        int8_t* to = image + row0 + at;             // (4-byte aligned: two dword writes)
-        uint32_t hi = 0u, lo = 1u;
-        for (int l = 0; l < L; ++l) {
-          reinterpret_cast<uint32_t*>(to)[0] = __builtin_amdgcn_perm(hi, lo, b0);
-          reinterpret_cast<uint32_t*>(to)[1] = __builtin_amdgcn_perm(hi, lo, b1);
-          to += HW;
-          hi = (l == 3) ? 1u : hi << 8;
-          lo = lo << 8;
-        }
-      }
-      continue;
-    }
-    for (int qbase = 0; 8 * qbase < HW; qbase += kWave) {
-      const int q = qbase + lane;
-      if (8 * q >= HW) continue;
-      const uint32_t at = (uint32_t)(8 * q + 8 <= HW ? 8 * q : HW - 8);
-      const uint32_t b0 = *reinterpret_cast<const uint32_t*>(board + at);
-      const uint32_t b1 = *reinterpret_cast<const uint32_t*>(board + at + 4);
-      if (kBoard) {
-        const uint8_t* ch = reinterpret_cast<const uint8_t*>(lds_char);
-        auto chars = [&](uint32_t b4) {
-          return (uint32_t)ch[b4 & 0xffu] | ((uint32_t)ch[(b4 >> 8) & 0xffu] << 8) |
-                 ((uint32_t)ch[(b4 >> 16) & 0xffu] << 16) | ((uint32_t)ch[b4 >> 24] << 24);
-        };
-        const uint32_t io = row0 + at;
-        if (io < (uint32_t)kRenderSpan) *reinterpret_cast<uint32_t*>(image + io) = chars(b0);
-        if (io + 4u < (uint32_t)kRenderSpan) *reinterpret_cast<uint32_t*>(image + io + 4u) = chars(b1);
-      } else if (L <= 8) {
-        uint32_t hi = 0u, lo = 1u, io = row0 + at;    // 1 << 8 l as {hi, lo}: see shape_rollout_kernel
-        for (int l = 0; l < L; ++l) {
-          if (io < (uint32_t)kRenderSpan)
-            *reinterpret_cast<uint32_t*>(image + io) = __builtin_amdgcn_perm(hi, lo, b0);
-          if (io + 4u < (uint32_t)kRenderSpan)
-            *reinterpret_cast<uint32_t*>(image + io + 4u) = __builtin_amdgcn_perm(hi, lo, b1);
-          io += (uint32_t)HW;
-          hi = (l == 3) ? 1u : hi << 8;
-          lo = lo << 8;
-        }
+      const uint32_t dr = ((z < 4 ? or0 : or1) >> sh) & 0xffu, dc = ((z < 4 ? oc0 : oc1) >> sh) & 0xffu;
+      uint64_t w;
+      if ((th >> 9) & 1u) {
+        const uint32_t rr = wrap_add(th >> 16 & 0xffu, dr, (uint32_t)H), cc = wrap_add(th >> 24, dc, (uint32_t)W);
+        w = rr == r ? 1ull << cc : 0ull;
       } else {
-        uint32_t lc = 0u, io = row0 + at;
-        for (int l = 0; l < L; ++l) {
-          if (io < (uint32_t)kRenderSpan)
-            *reinterpret_cast<uint32_t*>(image + io) = ((0x80808080u - (b0 ^ lc)) & 0x80808080u) >> 7;
-          if (io + 4u < (uint32_t)kRenderSpan)
-            *reinterpret_cast<uint32_t*>(image + io + 4u) = ((0x80808080u - (b1 ^ lc)) & 0x80808080u) >> 7;
-          io += (uint32_t)HW;
-          lc += 0x01010101u;
+        const uint32_t src = r >= dr ? r - dr : r + (uint32_t)H - dr;
+        w = pp.rowbits[z][dc * (uint32_t)H + src];
+      }
+      mine |= ((th & 0xffu) == l) ? (w & ~covered) : 0ull;
+      covered |= w;
+    }
+    // ---- the backdrop's row of this layer: the art, under the trails
+    uint64_t bd = pp.static_rows[l * (uint32_t)H + r];
+    if (S > 0) {
+      const uint64_t* key = pp.keys + ((int64_t)(key_frame / (uint32_t)kShapeKey) * pp.B + env) * (S * H);
+      uint64_t tw[CAMPX_SHAPE_MAX_THINGS];
+#pragma unroll
+      for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) tw[s] = s < S ? key[s * H + r] : 0ull;
+      for (uint32_t f = key_frame + 1u; f <= t; ++f) {     // (uniform: at most kShapeKey - 1 frames)
+        const uint32_t* ft = pp.trace + (int64_t)f * pp.B;
+        const uint32_t fr0 = ft[env], fc0 = ft[2 * pp.plane + env];
+        uint32_t fr1 = 0u, fc1 = 0u;
+        if (FD > 4) {
+          fr1 = ft[pp.plane + env];
+          fc1 = ft[3 * pp.plane + env];
+        }
+        if (fr0 & 0x80u) {
+#pragma unroll
+          for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) tw[s] = 0ull;
+        }
+#pragma unroll
+        for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) {
+          if (s < S) {
+            const uint32_t z = pp.trail_z[s], th = pp.thing[z];
+            const int sh = 8 * (z & 3);
+            const uint32_t rr = wrap_add(th >> 16 & 0xffu, (((z < 4 ? fr0 : fr1) & ~0x80u) >> sh) & 0xffu, (uint32_t)H);
+            const uint32_t cc = wrap_add(th >> 24, ((z < 4 ? fc0 : fc1) >> sh) & 0xffu, (uint32_t)W);
+            const uint64_t bit = rr == r ? 1ull << cc : 0ull;
+#pragma unroll
+            for (int q = 0; q < CAMPX_SHAPE_MAX_THINGS; ++q)
+              if (q < S) tw[q] = q == s ? (tw[q] | bit) : (tw[q] & ~bit);
+          }
         }
       }
-    }
-  }
-  __syncthreads();
-  // ---- out: every store instruction of a wave is one aligned, contiguous KiB
-  const int8_t* frame = dst + (int64_t)blockIdx.y * rp.slab_bytes;   // uniform
+      uint64_t any = 0ull, here = 0ull;
 #pragma unroll
-  for (int j = 0; j < kRenderSpan / (kRenderBlockWaves * kWave * 16); ++j) {
-    const uint32_t o = ((uint32_t)j * kRenderBlockWaves * kWave + threadIdx.x) * 16u;
-    const uint32_t off = w0 + o;
-    if (off < rp.slab_bytes)        // (chunks before the frame wrap to huge offsets; the slab is whole chunks)
-      store16_streaming_at(frame, off, *reinterpret_cast<const u32x4*>(image + o));
+      for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s)
+        if (s < S) {
+          any |= tw[s];
+          here |= ((pp.thing[pp.trail_z[s]] & 0xffu) == l) ? tw[s] : 0ull;
+        }
+      bd = (bd & ~any) | here;
+    }
+    const uint32_t at = base - s_first + lane;
+    if (at < (uint32_t)kSplitSlots) slots[at] = mine | (bd & ~covered);
+  }
+  // ---- out: every lane's 16 bytes are 16 bits of two neighbouring slots
+  int8_t* frame = dst + (int64_t)t * pp.slab_bytes;
+#pragma unroll
+  for (int j = 0; j < kSplitWin; ++j) {
+    const uint32_t off = woff0 + (uint32_t)j * 1024u + lane * 16u;
+    const bool inside = off < pp.slab_bytes;          // (bytes before the frame wrap to huge offsets)
+    const uint32_t o = inside ? off : wlo;
+    const uint32_t s = pp.by_w.div(o);
+    const uint32_t c = o - s * (uint32_t)W;
+    const uint32_t idx = s - s_first;
+    const uint64_t lo = slots[idx], hi = slots[idx + 1u < (uint32_t)kSplitSlots ? idx + 1u : idx];
+    const uint32_t bits = (uint32_t)(lo >> c) | (uint32_t)((hi << 1) << ((uint32_t)W - 1u - c));
+    if (inside) store16_streaming_at(frame, off, bits_to_bytes(bits));
   }
 }
 
-// Can this launch take the two-kernel path?  No trails, every frame kept back to back, rows
-// of whole dwords and frames of whole 16-byte chunks below 4 GiB, boards of at least 8 cells.
-bool shape_split_ok(const CampxShapeSpec& s, const CampxOutputs& out, int64_t B, int32_t T,
-                    int32_t emit_first) {
-  if (!out.trace || emit_first || T < 1 || T > 65535) return false;
+static inline uint32_t align8(uint32_t x) { return (x + 7u) & ~7u; }
+
+// Which games take the frame-major path: rows of 16 to 64 cells (a 16-byte chunk then spans at
+// most two slots, a slot is one 64-bit word), every trail sprite's words fitting the update
+// pass's LDS.
+static bool shape_tables_ok(const CampxShapeSpec& s) {
+  if (s.cols < 16 || s.cols > 64) return false;
+  int n_trail = 0;
+  for (int k = 0; k < s.first_drape; ++k) n_trail += s.things[k].visible ? 1 : 0;
+  if (n_trail * s.rows > 120) return false;          // 8 * S * H * 64 bytes of LDS per update wave
   for (int k = 0; k < s.first_drape; ++k)
-    if (s.things[k].visible) return false;
-  const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
-  if (HW % 4 || HW < 8 || (B * R) % 16 || B * R >= (1ll << 32) - 65536) return false;
-  if (out.board && ((B * HW) % 16 || out.board_t_stride != B * HW)) return false;
+    if (s.things[k].visible && s.things[k].n_cells != 1) return false;   // (sprites are one cell)
+  return true;
+}
+
+int64_t shape_tables_bytes(const CampxShapeSpec& s) {
+  if (!shape_tables_ok(s)) return 0;
+  int64_t bytes = align8((uint32_t)sizeof(ShapeTablesHeader)) + 8ll * s.n_layers * s.rows;
+  for (int k = s.first_drape; k < s.n_things; ++k)
+    if (s.things[k].visible && s.things[k].n_cells > 1) bytes += 8ll * s.cols * s.rows;
+  return bytes;
+}
+
+int32_t shape_tables_build(const CampxShapeSpec& s, void* host, int64_t bytes) {
+  if (bytes < shape_tables_bytes(s) || !shape_tables_ok(s)) return CAMPX_EINVAL;
+  memset(host, 0, (size_t)bytes);
+  ShapeTablesHeader* h = static_cast<ShapeTablesHeader*>(host);
+  char* blob = static_cast<char*>(host);
+  const int H = s.rows, W = s.cols;
+  h->magic = kShapeTablesMagic;
+  h->rows = H;
+  h->cols = W;
+  h->n_layers = s.n_layers;
+  h->n_things = s.n_things;
+  h->first_drape = s.first_drape;
+  uint32_t at = align8((uint32_t)sizeof(ShapeTablesHeader));
+  h->static_off = at;
+  uint64_t* st = reinterpret_cast<uint64_t*>(blob + at);
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) st[s.backdrop[r * W + c] * H + r] |= 1ull << c;
+  at += 8u * (uint32_t)(s.n_layers * H);
+  for (int k = s.first_drape; k < s.n_things; ++k) {
+    const CampxShapeThing& th = s.things[k];
+    if (!th.visible || th.n_cells <= 1) continue;
+    h->rowbits_off[k] = at;
+    uint64_t* rb = reinterpret_cast<uint64_t*>(blob + at);     // [dc][row]: the mask's row, rotated by dc
+    for (int i = 0; i < th.n_cells; ++i) {
+      const int r = s.cells[th.cell_begin + i] >> 8, c = s.cells[th.cell_begin + i] & 0xff;
+      for (int dc = 0; dc < W; ++dc) rb[dc * H + r] |= 1ull << ((c + dc) % W);
+    }
+    at += 8u * (uint32_t)(W * H);
+  }
+  h->bytes = at;
+  return CAMPX_OK;
+}
+
+static int shape_n_trail(const CampxShapeSpec& s) {
+  int n = 0;
+  for (int k = 0; k < s.first_drape; ++k) n += s.things[k].visible ? 1 : 0;
+  return n;
+}
+
+// Scratch of the frame-major path (CampxOutputs.trace): the offset trace uint32 [4][T][B], then
+// (8-byte aligned) the keyframes uint64 [ceil(T / key)][B][S][H].
+int64_t shape_scratch_bytes(const CampxShapeSpec& s, int64_t B, int32_t T) {
+  if (!shape_tables_ok(s) || B <= 0 || T <= 0) return 0;
+  const int64_t offsets = (16ll * T * B + 7) & ~7ll;
+  const int64_t keys = 8ll * ((T + kShapeKey - 1) / kShapeKey) * B * shape_n_trail(s) * s.rows;
+  return offsets + keys;
+}
+
+// Can this launch take the frame-major path?  Every frame kept back to back, int8, no flat
+// board, frames of whole 16-byte chunks below 4 GiB, the tables and the scratch given.
+bool shape_split_ok(const CampxShapeSpec& s, const void* tables, const CampxOutputs& out, int64_t B,
+                    int32_t T, int32_t emit_first) {
+  static const bool off = [] { const char* v = getenv("CAMPX_SHAPE_SPLIT"); return v && v[0] == '0'; }();
+  if (off || !tables || !out.trace || out.board || emit_first || T < 1 || T > 65535) return false;
+  if (!shape_tables_ok(s) || out.obs_format != CAMPX_OBS_INT8) return false;
+  const int64_t R = (int64_t)s.rows * s.cols * s.n_layers;
+  if ((B * R) % 16 || B * R >= (1ll << 32) - 65536 || (int64_t)T * B >= (1ll << 31)) return false;
+  if (reinterpret_cast<uintptr_t>(out.obs) & 15) return false;
   if (out.scalar_pitch && out.scalar_pitch != B) return false;
   return out.obs_t_stride == B * R;
 }
 
-template <bool kBoard>
-void launch_shape_render(const ShapeParams& sp, const CampxShapeSpec& s, const CampxShapeSpec* spec_dev,
-                         const uint32_t* trace, int8_t* dst, int64_t B, int32_t T, hipStream_t stream) {
-  ShapeRenderParams rp;
-  memset(&rp, 0, sizeof(rp));
-  rp.R = (uint32_t)(s.rows * s.cols * (kBoard ? 1 : s.n_layers));
-  uint32_t l = 0;
-  while ((1ull << l) < rp.R) ++l;
-  rp.m = (uint32_t)(((1ull << 32) * ((1ull << l) - rp.R)) / rp.R + 1);
-  rp.sh1 = l < 1 ? l : 1;
-  rp.sh2 = l > 0 ? l - 1 : 0;
-  rp.slab_bytes = (uint32_t)(B * rp.R);
-  rp.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 1023u);
-  rp.shift_slab = rp.slab_bytes & 1023u;
-  const uint64_t reach = (uint64_t)rp.slab_bytes + ((rp.shift_base | rp.shift_slab) ? 1023u : 0u);
-  const dim3 grid((unsigned)((reach + kRenderSpan - 1) / kRenderSpan), (unsigned)T);
-  hipLaunchKernelGGL((shape_render_kernel<kBoard>), grid, dim3(kRenderBlockWaves * kWave), 0, stream,
-                     sp, rp, spec_dev, trace, dst, B, (int64_t)T * B);
+int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const CampxShapeSpec* spec_dev,
+                           const void* tables_dev, CampxState st, int8_t* backdrop_state,
+                           const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                           int32_t reset_first, hipStream_t stream) {
+  ShapeSplitParams pp;
+  memset(&pp, 0, sizeof(pp));
+  const int H = s.rows, W = s.cols, L = s.n_layers;
+  pp.rows = H;
+  pp.cols = W;
+  pp.n_layers = L;
+  pp.n_things = s.n_things;
+  pp.first_drape = s.first_drape;
+  pp.R = (uint32_t)(L * H * W);
+  pp.slab_bytes = (uint32_t)(B * pp.R);
+  pp.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(out.obs) & (kSplitSpan - 1u));
+  pp.shift_slab = pp.slab_bytes & (kSplitSpan - 1u);
+  pp.n_slots = (uint32_t)(B * L * H);
+  pp.by_w = make_div((uint32_t)W);
+  pp.by_lh = make_div((uint32_t)(L * H));
+  pp.by_h = make_div((uint32_t)H);
+  // the tables blob: the host builds the same layout (shape_tables_build), so the offsets are known
+  const char* blob = static_cast<const char*>(tables_dev);
+  uint32_t at = align8((uint32_t)sizeof(ShapeTablesHeader));
+  pp.static_rows = reinterpret_cast<const uint64_t*>(blob + at);
+  at += 8u * (uint32_t)(L * H);
+  for (int k = 0; k < s.n_things; ++k) {
+    const CampxShapeThing& th = s.things[k];
+    uint32_t art = 0u;
+    if (th.n_cells >= 1) art = ((uint32_t)(s.cells[th.cell_begin] >> 8) << 16) | ((uint32_t)(s.cells[th.cell_begin] & 0xff) << 24);
+    pp.thing[k] = (uint32_t)th.layer | ((th.visible && th.n_cells > 0 ? 1u : 0u) << 8) |
+                  ((th.n_cells == 1 ? 1u : 0u) << 9) | art;
+    if (k >= s.first_drape && th.visible && th.n_cells > 1) {
+      pp.rowbits[k] = reinterpret_cast<const uint64_t*>(blob + at);
+      at += 8u * (uint32_t)(W * H);
+    }
+    if (k < s.first_drape && th.visible) pp.trail_z[pp.n_trail++] = (uint32_t)k;
+  }
+  uint32_t* trace = reinterpret_cast<uint32_t*>(out.trace);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(out.trace + ((16ll * T * B + 7) & ~7ll));
+  pp.trace = trace;
+  pp.keys = keys;
+  pp.B = B;
+  pp.plane = (int64_t)T * B;
+  const size_t lds = (size_t)8 * pp.n_trail * H * kWave;
+  hipLaunchKernelGGL(shape_update_split_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds,
+                     stream, sp, pp, spec_dev, st, backdrop_state, actions, out, trace, keys, B, T, reset_first);
+  const uint64_t reach = (uint64_t)pp.slab_bytes + ((pp.shift_base | pp.shift_slab) ? kSplitSpan - 1u : 0u);
+  const uint64_t block_span = (uint64_t)kSplitSpan * kSplitWaves;
+  const dim3 grid((unsigned)((((reach + block_span - 1) / block_span) + 7u) & ~(uint64_t)7), (unsigned)T);
+  hipLaunchKernelGGL(shape_render_split_kernel, grid, dim3(kSplitWaves * kWave), 0, stream, pp, out.obs);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }
 
 }  // namespace campx_impl
@@ -715,10 +897,27 @@ int32_t campx_shape_spec_validate(const CampxShapeSpec* s) {
   return CAMPX_OK;
 }
 
+int64_t campx_shape_tables_bytes(const CampxShapeSpec* spec_host) {
+  if (!spec_host || campx_shape_spec_validate(spec_host) != CAMPX_OK) return 0;
+  return shape_tables_bytes(*spec_host);
+}
+
+int32_t campx_shape_tables_build(const CampxShapeSpec* spec_host, void* tables_host, int64_t bytes) {
+  if (!spec_host || !tables_host) return CAMPX_EINVAL;
+  const int32_t v = campx_shape_spec_validate(spec_host);
+  if (v != CAMPX_OK) return v;
+  return shape_tables_build(*spec_host, tables_host, bytes);
+}
+
+int64_t campx_shape_scratch_bytes(const CampxShapeSpec* spec_host, int64_t B, int32_t T) {
+  if (!spec_host || campx_shape_spec_validate(spec_host) != CAMPX_OK) return 0;
+  return shape_scratch_bytes(*spec_host, B, T);
+}
+
 int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxShapeSpec* spec_dev,
-                                   CampxState st, int8_t* backdrop_state, const int8_t* actions,
-                                   CampxOutputs out, int64_t B, int32_t T, int32_t reset_first,
-                                   int32_t emit_first, void* stream) {
+                                   const void* tables_dev, CampxState st, int8_t* backdrop_state,
+                                   const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
+                                   int32_t reset_first, int32_t emit_first, void* stream) {
   if (!spec_host || !spec_dev || !st.pos || !st.done || !out.obs || B <= 0 || T < 0)
     return CAMPX_EINVAL;
   if (T > 0 && !actions) return CAMPX_EINVAL;
@@ -737,18 +936,11 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
   const ShapeParams sp = make_shape_params(*spec_host);
   // (the 16-bit formats: the serial kernel only; its 16-byte stores of eight halves are 8-byte
   // aligned when rows*cols is 4 modulo 8 - legal on this stack, tools/probes/unaligned_probe.hip)
-  if (out.obs_format == CAMPX_OBS_INT8 && shape_split_ok(*spec_host, out, B, T, emit_first)) {
-    // games without trails, every frame kept: update pass -> shape trace -> frame-major render
-    uint32_t* trace = reinterpret_cast<uint32_t*>(out.trace);
-    hipLaunchKernelGGL(shape_update_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, sp, st,
-                       actions, out, trace, B, T, reset_first);
-    // (a third variant - one wave per environment-frame storing its row straight from
-    // registers, no window image - measured 4.08 TB/s at B = 32 768, between this path and
-    // the serial kernel; removed again)
-    launch_shape_render<false>(sp, *spec_host, spec_dev, trace, out.obs, B, T, s);
-    if (out.board) launch_shape_render<true>(sp, *spec_host, spec_dev, trace, out.board, B, T, s);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+  if (shape_split_ok(*spec_host, tables_dev, out, B, T, emit_first)) {
+    if (reinterpret_cast<uintptr_t>(out.trace) & 7) return CAMPX_EINVAL;
+    // every frame kept, int8: update pass -> offset trace + trail keyframes -> frame-major render
+    return launch_shape_split(sp, *spec_host, spec_dev, tables_dev, st, backdrop_state, actions, out, B, T,
+                              reset_first, s);
   }
 #define CAMPX_SHAPE_LAUNCH(BOARD, FMT)                                                         \
   hipLaunchKernelGGL((shape_rollout_kernel<BOARD, FMT>), grid, block, 0, s, sp, spec_dev, st,  \

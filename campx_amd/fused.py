@@ -604,12 +604,14 @@ class FusedGame(object):
                          'one would overwrite at once: flush() and read them first')
       self.flush()
       if (out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
-          ((self.n_dyn >= 3 and self.batch >= 8192) or (self.n_dyn == 2 and self.batch >= 32768))):
+          self.n_dyn >= 3 and self.batch >= 8192):
         # Games of two to four movers past the shared launch's bounds: the update pass on the
         # (high-priority) side stream, under the render of the rollout before it - two kernels
-        # on two streams instead of two roles of one launch (sokoban with three boxes,
-        # B = 16 384 / 32 768: 0.70 / 0.78 of peak against 0.60 / 0.72 in order;
-        # profiles/r05_multimover_pipeline_ab.txt).  Complete a call early, like the rollout below.
+        # on two streams instead of two roles of one launch (sokoban with two / three boxes,
+        # B = 16 384: 0.61 / 0.70 of peak against 0.56 / 0.60 in order, 32 768: 0.74 / 0.78 against
+        # 0.69 / 0.72, 65 536: 0.86 / 0.86 against 0.81 / 0.81; the two-mover game gains nothing:
+        # 0.73 / 0.78 against 0.73 / 0.83, and stays in order; profiles/r05_multimover_deferred_ab.txt).
+        # Complete a call early, like the rollout below.
         self.rollout(ids, out=out, reset_first=reset_first, pipelined=True)
         self._deferred, self._deferred_rendered = out, True
         return prev

@@ -618,11 +618,10 @@ def _trace(engine, actions, max_plays):
   if mode != 'walk':
     from . import tabulate_batched
     from .lanes import CannotBatch
-    device = None
-    if getattr(engine, '_device', None) is not None and torch.cuda.is_available():
-      device = engine._device
     try:
-      game = tabulate_batched.trace(engine, actions, max_plays, device=device)
+      # (on the host: the game's own tensors - constants its classes keep, the Backdrop - live
+      # there, and half a million states take 15 s)
+      game = tabulate_batched.trace(engine, actions, max_plays, device=None)
       LAST_WALK[0] = 'lanes: {} frames for {} states'.format(game.batched_frames, game.n_states)
       return game
     except CannotBatch as why:

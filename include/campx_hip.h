@@ -498,16 +498,26 @@ int32_t campx_shape_spec_validate(const CampxShapeSpec* spec_host);
  * drape).  Outputs: out.obs (any out.obs_format), out.board, out.reward, out.discount, out.done,
  * out.bad_count / bad_flag; frames at base + t * stride as for campx_rollout_launch.
  * Action ids outside 0..4 move nothing, end nothing and are counted as bad.
- * out.trace (optional, 4-byte aligned, 16 * T * B bytes): scratch for the things' offsets per
- * frame, uint32 [4][T][B].  Given it, a game without trails (no visible sprite before the
- * first drape) whose frames are kept back to back runs as two kernels - update pass, then
- * a frame-major render with memory-aligned stores - which streams the observations faster
- * (NOTES.md 3.7); other games and calls ignore it.
+ * The frame-major path (round 5, csrc/k_shape.hip): with `tables_dev` (campx_shape_tables_build)
+ * and out.trace (8-byte aligned scratch of campx_shape_scratch_bytes(spec, B, T) bytes: the
+ * things' offsets per frame and, for games with trails, the per-environment trail words every
+ * fourth frame), a call that keeps every frame (int8, back to back, frames of whole 16-byte
+ * chunks, no flat board, no emit_first) runs as two kernels - the update pass, then a render pass
+ * of one-shot waves with memory-aligned 2 KiB windows that computes every W-cell row of the
+ * observation arithmetically from 64-bit row words - which streams the observations at the
+ * one-cell tier's rate.  Rows of 16 to 64 cells only; other games and calls ignore both (NULL is
+ * fine) and run the one-wave-per-environment kernel.  CAMPX_SHAPE_SPLIT=0: never.
  */
+int64_t campx_shape_tables_bytes(const CampxShapeSpec* spec_host);   /* 0: not a game for that path */
+/* Fills `tables_host` (HOST memory, `bytes` >= campx_shape_tables_bytes); the caller copies it
+ * to the device.  Pure host code. */
+int32_t campx_shape_tables_build(const CampxShapeSpec* spec_host, void* tables_host, int64_t bytes);
+int64_t campx_shape_scratch_bytes(const CampxShapeSpec* spec_host, int64_t B, int32_t T);
 int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxShapeSpec* spec_dev,
-                                   CampxState state, int8_t* backdrop_state,
+                                   const void* tables_dev, CampxState state, int8_t* backdrop_state,
                                    const int8_t* actions, CampxOutputs out, int64_t B, int32_t T,
                                    int32_t reset_first, int32_t emit_first, void* stream);
+
 
 /*
  * Wide tier: games whose update pass is a STATE table - one row per state the game can
