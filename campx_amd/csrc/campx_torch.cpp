@@ -664,7 +664,7 @@ void update_render_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const Op
 void shape_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, Tensor&, const OptTensor&,
                         const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
-                        const OptTensor&, bool, bool, const OptTensor&) {}
+                        const OptTensor&, bool, bool, const OptTensor&, const OptTensor&) {}
 void wide_rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&,
                        const OptTensor&, Tensor&, const OptTensor&, const OptTensor&,
                        const OptTensor&, const OptTensor&, const OptTensor&, Tensor&,

@@ -404,15 +404,12 @@ ShapeParams make_shape_params(const CampxShapeSpec& s) {
 #endif
 constexpr int kShapeKey = CAMPX_SHAPE_KEY;
 constexpr uint32_t kShapeTablesMagic = 0x54485343u;   // 'CSHT'
-#ifndef CAMPX_SHAPE_SPLIT_WAVES
-#define CAMPX_SHAPE_SPLIT_WAVES 2
-#endif
 #ifndef CAMPX_SHAPE_SPLIT_WIN
-#define CAMPX_SHAPE_SPLIT_WIN 2
+#define CAMPX_SHAPE_SPLIT_WIN 8
 #endif
-constexpr int kSplitWaves = CAMPX_SHAPE_SPLIT_WAVES, kSplitWin = CAMPX_SHAPE_SPLIT_WIN;
+// One wave per block, kSplitWin KiB of a frame per wave (see shape_render_split_kernel).
+constexpr int kSplitWaves = 1, kSplitWin = CAMPX_SHAPE_SPLIT_WIN;
 constexpr uint32_t kSplitSpan = 1024u * kSplitWin;
-constexpr int kSplitSlots = (int)kSplitSpan / 16 + 8;      // W >= 16: span / W + 2 slots, rounded up
 
 struct ShapeTablesHeader {       // the device blob campx_shape_tables_build() fills
   uint32_t magic;
@@ -447,11 +444,19 @@ struct ShapeSplitParams {
   // per thing (z-order): layer | visible << 8 | one_cell << 9 | art row << 16 | art col << 24
   uint32_t thing[CAMPX_SHAPE_MAX_THINGS];
   uint32_t trail_z[CAMPX_SHAPE_MAX_THINGS];    // the visible sprites before the first drape
+  // the visible things at / in front of the first drape, FRONT TO BACK, for the render pass:
+  // front[k] = thing word | z << 12 (bits 12-14); its row words (one-cell things: static_rows,
+  // never used).  n_front of them.
+  int32_t n_front;
+  uint32_t front[CAMPX_SHAPE_MAX_THINGS];
+  const uint64_t* front_rows[CAMPX_SHAPE_MAX_THINGS];
+  FastDiv by_sh;                               // (update pass: word index / (S * H))
   const uint64_t* static_rows;                 // device: [L][H]
   const uint64_t* rowbits[CAMPX_SHAPE_MAX_THINGS];   // device: [W][H], or null
   const uint32_t* trace;                       // [4][T][B] offsets (bit 7 of orow0: rebuilt)
   const uint64_t* keys;                        // [ceil(T / key)][B][S][H]
   int64_t B, plane;                            // plane = T * B
+  uint32_t max_pairs;                          // (environment, row) pairs a render window can touch
 };
 
 __device__ __forceinline__ uint32_t wrap_add(uint32_t a, uint32_t d, uint32_t n) {
@@ -463,17 +468,21 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t a, uint32_t d, uint32_t n)
 // words in LDS: [S * H][64] uint64, 8 * S * H * 64 bytes of dynamic shared memory).
 __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
     ShapeParams sp, ShapeSplitParams pp, const CampxShapeSpec* __restrict__ spec, CampxState st,
-    int8_t* __restrict__ backdrop_state, const int8_t* __restrict__ actions, CampxOutputs out,
+    uint64_t* __restrict__ state_words, const int8_t* __restrict__ actions, CampxOutputs out,
     uint32_t* __restrict__ trace, uint64_t* __restrict__ keys, int64_t B, int32_t T, int32_t reset_first) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t trail[];     // [S * H][64]
+  // this wave's 64 environments' trail words, laid out as the keyframes are: [64][S][H]
+  extern __shared__ __attribute__((aligned(16))) uint64_t trail[];
   __shared__ ShapeAction act[CAMPX_N_ACTIONS];   // (indexed by a lane's action: LDS, not kernarg)
   const int lane = threadIdx.x;
   if (lane < CAMPX_N_ACTIONS) act[lane] = sp.act[lane];
   const int64_t env0 = (int64_t)blockIdx.x * kWave;
   const int64_t env = env0 + lane;
   const bool live = env < B;
-  const int H = sp.rows, W = sp.cols, HW = H * W, N = sp.n_things, S = pp.n_trail, SH = S * H;
-  for (int i = 0; i < SH; ++i) trail[i * kWave + lane] = 0ull;
+  const int H = sp.rows, W = sp.cols, N = sp.n_things, S = pp.n_trail, SH = S * H;
+  const int64_t n_words = (B - env0 < kWave ? B - env0 : (int64_t)kWave) * SH;
+  // (the carried trail words: shape_words_from_backdrop_kernel made them from the backdrop state)
+  for (int i = lane; i < SH * kWave; i += kWave)
+    trail[i] = (!reset_first && i < n_words) ? state_words[env0 * SH + i] : 0ull;
   __syncthreads();
   uint32_t orow[2] = {0u, 0u}, ocol[2] = {0u, 0u};
   int over = 0, bad = 0;
@@ -487,30 +496,28 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
       }
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
-    if (S > 0 && backdrop_state) {
-      // the carried backdrop -> trail words: a cell that differs from the art's backdrop was
-      // painted by the trail sprite of that layer
-      const uint8_t* mine = reinterpret_cast<const uint8_t*>(backdrop_state) + env * HW;
-      for (int r = 0; r < H; ++r)
-        for (int c = 0; c < W; ++c) {
-          const uint32_t v = mine[r * W + c], art = spec->backdrop[r * W + c];
-          if (v != art)
-            for (int s = 0; s < S; ++s)
-              if ((pp.thing[pp.trail_z[s]] & 0xffu) == v) trail[(s * H + r) * kWave + lane] |= 1ull << c;
-        }
-    }
   }
+  uint32_t trail_pos[4] = {0u, 0u, 0u, 0u};   // sprite s: row | col << 8 in half s & 1 of word s >> 1
   auto paint_trails = [&]() {        // every trail sprite, back to front: mine, nobody else's
+    trail_pos[0] = trail_pos[1] = trail_pos[2] = trail_pos[3] = 0u;
     for (int s = 0; s < S; ++s) {
       const uint32_t z = pp.trail_z[s], th = pp.thing[z];
       const int sh = 8 * (z & 3);
       const uint32_t r = wrap_add(th >> 16 & 0xffu, ((z < 4 ? orow[0] : orow[1]) >> sh) & 0xffu, (uint32_t)H);
       const uint32_t c = wrap_add(th >> 24, ((z < 4 ? ocol[0] : ocol[1]) >> sh) & 0xffu, (uint32_t)W);
       const uint64_t bit = 1ull << c;
+      // (LDS atomics without a return value: the wave never waits for a word to come back - as
+      // read-modify-write these four dependent round trips were most of a frame's 1.2 us)
       for (int q = 0; q < S; ++q) {
-        uint64_t& w = trail[(q * H + r) * kWave + lane];
-        w = q == s ? (w | bit) : (w & ~bit);
+        uint64_t* w = &trail[lane * SH + q * H + (int)r];
+        if (q == s) __hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_and(w, ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      const uint32_t packed = (r | (c << 8)) << (16 * (s & 1));
+      trail_pos[0] |= (s >> 1) == 0 ? packed : 0u;
+      trail_pos[1] |= (s >> 1) == 1 ? packed : 0u;
+      trail_pos[2] |= (s >> 1) == 2 ? packed : 0u;
+      trail_pos[3] |= (s >> 1) == 3 ? packed : 0u;
     }
   };
   const int64_t plane = (int64_t)T * B;
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
         over = 0;
         ret = 0.0f;
         rebuilt = 0x80u;
-        for (int i = 0; i < SH; ++i) trail[i * kWave + lane] = 0ull;
+        for (int i = 0; i < SH; ++i) trail[lane * SH + i] = 0ull;
       }
       float reward = __builtin_nanf("");
       if (valid) {
@@ -555,6 +562,11 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
         trace[plane + at] = orow[1];
         trace[2 * plane + at] = ocol[0];
         trace[3 * plane + at] = ocol[1];
+        // (where the trail sprites stand after this frame, decoded: the render pass replays them)
+        if (S > 0) trace[4 * plane + at] = trail_pos[0];
+        if (S > 2) trace[5 * plane + at] = trail_pos[1];
+        if (S > 4) trace[6 * plane + at] = trail_pos[2];
+        if (S > 6) trace[7 * plane + at] = trail_pos[3];
         if (out.reward) out.reward[at] = reward;
         if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
         if (out.done) out.done[at] = (uint8_t)over;
@@ -562,10 +574,18 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
       if (S > 0 && t % kShapeKey == 0) {
         // keyframe: this wave's 64 environments x S * H words, contiguous in [key][B][S][H]
         uint64_t* to = keys + ((int64_t)(t / kShapeKey) * B + env0) * SH;
-        const int64_t n_words = (B - env0 < kWave ? B - env0 : (int64_t)kWave) * SH;
-        for (int i = lane; i < n_words; i += kWave) {
-          const int e = i / SH, w = i - e * SH;
-          to[i] = trail[w * kWave + e];
+        for (int i0 = 0; i0 < n_words; i0 += 8 * kWave) {       // (eight LDS reads in flight)
+          uint64_t v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * kWave + lane;
+            v[j] = trail[i < n_words ? i : 0];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = i0 + j * kWave + lane;
+            if (i < n_words) to[i] = v[j];
+          }
         }
       }
     }
@@ -579,126 +599,227 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
       }
     st.done[env] = (uint8_t)over;
     if (st.ret) st.ret[env] = ret;
-    if (S > 0 && backdrop_state) {
-      uint8_t* mine = reinterpret_cast<uint8_t*>(backdrop_state) + env * HW;
-      for (int r = 0; r < H; ++r)
-        for (int c = 0; c < W; ++c) {
-          uint32_t v = spec->backdrop[r * W + c];
-          for (int s = 0; s < S; ++s)
-            if ((trail[(s * H + r) * kWave + lane] >> c) & 1ull) v = pp.thing[pp.trail_z[s]] & 0xffu;
-          mine[r * W + c] = (uint8_t)v;
-        }
-    }
   }
+  if (S > 0)        // the trail words after the last frame: shape_backdrop_from_words_kernel reads them
+    for (int i = lane; i < n_words; i += kWave) state_words[env0 * SH + i] = trail[i];
   report_bad_actions(out, bad);
+}
+
+// The carried state of the two shape kernels is the per-environment backdrop, a layer per cell
+// (campx_shape_rollout_launch's `backdrop_state`); the frame-major path's update pass works on
+// trail WORDS.  Two small, fully parallel kernels convert at the ends of a launch (inside the
+// update pass, one lane walking its environment's 468 cells, they cost 85 us per launch).
+// backdrop -> words: a cell that differs from the art's backdrop was painted by the trail
+// sprite of that layer; one thread per (environment, sprite, row).
+__global__ __launch_bounds__(256) void shape_words_from_backdrop_kernel(
+    ShapeSplitParams pp, const CampxShapeSpec* __restrict__ spec, const int8_t* __restrict__ backdrop_state,
+    uint64_t* __restrict__ words, int64_t B) {
+  const int H = pp.rows, W = pp.cols, S = pp.n_trail;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * S * H) return;
+  const int r = (int)(i % H), s = (int)((i / H) % S);
+  const int64_t env = i / ((int64_t)S * H);
+  const uint32_t layer = pp.thing[pp.trail_z[s]] & 0xffu;
+  const uint8_t* mine = reinterpret_cast<const uint8_t*>(backdrop_state) + env * (int64_t)(H * W) + r * W;
+  const uint8_t* art = spec->backdrop + r * W;
+  uint64_t w = 0ull;
+  for (int c = 0; c < W; ++c) w |= (mine[c] != art[c] && mine[c] == layer) ? 1ull << c : 0ull;
+  words[i] = w;
+}
+
+// words -> backdrop: one thread per (environment, row); a wave's rows are contiguous bytes
+__global__ __launch_bounds__(256) void shape_backdrop_from_words_kernel(
+    ShapeSplitParams pp, const CampxShapeSpec* __restrict__ spec, const uint64_t* __restrict__ words,
+    int8_t* __restrict__ backdrop_state, int64_t B) {
+  const int H = pp.rows, W = pp.cols, S = pp.n_trail;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // env * H + r
+  if (i >= B * H) return;
+  const int r = (int)(i % H);
+  const int64_t env = i / H;
+  uint64_t tw[CAMPX_SHAPE_MAX_THINGS];
+  uint32_t layer[CAMPX_SHAPE_MAX_THINGS];
+#pragma unroll
+  for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) {
+    tw[s] = s < S ? words[(env * S + s) * H + r] : 0ull;
+    layer[s] = s < S ? pp.thing[pp.trail_z[s]] & 0xffu : 0u;
+  }
+  const uint8_t* art = spec->backdrop + r * W;
+  int8_t* mine = backdrop_state + i * W;
+  for (int c = 0; c < W; ++c) {
+    uint32_t v = art[c];
+#pragma unroll
+    for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) v = ((tw[s] >> c) & 1ull) ? layer[s] : v;
+    mine[c] = (int8_t)v;
+  }
 }
 
 // 16 bits -> 16 bytes 0 / 1 (bit i -> byte i)
 __device__ __forceinline__ u32x4 bits_to_bytes(uint32_t b) {
-  auto four = [](uint32_t n) { return ((n & 0xfu) * 0x00204081u) & 0x01010101u; };
+  auto four = [](uint32_t n) { return __umul24(n & 0xfu, 0x00204081u) & 0x01010101u; };
   return u32x4{four(b), four(b >> 4), four(b >> 8), four(b >> 12)};
 }
 
-__global__ __launch_bounds__(kSplitWaves * kWave) void shape_render_split_kernel(
+// NF: visible things at / in front of the first drape (1..8); NS: trail sprites, rounded up to
+// 0 / 2 / 8 (surplus entries repeat the last sprite: painting twice changes nothing).
+//
+// A block = ONE one-shot wave = kSplitWin consecutive KiB of one frame, aligned in memory.
+//   stage A  one lane per (environment, board row) the window touches - a few dozen: 8 KiB of
+//            Hello World are 2.5 environments of 13 rows, one pass - : everything that does not
+//            depend on the layer (the things' row words, what covers what, the trail words
+//            brought up to this frame) and from it the finished row of EVERY layer, into LDS:
+//            done once per (environment, row), not once per (environment, layer, row);
+//   stage B  one lane per slot of the window: the rows in the order the stream has them;
+//   stage C  one lane per 16-byte chunk: 16 bits of two neighbouring slots -> 16 bytes -> one
+//            aligned store; a KiB per instruction, kSplitWin instructions.
+// Every memory trip of stage A is issued as ONE batch: first the offsets of its frame (and of
+// the frames since the keyframe), then - their addresses depend on those - every thing's row
+// word and the keyframe's trail words.  (History, profiles/r05_shape_rocprofv3.txt: a loop over
+// the things paid one trip per thing: 3.3 TB/s; batched, every slot-lane recomputing its row's
+// things, 2 KiB per wave: VALU-bound at 4.4 TB/s, 3.0 with trails; stage A by one wave of a
+// four-wave block behind a barrier: fewer instructions and slower, 3.1 / 2.7 - three waves idle
+// for two memory trips.)
+// LDS (dynamic): rows [L][pairs] uint64, then slots [kSplitSpan / W + 8].
+template <int NF, int NS>
+__global__ __launch_bounds__(kWave) void shape_render_split_kernel(
     ShapeSplitParams pp, int8_t* __restrict__ dst) {
-  __shared__ __attribute__((aligned(16))) uint64_t slots_all[kSplitWaves][kSplitSlots];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+  const uint32_t lane = threadIdx.x;
   const uint32_t t = blockIdx.y;
   uint32_t bx = blockIdx.x;
   bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);     // gridDim.x is a multiple of 8: one XCD, one eighth
   const uint32_t shift = (pp.shift_base + t * pp.shift_slab) & (kSplitSpan - 1u);
-  const uint32_t widx = bx * (uint32_t)kSplitWaves + wave;
-  if ((uint64_t)widx * kSplitSpan >= (uint64_t)pp.slab_bytes + shift) return;
-  const uint32_t woff0 = widx * kSplitSpan - shift;
-  const uint32_t wlo = widx * kSplitSpan < shift ? 0u : woff0;
+  const uint32_t H = (uint32_t)pp.rows, W = (uint32_t)pp.cols, L = (uint32_t)pp.n_layers;
+  const uint32_t LH = L * H;
+  if ((uint64_t)bx * kSplitSpan >= (uint64_t)pp.slab_bytes + shift) return;
+  const uint32_t woff0 = bx * kSplitSpan - shift;
+  const uint32_t wlo = bx * kSplitSpan < shift ? 0u : woff0;
   const uint32_t wend = (woff0 + kSplitSpan - 1u < pp.slab_bytes) ? woff0 + kSplitSpan - 1u : pp.slab_bytes - 1u;
   const uint32_t s_first = pp.by_w.div(wlo);
   uint32_t s_last = pp.by_w.div(wend) + 1u;                    // (a chunk's tail reaches into the next slot)
   s_last = s_last < pp.n_slots ? s_last : pp.n_slots - 1u;
-  uint64_t* slots = slots_all[wave];
-  const int H = pp.rows, W = pp.cols, N = pp.n_things, S = pp.n_trail, FD = pp.first_drape;
-  const uint32_t LH = (uint32_t)(pp.n_layers * H);
+  const uint32_t env_first = pp.by_lh.div(s_first);
+  const uint32_t env_last = pp.by_lh.div(s_last);
+  const uint32_t n_pairs = (env_last - env_first + 1u) * H;
+  const uint32_t P = pp.max_pairs;                   // row pitch of `rows`
+  uint64_t* rows = lds64;                            // [L][P]
+  uint64_t* slots = lds64 + L * P;
   const uint32_t* frame_trace = pp.trace + (int64_t)t * pp.B;
   const uint32_t key_frame = t - t % (uint32_t)kShapeKey;
+  const bool upper = pp.n_things > 4;            // (uniform) offsets of things 4..7 are in use
 
+  // ---- stage A
+  for (uint32_t p0 = 0; p0 < n_pairs; p0 += kWave) {
+    uint32_t p = p0 + lane;
+    const bool live = p < n_pairs;
+    p = live ? p : n_pairs - 1u;
+    const uint32_t ei = pp.by_h.div(p);
+    const uint32_t r = p - ei * H;
+    const uint32_t env = env_first + ei;
+    // trip 1: the offsets of this frame, and of the frames since the keyframe
+    uint32_t off_r[2], off_c[2];
+    off_r[0] = frame_trace[env];
+    off_c[0] = frame_trace[2 * pp.plane + env];
+    off_r[1] = upper ? frame_trace[pp.plane + env] : 0u;
+    off_c[1] = upper ? frame_trace[3 * pp.plane + env] : 0u;
+    constexpr int kPosWords = (NS + 1) / 2 > 0 ? (NS + 1) / 2 : 1;
+    uint32_t ev_flag[kShapeKey - 1], ev_pos[kShapeKey - 1][kPosWords];
+    uint64_t tw[NS > 0 ? NS : 1];
+    const int S = pp.n_trail;
+    if (NS > 0) {
+#pragma unroll
+      for (int i = 0; i < kShapeKey - 1; ++i) {
+        // frame key_frame + 1 + i, clamped to t: a frame applied twice changes nothing
+        const uint32_t f = key_frame + 1u + (uint32_t)i <= t ? key_frame + 1u + (uint32_t)i : t;
+        const uint32_t* ft = pp.trace + (int64_t)f * pp.B;
+        ev_flag[i] = ft[env];                       // (bit 7: the frame began with a rebuild)
+#pragma unroll
+        for (int j = 0; j < kPosWords; ++j)
+          ev_pos[i][j] = 2 * j < S ? ft[(4 + j) * pp.plane + env] : 0u;
+      }
+      // (the keyframe's trail words: their address does not depend on the offsets - same trip)
+      const uint64_t* key = pp.keys + ((int64_t)(key_frame / (uint32_t)kShapeKey) * pp.B + env) * (S * (int)H);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) tw[s] = key[(s < S ? s : S - 1) * (int)H + (int)r];
+    }
+    // trip 2: every thing's row word
+    uint64_t wd[NF];
+    uint32_t one_r[NF], one_c[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      const uint32_t th = pp.front[k];
+      const uint32_t z = (th >> 12) & 7u;
+      const uint32_t sh = 8u * (z & 3u);
+      const uint32_t dr = ((off_r[z >> 2] & ~0x80u) >> sh) & 0xffu, dc = (off_c[z >> 2] >> sh) & 0xffu;
+      const uint32_t src = r >= dr ? r - dr : r + H - dr;
+      // (one-cell things load a word they never use: no branch between the loads)
+      const uint32_t idx = ((th >> 9) & 1u) ? 0u : dc * H + src;
+      wd[k] = pp.front_rows[k][idx];
+      one_r[k] = wrap_add(th >> 16 & 0xffu, dr, H);
+      one_c[k] = wrap_add(th >> 24, dc, W);
+    }
+    // the trail words, brought from the keyframe up to this frame (under trip 2)
+    uint64_t any = 0ull;
+    if (NS > 0) {
+#pragma unroll
+      for (int i = 0; i < kShapeKey - 1; ++i) {
+        if (ev_flag[i] & 0x80u) {             // the frame began with a rebuild: trails restart
+#pragma unroll
+          for (int s = 0; s < NS; ++s) tw[s] = 0ull;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int ss = s < S ? s : S - 1;
+          const uint32_t pos = ev_pos[i][s >> 1] >> (16 * (s & 1));
+          // (a surplus entry s >= S repeats sprite S - 1: same words, same position)
+          const uint32_t pos_ss = s < S ? pos : ev_pos[i][(S - 1) >> 1] >> (16 * ((S - 1) & 1));
+          const uint32_t rr = pos_ss & 0xffu, cc = (pos_ss >> 8) & 0xffu;
+          const uint64_t bit = rr == r ? 1ull << cc : 0ull;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            const int qq = q < S ? q : S - 1;
+            tw[q] = qq == ss ? (tw[q] | bit) : (tw[q] & ~bit);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) any |= tw[s];
+    }
+    // the things, front to back: what each shows of this row, what is covered
+    uint64_t covered = 0ull, vis[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      const uint32_t th = pp.front[k];
+      const uint64_t w = ((th >> 9) & 1u) ? (one_r[k] == r ? 1ull << one_c[k] : 0ull) : wd[k];
+      vis[k] = w & ~covered;
+      covered |= w;
+    }
+    // the finished row of every layer (the layer index is uniform: scalar selects)
+    const uint64_t open = ~(covered | any);          // where the art's backdrop shows
+    for (uint32_t l = 0; l < L; ++l) {
+      uint64_t row = pp.static_rows[l * H + r] & open;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) row |= ((pp.front[k] & 0xffu) == l) ? vis[k] : 0ull;
+      if (NS > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const int ss = s < S ? s : S - 1;
+          row |= ((pp.thing[pp.trail_z[ss]] & 0xffu) == l) ? (tw[s] & ~covered) : 0ull;
+        }
+      }
+      if (live) rows[l * P + p] = row;
+    }
+  }
+  // ---- stage B: the window's slots in stream order (one wave: LDS operations complete in order)
   for (uint32_t base = s_first; base <= s_last; base += kWave) {
     uint32_t g = base + lane;
     g = g <= s_last ? g : s_last;                 // (surplus lanes repeat the last slot)
     const uint32_t env = pp.by_lh.div(g);
     const uint32_t rem = g - env * LH;
     const uint32_t l = pp.by_h.div(rem);
-    const uint32_t r = rem - l * (uint32_t)H;
-    const uint32_t or0 = frame_trace[env] & ~0x80u, oc0 = frame_trace[2 * pp.plane + env];
-    uint32_t or1 = 0u, oc1 = 0u;
-    if (N > 4) {
-      or1 = frame_trace[pp.plane + env];
-      oc1 = frame_trace[3 * pp.plane + env];
-    }
-    // ---- things at and in front of the first drape, front to back
-    uint64_t covered = 0ull, mine = 0ull;
-    for (int z = N - 1; z >= FD; --z) {         // (uniform)
-      const uint32_t th = pp.thing[z];
-      if (!((th >> 8) & 1u)) continue;
-      const int sh = 8 * (z & 3);
-      const uint32_t dr = ((z < 4 ? or0 : or1) >> sh) & 0xffu, dc = ((z < 4 ? oc0 : oc1) >> sh) & 0xffu;
-      uint64_t w;
-      if ((th >> 9) & 1u) {
-        const uint32_t rr = wrap_add(th >> 16 & 0xffu, dr, (uint32_t)H), cc = wrap_add(th >> 24, dc, (uint32_t)W);
-        w = rr == r ? 1ull << cc : 0ull;
-      } else {
-        const uint32_t src = r >= dr ? r - dr : r + (uint32_t)H - dr;
-        w = pp.rowbits[z][dc * (uint32_t)H + src];
-      }
-      mine |= ((th & 0xffu) == l) ? (w & ~covered) : 0ull;
-      covered |= w;
-    }
-    // ---- the backdrop's row of this layer: the art, under the trails
-    uint64_t bd = pp.static_rows[l * (uint32_t)H + r];
-    if (S > 0) {
-      const uint64_t* key = pp.keys + ((int64_t)(key_frame / (uint32_t)kShapeKey) * pp.B + env) * (S * H);
-      uint64_t tw[CAMPX_SHAPE_MAX_THINGS];
-#pragma unroll
-      for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) tw[s] = s < S ? key[s * H + r] : 0ull;
-      for (uint32_t f = key_frame + 1u; f <= t; ++f) {     // (uniform: at most kShapeKey - 1 frames)
-        const uint32_t* ft = pp.trace + (int64_t)f * pp.B;
-        const uint32_t fr0 = ft[env], fc0 = ft[2 * pp.plane + env];
-        uint32_t fr1 = 0u, fc1 = 0u;
-        if (FD > 4) {
-          fr1 = ft[pp.plane + env];
-          fc1 = ft[3 * pp.plane + env];
-        }
-        if (fr0 & 0x80u) {
-#pragma unroll
-          for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) tw[s] = 0ull;
-        }
-#pragma unroll
-        for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s) {
-          if (s < S) {
-            const uint32_t z = pp.trail_z[s], th = pp.thing[z];
-            const int sh = 8 * (z & 3);
-            const uint32_t rr = wrap_add(th >> 16 & 0xffu, (((z < 4 ? fr0 : fr1) & ~0x80u) >> sh) & 0xffu, (uint32_t)H);
-            const uint32_t cc = wrap_add(th >> 24, ((z < 4 ? fc0 : fc1) >> sh) & 0xffu, (uint32_t)W);
-            const uint64_t bit = rr == r ? 1ull << cc : 0ull;
-#pragma unroll
-            for (int q = 0; q < CAMPX_SHAPE_MAX_THINGS; ++q)
-              if (q < S) tw[q] = q == s ? (tw[q] | bit) : (tw[q] & ~bit);
-          }
-        }
-      }
-      uint64_t any = 0ull, here = 0ull;
-#pragma unroll
-      for (int s = 0; s < CAMPX_SHAPE_MAX_THINGS; ++s)
-        if (s < S) {
-          any |= tw[s];
-          here |= ((pp.thing[pp.trail_z[s]] & 0xffu) == l) ? tw[s] : 0ull;
-        }
-      bd = (bd & ~any) | here;
-    }
-    const uint32_t at = base - s_first + lane;
-    if (at < (uint32_t)kSplitSlots) slots[at] = mine | (bd & ~covered);
+    const uint32_t r = rem - l * H;
+    slots[base - s_first + lane] = rows[l * P + (env - env_first) * H + r];
   }
-  // ---- out: every lane's 16 bytes are 16 bits of two neighbouring slots
+  // ---- stage C: every lane's 16 bytes are 16 bits of two neighbouring slots
   int8_t* frame = dst + (int64_t)t * pp.slab_bytes;
 #pragma unroll
   for (int j = 0; j < kSplitWin; ++j) {
@@ -706,10 +827,10 @@ __global__ __launch_bounds__(kSplitWaves * kWave) void shape_render_split_kernel
     const bool inside = off < pp.slab_bytes;          // (bytes before the frame wrap to huge offsets)
     const uint32_t o = inside ? off : wlo;
     const uint32_t s = pp.by_w.div(o);
-    const uint32_t c = o - s * (uint32_t)W;
+    const uint32_t c = o - s * W;
     const uint32_t idx = s - s_first;
-    const uint64_t lo = slots[idx], hi = slots[idx + 1u < (uint32_t)kSplitSlots ? idx + 1u : idx];
-    const uint32_t bits = (uint32_t)(lo >> c) | (uint32_t)((hi << 1) << ((uint32_t)W - 1u - c));
+    const uint64_t lo = slots[idx], hi = slots[idx + 1u];
+    const uint32_t bits = (uint32_t)(lo >> c) | (uint32_t)((hi << 1) << (W - 1u - c));
     if (inside) store16_streaming_at(frame, off, bits_to_bytes(bits));
   }
 }
@@ -719,11 +840,21 @@ static inline uint32_t align8(uint32_t x) { return (x + 7u) & ~7u; }
 // Which games take the frame-major path: rows of 16 to 64 cells (a 16-byte chunk then spans at
 // most two slots, a slot is one 64-bit word), every trail sprite's words fitting the update
 // pass's LDS.
+static uint32_t shape_max_pairs(const CampxShapeSpec& s) {
+  const int64_t R = (int64_t)s.rows * s.cols * s.n_layers;
+  const int64_t envs = ((int64_t)kSplitSpan + (int64_t)s.cols) / R + 2;
+  return (uint32_t)(envs * s.rows);
+}
+// dynamic LDS of a render wave: rows [L][pairs], slots [span / W + 8], 8 bytes each
+static size_t shape_render_lds(const CampxShapeSpec& s) {
+  return 8u * ((size_t)s.n_layers * shape_max_pairs(s) + (size_t)kSplitSpan / (size_t)s.cols + 72u);
+}
 static bool shape_tables_ok(const CampxShapeSpec& s) {
   if (s.cols < 16 || s.cols > 64) return false;
   int n_trail = 0;
   for (int k = 0; k < s.first_drape; ++k) n_trail += s.things[k].visible ? 1 : 0;
   if (n_trail * s.rows > 120) return false;          // 8 * S * H * 64 bytes of LDS per update wave
+  if (shape_render_lds(s) > 24 * 1024) return false;  // (a render wave's rows and slots)
   for (int k = 0; k < s.first_drape; ++k)
     if (s.things[k].visible && s.things[k].n_cells != 1) return false;   // (sprites are one cell)
   return true;
@@ -776,12 +907,19 @@ static int shape_n_trail(const CampxShapeSpec& s) {
   return n;
 }
 
-// Scratch of the frame-major path (CampxOutputs.trace): the offset trace uint32 [4][T][B], then
-// (8-byte aligned) the keyframes uint64 [ceil(T / key)][B][S][H].
+// bytes of the offset trace: uint32 [4 + ceil(S / 2)][T][B] - the things' offsets, then where the
+// trail sprites stand (row | col << 8, two sprites per word)
+static int64_t shape_offsets_bytes(const CampxShapeSpec& s, int64_t B, int32_t T) {
+  return ((4ll + (shape_n_trail(s) + 1) / 2) * 4 * T * B + 7) & ~7ll;
+}
+
+// Scratch of the frame-major path (CampxOutputs.trace): the offset trace, then
+// (8-byte aligned) the keyframes uint64 [ceil(T / key)][B][S][H], then the trail words at the
+// ends of the launch uint64 [B][S][H].
 int64_t shape_scratch_bytes(const CampxShapeSpec& s, int64_t B, int32_t T) {
   if (!shape_tables_ok(s) || B <= 0 || T <= 0) return 0;
-  const int64_t offsets = (16ll * T * B + 7) & ~7ll;
-  const int64_t keys = 8ll * ((T + kShapeKey - 1) / kShapeKey) * B * shape_n_trail(s) * s.rows;
+  const int64_t offsets = shape_offsets_bytes(s, B, T);
+  const int64_t keys = 8ll * ((T + kShapeKey - 1) / kShapeKey + 1) * B * shape_n_trail(s) * s.rows;
   return offsets + keys;
 }
 
@@ -836,19 +974,59 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
     }
     if (k < s.first_drape && th.visible) pp.trail_z[pp.n_trail++] = (uint32_t)k;
   }
+  for (int k = s.n_things - 1; k >= s.first_drape; --k) {
+    if (!((pp.thing[k] >> 8) & 1u)) continue;
+    pp.front[pp.n_front] = pp.thing[k] | ((uint32_t)k << 12);
+    pp.front_rows[pp.n_front] = pp.rowbits[k] ? pp.rowbits[k] : pp.static_rows;
+    ++pp.n_front;
+  }
+  pp.by_sh = make_div((uint32_t)(pp.n_trail * H > 0 ? pp.n_trail * H : 1));
   uint32_t* trace = reinterpret_cast<uint32_t*>(out.trace);
-  uint64_t* keys = reinterpret_cast<uint64_t*>(out.trace + ((16ll * T * B + 7) & ~7ll));
+  uint64_t* keys = reinterpret_cast<uint64_t*>(out.trace + shape_offsets_bytes(s, B, T));
   pp.trace = trace;
   pp.keys = keys;
   pp.B = B;
   pp.plane = (int64_t)T * B;
   const size_t lds = (size_t)8 * pp.n_trail * H * kWave;
+  uint64_t* state_words = keys + (int64_t)((T + kShapeKey - 1) / kShapeKey) * B * pp.n_trail * H;
+  const bool carried = pp.n_trail > 0 && backdrop_state != nullptr;
+  if (carried && !reset_first) {
+    const int64_t n = B * pp.n_trail * H;
+    hipLaunchKernelGGL(shape_words_from_backdrop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       pp, spec_dev, backdrop_state, state_words, B);
+  }
   hipLaunchKernelGGL(shape_update_split_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds,
-                     stream, sp, pp, spec_dev, st, backdrop_state, actions, out, trace, keys, B, T, reset_first);
+                     stream, sp, pp, spec_dev, st, state_words, actions, out, trace, keys, B, T, reset_first);
   const uint64_t reach = (uint64_t)pp.slab_bytes + ((pp.shift_base | pp.shift_slab) ? kSplitSpan - 1u : 0u);
   const uint64_t block_span = (uint64_t)kSplitSpan * kSplitWaves;
   const dim3 grid((unsigned)((((reach + block_span - 1) / block_span) + 7u) & ~(uint64_t)7), (unsigned)T);
-  hipLaunchKernelGGL(shape_render_split_kernel, grid, dim3(kSplitWaves * kWave), 0, stream, pp, out.obs);
+  pp.max_pairs = shape_max_pairs(s);
+  const size_t render_lds = shape_render_lds(s);
+#define CAMPX_SHAPE_RENDER(NF, NS) \
+  hipLaunchKernelGGL((shape_render_split_kernel<NF, NS>), grid, dim3(kWave), render_lds, stream, pp, out.obs)
+#define CAMPX_SHAPE_RENDER_NS(NF)                     \
+  do {                                                \
+    if (pp.n_trail == 0) CAMPX_SHAPE_RENDER(NF, 0);   \
+    else if (pp.n_trail <= 2) CAMPX_SHAPE_RENDER(NF, 2); \
+    else CAMPX_SHAPE_RENDER(NF, 8);                   \
+  } while (0)
+  switch (pp.n_front) {
+    case 1: CAMPX_SHAPE_RENDER_NS(1); break;
+    case 2: CAMPX_SHAPE_RENDER_NS(2); break;
+    case 3: CAMPX_SHAPE_RENDER_NS(3); break;
+    case 4: CAMPX_SHAPE_RENDER_NS(4); break;
+    case 5: CAMPX_SHAPE_RENDER_NS(5); break;
+    case 6: CAMPX_SHAPE_RENDER_NS(6); break;
+    case 7: CAMPX_SHAPE_RENDER_NS(7); break;
+    default: CAMPX_SHAPE_RENDER_NS(8); break;
+  }
+#undef CAMPX_SHAPE_RENDER_NS
+#undef CAMPX_SHAPE_RENDER
+  if (carried) {
+    const int64_t n = B * H;
+    hipLaunchKernelGGL(shape_backdrop_from_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       pp, spec_dev, state_words, backdrop_state, B);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }

@@ -24,12 +24,13 @@ from . import gamespec
 from .rendering import Observation
 
 
-# Games without trails can run rollouts as two kernels (update pass -> offset trace ->
-# frame-major render with memory-aligned stores, csrc/k_shape.hip).  Built, parity-tested
-# and MEASURED SLOWER than the single serial kernel (Hello World's art without trails,
-# B = 32 768: 4.0-4.2 against 4.9 TB/s; NOTES.md 3.7, profiles/r03_shape_rocprofv3.txt), so
-# it is off by default; CAMPX_SHAPE_SPLIT=1 (or setting this flag) turns it on.
-SPLIT_TRAIL_FREE = os.environ.get('CAMPX_SHAPE_SPLIT', '0') == '1'
+# Rollouts that keep every frame run FRAME-MAJOR (round 5, csrc/k_shape.hip): an update pass, then
+# a render pass of one-shot waves with memory-aligned 2 KiB windows that computes every row of the
+# observation arithmetically from 64-bit row words (the things' masks in every column rotation,
+# the per-environment trail words of sprites painted before the first drape) - the one-cell
+# tier's store pattern instead of "every wave streams its own row".  Boards with rows of 16 to 64
+# cells; CAMPX_SHAPE_SPLIT=0 (read by the library too): always the one-wave-per-environment kernel.
+FRAME_MAJOR = os.environ.get('CAMPX_SHAPE_SPLIT', '1') != '0'
 
 
 class ShapeGame(object):
@@ -63,6 +64,16 @@ class ShapeGame(object):
     # no visible sprite is painted before the first drape: the backdrop never changes, and
     # rollouts can take the two-kernel path (csrc/k_shape.hip shape_render_kernel)
     self.trail_free = not any(self.spec.things[k].visible for k in range(self.spec.first_drape))
+    # the frame-major path's row tables (campx_shape_tables_build: pure host code), if the game
+    # is one for it
+    self._tables = None
+    n = int(_hip.lib.campx_shape_tables_bytes(ctypes.byref(self.spec)))
+    if n > 0 and FRAME_MAJOR:
+      host = torch.zeros((n + 7) // 8, dtype=torch.int64)
+      _hip.check(_hip.lib.campx_shape_tables_build(ctypes.byref(self.spec),
+                                                   ctypes.c_void_p(host.data_ptr()), host.numel() * 8),
+                 'campx_shape_tables_build')
+      self._tables = host.to(self.device)
     B, dev = self.batch, self.device
     blob = ctypes.string_at(ctypes.addressof(self.spec), ctypes.sizeof(self.spec))
     self._spec_host = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
@@ -171,11 +182,14 @@ class ShapeGame(object):
       if want_board:
         board = (torch.empty((T, B, H, W), dtype=torch.int8, device=dev) if keep_obs
                  else self._board)
-    # Games without trails: the scratch of the two-kernel path (the things' offsets per
-    # frame, 16 bytes per environment-frame); the library ignores it for other games / calls
-    trace = (torch.empty((4, T, B), dtype=torch.int32, device=dev)
-             if SPLIT_TRAIL_FREE and self.trail_free and keep_obs and T > 0
-             and obs_dtype == torch.int8 else None)
+    # the scratch of the frame-major path (the things' offsets per frame, the trail words every
+    # fourth frame); the library ignores it for the calls that path does not take
+    trace = None
+    if (self._tables is not None and keep_obs and T > 0 and obs_dtype == torch.int8
+        and board is None):
+      need = int(_hip.lib.campx_shape_scratch_bytes(ctypes.byref(self.spec), B, T))
+      if need > 0:
+        trace = torch.empty((need + 7) // 8, dtype=torch.int64, device=dev)
     return dict(obs=obs, board=board,
                 reward=(torch.empty((T, B), dtype=torch.float32, device=dev)
                         if self.any_reward else None),
@@ -213,7 +227,8 @@ class ShapeGame(object):
     self._op(self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self.backdrop,
              ids, out['obs'], out['board'], out['reward'], out['discount'], out['done'],
              self._bad if validate else None, self._bad_flag if validate else None,
-             bool(reset_first), False, out.get('trace'))
+             bool(reset_first), False, out.get('trace'),
+             self._tables if out.get('trace') is not None else None)
     self.frame = T if reset_first else self.frame + T
     if validate:
       self._after_launch()

@@ -88,54 +88,89 @@ def test_zoo_random_streams_vs_oracle(name, batch):
       assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
 
 
+def _kernels_of(fn):
+  from torch.profiler import ProfilerActivity, profile
+  with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    fn()
+    torch.cuda.synchronize()
+  return [e.key for e in prof.key_averages() if 'campx_impl' in e.key]
+
+
+FRAME_MAJOR_GAMES = ['hello_world', 'shape_zoo3', 'shape_zoo4']     # rows of 16 to 64 cells
+
+
+@pytest.mark.parametrize('name', FRAME_MAJOR_GAMES)
 @pytest.mark.parametrize('batch', [4, 64, 1000, 4096])
-def test_two_kernel_path_for_games_without_trails(batch):
-  """shape_zoo4 (Hello World's art, the drape painted first: no trails) takes the update pass +
-  frame-major render kernels when a rollout keeps every frame: against the oracle, several
-  launches with the state carried over, with the flat board, and against the single serial
-  kernel (the same buffers without the offset-trace scratch)."""
+def test_frame_major_path_against_the_oracle_and_the_serial_kernel(name, batch):
+  """Round 5: rollouts that keep every frame run as an update pass + a frame-major render pass
+  that computes every row of the observation from 64-bit row words (csrc/k_shape.hip
+  shape_render_split_kernel) - Hello World and shape_zoo3 WITH their trails (per-environment
+  trail words, a keyframe every fourth frame, the frames since replayed from the offset trace),
+  shape_zoo4 without.  Against the oracle, several launches with the state carried over (the
+  carried backdrop <-> trail words), a quit in the middle of a launch, and against the serial
+  one-wave-per-environment kernel on a twin engine, byte for byte; play() in between runs the
+  serial kernel on the same state."""
   from campx_amd import shapes
-  name = 'shape_zoo4'
   game, _ = _game(batch, name)
-  assert game.fused.trail_free
-  serial, _ = _game(batch, name)
-  shapes.SPLIT_TRAIL_FREE = True       # (off by default: it measured slower than the serial kernel)
+  assert game.fused._tables is not None
+  shapes.FRAME_MAJOR = False
+  try:
+    serial, _ = _game(batch, name)
+  finally:
+    shapes.FRAME_MAJOR = True
+  assert serial.fused._tables is None
   og = cpu.OracleGame.from_description(gamespec.describe(SHAPE_GAMES[name]()))
   rng = np.random.RandomState(batch)
-  for launch, T in enumerate([1, 70, 33]):
+  quits = 0
+  for launch, T in enumerate([1, 70, 33, 9, 4, 5]):
     actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
     acts = torch.from_numpy(actions)
-    out = game.rollout(acts, want_board=True)
-    shapes.SPLIT_TRAIL_FREE = False
-    assert out['trace'] is not None
-    bufs = None
-    bufs = serial.fused.rollout_buffers(T, want_board=True)
-    assert bufs['trace'] is None
-    alone = serial.rollout(acts, out=bufs)
-    shapes.SPLIT_TRAIL_FREE = True
+    bufs = game.fused.rollout_buffers(T)
+    assert bufs['trace'] is not None
+    if launch == 1:
+      names = _kernels_of(lambda: game.fused.rollout_buffers(T) and None)
+      game2, _ = _game(batch, name)
+      names = _kernels_of(lambda: game2.rollout(acts, out=game2.fused.rollout_buffers(T)))
+      short = sorted(n.split('(')[0].split('::')[-1].split('<')[0] for n in names)
+      assert 'shape_render_split_kernel' in short and 'shape_update_split_kernel' in short and \
+          'shape_rollout_kernel' not in short, names
+    out = game.rollout(acts, out=bufs)
+    sbufs = serial.fused.rollout_buffers(T)
+    assert sbufs['trace'] is None
+    alone = serial.rollout(acts, out=sbufs)
     ref = og.rollout(actions, reset_first=(launch == 0))
-    for k in ('obs', 'board', 'reward', 'discount', 'done'):
+    for k in ('obs', 'reward', 'discount', 'done'):
+      if out[k] is None:
+        continue
       assert _same(out[k].cpu().numpy(), ref[k]), (launch, k)
       assert _same(out[k].cpu().numpy(), alone[k].cpu().numpy()), (launch, k)
     assert torch.equal(game.fused.pos, serial.fused.pos)
+    assert torch.equal(game.fused.backdrop, serial.fused.backdrop), launch
     assert _same(game.fused.ret.cpu().numpy(), serial.fused.ret.cpu().numpy())
-  shapes.SPLIT_TRAIL_FREE = False
-  # play() in between uses the serial kernel on the same state
-  obs, _, _ = game.play(torch.zeros(batch, dtype=torch.int8))
-  obs2, _, _ = serial.play(torch.zeros(batch, dtype=torch.int8))
-  assert torch.equal(obs.layered_board, obs2.layered_board)
-  assert ref['done'].sum() > 0 or batch < 64
+    quits += int(ref['done'].sum())
+    if launch in (2, 4):
+      # play() in between: the serial kernel, on the state the frame-major launches left
+      one = rng.randint(0, 4, size=batch).astype(np.int8)
+      obs, _, _ = game.play(torch.from_numpy(one))
+      obs2, _, _ = serial.play(torch.from_numpy(one))
+      ref1 = og.rollout(one[None], reset_first=False)
+      assert torch.equal(obs.layered_board, obs2.layered_board)
+      assert _same(obs.layered_board.cpu().numpy(), ref1['obs'][0])
+  assert quits > 0 or batch < 64
 
 
-def test_games_with_trails_never_take_the_two_kernel_path():
+def test_frame_major_needs_whole_chunks_and_every_frame():
   from campx_amd import shapes
-  game, _ = _game(64)                       # Hello World: sprites 1 and 2 behind the drape
-  assert not game.fused.trail_free
-  shapes.SPLIT_TRAIL_FREE = True
-  try:
-    assert game.fused.rollout_buffers(10)['trace'] is None
-  finally:
-    shapes.SPLIT_TRAIL_FREE = False
+  game, _ = _game(5)                        # 5 x 3 276 bytes per frame: not whole 16-byte chunks
+  acts = torch.randint(0, 4, (10, 5), dtype=torch.int8, device='cuda')
+  names = _kernels_of(lambda: game.rollout(acts))
+  assert len(names) == 1 and 'shape_rollout_kernel' in names[0], names
+  game, _ = _game(64)
+  assert game.fused.rollout_buffers(10, keep_obs=False)['trace'] is None
+  assert game.fused.rollout_buffers(10, want_board=True)['trace'] is None
+  assert game.fused.rollout_buffers(10, obs_dtype=torch.float16)['trace'] is None
+  game, _ = _game(64, 'shape_zoo0')         # rows of 9 cells: not a game for the row-word render
+  assert game.fused._tables is None and game.fused.rollout_buffers(10)['trace'] is None
 
 
 def test_golden_rollout(golden):

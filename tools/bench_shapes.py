@@ -9,13 +9,15 @@ import shape_zoo
 
 from campx_amd import shapes
 
-# hello_world: trails (serial kernel); shape_zoo4: the same art without trails, on the serial
-# kernel (the default) and on the two-kernel path (`split`: shapes.SPLIT_TRAIL_FREE)
-for which, B in (('hello_world', 4096), ('hello_world', 32768), ('shape_zoo4', 4096),
-                 ('shape_zoo4', 32768), ('shape_zoo4 split', 4096), ('shape_zoo4 split', 32768)):
-  shapes.SPLIT_TRAIL_FREE = which.endswith('split')
+# hello_world: trails; shape_zoo4: the same art without trails; each on the frame-major path (the
+# default since round 5: update pass + row-word render, csrc/k_shape.hip) and on the serial
+# one-wave-per-environment kernel (`serial`: shapes.FRAME_MAJOR = False when the game is built)
+for which, B in (('hello_world', 4096), ('hello_world', 32768), ('hello_world serial', 4096),
+                 ('hello_world serial', 32768), ('shape_zoo4', 4096), ('shape_zoo4', 32768),
+                 ('shape_zoo4 serial', 4096), ('shape_zoo4 serial', 32768)):
+  shapes.FRAME_MAJOR = not which.endswith('serial')
   T = 100
-  if which == 'hello_world':
+  if which.startswith('hello_world'):
     game, _, _, _ = hello_world.make_game(batch=B, device='cuda')
   else:
     game = shape_zoo.library_builders()['shape_zoo4'](batch=B, device='cuda')

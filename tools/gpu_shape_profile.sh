@@ -9,10 +9,10 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp
 cmd="python3 $GRAFT_REPO_ROOT/tools/bench_shapes.py"
-rocprofv3 --kernel-trace --stats -d $out -o trace -- $cmd > $out/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $out -o pmc_insts -- $cmd > $out/pmc_insts.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $out -o pmc_wait -- $cmd > $out/pmc_wait.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out -o pmc_write -- $cmd > $out/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $out -o trace -- $cmd > $out/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $out -o pmc_insts -- $cmd > $out/pmc_insts.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $out -o pmc_wait -- $cmd > $out/pmc_wait.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out -o pmc_write -- $cmd > $out/pmc_write.log 2>&1
 grep -v amdgpu $out/trace.log | grep "TB/s\|per launch"
 cd $GRAFT_REPO_ROOT
 python3 tools/rocpd_summary.py gpurun_out/$tag > gpurun_out/$tag/summary.txt 2>&1
