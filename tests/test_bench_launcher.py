@@ -140,12 +140,55 @@ def test_two_rccl_ranks_through_the_real_launcher():
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(_hip_devices() < 8, reason='needs eight HIP devices (BASELINE config 5)')
+def test_eight_rccl_ranks_keep_the_one_rank_step_time(tmp_path):
+  """BASELINE config 5 itself: 8 x 65 536 environments, RCCL all-gather of the episode returns.
+  Weak scaling with no collective on the step path: every rank's `ms_per_step` must stay within
+  5 % of the N = 1 figure measured in the same session, and the gathered log must match on every
+  rank.  Skips without an 8-GPU node (none was ever available to this build: DESIGN section 7 says
+  "unmeasured" until this test has run); when it runs it leaves a SCALE-style record."""
+  args = ['--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-extras']
+  one = _run(['--gpus', '1'] + args)
+  assert one.returncode == 0, one.stderr[-3000:]
+  base = json.loads([l for l in one.stdout.splitlines() if l.startswith('{')][0])
+  r = _run(['--gpus', '8'] + args)
+  assert r.returncode == 0, r.stderr[-3000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+  cfg = line['config']
+  assert line['n_gpus'] == 8 and cfg['rccl_world'] == 8 and cfg['global_batch'] == 8 * 65536
+  assert cfg['per_rank_gathered_log_matches_local'] == [True] * 8
+  record = {'n1': {'value': base['value'], 'ms_per_step': base['ms_per_step']},
+            'n8': {'value': line['value'], 'ms_per_step': line['ms_per_step'],
+                   'per_rank_ms_per_step': cfg['per_rank_ms_per_step'], 'window_us': cfg['window_us'],
+                   'gathers': cfg['gathers']},
+            'efficiency': line['value'] / (8 * base['value'])}
+  out = os.path.join(REPO, 'gpurun_out', 'scale_8gpu_test.json')
+  os.makedirs(os.path.dirname(out), exist_ok=True)
+  with open(out, 'w') as f:
+    json.dump(record, f)
+  for ms in cfg['per_rank_ms_per_step']:
+    assert ms <= 1.05 * base['ms_per_step'], (ms, base['ms_per_step'])
+  assert record['efficiency'] >= 0.9, record
+
+
+@pytest.mark.gpu
 def test_one_rccl_rank_through_the_real_launcher():
-  """What a one-GPU box CAN show of that path: the launcher, an RCCL group of one, the gather."""
-  r = _run(['--gpus', '1', '--force-dist', '--steps', '5', '--warmup', '2', '--no-cpu-baseline',
+  """What a one-GPU box CAN show of that path: the launcher, an RCCL group of one, the gather -
+  at the DRIVER's own command (`--steps 20 --warmup 5`).  VERDICT r4: the driver's round-4 line
+  read ms_per_step = 1.219 x kernel_ms (0.8 ms after the last launch); the line now says where a
+  window's time went (`config.window_us`, `config.gathers`), RCCL's stream is high priority, and
+  60 driver-style runs read 1.008-1.026 (profiles/r05_driver_repro.txt): the bound is 1.05."""
+  r = _run(['--gpus', '1', '--force-dist', '--steps', '20', '--warmup', '5', '--no-cpu-baseline',
             '--no-extras'])
   assert r.returncode == 0, r.stderr[-3000:]
   line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-  assert line['config']['rccl_world'] == 1 and line['config']['gathered_log_matches_local'] is True
+  cfg = line['config']
+  assert cfg['rccl_world'] == 1 and cfg['gathered_log_matches_local'] is True
+  # where the window's time went, and when its one gather ran: well before the launches ended
+  w, g = cfg['window_us'], cfg['gathers']
+  assert set(w) >= {'loop', 'log_wait', 'synchronize', 'total', 'launches_done'} and len(g) == 1
+  assert abs(w['total'] - line['ms_per_step'] * 20 * 1e3) < 1.0
+  assert 0 < g[0]['ready_us'] < g[0]['done_us'] < w['launches_done']
+  assert g[0]['done_us'] - g[0]['ready_us'] < 500.0
   # the closing barrier is off the clock: the step time is the kernels' plus the host's share
-  assert line["ms_per_step"] < 1.25 * line["roofline"]["kernel_ms"]
+  assert line["ms_per_step"] < 1.05 * line["roofline"]["kernel_ms"], (w, g)
