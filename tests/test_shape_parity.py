@@ -127,13 +127,6 @@ def test_frame_major_path_against_the_oracle_and_the_serial_kernel(name, batch):
     acts = torch.from_numpy(actions)
     bufs = game.fused.rollout_buffers(T)
     assert bufs['trace'] is not None
-    if launch == 1:
-      names = _kernels_of(lambda: game.fused.rollout_buffers(T) and None)
-      game2, _ = _game(batch, name)
-      names = _kernels_of(lambda: game2.rollout(acts, out=game2.fused.rollout_buffers(T)))
-      short = sorted(n.split('(')[0].split('::')[-1].split('<')[0] for n in names)
-      assert 'shape_render_split_kernel' in short and 'shape_update_split_kernel' in short and \
-          'shape_rollout_kernel' not in short, names
     out = game.rollout(acts, out=bufs)
     sbufs = serial.fused.rollout_buffers(T)
     assert sbufs['trace'] is None
@@ -159,11 +152,28 @@ def test_frame_major_path_against_the_oracle_and_the_serial_kernel(name, batch):
   assert quits > 0 or batch < 64
 
 
+def test_frame_major_is_the_path_a_full_rollout_takes():
+  game, _ = _game(64)
+  acts = torch.randint(0, 4, (20, 64), dtype=torch.int8, device='cuda')
+  bufs = game.fused.rollout_buffers(20)
+  game.rollout(acts, out=bufs)
+  for attempt in range(3):           # (the profiler now and then hands back an empty trace)
+    names = _kernels_of(lambda: game.rollout(acts, out=bufs))
+    if names:
+      break
+  short = sorted(n.split('(')[0].split('::')[-1].split('<')[0] for n in names)
+  assert 'shape_render_split_kernel' in short and 'shape_update_split_kernel' in short and \
+      'shape_rollout_kernel' not in short, names
+
+
 def test_frame_major_needs_whole_chunks_and_every_frame():
   from campx_amd import shapes
   game, _ = _game(5)                        # 5 x 3 276 bytes per frame: not whole 16-byte chunks
   acts = torch.randint(0, 4, (10, 5), dtype=torch.int8, device='cuda')
-  names = _kernels_of(lambda: game.rollout(acts))
+  for attempt in range(3):
+    names = _kernels_of(lambda: game.rollout(acts))
+    if names:
+      break
   assert len(names) == 1 and 'shape_rollout_kernel' in names[0], names
   game, _ = _game(64)
   assert game.fused.rollout_buffers(10, keep_obs=False)['trace'] is None
