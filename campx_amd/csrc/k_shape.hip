@@ -466,6 +466,9 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t a, uint32_t d, uint32_t n)
 
 // The update pass: one lane per environment, one wave per workgroup (its 64 environments' trail
 // words in LDS: [S * H][64] uint64, 8 * S * H * 64 bytes of dynamic shared memory).
+// KS: the number of trail sprites when it is 0, 1 or 2 (loops unrolled, per-sprite constants in
+// registers), -1: whatever pp.n_trail says.
+template <int KS>
 __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
     ShapeParams sp, ShapeSplitParams pp, const CampxShapeSpec* __restrict__ spec, CampxState st,
     uint64_t* __restrict__ state_words, const int8_t* __restrict__ actions, CampxOutputs out,
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
   const int64_t env0 = (int64_t)blockIdx.x * kWave;
   const int64_t env = env0 + lane;
   const bool live = env < B;
-  const int H = sp.rows, W = sp.cols, N = sp.n_things, S = pp.n_trail, SH = S * H;
+  const int H = sp.rows, W = sp.cols, N = sp.n_things, S = KS >= 0 ? KS : pp.n_trail, SH = S * H;
   const int64_t n_words = (B - env0 < kWave ? B - env0 : (int64_t)kWave) * SH;
   // (the carried trail words: shape_words_from_backdrop_kernel made them from the backdrop state)
   for (int i = lane; i < SH * kWave; i += kWave)
@@ -498,18 +501,32 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
     if (st.ret) ret = st.ret[env];
   }
   uint32_t trail_pos[4] = {0u, 0u, 0u, 0u};   // sprite s: row | col << 8 in half s & 1 of word s >> 1
+  // (the sprites' constants, fetched once: thing word and the byte of the offset words it owns)
+  uint32_t tz[KS > 0 ? KS : 1], tth[KS > 0 ? KS : 1];
+  if (KS > 0) {
+#pragma unroll
+    for (int s = 0; s < (KS > 0 ? KS : 0); ++s) {
+      tz[s] = pp.trail_z[s];
+      tth[s] = pp.thing[tz[s]];
+    }
+  }
+  uint64_t* const my_trail = trail + lane * SH;
   auto paint_trails = [&]() {        // every trail sprite, back to front: mine, nobody else's
     trail_pos[0] = trail_pos[1] = trail_pos[2] = trail_pos[3] = 0u;
-    for (int s = 0; s < S; ++s) {
-      const uint32_t z = pp.trail_z[s], th = pp.thing[z];
+#pragma unroll
+    for (int s = 0; s < (KS >= 0 ? KS : CAMPX_SHAPE_MAX_THINGS); ++s) {
+      if (KS < 0 && s >= S) break;
+      const uint32_t z = KS > 0 ? tz[s] : pp.trail_z[s], th = KS > 0 ? tth[s] : pp.thing[z];
       const int sh = 8 * (z & 3);
       const uint32_t r = wrap_add(th >> 16 & 0xffu, ((z < 4 ? orow[0] : orow[1]) >> sh) & 0xffu, (uint32_t)H);
       const uint32_t c = wrap_add(th >> 24, ((z < 4 ? ocol[0] : ocol[1]) >> sh) & 0xffu, (uint32_t)W);
       const uint64_t bit = 1ull << c;
       // (LDS atomics without a return value: the wave never waits for a word to come back - as
       // read-modify-write these four dependent round trips were most of a frame's 1.2 us)
-      for (int q = 0; q < S; ++q) {
-        uint64_t* w = &trail[lane * SH + q * H + (int)r];
+#pragma unroll
+      for (int q = 0; q < (KS >= 0 ? KS : CAMPX_SHAPE_MAX_THINGS); ++q) {
+        if (KS < 0 && q >= S) break;
+        uint64_t* w = my_trail + q * H + (int)r;
         if (q == s) __hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_fetch_and(w, ~bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
       const int t = t0 + j < T ? t0 + j : T - 1;
       a16[j] = live ? (int)actions[(int64_t)t * B + env] : 4;
     }
-#pragma unroll 1
+#pragma unroll 4
     for (int j = 0; j < kAhead; ++j) {
       const int t = t0 + j;
       if (t >= T) break;        // (uniform)
@@ -542,7 +559,7 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
         over = 0;
         ret = 0.0f;
         rebuilt = 0x80u;
-        for (int i = 0; i < SH; ++i) trail[lane * SH + i] = 0ull;
+        for (int i = 0; i < SH; ++i) my_trail[i] = 0ull;
       }
       float reward = __builtin_nanf("");
       if (valid) {
@@ -995,8 +1012,14 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
     hipLaunchKernelGGL(shape_words_from_backdrop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        pp, spec_dev, backdrop_state, state_words, B);
   }
-  hipLaunchKernelGGL(shape_update_split_kernel, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds,
-                     stream, sp, pp, spec_dev, st, state_words, actions, out, trace, keys, B, T, reset_first);
+#define CAMPX_SHAPE_UPDATE(KS)                                                                              \
+  hipLaunchKernelGGL(shape_update_split_kernel<KS>, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds, \
+                     stream, sp, pp, spec_dev, st, state_words, actions, out, trace, keys, B, T, reset_first)
+  if (pp.n_trail == 0) CAMPX_SHAPE_UPDATE(0);
+  else if (pp.n_trail == 1) CAMPX_SHAPE_UPDATE(1);
+  else if (pp.n_trail == 2) CAMPX_SHAPE_UPDATE(2);
+  else CAMPX_SHAPE_UPDATE(-1);
+#undef CAMPX_SHAPE_UPDATE
   const uint64_t reach = (uint64_t)pp.slab_bytes + ((pp.shift_base | pp.shift_slab) ? kSplitSpan - 1u : 0u);
   const uint64_t block_span = (uint64_t)kSplitSpan * kSplitWaves;
   const dim3 grid((unsigned)((((reach + block_span - 1) / block_span) + 7u) & ~(uint64_t)7), (unsigned)T);
