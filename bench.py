@@ -48,7 +48,9 @@ BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194,
                       # wide tier: 6 characters, one mover (S = 2) + the done byte
                       'maze16': 6 * 256 + 4 + 1 + 4 + 1, 'maze32': 6 * 1024 + 4 + 1 + 4 + 1,
                       # 16x16 sokoban, two boxes: 6 characters, three movers (S = 6)
-                      'sokoban16': 6 * 256 + 4 + 1 + 12 + 1}
+                      'sokoban16': 6 * 256 + 4 + 1 + 12 + 1,
+                      # Hello World 13x36 (shape tier): 7 characters, five things' offsets (S = 10)
+                      'hello_world': 7 * 468 + 4 + 1 + 20 + 1}
 WORKLOADS = {
     'boat_race': ('boat_race 5x5', 65536),
     'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
@@ -62,6 +64,8 @@ WORKLOADS = {
     # not a BASELINE config: a multi-mover rule game above 128 cells - 4.4 million states
     # enumerated on the device (campx_amd/enumerate_states.py), run by the wide tier
     'sokoban16': ('sokoban 16x16 with two boxes (build-authored level 3, wide tier)', 65536),
+    # not a BASELINE config: the reference's Hello World notebook (rigid multi-cell things, trails)
+    'hello_world': ('Hello World 13x36, 7 characters, trails (shape tier)', 32768),
 }
 
 
@@ -248,6 +252,9 @@ def measured_traffic(game, batch, frames, path):
 def kernel_names(fused, split, B=None, T=None):
   if type(fused).__name__ == 'WideGame':
     return 'wide_update_kernel + render_kernel'
+  if type(fused).__name__ == 'ShapeGame':
+    return ('shape_update_split_kernel + shape_render_split_kernel' if fused._tables is not None
+            else 'shape_rollout_kernel')
   if split:
     # (one-mover games at small batches: update pass and render share ONE launch - asked of the
     # library itself, campx_flow_shared: its bounds and knobs, not a copy of them)
@@ -365,8 +372,8 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   if log is not None:
     log.wait()
     log.align()                       # the timed window starts on a block boundary of the log
-  if log is not None and on_gpu:
-    log.timing = []                   # the gathers of the timed window leave their start / end events
+  if log is not None and on_gpu and os.environ.get('CAMPX_BENCH_NO_GATHER_TIMING') != '1':
+    log.time_gathers()                # the gathers of the timed window leave their start / end events
   gc.collect()                        # (before the fence: the chip should not idle longer than it must)
   gc.disable()                        # no collector pause between two launches of the timed region
   fence()
@@ -380,7 +387,12 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   if on_gpu:
     ev1.record()
   t_loop = time.perf_counter()
+  t_launches = t_loop
+  if on_gpu:
+    ev1.synchronize()                 # the last launch has finished: was every gather done by then?
+    t_launches = time.perf_counter()
   if log is not None:
+    log.poll()
     log.wait()
   t_wait = time.perf_counter()
   if on_gpu:
@@ -402,13 +414,26 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   gc.enable()
   # where the window's time went, on the host's clock, and when its gathers ran, on the device's
   # (relative to the event that opens the window on the launch stream)
-  window_us = {'loop': (t_loop - t0) * 1e6, 'log_wait': (t_wait - t_loop) * 1e6,
-               'synchronize': (t_sync - t_wait) * 1e6, 'total': elapsed * 1e6}
+  if log is not None:
+    log.poll()                        # (whatever was not seen complete before: stamped now, at the end)
+  window_us = {'loop': (t_loop - t0) * 1e6, 'launches': (t_launches - t_loop) * 1e6,
+               'log_wait': (t_wait - t_launches) * 1e6, 'synchronize': (t_sync - t_wait) * 1e6,
+               'total': elapsed * 1e6}
   gathers = None
   if log is not None and log.timing is not None:
-    gathers = [{'after_episode': n - log.timing[0][0] + gather_every,
-                'ready_us': ev0.elapsed_time(ready) * 1e3, 'done_us': ev0.elapsed_time(done) * 1e3}
-               for n, ready, done in log.timing]
+    # per gather of the window: when the block was complete (device clock, from the window's
+    # opening event), when the collective was issued and how long the call took the host, and
+    # when it was first SEEN complete (host clock from the window's start, asked once per
+    # launch: a gather still running after the last launch shows here)
+    gathers = [{'after_episode': rec['count'] - log.timing[0]['count'] + gather_every,
+                'ready_us': ev0.elapsed_time(rec['ready']) * 1e3,
+                'issued_us': (rec['issued'] - t0) * 1e6,
+                'call_us': (rec['returned'] - rec['issued']) * 1e6,
+                'seen_done_us': None if rec['seen_done'] is None else (rec['seen_done'] - t0) * 1e6,
+                # (asked right after the last launch finished: a gather that still ran then is
+                # what stretches the window)
+                'done_when_launches_ended': rec['seen_done'] is not None and rec['seen_done'] <= t_launches + 2e-5}
+               for rec in log.timing]
     window_us['launches_done'] = ev0.elapsed_time(ev1) * 1e3
     log.timing = None
   if dist is not None:
@@ -642,10 +667,13 @@ def run_rank(args):
             'rccl_world': world if (dist is not None and standin is None) else None,
             'gather_every': m['gather_every'],
             'settle_launches': m['settle'],
-            # rank 0's timed window: host clock (the loop that issues the launches, the wait for
-            # the log's last gather, the synchronise that closes the window) and, on the device
-            # clock from the window's opening event, when the launches were done and when each
-            # gather of the window could start (`ready_us`) and had finished (`done_us`)
+            # rank 0's timed window: host clock (the loop that issues the launches, the wait for the
+            # last launch to finish, for the log's last gather, the synchronise that closes the window) and, on the device
+            # clock from the window's opening event, when the launches were done; per gather:
+            # `ready_us` (device clock: its block complete), `issued_us` / `call_us` / `seen_done_us`
+            # (host clock from the window's start: the collective issued, the call's own cost,
+            # first seen complete - asked once per launch, once when the last launch has finished,
+            # once at the end), `done_when_launches_ended`
             'window_us': m['window_us'],
             'gathers': m['gathers'],
             'per_rank_ms_per_step': per_rank_ms,
@@ -660,7 +688,7 @@ def run_rank(args):
     solo = world == 1 and standin is None and not args.force_dist
     if solo and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds,
-                                          batch=4096 if args.game.startswith(('maze', 'sokoban16')) else 65536)
+                                          batch=4096 if args.game.startswith(('maze', 'sokoban16', 'hello')) else 65536)
       line['cpu_baseline']['generic_b1'] = generic_b1()
       line['cpu_baseline']['reference_b1_build_container'] = {
           'value': 954.8, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference',
@@ -698,7 +726,7 @@ def run_rank(args):
       also = []
       # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
       # second one's 4.4 M-state table is enumerated on the device during its_showtime())
-      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16'):
+      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16', 'hello_world'):
         oname, ob = WORKLOADS[other]
         steps = args.steps
         om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
@@ -713,7 +741,7 @@ def run_rank(args):
                                  om['per_launch_ms']),
             'cpu_baseline': None if args.no_cpu_baseline else
                             cpu_baseline(other, T, args.cpu_seconds / 2,
-                                         batch=4096 if other.startswith(('maze', 'sokoban16')) else ob)})
+                                         batch=4096 if other.startswith(('maze', 'sokoban16', 'hello')) else ob)})
         del om
         torch.cuda.empty_cache()
       line['also'] = also

@@ -12,6 +12,8 @@ side stream from a snapshot of the returns, so the next episode's kernel never
 waits for it.
 """
 
+import time
+
 import torch
 
 
@@ -118,11 +120,25 @@ class ReturnLog(object):
     self._work = [None, None]
     self._count = 0
     self._last = None
-    # (bench.py: `timing = []` makes every gather leave a pair of events - recorded on the
-    # caller's stream when the block is complete, and on an observer stream once the
-    # collective has finished - so a line can say when its gather ran)
+    # (bench.py: `time_gathers()` makes every gather leave a record - see there)
     self.timing = None
-    self._observer = None
+
+  def time_gathers(self):
+    """From now on every gather leaves a record in `self.timing`: an event on the caller's
+    stream when the block was complete (`ready`), the host's clock before and after the
+    collective call (`issued`, `returned`) and the host's clock when the collective was first
+    SEEN complete (`seen_done`: `is_completed()` is asked once per episode while a gather is
+    pending, and by `poll()` whenever the caller likes - a query, ~1 us).  (Two earlier forms put
+    the END on the device clock with an observer stream that waited for the work object:
+    `Work.wait()` cost the host 0.5-2 ms per gather - at small batches, a launch per 20 us, it
+    tripled the step time - and what the observer's event then showed was the launch stream's
+    progress at the time of the call, not the collective's end.)"""
+    self.timing = []
+
+  def poll(self):
+    """Stamp the gathers that have completed since the last look with the host's clock."""
+    if self.timing:
+      self._poll()
 
   def row(self):
     """The float32 [batch] buffer the next episode accumulates its returns in."""
@@ -134,6 +150,8 @@ class ReturnLog(object):
     self._count += 1
     block, row = divmod(self._count, self.episodes)
     if row != 0:
+      if self.timing:
+        self._poll()
       return False
     i = (block - 1) & 1                      # the block just completed
     nxt = block & 1                          # about to be overwritten
@@ -142,8 +160,10 @@ class ReturnLog(object):
       work.wait()
     timed = self.timing is not None and self.on_gpu
     if timed:
+      self._poll()
       ready = torch.cuda.Event(enable_timing=True)
       ready.record()                         # the block's last episode has finished
+      issued = time.perf_counter()
     if self.dist is not None:
       self._work[i] = self.dist.all_gather_into_tensor(
           self._out[i].view(-1), self._log[i].view(-1), group=self.group,
@@ -151,20 +171,15 @@ class ReturnLog(object):
     else:
       self._out[i][0].copy_(self._log[i])
     if timed:
-      # the collective runs on the process group's own stream; an observer stream waits for
-      # it (never the caller's stream) and records when it was done
-      if self._observer is None:
-        self._observer = torch.cuda.Stream(self.device)
-      done = torch.cuda.Event(enable_timing=True)
-      if self.dist is not None:
-        with torch.cuda.stream(self._observer):
-          self._work[i].wait()
-          done.record()
-      else:
-        done.record()                        # (the local copy ran on the caller's stream)
-      self.timing.append((self._count, ready, done))
+      self.timing.append(dict(count=self._count, ready=ready, issued=issued,
+                              returned=time.perf_counter(), seen_done=None, work=self._work[i]))
     self._last = i
     return True
+
+  def _poll(self):
+    for rec in self.timing:
+      if rec['seen_done'] is None and (rec['work'] is None or rec['work'].is_completed()):
+        rec['seen_done'] = time.perf_counter()
 
   def align(self):
     """Skip to the start of the next block (rows already logged in the current one are
@@ -191,6 +206,8 @@ class ReturnLog(object):
     work = self._work[self._last]
     if work is not None:
       work.wait()
+    if self.timing:
+      self._poll()
     return self._out[self._last]
 
 

@@ -186,9 +186,10 @@ def test_one_rccl_rank_through_the_real_launcher():
   assert cfg['rccl_world'] == 1 and cfg['gathered_log_matches_local'] is True
   # where the window's time went, and when its one gather ran: well before the launches ended
   w, g = cfg['window_us'], cfg['gathers']
-  assert set(w) >= {'loop', 'log_wait', 'synchronize', 'total', 'launches_done'} and len(g) == 1
+  assert set(w) >= {'loop', 'launches', 'log_wait', 'synchronize', 'total', 'launches_done'} and len(g) == 1
   assert abs(w['total'] - line['ms_per_step'] * 20 * 1e3) < 1.0
-  assert 0 < g[0]['ready_us'] < g[0]['done_us'] < w['launches_done']
-  assert g[0]['done_us'] - g[0]['ready_us'] < 500.0
+  assert 0 < g[0]['ready_us'] < w['launches_done']
+  assert 0 < g[0]['issued_us'] < w['loop'] and 0 < g[0]['call_us'] < 5000.0
+  assert g[0]['done_when_launches_ended'] is True          # hidden under the launches that follow it
   # the closing barrier is off the clock: the step time is the kernels' plus the host's share
   assert line["ms_per_step"] < 1.05 * line["roofline"]["kernel_ms"], (w, g)

@@ -29,7 +29,7 @@ def main():
   cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '20',
          '--warmup', '5', '--no-cpu-baseline', '--no-extras'] + extra
   print('# ' + ' '.join(cmd[1:]))
-  print('# run  ms_per_step  kernel_ms  ratio   loop  log_wait  sync | launches_done  gather ready..done (us)')
+  print('# run  ms_per_step  kernel_ms  ratio   loop launches log_wait  sync | launches_done(dev)  gather: ready(dev) | issued+call..seen_done(host), done when the launches ended? (us)')
   worst = 0.0
   for i in range(n):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
@@ -42,10 +42,13 @@ def main():
     g = d['config']['gathers'] or []
     ratio = d['ms_per_step'] / d['roofline']['kernel_ms']
     worst = max(worst, ratio)
-    print('%3d  %.4f  %.4f  %.3f  %6.0f %6.0f %6.0f | %6.0f  %s' % (
-        i, d['ms_per_step'], d['roofline']['kernel_ms'], ratio, w['loop'], w['log_wait'],
-        w['synchronize'], w.get('launches_done', 0.0),
-        ' '.join('%.0f..%.0f' % (x['ready_us'], x['done_us']) for x in g)))
+    print('%3d  %.4f  %.4f  %.3f  %6.0f %6.0f %6.0f %6.0f | %6.0f  %s' % (
+        i, d['ms_per_step'], d['roofline']['kernel_ms'], ratio, w['loop'], w.get('launches', 0.0),
+        w['log_wait'], w['synchronize'], w.get('launches_done', 0.0),
+        ' '.join('%.0f | %.0f+%.0f..%s %s' % (
+            x['ready_us'], x['issued_us'], x['call_us'],
+            '-' if x['seen_done_us'] is None else '%.0f' % x['seen_done_us'],
+            'yes' if x.get('done_when_launches_ended') else 'NO') for x in g)))
     sys.stdout.flush()
   print('# worst ratio %.3f over %d runs' % (worst, n))
 
