@@ -998,53 +998,83 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
     ++pp.n_front;
   }
   pp.by_sh = make_div((uint32_t)(pp.n_trail * H > 0 ? pp.n_trail * H : 1));
-  uint32_t* trace = reinterpret_cast<uint32_t*>(out.trace);
-  uint64_t* keys = reinterpret_cast<uint64_t*>(out.trace + shape_offsets_bytes(s, B, T));
-  pp.trace = trace;
-  pp.keys = keys;
   pp.B = B;
-  pp.plane = (int64_t)T * B;
+  pp.max_pairs = shape_max_pairs(s);
   const size_t lds = (size_t)8 * pp.n_trail * H * kWave;
-  uint64_t* state_words = keys + (int64_t)((T + kShapeKey - 1) / kShapeKey) * B * pp.n_trail * H;
+  const size_t render_lds = shape_render_lds(s);
+  // the trail words at the ends of the launch sit behind the keyframes of a whole-T launch
+  uint64_t* state_words = reinterpret_cast<uint64_t*>(out.trace + shape_offsets_bytes(s, B, T)) +
+                          (int64_t)((T + kShapeKey - 1) / kShapeKey) * B * pp.n_trail * H;
   const bool carried = pp.n_trail > 0 && backdrop_state != nullptr;
   if (carried && !reset_first) {
     const int64_t n = B * pp.n_trail * H;
     hipLaunchKernelGGL(shape_words_from_backdrop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        pp, spec_dev, backdrop_state, state_words, B);
   }
-#define CAMPX_SHAPE_UPDATE(KS)                                                                              \
-  hipLaunchKernelGGL(shape_update_split_kernel<KS>, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds, \
-                     stream, sp, pp, spec_dev, st, state_words, actions, out, trace, keys, B, T, reset_first)
-  if (pp.n_trail == 0) CAMPX_SHAPE_UPDATE(0);
-  else if (pp.n_trail == 1) CAMPX_SHAPE_UPDATE(1);
-  else if (pp.n_trail == 2) CAMPX_SHAPE_UPDATE(2);
-  else CAMPX_SHAPE_UPDATE(-1);
-#undef CAMPX_SHAPE_UPDATE
+  // Long launches run as CHUNKS of frames, update pass and render alternating, like the one-cell
+  // tier's (campx_api.hip launch_split): a render wave gathers two dozen small pieces of the offset
+  // trace and the keyframes, which come from the 256 MB memory-side cache while a chunk's scratch
+  // fits it and from HBM, piece by piece, when it does not - Hello World, render kernel alone:
+  // B x T = 1.6 M environment-frames 5.8 TB/s, 3.3 M 5.4, 6.6 M 3.9 (the trail-free art, which
+  // reads a third of that, holds 6.7).  A chunk is at most CAMPX_SHAPE_CHUNK_KF thousand
+  // environment-frames (2 000; bench.py --game hello_world, of peak, whole / 700 / 1 000 / 1 400 /
+  // 2 000 / 2 800: B = 32 768 0.70 / 0.77 / 0.79 / 0.76 / 0.81 / 0.80, B = 65 536 0.47 / 0.76 / 0.79 /
+  // 0.83 / 0.83 / 0.83), a multiple of the key interval.
+  static const int64_t chunk_env_frames = [] {
+    const char* v = getenv("CAMPX_SHAPE_CHUNK_KF");
+    return (int64_t)(v && *v ? atoll(v) : 2000) * 1000;
+  }();
+  int64_t chunk = chunk_env_frames / B;
+  chunk = chunk / kShapeKey * kShapeKey;
+  chunk = chunk < kShapeKey ? kShapeKey : chunk;
   const uint64_t reach = (uint64_t)pp.slab_bytes + ((pp.shift_base | pp.shift_slab) ? kSplitSpan - 1u : 0u);
   const uint64_t block_span = (uint64_t)kSplitSpan * kSplitWaves;
-  const dim3 grid((unsigned)((((reach + block_span - 1) / block_span) + 7u) & ~(uint64_t)7), (unsigned)T);
-  pp.max_pairs = shape_max_pairs(s);
-  const size_t render_lds = shape_render_lds(s);
+  const unsigned grid_x = (unsigned)((((reach + block_span - 1) / block_span) + 7u) & ~(uint64_t)7);
+  for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+    const int32_t n = (int32_t)(T - t0 < chunk ? T - t0 : chunk);
+    CampxOutputs part = out;
+    part.obs = out.obs + t0 * out.obs_t_stride;
+    if (out.reward) part.reward = out.reward + t0 * B;
+    if (out.discount) part.discount = out.discount + t0 * B;
+    if (out.done) part.done = out.done + t0 * B;
+    uint32_t* trace = reinterpret_cast<uint32_t*>(out.trace);
+    uint64_t* keys = reinterpret_cast<uint64_t*>(out.trace + shape_offsets_bytes(s, B, n));
+    pp.trace = trace;
+    pp.keys = keys;
+    pp.plane = (int64_t)n * B;
+    // (windows are aligned in memory: the alignment of THIS chunk's first frame)
+    pp.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(part.obs) & (kSplitSpan - 1u));
+    const int32_t fresh = t0 == 0 ? reset_first : 0;
+#define CAMPX_SHAPE_UPDATE(KS)                                                                              \
+  hipLaunchKernelGGL(shape_update_split_kernel<KS>, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds, \
+                     stream, sp, pp, spec_dev, st, state_words, actions + t0 * B, part, trace, keys, B, n, fresh)
+    if (pp.n_trail == 0) CAMPX_SHAPE_UPDATE(0);
+    else if (pp.n_trail == 1) CAMPX_SHAPE_UPDATE(1);
+    else if (pp.n_trail == 2) CAMPX_SHAPE_UPDATE(2);
+    else CAMPX_SHAPE_UPDATE(-1);
+#undef CAMPX_SHAPE_UPDATE
+    const dim3 grid(grid_x, (unsigned)n);
 #define CAMPX_SHAPE_RENDER(NF, NS) \
-  hipLaunchKernelGGL((shape_render_split_kernel<NF, NS>), grid, dim3(kWave), render_lds, stream, pp, out.obs)
+  hipLaunchKernelGGL((shape_render_split_kernel<NF, NS>), grid, dim3(kWave), render_lds, stream, pp, part.obs)
 #define CAMPX_SHAPE_RENDER_NS(NF)                     \
   do {                                                \
     if (pp.n_trail == 0) CAMPX_SHAPE_RENDER(NF, 0);   \
     else if (pp.n_trail <= 2) CAMPX_SHAPE_RENDER(NF, 2); \
     else CAMPX_SHAPE_RENDER(NF, 8);                   \
   } while (0)
-  switch (pp.n_front) {
-    case 1: CAMPX_SHAPE_RENDER_NS(1); break;
-    case 2: CAMPX_SHAPE_RENDER_NS(2); break;
-    case 3: CAMPX_SHAPE_RENDER_NS(3); break;
-    case 4: CAMPX_SHAPE_RENDER_NS(4); break;
-    case 5: CAMPX_SHAPE_RENDER_NS(5); break;
-    case 6: CAMPX_SHAPE_RENDER_NS(6); break;
-    case 7: CAMPX_SHAPE_RENDER_NS(7); break;
-    default: CAMPX_SHAPE_RENDER_NS(8); break;
-  }
+    switch (pp.n_front) {
+      case 1: CAMPX_SHAPE_RENDER_NS(1); break;
+      case 2: CAMPX_SHAPE_RENDER_NS(2); break;
+      case 3: CAMPX_SHAPE_RENDER_NS(3); break;
+      case 4: CAMPX_SHAPE_RENDER_NS(4); break;
+      case 5: CAMPX_SHAPE_RENDER_NS(5); break;
+      case 6: CAMPX_SHAPE_RENDER_NS(6); break;
+      case 7: CAMPX_SHAPE_RENDER_NS(7); break;
+      default: CAMPX_SHAPE_RENDER_NS(8); break;
+    }
 #undef CAMPX_SHAPE_RENDER_NS
 #undef CAMPX_SHAPE_RENDER
+  }
   if (carried) {
     const int64_t n = B * H;
     hipLaunchKernelGGL(shape_backdrop_from_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,

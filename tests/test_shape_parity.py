@@ -166,6 +166,49 @@ def test_frame_major_is_the_path_a_full_rollout_takes():
       'shape_rollout_kernel' not in short, names
 
 
+_CHUNKED = r'''
+import sys
+sys.path.insert(0, %(repo)r); sys.path.insert(0, %(tests)r)
+import numpy as np, torch
+from campx_amd import gamespec
+from games_under_test import SHAPE_GAMES
+from oracle import cpu
+for name, batch in (('hello_world', 64), ('shape_zoo3', 1000), ('shape_zoo4', 64)):
+  game = SHAPE_GAMES[name](batch=batch, device='cuda')
+  game.its_showtime()
+  og = cpu.OracleGame.from_description(gamespec.describe(SHAPE_GAMES[name]()))
+  rng = np.random.RandomState(3)
+  for launch, T in enumerate([70, 33, 5]):
+    actions = rng.choice(5, size=(T, batch), p=[.24, .24, .24, .24, .04]).astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions))
+    assert out['trace'] is not None
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'reward', 'discount', 'done'):
+      if out[k] is not None:
+        a, b = out[k].cpu().numpy(), ref[k]
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b), (name, launch, k)
+print('ok')
+'''
+
+
+def test_long_launches_run_as_chunks_of_frames():
+  """A launch of more than CAMPX_SHAPE_CHUNK_KF thousand environment-frames (default 2 000) runs
+  as chunks - update pass and render alternating, positions / trail words / returns carried from
+  chunk to chunk - so that a chunk's offset trace and keyframes stay in the memory-side cache.
+  With the bound set to 1 000 environment-frames: 64 environments x 70 frames in chunks of 12, 1 000
+  environments in chunks of 4 (one key interval): against the oracle, byte for byte."""
+  import os
+  import subprocess
+  import sys
+  from conftest import REPO
+  env = dict(os.environ, CAMPX_SHAPE_CHUNK_KF='1')
+  out = subprocess.run([sys.executable, '-c', _CHUNKED % dict(repo=REPO, tests=os.path.join(REPO, 'tests'))],
+                       env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+  assert out.stdout.strip().endswith('ok')
+
+
 def test_frame_major_needs_whole_chunks_and_every_frame():
   from campx_amd import shapes
   game, _ = _game(5)                        # 5 x 3 276 bytes per frame: not whole 16-byte chunks

@@ -6,10 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import ProfilerActivity, profile
 from campx_amd.games import hello_world
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 
-for B in (4096, 32768):
-  for T in (4, 20, 100):
-    game, _, _, _ = hello_world.make_game(batch=B, device='cuda')
+for B in [int(x) for x in (sys.argv[1:] or ['4096', '32768'])]:
+  for T in [int(x) for x in os.environ.get('PROBE_T', '20 100').split()]:
+    if os.environ.get('PROBE_GAME'):
+      import shape_zoo
+      game = shape_zoo.library_builders()[os.environ['PROBE_GAME']](batch=B, device='cuda')
+      game.its_showtime()
+    else:
+      game, _, _, _ = hello_world.make_game(batch=B, device='cuda')
     game.fused.validate_actions = False
     acts = torch.randint(0, 4, (T, B), dtype=torch.int8, device='cuda')
     bufs = game.fused.rollout_buffers(T)
