@@ -930,13 +930,27 @@ static int64_t shape_offsets_bytes(const CampxShapeSpec& s, int64_t B, int32_t T
   return ((4ll + (shape_n_trail(s) + 1) / 2) * 4 * T * B + 7) & ~7ll;
 }
 
-// Scratch of the frame-major path (CampxOutputs.trace): the offset trace, then
+// Frames per chunk of a frame-major launch of T frames of B environments (launch_shape_split).
+static int32_t shape_chunk_frames(int64_t B, int32_t T) {
+  static const int64_t chunk_env_frames = [] {
+    const char* v = getenv("CAMPX_SHAPE_CHUNK_KF");
+    return (int64_t)(v && *v ? atoll(v) : 2000) * 1000;
+  }();
+  int64_t chunk = chunk_env_frames / B;
+  chunk = chunk / kShapeKey * kShapeKey;
+  chunk = chunk < kShapeKey ? kShapeKey : chunk;
+  return (int32_t)(chunk < T ? chunk : T);
+}
+
+// Scratch of the frame-major path (CampxOutputs.trace), sized for ONE chunk of frames (every
+// chunk of a launch reuses it): the offset trace, then
 // (8-byte aligned) the keyframes uint64 [ceil(T / key)][B][S][H], then the trail words at the
 // ends of the launch uint64 [B][S][H].
 int64_t shape_scratch_bytes(const CampxShapeSpec& s, int64_t B, int32_t T) {
   if (!shape_tables_ok(s) || B <= 0 || T <= 0) return 0;
-  const int64_t offsets = shape_offsets_bytes(s, B, T);
-  const int64_t keys = 8ll * ((T + kShapeKey - 1) / kShapeKey + 1) * B * shape_n_trail(s) * s.rows;
+  const int32_t Tc = shape_chunk_frames(B, T);
+  const int64_t offsets = shape_offsets_bytes(s, B, Tc);
+  const int64_t keys = 8ll * ((Tc + kShapeKey - 1) / kShapeKey + 1) * B * shape_n_trail(s) * s.rows;
   return offsets + keys;
 }
 
@@ -1002,9 +1016,10 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
   pp.max_pairs = shape_max_pairs(s);
   const size_t lds = (size_t)8 * pp.n_trail * H * kWave;
   const size_t render_lds = shape_render_lds(s);
-  // the trail words at the ends of the launch sit behind the keyframes of a whole-T launch
-  uint64_t* state_words = reinterpret_cast<uint64_t*>(out.trace + shape_offsets_bytes(s, B, T)) +
-                          (int64_t)((T + kShapeKey - 1) / kShapeKey) * B * pp.n_trail * H;
+  // the trail words at the ends of the launch (and of every chunk) sit behind a full chunk's keyframes
+  const int32_t chunk = shape_chunk_frames(B, T);
+  uint64_t* state_words = reinterpret_cast<uint64_t*>(out.trace + shape_offsets_bytes(s, B, chunk)) +
+                          (int64_t)((chunk + kShapeKey - 1) / kShapeKey) * B * pp.n_trail * H;
   const bool carried = pp.n_trail > 0 && backdrop_state != nullptr;
   if (carried && !reset_first) {
     const int64_t n = B * pp.n_trail * H;
@@ -1020,18 +1035,11 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
   // environment-frames (2 000; bench.py --game hello_world, of peak, whole / 700 / 1 000 / 1 400 /
   // 2 000 / 2 800: B = 32 768 0.70 / 0.77 / 0.79 / 0.76 / 0.81 / 0.80, B = 65 536 0.47 / 0.76 / 0.79 /
   // 0.83 / 0.83 / 0.83), a multiple of the key interval.
-  static const int64_t chunk_env_frames = [] {
-    const char* v = getenv("CAMPX_SHAPE_CHUNK_KF");
-    return (int64_t)(v && *v ? atoll(v) : 2000) * 1000;
-  }();
-  int64_t chunk = chunk_env_frames / B;
-  chunk = chunk / kShapeKey * kShapeKey;
-  chunk = chunk < kShapeKey ? kShapeKey : chunk;
   const uint64_t reach = (uint64_t)pp.slab_bytes + ((pp.shift_base | pp.shift_slab) ? kSplitSpan - 1u : 0u);
   const uint64_t block_span = (uint64_t)kSplitSpan * kSplitWaves;
   const unsigned grid_x = (unsigned)((((reach + block_span - 1) / block_span) + 7u) & ~(uint64_t)7);
   for (int64_t t0 = 0; t0 < T; t0 += chunk) {
-    const int32_t n = (int32_t)(T - t0 < chunk ? T - t0 : chunk);
+    const int32_t n = (int32_t)(T - t0 < chunk ? T - t0 : (int64_t)chunk);
     CampxOutputs part = out;
     part.obs = out.obs + t0 * out.obs_t_stride;
     if (out.reward) part.reward = out.reward + t0 * B;

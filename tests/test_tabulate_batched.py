@@ -15,6 +15,7 @@ generic tier.
 """
 
 import os
+import random
 import subprocess
 import sys
 import time
@@ -127,6 +128,90 @@ def test_python_level_reads_need_every_lane_to_agree():
   assert torch.equal(lanes.plain(torch.roll(x, 1, 1)), torch.roll(lanes.plain(x), 1, 2))
   assert torch.equal(lanes.plain(x.sum(dim=0)), lanes.plain(x).sum(dim=1))
   assert torch.equal(lanes.plain(x.t()), lanes.plain(x).transpose(1, 2))
+
+
+# ------------------------------------------------ Lanes against single tensors, random programs
+
+def rand_leaf(rng, n):
+  kind = rng.choice(['u8', 'u8', 'f32', 'i64', 'bool', 'scalar0d_i64', 'scalar0d_f32', 'pyint', 'pyfloat', 'plain_u8', 'plain_f32'])
+  g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+  if kind == 'u8': return [(torch.rand(4, 5, generator=g) < 0.4).to(torch.uint8) for _ in range(n)], True
+  if kind == 'f32': return [torch.randint(-3, 4, (4, 5), generator=g).float() * 0.25 for _ in range(n)], True
+  if kind == 'i64': return [torch.randint(-3, 4, (4, 5), generator=g) for _ in range(n)], True
+  if kind == 'bool': return [torch.rand(4, 5, generator=g) < 0.5 for _ in range(n)], True
+  if kind == 'scalar0d_i64': return [torch.randint(0, 3, (), generator=g) for _ in range(n)], True
+  if kind == 'scalar0d_f32': return [torch.randint(0, 3, (), generator=g).float() * 0.5 for _ in range(n)], True
+  if kind == 'pyint': v = rng.randrange(-2, 3); return [v] * n, False
+  if kind == 'pyfloat': v = rng.choice([-0.25, 0.5, 1.0, 2.0]); return [v] * n, False
+  if kind == 'plain_u8': t = (torch.rand(4, 5, generator=g) < 0.4).to(torch.uint8); return [t] * n, False
+  t = torch.randint(-2, 3, (4, 5), generator=g).float(); return [t] * n, False
+
+BIN = [lambda a, b: a + b, lambda a, b: a - b, lambda a, b: a * b, lambda a, b: a >= b, lambda a, b: a <= b,
+       lambda a, b: a == b, lambda a, b: 1 - a if not isinstance(a, (int, float)) else b, lambda a, b: b - a]
+UN = [lambda a: a.sum(), lambda a: a.float(), lambda a: a.byte(), lambda a: a.long(),
+      lambda a: torch.cat([a[:, 1:], a[:, :1]], dim=1) if a.dim() == 2 else a,
+      lambda a: torch.cat([a[-1:], a[:-1]], dim=0) if a.dim() == 2 else a,
+      lambda a: a[1:3, 2] if a.dim() == 2 else a, lambda a: a[0] if a.dim() >= 1 else a,
+      lambda a: (a * 2).sum() if a.dtype != torch.bool else a.sum()]
+
+def _run_program(seed, n=3):
+  rng = random.Random(seed)
+  vals = []     # list of (per-lane list, is_lanes)
+  for _ in range(3): vals.append(rand_leaf(rng, n))
+  prog = []
+  for step in range(6):
+    if rng.random() < 0.6:
+      i, j = rng.randrange(len(vals)), rng.randrange(len(vals)); op = rng.randrange(len(BIN)); prog.append(('b', op, i, j))
+    else:
+      i = rng.randrange(len(vals)); op = rng.randrange(len(UN)); prog.append(('u', op, i))
+    vals.append(None)
+  def execute(leaves):
+    env = list(leaves)
+    for ins in prog:
+      if ins[0] == 'b':
+        a, b = env[ins[2]], env[ins[3]]
+        env.append(BIN[ins[1]](a, b))
+      else:
+        a = env[ins[2]]
+        if isinstance(a, (int, float)): env.append(a); continue
+        env.append(UN[ins[1]](a))
+    return env[3:]
+  leaves = vals[:3]
+  try:
+    singles = [execute([lv[0][k] for lv in leaves]) for k in range(n)]
+  except Exception as e:
+    return 'skip'
+  batched_leaves = [lanes.wrap(torch.stack(list(lv[0]))) if lv[1] else lv[0][0] for lv in leaves]
+  try:
+    batched = execute(batched_leaves)
+  except lanes.CannotBatch as e:
+    return 'cannot:' + str(e)[:60]
+  for step, out in enumerate(batched):
+    for k in range(n):
+      want = singles[k][step]
+      if isinstance(out, lanes.Lanes):
+        got = lanes.plain(out)[k]
+      else:
+        got = out
+      if isinstance(want, (int, float)):
+        if got != want: return 'MISMATCH py step %d' % step
+        continue
+      if not torch.is_tensor(got): return 'MISMATCH type step %d: %r vs %r' % (step, type(got), type(want))
+      if got.dtype != want.dtype or tuple(got.shape) != tuple(want.shape) or not torch.equal(got, want):
+        return 'MISMATCH seed %d step %d prog %r: got %s %s want %s %s' % (seed, step, prog[step], got.dtype, tuple(got.shape), want.dtype, tuple(want.shape))
+  return 'ok'
+
+
+
+def test_random_programs_of_the_supported_operations_match_lane_by_lane():
+  """Six-instruction programs drawn from the operations arithmetic-only game classes use (+ - *,
+  comparisons, `1 - x`, cat-shifts, slices, sum, dtype conversions) over uint8 / float32 / int64 /
+  bool boards, 0-d tensors, Python numbers and tensors every lane shares: values, dtypes and
+  shapes of EVERY intermediate equal what the same program gives on each lane's tensors alone."""
+  outcomes = [_run_program(seed) for seed in range(400)]
+  bad = [o for o in outcomes if o.startswith('MISMATCH')]
+  assert not bad, bad[:3]
+  assert sum(o == 'ok' for o in outcomes) > 200
 
 
 # ------------------------------------------------------------------------- the two walkers
