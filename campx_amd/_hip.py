@@ -182,7 +182,7 @@ def _load_ops():
 
 
 ops = _load_ops()
-OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'shape_rollout', 'wide_rollout',
+OP_NAMES = ('reset', 'step', 'rollout', 'update', 'render', 'rollout_pipelined', 'shape_rollout', 'wide_rollout',
             'onehot_to_ids', 'check_actions')
 
 

@@ -39,7 +39,10 @@
 #include <hip/hip_runtime.h>
 #include <torch/library.h>
 
+#include <map>
+#include <mutex>
 #include <optional>
+#include <unordered_map>
 #include <vector>
 
 #include "campx_hip.h"
@@ -342,6 +345,101 @@ void render(const Tensor& spec_host, const Tensor& spec_dev, const Tensor& trace
                                (int32_t)T,
                                c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()),
            "campx_render_launch");
+}
+
+// A rollout over TWO streams (fused.py rollout(pipelined=True), in C++ since round 5): the update
+// pass on a HIGH-priority side stream, the render on the caller's stream behind it - so that the
+// update pass of the NEXT call runs under this call's render.  What makes it pay is the host: as
+// two op dispatches and five stream / event calls from Python it cost 36-46 us per call, more
+// than a middle-sized rollout takes (sokoban B = 16 384: 62 us in order); here it is one dispatch.
+// The side stream and the events live in this binding layer, per device (the C library below it
+// holds no state); `resync`: work has been issued on the caller's stream since the last
+// pipelined call that the update pass must come after (state set up by other calls).
+struct PipeStreams {
+  hipStream_t side = nullptr;
+  hipEvent_t updated = nullptr, synced = nullptr;
+  std::unordered_map<const void*, hipEvent_t> readers;   // trace buffer -> its last render
+};
+
+void hip_ok(hipError_t e, const char* what) {
+  TORCH_CHECK(e == hipSuccess, "campx: ", what, " failed: ", hipGetErrorString(e));
+}
+
+PipeStreams& pipe_streams(int device) {
+  static std::mutex lock;
+  static std::map<int, PipeStreams> all;
+  std::lock_guard<std::mutex> hold(lock);
+  PipeStreams& p = all[device];
+  if (!p.side) {
+    int least = 0, greatest = 0;
+    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    hip_ok(hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    hip_ok(hipEventCreateWithFlags(&p.updated, hipEventDisableTiming), "hipEventCreateWithFlags");
+    hip_ok(hipEventCreateWithFlags(&p.synced, hipEventDisableTiming), "hipEventCreateWithFlags");
+  }
+  return p;
+}
+
+void rollout_pipelined(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tensor& done,
+                       const OptTensor& ret, const OptTensor& pair_table, const Tensor& actions,
+                       Tensor& obs, const OptTensor& board, const OptTensor& reward,
+                       const OptTensor& discount, const OptTensor& step_done, const OptTensor& perf,
+                       Tensor& trace, const OptTensor& bad_count, const OptTensor& bad_flag,
+                       bool reset_first, bool resync) {
+  const Game g = unpack_game(spec_host, spec_dev, pos, done, ret, pair_table);
+  TORCH_CHECK(actions.dim() == 2, "campx::rollout_pipelined: actions must be int8 [T, B]");
+  const int64_t T = actions.size(0);
+  TORCH_CHECK(T >= 1 && T <= 65535, "campx::rollout_pipelined: 1 to 65535 frames");
+  want(actions, "actions", at::kChar, g.dev, {T, g.B});
+  int64_t pitch = 0;
+  want_trace(trace, g.dev, g.K, T, g.B, pitch);
+  if (reward.has_value()) want_rows(*reward, "reward", at::kFloat, g.dev, T, g.B, pitch);
+  if (discount.has_value()) want_rows(*discount, "discount", at::kFloat, g.dev, T, g.B, pitch);
+  if (step_done.has_value()) want_rows(*step_done, "step_done", at::kByte, g.dev, T, g.B, pitch);
+  if (perf.has_value()) want_rows(*perf, "perf", at::kChar, g.dev, T, g.B, pitch);
+  if (bad_count.has_value()) want(*bad_count, "bad_count", at::kInt, g.dev, {1});
+  CampxOutputs upd{};
+  upd.scalar_pitch = pitch;
+  upd.reward = opt_ptr<float>(reward);
+  upd.discount = opt_ptr<float>(discount);
+  upd.done = opt_ptr<uint8_t>(step_done);
+  upd.perf = opt_ptr<int8_t>(perf);
+  upd.trace = reinterpret_cast<uint8_t*>(trace.data_ptr());
+  upd.bad_count = opt_ptr<int32_t>(bad_count);
+  upd.bad_flag = flag_ptr(bad_flag, g.dev);
+  CampxOutputs ren{};
+  ren.scalar_pitch = pitch;
+  ren.obs_format = obs_format_of(obs);
+  want(obs, "obs", obs.scalar_type(), g.dev, {T, g.B, g.L, g.H, g.W});
+  ren.obs = reinterpret_cast<int8_t*>(obs.data_ptr());
+  ren.obs_t_stride = g.B * g.L * g.H * g.W;
+  if (board.has_value()) {
+    want(*board, "board", at::kChar, g.dev, {T, g.B, g.H, g.W});
+    ren.board = opt_ptr<int8_t>(board);
+    ren.board_t_stride = g.B * g.H * g.W;
+  }
+  ren.trace = upd.trace;
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
+  hipStream_t main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+  PipeStreams& p = pipe_streams(g.dev.index());
+  if (resync) {       // everything issued on the caller's stream so far, renders included
+    hip_ok(hipEventRecord(p.synced, main), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(p.side, p.synced, 0), "hipStreamWaitEvent");
+    // (events of trace buffers last rendered before this point are covered by it)
+  }
+  // the side stream runs ahead of the caller's without bound; what it may not do is overwrite a
+  // trace buffer whose last render is still running
+  hipEvent_t& reader = p.readers[upd.trace];
+  if (reader && !resync) hip_ok(hipStreamWaitEvent(p.side, reader, 0), "hipStreamWaitEvent");
+  check_ok(campx_update_launch(g.spec_host, g.spec_dev, g.state,
+                               reinterpret_cast<const int8_t*>(actions.data_ptr()), upd, g.B, (int32_t)T,
+                               reset_first ? 1 : 0, p.side),
+           "campx_update_launch");
+  hip_ok(hipEventRecord(p.updated, p.side), "hipEventRecord");
+  hip_ok(hipStreamWaitEvent(main, p.updated, 0), "hipStreamWaitEvent");
+  check_ok(campx_render_launch(g.spec_host, g.spec_dev, ren, g.B, (int32_t)T, main), "campx_render_launch");
+  if (!reader) hip_ok(hipEventCreateWithFlags(&reader, hipEventDisableTiming), "hipEventCreateWithFlags");
+  hip_ok(hipEventRecord(reader, main), "hipEventRecord");
 }
 
 // The update pass of one rollout and the render pass of the one before it as ONE call
@@ -650,6 +748,10 @@ void rollout_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTenso
                   const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                   const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                   const OptTensor&, bool, const OptTensor&, const OptTensor&, const OptTensor&) {}
+void rollout_pipelined_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
+                            const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
+                            const OptTensor&, const OptTensor&, Tensor&, const OptTensor&, const OptTensor&,
+                            bool, bool) {}
 void step_meta(const Tensor&, const Tensor&, Tensor&, Tensor&, const OptTensor&, const OptTensor&,
                const Tensor&, Tensor&, const OptTensor&, const OptTensor&, const OptTensor&,
                const OptTensor&, const OptTensor&, const OptTensor&, const OptTensor&) {}
@@ -720,6 +822,11 @@ TORCH_LIBRARY(campx, m) {
       "render(Tensor spec_host, Tensor spec_dev, Tensor trace, Tensor(a!) obs, Tensor(b!)? board) "
       "-> ()");
   m.def(
+      "rollout_pipelined(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, "
+      "Tensor(c!)? ret, Tensor? pair_table, Tensor actions, Tensor(d!) obs, Tensor(e!)? board, "
+      "Tensor(f!)? reward, Tensor(g!)? discount, Tensor(h!)? step_done, Tensor(i!)? perf, "
+      "Tensor(j!) trace, Tensor(k!)? bad_count, Tensor(l!)? bad_flag, bool reset_first, bool resync) -> ()");
+  m.def(
       "update_render(Tensor spec_host, Tensor spec_dev, Tensor(a!) pos, Tensor(b!) done, "
       "Tensor(c!)? ret, Tensor? pair_table, Tensor actions, Tensor(d!)? reward, Tensor(e!)? discount, "
       "Tensor(f!)? step_done, Tensor(g!)? perf, Tensor(h!) trace, Tensor(i!)? bad_count, "
@@ -745,6 +852,7 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
   m.impl("rollout", &rollout);
   m.impl("update", &update);
   m.impl("render", &render);
+  m.impl("rollout_pipelined", &rollout_pipelined);
   m.impl("update_render", &update_render);
   m.impl("shape_rollout", &shape_rollout);
   m.impl("wide_rollout", &wide_rollout);
@@ -753,7 +861,7 @@ TORCH_LIBRARY_IMPL(campx, CUDA, m) {
 }
 
 TORCH_LIBRARY_IMPL(campx, ADInplaceOrView, m) {
-  for (const char* name : {"reset", "step", "rollout", "update", "render", "update_render", "shape_rollout",
+  for (const char* name : {"reset", "step", "rollout", "update", "render", "rollout_pipelined", "update_render", "shape_rollout",
                            "wide_rollout", "onehot_to_ids", "check_actions"})
     m.impl(name, torch::CppFunction::makeFromBoxedFunction<&run_then_bump_versions>());
 }
@@ -764,6 +872,7 @@ TORCH_LIBRARY_IMPL(campx, Meta, m) {
   m.impl("rollout", &rollout_meta);
   m.impl("update", &update_meta);
   m.impl("render", &render_meta);
+  m.impl("rollout_pipelined", &rollout_pipelined_meta);
   m.impl("update_render", &update_render_meta);
   m.impl("shape_rollout", &shape_rollout_meta);
   m.impl("wide_rollout", &wide_rollout_meta);

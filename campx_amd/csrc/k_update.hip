@@ -1577,16 +1577,19 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
   if (B > max_b || B * R * T > max_bytes) return false;
   if (s.n_dyn >= 2) {
     // Two to four movers (pipe_multi_kernel; sokoban levels 0 / 1 / 2, T = 100, of HBM peak, two
-    // launches -> one, profiles/r05_multimover_deferred_ab.txt): B = 4 096 0.21 -> 0.27 / 0.25 ->
-    // 0.37 / 0.29 -> 0.39, 8 192 0.41 -> 0.49 / 0.41 -> 0.58 / 0.43 -> 0.56, 16 384 0.61 -> 0.67 /
-    // 0.58 -> 0.61 / 0.61 -> 0.55, 32 768 0.73 -> 0.67 / 0.72 -> 0.64 / 0.74 -> 0.60: the update
-    // role's registers (99 / 122 / 128 VGPRs) leave the render role 16 waves per CU, which hiding
-    // the update pass repays only while that pass is a large part of the rollout.
+    // launches in order -> the shared launch, profiles/r05_multimover_deferred_ab.txt): B = 4 096
+    // 0.30 -> 0.49 / 0.25 -> 0.42 / 0.29 -> 0.40, 8 192 0.45 -> 0.60 / 0.41 -> 0.56 / 0.43 -> 0.57,
+    // 16 384 0.60 -> 0.67 / 0.58 -> 0.61 / 0.60 -> 0.61, 32 768 0.73 -> 0.73 / 0.72 -> 0.65 / 0.72 ->
+    // 0.63: the update role's registers (99 / 122 / 128 VGPRs) leave the render role 16 waves per
+    // CU, which hiding the update pass repays only while that pass is a large part of the rollout.
+    // From 16 384 environments up the update pass of three- / four-mover games on a high-priority
+    // side stream (campx::rollout_pipelined, one op) does better - 0.70 / 0.75, 32 768: 0.85 / 0.84 -
+    // so they take the shared launch up to 8 192, the two-mover game up to 16 384.
     static const int64_t forced = [] {
       const char* v = getenv("CAMPX_PIPE_MULTI_MAX_B");
       return (int64_t)(v && *v ? atoll(v) : -1);
     }();
-    const int64_t multi_max = forced >= 0 ? forced : (s.n_dyn == 4 ? 8192 : 16384);
+    const int64_t multi_max = forced >= 0 ? forced : (s.n_dyn == 2 ? 16384 : 8192);
     if (B > multi_max) return false;
   }
   (void)out;

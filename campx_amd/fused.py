@@ -69,6 +69,8 @@ def _ptr(t):
 
 # (A/B knob: deferred rollouts of multi-mover games past the shared launch run in order)
 _PIPELINE_DEFERRED = os.environ.get('CAMPX_NO_PIPELINE_DEFERRED', '0') != '1'
+# (A/B knob: the two-stream choreography of pipelined rollouts from Python instead of the C++ op)
+_PIPELINE_IN_CPP = os.environ.get('CAMPX_PIPELINE_PY', '0') != '1'
 
 
 class FusedGame(object):
@@ -181,6 +183,7 @@ class FusedGame(object):
     self._update = _hip.ops.update.default
     self._render = _hip.ops.render.default
     self._update_render = _hip.ops.update_render.default
+    self._rollout_pipelined = _hip.ops.rollout_pipelined.default
     self._flow_scratch = None
     self._flow_state = None    # the scratch block's CampxFlowState: host memory, ours (int64[4])
     self._flow_shared = {}     # (T, pitch) -> whether the library runs such a rollout as one launch
@@ -505,6 +508,22 @@ class FusedGame(object):
       if out['trace'] is None:
         raise ValueError('pipelined rollouts need the two-kernel path (a trace buffer: '
                          'keep_obs=True on a game whose update pass is tabulated)')
+      if not self.aux_cus and _PIPELINE_IN_CPP:
+        # one op does the two-stream choreography (csrc/campx_torch.cpp rollout_pipelined: the
+        # update pass on a high-priority side stream, the render on this stream behind it; from
+        # Python - below, kept for the CU-subset A/B - the same calls cost the host 36-46 us)
+        self._rollout_pipelined(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                                self._pair_table, ids, out['obs'], out['board'], out['reward'],
+                                out['discount'], out['done'], out['perf'], out['trace'],
+                                self._bad if validate else None,
+                                self._bad_flag if validate else None, bool(reset_first),
+                                not self._aux_in_sync)
+        self._aux_in_sync = True
+        self.frame = T if reset_first else self.frame + T
+        self.check_ok()
+        if validate:
+          self._after_launch()
+        return out
       main = torch.cuda.current_stream(self.device)
       if self._aux is None:
         self._aux = self._side_stream()
@@ -604,13 +623,14 @@ class FusedGame(object):
                          'one would overwrite at once: flush() and read them first')
       self.flush()
       if (out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
-          self.n_dyn >= 3 and self.batch >= 8192):
-        # Games of two to four movers past the shared launch's bounds: the update pass on the
-        # (high-priority) side stream, under the render of the rollout before it - two kernels
-        # on two streams instead of two roles of one launch (sokoban with two / three boxes,
-        # B = 16 384: 0.61 / 0.70 of peak against 0.56 / 0.60 in order, 32 768: 0.74 / 0.78 against
-        # 0.69 / 0.72, 65 536: 0.86 / 0.86 against 0.81 / 0.81; the two-mover game gains nothing:
-        # 0.73 / 0.78 against 0.73 / 0.83, and stays in order; profiles/r05_multimover_deferred_ab.txt).
+          self.batch > 8192 and (self.n_dyn >= 3 or self.batch < 32768)):
+        # Games of two to four movers past the shared launch's bounds (16 384 environments with
+        # two movers, 8 192 with more): the update pass on the (high-priority) side stream, under
+        # the render of the rollout before it - two kernels on two streams instead of two roles of
+        # one launch, one op (campx::rollout_pipelined).  Sokoban with two / three boxes, of peak,
+        # in order -> two streams: B = 16 384 0.58 -> 0.70 / 0.60 -> 0.75, 32 768 0.72 -> 0.85 / 0.72 ->
+        # 0.84, 65 536 0.81 -> 0.77-0.85 / 0.81 -> 0.86; the two-mover game gains nothing from 32 768
+        # up (0.73 -> 0.74, 0.83 -> 0.81) and stays in order (profiles/r05_multimover_deferred_ab.txt).
         # Complete a call early, like the rollout below.
         self.rollout(ids, out=out, reset_first=reset_first, pipelined=True)
         self._deferred, self._deferred_rendered = out, True

@@ -108,11 +108,13 @@ def test_games_of_two_to_four_movers_share_the_launch(level, B, Ts):
 
 
 def test_multi_mover_games_past_the_shared_launch_pipeline_over_two_streams():
-  # 33 024 environments of the two-mover game: past what the shared launch takes, each rollout
-  # whole, in order.  16 384 of the four-mover one, 20 000 of the three-mover one:
-  # rollout_deferred() runs the update pass on the high-priority side stream under the previous
-  # rollout's render (two kernels, two streams), complete a call early
+  # 33 024 environments of the two-mover game: each rollout whole, in order.  20 000 of the two-
+  # and of the three-mover one, 16 384 of the four-mover one: past what the shared launch takes
+  # (16 384 / 8 192), rollout_deferred() runs the update pass on the high-priority side stream under the
+  # previous rollout's render (campx::rollout_pipelined: two kernels, two streams, one op),
+  # complete a call early
   _check(sokoban.build, 33024, [10, 10, 10], seed=6)
+  _check(sokoban.build, 20000, [30, 30, 30], seed=9)
   _check(sokoban.build, 16384, [20, 20, 7, 20], seed=7, build_kwargs=dict(level=2))
   _check(sokoban.build, 20000, [16, 16, 16], seed=8, build_kwargs=dict(level=1))
 

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_shape_parity.py -m gpu -x -q 2>&1 | tail -3
-PROBE_T="100 200" python tools/shape_update_probe.py 32768 65536 2>&1 | grep "signed char"
-bash tools/gpu_sweep.sh hello_world "4096 16384 32768 65536" "100"
-for kf in 700 1000 2000 2800; do echo "== chunk bound $kf k env-frames"; CAMPX_SHAPE_CHUNK_KF=$kf bash tools/gpu_sweep.sh hello_world "32768 65536" "100"; done
+timeout 900 python -m pytest tests/test_torch_ops.py tests/test_deferred.py -m gpu -x -q 2>&1 | tail -3
+for g in sokoban sokoban_l1 sokoban_l2; do for b in 4096 8192 16384 32768; do
+  echo "== $g B=$b deferred (as shipped)"; BENCH_FLAGS=--deferred tools/gpu_sweep.sh $g $b 100
+done; done
