@@ -260,7 +260,8 @@ def kernel_names(fused, split, B=None, T=None):
     # library itself, campx_flow_shared: its bounds and knobs, not a copy of them)
     one = getattr(fused, '_one_launch', None)
     if one is not None and B is not None and one(T, (B + 15) // 16 * 16):
-      return 'pipe_table_kernel<true> (update pass + render in one launch)'
+      return ('pipe_table_kernel<true>' if fused.n_dyn == 1 else 'pipe_multi_kernel<K, ., true>') + \
+          ' (update pass + render in one launch)'
     first = ('update_table_kernel' if fused.n_dyn == 1 else
              'update_pair_kernel' if fused.n_dyn == 2 and fused.uses_table else
              'update_tuple_kernel' if fused.uses_table else 'rollout_kernel<trace>')

@@ -166,9 +166,11 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
   chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
   const bool whole = (per_frame * T <= knob_trace_whole_bytes() && T <= 65535) || T <= chunk;
-  if (whole && !last_frame_only(out) && flow_ok(s, out, B, T, use_table, stream)) {
-    // one-mover table games up to 65 536 environments: one launch, the render role following
-    // the update role group by group (k_update.hip flow_table launch)
+  // (two to four movers: their pair / tuple table is the caller's, CampxState.pair_table)
+  const bool multi_table = s.n_dyn >= 2 && st.pair_table && (!knob_no_table() || s.table_only);
+  if (whole && !last_frame_only(out) && flow_ok(s, out, B, T, use_table || multi_table, stream)) {
+    // table games of small batches: one launch, the render role following the update role as
+    // its entries arrive (k_update.hip, launch_flow)
     int32_t rc = launch_flow(s, spec_dev, st, actions, out, B, T, reset_first, stream);
     if (rc != CAMPX_OK || !out.board) return rc;
     return launch_render(s, spec_dev, out.trace, out.board, B, T, plane, pitch, true, 0, stream);
@@ -712,7 +714,10 @@ int32_t campx_flow_shared(const CampxSpec* spec_host, int64_t B, int32_t T, int6
   out.overlap_ctl_bytes = flow_scratch_bytes(B, T);
   out.flow_state = &some_state;
   out.error_flag = &some_flag;
-  return flow_ok(*spec_host, out, B, T, use_table, nullptr, /*ask_stream=*/false) ? 1 : 0;
+  // (two to four movers: with their pair / tuple table in CampxState.pair_table, which this query
+  // cannot see - a caller without one gets two launches whatever this says)
+  const bool multi_table = spec_host->n_dyn >= 2 && (!knob_no_table() || spec_host->table_only);
+  return flow_ok(*spec_host, out, B, T, use_table || multi_table, nullptr, /*ask_stream=*/false) ? 1 : 0;
 }
 
 int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out) {

@@ -68,6 +68,21 @@ __device__ __forceinline__ void store16_update(void* p, u32x4 v) {
 __device__ __forceinline__ void store16_tagged(void* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// Sixteen trace bytes (four packed dwords) as sixteen entries byte | tag << 8: two such stores.
+__device__ __forceinline__ void store_tagged_row(uint16_t* at, const uint32_t (&tr)[4], uint32_t tag) {
+  const uint32_t tt = (tag << 8) | (tag << 24);
+  uint32_t e[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e[2 * k] = (tr[k] & 0xffu) | ((tr[k] & 0xff00u) << 8) | tt;
+    e[2 * k + 1] = ((tr[k] >> 16) & 0xffu) | ((tr[k] >> 8) & 0xff0000u) | tt;
+  }
+  store16_tagged(at, u32x4{e[0], e[1], e[2], e[3]});
+  store16_tagged(at + 8, u32x4{e[4], e[5], e[6], e[7]});
+}
+__device__ __forceinline__ void store_tagged_one(uint16_t* at, uint32_t byte, uint32_t tag) {
+  __hip_atomic_store(at, (uint16_t)((byte & 0xffu) | (tag << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Number of bytes >= 5 (as unsigned) among the 16 of v: the action ids outside 0..4.
 __device__ __forceinline__ int count_bad16(u32x4 v) {
@@ -486,17 +501,7 @@ __device__ __forceinline__ void update_table_body(
               if (e0 + 16 <= Bv) {  // (aligned when the row pitch is a multiple of 16; else legal, slower)
                 const u32x4 t4 = {tr[0], tr[1], tr[2], tr[3]};
                 store16_update(out.trace + at, t4);
-                if (kTagged) {
-                  const uint32_t tt = (tag << 8) | (tag << 24);
-                  uint32_t e[8];
-#pragma unroll
-                  for (int k = 0; k < 4; ++k) {
-                    e[2 * k] = (tr[k] & 0xffu) | ((tr[k] & 0xff00u) << 8) | tt;
-                    e[2 * k + 1] = ((tr[k] >> 16) & 0xffu) | ((tr[k] >> 8) & 0xff0000u) | tt;
-                  }
-                  store16_tagged(tagged + at, u32x4{e[0], e[1], e[2], e[3]});
-                  store16_tagged(tagged + at + 8, u32x4{e[4], e[5], e[6], e[7]});
-                }
+                if (kTagged) store_tagged_row(tagged + at, tr, tag);
                 if (out.done) {
                   const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
                   store16_update(out.done + at, d4);
@@ -509,9 +514,7 @@ __device__ __forceinline__ void update_table_body(
                 for (int i = 0; i < 16 && e0 + i < B; ++i) {
                   const int sh = (i & 3) * 8;
                   out.trace[at + i] = (uint8_t)(tr[i >> 2] >> sh);
-                  if (kTagged)
-                    __hip_atomic_store(tagged + at + i, (uint16_t)(((tr[i >> 2] >> sh) & 0xffu) | (tag << 8)),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (kTagged) store_tagged_one(tagged + at + i, tr[i >> 2] >> sh, tag);
                   if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
                   if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
                 }
@@ -594,11 +597,14 @@ struct UpdatePairLds {
 };
 
 // The body of update_pair_kernel.  `wg`: which kProd * 64 environments this workgroup owns.
-template <bool kLdsEntries, int kProd, int kCons>
+// kTagged (one-launch rollouts): a tagged copy of each mover's plane of the trace beside it, planes
+// `trace_plane` entries apart like the trace's own (update_table_body's `tagged`, `tag`).
+template <bool kLdsEntries, int kProd, int kCons, bool kTagged = false>
 __device__ __forceinline__ void update_pair_body(
     UpdatePairLds<kProd, CAMPX_PAIR_GROUP>& L, uint32_t* lds_entries, uint32_t wg, const PairParams& pp,
     const CampxState& st, const int8_t* __restrict__ actions, const CampxOutputs& out, int64_t B, int32_t T,
-    int32_t reset_first, int64_t trace_plane, const FrameCodec& fc) {
+    int32_t reset_first, int64_t trace_plane, const FrameCodec& fc, uint16_t* tagged = nullptr,
+    uint32_t tag = 0) {
   constexpr int kLoad = update_loaders(kProd), kG = CAMPX_PAIR_GROUP;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -753,6 +759,10 @@ __device__ __forceinline__ void update_pair_body(
                 const u32x4 a4 = {ta[0], ta[1], ta[2], ta[3]}, b4 = {tb[0], tb[1], tb[2], tb[3]};
                 store16_update(out.trace + at, a4);
                 store16_update(out.trace + plane + at, b4);
+                if (kTagged) {
+                  store_tagged_row(tagged + at, ta, tag);
+                  store_tagged_row(tagged + plane + at, tb, tag);
+                }
                 if (out.done) {
                   const u32x4 d4 = {dn[0], dn[1], dn[2], dn[3]};
                   store16_update(out.done + at, d4);
@@ -766,6 +776,10 @@ __device__ __forceinline__ void update_pair_body(
                   const int sh = (i & 3) * 8;
                   out.trace[at + i] = (uint8_t)(ta[i >> 2] >> sh);
                   out.trace[plane + at + i] = (uint8_t)(tb[i >> 2] >> sh);
+                  if (kTagged) {
+                    store_tagged_one(tagged + at + i, ta[i >> 2] >> sh, tag);
+                    store_tagged_one(tagged + plane + at + i, tb[i >> 2] >> sh, tag);
+                  }
                   if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
                   if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
                 }
@@ -837,11 +851,12 @@ struct UpdateTupleLds {
 };
 
 // The body of update_tuple_kernel.  `wg`: which kProd * 64 environments this workgroup owns.
-template <int K, int kProd, int kCons>
+template <int K, int kProd, int kCons, bool kTagged = false>
 __device__ __forceinline__ void update_tuple_body(
     UpdateTupleLds<kProd>& L, const uint32_t wg, const TupleParams tp, const CampxState st,
     const int8_t* __restrict__ actions, const CampxOutputs out, const int64_t B, const int32_t T,
-    const int32_t reset_first, const int64_t trace_plane, const FrameCodec fc) {
+    const int32_t reset_first, const int64_t trace_plane, const FrameCodec fc, uint16_t* const tagged = nullptr,
+    const uint32_t tag = 0) {
   constexpr int kLoad = update_loaders(kProd), kG = kTupleGroup;
   constexpr int E = kProd * kWave, CL = kCons * kWave, kThreads = (kProd + kCons + kLoad) * kWave;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -1001,11 +1016,35 @@ __device__ __forceinline__ void update_tuple_body(
                 const u32x4 p4 = {pf[0], pf[1], pf[2], pf[3]};
                 store16_update(out.perf + at, p4);
               }
+              if (kTagged) {
+                // the tagged copy in a pass of its own, one mover at a time from the ring again (rolled:
+                // beside the K planes above, the entries' registers spilled - 11 / 28 VGPRs for three /
+                // four movers under the 128 of two workgroups per CU)
+#pragma unroll 1
+                for (int k = 0; k < K; ++k) {
+                  uint32_t tk[4];
+#pragma unroll
+                  for (int w = 0; w < 4; ++w) {
+                    uint32_t b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      const uint32_t lo = (uint32_t)L.ring[rb][j][16 * q + 4 * w + i];
+                      b[i] = ((lo >> (7 * k)) & 0x7fu) | (((lo >> (28 + k)) & 1u) << 7);
+                    }
+                    tk[w] = pack4(b[0], b[1], b[2], b[3]);
+                  }
+                  store_tagged_row(tagged + k * plane + at, tk, tag);
+                }
+              }
             } else {
               for (int i = 0; i < 16 && e0 + i < B; ++i) {
                 const int sh = (i & 3) * 8;
 #pragma unroll
                 for (int k = 0; k < K; ++k) out.trace[k * plane + at + i] = (uint8_t)(tr[k][i >> 2] >> sh);
+                if (kTagged) {
+#pragma unroll
+                  for (int k = 0; k < K; ++k) store_tagged_one(tagged + k * plane + at + i, tr[k][i >> 2] >> sh, tag);
+                }
                 if (out.done) out.done[at + i] = (uint8_t)(dn[i >> 2] >> sh);
                 if (out.perf) out.perf[at + i] = (int8_t)(pf[i >> 2] >> sh);
               }
@@ -1445,7 +1484,9 @@ using PipeMultiLds = std::conditional_t<K == 2, UpdatePairLds<kPipeProd, CAMPX_P
 #ifndef CAMPX_PIPE_MULTI_MINWAVES
 #define CAMPX_PIPE_MULTI_MINWAVES 4     // (128 VGPRs: the four-mover update role would take 138 and a wave per SIMD)
 #endif
-template <int K, bool kLdsEntries>
+// kFlow: the render role is THIS rollout's, as in pipe_table_kernel<true>: the update role stores a
+// tagged copy of every mover's plane, a render wave waits for the entries of its rows.
+template <int K, bool kLdsEntries, bool kFlow = false>
 __global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void pipe_multi_kernel(
     PairParams pp, TupleParams tp, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out,
     int64_t B, int32_t T, int32_t reset_first, int64_t trace_plane, FrameCodec fc, PipeRender rr) {
@@ -1454,12 +1495,14 @@ __global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void
   static_assert(sizeof(L) >= kPipeWaves * (kPipeSpan + 2 * CAMPX_MAX_CELLS), "render windows fit the update LDS");
   static_assert(K >= 2 && K <= CAMPX_MAX_DYN, "two to four movers");
   if (blockIdx.x < rr.U) {
+    if (kFlow && rr.debug_delay)     // (tests: hold the update role back so that render waves time out)
+      for (uint32_t i = 0; i < rr.debug_delay; ++i) __builtin_amdgcn_s_sleep(127);
     if constexpr (K == 2)
-      update_pair_body<kLdsEntries, kPipeProd, kPipeCons>(L, lds_entries, blockIdx.x, pp, st, actions, out, B, T,
-                                                          reset_first, trace_plane, fc);
+      update_pair_body<kLdsEntries, kPipeProd, kPipeCons, kFlow>(L, lds_entries, blockIdx.x, pp, st, actions, out,
+                                                                 B, T, reset_first, trace_plane, fc, rr.tagged, rr.tag);
     else
-      update_tuple_body<K, kPipeProd, kPipeCons>(L, blockIdx.x, tp, st, actions, out, B, T, reset_first,
-                                                 trace_plane, fc);
+      update_tuple_body<K, kPipeProd, kPipeCons, kFlow>(L, blockIdx.x, tp, st, actions, out, B, T, reset_first,
+                                                        trace_plane, fc, rr.tagged, rr.tag);
     return;
   }
   constexpr uint32_t P = 2u * K;                       // patches per row: (mover) x (set | clear)
@@ -1486,15 +1529,27 @@ __global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void
   const uint32_t slots = (last_row - first_row + 1u) * P;
   const uint8_t* frame_trace = rr.trace + (int64_t)t * rr.pitch;
   // ---- loads first: two trace bytes per lane, the window's scenery chunks, two cells' scenery layer
+  // kFlow: from the tagged copy - the raw aligned dword a slot's entry sits in (agent-scope loads;
+  // shifting it here would wait for it here), valid when it carries this launch's tag
+  const uint16_t* frame_tagged = kFlow ? rr.tagged + (int64_t)t * rr.pitch : nullptr;
   auto entry_of = [&](uint32_t sidx) {
     const uint32_t r = sidx / P, d = (sidx - r * P) >> 1;
     uint32_t row = first_row + r;
     row = row <= last_row ? row : last_row;              // clamp: slot unused, entry ignored
+    if (kFlow)
+      return __hip_atomic_load(reinterpret_cast<const uint32_t*>(frame_tagged + (int64_t)d * rr.plane + (row & ~1u)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (uint32_t)frame_trace[(int64_t)d * rr.plane + row];
   };
+  auto half_of = [&](uint32_t sidx) {                    // which half of that dword
+    uint32_t row = first_row + sidx / P;
+    row = row <= last_row ? row : last_row;
+    return (row & 1u) * 16u;
+  };
   uint32_t ent[2];
+  const bool two = slots > kWave;
   ent[0] = entry_of(lane);
-  ent[1] = slots > kWave ? entry_of(lane + kWave) : 0u;
+  ent[1] = two ? entry_of(lane + kWave) : 0u;
   u32x4 scen[kPipeWin];
 #pragma unroll
   for (int j = 0; j < kPipeWin; ++j) {
@@ -1514,6 +1569,24 @@ __global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void
     const uint32_t hi2 = (top2 >> 8) * (uint32_t)rr.cells + c + 1u;
     *reinterpret_cast<uint32_t*>(scen_off + c) = lo | (hi2 << 16);
   }
+  if (kFlow) {
+    // a wave whose rows are not there yet sleeps and looks again - at its own entries
+    uint32_t naps = 0;
+    const uint32_t sh0 = half_of(lane), sh1 = half_of(lane + kWave);
+    const uint32_t want = rr.tag << 8;
+    while (__any(((ent[0] >> sh0) & 0xff00u) != want || (two && ((ent[1] >> sh1) & 0xff00u) != want))) {
+      if (naps < 4u) __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP);
+      else __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
+      if (++naps > rr.max_naps) {      // (see pipe_table_kernel: loudly, and on with what it has)
+        flow_gave_up(rr.error_flag);
+        break;
+      }
+      ent[0] = entry_of(lane);
+      if (two) ent[1] = entry_of(lane + kWave);
+    }
+    ent[0] = (ent[0] >> sh0) & 0xffu;
+    ent[1] = (ent[1] >> sh1) & 0xffu;
+  }
   // ---- patches (a select chain over the kernel arguments, as in render_kernel)
   auto off_of = [&](uint32_t d) {
     int v = __builtin_amdgcn_readfirstlane(rr.dyn_offs[0]);
@@ -1531,7 +1604,19 @@ __global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void
   apply(lane, ent[0]);
   apply(lane + kWave, ent[1]);
   for (uint32_t sidx = lane + 2u * kWave; sidx < slots; sidx += kWave)     // short rows only
-    apply(sidx, entry_of(sidx));
+    if (kFlow) {   // (each lane waits for its own entry)
+      const uint32_t sh = half_of(sidx);
+      uint32_t e = entry_of(sidx) >> sh;
+      for (uint32_t naps = 0; ((e >> 8) & 0xffu) != rr.tag && naps < rr.max_naps; ++naps) {
+        __builtin_amdgcn_s_sleep(CAMPX_FLOW_NAP_LONG);
+        e = entry_of(sidx) >> sh;
+      }
+      if (((e >> 8) & 0xffu) != rr.tag && rr.error_flag)
+        __hip_atomic_fetch_or(rr.error_flag, CAMPX_ERR_FLOW_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      apply(sidx, e & 0xffu);
+    } else {
+      apply(sidx, entry_of(sidx));
+    }
   // ---- out: aligned, contiguous KiB stores
   int8_t* frame = rr.dst + (int64_t)t * rr.slab_bytes;
 #pragma unroll
@@ -1597,10 +1682,10 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
 }
 
 // The tagged copy of the trace of one-launch rollouts lives in the caller's scratch block
-// (CampxOutputs.overlap_ctl): 16 bytes of header, then [T, pitch] 16-bit entries.
+// (CampxOutputs.overlap_ctl): 16 bytes of header, then per mover [T, pitch] 16-bit entries.
 int64_t flow_scratch_bytes(int64_t B, int32_t T) {
   const int64_t pitch = (B + 15) / 16 * 16;       // (the widest row pitch a caller may use)
-  return 16 + 2 * (int64_t)T * pitch;
+  return 16 + 2 * (int64_t)CAMPX_MAX_DYN * T * pitch;     // (and the most movers a game may have)
 }
 
 // A launch's tag: 1..255, counting up per scratch block - in the CALLER's CampxFlowState (the
@@ -1617,6 +1702,21 @@ static uint32_t next_flow_tag(CampxFlowState& l, void* block, int64_t block_byte
   }
   l.tag = l.tag % 255 + 1;
   return (uint32_t)l.tag;
+}
+
+static uint32_t flow_max_naps() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAMPX_FLOW_MAX_NAPS");
+    return (uint32_t)(e && *e ? strtoul(e, nullptr, 10) : kFlowMaxNaps);
+  }();
+  return v;
+}
+static uint32_t flow_debug_delay() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAMPX_FLOW_DEBUG_DELAY");
+    return (uint32_t)(e && *e ? strtoul(e, nullptr, 10) : 0u);
+  }();
+  return v;
 }
 
 static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
@@ -1660,7 +1760,14 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
   // 16 384: profiles/r04_deferred_ab.txt)
   if (s.n_dyn >= 2) {
     // two to four movers (deferred rollouts only): pipe_multi_kernel over the caller's pair / tuple table
-    if (flow || !st.pair_table) return CAMPX_EINVAL;
+    if (!st.pair_table) return CAMPX_EINVAL;
+    if (flow) {
+      rr.tagged = reinterpret_cast<uint16_t*>(out.overlap_ctl + 4);
+      rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, stream);
+      rr.max_naps = flow_max_naps();
+      rr.debug_delay = flow_debug_delay();
+      rr.error_flag = out.error_flag;
+    }
     const PairParams pp = make_pair_params(s);
     const TupleParams tp = make_tuple_params(s);
     const int64_t plane = (int64_t)T * row_pitch(out, B);
@@ -1671,27 +1778,25 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
     static const bool want_lds = [] { const char* v = getenv("CAMPX_PIPE_PAIR_LDS"); return !(v && v[0] == '0'); }();
     const bool in_lds = s.n_dyn == 2 && want_lds && n_entries <= kPairLdsEntries;
     const size_t shmem = in_lds ? (((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15) : 0;
-#define CAMPX_PIPE_MULTI(KK, LDS)                                                                  \
-  hipLaunchKernelGGL((pipe_multi_kernel<KK, LDS>), grid, block, shmem, stream, pp, tp, st, actions, \
-                     out, B, T, reset_first, plane, fc, rr)
+#define CAMPX_PIPE_MULTI(KK, LDS)                                                                        \
+  do {                                                                                                   \
+    if (flow)                                                                                            \
+      hipLaunchKernelGGL((pipe_multi_kernel<KK, LDS, true>), grid, block, shmem, stream, pp, tp, st,     \
+                         actions, out, B, T, reset_first, plane, fc, rr);                                \
+    else                                                                                                 \
+      hipLaunchKernelGGL((pipe_multi_kernel<KK, LDS, false>), grid, block, shmem, stream, pp, tp, st,    \
+                         actions, out, B, T, reset_first, plane, fc, rr);                                \
+  } while (0)
     if (s.n_dyn == 2 && in_lds) CAMPX_PIPE_MULTI(2, true);
     else if (s.n_dyn == 2) CAMPX_PIPE_MULTI(2, false);
     else if (s.n_dyn == 3) CAMPX_PIPE_MULTI(3, false);
     else CAMPX_PIPE_MULTI(4, false);
 #undef CAMPX_PIPE_MULTI
   } else if (flow) {
-    static const uint32_t max_naps = [] {
-      const char* v = getenv("CAMPX_FLOW_MAX_NAPS");
-      return (uint32_t)(v && *v ? strtoul(v, nullptr, 10) : kFlowMaxNaps);
-    }();
-    static const uint32_t debug_delay = [] {
-      const char* v = getenv("CAMPX_FLOW_DEBUG_DELAY");
-      return (uint32_t)(v && *v ? strtoul(v, nullptr, 10) : 0u);
-    }();
     rr.tagged = reinterpret_cast<uint16_t*>(out.overlap_ctl + 4);
     rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, stream);
-    rr.max_naps = max_naps;
-    rr.debug_delay = debug_delay;
+    rr.max_naps = flow_max_naps();
+    rr.debug_delay = flow_debug_delay();
     rr.error_flag = out.error_flag;
     hipLaunchKernelGGL(pipe_table_kernel<true>, grid, block, 0, stream, mp, spec_dev, st, actions, out, B, T,
                        reset_first, fc, rr);
@@ -1740,10 +1845,21 @@ bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, 
   if (off || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
   // (no caller-owned tag state, or nowhere to report a render wave that gave up: two launches)
   if (!out.flow_state || !out.error_flag) return false;
-  if (out.overlap_ctl_bytes < 16 + 2 * (int64_t)T * row_pitch(out, B) ||
+  if (s.n_dyn < 1 || out.overlap_ctl_bytes < 16 + 2 * (int64_t)s.n_dyn * T * row_pitch(out, B) ||
       (reinterpret_cast<uintptr_t>(out.overlap_ctl) & 15))
     return false;
   if (row_pitch(out, B) % 2 != 0) return false;     // (entries are read as aligned dwords)
+  // Two to four movers (pipe_multi_kernel<K, ., true>; sokoban levels 0 / 1 / 2, T = 100, us per
+  // rollout, two launches / one; profiles/r05_multimover_flow_ab.txt): B = 1 024 28 / 23, 50 / 46,
+  // 52 / 68; 4 096 35 / 30, 62 / 53, 65 / 71; 8 192 46 / 44, 77 / 71, 86 / 79.  The four-mover game's
+  // update role (64 environments a workgroup, its chain a load from the 212 MB tuple table per
+  // frame, 128 VGPRs with 12 spilled) is the longer part of a small launch and slower beside
+  // render waves than alone: it takes the one launch from 4 097 environments up only.
+  static const int64_t four_min_b = [] {
+    const char* v = getenv("CAMPX_FLOW4_MIN_B");
+    return (int64_t)(v && *v ? atoll(v) : 4097);
+  }();
+  if (s.n_dyn >= 4 && B < four_min_b) return false;
   CampxOutputs self = out;
   self.board = nullptr;          // (rendered by the ordinary kernel afterwards)
   if (!pipe_ok(s, out, self, B, T, use_table)) return false;

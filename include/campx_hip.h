@@ -263,14 +263,17 @@ typedef struct CampxOutputs {
                          observation / board frames are never padded. */
   uint32_t* overlap_ctl; /* optional device scratch of campx_flow_scratch_bytes(B, T) bytes, 16-byte
                          aligned; NULL: two launches per rollout.  With it - AND `flow_state` AND
-                         `error_flag` below - a rollout of a one-mover game at a batch of at most
-                         8 192 environments (int8 observations of every frame, whole 16-byte
-                         chunks per frame) runs as ONE launch whose update pass and render
-                         overlap: update workgroups first, render workgroups behind them reading
-                         a tagged 16-bit copy of the trace kept in this block as the update role
-                         writes it (csrc/k_update.hip, pipe_table_kernel<true>): 15 / 22 / 34 us
-                         against 20 / 27 / 38 at B = 1 024 / 4 096 / 8 192.  Not while `stream` is
-                         being captured into a graph.  CAMPX_NO_FLOW=1 in the environment: never.
+                         `error_flag` below - a rollout of a table game (one mover; two to four
+                         with CampxState.pair_table) at a batch of at most 8 192 environments
+                         (int8 observations of every frame, whole 16-byte chunks per frame) runs
+                         as ONE launch whose update pass and render overlap: update workgroups
+                         first, render workgroups behind them reading a tagged 16-bit copy of
+                         each mover's trace kept in this block as the update role writes it
+                         (csrc/k_update.hip, pipe_table_kernel<true>: 15 / 22 / 34 us against
+                         20 / 27 / 38 at B = 1 024 / 4 096 / 8 192; pipe_multi_kernel<K, ., true>,
+                         sokoban with one box: 23 / 30 / 44 against 28 / 35 / 46; the four-mover
+                         level from 4 097 environments up).  Not while `stream` is being
+                         captured into a graph.  CAMPX_NO_FLOW=1 in the environment: never.
                          Two launches that may run at the same time must not share a block.
                          campx_flow_shared() says whether a call will take this path. */
   int64_t overlap_ctl_bytes;
@@ -292,13 +295,15 @@ typedef struct CampxOutputs {
                          that this failure cannot pass unseen. */
 } CampxOutputs;
 
-/* Size of CampxOutputs.overlap_ctl for rollouts of T frames of B environments. */
+/* Size of CampxOutputs.overlap_ctl for rollouts of T frames of B environments (of any game: a
+ * 16-byte header and, for each of up to CAMPX_MAX_DYN movers, T rows of B rounded up to 16 entries). */
 int64_t campx_flow_scratch_bytes(int64_t B, int32_t T);
 
 /* 1 when campx_rollout_launch() of T frames of B environments of this game, with a scratch
  * block, flow state and error flag supplied, int8 observations of every frame at a 16-byte
  * aligned address, rows of the per-frame streams `scalar_pitch` apart (0: B) and a stream that
- * is not being captured, runs as ONE launch (pipe_table_kernel<true>); 0 when it runs as an
+ * is not being captured, runs as ONE launch (pipe_table_kernel<true>, pipe_multi_kernel<K, ., true>
+ * - the latter given the game's pair / tuple table, which this query cannot see); 0 when it runs as an
  * update launch and a render launch.  The library's own bounds and environment knobs, for
  * callers that allocate the block only where it is used and for whoever reports which kernel
  * ran (bench.py). */

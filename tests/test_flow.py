@@ -1,5 +1,6 @@
-"""One-launch rollouts of one-mover games at small batches (csrc/k_update.hip
-pipe_table_kernel<true>: update workgroups first, render workgroups of the SAME rollout behind
+"""One-launch rollouts of table games at small batches (csrc/k_update.hip
+pipe_table_kernel<true>, and pipe_multi_kernel<K, ., true> for games of two to four movers:
+update workgroups first, render workgroups of the SAME rollout behind
 them, reading a tagged 16-bit copy of the trace as the update role writes it).  The default path
 of `rollout()` up to 8 192 environments, so every parity test of such games already runs it; here:
 that it IS the path taken (the profiler sees one kernel), the same bytes with it switched off
@@ -16,7 +17,7 @@ import pytest
 import torch
 
 from campx_amd import gamespec
-from campx_amd.games import boat_race, wall_world
+from campx_amd.games import boat_race, sokoban, wall_world
 from conftest import REPO
 from oracle import cpu
 
@@ -49,9 +50,32 @@ def test_small_batch_rollouts_take_one_launch():
   assert sorted(n.split('<')[0].split('::')[-1] for n in names) == ['render_kernel', 'update_table_kernel'], names
 
 
+def _sokoban(level):
+  def build(**kw):
+    return sokoban.build(level=level, **kw)
+  return build
+
+
+def test_small_batch_rollouts_of_two_to_four_movers_take_one_launch():
+  """Round 5: the same one launch for sokoban's levels (two / three / four movers) - the four-mover
+  game from 4 097 environments up only (below, its update role's chain of loads from the 212 MB
+  tuple table is the longer part and runs faster alone)."""
+  for level, B, want in ((0, 2048, 1), (0, 8192, 1), (0, 16384, 2), (1, 1024, 1), (2, 1024, 2), (2, 8192, 1)):
+    game = sokoban.build(level=level, batch=B, device='cuda')
+    game.its_showtime()
+    acts = torch.randint(0, 5, (30, B), dtype=torch.int8, device='cuda')
+    out = game.fused.rollout_buffers(30)
+    game.rollout(acts, out=out)
+    names = _kernels_of(lambda: game.rollout(acts, out=out))
+    assert len(names) == want, (level, B, names)
+    assert ('pipe_multi_kernel' in names[0]) == (want == 1), (level, B, names)
+    assert game.fused._one_launch(30, out['trace'].stride(1)) == (want == 1)
+
+
 @pytest.mark.parametrize('build,B', [(boat_race.build, 16), (boat_race.build, 1024),
                                      (boat_race.build, 5008), (boat_race.build, 8192),
-                                     (wall_world.build, 2000)])
+                                     (wall_world.build, 2000), (_sokoban(0), 16), (_sokoban(0), 1000),
+                                     (_sokoban(0), 8192), (_sokoban(1), 2064), (_sokoban(2), 5008)])
 def test_many_launches_of_changing_length_match_the_oracle(build, B):
   game = build(batch=B, device='cuda')
   game.its_showtime()
@@ -144,12 +168,13 @@ def test_switched_off_the_two_launches_give_the_same_bytes():
   assert out.stdout.strip().endswith('ok')
 
 
-@pytest.mark.parametrize('B', [4096, 8192])
-def test_back_to_back_launches_beside_a_busy_stream(B):
+@pytest.mark.parametrize('B,game', [(4096, 'boat_race'), (8192, 'boat_race'), (4096, 'sokoban'),
+                                    (8192, 'sokoban_l1'), (8192, 'sokoban_l2')])
+def test_back_to_back_launches_beside_a_busy_stream(B, game):
   """tools/flow_stress.py: launches queued without a pause, every one compared on the device with
   the two kernels of a twin engine, while another stream fills memory and rolls out a third game."""
-  out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'flow_stress.py'), str(B), '3000', '100', '1'],
-                       capture_output=True, text=True, timeout=600)
+  out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'flow_stress.py'), str(B), '3000', '100', '1',
+                        game], capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
   assert out.stdout.strip().endswith('ok B=%d launches=3000' % B)
 
@@ -160,9 +185,9 @@ _GIVE_UP = r'''
 import sys
 sys.path.insert(0, %(repo)r)
 import torch
-from campx_amd.games import boat_race
+from campx_amd.games import boat_race, sokoban
 B, T = 4096, 40
-game = boat_race.build(batch=B, device='cuda')
+game = %(build)s(batch=B, device='cuda')
 game.its_showtime()
 game.fused.validate_actions = False          # the error word is looked at whatever this says
 acts = torch.randint(0, 5, (T, B), dtype=torch.int8, device='cuda')
@@ -181,19 +206,20 @@ else:
 '''
 
 
-def test_a_render_wave_that_gives_up_says_so():
+@pytest.mark.parametrize('build', ['boat_race.build', 'sokoban.build'])
+def test_a_render_wave_that_gives_up_says_so(build):
   """a render wave whose trace entries never get this launch's tag used to
   `break` and render stale bytes without a word.  Provoked here with the library's two test knobs -
   the update role held back by a sleep, render waves allowed ONE second look - the launch must
   raise CAMPX_ERR_FLOW_TIMEOUT in the error word and `rollout()` / `check_ok()` a RuntimeError."""
   env = dict(os.environ, CAMPX_FLOW_MAX_NAPS='1', CAMPX_FLOW_DEBUG_DELAY='3000')
-  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO)], env=env,
+  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO, build=build)], env=env,
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
   assert out.stdout.strip().endswith('raised'), out.stdout[-500:]
   # ... and with the default patience the same delay is simply waited out: right frames, no error
   env = dict(os.environ, CAMPX_FLOW_DEBUG_DELAY='3000')
-  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO)], env=env,
+  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO, build=build)], env=env,
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
   assert out.stdout.strip().endswith('silent'), out.stdout[-500:]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stress of the one-launch rollout: N launches compared, every one, with the two-kernel path of a
 twin engine (campx::update and campx::render as separate ops on the same stream).
-    python tools/flow_stress.py [batch] [launches] [frames] [1: with another stream busy]"""
+    python tools/flow_stress.py [batch] [launches] [frames] [1: with another stream busy] [game]
+game: boat_race (default), sokoban, sokoban_l1, sokoban_l2 (two to four movers: pipe_multi_kernel)."""
 import os
 import sys
 import time
@@ -9,12 +10,16 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from campx_amd.games import boat_race  # noqa: E402
+from campx_amd.games import boat_race, sokoban  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-a, b = (boat_race.build(batch=B, device='cuda') for _ in range(2))
+GAME = sys.argv[5] if len(sys.argv) > 5 else 'boat_race'
+build = {'boat_race': boat_race.build, 'sokoban': sokoban.build,
+         'sokoban_l1': lambda **kw: sokoban.build(level=1, **kw),
+         'sokoban_l2': lambda **kw: sokoban.build(level=2, **kw)}[GAME]
+a, b = (build(batch=B, device='cuda') for _ in range(2))
 for g in (a, b):
   g.its_showtime()
   g.fused.validate_actions = False
@@ -55,4 +60,4 @@ for i in range(N):
 torch.cuda.synchronize()
 assert int(bad) == 0, int(bad)
 assert torch.equal(a.fused.pos, b.fused.pos) and torch.equal(a.fused.ret, b.fused.ret)
-print('ok B=%d launches=%d' % (B, N))
+print('ok B=%d launches=%d' % (B, N))   # (tests look for this line)
