@@ -1,0 +1,209 @@
+"""User-style games that poke at the lane tabulator's edges (tests/test_tabulate_batched.py): things a
+game class may legally do on plain tensors - `torch.where`, writes through views, gathers, another
+thing's curtain re-bound, the board read as characters, NaN rewards, Python counters, Plot entries,
+random draws, `nonzero()`, branches on a tensor, z-order changes.  Each is either tabulated on lanes
+identically to the one-frame-per-play walk, or handed to that walk (which takes it or refuses it
+with its own message); never tabulated differently."""
+
+import torch
+
+from campx import things
+from campx.ascii_art import ascii_art_to_game
+
+ART = ['######', '#A   #', '#  G #', '# B  #', '######']
+def shifted(b):
+  return [torch.cat([b[:, 1:], b[:, :1]], dim=1), torch.cat([b[:, -1:], b[:, :-1]], dim=1),
+          torch.cat([b[1:], b[:1]], dim=0), torch.cat([b[-1:], b[:-1]], dim=0), b]
+def moved(act, b):
+  s = shifted(b)
+  return sum(act[i] * s[i] for i in range(5))
+
+class Base(things.Drape):
+  def step(self, act, layers, solid='#'):
+    there = moved(act, self.curtain)
+    hit = (there * layers[solid]).sum()
+    free = (1 - (hit >= 1).long()).byte()
+    return (free * there) + ((1 - free) * self.curtain)
+
+class Where(Base):       # torch.where on layers
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    act = actions.byte()
+    there = moved(act, self.curtain)
+    blocked = (there * layers['#']).sum() >= 1
+    self.curtain.set_(torch.where(blocked, self.curtain, there))
+    the_plot.add_reward((self.curtain * layers['G']).sum().float())
+
+class Counter(Base):     # python int attribute
+  def __init__(self, curtain, character):
+    super().__init__(curtain, character); self.n = 0
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.n = min(self.n + 1, 3)
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(float(self.n))
+
+class PlotMem(Base):     # remembers the previous curtain in the plot (a clone) and rewards on standing still
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    prev = the_plot.get('prev')
+    self.curtain.set_(self.step(actions.byte(), layers))
+    if prev is not None:
+      the_plot.add_reward((prev * self.curtain).sum().float())
+    the_plot['prev'] = self.curtain.clone()
+
+class Rand(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(float(torch.rand(()) > 0.5))
+
+class Nonzero(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    pos = self.curtain.nonzero()
+    the_plot.add_reward(float(pos[0, 0] * 10 + pos[0, 1]))
+
+class Roll(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    a = int(actions.argmax())
+    shift, axis = ((-1, 1), (1, 1), (-1, 0), (1, 0), (0, 0))[a]
+    there = torch.roll(self.curtain, shift, axis)
+    hit = (there * layers['#']).sum()
+    free = (1 - (hit >= 1).long()).byte()
+    self.curtain.set_((free * there) + ((1 - free) * self.curtain))
+    the_plot.add_reward(self.curtain.float().mul(torch.arange(30.).reshape(5, 6)).sum())
+
+class Terminator(Base):   # terminates on G: state-dependent termination through a tensor
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    on = (self.curtain * layers['G']).sum()
+    the_plot.add_reward(on.float())
+    if on > 0:
+      the_plot.terminate_episode()
+
+class Grower(Base):   # curtain grows: multi-cell drape (trail)
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    head = self.step(actions.byte(), layers)
+    self.curtain.set_(((self.curtain + head) >= 1).byte())
+
+class Indexer(Base):  # gather with a lane tensor index
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    flat = self.curtain.reshape(-1).long()
+    idx = (flat * torch.arange(30)).sum()
+    table = torch.arange(30.) * 0.5
+    the_plot.add_reward(table[idx])
+
+class Float(Base):   # float curtain arithmetic / division
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    m = self.curtain.float()
+    rows = m.sum(dim=1)
+    the_plot.add_reward((rows * torch.tensor([0., 1., 2., 3., 4.])).sum() / 3)
+
+class ChangeZ(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    if actions[4] == 1:
+      the_plot.change_z_order('A', 'G')
+
+class ViewWrite(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    new = self.step(actions.byte(), layers)
+    row = self.curtain[1]
+    row.zero_()
+    self.curtain[2:] = 0
+    self.curtain.add_(new)
+    the_plot.add_reward((self.curtain * layers['G']).sum().float() * 2)
+
+class Pusher(Base):     # moves ANOTHER thing's curtain
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    act = actions.byte()
+    there = moved(act, self.curtain)
+    b = all_things['B'].curtain
+    push = (there * b).sum().byte()
+    b_there = moved(act, b)
+    b_free = (1 - ((b_there * layers['#']).sum() >= 1).long()).byte()
+    ok = push * b_free
+    b.set_((ok * b_there) + ((1 - ok) * b))
+    blocked = ((there * layers['#']).sum() >= 1).long().byte() + (push * (1 - b_free))
+    free = (1 - (blocked >= 1).long()).byte()
+    self.curtain.set_((free * there) + ((1 - free) * self.curtain))
+
+class Still(things.Drape):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    pass
+
+class BoardReader(Base):   # reads `board` (int64 ords) and backdrop
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    there = moved(actions.byte(), self.curtain)
+    wall = (board == ord('#')).byte()
+    hit = (there * wall).sum() + (there * (board == ord('B')).byte()).sum()
+    free = (1 - (hit >= 1).long()).byte()
+    self.curtain.set_((free * there) + ((1 - free) * self.curtain))
+    the_plot.add_reward(((board == ord('G')).byte() * self.curtain).sum().float() + (backdrop.curtain == ord(' ')).sum().float() * 0)
+
+class Chaser(Base):      # B chases A: reads all_things['A'].curtain
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    a = all_things['A'].curtain.float()
+    me = self.curtain.float()
+    cols = torch.arange(6.); rows = torch.arange(5.)
+    dx = (a.sum(0) * cols).sum() - (me.sum(0) * cols).sum()
+    dy = (a.sum(1) * rows).sum() - (me.sum(1) * rows).sum()
+    go_right = (dx > 0).byte(); go_left = (dx < 0).byte()
+    s = shifted(self.curtain)
+    there = go_left * s[0] + go_right * s[1] + (1 - go_left - go_right) * s[4]
+    hit = (there * layers['#']).sum() + (there * layers['A']).sum()
+    free = (1 - (hit >= 1).long()).byte()
+    self.curtain.set_((free * there) + ((1 - free) * self.curtain))
+    the_plot.add_reward(-(dx.abs() + dy.abs()))
+
+class Mover(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+
+class NanReward(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    on = (self.curtain * layers['G']).sum().float()
+    the_plot.add_reward(on / on)       # nan off the goal, 1 on it
+
+class Discounter(Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None: return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    if actions[0] == 1:
+      the_plot.terminate_episode(0.5)
+
+
+def game(a, b=Still):
+  def build():
+    return ascii_art_to_game(ART, what_lies_beneath=' ',
+                             drapes={'A': a, 'B': b, '#': things.FixedDrape, 'G': things.FixedDrape},
+                             z_order='G#BA', update_schedule='AB#G')
+  return build
+
+
+# (class of 'A', class of 'B', what the auto walker's LAST_WALK must start with, or the refusal both give)
+CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes: something besides the curtains'),
+         (ViewWrite, Still, 'lanes: '), (PlotMem, Still, "one frame per play (lanes: the_plot['prev']"),
+         (Rand, Still, 'REFUSED: keeps state outside'), (Nonzero, Still, 'one frame per play (lanes: nonzero'),
+         (Roll, Still, 'lanes: '), (Terminator, Still, 'one frame per play (lanes: bool() of a value that differs'),
+         (Grower, Still, 'REFUSED: covers'), (Indexer, Still, 'one frame per play (lanes: __getitem__'),
+         (Float, Still, 'lanes: '), (ChangeZ, Still, 'one frame per play (lanes: the game changes the z-order'),
+         (Pusher, Still, 'lanes: '), (BoardReader, Still, 'lanes: '), (Mover, Chaser, 'lanes: '),
+         (NanReward, Still, 'lanes: '), (Discounter, Still, 'lanes: ')]

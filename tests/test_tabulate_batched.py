@@ -28,6 +28,7 @@ from campx_amd import lanes, tabulate, tabulate_batched
 from campx_amd.games import boat_race, wall_world
 from conftest import GOLDEN_DIR, REPO
 import lanes_games
+import lanes_probes
 import traced_games
 
 
@@ -340,6 +341,31 @@ def test_games_the_lane_walker_does_not_take_fall_back_and_say_why(monkeypatch):
   monkeypatch.setenv('CAMPX_TABULATE', 'batch')
   with pytest.raises(tabulate.TabulationError, match='differs between states'):
     tabulate.trace(build(), cache=False)
+
+
+@pytest.mark.parametrize('a,b,expect', lanes_probes.CASES, ids=[c[0].__name__ for c in lanes_probes.CASES])
+def test_games_at_the_edges_are_tabulated_the_same_or_handed_to_the_walk(a, b, expect, monkeypatch):
+  """tests/lanes_probes.py: whatever a game class does, the default walker's table equals the
+  one-frame-per-play walker's - through lanes where the operations have a lane-by-lane form,
+  through the fall-back where they do not - or both refuse the game with the same message."""
+  outcome = {}
+  for mode in ('walk', 'auto'):
+    monkeypatch.setenv('CAMPX_TABULATE', mode)
+    try:
+      outcome[mode] = tabulate.trace(lanes_probes.game(a, b)(), cache=False)
+      if mode == 'auto':
+        how = tabulate.LAST_WALK[0]
+    except tabulate.TabulationError as e:
+      outcome[mode] = str(e)
+  if expect.startswith('REFUSED: '):
+    assert isinstance(outcome['walk'], str) and outcome['walk'] == outcome['auto']
+    assert expect[len('REFUSED: '):] in outcome['walk']
+    return
+  assert not isinstance(outcome['walk'], str), outcome['walk']
+  assert not isinstance(outcome['auto'], str), outcome['auto']
+  assert how.startswith(expect), how
+  assert outcome['walk'].n_states == outcome['auto'].n_states > 1
+  assert _first_difference(outcome['walk'], outcome['auto']) is None
 
 
 # ------------------------------------------------------------------------------- GPU
