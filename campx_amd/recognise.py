@@ -579,6 +579,11 @@ def shapes(engine, actions=None):
   actions = detect_actions(engine) if actions is None else list(actions)
   if len(actions) != N_ACTIONS:
     raise ValueError('exactly {} actions are needed'.format(N_ACTIONS))
+  # (a live Sprite / Drape / Engine / Plot reached through a module global, a closure or a default
+  # argument: the recording stand-ins below never see it read - refused by its name, statically)
+  behind = tabulate.reached_behind_the_engine(engine)
+  if behind:
+    _fail(behind)
 
   probe = tabulate.clone_engine(engine)
   probe._batch, probe._device, probe._fused = None, None, None

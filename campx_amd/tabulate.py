@@ -62,7 +62,14 @@ must reproduce the tabulated next state, reward, discount, game-over and board; 
 such state only if it shows within one frame of one second arrival (a `random` call does; a
 global counter that matters fifty frames later does not).  Games are deterministic functions of
 their entities and their Plot in every example of the reference; one that is not must not be
-handed to a batched Engine.
+handed to a batched Engine.  One such route is not left to the spot check, because it would not
+be caught but tabulated wrong: a LIVE Sprite / Drape / Backdrop / Engine / Plot that a class reaches
+through a module global, a closure variable, a default argument or a class attribute.  The walks
+run on deep copies of the engine, which such a reference does not follow - the object would
+seem to stand still - so `reached_behind_the_engine()` looks for it in the code of the game's
+classes (and the user functions and classes they name) before anything is walked, and the game
+is refused by the name of the route.  (A partner kept in an INSTANCE attribute is copied along
+with its owner and tabulates correctly.)
 
 Host logic only (numpy + the generic tier): runs without a GPU.  `fused.FusedGame`
 uploads the result.
@@ -545,6 +552,151 @@ def _feed(h, x, depth=0, seen=frozenset()):
     raise _NoFingerprint()
 
 
+# ---- live game objects reached behind the engine's back ------------------------------------
+# `update()` is handed everything it may look at (campx/engine.py:200-204).  A class that reaches
+# a live Engine, Plot, Sprite, Drape or Backdrop some other way - a module global, a closure
+# variable, a default argument: `REGISTRY['A'].curtain` - reads state the tabulators never see
+# change: they work on deep copies of the engine, which such a reference does not follow, so the
+# table would be built as if the object stood still.  That is checked statically, before any walk.
+
+def _global_loads(code, into):
+  """Names the code object (and those nested in it) loads as GLOBALS - not attribute names."""
+  import dis
+  for ins in dis.get_instructions(code):
+    if ins.opname in ('LOAD_GLOBAL', 'LOAD_NAME'):
+      into.add(ins.argval)
+  for const in code.co_consts:
+    if hasattr(const, 'co_code'):
+      _global_loads(const, into)
+  return into
+
+
+def _attribute_names(code, into):
+  into.update(code.co_names)
+  for const in code.co_consts:
+    if hasattr(const, 'co_code'):
+      _attribute_names(const, into)
+  return into
+
+
+def _live_in_value(x, live, depth, seen):
+  """A description of the first live game object inside `x` (containers, plain objects, user
+  functions and classes are followed), or None."""
+  if depth > 5 or x is None or isinstance(x, (bool, int, float, str, bytes)) or torch.is_tensor(x) or \
+      isinstance(x, (np.ndarray, np.generic)) or id(x) in seen:
+    return None
+  if isinstance(x, live):
+    return 'a live {}'.format(type(x).__name__)
+  seen.add(id(x))
+  if isinstance(x, (list, tuple, set, frozenset)):
+    for item in x:
+      found = _live_in_value(item, live, depth + 1, seen)
+      if found:
+        return found
+    return None
+  if isinstance(x, dict):
+    for key, item in x.items():
+      found = _live_in_value(key, live, depth + 1, seen) or _live_in_value(item, live, depth + 1, seen)
+      if found:
+        return found
+    return None
+  if isinstance(x, type(sys)) or isinstance(x, type(len)):
+    return None
+  if isinstance(x, type):
+    return _live_in_class(x, live, depth + 1, seen)
+  if getattr(x, '__code__', None) is not None and hasattr(x, '__globals__'):
+    mod = sys.modules.get(getattr(x, '__module__', None) or '')
+    if mod is not None and _is_library_module(mod):
+      return None
+    return _live_in_function(x, live, depth + 1, seen)
+  if hasattr(x, '__func__'):                       # a bound method: its object and its function
+    return _live_in_value(getattr(x, '__self__', None), live, depth + 1, seen) or \
+        _live_in_value(x.__func__, live, depth + 1, seen)
+  if hasattr(x, '__dict__') and not callable(x):
+    return _live_in_value(vars(x), live, depth + 1, seen)
+  return None
+
+
+def _live_in_function(fn, live, depth, seen):
+  code = fn.__code__
+  if id(code) in seen:
+    return None
+  seen.add(id(code))
+  for what, value in (('a default argument', fn.__defaults__), ('a default argument', fn.__kwdefaults__)):
+    found = _live_in_value(value, live, depth + 1, seen)
+    if found:
+      return '{} through {} of {}()'.format(found, what, fn.__name__)
+  for name, cell in zip(code.co_freevars, fn.__closure__ or ()):
+    try:
+      inside = cell.cell_contents
+    except ValueError:
+      continue
+    if isinstance(inside, type) and name == '__class__':
+      continue
+    found = _live_in_value(inside, live, depth + 1, seen)
+    if found:
+      return '{} through the closure variable {!r} of {}()'.format(found, name, fn.__name__)
+  space = fn.__globals__
+  attrs = None
+  for name in sorted(_global_loads(code, set())):
+    if name not in space:
+      continue
+    value = space[name]
+    if isinstance(value, type(sys)):
+      if _is_library_module(value):
+        continue
+      attrs = _attribute_names(code, set()) if attrs is None else attrs
+      for attr in sorted(attrs):                   # `config.REGISTRY`: the attributes it names
+        if hasattr(value, attr):
+          found = _live_in_value(getattr(value, attr), live, depth + 1, seen)
+          if found:
+            return '{} through {}.{} (named by {}())'.format(found, name, attr, fn.__name__)
+      continue
+    found = _live_in_value(value, live, depth + 1, seen)
+    if found:
+      return '{} through the module global {!r} (named by {}())'.format(found, name, fn.__name__)
+  return None
+
+
+def _live_in_class(klass, live, depth, seen):
+  if id(klass) in seen and depth > 0:
+    return None
+  seen.add(id(klass))
+  for base in klass.__mro__:
+    if base.__module__.split('.')[0] in ('campx_amd', 'campx', 'builtins', 'abc', 'collections', 'typing'):
+      continue
+    for name in sorted(vars(base)):
+      member = vars(base)[name]
+      fn = getattr(member, '__func__', member)
+      fn = getattr(fn, 'fget', fn)
+      if getattr(fn, '__code__', None) is not None and hasattr(fn, '__globals__'):
+        found = _live_in_function(fn, live, depth + 1, seen)
+        if found:
+          return found
+      elif not name.startswith('__'):              # a class attribute (deep copies share classes)
+        found = _live_in_value(member, live, depth + 1, seen)
+        if found:
+          return '{} through the class attribute {}.{}'.format(found, base.__name__, name)
+  return None
+
+
+def reached_behind_the_engine(engine):
+  """None, or what to tell the user: the first live game object that the code of one of the
+  game's classes reaches through a module global, a closure variable or a default argument."""
+  from . import plot as _plot
+  live = (_things.Sprite, _things.Drape, _things.Backdrop, _plot.Plot, type(engine))
+  seen = set()
+  for ent in list(engine.things.values()) + [engine.backdrop]:
+    if ent is None:
+      continue
+    found = _live_in_class(type(ent), live, 0, seen)
+    if found:
+      return ('{!r} ({}): its code reaches {}.  update() is handed everything it may read '
+              '(layers, all_things, the_plot); state reached any other way is invisible to the '
+              'tabulation'.format(getattr(ent, 'character', 'backdrop'), type(ent).__name__, found))
+  return None
+
+
 def fingerprint(engine, actions):
   """A key under which the tabulation of a set-up engine can be reused: every entity's class
   (by the code of its methods) and attributes, the backdrop, the update groups and z-order, the hidden-
@@ -614,6 +766,9 @@ def _trace(engine, actions, max_plays):
   number in the state first; when the game turns out to read `the_plot.frame`
   (campx/plot.py:259-280), again with it.  CAMPX_TABULATE=walk: never lane by lane; =batch:
   only lane by lane (the refusal is raised)."""
+  behind = reached_behind_the_engine(engine)
+  if behind:
+    _fail(behind)
   mode = os.environ.get('CAMPX_TABULATE', 'auto')
   if mode != 'walk':
     from . import tabulate_batched

@@ -207,3 +207,107 @@ CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes:
          (Float, Still, 'lanes: '), (ChangeZ, Still, 'one frame per play (lanes: the game changes the z-order'),
          (Pusher, Still, 'lanes: '), (BoardReader, Still, 'lanes: '), (Mover, Chaser, 'lanes: '),
          (NanReward, Still, 'lanes: '), (Discounter, Still, 'lanes: ')]
+
+
+# ---- live game objects reached behind the engine's back: refused statically, by name
+REGISTRY = {}
+
+
+class Spy(things.Drape):
+  """Rewards by where 'A' stands - read through a module global, not through all_things."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    a = REGISTRY['A'].curtain
+    the_plot.add_reward((a * torch.arange(30, dtype=torch.uint8).reshape(5, 6)).sum().float())
+
+
+def spy_through_a_global():
+  eng = game(Mover, Spy)()
+  REGISTRY['A'] = eng.things['A']
+  return eng
+
+
+def spy_through_a_closure():
+  seen = []
+
+  class ClosureSpy(things.Drape):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      if actions is None:
+        return
+      the_plot.add_reward((seen[0].curtain * torch.arange(30, dtype=torch.uint8).reshape(5, 6)).sum().float())
+
+  eng = game(Mover, ClosureSpy)()
+  seen.append(eng.things['A'])
+  return eng
+
+
+def spy_through_a_default_argument():
+  box = {}
+
+  class DefaultSpy(things.Drape):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot, where=box):
+      if actions is None:
+        return
+      a = where['engine'].things['A'].curtain
+      the_plot.add_reward((a * torch.arange(30, dtype=torch.uint8).reshape(5, 6)).sum().float())
+
+  eng = game(Mover, DefaultSpy)()
+  box['engine'] = eng
+  return eng
+
+
+def _helper_reward():
+  return (REGISTRY['A'].curtain * torch.arange(30, dtype=torch.uint8).reshape(5, 6)).sum().float()
+
+
+class HelperSpy(things.Drape):
+  """... through a helper function of the user's module."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    the_plot.add_reward(_helper_reward())
+
+
+def spy_through_a_helper():
+  eng = game(Mover, HelperSpy)()
+  REGISTRY['A'] = eng.things['A']
+  return eng
+
+
+SPIES = [(spy_through_a_global, "a live Mover through the module global 'REGISTRY'"),
+         (spy_through_a_closure, "a live Mover through the closure variable 'seen'"),
+         (spy_through_a_default_argument, 'a live Engine through a default argument'),
+         (spy_through_a_helper, "a live Mover through the module global 'REGISTRY' (named by _helper_reward())")]
+
+
+class AttrSpy(things.Drape):
+  """... through an attribute of its own instance: deep copies keep that consistent (the copy's
+  partner is the copy's 'A'), so this one IS tabulated - and must predict live play."""
+  partner = None
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    the_plot.add_reward((self.partner.curtain * torch.arange(30, dtype=torch.uint8).reshape(5, 6)).sum().float())
+
+
+def spy_through_its_own_attribute():
+  eng = game(Mover, AttrSpy)()
+  eng.things['B'].partner = eng.things['A']
+  return eng
+
+
+class ClassAttrSpy(AttrSpy):
+  pass
+
+
+def spy_through_a_class_attribute():
+  eng = game(Mover, ClassAttrSpy)()
+  ClassAttrSpy.partner = eng.things['A']       # (classes are shared between deep copies)
+  return eng
+
+
+SPIES.append((spy_through_a_class_attribute, 'a live Mover through the class attribute ClassAttrSpy.partner'))

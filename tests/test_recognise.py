@@ -267,6 +267,40 @@ def test_a_sprite_that_reads_layers_board_things_or_the_plot_is_refused():
   assert _spec_bytes(gamespec.lower_shapes(desc)) == _golden('hello_world_spec')['spec'].tobytes()
 
 
+_PEERS = {}
+
+
+def test_a_sprite_that_reaches_another_through_a_global_or_a_closure_is_refused():
+  """The recording stand-ins see what update() is HANDED; a live Sprite kept in a module global
+  or a closure is read without them knowing, and the per-thing proof - on a deep copy - would see
+  it stand still.  Refused statically, by the name of the route (tabulate.reached_behind_the_engine)."""
+  ex, _ = _hello()
+
+  class ThroughGlobal(ex.Bishop):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      ex.Bishop.update(self, actions, board, layers, backdrop, all_things, the_plot)
+      if actions is not None and _PEERS['4'].position == (2, 3):
+        self._teleport((0, 0))
+
+  game = ex.make_game(bishop=ThroughGlobal)
+  _PEERS['4'] = game.things['4']
+  with pytest.raises(recognise.RecogniseError, match=r"a live \w+ through the module global '_PEERS'"):
+    recognise.shapes(game)
+
+  peers = []
+
+  class ThroughClosure(ex.Bishop):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      ex.Bishop.update(self, actions, board, layers, backdrop, all_things, the_plot)
+      if actions is not None and peers[0].things['4'].position == (2, 3):
+        self._teleport((0, 0))
+
+  game = ex.make_game(bishop=ThroughClosure)
+  peers.append(game)
+  with pytest.raises(recognise.RecogniseError, match=r"a live Engine through the closure variable 'peers'"):
+    recognise.shapes(game)
+
+
 def test_a_backdrop_that_changes_or_looks_is_refused():
   from campx import things
   from campx.ascii_art import ascii_art_to_game

@@ -343,6 +343,35 @@ def test_games_the_lane_walker_does_not_take_fall_back_and_say_why(monkeypatch):
     tabulate.trace(build(), cache=False)
 
 
+def _predicts_live_play(table, build, frames=60, seed=3):
+  """The table against the user's classes played live on the generic tier: board, reward bits, discount."""
+  rng = np.random.RandomState(seed)
+  eng = build()
+  obs, _, _ = eng.its_showtime()
+  one_hot = torch.eye(5)
+  s = 0
+  assert np.array_equal(obs.board.numpy().astype(np.uint8).reshape(-1), table.st_board[0])
+  for t in range(frames):
+    if eng.game_over:
+      break
+    a = int(rng.randint(5))
+    obs, reward, discount = eng.play(one_hot[a].clone())
+    assert table.st_reached[s, a], (t, s, a)
+    want, got = np.float32(table.st_reward[s, a]), np.float32(float('nan') if reward is None else float(reward))
+    assert want.view(np.uint32) == got.view(np.uint32) or (np.isnan(want) and np.isnan(got)), (t, s, a, want, got)
+    s = int(table.st_next[s, a])
+    if not eng.game_over:
+      assert np.array_equal(obs.board.numpy().astype(np.uint8).reshape(-1), table.st_board[s]), (t, s, a)
+
+
+def test_a_partner_kept_in_an_instance_attribute_is_followed_by_the_copies(monkeypatch):
+  for mode in ('walk', 'auto'):
+    monkeypatch.setenv('CAMPX_TABULATE', mode)
+    table = tabulate.trace(lanes_probes.spy_through_its_own_attribute(), cache=False)
+    assert table.n_states == 12
+    _predicts_live_play(table, lanes_probes.spy_through_its_own_attribute)
+
+
 @pytest.mark.parametrize('a,b,expect', lanes_probes.CASES, ids=[c[0].__name__ for c in lanes_probes.CASES])
 def test_games_at_the_edges_are_tabulated_the_same_or_handed_to_the_walk(a, b, expect, monkeypatch):
   """tests/lanes_probes.py: whatever a game class does, the default walker's table equals the
@@ -358,7 +387,8 @@ def test_games_at_the_edges_are_tabulated_the_same_or_handed_to_the_walk(a, b, e
     except tabulate.TabulationError as e:
       outcome[mode] = str(e)
   if expect.startswith('REFUSED: '):
-    assert isinstance(outcome['walk'], str) and outcome['walk'] == outcome['auto']
+    cut = lambda text: text.split(' answered action ')[0]      # (which action showed it: the random game's luck)
+    assert isinstance(outcome['walk'], str) and cut(outcome['walk']) == cut(outcome['auto'])
     assert expect[len('REFUSED: '):] in outcome['walk']
     return
   assert not isinstance(outcome['walk'], str), outcome['walk']
@@ -366,6 +396,25 @@ def test_games_at_the_edges_are_tabulated_the_same_or_handed_to_the_walk(a, b, e
   assert how.startswith(expect), how
   assert outcome['walk'].n_states == outcome['auto'].n_states > 1
   assert _first_difference(outcome['walk'], outcome['auto']) is None
+  _predicts_live_play(outcome['auto'], lanes_probes.game(a, b))
+
+
+@pytest.mark.parametrize('build,what', lanes_probes.SPIES, ids=[b.__name__ for b, _ in lanes_probes.SPIES])
+def test_a_live_game_object_reached_behind_the_engine_is_refused_by_name(build, what, monkeypatch):
+  """A class that reads another thing through a module global, a closure or a default argument
+  (not through `all_things`) reads an object the tabulators' deep copies do not follow: both
+  walkers would tabulate the game as if that thing stood still - silently wrong tables.  Refused
+  statically, naming the route; the generic tier (batch=None) still plays such a game."""
+  for mode in ('walk', 'auto'):
+    monkeypatch.setenv('CAMPX_TABULATE', mode)
+    with pytest.raises(tabulate.TabulationError) as e:
+      tabulate.trace(build(), cache=False)
+    assert what in str(e.value), str(e.value)
+  eng = build()
+  eng.its_showtime()
+  one_hot = torch.eye(5)
+  rewards = [float(eng.play(one_hot[a])[1]) for a in (1, 1, 3, 3)]
+  assert len(set(rewards)) > 1          # (the live reference does matter to the game)
 
 
 # ------------------------------------------------------------------------------- GPU
