@@ -319,6 +319,18 @@ class Engine(object):
               recognised = recognise.shapes(self, actions)
             except recognise.RecogniseError as other:
               raise tabulate.TabulationError('{} (and {})'.format(refusal, other))
+      elif not gamespec.is_shape_rule_game(self):
+        # a rule game the rule lowering does not take (a tile painted in front of the agent that
+        # does not block it, more rules than the interpreter's program holds ...): the rule classes
+        # are ordinary Python classes too, so the tabulator gets the game, as it would a user's
+        try:
+          gamespec.lower(gamespec.describe(self))
+        except ValueError as refusal:
+          from . import tabulate
+          try:
+            traced = tabulate.trace(self)
+          except tabulate.TabulationError as other:
+            raise ValueError('{} (and {})'.format(refusal, other))
     self._showtime = True
     self._update_groups = [(name, self._update_groups[name])
                            for name in sorted(self._update_groups.keys())]

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""tests/golden/random_tracks.npz: the seeded family of tests/random_tracks.py, every game built
+from the REFERENCE's own classes (examples/boat_race.py AgentDrape, DirectionalHoverRewardDrape;
+campx.things.FixedDrape) and run on the reference's engine / renderer / Plot, imported from
+/root/reference where they lie (ref_harness).  Build container only:
+
+    python tests/golden/make_random_golden.py
+
+Per game k the arrays of make_golden.py's layout under `k<k>_<name>` (board, layered, reward,
+discount, done, actions, chars), plus the definition itself - `k<k>_art` [H, W] uint8, `k<k>_meta`
+a JSON string (tiles, reward vectors, z-order, update groups, blocking characters) - so that the
+test notices a generator that no longer produces the games these frames belong to.  Each game is
+also run with this repo's rule-library classes bound to the reference's `things` on the reference
+engine and must give the same frames before anything is written.
+"""
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (loads the reference through ref_harness; repo appended after it)
+
+sys.path.append(os.path.dirname(HERE))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import random_tracks  # noqa: E402
+
+T, N = 48, 6
+
+
+def main():
+  torch.set_num_threads(1)
+  ref = mg.ref
+  out, rewards, blocked_by_tile, in_front = {}, 0, 0, 0
+  for k, d in enumerate(random_tracks.definitions()):
+    acts = mg.random_actions(5000 + k, T, N)
+    acts[:, 0] = np.random.RandomState(6000 + k).choice(4, size=T)          # one that never stays
+
+    def reference_game():
+      return random_tracks.build(d, mg.to_game, mg.Partial, ref.boat_race.AgentDrape,
+                                 ref.boat_race.DirectionalHoverRewardDrape, ref.things.FixedDrape,
+                                 torch.FloatTensor)
+
+    def library_game():
+      return random_tracks.build(d, mg.to_game, mg.Partial, mg.R.AgentDrape,
+                                 mg.R.DirectionalHoverRewardDrape, mg.R.FixedDrape, torch.FloatTensor)
+
+    golden = mg.run(reference_game, acts)
+    mg.assert_same(golden, mg.run(library_game, acts), 'random track {}: library rules'.format(k))
+    for name, value in golden.items():
+      out['k{}_{}'.format(k, name)] = value
+    out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
+    out['k{}_meta'.format(k)] = np.array(json.dumps(
+        dict(tiles=d['tiles'], dctns=d['dctns'], z_order=d['z_order'], schedule=d['schedule'],
+             blocking=d['blocking']), sort_keys=True))
+    base = -0.25 * len(d['tiles'])
+    rewards += int((golden['reward'] != np.float32(base)).sum())
+    blocked_by_tile += int(len(d['blocking']) > 1)
+    in_front += int(any(d['z_order'].index(ch) > d['z_order'].index('A') for ch in d['tiles']))
+    print('track {:2d} {}x{} tiles {!r:6} z {!r:8} groups {} blocking {!r:4} return[mean] {:.2f}'.format(
+        k, len(d['art']), len(d['art'][0]), d['tiles'], d['z_order'], len(d['schedule']), d['blocking'],
+        float(golden['reward'].sum(0).mean())))
+  assert rewards > 200 and blocked_by_tile >= 4 and in_front >= 8, (rewards, blocked_by_tile, in_front)
+  path = os.path.join(HERE, 'random_tracks.npz')
+  np.savez_compressed(path, **out)
+  print('{} games, {} frames with a bonus, {} with a blocking tile, {} with a tile in front of the '
+        'agent -> {} KiB; reference at {}'.format(random_tracks.N_GAMES, rewards, blocked_by_tile, in_front,
+                                                   os.path.getsize(path) // 1024, ref.campx.__file__))
+
+
+if __name__ == '__main__':
+  main()
