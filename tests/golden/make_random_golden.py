@@ -4,7 +4,10 @@ from the REFERENCE's own classes (examples/boat_race.py AgentDrape, DirectionalH
 campx.things.FixedDrape) and run on the reference's engine / renderer / Plot, imported from
 /root/reference where they lie (ref_harness).  Build container only:
 
-    python tests/golden/make_random_golden.py
+    python tests/golden/make_random_golden.py [tracks] [hellos]
+
+(`hellos`: tests/golden/random_hellos.npz, the family of tests/random_hellos.py from the Hello World
+notebook's own RollingDrape / SlidingSprite - see hellos() below.)
 
 Per game k the arrays of make_golden.py's layout under `k<k>_<name>` (board, layered, reward,
 discount, done, actions, chars), plus the definition itself - `k<k>_art` [H, W] uint8, `k<k>_meta`
@@ -71,5 +74,49 @@ def main():
                                                    os.path.getsize(path) // 1024, ref.campx.__file__))
 
 
+def hellos():
+  """tests/golden/random_hellos.npz: tests/random_hellos.py's family from the notebook's own
+  classes (Hello World Example.ipynb cell 3), integer actions 0..4 (4: quit)."""
+  import ref_harness
+  import random_hellos
+  ns = ref_harness.notebook_namespace('Hello World Example.ipynb', [3])
+  T, N = 40, 4
+  out, trails, quits = {}, 0, 0
+  for k, d in enumerate(random_hellos.definitions()):
+    acts = mg.random_actions(7000 + k, T, N, n_actions=4)
+    acts[:, 1] = mg.random_actions(7100 + k, T, 1, n_actions=5)[:, 0]          # with quits
+    acts[:, 2] = int(k % 4)                                                    # a long straight trail
+
+    def notebook_game():
+      return random_hellos.build(d, mg.to_game, mg.Partial, ns['RollingDrape'], ns['SlidingSprite'])
+
+    def library_game():
+      return random_hellos.build(d, mg.to_game, mg.Partial, mg.R.RollingDrape, mg.R.SlidingSprite)
+
+    golden = mg.run(notebook_game, acts, to_action=int)
+    mg.assert_same(golden, mg.run(library_game, acts, to_action=int), 'random hello {}: library rules'.format(k))
+    for name, value in golden.items():
+      out['k{}_{}'.format(k, name)] = value
+    out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
+    out['k{}_meta'.format(k)] = np.array(json.dumps(
+        dict(drapes=d['drapes'], sprites=d['sprites'], z_order=d['z_order'], schedule=d['schedule']),
+        sort_keys=True))
+    first_drape = min(d['z_order'].index(ch) for ch in d['drapes'])
+    trails += int(first_drape > 0)
+    quits += int(golden['done'].sum())
+    print('hello {:2d} {}x{} drapes {!r:4} sprites {} z {!r:9} return[mean] {:.1f} done {}'.format(
+        k, len(d['art']), len(d['art'][0]), d['drapes'], len(d['sprites']), d['z_order'],
+        float(np.nansum(golden['reward'], 0).mean()), int(golden['done'].sum())))
+  assert trails >= 8 and quits >= 40, (trails, quits)
+  path = os.path.join(HERE, 'random_hellos.npz')
+  np.savez_compressed(path, **out)
+  print('{} games, {} with trails, {} episode ends -> {} KiB'.format(
+      random_hellos.N_GAMES, trails, quits, os.path.getsize(path) // 1024))
+
+
 if __name__ == '__main__':
-  main()
+  which = sys.argv[1:] or ['tracks', 'hellos']
+  if 'tracks' in which:
+    main()
+  if 'hellos' in which:
+    hellos()
