@@ -70,7 +70,7 @@ def main():
   path = os.path.join(HERE, 'random_tracks.npz')
   np.savez_compressed(path, **out)
   print('{} games, {} frames with a bonus, {} with a blocking tile, {} with a tile in front of the '
-        'agent -> {} KiB; reference at {}'.format(random_tracks.N_GAMES, rewards, blocked_by_tile, in_front,
+        'agent -> {} KiB; reference at {}'.format(random_tracks.N_GAMES + random_tracks.N_BIG, rewards, blocked_by_tile, in_front,
                                                    os.path.getsize(path) // 1024, ref.campx.__file__))
 
 

@@ -16,13 +16,15 @@ constructor signatures.
 import numpy as np
 
 N_GAMES = 32
+N_BIG = 8            # more games, on boards above 128 cells: the batched engine runs those from their state table
 SEED = 20261003
 TILES = '^>v<'
 BONUSES = (0.0, 1.0, 3.0, -2.0, 0.5)
 
 
-def _one(rng):
-  H, W = int(rng.randint(4, 9)), int(rng.randint(4, 11))
+def _one(rng, big=False):
+  H, W = (int(rng.randint(4, 9)), int(rng.randint(4, 11))) if not big else \
+      (int(rng.randint(10, 17)), int(rng.randint(14, 25)))
   grid = np.full((H, W), ' ', dtype='<U1')
   grid[0, :] = grid[-1, :] = grid[:, 0] = grid[:, -1] = '#'
   inner = [(r, c) for r in range(1, H - 1) for c in range(1, W - 1)]
@@ -60,7 +62,8 @@ def _one(rng):
 
 def definitions():
   rng = np.random.RandomState(SEED)
-  return [_one(rng) for _ in range(N_GAMES)]
+  games = [_one(rng) for _ in range(N_GAMES)]
+  return games + [_one(rng, big=True) for _ in range(N_BIG)]
 
 
 def build(d, to_game, partial, agent, hover, fixed, tensor, **engine_kwargs):

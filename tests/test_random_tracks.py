@@ -1,4 +1,5 @@
-"""A seeded family of 32 race-track games (tests/random_tracks.py) against what the REFERENCE's own
+"""A seeded family of 40 race-track games (tests/random_tracks.py; the last 8 on boards of 140 to 384
+cells, which the batched engine runs from their state table - the wide tier) against what the REFERENCE's own
 classes did on the reference's engine (tests/golden/random_tracks.npz, make_random_golden.py):
 random boards, tiles, reward vectors, z-orders (tiles in front of the agent or behind it), update
 schedules of one to three groups, tiles that block.  Outside the hand-made example games, this is
@@ -40,7 +41,7 @@ def _same(a, b):
 
 
 def test_the_generator_still_makes_the_games_of_the_fixture():
-  assert len(DEFS) == random_tracks.N_GAMES == 32
+  assert len(DEFS) == random_tracks.N_GAMES + random_tracks.N_BIG == 40
   for k, d in enumerate(DEFS):
     gold = _gold(k)
     assert [''.join(chr(c) for c in row) for row in gold['art']] == d['art'], k
@@ -70,6 +71,20 @@ def test_generic_tier_gives_the_reference_engines_frames(k):
       assert np.array_equal(obs.layered_board.numpy(), gold['layered'][t + 1, n]), (n, t)
       assert _same(np.nan if reward is None else float(reward), gold['reward'][t, n]), (n, t)
       assert np.float32(discount) == gold['discount'][t, n] and not game.game_over
+
+
+def _walk_table(traced, actions):
+  """The tabulated game walked on the host: (reward, discount, done, render(t)) - through the
+  cell-indexed tables, or through the state table where the game runs from that (the wide tier)."""
+  from oracle.table_replay import StateWalker, TableWalker
+  B = actions.shape[1]
+  if traced.dense_reason is not None:
+    walker = StateWalker(traced, B)
+    want = walker.rollout(actions, reset_first=True)
+    return want, lambda t: walker.render(want['state'][t])
+  walker = TableWalker(traced, B)
+  want = walker.rollout(actions, reset_first=True)
+  return want, lambda t: walker.render(want['cells'][:, t].astype(np.int64))
 
 
 def _lowers(d):
@@ -107,18 +122,17 @@ def test_rule_lowering_run_by_the_c_oracle_gives_them_too(k):
 def test_the_table_tabulated_from_the_classes_gives_them_too(k):
   """Every game, its classes bound afresh - arbitrary Python classes to the engine, as a user's
   own are: tabulated (on lanes, many states per call), the table walked on the host."""
-  from oracle.table_replay import TableWalker
   gold = _gold(k)
   T, N = gold['actions'].shape
   traced = tabulate.trace(random_tracks.library_builder(DEFS[k], rebound=True)(), cache=False)
   assert tabulate.LAST_WALK[0].startswith('lanes: '), tabulate.LAST_WALK[0]
   assert [ord(c) for c in traced.chars] == gold['chars'].tolist()
-  walker = TableWalker(traced, N)
-  want = walker.rollout(gold['actions'], reset_first=True)
+  assert (traced.dense_reason is not None) == (k >= random_tracks.N_GAMES)       # the big boards
+  want, render = _walk_table(traced, gold['actions'])
   for name in ('reward', 'discount', 'done'):
     assert _same(want[name], gold[name]), name
   for t in range(T):
-    board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+    board, layered = render(t)
     assert np.array_equal(board, gold['board'][t + 1]), t
     assert np.array_equal(layered, gold['layered'][t + 1].astype(np.int8)), t
 
@@ -136,6 +150,7 @@ def test_hip_path_gives_the_reference_engines_frames(k, rebound):
   first, _, _ = game.its_showtime()
   assert game.fused is not None
   assert (game.fused.traced is not None) == (rebound or _lowers(DEFS[k]) is None)
+  assert (type(game.fused).__name__ == 'WideGame') == (k >= random_tracks.N_GAMES)     # the big boards
   assert [ord(c) for c in game.fused.chars] == gold['chars'].tolist()
   assert np.array_equal(first.board.cpu().numpy(), gold['board'][0])
   assert np.array_equal(first.layered_board.cpu().numpy(), gold['layered'][0].astype(np.int8))
@@ -158,7 +173,6 @@ def test_hip_path_gives_the_reference_engines_frames(k, rebound):
 def test_a_large_batch_of_every_track_against_the_lowering_on_the_host():
   """B = 4 096 random action streams per game: the HIP path against the C oracle (rule lowering)
   or the table walker (tabulated games) - whichever the fixture pinned above."""
-  from oracle.table_replay import TableWalker
   B, T = 4096, 40
   for k, d in enumerate(DEFS):
     build = random_tracks.library_builder(d)
@@ -174,10 +188,9 @@ def test_a_large_batch_of_every_track_against_the_lowering_on_the_host():
       assert _same(out['reward'].cpu().numpy(), ref['reward']), k
     else:
       traced = tabulate.trace(build(), cache=False)
-      walker = TableWalker(traced, B)
-      want = walker.rollout(actions, reset_first=True)
+      want, render = _walk_table(traced, actions)
       assert _same(out['reward'].cpu().numpy(), want['reward']), k
       for t in (0, T // 2, T - 1):
-        board, layered = walker.render(want['cells'][:, t].astype(np.int64))
+        board, layered = render(t)
         assert np.array_equal(out['board'][t].cpu().numpy(), board), (k, t)
         assert np.array_equal(out['obs'][t].cpu().numpy(), layered), (k, t)
