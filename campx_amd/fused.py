@@ -577,11 +577,13 @@ class FusedGame(object):
     `flush()`.  For callers whose next actions do not wait for those observations (open-loop
     action streams: random exploration, scripted or replayed episodes).
 
-    Where the library has no shared launch for the game or the sizes (two moving things, more
-    than 32 768 environments or ~2 GB of observations per rollout, batches whose frames are not
-    whole 16-byte chunks: `campx_update_render_shared`), the rollout is run whole at once -
-    deferring would only make its render read a trace gone cold - and `out` is simply complete
-    a call early.
+    Where the library has no shared launch for the game or the sizes (a multi-mover game without
+    its table or past its bounds, more than 32 768 environments or ~2 GB of observations per
+    rollout, batches whose frames are not whole 16-byte chunks: `campx_update_render_shared`),
+    the rollout is run whole at once - deferring would only make its render read a trace gone
+    cold - and `out` is simply complete a call early; unless `out` shares its observation buffer
+    with the previous call's dict, which the caller is about to read: then the update pass runs
+    now and the render kernel with the next call, as everywhere else.
 
     Args:
       actions: int tensor [T, B] of action ids.
@@ -613,14 +615,30 @@ class FusedGame(object):
       one_launch = self._shared_launch[T] = bool(
           (self.n_dyn == 1 or self._pair_table is not None) and
           _hip.lib.campx_update_render_shared(ctypes.byref(self.spec), self.batch, T))
+    head = (self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self._pair_table, ids,
+            out['reward'], out['discount'], out['done'], out['perf'], out['trace'],
+            self._bad if validate else None, self._bad_flag if validate else None,
+            bool(reset_first))
     if not one_launch or out['obs'].dtype != torch.int8:
-      # Nothing to gain from deferring (two movers, a batch or a rollout too big for the shared
-      # launch, 16-bit observations): the whole rollout now, rendered while its trace is still
+      # Nothing to gain from deferring (a game without its pair / tuple table, a batch or a rollout
+      # too big for the shared launch, 16-bit observations).
+      if prev is not None and prev['obs'].data_ptr() == out['obs'].data_ptr():
+        # ... but the two dicts share their observation buffer, and the caller reads the PREVIOUS
+        # rollout's observations from it after this call: this rollout's render has to wait for
+        # the next call, as the contract says (update pass now; render kernel then).  (Until round
+        # 5 this case rendered at once and handed back a dict whose observations were already the
+        # new rollout's - tests/test_random_warehouses.py found it.)
+        if not self._deferred_rendered:
+          self._render(self._spec_host, self._spec_dev, prev['trace'], prev['obs'], None)
+        self._aux_in_sync = False
+        self._update(*head)
+        self._deferred, self._deferred_rendered = out, False
+        self.frame = T if reset_first else self.frame + T
+        if validate:
+          self._after_launch()
+        return prev
+      # Separate observation buffers: the whole rollout now, rendered while its trace is still
       # cached.  `out` is complete a call early; what the caller sees is the same.
-      if (prev is not None and not self._deferred_rendered
-          and prev['obs'].data_ptr() == out['obs'].data_ptr()):
-        raise ValueError('the previous rollout still owes its observations to the buffer this '
-                         'one would overwrite at once: flush() and read them first')
       self.flush()
       if (out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
           self.batch > 8192 and (self.n_dyn >= 3 or self.batch < 32768)):
@@ -653,10 +671,6 @@ class FusedGame(object):
              and tuple(prev['trace'].shape) == tuple(out['trace'].shape))
     if prev is not None and not share:
       self.flush()
-    head = (self._spec_host, self._spec_dev, self.pos, self.done, self.ret, self._pair_table, ids,
-            out['reward'], out['discount'], out['done'], out['perf'], out['trace'],
-            self._bad if validate else None, self._bad_flag if validate else None,
-            bool(reset_first))
     if share:
       self._update_render(*(head + (prev['trace'], prev['obs'])))
     else:

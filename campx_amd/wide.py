@@ -141,6 +141,11 @@ class WideGame(fused.FusedGame):
     run whole, at once, and `out` is simply complete a call early; returns the previous call's
     dict (None on the first)."""
     prev = getattr(self, '_deferred', None)
+    if prev is not None and prev['obs'].data_ptr() == out['obs'].data_ptr():
+      raise ValueError('the state-table tier runs a deferred rollout whole, at once: two dicts over ONE '
+                       'observation buffer (rollout_buffers(T, share=...)) would hand back the previous '
+                       'rollout\'s dict with this rollout\'s observations in it - give each dict its own '
+                       'buffers (rollout_buffers(T) twice)')
     self.rollout(actions, out=out, reset_first=reset_first)
     self._deferred = out
     return prev

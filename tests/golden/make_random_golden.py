@@ -4,7 +4,7 @@ from the REFERENCE's own classes (examples/boat_race.py AgentDrape, DirectionalH
 campx.things.FixedDrape) and run on the reference's engine / renderer / Plot, imported from
 /root/reference where they lie (ref_harness).  Build container only:
 
-    python tests/golden/make_random_golden.py [tracks] [hellos]
+    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses]
 
 (`hellos`: tests/golden/random_hellos.npz, the family of tests/random_hellos.py from the Hello World
 notebook's own RollingDrape / SlidingSprite - see hellos() below.)
@@ -114,9 +114,58 @@ def hellos():
       random_hellos.N_GAMES, trails, quits, os.path.getsize(path) // 1024))
 
 
+def warehouses():
+  """tests/golden/random_warehouses.npz: tests/random_warehouses.py's sokoban levels - the
+  reference's AgentDrape + this repo's Box / Goal rules bound to the reference's `things`, on
+  the reference's engine."""
+  import random_warehouses
+  ref = mg.ref
+  T, N = 60, 8
+  out, pushes, ends = {}, 0, 0
+  for k, d in enumerate(random_warehouses.definitions()):
+    acts = mg.random_actions(8000 + k, T, N)
+    acts[:, 0] = np.random.RandomState(8100 + k).choice(4, size=T)            # one that never stays
+    runs = np.random.RandomState(8200 + k)
+    for n in (1, 2, 3):                                                        # three that keep going: pushes
+      t = 0
+      while t < T:
+        length = int(runs.randint(2, 6))
+        acts[t:t + length, n] = int(runs.randint(4))
+        t += length
+
+    def game(agent_cls, fixed_cls):
+      return lambda: random_warehouses.build(d, mg.to_game, mg.Partial, agent_cls, mg.R.BoxDrape,
+                                             mg.R.GoalDrape, fixed_cls)
+
+    golden = mg.run(game(ref.boat_race.AgentDrape, ref.things.FixedDrape), acts)
+    mg.assert_same(golden, mg.run(game(mg.R.AgentDrape, mg.R.FixedDrape), acts),
+                   'random warehouse {}: library agent'.format(k))
+    for name, value in golden.items():
+      out['k{}_{}'.format(k, name)] = value
+    out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
+    out['k{}_meta'.format(k)] = np.array(json.dumps(
+        dict(boxes=d['boxes'], z_order=d['z_order'], schedule=d['schedule']), sort_keys=True))
+    moved = 0
+    for ch in d['boxes']:
+      where = (golden['board'] == ord(ch)).reshape(T + 1, N, -1).argmax(-1)
+      moved += int((where[1:] != where[:-1]).sum())
+    pushes += moved
+    ends += int(golden['done'].sum())
+    print('warehouse {:2d} {}x{} boxes {!r:4} z {!r:7} groups {} pushes {} done {}'.format(
+        k, len(d['art']), len(d['art'][0]), d['boxes'], d['z_order'], d['schedule'], moved,
+        int(golden['done'].sum())))
+  assert pushes > 150 and ends >= 5, (pushes, ends)
+  path = os.path.join(HERE, 'random_warehouses.npz')
+  np.savez_compressed(path, **out)
+  print('{} levels, {} box moves, {} episode ends -> {} KiB'.format(
+      random_warehouses.N_GAMES, pushes, ends, os.path.getsize(path) // 1024))
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['tracks', 'hellos']
+  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses']
   if 'tracks' in which:
     main()
   if 'hellos' in which:
     hellos()
+  if 'warehouses' in which:
+    warehouses()

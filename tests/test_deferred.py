@@ -156,6 +156,55 @@ def test_two_buffer_sets_may_share_their_observations():
   assert np.array_equal(fused.flush()['obs'].cpu().numpy(), ref_prev['obs'])
 
 
+@pytest.mark.parametrize('build,kw,B', [(boat_race.build, {}, 1000), (boat_race.build, {}, 40000),
+                                        (sokoban.build, dict(level=2), 20000), (sokoban.build, {}, 40000)],
+                         ids=['ragged-frames', 'past-the-shared-launch', 'two-streams', 'two-movers-in-order'])
+def test_shared_observations_where_nothing_is_deferred(build, kw, B):
+  """Sizes and games `rollout_deferred()` has no shared launch for (frames that are not whole
+  16-byte chunks, more than 32 768 environments, the multi-mover games past their bounds): with
+  two dicts over ONE observation buffer the dict a call hands back must still hold the PREVIOUS
+  rollout's observations.  Until round 5 these cases rendered the new rollout at once - into the
+  buffer the caller was about to read (found by tests/test_random_warehouses.py)."""
+  T = 12
+  game = build(batch=B, device='cuda', **kw)
+  game.its_showtime()
+  fused = game.fused
+  og = cpu.OracleGame.from_description(gamespec.describe(build(**kw)))
+  rng = np.random.RandomState(B)
+  first = fused.rollout_buffers(T)
+  sets = [first, fused.rollout_buffers(T, share=first)]
+  ref_prev = None
+  for call in range(5):
+    actions = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+    ref = og.rollout(actions, reset_first=(call == 0))
+    prev = fused.rollout_deferred(torch.from_numpy(actions).cuda(), sets[call & 1], reset_first=(call == 0))
+    # this call's scalars are there at once, the previous call's observations now
+    assert np.array_equal(sets[call & 1]['reward'].cpu().numpy().view(np.uint32), ref['reward'].view(np.uint32))
+    if prev is not None:
+      assert prev is sets[(call - 1) & 1]
+      assert np.array_equal(prev['obs'].cpu().numpy(), ref_prev['obs']), call
+    ref_prev = ref
+  assert np.array_equal(fused.flush()['obs'].cpu().numpy(), ref_prev['obs'])
+
+
+def test_tiers_that_run_deferred_rollouts_whole_refuse_a_shared_observation_buffer():
+  from campx_amd.games import hello_world, maze
+  for game, n_actions in ((maze.build(16, 16, batch=256, device='cuda'), 5),
+                          (hello_world.make_game(batch=256, device='cuda')[0], 4)):
+    if game.fused is None:
+      game.its_showtime()
+    T = 8
+    first = game.rollout_buffers(T)
+    acts = torch.randint(0, n_actions, (T, 256), dtype=torch.int8, device='cuda')
+    assert game.rollout_deferred(acts, first, reset_first=True) is None
+    with pytest.raises(ValueError, match='would hand back the previous'):
+      game.rollout_deferred(acts, game.rollout_buffers(T, share=first))
+    own = game.rollout_buffers(T)
+    kept = first['obs'].clone()
+    assert game.rollout_deferred(acts, own) is first and torch.equal(first['obs'], kept)
+    assert game.flush() is own
+
+
 def test_the_entry_point_runs_the_passes_one_after_the_other_when_it_must():
   # B = 1000: frames of 175 000 bytes, not whole 16-byte chunks - rollout_deferred() would not
   # defer at all; campx_update_render_launch itself (C callers) issues update, then render
