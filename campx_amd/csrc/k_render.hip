@@ -163,7 +163,12 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     const uint32_t hi = __umulhi(rp.m, off);
     const uint32_t row = (((off - hi) >> rp.sh1) + hi) >> rp.sh2;  // off / R
     int k = (int)(off - row * rp.R);                                 // off % R
-    if (kOdd && off >= 0xfffffff0u) k = R - (int)(0u - off);         // starts 1..15 bytes before the frame
+    // a chunk that starts 1..15 bytes before the frame: with frames that are not whole chunks, and
+    // (round 5) with 16-bit observations of frames that are whole 8-element stores but not whole
+    // 16-byte chunks of the IMAGE (B * R = 8 mod 16: boat race at B = 1 000) - every other frame
+    // then starts 8 image bytes into a scenery chunk, and `off % R` of the wrapped offset put
+    // another part of the row in the frame's first 8 elements
+    if ((kOdd || kFmt != 0) && off >= 0xfffffff0u) k = R - (int)(0u - off);
     scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
   }
   // the scenery layer of two cells per lane (kBoard needs none of it)

@@ -1,0 +1,163 @@
+"""Random SEQUENCES of calls on one batched engine - play(), rollout() with and without a reset,
+with a flat board, keeping only the last frame, 16-bit observations, reused buffers, the two-stream
+form, deferred rollouts over own and shared observation buffers, flush() - against the C oracle
+fed the same actions in the same order (state carried from call to call: positions, game-over
+flags, episode returns; an environment whose episode ended is rebuilt before its next action).
+Every tier: one-cell (one, two, three movers; batches on both sides of the one-launch rollout's
+bound), state table, shapes.  Seeded."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from campx_amd import gamespec
+from campx_amd.games import boat_race, hello_world, maze, sokoban, wall_world
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+  a, b = np.asarray(a), np.asarray(b)
+  if a.dtype.kind == 'f' or b.dtype.kind == 'f':
+    return np.array_equal(a.astype(np.float32).view(np.uint32), b.astype(np.float32).view(np.uint32)) or \
+        np.array_equal(a.astype(np.float32), b.astype(np.float32), equal_nan=True)
+  return np.array_equal(a, b)
+
+
+GAMES = {
+    'boat_race': (boat_race.build, {}, 5),
+    'wall_world': (wall_world.build, {}, 5),
+    'sokoban': (sokoban.build, {}, 5),
+    'sokoban_l1': (sokoban.build, dict(level=1), 5),
+    'maze_16x16': (lambda **kw: maze.build(16, 16, **kw), {}, 5),
+    'hello_world': (hello_world.build, {}, 5),
+}
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_SEQ_SEEDS', '8'))))
+@pytest.mark.parametrize('name', sorted(GAMES))
+def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
+  build, kw, n_actions = GAMES[name]
+  rng = np.random.RandomState(1000 * seed + len(name))
+  B = int(rng.choice([7, 8, 64, 1000, 1002, 4096, 9000, 9008]))
+  game = build(batch=B, device='cuda', **kw)
+  first, _, _ = game.its_showtime()
+  f = game.fused
+  one_cell = type(f).__name__ == 'FusedGame'
+  og = cpu.OracleGame.from_description(gamespec.describe(build(**kw)))
+  obs0, board0 = og.first_frame()
+  assert np.array_equal(first.layered_board.cpu().numpy()[0], obs0.astype(np.int8))
+  kept = {}                      # T -> buffers reused across calls
+  fresh = True                   # nothing played yet: the first action needs no reset either way
+  log = []
+
+  def actions(T):
+    return rng.randint(0, n_actions, size=(T, B)).astype(np.int8)
+
+  def check(out, ref, what, obs=True, board=False, last_only=False):
+    log.append(what)
+    if obs and not last_only:
+      assert _same(out['obs'].cpu().numpy(), ref['obs']), log
+    if last_only:
+      assert _same(out['obs'].cpu().numpy().reshape(ref['obs'][-1].shape), ref['obs'][-1]), log
+    if board:
+      assert _same(out['board'].cpu().numpy(), ref['board']), log
+    for k in ('reward', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (log, k)
+
+  for step in range(14):
+    op = rng.choice(['play', 'play', 'rollout', 'rollout', 'rollout-reset', 'rollout-board', 'rollout-out',
+                     'rollout-last', 'rollout-f16', 'pipelined', 'deferred', 'deferred-shared'])
+    if op == 'play':
+      for _ in range(int(rng.randint(1, 4))):
+        a = actions(1)
+        obs, reward, discount = game.play(torch.from_numpy(a[0]))
+        ref = og.rollout(a, reset_first=False)
+        log.append('play')
+        assert _same(obs.layered_board.cpu().numpy(), ref['obs'][0]), log
+        assert _same(obs.board.cpu().numpy(), ref['board'][0]), log
+        assert _same(reward.cpu().numpy(), ref['reward'][0]), log
+        assert _same(discount.cpu().numpy(), ref['discount'][0]), log
+      continue
+    T = int(rng.choice([1, 5, 16, 23, 40]))
+    a = actions(T)
+    dev = torch.from_numpy(a).cuda()
+    if op in ('rollout', 'rollout-reset', 'rollout-board'):
+      reset = op == 'rollout-reset'
+      out = game.rollout(dev, reset_first=reset, want_board=(op == 'rollout-board'))
+      check(out, og.rollout(a, reset_first=reset), '%s T=%d' % (op, T), board=(op == 'rollout-board'))
+    elif op == 'rollout-out':
+      out = kept.setdefault(T, game.rollout_buffers(T))
+      got = game.rollout(dev, out=out)
+      assert got['obs'] is out['obs']
+      check(out, og.rollout(a, reset_first=False), 'rollout out= T=%d' % T)
+    elif op == 'rollout-last':
+      out = game.rollout(dev, keep_obs=False)
+      check(out, og.rollout(a, reset_first=False), 'rollout keep_obs=False T=%d' % T, obs=False, last_only=True)
+    elif op == 'rollout-f16':
+      dt = torch.float16 if rng.rand() < 0.5 else torch.bfloat16
+      out = game.rollout(dev, obs_dtype=dt)
+      assert out['obs'].dtype == dt
+      ref = og.rollout(a, reset_first=False)
+      log.append('rollout %s T=%d' % (dt, T))
+      assert _same(out['obs'].float().cpu().numpy(), ref['obs'].astype(np.float32)), log
+      assert _same(out['reward'].cpu().numpy(), ref['reward']), log
+    elif op == 'pipelined':
+      if not one_cell:
+        continue
+      bufs = [f.rollout_buffers(T), f.rollout_buffers(T)]
+      refs = []
+      streams = [actions(T) for _ in range(3)]
+      for i, s in enumerate(streams):
+        f.rollout(torch.from_numpy(s).cuda(), out=bufs[i & 1], pipelined=True)
+        refs.append(og.rollout(s, reset_first=False))
+        if i >= 1:                # (a buffer set is the caller's again once the NEXT call was issued)
+          check(bufs[(i - 1) & 1], refs[i - 1], 'pipelined %d T=%d' % (i - 1, T))
+      torch.cuda.synchronize()
+      check(bufs[(len(streams) - 1) & 1], refs[-1], 'pipelined last T=%d' % T)
+    else:
+      shared = op == 'deferred-shared' and one_cell
+      one = game.rollout_buffers(T)
+      bufs = [one, game.rollout_buffers(T, share=one) if shared else game.rollout_buffers(T)]
+      refs = []
+      n = int(rng.randint(1, 5))
+      for i in range(n):
+        s = actions(T)
+        prev = game.rollout_deferred(torch.from_numpy(s).cuda(), bufs[i & 1])
+        refs.append(og.rollout(s, reset_first=False))
+        assert (prev is None) == (i == 0), log
+        assert _same(bufs[i & 1]['reward'].cpu().numpy(), refs[i]['reward']), (log, 'deferred scalars', i)
+        if prev is not None:
+          assert prev is bufs[(i - 1) & 1]
+          check(prev, refs[i - 1], 'deferred%s %d/%d T=%d' % (' shared' if shared else '', i - 1, n, T))
+      if rng.rand() < 0.5 or not one_cell:
+        check(game.flush(), refs[-1], 'flush T=%d' % T)
+      else:
+        # not flushed: the next call of any kind must leave the owed observations right, or
+        # render them first - play() reads and writes the engine's own frame buffer only
+        a1 = actions(1)
+        obs, reward, _ = game.play(torch.from_numpy(a1[0]))
+        ref1 = og.rollout(a1, reset_first=False)
+        log.append('play after deferred')
+        assert _same(obs.layered_board.cpu().numpy(), ref1['obs'][0]), log
+        check(game.flush(), refs[-1], 'late flush T=%d' % T)
+
+  # ... and the per-frame hand-off in the policy network's dtype (one-cell tier, table games)
+  if one_cell and f.uses_table:
+    dt = torch.float16 if rng.rand() < 0.5 else torch.bfloat16
+    f.set_play_obs_dtype(dt)
+    for _ in range(3):
+      a = actions(1)
+      obs, reward, _ = game.play(torch.from_numpy(a[0]))
+      ref = og.rollout(a, reset_first=False)
+      log.append('play %s' % dt)
+      assert obs.layered_board.dtype == dt
+      assert _same(obs.layered_board.float().cpu().numpy(), ref['obs'][0].astype(np.float32)), log
+      assert _same(reward.cpu().numpy(), ref['reward'][0]), log
+    f.set_play_obs_dtype(torch.int8)
+    a = actions(1)
+    obs, _, _ = game.play(torch.from_numpy(a[0]))
+    assert _same(obs.layered_board.cpu().numpy(), og.rollout(a, reset_first=False)['obs'][0]), log

@@ -497,11 +497,15 @@ def test_sixteen_bit_observations(name, dtype, golden):
 
 
 @pytest.mark.parametrize('name,batch', [('boat_race', 5), ('boat_race', 1001), ('sokoban', 63),
-                                        ('sokoban_l2', 77), ('wall_world', 3)])
+                                        ('sokoban_l2', 77), ('wall_world', 3), ('boat_race', 1000),
+                                        ('boat_race', 8), ('wall_world', 1), ('wall_world', 77)])
 def test_sixteen_bit_observations_at_odd_batch_sizes(name, batch):
   """Frames that are not whole 16-byte chunks (batch * L*H*W odd multiples): the render
   kernel's chunks straddle frames; across two launches so that a launch boundary falls
-  mid-chunk too."""
+  mid-chunk too.  And frames of 8 (mod 16) elements - boat race at B = 1 000 or 8: whole 16-byte
+  stores of 16-bit elements, but every other frame starts in the middle of a 16-byte chunk of
+  the image (tests/test_api_sequences.py found the first 8 elements of those frames wrong; the
+  sokoban cases of this class passed by luck - zeros either way)."""
   rng = np.random.RandomState(batch)
   game, _ = _fused(name, batch)
   og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES[name]()))
