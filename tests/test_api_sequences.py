@@ -35,9 +35,17 @@ GAMES = {
     'maze_16x16': (lambda **kw: maze.build(16, 16, **kw), {}, 5),
     'hello_world': (hello_world.build, {}, 5),
 }
+# more of the shape tier (eight things and quits; a 16x24 board with a static drape; two drapes on
+# 13x36 from the random family) and a two-box sokoban on 16x16 (state table enumerated on the device)
+import shape_zoo  # noqa: E402
+import random_hellos  # noqa: E402
+GAMES['zoo1'] = (shape_zoo.library_builders()['shape_zoo1'], {}, 5)
+GAMES['zoo3'] = (shape_zoo.library_builders()['shape_zoo3'], {}, 5)
+GAMES['random_hello3'] = (random_hellos.library_builder(random_hellos.definitions()[3]), {}, 5)
+GAMES['sokoban_l3'] = (sokoban.build, dict(level=3), 5)
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_SEQ_SEEDS', '8'))))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_SEQ_SEEDS', '6'))))
 @pytest.mark.parametrize('name', sorted(GAMES))
 def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
   build, kw, n_actions = GAMES[name]
