@@ -65,8 +65,27 @@ def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
   def actions(T):
     return rng.randint(0, n_actions, size=(T, B)).astype(np.int8)
 
+  # the episode return every environment carries (CampxState.ret: what bench.py's return log
+  # gathers), accumulated here from the oracle's rewards: restarted by the frame that follows an
+  # episode's end, NaN (the reference's None) counted as 0
+  carried = dict(ret=np.zeros(B, np.float32), over=np.ones(B, bool))
+
+  oracle_rollout = og.rollout
+
+  def accounted(actions, reset_first=False):
+    if reset_first:
+      carried['over'][:] = True
+    ref = oracle_rollout(actions, reset_first=reset_first)
+    pending.append(ref)
+    return ref
+
+  pending = []
+  og.rollout = accounted
+
   def check(out, ref, what, obs=True, board=False, last_only=False):
     log.append(what)
+    if out.get('perf') is not None and ref.get('perf') is not None:
+      assert _same(out['perf'].cpu().numpy(), ref['perf']), (log, 'perf')
     if obs and not last_only:
       assert _same(out['obs'].cpu().numpy(), ref['obs']), log
     if last_only:
@@ -76,7 +95,21 @@ def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
     for k in ('reward', 'discount', 'done'):
       assert _same(out[k].cpu().numpy(), ref[k]), (log, k)
 
+  def settle():
+    torch.cuda.synchronize()
+    while pending:
+      ref = pending.pop(0)
+      last = not pending
+      for t in range(ref['reward'].shape[0]):
+        r = np.where(np.isnan(ref['reward'][t]), np.float32(0), ref['reward'][t]).astype(np.float32)
+        carried['ret'] = (np.where(carried['over'], np.float32(0), carried['ret']) + r).astype(np.float32)
+        carried['over'] = ref['done'][t] != 0
+      if last and hasattr(f, 'ret') and f.ret is not None:
+        assert _same(f.ret.cpu().numpy(), carried['ret']), (log, 'episode returns')
+        assert np.array_equal(f.done.cpu().numpy() != 0, carried['over']), (log, 'game-over flags')
+
   for step in range(14):
+    settle()
     op = rng.choice(['play', 'play', 'rollout', 'rollout', 'rollout-reset', 'rollout-board', 'rollout-out',
                      'rollout-last', 'rollout-f16', 'pipelined', 'deferred', 'deferred-shared'])
     if op == 'play':
@@ -152,6 +185,9 @@ def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
         log.append('play after deferred')
         assert _same(obs.layered_board.cpu().numpy(), ref1['obs'][0]), log
         check(game.flush(), refs[-1], 'late flush T=%d' % T)
+
+  settle()
+  assert not pending and len(log) >= 10
 
   # ... and the per-frame hand-off in the policy network's dtype (one-cell tier, table games)
   if one_cell and f.uses_table:
