@@ -35,6 +35,10 @@ import subprocess
 import sys
 import time
 
+# (the pool's host driver only supports dmabuf IPC: without this RCCL between processes fails with
+# hipIpcGetMemHandle: invalid argument; the image exports it, a rank launched from elsewhere might not)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
   sys.path.insert(0, REPO)
