@@ -18,6 +18,8 @@ echo "# frac = algorithmic bytes per env-step x B x T / HIP-event time per launc
 bash tools/gpu_sweep.sh boat_race "1000 4096 16384 65535 65536 100000 100001 200000 499984 524288" "100"
 bash tools/gpu_sweep.sh boat_race "65536" "16 64 400 1000 4000"
 bash tools/gpu_sweep.sh wall_world "1000 16384 65536 262143 262144 524288" "100"
-bash tools/gpu_sweep.sh sokoban "1000 16384 65536 99999 131071 131072 262144 524288" "100"
-bash tools/gpu_sweep.sh sokoban_l2 "16384 131072" "100"
+bash tools/gpu_sweep.sh sokoban "1000 4096 8192 16384 65536 99999 131071 131072 262144 524288" "100"
+bash tools/gpu_sweep.sh sokoban_l1 "4096 8192" "100"
+bash tools/gpu_sweep.sh sokoban_l2 "8192 16384 131072" "100"
+bash tools/gpu_sweep.sh hello_world "4096 16384 32768 65536" "100"
 } | tee gpurun_out/$1/sweep.txt
