@@ -110,7 +110,7 @@ def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
 
   for step in range(14):
     settle()
-    op = rng.choice(['play', 'play', 'rollout', 'rollout', 'rollout-reset', 'rollout-board', 'rollout-out',
+    op = rng.choice(['play', 'play', 'play-forms', 'rollout', 'rollout', 'rollout-reset', 'rollout-board', 'rollout-out',
                      'rollout-last', 'rollout-f16', 'pipelined', 'deferred', 'deferred-shared'])
     if op == 'play':
       for _ in range(int(rng.randint(1, 4))):
@@ -122,6 +122,50 @@ def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
         assert _same(obs.board.cpu().numpy(), ref['board'][0]), log
         assert _same(reward.cpu().numpy(), ref['reward'][0]), log
         assert _same(discount.cpu().numpy(), ref['discount'][0]), log
+      continue
+    if op == 'play-forms':
+      # the other forms an action may take: one-hot floats [B, 5] (the reference's format,
+      # examples/boat_race.py:154-184), int64 ids, a Python list of ids, ONE one-hot vector or ONE
+      # id for every environment, and - unchecked - ids outside 0..4, which act as "stay"
+      form = rng.choice(['onehot', 'int64', 'list', 'one-vector', 'one-id', 'outside'])
+      if type(f).__name__ == 'ShapeGame' and form in ('onehot', 'one-vector'):
+        form = 'int64'           # (the Hello World kind takes integer ids, as its notebook passes them)
+      a = actions(1)
+      sent = torch.from_numpy(a[0])
+      if form == 'onehot':
+        sent = torch.eye(5)[torch.from_numpy(a[0]).long()]
+      elif form == 'int64':
+        sent = torch.from_numpy(a[0]).long().cuda()
+      elif form == 'list':
+        sent = [int(x) for x in a[0]]
+        if B == 5:
+          sent = torch.tensor(sent)
+      elif form == 'one-vector':
+        a[0, :] = a[0, 0]
+        sent = torch.eye(5)[int(a[0, 0])]
+      elif form == 'one-id':
+        a[0, :] = a[0, 0]
+        sent = int(a[0, 0])
+      else:
+        if n_actions != 5 or not one_cell:
+          continue
+        raw = a[0].copy()
+        raw[rng.rand(B) < 0.3] = int(rng.choice([5, 9, 100, -1, -128]))
+        a[0] = np.where((raw < 0) | (raw > 4), 4, raw)
+        sent = torch.from_numpy(raw)
+        f.validate_actions = False
+      obs, reward, discount = game.play(sent)
+      f.validate_actions = True
+      if form == 'outside':            # (counted: the next look would raise; take the count back)
+        torch.cuda.synchronize()
+        f._bad.zero_()
+        if hasattr(f, '_bad_flag') and f._bad_flag is not None:
+          f._bad_flag.zero_()
+      ref = og.rollout(a, reset_first=False)
+      log.append('play ' + form)
+      assert _same(obs.layered_board.cpu().numpy(), ref['obs'][0]), log
+      assert _same(reward.cpu().numpy(), ref['reward'][0]), log
+      assert _same(discount.cpu().numpy(), ref['discount'][0]), log
       continue
     T = int(rng.choice([1, 5, 16, 23, 40]))
     a = actions(T)
