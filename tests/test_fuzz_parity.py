@@ -245,6 +245,72 @@ def test_random_big_boards(seed):
     assert _same(discount.cpu().numpy(), ref['discount'][t])
 
 
+def random_big_warehouse(rng):
+  """A sokoban level of one or two boxes on a random walled board of 132 to 240 cells: a multi-mover
+  rule game above 128 cells - its states (10^4 to 10^6) are enumerated on the device by the rules
+  themselves (campx_amd/enumerate_states.py), the state table runs on the wide tier."""
+  H, W = int(rng.randint(9, 15)), int(rng.randint(11, 19))
+  while not 132 <= H * W <= 240:
+    H, W = int(rng.randint(9, 15)), int(rng.randint(11, 19))
+  art = np.full((H, W), ' ', dtype='<U1')
+  art[0, :] = art[-1, :] = '#'
+  art[:, 0] = art[:, -1] = '#'
+  inner = art[1:-1, 1:-1]
+  inner[rng.rand(H - 2, W - 2) < 0.15] = '#'
+  free = list(zip(*np.where(art == ' ')))
+  rng.shuffle(free)
+  boxes = 'XY'[:int(rng.randint(1, 3))]
+  r, c = free.pop()
+  art[r, c] = 'A'
+  beside = [q for q in free if abs(q[0] - r) + abs(q[1] - c) == 1]
+  for i, ch in enumerate(boxes):
+    spot = beside.pop() if (i == 0 and beside) else free.pop()
+    if spot in free:
+      free.remove(spot)
+    art[spot] = ch
+  art[free.pop()] = 'G'
+  rows = [''.join(x) for x in art]
+
+  def build(batch=None, device=None):
+    drapes = {'#': rules.FixedDrape, 'A': Partial(rules.AgentDrape, blocking_chars='#' + boxes),
+              'G': Partial(rules.GoalDrape, agent_char='A', step_reward=-1, goal_reward=50)}
+    for ch in boxes:
+      drapes[ch] = Partial(rules.BoxDrape, agent_char='A',
+                           blocking_chars='#' + ''.join(b for b in boxes if b != ch))
+    return ascii_art_to_game(rows, what_lies_beneath=' ', drapes=drapes,
+                             update_schedule=[list(boxes), ['A', 'G', '#']], z_order='G' + boxes + 'A#',
+                             batch=batch, device=device)
+  return build, rows
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('CAMPX_FUZZ_WAREHOUSE_SEEDS', '5'))))
+def test_random_big_warehouses(seed):
+  """Device-enumerated state tables of random multi-mover levels against the C oracle: actions that
+  keep going (pushes), two launches with the state carried, then play()."""
+  from campx_amd import wide
+  rng = np.random.RandomState(8000 + seed)
+  build, rows = random_big_warehouse(rng)
+  batch = int(rng.choice([7, 257, 2048]))
+  game = build(batch=batch, device='cuda')
+  first, _, _ = game.its_showtime()
+  assert isinstance(game.fused, wide.WideGame) and game.fused.n_dyn >= 2, rows
+  og = cpu.OracleGame.from_description(gamespec.describe(build()))
+  for launch, T in enumerate([int(rng.randint(20, 60)), int(rng.randint(1, 120))]):
+    actions = np.repeat(rng.randint(0, 5, size=((T + 3) // 4, batch)), 4, axis=0)[:T].astype(np.int8)
+    out = game.rollout(torch.from_numpy(actions), want_board=True)
+    ref = og.rollout(actions, reset_first=(launch == 0))
+    for k in ('obs', 'board', 'reward', 'discount', 'done'):
+      assert _same(out[k].cpu().numpy(), ref[k]), (rows, batch, T, k)
+  moved = sum(len(set((ref['board'][:, 0] == ord(ch)).reshape(ref['board'].shape[0], -1).argmax(1).tolist())) > 1
+              for ch in 'XY')
+  acts = rng.randint(0, 5, size=(5, batch)).astype(np.int8)
+  ref = og.rollout(acts)
+  for t in range(5):
+    obs, reward, discount = game.play(torch.from_numpy(acts[t]))
+    assert _same(obs.layered_board.cpu().numpy(), ref['obs'][t]), (rows, batch, t)
+    assert _same(reward.cpu().numpy(), ref['reward'][t]), (rows, batch, t)
+
+
 def random_python_game(rng):
   """A random game of plain Python classes (tests/traced_games.py: a walker whose tiles change
   the frame's discount and end the episode, plus up to two coins that vanish when collected)
