@@ -429,6 +429,14 @@ void rollout_pipelined(const Tensor& spec_host, const Tensor& spec_dev, Tensor& 
   }
   // the side stream runs ahead of the caller's without bound; what it may not do is overwrite a
   // trace buffer whose last render is still running
+  if (p.readers.size() >= 64 && !p.readers.count(upd.trace)) {
+    // (a caller that allocates new buffers for every rollout: the events of buffers long gone are
+    // let go - behind one wait for everything the caller's stream holds, which covers them all)
+    hip_ok(hipEventRecord(p.synced, main), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(p.side, p.synced, 0), "hipStreamWaitEvent");
+    for (auto& kept : p.readers) (void)hipEventDestroy(kept.second);
+    p.readers.clear();
+  }
   hipEvent_t& reader = p.readers[upd.trace];
   if (reader && !resync) hip_ok(hipStreamWaitEvent(p.side, reader, 0), "hipStreamWaitEvent");
   check_ok(campx_update_launch(g.spec_host, g.spec_dev, g.state,

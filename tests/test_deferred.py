@@ -298,3 +298,24 @@ def test_engine_level_calls_on_tiers_without_a_shared_launch(tier):
     want_prev = want['obs'].clone()
   assert torch.equal(a.flush()['obs'], want_prev)
   assert a.flush() is None
+
+
+def test_the_two_stream_form_with_new_buffers_for_every_rollout():
+  """campx::rollout_pipelined keeps an event per trace buffer it has seen (the update pass may
+  not overwrite a trace its last render still reads); a caller that allocates new buffers for
+  every rollout used to grow that table without bound - now it is let go of, behind one wait,
+  once it holds 64.  150 rollouts into fresh buffers, against the oracle."""
+  B, T = 20000, 6
+  game = sokoban.build(level=1, batch=B, device='cuda')
+  game.its_showtime()
+  og = cpu.OracleGame.from_description(gamespec.describe(sokoban.build(level=1)))
+  rng = np.random.RandomState(0)
+  keep = []
+  for i in range(150):
+    a = rng.randint(0, 5, size=(T, B)).astype(np.int8)
+    out = game.fused.rollout_buffers(T)
+    game.fused.rollout(torch.from_numpy(a).cuda(), out=out, pipelined=True)
+    ref = og.rollout(a, reset_first=False)
+    keep = (keep + [out])[-3:]
+    if i % 10 == 0 or i > 140:
+      assert np.array_equal(out['obs'].cpu().numpy(), ref['obs']), i
