@@ -536,6 +536,9 @@ class FusedGame(object):
       # overwrite a trace buffer that a render on the main stream is still reading (with two
       # alternating buffer sets: the render of two calls ago).
       trace_key = out['trace'].data_ptr()
+      if len(self._trace_readers) >= 64 and trace_key not in self._trace_readers:
+        self._aux.wait_stream(main)      # (new buffers every call: let the old events go)
+        self._trace_readers.clear()
       reader = self._trace_readers.get(trace_key)
       if reader is not None:
         self._aux.wait_event(reader)
