@@ -331,6 +331,8 @@ class Engine(object):
             traced = tabulate.trace(self)
           except tabulate.TabulationError as other:
             raise ValueError('{} (and {})'.format(refusal, other))
+          except Exception:        # noqa: BLE001 - a set-up the classes themselves trip over (a rule
+            raise refusal          # naming a character the game does not have): the lowering said it best
     self._showtime = True
     self._update_groups = [(name, self._update_groups[name])
                            for name in sorted(self._update_groups.keys())]
