@@ -464,24 +464,35 @@ __device__ __forceinline__ uint32_t wrap_add(uint32_t a, uint32_t d, uint32_t n)
   return t >= n ? t - n : t;
 }
 
-// The update pass: one lane per environment, one wave per workgroup (its 64 environments' trail
-// words in LDS: [S * H][64] uint64, 8 * S * H * 64 bytes of dynamic shared memory).
+// The update pass: one lane per environment, 64 environments per workgroup (their trail words in
+// LDS: [S * H][64] uint64, 8 * S * H * 64 bytes of dynamic shared memory per wave).
+// A workgroup is blockDim.x / 64 REPLICAS of that wave (round 5, late): every replica walks the
+// whole chain of its 64 environments - the offsets, the trail words in an LDS copy of its own -
+// and writes only ITS share of what the pass produces: replica r the frames and the keyframe of
+// the key intervals k with k % replicas == r; replica 0 the state at the end.  What a frame costs
+// a wave (Hello World, B = 4 096, T = 100, one replica: 78 us) is mostly what it WRITES - the
+// keyframes 28 us, the trace and scalar rows 13 us, the trail painting 11 us, everything else
+// 26 us - and a second wave that repeats the cheap part to take half of the expensive one is the
+// whole hand-over: no ring, no barrier, no flag (profiles/r05_shape_rocprofv3.txt).
 // KS: the number of trail sprites when it is 0, 1 or 2 (loops unrolled, per-sprite constants in
 // registers), -1: whatever pp.n_trail says.
+constexpr int kShapeMaxReplicas = 4;
 template <int KS>
-__global__ __launch_bounds__(kWave) void shape_update_split_kernel(
+__global__ __launch_bounds__(kWave * kShapeMaxReplicas) void shape_update_split_kernel(
     ShapeParams sp, ShapeSplitParams pp, const CampxShapeSpec* __restrict__ spec, CampxState st,
     uint64_t* __restrict__ state_words, const int8_t* __restrict__ actions, CampxOutputs out,
     uint32_t* __restrict__ trace, uint64_t* __restrict__ keys, int64_t B, int32_t T, int32_t reset_first) {
   // this wave's 64 environments' trail words, laid out as the keyframes are: [64][S][H]
-  extern __shared__ __attribute__((aligned(16))) uint64_t trail[];
+  extern __shared__ __attribute__((aligned(16))) uint64_t all_trails[];
   __shared__ ShapeAction act[CAMPX_N_ACTIONS];   // (indexed by a lane's action: LDS, not kernarg)
-  const int lane = threadIdx.x;
-  if (lane < CAMPX_N_ACTIONS) act[lane] = sp.act[lane];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int replica = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), replicas = (int)(blockDim.x >> 6);
+  if (threadIdx.x < CAMPX_N_ACTIONS) act[threadIdx.x] = sp.act[threadIdx.x];
   const int64_t env0 = (int64_t)blockIdx.x * kWave;
   const int64_t env = env0 + lane;
   const bool live = env < B;
   const int H = sp.rows, W = sp.cols, N = sp.n_things, S = KS >= 0 ? KS : pp.n_trail, SH = S * H;
+  uint64_t* const trail = all_trails + (size_t)replica * SH * kWave;      // this replica's copy
   const int64_t n_words = (B - env0 < kWave ? B - env0 : (int64_t)kWave) * SH;
   // (the carried trail words: shape_words_from_backdrop_kernel made them from the backdrop state)
   for (int i = lane; i < SH * kWave; i += kWave)
@@ -573,7 +584,9 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
         if (e.flags & 1u) over = 1;   // plot.py:183-184 (discount 0 on that frame)
       }
       if (S > 0) paint_trails();
-      if (live) {
+      // (this replica's share: the frames and the keyframe of every `replicas`-th key interval)
+      const bool mine = (t / kShapeKey) % replicas == replica;
+      if (live && mine) {
         const int64_t at = (int64_t)t * B + env;
         trace[at] = orow[0] | rebuilt;
         trace[plane + at] = orow[1];
@@ -588,7 +601,7 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
         if (out.discount) out.discount[at] = over ? 0.0f : 1.0f;
         if (out.done) out.done[at] = (uint8_t)over;
       }
-      if (S > 0 && t % kShapeKey == 0) {
+      if (S > 0 && t % kShapeKey == 0 && mine) {
         // keyframe: this wave's 64 environments x S * H words, contiguous in [key][B][S][H]
         uint64_t* to = keys + ((int64_t)(t / kShapeKey) * B + env0) * SH;
         for (int i0 = 0; i0 < n_words; i0 += 8 * kWave) {       // (eight LDS reads in flight)
@@ -607,6 +620,7 @@ __global__ __launch_bounds__(kWave) void shape_update_split_kernel(
       }
     }
   }
+  if (replica != 0) return;         // (every replica ends in the same state: one writes it down)
   if (live) {
 #pragma unroll
     for (int k = 0; k < CAMPX_SHAPE_MAX_THINGS; ++k)
@@ -1014,7 +1028,20 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
   pp.by_sh = make_div((uint32_t)(pp.n_trail * H > 0 ? pp.n_trail * H : 1));
   pp.B = B;
   pp.max_pairs = shape_max_pairs(s);
-  const size_t lds = (size_t)8 * pp.n_trail * H * kWave;
+  // replicas of an update wave (see the kernel): 4, fewer where four copies of the trail words do
+  // not fit the 64 KiB a workgroup may ask for; CAMPX_SHAPE_REPLICAS overrides (1: round 5's first form)
+  static const int want_replicas = [] {
+    const char* v = getenv("CAMPX_SHAPE_REPLICAS");
+    const int n = v && *v ? atoi(v) : kShapeMaxReplicas;
+    return n < 1 ? 1 : (n > kShapeMaxReplicas ? kShapeMaxReplicas : n);
+  }();
+  const size_t lds_one = (size_t)8 * pp.n_trail * H * kWave;
+  // (Hello World, T = 100, of peak, 1 / 2 / 4 replicas: B = 4 096 0.507 / 0.533 / 0.545, 16 384 0.745 /
+  // 0.757 / 0.765, 32 768 0.801 / 0.802 / 0.808, 65 536 0.830 / 0.833 / 0.79-0.81: past 512 workgroups
+  // four waves each cost more than they take off the chain - two there)
+  int replicas = (B + kWave - 1) / kWave > 512 && want_replicas > 2 ? 2 : want_replicas;
+  while (replicas > 1 && lds_one * replicas > 60 * 1024) --replicas;
+  const size_t lds = lds_one * replicas;
   const size_t render_lds = shape_render_lds(s);
   // the trail words at the ends of the launch (and of every chunk) sit behind a full chunk's keyframes
   const int32_t chunk = shape_chunk_frames(B, T);
@@ -1054,7 +1081,7 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
     pp.shift_base = (uint32_t)(reinterpret_cast<uintptr_t>(part.obs) & (kSplitSpan - 1u));
     const int32_t fresh = t0 == 0 ? reset_first : 0;
 #define CAMPX_SHAPE_UPDATE(KS)                                                                              \
-  hipLaunchKernelGGL(shape_update_split_kernel<KS>, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave), lds, \
+  hipLaunchKernelGGL(shape_update_split_kernel<KS>, dim3((unsigned)((B + kWave - 1) / kWave)), dim3(kWave * replicas), lds, \
                      stream, sp, pp, spec_dev, st, state_words, actions + t0 * B, part, trace, keys, B, n, fresh)
     if (pp.n_trail == 0) CAMPX_SHAPE_UPDATE(0);
     else if (pp.n_trail == 1) CAMPX_SHAPE_UPDATE(1);
