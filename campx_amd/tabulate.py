@@ -939,6 +939,19 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   for _, members in probe._update_groups:
     schedule.extend(ent.character for ent in members)
   movers = [ch for ch in schedule if order.index(ch) in varying]
+  if not movers:
+    # nothing ever moves (an agent walled in by what blocks it): the kernels still track one thing
+    # - any that stands on exactly one cell will do; one state, five edges back to it
+    for ch in schedule:
+      part, ent = things0[order.index(ch)], probe.things[ch]
+      if isinstance(ent, _things.Sprite):
+        single = bool(part[2])
+      else:
+        mask = np.frombuffer(part, np.uint8)
+        single = mask.max() <= 1 and int(mask.sum()) == 1
+      if single:
+        movers = [ch]
+        break
   # What tells two reached states with the same curtains apart - the z-order in force
   # (Plot.change_z_order) and the hidden values that are not themselves functions of the
   # curtains (`the_plot['prev_pos_A'] = layers['A']`, examples/boat_race.py:59, is one: the

@@ -4,7 +4,7 @@ from the REFERENCE's own classes (examples/boat_race.py AgentDrape, DirectionalH
 campx.things.FixedDrape) and run on the reference's engine / renderer / Plot, imported from
 /root/reference where they lie (ref_harness).  Build container only:
 
-    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses]
+    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses] [coins]
 
 (`hellos`: tests/golden/random_hellos.npz, the family of tests/random_hellos.py from the Hello World
 notebook's own RollingDrape / SlidingSprite - see hellos() below.)
@@ -161,11 +161,56 @@ def warehouses():
       random_warehouses.N_GAMES, pushes, ends, os.path.getsize(path) // 1024))
 
 
+def coins():
+  """tests/golden/random_coins.npz: tests/random_coins.py's coin fields from Demo 3's own AgentDrape
+  (notebook cell 3), one-hot LISTS as actions, as the notebook's cells pass them."""
+  import ref_harness
+  import random_coins
+  ref = mg.ref
+  ns = ref_harness.notebook_namespace('Demo 3: Hover Reward Example.ipynb', [3])
+  T, N = 48, 6
+  out, paid, in_front = {}, 0, 0
+  for k, d in enumerate(random_coins.definitions()):
+    acts = mg.random_actions(9000 + k, T, N)
+    acts[:, 0] = np.random.RandomState(9100 + k).choice(4, size=T)
+
+    def notebook_game():
+      return random_coins.build(d, mg.to_game, mg.Partial(ns['AgentDrape'], blocking_chars=d['blocking'],
+                                                          reward_chars=d['rewarding']), ref.things.FixedDrape)
+
+    def library_game():
+      return random_coins.build(d, mg.to_game, mg.Partial(mg.R.AgentDrape, blocking_chars=d['blocking'],
+                                                          step_reward=0, reward_chars=d['rewarding']),
+                                mg.R.FixedDrape)
+
+    golden = mg.run(notebook_game, acts, to_action=mg.one_hot_list)
+    mg.assert_same(golden, mg.run(library_game, acts, to_action=mg.one_hot_list),
+                   'random coins {}: library rules'.format(k))
+    for name, value in golden.items():
+      out['k{}_{}'.format(k, name)] = value
+    out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
+    out['k{}_meta'.format(k)] = np.array(json.dumps(
+        dict(tiles=d['tiles'], z_order=d['z_order'], schedule=d['schedule'], blocking=d['blocking'],
+             rewarding=d['rewarding']), sort_keys=True))
+    paid += int((golden['reward'] > 0).sum())
+    in_front += int(any(d['z_order'].index(ch) > d['z_order'].index('A') for ch in d['tiles']))
+    print('coins {:2d} {}x{} tiles {!r:4} z {!r:6} schedule {!r:6} blocking {!r:4} rewarding {!r:4} paid {}'.format(
+        k, len(d['art']), len(d['art'][0]), d['tiles'], d['z_order'], d['schedule'], d['blocking'], d['rewarding'],
+        int((golden['reward'] > 0).sum())))
+  assert paid > 150 and in_front >= 4, (paid, in_front)
+  path = os.path.join(HERE, 'random_coins.npz')
+  np.savez_compressed(path, **out)
+  print('{} games, {} paid frames, {} with a tile in front of the agent -> {} KiB'.format(
+      random_coins.N_GAMES, paid, in_front, os.path.getsize(path) // 1024))
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses']
+  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses', 'coins']
   if 'tracks' in which:
     main()
   if 'hellos' in which:
     hellos()
   if 'warehouses' in which:
     warehouses()
+  if 'coins' in which:
+    coins()
