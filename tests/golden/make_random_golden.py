@@ -4,7 +4,7 @@ from the REFERENCE's own classes (examples/boat_race.py AgentDrape, DirectionalH
 campx.things.FixedDrape) and run on the reference's engine / renderer / Plot, imported from
 /root/reference where they lie (ref_harness).  Build container only:
 
-    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses] [coins]
+    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses] [coins] [quests]
 
 (`hellos`: tests/golden/random_hellos.npz, the family of tests/random_hellos.py from the Hello World
 notebook's own RollingDrape / SlidingSprite - see hellos() below.)
@@ -204,8 +204,42 @@ def coins():
       random_coins.N_GAMES, paid, in_front, os.path.getsize(path) // 1024))
 
 
+def quests():
+  """tests/golden/random_quests.npz: tests/random_quests.py's games of arbitrary Python classes
+  (tests/traced_games.py, which in this process imports the REFERENCE's campx) on the reference's
+  engine; an environment whose episode ended gets a fresh game before its next action."""
+  import random_quests
+  import traced_games
+  assert traced_games.things is mg.ref.things
+  T, N = 60, 6
+  out, ends, discounts = {}, 0, set()
+  for k, d in enumerate(random_quests.definitions()):
+    acts = mg.random_actions(9500 + k, T, N)
+    runs = np.random.RandomState(9600 + k)
+    for n in (1, 2):                                   # two that keep going
+      t = 0
+      while t < T:
+        length = int(runs.randint(2, 6))
+        acts[t:t + length, n] = int(runs.randint(4))
+        t += length
+    golden = mg.run(random_quests.builder(d), acts)
+    for name, value in golden.items():
+      out['k{}_{}'.format(k, name)] = value
+    out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
+    out['k{}_meta'.format(k)] = np.array(json.dumps(dict(kind=d['kind']), sort_keys=True))
+    ends += int(golden['done'].sum())
+    discounts |= set(np.unique(golden['discount']).tolist())
+    print('quest {:2d} {:6s} {}x{} return[mean] {:.2f} done {} discounts {}'.format(
+        k, d['kind'], len(d['art']), len(d['art'][0]), float(np.nansum(golden['reward'], 0).mean()),
+        int(golden['done'].sum()), sorted(set(np.unique(golden['discount']).tolist()))))
+  assert ends >= 10 and discounts >= {0.0, 0.25, 0.5, 0.75, 1.0}, (ends, discounts)
+  path = os.path.join(HERE, 'random_quests.npz')
+  np.savez_compressed(path, **out)
+  print('{} games, {} episode ends -> {} KiB'.format(random_quests.N_GAMES, ends, os.path.getsize(path) // 1024))
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses', 'coins']
+  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses', 'coins', 'quests']
   if 'tracks' in which:
     main()
   if 'hellos' in which:
@@ -214,3 +248,5 @@ if __name__ == '__main__':
     warehouses()
   if 'coins' in which:
     coins()
+  if 'quests' in which:
+    quests()
