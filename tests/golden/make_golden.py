@@ -311,6 +311,19 @@ def gen_demos():
   assert_same(golden, run(demo4_library, acts), 'demo4 library rules')
   save('demo4', golden)
 
+  # ---- Demo 5 (the boat-race training notebook): cell 1 defines Demo 4's game again, with classes
+  # of its own; the rest is the RL driver.  Same frames, so tests hold it to demo4.npz.
+  ns5 = ref_harness.notebook_namespace('Demo 5: Boat Race Example.ipynb', [1])
+  assert ns5['GAME_ART'] == ns['GAME_ART'] and ns5['AgentDrape'] is not ns['AgentDrape']
+
+  def demo5_reference():
+    drapes = {'A': ns5['AgentDrape'], '#': ref.things.FixedDrape}
+    for ch, d in unit.items():
+      drapes[ch] = Partial(ns5['DirectionalHoverRewardDrape'], dctns=torch.FloatTensor(d))
+    return to_game(ns5['GAME_ART'], what_lies_beneath=' ', drapes=drapes,
+                   z_order='^>v<A#', update_schedule='A^>v<#')
+  assert_same(golden, run(demo5_reference, acts), "Demo 5's classes give Demo 4's frames")
+
   # ---- recorded notebook outputs that the current code still reproduces
   demo1_recorded = [[35, 35, 35, 35, 35], [65, 32, 42, 32, 35], [35, 42, 35, 42, 35],
                     [35, 32, 42, 32, 35], [35, 35, 35, 35, 35]]       # Demo 1 cell 6

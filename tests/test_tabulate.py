@@ -127,14 +127,14 @@ def save_table(t, path):
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE_EXAMPLES),
                     reason='reference tree not present (GPU box)')
-@pytest.mark.parametrize('name', ['demo1', 'demo2', 'demo3', 'demo4'])
+@pytest.mark.parametrize('name', ['demo1', 'demo2', 'demo3', 'demo4', 'demo5'])
 def test_unmodified_notebook_classes_tabulate_to_their_goldens(name, golden, tmp_path):
   """The Demo 1-4 notebooks' own classes (cells exec'd unchanged from the .ipynb under
   /root/reference, against this repo's `campx` alias), tabulated - Demo 1-3 with the plain
   one-hot LISTS those notebooks pass to play() - and the table walked over the golden
   action streams: the frames the REFERENCE engine produced (tests/golden/demoN.npz)."""
   from oracle.table_replay import TableWalker
-  from test_generic_golden import NOTEBOOK_GAMES
+  from test_generic_golden import GOLDEN_OF, NOTEBOOK_GAMES
   notebook, cells, build = NOTEBOOK_GAMES[name]
   code = r'''
 import json, sys, collections, itertools
@@ -150,14 +150,14 @@ for i in %(cells)r:
     exec(compile(''.join(nb['cells'][i]['source']), 'cell %%d' %% i, 'exec'), ns)
 game = eval(%(build)r, ns)
 assert type(game.things['A']).__module__ == '__main__'    # the notebook's own class
-if %(name)r != 'demo4':     # Demo 1-3 call play([1, 0, 0, 0, 0])
+if %(name)r not in ('demo4', 'demo5'):     # Demo 1-3 call play([1, 0, 0, 0, 0])
     game.set_action_set([[int(i == a) for i in range(5)] for a in range(5)])
 %(save)s
 save_table(tabulate.trace(game, actions=game._action_set), %(out)r)
 ''' % dict(repo=REPO, ref=REFERENCE_EXAMPLES, notebook=notebook, cells=cells, build=build,
            name=name, save=_SAVE_TABLE, out=str(tmp_path / 'table.npz'))
   subprocess.run([sys.executable, '-c', code], check=True)
-  gold = golden(name)
+  gold = golden(GOLDEN_OF.get(name, name))
   H, W = gold['board'].shape[-2:]
   traced, _ = _traced_from_npz(tmp_path / 'table.npz', H, W)
   assert [ord(c) for c in traced.chars] == gold['chars'].tolist() and traced.movers == ['A']
