@@ -221,6 +221,8 @@ class ShapeGame(object):
     if pipelined:
       raise ValueError('the shape tier is a single kernel: nothing to pipeline')
     T = int(actions.shape[0])
+    if T < 1:
+      raise ValueError('a rollout needs at least one frame: actions [T, B] with T >= 1')
     ids = self._ids(actions, (T, self.batch))
     if out is None:
       out = self.rollout_buffers(T, keep_obs, want_board or board is not None, obs_dtype)

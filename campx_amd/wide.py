@@ -161,6 +161,8 @@ class WideGame(fused.FusedGame):
     if pipelined:
       raise ValueError('wide tier: pipelined rollouts are not offered')
     T = int(actions.shape[0])
+    if T < 1:
+      raise ValueError('a rollout needs at least one frame: actions [T, B] with T >= 1')
     if (torch.is_tensor(actions) and actions.dtype == torch.int8 and actions.device == self.device
         and actions.shape == (T, self.batch) and actions.is_contiguous()):
       ids = actions

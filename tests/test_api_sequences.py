@@ -249,3 +249,12 @@ def test_a_random_sequence_of_calls_matches_the_oracle(name, seed):
     a = actions(1)
     obs, _, _ = game.play(torch.from_numpy(a[0]))
     assert _same(obs.layered_board.cpu().numpy(), og.rollout(a, reset_first=False)['obs'][0]), log
+
+
+def test_a_rollout_of_no_frames_is_refused_in_words():
+  for name in ('boat_race', 'sokoban_l1', 'maze_16x16', 'hello_world'):
+    build, kw, _ = GAMES[name]
+    game = build(batch=16, device='cuda', **kw)
+    game.its_showtime()
+    with pytest.raises(ValueError, match='at least one frame'):
+      game.rollout(torch.zeros((0, 16), dtype=torch.int8))
