@@ -84,6 +84,39 @@ def test_rule_lowering_run_by_the_c_oracle_gives_them_too(k):
     assert _same(out[name], gold[name]), name
 
 
+@pytest.mark.parametrize('k', [1, 2, 6, 11, 12, 14, 15])
+def test_the_rule_classes_bound_afresh_are_tabulated_to_the_same_frames(k):
+  """The smaller levels with their classes bound afresh - arbitrary Python classes to the engine,
+  Python branches and all, so the one-frame-per-play walker tabulates them (7 to 225 states) - and
+  the table walked on the host: the reference engine's frames once more, through a route that
+  shares nothing with the rule lowering."""
+  from campx import things
+  from campx.ascii_art import ascii_art_to_game, Partial
+  from campx_amd import rules
+  from oracle.table_replay import StateWalker, TableWalker
+  R = rules.bind(things)
+  gold = _gold(k)
+  T, N = gold['actions'].shape
+  game = random_warehouses.build(DEFS[k], ascii_art_to_game, Partial, R.AgentDrape, R.BoxDrape, R.GoalDrape,
+                                 R.FixedDrape)
+  assert not gamespec.is_rule_game(game)
+  traced = tabulate.trace(game, cache=False)
+  if traced.dense_reason is not None:
+    walker = StateWalker(traced, N)
+    want = walker.rollout(gold['actions'], reset_first=True)
+    render = lambda t: walker.render(want['state'][t])
+  else:
+    walker = TableWalker(traced, N)
+    want = walker.rollout(gold['actions'], reset_first=True)
+    render = lambda t: walker.render(want['cells'][:, t].astype(np.int64))
+  for name in ('reward', 'discount', 'done'):
+    assert _same(want[name], gold[name]), name
+  for t in range(T):
+    board, layered = render(t)
+    assert np.array_equal(board, gold['board'][t + 1]), t
+    assert np.array_equal(layered, gold['layered'][t + 1].astype(np.int8)), t
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('k', range(len(DEFS)), ids=IDS)
 def test_hip_path_gives_the_reference_engines_frames(k):
