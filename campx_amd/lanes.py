@@ -8,9 +8,12 @@ so that they run on other tensor types.  `Lanes` is such a type: physically `[N,
 logically `shape`, every torch function applied lane by lane (`torch.func.vmap` of the very
 function the game called, so `dim=` arguments, slices, broadcasting and type promotion keep
 their single-tensor meaning), in-place methods and `set_` redirected to the lanes' storage, and
-Python-level reads - `bool()`, `int()`, `.item()`, a branch on a tensor - allowed only where
-every lane agrees (`CannotBatch` otherwise: the host tabulator then falls back to one frame of
-Python per state and action, campx_amd/tabulate.py).
+Python-level reads - `bool()`, `int()`, `.item()`, a branch on a tensor - answered where every
+lane agrees; where they do not, `Diverged` (a `CannotBatch`) carries what each lane reads, and
+the tabulator runs the frame again for each group of lanes that agree
+(campx_amd/tabulate_batched.py); anything else without a lane-by-lane meaning is a plain
+`CannotBatch`: the host tabulator then falls back to one frame of Python per state and action
+(campx_amd/tabulate.py).
 
 Host logic; used by campx_amd/tabulate_batched.py only.
 """
@@ -21,6 +24,17 @@ from torch.utils import _pytree as pytree
 
 class CannotBatch(Exception):
   """The game did something that has no lane-by-lane meaning (the message says what)."""
+
+
+class Diverged(CannotBatch):
+  """A Python-level read - `if x:`, `int(x)`, `.item()` - of a value that is not the same in every
+  lane.  `values` [N] says which lane reads what: whoever runs the frame may run it again for
+  each group of lanes that agree (campx_amd/tabulate_batched.py does; anyone else sees a
+  `CannotBatch`)."""
+
+  def __init__(self, message, values):
+    CannotBatch.__init__(self, message)
+    self.values = values
 
 
 def _guard():
@@ -64,8 +78,8 @@ def _uniform_value(x, what):
     raise CannotBatch('{} of a tensor with {} elements'.format(what, p[0].numel()))
   flat = p.reshape(p.shape[0])
   if not bool((flat == flat[0]).all()):
-    raise CannotBatch('{} of a value that differs between states (a data-dependent branch or '
-                      'Python number: no lane-by-lane meaning)'.format(what))
+    raise Diverged('{} of a value that differs between states (a data-dependent branch or '
+                   'Python number: no lane-by-lane meaning)'.format(what), flat.clone())
   return flat[0]
 
 

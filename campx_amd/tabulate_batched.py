@@ -24,9 +24,12 @@ to the one-frame-per-play walk, which takes anything and says what is wrong with
   * nothing a frame can read changes besides the curtains and what renders from them: entity
     attributes, Plot entries (other than aliases of the renderer's live layers,
     `the_plot['prev_pos_A'] = layers['A']`, boat_race.py:59), the z-order, the frame number;
-  * Python-level control flow never depends on a lane-varying value (`if gate:` with a tensor
-    that differs between states, `int(x)`, `.item()`, `.numpy()`); rewards are lane tensors or
-    plain numbers, termination and discounts are per action, not per state.
+  * Python-level reads of a value that differs between states - `if pushed and not blocked:`,
+    `int(x)`, `.item()` - SPLIT the frame (round 5, late): it is run again for each group of
+    states that read the same, recursively, at most `MAX_SPLITS` groups per (level, action); so
+    rewards, termination and discounts may differ from state to state.  What has no lane-by-lane
+    form at all - `.numpy()`, `nonzero()`, a tensor index into a tensor - still hands the game to
+    the other walker.
 A sample of the tabulated edges (every action from the first state, and `CHECK_EDGES` random
 ones) is then replayed on the ordinary generic tier - the user's code on plain tensors - and must
 agree bit for bit; a disagreement falls back as well.
@@ -44,7 +47,7 @@ from . import lanes
 from . import rendering
 from . import tabulate
 from . import things as _things
-from .lanes import CannotBatch, Lanes
+from .lanes import CannotBatch, Diverged, Lanes
 
 N_ACTIONS = gamespec.N_ACTIONS
 CHECK_EDGES = 48
@@ -215,9 +218,13 @@ class _Frontier(object):
     eng._render()                       # the states' own rendering: what this frame's update() reads
     eng._game_over = False
     eng._the_plot._clear_engine_directives()
-    eng._update_and_render(copy.deepcopy(self.actions[a]))
-    reward, discount, rerender = eng._apply_and_clear_plot()
-    eng._the_plot._frame -= 1            # (one frame, over and over: its number is not part of this tier's state)
+    frame_number = eng._the_plot._frame
+    try:
+      eng._update_and_render(copy.deepcopy(self.actions[a]))
+      reward, discount, rerender = eng._apply_and_clear_plot()
+    finally:                             # (one frame, over and over - also when it is given up half way)
+      eng._the_plot._frame = frame_number
+      eng._the_plot.update_group = None
     if tabulate.FRAME_READS[0] != self.reads0:
       raise CannotBatch('the game reads the_plot.frame')
     if rerender or ''.join(eng.things.keys()) != self.z0:
@@ -252,6 +259,46 @@ class _Frontier(object):
       raise CannotBatch('something besides the curtains changed (an entity attribute, a Plot entry)')
     board = lanes.plain(self.renderer._board).to(torch.uint8).reshape(n, self.H * self.W)
     return nxt, r, float(np.float32(discount)), over, board
+
+
+MAX_SPLITS = 64          # groups of states one (level, action) frame may fall into
+
+
+def _frame_any(front, curtains, a, budget=None):
+  """`front.frame()` for N states whose Python-level reads need not agree: when a branch (`if
+  x:`, `int(x)`, `.item()`) reads different values in different states, the frame is run again
+  for each group of states that read the same - recursively, a later branch may split a group
+  again.  Returns (next curtains, reward f32 [N], discount f32 [N], over bool [N], boards)."""
+  n = int(next(iter(curtains.values())).shape[0])
+  budget = [MAX_SPLITS] if budget is None else budget
+  try:
+    nxt, r, discount, over, board = front.frame(curtains, a)
+    dev = r.device
+    return (nxt, r, torch.full((n,), discount, dtype=torch.float32, device=dev),
+            torch.full((n,), bool(over), dtype=torch.bool, device=dev), board)
+  except Diverged as split:
+    values = split.values.reshape(-1)
+    if values.numel() != n:
+      raise CannotBatch(str(split))
+    groups = torch.unique(values)
+    budget[0] -= int(groups.numel())
+    if groups.numel() < 2 or budget[0] < 0:
+      raise CannotBatch('{} - in more than {} different ways in one frame'.format(split, MAX_SPLITS))
+    parts = []
+    for g in groups:
+      idx = torch.nonzero(values == g).reshape(-1)
+      parts.append((idx, _frame_any(front, {ch: c[idx] for ch, c in curtains.items()}, a, budget)))
+    dev = parts[0][1][1].device
+    nxt = {ch: torch.empty_like(c) for ch, c in curtains.items()}
+    r = torch.empty((n,), dtype=torch.float32, device=dev)
+    discount = torch.empty((n,), dtype=torch.float32, device=dev)
+    over = torch.empty((n,), dtype=torch.bool, device=dev)
+    board = torch.empty((n, front.H * front.W), dtype=torch.uint8, device=dev)
+    for idx, (pn, pr, pd, po, pb) in parts:
+      for ch in nxt:
+        nxt[ch][idx] = pn[ch]
+      r[idx], discount[idx], over[idx], board[idx] = pr, pd, po, pb
+    return nxt, r, discount, over, board
 
 
 def trace(engine, actions=None, max_plays=None, device=None):
@@ -299,7 +346,7 @@ def _trace(engine, actions, device, H, W, HW, chars):
   moving = set()
   first = {}
   for a in range(N_ACTIONS):
-    first[a] = front.frame(start, a)
+    first[a] = _frame_any(front, start, a)
     for ch in drapes:
       if not torch.equal(first[a][0][ch], start[ch]):
         moving.add(ch)
@@ -313,10 +360,11 @@ def _trace(engine, actions, device, H, W, HW, chars):
     except _NewMover as e:
       moving.add(e.ch)
 
-  cells, nxt, reward, over_a, disc_a, boards, n_frames = graph
+  cells, nxt, reward, over, disc, queue_pos, boards, n_frames = graph
   game = _finish_arrays(engine, probe, chars, sorted(moving), start, cells.cpu().numpy(),
-                        nxt.cpu().numpy(), reward.cpu().numpy(), over_a, disc_a,
-                        boards.cpu().numpy(), n_frames, obs, things0, backdrop0, z0, actions)
+                        nxt.cpu().numpy(), reward.cpu().numpy(), over.cpu().numpy(), disc.cpu().numpy(),
+                        queue_pos.cpu().numpy(), boards.cpu().numpy(), n_frames, obs, things0,
+                        backdrop0, z0, actions)
   game.batched_frames = n_frames
   return game
 
@@ -325,8 +373,8 @@ def _fail(msg):
   raise tabulate.TabulationError('cannot tabulate this game for the HIP tier: ' + msg)
 
 
-def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, reward, over_a, disc_a,
-                   boards, n_frames, obs0, things0, backdrop0, z0, actions):
+def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, reward, over, disc,
+                   queue_pos, boards, n_frames, obs0, things0, backdrop0, z0, actions):
   """`tabulate._finish` for the many-states-per-call walk, on arrays: the same `TracedGame`,
   field for field (tests/test_tabulate_batched.py compares the two walkers' results), without a
   Python loop over states - one z-order, no hidden values, drapes only, which is what this tier
@@ -454,21 +502,24 @@ def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, rewar
   game.st_next = nxt_safe.astype(np.int32)
   game.st_reached = np.broadcast_to(walked[:, None], (S, N_ACTIONS)).copy()
   game.st_reward = np.where(game.st_reached, reward, np.float32(np.nan)).astype(np.float32)
-  over = np.array(over_a, bool)
-  game.st_done = (game.st_reached & over[None, :]).astype(np.uint8)
-  disc = np.array(disc_a, np.float32)
-  game.st_discount = np.where(game.st_reached, disc[None, :], np.float32(1.0)).astype(np.float32)
+  over = over.astype(bool) & game.st_reached                 # [S, 5]: per state since the frames may split
+  game.st_done = over.astype(np.uint8)
+  disc = disc.astype(np.float32)
+  game.st_discount = np.where(game.st_reached, disc, np.float32(1.0)).astype(np.float32)
   game.st_dcode = np.zeros((S, N_ACTIONS), np.uint8)
   game.discount_list = [1.0]
-  if walked.any():
-    for a in range(N_ACTIONS):
-      d = float(disc[a])
-      if d != (0.0 if over[a] else 1.0):
-        if d not in game.discount_list[1:]:
-          if len(game.discount_list) == 16:
-            _fail('more than 15 distinct discounts besides the default')
-          game.discount_list.append(d)
-        game.st_dcode[walked, a] = 1 + game.discount_list[1:].index(d)
+  special = game.st_reached & (game.st_discount != np.where(over, np.float32(0.0), np.float32(1.0)))
+  if special.any():
+    # codes in the order the one-frame walker meets them: states as they leave its queue, actions 0..4
+    ss, aa = np.nonzero(special)
+    for i in np.lexsort((aa, queue_pos[ss])):
+      d = float(game.st_discount[ss[i], aa[i]])
+      if d not in game.discount_list[1:]:
+        if len(game.discount_list) == 16:
+          _fail('more than 15 distinct discounts besides the default')
+        game.discount_list.append(d)
+    for code, d in enumerate(game.discount_list[1:], 1):
+      game.st_dcode[special & (game.st_discount == np.float32(d))] = code
   game.st_perf = np.where(game.st_reached, perf, 0).astype(np.int8)
   game.any_reward = bool((~np.isnan(game.st_reward[game.st_reached])).any())
   game.has_perf = has_perf
@@ -510,8 +561,7 @@ def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, rewar
       game.perf[i] = game.st_perf[src, a]
       game.reached[i] = True
 
-  _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, reward, over_a, disc_a,
-               boards)
+  _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, reward, over, disc, boards)
   return game
 
 
@@ -523,7 +573,8 @@ class _NewMover(Exception):
 
 def _walk(front, start, movers, drapes, HW, device):
   """Breadth-first over levels.  Returns (cells int64 [S, K], next int64 [S, 5] (-1: never
-  expanded), reward f32 [S, 5], over per action, discount per action, boards uint8 [S, HW],
+  expanded), reward f32 [S, 5], over bool [S, 5], discount f32 [S, 5], the place of every state in
+  the order the walk expanded them (int64 [S], a large number: never), boards uint8 [S, HW],
   frames run)."""
   K = len(movers)
   if K == 0:
@@ -572,10 +623,9 @@ def _walk(front, start, movers, drapes, HW, device):
   known_index = torch.zeros(1, dtype=torch.int64, device=device)
   S = 1
   boards = [_render_states(front, start)]
-  nxt_rows, reward_rows, level_states = [], [], []
+  nxt_rows, reward_rows, over_rows, disc_rows, level_states = [], [], [], [], []
   queued = torch.ones(1, dtype=torch.bool, device=device)       # ever put on the walk's queue
   frontier = torch.zeros(1, dtype=torch.int64, device=device)   # state indices in QUEUE order
-  over_a, disc_a = [None] * N_ACTIONS, [None] * N_ACTIONS
   frames = 0
   big = 1 << 62
 
@@ -585,21 +635,21 @@ def _walk(front, start, movers, drapes, HW, device):
     keys = torch.empty((F, N_ACTIONS), dtype=torch.int64, device=device)
     ncell = torch.empty((F, N_ACTIONS, K), dtype=torch.int64, device=device)
     rew = torch.empty((F, N_ACTIONS), dtype=torch.float32, device=device)
+    ended = torch.empty((F, N_ACTIONS), dtype=torch.bool, device=device)
+    disc = torch.empty((F, N_ACTIONS), dtype=torch.float32, device=device)
     nboard = [None] * N_ACTIONS
     for a in range(N_ACTIONS):
-      nxt, r, discount, over, board = front.frame(cur, a)
+      nxt, r, discount, over, board = _frame_any(front, cur, a)
       frames += 1
       for ch in drapes:
         if ch not in movers and not torch.equal(nxt[ch], cur[ch].expand(F, H, W)):
           raise _NewMover(ch)
-      if over_a[a] is None:
-        over_a[a], disc_a[a] = over, discount
-      elif over_a[a] != over or disc_a[a] != discount:
-        raise CannotBatch('action {} ends the episode (or sets the discount) in some states only'.format(a))
       c = cells_of(nxt)
       ncell[:, a] = c
       keys[:, a] = key_of(c)
       rew[:, a] = r
+      ended[:, a] = over
+      disc[:, a] = discount
       nboard[a] = board
     flat_keys = keys.reshape(-1)              # slot = state's place in the queue * 5 + action: discovery order
     pos = torch.searchsorted(known_keys, flat_keys).clamp(max=known_keys.numel() - 1)
@@ -631,15 +681,16 @@ def _walk(front, start, movers, drapes, HW, device):
     target = target.reshape(F, N_ACTIONS)
     nxt_rows.append(target)
     reward_rows.append(rew)
+    over_rows.append(ended)
+    disc_rows.append(disc)
     level_states.append(frontier)
     # the walk goes on from a state once an edge that does not end the episode reaches it, in
     # the order those edges are played (tabulate._trace_once's queue)
-    live = [a for a in range(N_ACTIONS) if not over_a[a]]
-    if not live:
+    live = torch.nonzero(~ended.reshape(-1)).reshape(-1)            # slots = place in the queue * 5 + action
+    if not live.numel():
       break
-    slots = (torch.arange(F, device=device)[:, None] * N_ACTIONS +
-             torch.tensor(live, device=device)[None, :]).reshape(-1)
-    reached = target[:, live].reshape(-1)
+    slots = live
+    reached = target.reshape(-1)[live]
     first_slot = torch.full((S,), big, dtype=torch.int64, device=device)
     first_slot.scatter_reduce_(0, reached, slots, reduce='amin', include_self=True)
     newly = (first_slot < big) & ~queued
@@ -649,10 +700,15 @@ def _walk(front, start, movers, drapes, HW, device):
 
   nxt_all = torch.full((S, N_ACTIONS), -1, dtype=torch.int64, device=device)
   rew_all = torch.full((S, N_ACTIONS), float('nan'), dtype=torch.float32, device=device)
-  for st, t, r in zip(level_states, nxt_rows, reward_rows):
-    nxt_all[st] = t
-    rew_all[st] = r
-  return cells, nxt_all, rew_all, [bool(x) for x in over_a], disc_a, torch.cat(boards), frames
+  over_all = torch.zeros((S, N_ACTIONS), dtype=torch.bool, device=device)
+  disc_all = torch.ones((S, N_ACTIONS), dtype=torch.float32, device=device)
+  queue_pos = torch.full((S,), big, dtype=torch.int64, device=device)
+  at = 0
+  for st, t, r, o, d in zip(level_states, nxt_rows, reward_rows, over_rows, disc_rows):
+    nxt_all[st], rew_all[st], over_all[st], disc_all[st] = t, r, o, d
+    queue_pos[st] = at + torch.arange(st.numel(), device=device)
+    at += int(st.numel())
+  return cells, nxt_all, rew_all, over_all, disc_all, queue_pos, torch.cat(boards), frames
 
 
 def _render_states(front, curtains):
@@ -667,8 +723,8 @@ def _render_states(front, curtains):
   return lanes.plain(front.renderer._board).to(torch.uint8).reshape(n, front.H * front.W).clone()
 
 
-def _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, reward, over_a,
-                 disc_a, boards):
+def _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, reward, over,
+                 disc, boards):
   """Replay a sample of the tabulated edges with the user's code on PLAIN tensors (the generic
   tier, one state, one action) and demand the same next state, reward, discount, game-over and
   board: the lane-by-lane frames are the game's own frames."""
@@ -697,7 +753,7 @@ def _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, 
     eng._render()
     obs, got_reward, discount = eng.play(copy.deepcopy(actions[a]))
     t = int(nxt[s, a])
-    ok = (bool(eng.game_over) == bool(over_a[a]) and float(np.float32(discount)) == float(disc_a[a]) and
+    ok = (bool(eng.game_over) == bool(over[s, a]) and float(np.float32(discount)) == float(disc[s, a]) and
           obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes() == boards[t].tobytes() and
           np.array([tabulate.reward_f32(got_reward)]).view(np.uint32)[0] ==
           np.array([np.float32(reward[s, a])]).view(np.uint32)[0])

@@ -202,7 +202,7 @@ def game(a, b=Still):
 CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes: something besides the curtains'),
          (ViewWrite, Still, 'lanes: '), (PlotMem, Still, "one frame per play (lanes: the_plot['prev']"),
          (Rand, Still, 'REFUSED: keeps state outside'), (Nonzero, Still, 'one frame per play (lanes: nonzero'),
-         (Roll, Still, 'lanes: '), (Terminator, Still, 'one frame per play (lanes: bool() of a value that differs'),
+         (Roll, Still, 'lanes: '), (Terminator, Still, 'lanes: '),
          (Grower, Still, 'REFUSED: covers'), (Indexer, Still, 'one frame per play (lanes: __getitem__'),
          (Float, Still, 'lanes: '), (ChangeZ, Still, 'one frame per play (lanes: the game changes the z-order'),
          (Pusher, Still, 'lanes: '), (BoardReader, Still, 'lanes: '), (Mover, Chaser, 'lanes: '),

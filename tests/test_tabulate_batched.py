@@ -336,11 +336,12 @@ def test_games_the_lane_walker_does_not_take_fall_back_and_say_why(monkeypatch):
   def build():
     return ascii_art_to_game(['#####', '#B  #', '#   #', '#####'], what_lies_beneath=' ',
                              drapes={'B': Branchy, '#': things.FixedDrape}, z_order='B#', update_schedule='B#')
+  # (round 5, late: such a frame is run again for each group of states that branch the same way -
+  # the lane walker takes the game, and gives what the one-frame walker gives)
   game = tabulate.trace(build(), cache=False)
-  assert game.n_states == 6 and 'differs between states' in tabulate.LAST_WALK[0]
-  monkeypatch.setenv('CAMPX_TABULATE', 'batch')
-  with pytest.raises(tabulate.TabulationError, match='differs between states'):
-    tabulate.trace(build(), cache=False)
+  assert game.n_states == 6 and tabulate.LAST_WALK[0].startswith('lanes: '), tabulate.LAST_WALK[0]
+  monkeypatch.setenv('CAMPX_TABULATE', 'walk')
+  assert _first_difference(tabulate.trace(build(), cache=False), game) is None
 
 
 def _predicts_live_play(table, build, frames=60, seed=3):
