@@ -190,6 +190,50 @@ class Discounter(Base):
       the_plot.terminate_episode(0.5)
 
 
+class IntIndex(Base):   # int() of a value that differs between states, as an index into a Python list
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    where = int((self.curtain.reshape(-1).long() * torch.arange(30)).sum())
+    the_plot.add_reward([0.25 * (i % 7) for i in range(30)][where])
+
+
+class TwoBranches(Base):   # a branch in 'A' and, later in the same frame, one in 'B': groups split again
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    new = self.step(actions.byte(), layers)
+    if (new * layers['G']).sum() > 0:
+      the_plot.add_reward(5.0)
+      if actions[4] == 1:
+        the_plot.terminate_episode(0.5)
+    self.curtain.set_(new)
+
+
+class Follower(Base):      # 'B': steps towards the left whenever 'A' stands in the upper half
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    if all_things['A'].curtain[:2].sum() > 0:
+      act = torch.tensor([1, 0, 0, 0, 0], dtype=torch.uint8)
+    else:
+      act = torch.tensor([0, 0, 0, 0, 1], dtype=torch.uint8)
+    there = moved(act, self.curtain)
+    hit = (there * layers['#']).sum() + (there * all_things['A'].curtain).sum()
+    if hit == 0:
+      self.curtain.set_(there)
+      the_plot.add_reward(-0.5)
+
+
+class LeavesAMark(Base):   # sets a Plot entry, THEN something later in the frame branches
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    the_plot['mark'] = 1
+    self.curtain.set_(self.step(actions.byte(), layers))
+
+
 def game(a, b=Still):
   def build():
     return ascii_art_to_game(ART, what_lies_beneath=' ',
@@ -206,7 +250,9 @@ CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes:
          (Grower, Still, 'REFUSED: covers'), (Indexer, Still, 'one frame per play (lanes: __getitem__'),
          (Float, Still, 'lanes: '), (ChangeZ, Still, 'one frame per play (lanes: the game changes the z-order'),
          (Pusher, Still, 'lanes: '), (BoardReader, Still, 'lanes: '), (Mover, Chaser, 'lanes: '),
-         (NanReward, Still, 'lanes: '), (Discounter, Still, 'lanes: ')]
+         (NanReward, Still, 'lanes: '), (Discounter, Still, 'lanes: '), (IntIndex, Still, 'lanes: '),
+         (TwoBranches, Follower, 'lanes: '), (Terminator, Follower, 'lanes: '),
+         (LeavesAMark, Follower, 'one frame per play (lanes: something besides the curtains')]
 
 
 # ---- live game objects reached behind the engine's back: refused statically, by name
