@@ -278,8 +278,8 @@ def _frame_any(front, curtains, a, budget=None):
             torch.full((n,), bool(over), dtype=torch.bool, device=dev), board)
   except Diverged as split:
     values = split.values.reshape(-1)
-    if values.numel() != n:
-      raise CannotBatch(str(split))
+    if values.numel() != n or (values.is_floating_point() and bool(torch.isnan(values).any())):
+      raise CannotBatch(str(split))          # (not this frame's lanes, or a NaN: no grouping by value)
     groups = torch.unique(values)
     budget[0] -= int(groups.numel())
     if groups.numel() < 2 or budget[0] < 0:
