@@ -294,6 +294,23 @@ class Lanes(torch.Tensor):
       v = _uniform_value(first, name.strip('_') + '()')
       with _guard():
         return getattr(v, name)()
+    if name in ('tolist', 'numpy', '__array__') and isinstance(first, Lanes):
+      # the whole tensor as a Python / numpy value: the one every lane holds - a READ-ONLY copy (a
+      # write through it would have gone to the tensor's storage on plain tensors: not here, so
+      # it must not pass silently) - or, where lanes differ, a `Diverged` whose groups are the
+      # lanes with the same contents (a one-cell curtain: one group per cell it can be in)
+      p = plain(first)
+      flat = p.reshape(p.shape[0], -1)
+      if flat.shape[0] > 1 and not bool((flat == flat[:1]).all()):
+        _, inverse = torch.unique(flat, dim=0, return_inverse=True)
+        raise Diverged('{}() of a tensor that differs between states'.format(name), inverse)
+      with _guard():
+        value = p[0].clone()
+        if name == 'tolist':
+          return value.tolist()
+        array = value.numpy() if name == 'numpy' else value.numpy().__array__(*args[1:], **kwargs)
+      array.flags.writeable = False
+      return array
     if name in ('tolist', 'numpy', '__array__', '__array_wrap__', 'data_ptr', 'storage',
                 'untyped_storage', '__reduce_ex__', '__dlpack__', 'cpu_', 'share_memory_'):
       raise CannotBatch('{}() of a tensor that stands for many states'.format(name))

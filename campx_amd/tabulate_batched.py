@@ -27,9 +27,11 @@ to the one-frame-per-play walk, which takes anything and says what is wrong with
   * Python-level reads of a value that differs between states - `if pushed and not blocked:`,
     `int(x)`, `.item()` - SPLIT the frame (round 5, late): it is run again for each group of
     states that read the same, recursively, at most `MAX_SPLITS` groups per (level, action); so
-    rewards, termination and discounts may differ from state to state.  What has no lane-by-lane
-    form at all - `.numpy()`, `nonzero()`, a tensor index into a tensor - still hands the game to
-    the other walker.
+    rewards, termination and discounts may differ from state to state.  `.numpy()` / `.tolist()`
+    of a tensor that differs between states split the same way, by the tensor's whole contents
+    (the value handed out is a read-only copy).  What has no lane-by-lane form at all -
+    `nonzero()` ON a lane tensor, a tensor index into a tensor - still hands the game to the
+    other walker.
 A sample of the tabulated edges (every action from the first state, and `CHECK_EDGES` random
 ones) is then replayed on the ordinary generic tier - the user's code on plain tensors - and must
 agree bit for bit; a disagreement falls back as well.
@@ -261,7 +263,8 @@ class _Frontier(object):
     return nxt, r, float(np.float32(discount)), over, board
 
 
-MAX_SPLITS = 64          # groups of states one (level, action) frame may fall into
+MAX_SPLITS = 2048        # groups of states one (level, action) frame may fall into (a class that
+                         # reads its one-cell curtain as numpy: one group per cell it stands on)
 
 
 def _frame_any(front, curtains, a, budget=None):

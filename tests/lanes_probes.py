@@ -234,6 +234,35 @@ class LeavesAMark(Base):   # sets a Plot entry, THEN something later in the fram
     self.curtain.set_(self.step(actions.byte(), layers))
 
 
+class NumpyReader(Base):   # finds itself through numpy views, as tests/traced_games.py's classes do
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    import numpy as np
+    a = int(actions.argmax())
+    dr, dc = ((0, -1), (0, 1), (-1, 0), (1, 0), (0, 0))[a]
+    (r,), (c,) = np.nonzero(self.curtain.numpy())
+    wall = all_things['#'].curtain.numpy()
+    if not wall[r + dr, c + dc] and not all_things['B'].curtain[r + dr, c + dc]:
+      self.curtain.zero_()
+      self.curtain[r + dr, c + dc] = 1
+    the_plot.add_reward(float(all_things['G'].curtain.numpy()[r, c]) - 0.125)
+
+
+class NumpyWriter(Base):   # moves by writing THROUGH the numpy view of its curtain (shared memory on plain tensors)
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    import numpy as np
+    a = int(actions.argmax())
+    dr, dc = ((0, -1), (0, 1), (-1, 0), (1, 0), (0, 0))[a]
+    view = self.curtain.numpy()
+    (r,), (c,) = np.nonzero(view)
+    if not all_things['#'].curtain.numpy()[r + dr, c + dc]:
+      view[r, c] = 0
+      view[r + dr, c + dc] = 1
+
+
 def game(a, b=Still):
   def build():
     return ascii_art_to_game(ART, what_lies_beneath=' ',
@@ -252,7 +281,9 @@ CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes:
          (Pusher, Still, 'lanes: '), (BoardReader, Still, 'lanes: '), (Mover, Chaser, 'lanes: '),
          (NanReward, Still, 'lanes: '), (Discounter, Still, 'lanes: '), (IntIndex, Still, 'lanes: '),
          (TwoBranches, Follower, 'lanes: '), (Terminator, Follower, 'lanes: '),
-         (LeavesAMark, Follower, 'one frame per play (lanes: something besides the curtains')]
+         (LeavesAMark, Follower, 'one frame per play (lanes: something besides the curtains'),
+         (NumpyReader, Still, 'lanes: '), (NumpyReader, Follower, 'lanes: '),
+         (NumpyWriter, Still, 'one frame per play (lanes: ValueError')]
 
 
 # ---- live game objects reached behind the engine's back: refused statically, by name

@@ -122,8 +122,18 @@ def test_python_level_reads_need_every_lane_to_agree():
       read(differs)
   with pytest.raises(lanes.CannotBatch, match='differs between states'):
     assert differs == 1
-  with pytest.raises(lanes.CannotBatch, match=r'numpy\(\) of a tensor that stands for many states'):
-    differs.numpy()
+  # the whole tensor as a numpy / Python value: every lane's where they agree (a read-only copy), a
+  # `Diverged` that groups the lanes by their contents where they do not
+  assert same.numpy().tolist() == 3 and same.tolist() == 3
+  board = lanes.wrap(torch.tensor([[1, 0], [1, 0], [1, 0]]))
+  assert board.numpy().tolist() == [1, 0] and not board.numpy().flags.writeable
+  with pytest.raises(lanes.Diverged, match=r'numpy\(\) of a tensor that differs between states') as split:
+    lanes.wrap(torch.tensor([[0, 1], [1, 0], [0, 1]])).numpy()
+  groups = split.value.values.tolist()
+  assert groups[0] == groups[2] != groups[1]
+  with pytest.raises(lanes.Diverged) as split:
+    bool(differs)
+  assert split.value.values.tolist() == [0, 1, 1]
   # the general path (vmap of the very function): dim arguments keep their meaning
   x = lanes.wrap(torch.arange(24.).reshape(2, 3, 4))
   assert torch.equal(lanes.plain(torch.roll(x, 1, 1)), torch.roll(lanes.plain(x), 1, 2))
@@ -314,7 +324,7 @@ def test_a_warehouse_of_half_a_million_states_tabulates_in_seconds_and_predicts_
 
 def test_games_the_lane_walker_does_not_take_fall_back_and_say_why(monkeypatch):
   monkeypatch.delenv('CAMPX_TABULATE', raising=False)
-  for build, why in ((traced_games.ice_rink, r'numpy\(\) of a tensor'),
+  for build, why in ((traced_games.burrow, r'changes the z-order'),
                      (traced_games.mirror, r"is a Sprite")):
     game = tabulate.trace(build(), cache=False)
     assert game.n_states > 1
