@@ -19,8 +19,10 @@ the same graph and produce the same `TracedGame`.
 
 What this tier takes - checked, `CannotBatch` otherwise, and `tabulate.trace()` then falls back
 to the one-frame-per-play walk, which takes anything and says what is wrong with the rest:
-  * things are Drapes with 0/1 curtains (a Sprite's position is a Python tuple: one value for all
-    lanes), the Backdrop's `update()` is the base class's no-op;
+  * things are Drapes with 0/1 curtains, or Sprites (a Sprite's position is a Python tuple, one
+    value for all lanes: a frame whose states have their sprites in different places is split by
+    where they stand, like a frame that branches; an invisible Sprite must stand where it stood
+    at the start); the Backdrop's `update()` is the base class's no-op;
   * nothing a frame can read changes besides the curtains and what renders from them: entity
     attributes, Plot entries (other than aliases of the renderer's live layers,
     `the_plot['prev_pos_A'] = layers['A']`, boat_race.py:59), the z-order, the frame number;
@@ -178,12 +180,15 @@ class _Frontier(object):
     self.actions = actions
     self.device = device
     self.H, self.W = eng.rows, eng.cols
-    for ch, ent in eng.things.items():
-      if isinstance(ent, _things.Sprite):
-        raise CannotBatch('{!r} is a Sprite: its position is a Python tuple, one for every state'.format(ch))
     if type(eng.backdrop).update is not _things.Backdrop.update:
       raise CannotBatch('the Backdrop has an update() of its own')
-    self.drapes = sorted(eng.things.keys())
+    self.drapes = sorted(eng.things.keys())          # every thing, ascending: _image()'s order
+    # A Sprite's state is a Python tuple and a flag, one value for every lane: among the states'
+    # arrays it is a one-cell "curtain" (empty while it does not show), and a frame whose states
+    # disagree about a sprite is split like one whose states branch differently (frame()).  An
+    # invisible sprite keeps no cell, so it has to stand where it stood at the start.
+    self.sprites = {ch: (ent.position.row, ent.position.col) for ch, ent in eng.things.items()
+                    if isinstance(ent, _things.Sprite)}
     old = eng._renderer
     chars = set(eng.things.keys()) | set(eng.backdrop.palette)
     self.renderer = _LanesRenderer(self.H, self.W, chars, device)
@@ -197,6 +202,8 @@ class _Frontier(object):
       if id(value) in remap:
         _put(container, key, remap[id(value)])
     for ch in self.drapes:
+      if ch in self.sprites:
+        continue
       ent = eng.things[ch]
       ent._curtain = lanes.wrap(ent._curtain.to(device).to(torch.uint8).unsqueeze(0).clone())
     self.slots = [(path, c, k) for path, c, k in _tensor_slots(eng)]
@@ -205,14 +212,50 @@ class _Frontier(object):
     self.reads0 = tabulate.FRAME_READS[0]
     self.z0 = ''.join(eng.things.keys())
 
+  def sprite_mask(self, ch, n):
+    """The one-cell curtain of sprite `ch` as it stands in the engine now, for n states."""
+    ent = self.eng.things[ch]
+    mask = torch.zeros((n, self.H, self.W), dtype=torch.uint8, device=self.device)
+    if ent.visible:
+      mask[:, ent.position.row, ent.position.col] = 1
+    elif (ent.position.row, ent.position.col) != self.sprites[ch]:
+      raise CannotBatch('{!r} is a Sprite that moves while it does not show'.format(ch))
+    return mask
+
+  def place_sprites(self, curtains):
+    """Every sprite where its mask says - one place for all the states of this frame, else the
+    frame is split (`Diverged`: states grouped by where the sprites stand)."""
+    if not self.sprites:
+      return
+    n = int(next(iter(curtains.values())).shape[0])
+    if n > 1:
+      flat = torch.cat([curtains[ch].reshape(n, -1) for ch in sorted(self.sprites)], dim=1)
+      if not bool((flat == flat[:1]).all()):
+        _, inverse = torch.unique(flat, dim=0, return_inverse=True)
+        raise Diverged('the states of this frame have their sprites in different places', inverse)
+    for ch in self.sprites:
+      ent = self.eng.things[ch]
+      cell = torch.nonzero(curtains[ch][0].reshape(-1)).reshape(-1)
+      if cell.numel() > 1:
+        raise CannotBatch('sprite {!r} on more than one cell'.format(ch))
+      if cell.numel():
+        ent._position = ent.Position(int(cell[0]) // self.W, int(cell[0]) % self.W)
+        ent._visible = True
+      else:
+        ent._position = ent.Position(*self.sprites[ch])
+        ent._visible = False
+
   def frame(self, curtains, a):
     """One frame of action `a` for N states (`curtains[ch]`: uint8 `[N, H, W]`).  Returns
     (next curtains, reward f32 [N] with NaN for None, discount, over, boards uint8 [N, H*W])."""
     eng = self.eng
     n = int(next(iter(curtains.values())).shape[0])
     self.renderer.n = n
+    self.place_sprites(curtains)
     with lanes._guard():
       for ch in self.drapes:
+        if ch in self.sprites:
+          continue
         ent = eng.things[ch]
         if not isinstance(ent._curtain, Lanes):
           raise CannotBatch('{!r} replaced its curtain by an ordinary tensor'.format(ch))
@@ -236,6 +279,9 @@ class _Frontier(object):
       raise CannotBatch('a discount that differs between states')
     nxt = {}
     for ch in self.drapes:
+      if ch in self.sprites:
+        nxt[ch] = self.sprite_mask(ch, n)
+        continue
       cur = eng.things[ch]._curtain
       if not isinstance(cur, Lanes):
         raise CannotBatch('{!r} replaced its curtain by an ordinary tensor'.format(ch))
@@ -340,7 +386,8 @@ def _trace(engine, actions, device, H, W, HW, chars):
   hidden0 = tabulate.hidden_image(probe, False)
   front = _Frontier(probe, actions, device)
   drapes = front.drapes                                   # ascending characters = _image()'s order
-  start = {ch: lanes.plain(front.eng.things[ch]._curtain).clone() for ch in drapes}
+  start = {ch: (front.sprite_mask(ch, 1) if ch in front.sprites
+                else lanes.plain(front.eng.things[ch]._curtain).clone()) for ch in drapes}
   for ch in drapes:
     if int(start[ch].max()) > 1:
       raise CannotBatch('the curtain of {!r} holds values other than 0 and 1'.format(ch))
@@ -719,9 +766,11 @@ def _render_states(front, curtains):
   eng = front.eng
   n = int(next(iter(curtains.values())).shape[0])
   front.renderer.n = n
+  front.place_sprites(curtains)
   with lanes._guard():
     for ch in front.drapes:
-      torch.Tensor.set_(eng.things[ch]._curtain, curtains[ch].clone())
+      if ch not in front.sprites:
+        torch.Tensor.set_(eng.things[ch]._curtain, curtains[ch].clone())
   eng._render()
   return lanes.plain(front.renderer._board).to(torch.uint8).reshape(n, front.H * front.W).clone()
 
@@ -752,7 +801,15 @@ def _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, 
   for s, a in sample:
     eng = tabulate.clone_engine(probe)
     for ch in drapes:
-      eng.things[ch].curtain.copy_(torch.from_numpy(curtain_of(s, ch).copy()))
+      ent, mask = eng.things[ch], curtain_of(s, ch)
+      if isinstance(ent, _things.Sprite):
+        at = np.flatnonzero(mask.reshape(-1))
+        if len(at):
+          ent._position, ent._visible = ent.Position(int(at[0]) // W, int(at[0]) % W), True
+        else:
+          ent._visible = False
+      else:
+        ent.curtain.copy_(torch.from_numpy(mask.copy()))
     eng._render()
     obs, got_reward, discount = eng.play(copy.deepcopy(actions[a]))
     t = int(nxt[s, a])
@@ -761,7 +818,14 @@ def _cross_check(probe, actions, drapes, movers, start_np, cells, present, nxt, 
           np.array([tabulate.reward_f32(got_reward)]).view(np.uint32)[0] ==
           np.array([np.float32(reward[s, a])]).view(np.uint32)[0])
     for ch in drapes:
-      ok = ok and np.array_equal(eng.things[ch].curtain.detach().numpy().astype(np.uint8), curtain_of(t, ch))
+      ent = eng.things[ch]
+      if isinstance(ent, _things.Sprite):
+        now = np.zeros((H, W), np.uint8)
+        if ent.visible:
+          now[ent.position.row, ent.position.col] = 1
+      else:
+        now = ent.curtain.detach().numpy().astype(np.uint8)
+      ok = ok and np.array_equal(now, curtain_of(t, ch))
     if not ok:
       raise CannotBatch('a frame run lane by lane disagrees with the same frame on the generic tier '
                         '(state {}, action {})'.format(s, a))

@@ -388,3 +388,48 @@ def spy_through_a_class_attribute():
 
 
 SPIES.append((spy_through_a_class_attribute, 'a live Mover through the class attribute ClassAttrSpy.partner'))
+
+
+# ---- a Sprite agent, PyColab style: Python ints and branches; and a crate that reads where it stands
+class Porter(things.Sprite):
+  """Walks one cell; walls and a crate that cannot give way stop it (it looks a cell further)."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    dr, dc = ((0, -1), (0, 1), (-1, 0), (1, 0), (0, 0))[int(actions.argmax())]
+    r, c = self.position.row + dr, self.position.col + dc
+    if layers['#'][r, c]:
+      return
+    if all_things['X'].curtain[r, c]:
+      if layers['#'][r + dr, c + dc]:
+        return                                   # the crate is against a wall: nobody moves
+    self._position = self.Position(r, c)
+    the_plot.add_reward(-0.25)
+
+
+class Crate(things.Drape):
+  """Updated AFTER the porter: if he now stands on it, it moves on one cell the way he came."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    p = all_things['P'].position
+    if self.curtain[p.row, p.col]:
+      dr, dc = ((0, -1), (0, 1), (-1, 0), (1, 0), (0, 0))[int(actions.argmax())]
+      self.curtain[p.row, p.col] = 0
+      self.curtain[p.row + dr, p.col + dc] = 1
+      if all_things['G'].curtain[p.row + dr, p.col + dc]:
+        the_plot.add_reward(5.0)
+        the_plot.terminate_episode()
+
+
+PORTER_ART = ['#######', '#P    #', '# X   #', '#   G #', '#     #', '#######']
+
+
+def porter(art=None):
+  def build():
+    return ascii_art_to_game(art or PORTER_ART, what_lies_beneath=' ', sprites={'P': Porter},
+                             drapes={'X': Crate, '#': things.FixedDrape, 'G': things.FixedDrape},
+                             z_order='G#XP', update_schedule='PX#G')
+  return build

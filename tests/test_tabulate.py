@@ -350,7 +350,10 @@ def test_a_second_make_game_of_the_same_game_reuses_the_tabulation():
   assert tabulate.fingerprint(game, tabulate.default_actions()) is None
 
 
-def test_too_large_a_state_space_is_refused_with_a_pointer_to_the_rule_library():
+def test_too_large_a_state_space_is_refused_with_a_pointer_to_the_rule_library(monkeypatch):
+  # (the one-frame-per-play walker's budget; the lane walker, which takes this game since round 5,
+  # spends 65 frames on its 388 states)
+  monkeypatch.setenv('CAMPX_TABULATE', 'walk')
   with pytest.raises(tabulate.TabulationError, match='campx_amd.rules'):
     tabulate.trace(traced_games.mirror(), max_plays=50)
 

@@ -325,7 +325,7 @@ def test_a_warehouse_of_half_a_million_states_tabulates_in_seconds_and_predicts_
 def test_games_the_lane_walker_does_not_take_fall_back_and_say_why(monkeypatch):
   monkeypatch.delenv('CAMPX_TABULATE', raising=False)
   for build, why in ((traced_games.burrow, r'changes the z-order'),
-                     (traced_games.mirror, r"is a Sprite")):
+                     (traced_games.time_limit, r'the_plot\.frame|something besides the curtains')):
     game = tabulate.trace(build(), cache=False)
     assert game.n_states > 1
     assert tabulate.LAST_WALK[0].startswith('one frame per play (lanes: ') and \
@@ -408,6 +408,27 @@ def test_games_at_the_edges_are_tabulated_the_same_or_handed_to_the_walk(a, b, e
   assert outcome['walk'].n_states == outcome['auto'].n_states > 1
   assert _first_difference(outcome['walk'], outcome['auto']) is None
   _predicts_live_play(outcome['auto'], lanes_probes.game(a, b))
+
+
+def test_a_sprite_agent_written_with_python_ints_and_branches_is_tabulated_on_lanes(monkeypatch):
+  """PyColab's usual style - the agent a Sprite whose update() is integer arithmetic and `if`s on
+  what it finds, a crate that reads where the agent stands: frames are split by where the sprite
+  stands and by how the branches fall; same table as the one-frame walker, and it predicts live
+  play.  On a larger board: thousands of states in seconds."""
+  monkeypatch.setenv('CAMPX_TABULATE', 'walk')
+  walked = tabulate.trace(lanes_probes.porter()(), cache=False)
+  monkeypatch.setenv('CAMPX_TABULATE', 'batch')
+  batched = tabulate.trace(lanes_probes.porter()(), cache=False)
+  assert tabulate.LAST_WALK[0].startswith('lanes: '), tabulate.LAST_WALK[0]
+  assert walked.n_states == batched.n_states > 100 and _first_difference(walked, batched) is None
+  _predicts_live_play(batched, lanes_probes.porter(), frames=200)
+  big = ['############', '#P         #', '# X    #   #', '#      #   #', '#   ####   #', '#          #',
+         '#      G   #', '#   #      #', '#   #      #', '############']
+  t0 = time.perf_counter()
+  table = tabulate.trace(lanes_probes.porter(big)(), cache=False)
+  assert tabulate.LAST_WALK[0].startswith('lanes: ') and table.n_states > 3000
+  assert time.perf_counter() - t0 < 60
+  _predicts_live_play(table, lanes_probes.porter(big), frames=300, seed=9)
 
 
 @pytest.mark.parametrize('build,what', lanes_probes.SPIES, ids=[b.__name__ for b, _ in lanes_probes.SPIES])
