@@ -22,8 +22,11 @@ import torch
 from torch.utils import _pytree as pytree
 
 
-class CannotBatch(Exception):
-  """The game did something that has no lane-by-lane meaning (the message says what)."""
+class CannotBatch(BaseException):
+  """The game did something that has no lane-by-lane meaning (the message says what).
+  (A BaseException: a game class that wraps its own code in `except Exception:` must not swallow
+  it - least of all `Diverged`, after which the frame would go on down the wrong branch for some
+  of its states.)"""
 
 
 class Diverged(CannotBatch):

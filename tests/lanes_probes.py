@@ -433,3 +433,19 @@ def porter(art=None):
                              drapes={'X': Crate, '#': things.FixedDrape, 'G': things.FixedDrape},
                              z_order='G#XP', update_schedule='PX#G')
   return build
+
+
+class Swallower(Base):     # wraps its branch in `except Exception`: must not swallow the frame's split
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    new = self.step(actions.byte(), layers)
+    try:
+      if (new * layers['G']).sum() > 0:
+        the_plot.add_reward(2.0)
+    except Exception:       # noqa: BLE001
+      the_plot.add_reward(-100.0)
+    self.curtain.set_(new)
+
+
+CASES.append((Swallower, Still, 'lanes: '))
