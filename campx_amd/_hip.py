@@ -58,7 +58,7 @@ class CampxFlowState(ctypes.Structure):
   """include/campx_hip.h: what the library remembers about a scratch block of one-launch
   rollouts, in the caller's (host) memory."""
   _fields_ = [('tag', ctypes.c_int64), ('B', ctypes.c_int64), ('T', ctypes.c_int64),
-              ('pitch', ctypes.c_int64)]
+              ('pitch', ctypes.c_int64), ('n_dyn', ctypes.c_int64), ('block', ctypes.c_int64)]
 
 
 ERR_FLOW_TIMEOUT = 1

@@ -262,7 +262,7 @@ void rollout(const Tensor& spec_host, const Tensor& spec_dev, Tensor& pos, Tenso
                 "campx::rollout: scratch must be a contiguous int32 tensor on ", g.dev);
     out.overlap_ctl = reinterpret_cast<uint32_t*>(scratch->data_ptr());
     out.overlap_ctl_bytes = scratch->numel() * 4;
-    // the block's CampxFlowState lives with its owner, in host memory: four int64 (zeroed when
+    // the block's CampxFlowState lives with its owner, in host memory: six int64 (zeroed when
     // the block was allocated); without it, or without an error word, the library runs two launches
     if (scratch_state.has_value()) {
       TORCH_CHECK(scratch_state->device().is_cpu() && scratch_state->scalar_type() == at::kLong &&
@@ -356,6 +356,10 @@ void render(const Tensor& spec_host, const Tensor& spec_dev, const Tensor& trace
 // holds no state); `resync`: work has been issued on the caller's stream since the last
 // pipelined call that the update pass must come after (state set up by other calls).
 struct PipeStreams {
+  // held for the whole body of rollout_pipelined: the op releases the GIL, so two actor threads
+  // on one device would otherwise interleave their event records / waits and rehash `readers`
+  // under each other (round 5 advice).  One pipelined rollout per device at a time is issued.
+  std::mutex busy;
   hipStream_t side = nullptr;
   hipEvent_t updated = nullptr, synced = nullptr;
   std::unordered_map<const void*, hipEvent_t> readers;   // trace buffer -> its last render
@@ -422,6 +426,7 @@ void rollout_pipelined(const Tensor& spec_host, const Tensor& spec_dev, Tensor& 
   const c10::hip::HIPGuardMasqueradingAsCUDA guard(g.dev);
   hipStream_t main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
   PipeStreams& p = pipe_streams(g.dev.index());
+  std::lock_guard<std::mutex> one_at_a_time(p.busy);
   if (resync) {       // everything issued on the caller's stream so far, renders included
     hip_ok(hipEventRecord(p.synced, main), "hipEventRecord");
     hip_ok(hipStreamWaitEvent(p.side, p.synced, 0), "hipStreamWaitEvent");
@@ -437,7 +442,7 @@ void rollout_pipelined(const Tensor& spec_host, const Tensor& spec_dev, Tensor& 
     for (auto& kept : p.readers) (void)hipEventDestroy(kept.second);
     p.readers.clear();
   }
-  hipEvent_t& reader = p.readers[upd.trace];
+  hipEvent_t reader = p.readers[upd.trace];      // (by value: the map may rehash)
   if (reader && !resync) hip_ok(hipStreamWaitEvent(p.side, reader, 0), "hipStreamWaitEvent");
   check_ok(campx_update_launch(g.spec_host, g.spec_dev, g.state,
                                reinterpret_cast<const int8_t*>(actions.data_ptr()), upd, g.B, (int32_t)T,
@@ -446,7 +451,10 @@ void rollout_pipelined(const Tensor& spec_host, const Tensor& spec_dev, Tensor& 
   hip_ok(hipEventRecord(p.updated, p.side), "hipEventRecord");
   hip_ok(hipStreamWaitEvent(main, p.updated, 0), "hipStreamWaitEvent");
   check_ok(campx_render_launch(g.spec_host, g.spec_dev, ren, g.B, (int32_t)T, main), "campx_render_launch");
-  if (!reader) hip_ok(hipEventCreateWithFlags(&reader, hipEventDisableTiming), "hipEventCreateWithFlags");
+  if (!reader) {
+    hip_ok(hipEventCreateWithFlags(&reader, hipEventDisableTiming), "hipEventCreateWithFlags");
+    p.readers[upd.trace] = reader;
+  }
   hip_ok(hipEventRecord(reader, main), "hipEventRecord");
 }
 

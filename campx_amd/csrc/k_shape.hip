@@ -497,7 +497,9 @@ __global__ __launch_bounds__(kWave * kShapeMaxReplicas) void shape_update_split_
   // (the carried trail words: shape_words_from_backdrop_kernel made them from the backdrop state)
   for (int i = lane; i < SH * kWave; i += kWave)
     trail[i] = (!reset_first && i < n_words) ? state_words[env0 * SH + i] : 0ull;
-  __syncthreads();
+  // (the carried state is loaded BEFORE the barrier: replica 0 writes the same words at the end of
+  // a chunk, and with a chunk of one or two frames nothing else would order another replica's
+  // loads before those stores - round 5 advice)
   uint32_t orow[2] = {0u, 0u}, ocol[2] = {0u, 0u};
   int over = 0, bad = 0;
   float ret = 0.0f;
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(kWave * kShapeMaxReplicas) void shape_update_split_
     over = st.done[env];
     if (st.ret) ret = st.ret[env];
   }
+  __syncthreads();
   uint32_t trail_pos[4] = {0u, 0u, 0u, 0u};   // sprite s: row | col << 8 in half s & 1 of word s >> 1
   // (the sprites' constants, fetched once: thing word and the byte of the offset words it owns)
   uint32_t tz[KS > 0 ? KS : 1], tth[KS > 0 ? KS : 1];

@@ -1695,10 +1695,11 @@ int64_t flow_scratch_bytes(int64_t B, int32_t T) {
 // which the 255-tag wrap would make current again), or the state is fresh: then the whole block is
 // zeroed first (stream-ordered; tag 0 is never used).
 static uint32_t next_flow_tag(CampxFlowState& l, void* block, int64_t block_bytes, int64_t B, int32_t T,
-                              int64_t pitch, hipStream_t stream) {
-  if (l.tag < 1 || l.tag > 255 || l.B != B || l.T != T || l.pitch != pitch) {
+                              int64_t pitch, int n_dyn, hipStream_t stream) {
+  if (l.tag < 1 || l.tag > 255 || l.B != B || l.T != T || l.pitch != pitch || l.n_dyn != n_dyn ||
+      l.block != (int64_t)(intptr_t)block) {
     (void)hipMemsetAsync(block, 0, (size_t)block_bytes, stream);
-    l = CampxFlowState{0, B, T, pitch};
+    l = CampxFlowState{0, B, T, pitch, n_dyn, (int64_t)(intptr_t)block};
   }
   l.tag = l.tag % 255 + 1;
   return (uint32_t)l.tag;
@@ -1763,7 +1764,7 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
     if (!st.pair_table) return CAMPX_EINVAL;
     if (flow) {
       rr.tagged = reinterpret_cast<uint16_t*>(out.overlap_ctl + 4);
-      rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, stream);
+      rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, s.n_dyn, stream);
       rr.max_naps = flow_max_naps();
       rr.debug_delay = flow_debug_delay();
       rr.error_flag = out.error_flag;
@@ -1794,7 +1795,7 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
 #undef CAMPX_PIPE_MULTI
   } else if (flow) {
     rr.tagged = reinterpret_cast<uint16_t*>(out.overlap_ctl + 4);
-    rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, stream);
+    rr.tag = next_flow_tag(*out.flow_state, out.overlap_ctl, out.overlap_ctl_bytes, B, T, rr.pitch, s.n_dyn, stream);
     rr.max_naps = flow_max_naps();
     rr.debug_delay = flow_debug_delay();
     rr.error_flag = out.error_flag;

@@ -307,18 +307,23 @@ class Engine(object):
         # games above 128 cells go the same way (hundreds of states).  Games of rigidly
         # translating multi-cell things (the Hello World notebook's own classes) cannot be
         # enumerated; they are recognised for the shape tier instead (campx_amd/recognise.py).
-        from . import recognise, tabulate
-        actions = recognise.detect_actions(self)
-        if recognise.looks_like_shapes(self, actions):
-          recognised = recognise.shapes(self, actions)
-        else:
-          try:
-            traced = tabulate.trace(self, actions=actions)
-          except tabulate.TabulationError as refusal:
+        from . import chance, recognise, tabulate
+        # (one guard round all of it - the action-format probe and the shape probe run the game's
+        # classes too: a game that draws random numbers or reads the clock is refused by name)
+        with chance.forbidden(tabulate.TabulationError):
+          actions = recognise.detect_actions(self)
+          if recognise.looks_like_shapes(self, actions):
+            recognised = recognise.shapes(self, actions)
+          else:
             try:
-              recognised = recognise.shapes(self, actions)
-            except recognise.RecogniseError as other:
-              raise tabulate.TabulationError('{} (and {})'.format(refusal, other))
+              traced = tabulate.trace(self, actions=actions)
+            except tabulate.TabulationError as refusal:
+              if getattr(refusal, 'campx_chance', False):
+                raise
+              try:
+                recognised = recognise.shapes(self, actions)
+              except recognise.RecogniseError as other:
+                raise tabulate.TabulationError('{} (and {})'.format(refusal, other))
       elif not gamespec.is_shape_rule_game(self):
         # a rule game the rule lowering does not take (a tile painted in front of the agent that
         # does not block it, more rules than the interpreter's program holds ...): the rule classes
@@ -404,14 +409,15 @@ class Engine(object):
                          'been through its_showtime()')
     return self._fused.rollout_buffers(T, **kwargs)
 
-  def rollout_deferred(self, actions, out, reset_first=False):
+  def rollout_deferred(self, actions, out, reset_first=False, actions_ready=False):
     """Fused tiers only: T frames whose observations may arrive with the NEXT call - for action
     streams that do not wait for them.  Returns the previous call's buffers, complete; see
     `fused.FusedGame.rollout_deferred` (tiers without a shared launch run the rollout whole)."""
     if self._fused is None:
       raise RuntimeError('rollout_deferred() needs a batched Engine (batch=B) that has '
                          'been through its_showtime()')
-    return self._fused.rollout_deferred(actions, out, reset_first=reset_first)
+    return self._fused.rollout_deferred(actions, out, reset_first=reset_first,
+                                        actions_ready=actions_ready)
 
   def flush(self):
     """The buffers of the last `rollout_deferred()` call, complete (None if there is none)."""

@@ -185,7 +185,7 @@ class FusedGame(object):
     self._update_render = _hip.ops.update_render.default
     self._rollout_pipelined = _hip.ops.rollout_pipelined.default
     self._flow_scratch = None
-    self._flow_state = None    # the scratch block's CampxFlowState: host memory, ours (int64[4])
+    self._flow_state = None    # the scratch block's CampxFlowState: host memory, ours (int64[6])
     self._flow_shared = {}     # (T, pitch) -> whether the library runs such a rollout as one launch
     # what a launch could not do although its call returned: bits the kernels raise in pinned
     # host memory (include/campx_hip.h CampxOutputs.error_flag), looked at after EVERY launch
@@ -233,14 +233,20 @@ class FusedGame(object):
                        'exactly one-hot)'.format(n, gamespec.N_ACTIONS - 1))
 
   def check_actions(self):
-    """Synchronise and raise ValueError if any consumed action id was outside 0..4."""
+    """Synchronise and raise ValueError if any consumed action id was outside 0..4 (and
+    RuntimeError if any launch so far raised its error word: after the synchronise that is
+    definitive for every rollout issued)."""
     torch.cuda.synchronize(self.device)
+    self.check_ok()
     self._raise_bad()
 
   def check_ok(self):
     """Raise RuntimeError if a launch reported, through the error word, that it could not do what
-    it was asked to (a plain host read; `check_ok()` after a synchronise is definitive).  Called
-    after every rollout launch, whatever `validate_actions` says."""
+    it was asked to.  A plain host read of pinned memory: right after an asynchronous launch it
+    can only show what an EARLIER launch raised (the rollout named in the message may be a
+    previous one); after a synchronise - `check_actions()`, `flush()` of the last deferred
+    rollout followed by one - it is definitive.  Called after every rollout launch, whatever
+    `validate_actions` says."""
     bits = int(self._err_flag_view[0])
     if bits:
       self._err_flag_view[0] = 0
@@ -248,7 +254,8 @@ class FusedGame(object):
       if bits & _hip.ERR_FLOW_TIMEOUT:
         what.append('a render wave of a one-launch rollout (pipe_table_kernel<true>) waited for '
                     'its own launch\'s trace entries until it gave up and wrote frames from '
-                    'stale ones: the observations of that rollout are WRONG (two launches '
+                    'stale ones: the observations of that rollout - this call\'s or an earlier '
+                    'one\'s, the flag is read without synchronising - are WRONG (two launches '
                     'sharing one scratch block at the same time?)')
       if bits & ~_hip.ERR_FLOW_TIMEOUT:
         what.append('error bits {:#x}'.format(bits & ~_hip.ERR_FLOW_TIMEOUT))
@@ -394,7 +401,7 @@ class FusedGame(object):
     need = (int(_hip.lib.campx_flow_scratch_bytes(self.batch, T)) + 3) // 4
     if self._flow_scratch is None or self._flow_scratch.numel() < need:
       self._flow_scratch = torch.zeros(need, dtype=torch.int32, device=self.device)
-      self._flow_state = torch.zeros(4, dtype=torch.int64)
+      self._flow_state = torch.zeros(ctypes.sizeof(_hip.CampxFlowState) // 8, dtype=torch.int64)
     return self._flow_scratch, self._flow_state
 
   def rollout_buffers(self, T, keep_obs=True, want_board=False,
@@ -514,12 +521,14 @@ class FusedGame(object):
         # one op does the two-stream choreography (csrc/campx_torch.cpp rollout_pipelined: the
         # update pass on a high-priority side stream, the render on this stream behind it; from
         # Python - below, kept for the CU-subset A/B - the same calls cost the host 36-46 us)
+        # (ids made from the caller's actions by kernels on THIS stream - clamp / to(int8) /
+        # onehot_to_ids - are work the side stream has to come after: resync for this call)
         self._rollout_pipelined(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
                                 self._pair_table, ids, out['obs'], out['board'], out['reward'],
                                 out['discount'], out['done'], out['perf'], out['trace'],
                                 self._bad if validate else None,
                                 self._bad_flag if validate else None, bool(reset_first),
-                                not self._aux_in_sync)
+                                not self._aux_in_sync or ids is not actions)
         self._aux_in_sync = True
         self.frame = T if reset_first else self.frame + T
         self.check_ok()
@@ -530,8 +539,8 @@ class FusedGame(object):
       if self._aux is None:
         self._aux = self._side_stream()
         self._aux_event = torch.cuda.Event()
-      if not self._aux_in_sync:
-        self._aux.wait_stream(main)      # once: state set up by earlier non-pipelined work
+      if not self._aux_in_sync or ids is not actions:
+        self._aux.wait_stream(main)      # state set up by earlier non-pipelined work; ids made on `main`
         self._aux_in_sync = True
         self._trace_readers.clear()      # ... which also covers every render issued so far
       # The side stream runs ahead of the main one without bound; what it may not do is
@@ -569,7 +578,7 @@ class FusedGame(object):
       self._after_launch()
     return out
 
-  def rollout_deferred(self, actions, out, reset_first=False):
+  def rollout_deferred(self, actions, out, reset_first=False, actions_ready=False):
     """Rollouts pipelined across calls: T frames of update pass now, their observations with
     the NEXT call.
 
@@ -596,10 +605,19 @@ class FusedGame(object):
           of the previous call - alternate two of them.  They may share 'obs'
           (`rollout_buffers(T, share=first)`): a rollout's observations are complete after the
           next call and, shared, overwritten by the one after that.
+      actions_ready: the caller's promise that `actions` and `out` are not being produced or
+          read by work still queued on the current stream (the two promises of
+          `rollout(pipelined=True)`): only then may a multi-mover game past the shared launch's
+          bounds run its update pass on the side stream, AHEAD of what the current stream holds.
+          Without it (the default) everything this call issues is in order on the current stream
+          (round 5 took the two-stream route silently: actions made by a `torch.randint` on the
+          current stream could be read before they were written).
     Returns:
       the previous call's dict, whose 'obs' this launch completes; None on the first call.
     """
     T = int(actions.shape[0])
+    if T < 1:
+      raise ValueError('a rollout needs at least one frame: actions [T, B] with T >= 1')
     if (torch.is_tensor(actions) and actions.dtype == torch.int8
         and actions.device == self.device and actions.shape == (T, self.batch)
         and actions.is_contiguous()):
@@ -639,13 +657,14 @@ class FusedGame(object):
         self._update(*head)
         self._deferred, self._deferred_rendered = out, False
         self.frame = T if reset_first else self.frame + T
+        self.check_ok()
         if validate:
           self._after_launch()
         return prev
       # Separate observation buffers: the whole rollout now, rendered while its trace is still
       # cached.  `out` is complete a call early; what the caller sees is the same.
       self.flush()
-      if (out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
+      if (actions_ready and out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
           self.batch > 8192 and (self.n_dyn >= 3 or self.batch < 32768)):
         # Games of two to four movers past the shared launch's bounds (16 384 environments with
         # two movers, 8 192 with more): the update pass on the (high-priority) side stream, under
@@ -682,6 +701,7 @@ class FusedGame(object):
       self._update(*head)
     self._deferred, self._deferred_rendered = out, False
     self.frame = T if reset_first else self.frame + T
+    self.check_ok()
     if validate:
       self._after_launch()
     return prev
@@ -693,4 +713,5 @@ class FusedGame(object):
     if prev is not None and not self._deferred_rendered:
       self._render(self._spec_host, self._spec_dev, prev['trace'], prev['obs'], None)
     self._deferred_rendered = False
+    self.check_ok()
     return prev

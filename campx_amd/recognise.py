@@ -570,7 +570,15 @@ def looks_like_shapes(engine, actions):
 def shapes(engine, actions=None):
   """A set-up (not started) `Engine` of arbitrary classes -> the `gamespec.GameDescription`
   `gamespec.describe()` gives for the same game written with `rules.RollingDrape` /
-  `rules.SlidingSprite` / `FixedDrape`, or `RecogniseError`.  `engine` is not touched."""
+  `rules.SlidingSprite` / `FixedDrape`, or `RecogniseError`.  `engine` is not touched.  A game
+  that draws random numbers or reads the clock is refused (`tabulate.TabulationError`:
+  campx_amd/chance.py - stand-ins for the sources of chance while the classes are run)."""
+  from . import chance
+  with chance.forbidden(tabulate.TabulationError):
+    return _shapes(engine, actions)
+
+
+def _shapes(engine, actions):
   if engine.backdrop is None:
     raise ValueError('the Engine has no Backdrop yet')
   H, W = engine.rows, engine.cols

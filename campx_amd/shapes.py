@@ -197,7 +197,7 @@ class ShapeGame(object):
                 done=torch.empty((T, B), dtype=torch.uint8, device=dev),
                 perf=None, trace=trace)
 
-  def rollout_deferred(self, actions, out, reset_first=False):
+  def rollout_deferred(self, actions, out, reset_first=False, actions_ready=False):
     """`FusedGame.rollout_deferred` for this tier, which has no shared launch (one kernel does
     update and render): the rollout is run whole, at once, and `out` is simply complete a call
     early; returns the previous call's dict (None on the first)."""

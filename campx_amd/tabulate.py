@@ -84,6 +84,7 @@ import sys
 import numpy as np
 import torch
 
+from . import chance
 from . import gamespec
 from . import things as _things
 
@@ -587,6 +588,9 @@ def _live_in_value(x, live, depth, seen):
     return None
   if isinstance(x, live):
     return 'a live {}'.format(type(x).__name__)
+  source = chance.named_source(x)      # a generator object, a bound method of one, a clock
+  if source:
+    return source
   seen.add(id(x))
   if isinstance(x, (list, tuple, set, frozenset)):
     for item in x:
@@ -690,6 +694,11 @@ def reached_behind_the_engine(engine):
     if ent is None:
       continue
     found = _live_in_class(type(ent), live, 0, seen)
+    if found and not found.startswith('a live '):
+      return ('{!r} ({}): its code names {}.  A batched Engine runs a game from a table of what its '
+              'classes do in each state, which a game of chance (or of the clock) does not have; run '
+              'it on the generic tier (batch=None)'.format(
+                  getattr(ent, 'character', 'backdrop'), type(ent).__name__, found))
     if found:
       return ('{!r} ({}): its code reaches {}.  update() is handed everything it may read '
               '(layers, all_things, the_plot); state reached any other way is invisible to the '
@@ -749,7 +758,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
       if key in _CACHE:
         _CACHE.move_to_end(key)
         return _CACHE[key]
-  game = _trace(engine, actions, max_plays)
+  with chance.forbidden(TabulationError):     # (random numbers, clocks: refused by proof)
+    game = _trace(engine, actions, max_plays)
   if key is not None:
     _CACHE[key] = game
     while len(_CACHE) > CACHE_SIZE:

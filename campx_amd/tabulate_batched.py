@@ -326,6 +326,15 @@ def _frame_any(front, curtains, a, budget=None):
     return (nxt, r, torch.full((n,), discount, dtype=torch.float32, device=dev),
             torch.full((n,), bool(over), dtype=torch.bool, device=dev), board)
   except Diverged as split:
+    # What the abandoned frame did BEFORE the branch that split it stays in the lifted engine:
+    # curtains are re-bound by the next frame(), but an attribute written, a Plot entry set or a
+    # plain tensor edited in place would be the pre-state of the sub-groups' re-runs - and a
+    # write the rest of the frame undoes (a flag set, read, cleared) would pass the image check
+    # of the completed frames.  So: the abandoned prefix must have changed nothing.
+    if _plain_image(front.eng) != front.image0:
+      raise CannotBatch('{} - after the frame had already changed something besides the curtains '
+                        '(an entity attribute, a Plot entry): it cannot be run again for each '
+                        'group of states from there'.format(split))
     values = split.values.reshape(-1)
     if values.numel() != n or (values.is_floating_point() and bool(torch.isnan(values).any())):
       raise CannotBatch(str(split))          # (not this frame's lanes, or a NaN: no grouping by value)
@@ -352,7 +361,14 @@ def _frame_any(front, curtains, a, budget=None):
 
 def trace(engine, actions=None, max_plays=None, device=None):
   """The `TracedGame` `tabulate.trace()` would return, from many-states-per-call frames; raises
-  `CannotBatch` for games this tier does not take (module docstring)."""
+  `CannotBatch` for games this tier does not take (module docstring).  A game that draws random
+  numbers or reads the clock is refused (`tabulate.TabulationError`; campx_amd/chance.py)."""
+  from . import chance
+  with chance.forbidden(tabulate.TabulationError):
+    return _trace_on_lanes(engine, actions, max_plays, device)
+
+
+def _trace_on_lanes(engine, actions, max_plays, device):
   if engine.backdrop is None:
     raise ValueError('the Engine has no Backdrop yet')
   H, W = engine.rows, engine.cols

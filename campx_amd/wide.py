@@ -136,7 +136,7 @@ class WideGame(fused.FusedGame):
     out['trace'] = self._trace_rows(T)
     return out
 
-  def rollout_deferred(self, actions, out, reset_first=False):
+  def rollout_deferred(self, actions, out, reset_first=False, actions_ready=False):
     """`FusedGame.rollout_deferred` for this tier, which has no shared launch: the rollout is
     run whole, at once, and `out` is simply complete a call early; returns the previous call's
     dict (None on the first)."""

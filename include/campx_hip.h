@@ -207,6 +207,10 @@ typedef struct CampxFlowState {
   int64_t tag;    /* 1..255, of the block's last launch; 0: none yet (the block is cleared first) */
   int64_t B, T;   /* what the block's entries were written for */
   int64_t pitch;  /* the row pitch they were written with */
+  int64_t n_dyn;  /* how many movers' planes they were written for (a game with MORE movers on the
+                     same block would find stale tags in the extra planes) */
+  int64_t block;  /* the address of the block this state describes (a state handed over with
+                     another block starts afresh) */
 } CampxFlowState;
 
 typedef struct CampxOutputs {

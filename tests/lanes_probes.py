@@ -274,7 +274,7 @@ def game(a, b=Still):
 # (class of 'A', class of 'B', what the auto walker's LAST_WALK must start with, or the refusal both give)
 CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes: something besides the curtains'),
          (ViewWrite, Still, 'lanes: '), (PlotMem, Still, "one frame per play (lanes: the_plot['prev']"),
-         (Rand, Still, 'REFUSED: keeps state outside'), (Nonzero, Still, 'one frame per play (lanes: nonzero'),
+         (Rand, Still, 'REFUSED: draws random numbers in Rand.update (torch.rand)'), (Nonzero, Still, 'one frame per play (lanes: nonzero'),
          (Roll, Still, 'lanes: '), (Terminator, Still, 'lanes: '),
          (Grower, Still, 'REFUSED: covers'), (Indexer, Still, 'one frame per play (lanes: __getitem__'),
          (Float, Still, 'lanes: '), (ChangeZ, Still, 'one frame per play (lanes: the game changes the z-order'),

@@ -1,0 +1,280 @@
+"""Games of chance are refused by proof, in every front end (campx_amd/chance.py).
+
+Round 5's verdict: an `update()` that draws `random.random() < 0.02` was accepted five to eight
+times in ten by the lane tabulator (one Python call per LEVEL of the state graph: ~30 frames + 53
+sampled replays to see the draw fire) and then ran on the kernels with the reward table of one
+draw.  The reference's games are deterministic by construction (examples/boat_race.py:35-91);
+"non-deterministic games" are out of scope - so they must be refused, not
+sampled.  Here: the verdict's probe classes (rare draws through `random`, `torch`, `numpy.random`,
+the clock), draws through references no stand-in sees, draws the game's own `except` swallows -
+refused in `walk`, `auto` and `batch` modes and by the shape recogniser, in ten seeds out of ten,
+with a message that names class and method; every entry point restored afterwards; and games
+that do none of this tabulate as before (the rest of the suite holds the reference's boat race
+and Demo cells to the committed fixtures through the same guard).
+"""
+
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from campx import things
+from campx_amd import chance, recognise, tabulate
+from conftest import REPO
+import lanes_probes
+
+P = 0.02          # how rarely the probes' draws fire
+
+
+class RareRandom(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if random.random() < P else 0.0)
+
+
+class RareTorch(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if float(torch.rand(())) < P else 0.0)
+
+
+class RareNumpy(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if np.random.rand() < P else 0.0)
+
+
+class Clock(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if time.time() % 50 < 1 else 0.0)     # one second in fifty
+
+
+class InPlace(lanes_probes.Base):         # torch's in-place samplers
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if float(torch.empty(()).uniform_()) < P else 0.0)
+
+
+def _noise():
+  return random.randint(0, 999) < 1000 * P
+
+
+class ThroughAHelper(lanes_probes.Base):  # the draw is a module-level function's, two calls down
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if _noise() else 0.0)
+
+
+class Swallows(lanes_probes.Base):        # ... and the game's own `except` eats the refusal
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    try:
+      lucky = random.random() < P
+    except Exception:                     # noqa: BLE001 - what a defensive class does
+      lucky = False
+    the_plot.add_reward(1.0 if lucky else 0.0)
+
+
+class OsEntropy(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if os.urandom(1)[0] < 256 * P else 0.0)
+
+
+class UnseededGenerator(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if np.random.default_rng().random() < P else 0.0)
+
+
+class BehindTheStandIns(lanes_probes.Base):
+  """The legacy generator's own method, through the library module: no attribute of `numpy.random`
+  is looked up, so no stand-in is in the way - the generator's state moving gives it away."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if np.random.mtrand._rand.random_sample() < P else 0.0)
+
+
+from random import random as _from_import_draw        # noqa: E402 - bound before any guard
+from time import perf_counter as _from_import_clock   # noqa: E402
+_OWN_STREAM = random.Random(5)
+
+
+class FromImport(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if _from_import_draw() < P else 0.0)
+
+
+class FromImportClock(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if _from_import_clock() % 50 < 1 else 0.0)
+
+
+class OwnStream(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if _OWN_STREAM.random() < P else 0.0)
+
+
+class SeededEveryFrame(lanes_probes.Base):
+  """NOT a game of chance: a generator made from a constant seed inside the frame is a function of
+  that seed - and so is a torch sampler handed an explicitly seeded generator."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    g = torch.Generator().manual_seed(11)
+    bonus = float(np.random.default_rng(3).integers(0, 4)) + float(torch.randint(0, 3, (), generator=g))
+    the_plot.add_reward(bonus)
+
+
+DYNAMIC = [(RareRandom, r'draws random numbers in RareRandom\.update \(random\.random\)'),
+           (RareTorch, r'draws random numbers in RareTorch\.update \(torch\.rand\)'),
+           (RareNumpy, r'draws random numbers in RareNumpy\.update \(numpy\.random\.rand\)'),
+           (Clock, r'reads the clock in Clock\.update \(time\.time\)'),
+           (InPlace, r'draws random numbers in InPlace\.update \(torch\.Tensor\.uniform_\)'),
+           (ThroughAHelper, r'draws random numbers in ThroughAHelper\.update \(random\.randint\)'),
+           (Swallows, r'draws random numbers in Swallows\.update \(random\.random\)'),
+           (OsEntropy, r'draws random numbers in OsEntropy\.update \(os\.urandom\)'),
+           (UnseededGenerator, r'draws random numbers in UnseededGenerator\.update \(numpy\.random\.default_rng\(\) '
+                               r'without a seed\)'),
+           (BehindTheStandIns, r'drew from the process-wide generator of numpy\.random')]
+STATIC = [(FromImport, r"its code names a method of a random number generator \(random\.Random\.random\) through "
+                       r"the module global '_from_import_draw'"),
+          (FromImportClock, r"its code names the clock time\.perf_counter through the module global"),
+          (OwnStream, r"its code names a random number generator \(random\.Random\) through the module global "
+                      r"'_OWN_STREAM'")]
+
+
+def _entry_points():
+  return (random.random, random.randint, np.random.rand, np.random.default_rng, torch.rand, torch.randint,
+          torch.Tensor.uniform_, torch.Tensor.random_, time.time, time.perf_counter, os.urandom,
+          random.SystemRandom.random, 'uniform_' in vars(torch.Tensor))
+
+
+@pytest.mark.parametrize('mode', ['walk', 'auto', 'batch'])
+@pytest.mark.parametrize('klass,message', DYNAMIC + STATIC, ids=[c[0].__name__ for c in DYNAMIC + STATIC])
+def test_games_of_chance_are_refused_in_ten_seeds_out_of_ten(klass, message, mode, monkeypatch):
+  monkeypatch.setenv('CAMPX_TABULATE', mode)
+  before = _entry_points()
+  for seed in range(10):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    with pytest.raises(tabulate.TabulationError, match=message):
+      tabulate.trace(lanes_probes.game(klass)(), cache=False)
+    assert _entry_points() == before            # every stand-in gone again
+
+
+def test_the_lane_tabulator_called_directly_refuses_too():
+  from campx_amd import tabulate_batched
+  with pytest.raises(tabulate.TabulationError, match='draws random numbers in RareRandom.update'):
+    tabulate_batched.trace(lanes_probes.game(RareRandom)())
+
+
+def test_a_function_of_a_constant_seed_is_not_chance():
+  table = tabulate.trace(lanes_probes.game(SeededEveryFrame)(), cache=False)
+  assert table.n_states > 1
+  want = float(np.random.default_rng(3).integers(0, 4)) + \
+      float(torch.randint(0, 3, (), generator=torch.Generator().manual_seed(11)))
+  rewards = np.asarray(table.reward, np.float32)      # (NaN: entries of states the game never reaches)
+  assert set(np.unique(rewards[~np.isnan(rewards)])) == {np.float32(want)}
+
+
+def test_other_callers_are_not_in_the_way():
+  """The stand-ins only stop a Sprite / Drape / Backdrop method: this package's own sampled
+  cross-checks, a test, a logging thread draw and read the clock as ever - and are not mistaken for
+  the game's draws (the state comparison only looks at the generators the game could reach)."""
+  with chance.forbidden(tabulate.TabulationError):
+    assert time.time() > 0 and len(os.urandom(4)) == 4
+    assert np.random.default_rng().random() < 1.0
+    assert torch.rand(3, generator=torch.Generator().manual_seed(1)).shape == (3,)
+  # (a caller that is not a game, inside the context, that draws from a PROCESS-WIDE generator does
+  # move its state: reported - the front ends themselves use private RandomState objects)
+  with pytest.raises(tabulate.TabulationError, match='process-wide generator of random'):
+    with chance.forbidden(tabulate.TabulationError):
+      assert 0.0 <= random.random() < 1.0     # (the call itself goes through)
+
+
+def _hello():
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import hello_world_batched as ex
+  return ex
+
+
+def test_the_shape_recogniser_refuses_a_bishop_that_gambles():
+  ex = _hello()
+
+  class Gambling(ex.Bishop):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      ex.Bishop.update(self, actions, board, layers, backdrop, all_things, the_plot)
+      if actions is not None and random.random() < P:
+        the_plot.add_reward(5)
+
+  class ClockWatcher(ex.Scroller):
+    def update(self, actions, board, layers, backdrop, all_things, the_plot):
+      ex.Scroller.update(self, actions, board, layers, backdrop, all_things, the_plot)
+      if actions is not None and time.monotonic() % 50 < 1:
+        the_plot.add_reward(5)
+
+  before = _entry_points()
+  for seed in range(10):
+    random.seed(seed)
+    with pytest.raises(tabulate.TabulationError, match=r'draws random numbers in Gambling\.update \(random\.random\)'):
+      recognise.shapes(ex.make_game(bishop=Gambling))
+    with pytest.raises(tabulate.TabulationError, match=r'reads the clock in ClockWatcher\.update \(time\.monotonic\)'):
+      recognise.shapes(ex.make_game(scroller=ClockWatcher))
+  assert _entry_points() == before
+  # ... and through the engine's own front door (its_showtime() of a batched Engine; the GPU is
+  # only needed after the front ends have had their say)
+  game = ex.make_game(bishop=Gambling)
+  game._batch, game._device = 4, 'cpu'
+  with pytest.MonkeyPatch.context() as mp:
+    mp.setattr(torch.cuda, 'is_available', lambda: True)
+    with pytest.raises(tabulate.TabulationError, match=r'draws random numbers in Gambling\.update'):
+      game.its_showtime()
+  assert _entry_points() == before
+
+
+def test_a_batched_engine_refuses_a_tabulated_game_of_chance_at_showtime():
+  game = lanes_probes.game(RareTorch)()
+  game._batch, game._device = 4, 'cpu'
+  with pytest.MonkeyPatch.context() as mp:
+    mp.setattr(torch.cuda, 'is_available', lambda: True)
+    with pytest.raises(tabulate.TabulationError, match=r'draws random numbers in RareTorch\.update \(torch\.rand\)'):
+      game.its_showtime()

@@ -23,7 +23,7 @@ import traced_games
 pytestmark = pytest.mark.gpu
 
 
-def _check(build, B, Ts, seed, build_kwargs=None):
+def _check(build, B, Ts, seed, build_kwargs=None, actions_ready=False):
   kw = build_kwargs or {}
   game = build(batch=B, device='cuda', **kw)
   game.its_showtime()
@@ -40,7 +40,8 @@ def _check(build, B, Ts, seed, build_kwargs=None):
       bufs[key] = fused.rollout_buffers(T)
     out = bufs[key]
     out['obs'].fill_(-7)
-    prev = fused.rollout_deferred(torch.from_numpy(actions).cuda(), out, reset_first=(call == 0))
+    prev = fused.rollout_deferred(torch.from_numpy(actions).cuda(), out, reset_first=(call == 0),
+                                  actions_ready=actions_ready)
     assert prev is (dicts[-1] if dicts else None)
     # this call's scalars are ready, the previous call's observations too
     for k in ('reward', 'discount'):
@@ -110,13 +111,49 @@ def test_games_of_two_to_four_movers_share_the_launch(level, B, Ts):
 def test_multi_mover_games_past_the_shared_launch_pipeline_over_two_streams():
   # 33 024 environments of the two-mover game: each rollout whole, in order.  20 000 of the two-
   # and of the three-mover one, 16 384 of the four-mover one: past what the shared launch takes
-  # (16 384 / 8 192), rollout_deferred() runs the update pass on the high-priority side stream under the
-  # previous rollout's render (campx::rollout_pipelined: two kernels, two streams, one op),
-  # complete a call early
-  _check(sokoban.build, 33024, [10, 10, 10], seed=6)
-  _check(sokoban.build, 20000, [30, 30, 30], seed=9)
-  _check(sokoban.build, 16384, [20, 20, 7, 20], seed=7, build_kwargs=dict(level=2))
-  _check(sokoban.build, 20000, [16, 16, 16], seed=8, build_kwargs=dict(level=1))
+  # (16 384 / 8 192), rollout_deferred(actions_ready=True) runs the update pass on the high-priority
+  # side stream under the previous rollout's render (campx::rollout_pipelined: two kernels, two
+  # streams, one op), complete a call early; without the promise (the default) the same rollouts
+  # run in order on the caller's stream
+  for ready in (True, False):
+    _check(sokoban.build, 33024, [10, 10, 10], seed=6, actions_ready=ready)
+    _check(sokoban.build, 20000, [30, 30, 30], seed=9, actions_ready=ready)
+    _check(sokoban.build, 16384, [20, 20, 7, 20], seed=7, build_kwargs=dict(level=2), actions_ready=ready)
+    _check(sokoban.build, 20000, [16, 16, 16], seed=8, build_kwargs=dict(level=1), actions_ready=ready)
+
+
+@pytest.mark.parametrize('ready', [False, True])
+def test_deferred_rollouts_come_after_the_work_that_makes_their_actions(ready):
+  """Round 5 advice: actions produced by kernels queued on the caller's stream BEHIND a long render
+  (a `torch.randint`, the int64 -> int8 narrowing of `_action_ids`) must have been written before
+  the update pass reads them - whichever route the call takes.  With `actions_ready=True` and ids
+  that are NOT the caller's own int8 tensor the side stream waits for the caller's stream."""
+  B, T, level = 16384, 40, 2
+  game = sokoban.build(level=level, batch=B, device='cuda')
+  game.its_showtime()
+  f = game.fused
+  og = cpu.OracleGame.from_description(gamespec.describe(sokoban.build(level=level)))
+  sets = [f.rollout_buffers(T), f.rollout_buffers(T)]
+  big = torch.empty((1 << 28,), dtype=torch.int32, device='cuda')    # 1 GiB: a fill takes ~0.15 ms
+  gen = torch.Generator(device='cuda').manual_seed(77)
+  scratch = torch.empty((T, B), dtype=torch.int64, device='cuda')
+  got, fed = [], []
+  for call in range(6):
+    for _ in range(4):
+      big.fill_(call)                     # the stream is busy when the actions are made ...
+    scratch.fill_(4)                      # ... in a buffer that held "stay" until this instant
+    scratch.random_(0, 5, generator=gen)
+    prev = f.rollout_deferred(scratch, sets[call & 1], reset_first=(call == 0), actions_ready=ready)
+    fed.append(scratch.cpu().numpy().astype(np.int8))
+    if prev is not None:
+      got.append({k: prev[k].cpu().numpy().copy() for k in ('obs', 'reward', 'done')})
+  last = f.flush()
+  got.append({k: last[k].cpu().numpy().copy() for k in ('obs', 'reward', 'done')})
+  for call, (a, g) in enumerate(zip(fed, got)):
+    ref = og.rollout(a, reset_first=(call == 0))
+    assert np.array_equal(g['reward'].view(np.uint32), ref['reward'].view(np.uint32)), call
+    assert np.array_equal(g['done'], ref['done']), call
+    assert np.array_equal(g['obs'], ref['obs']), call
 
 
 def test_deferred_rollouts_refuse_what_they_cannot_do():
