@@ -110,10 +110,6 @@ def parse_args(argv=None):
                       'log is copied locally instead of all-gathered)')
   p.add_argument('--no-extras', action='store_true',
                  help='skip play()-mode and the wall_world / sokoban side measurements')
-  p.add_argument('--pipeline', action='store_true',
-                 help='A/B: issue the update pass of each rollout on a side stream so that '
-                      'it overlaps the previous launch (measured SLOWER: the two kernels '
-                      'contend for CU slots; NOTES.md "Kernels")')
   p.add_argument('--deferred', action='store_true',
                  help='A/B: rollouts pipelined across calls (FusedGame.rollout_deferred): one '
                       'launch holds the update pass of rollout i+1 and the render pass of rollout '
@@ -127,10 +123,8 @@ def parse_args(argv=None):
                  help='priority of the stream RCCL runs its collectives on (ProcessGroupNCCL.Options.'
                       'is_high_priority_stream): high = the episode-return gather is dispatched '
                       'ahead of the rollout\'s queued workgroups instead of competing with them')
-  p.add_argument('--reserve-cus', type=int, default=0,
-                 help='A/B: launch the rollouts on a stream confined to all but this many compute '
-                      'units (campx_stream_create_cu_subset), so that a collective always finds '
-                      'free ones')
+  p.add_argument('--no-pin', action='store_true',
+                 help='do not pin the rank\'s host threads to the NUMA node of its GPU')
   p.add_argument('--episode-csv', default=None,
                  help='rank 0: after the timed region, write the last all-gathered block of '
                       'episode returns in the reference\'s CSV format '
@@ -173,6 +167,107 @@ def launch_ranks(n, argv):
     sys.stdout.write(line)
     sys.stdout.flush()
   return proc.wait()
+
+
+def pin_to_gpu_numa_node(local_rank):
+  """Pin this process (and the threads it will start) to the CPUs of the NUMA node its GPU hangs
+  off, BEFORE anything touches the GPU: on a two-socket node a rank whose launch loop runs on
+  the far socket pays a cross-socket hop per doorbell.  Best effort from sysfs - amdgpu cards in
+  PCI order, `*_VISIBLE_DEVICES` honoured when it is a plain list of ordinals - and reported in
+  the line (`config.numa_node`, `config.cpus_pinned`): None when the node could not be told.
+  Returns (node, number of CPUs, the affinity mask to restore before all-core CPU work)."""
+  import glob
+  import re
+  before = None
+  try:
+    before = os.sched_getaffinity(0)
+    ordinal = local_rank
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+      listed = os.environ.get(var)
+      if listed and all(x.strip().isdigit() for x in listed.split(',')):
+        ids = [int(x) for x in listed.split(',')]
+        if local_rank < len(ids):
+          ordinal = ids[local_rank]
+        break
+    cards = []
+    for d in glob.glob('/sys/class/drm/card*'):
+      if not re.fullmatch(r'card\d+', os.path.basename(d)):
+        continue
+      dev = os.path.join(d, 'device')
+      try:
+        with open(os.path.join(dev, 'vendor')) as f:
+          if f.read().strip() != '0x1002':
+            continue
+        with open(os.path.join(dev, 'numa_node')) as f:
+          node = int(f.read().strip())
+      except (OSError, ValueError):
+        continue
+      cards.append((os.path.basename(os.path.realpath(dev)), node))
+    cards.sort()
+    if ordinal >= len(cards) or cards[ordinal][1] < 0:
+      return None, None, before
+    node = cards[ordinal][1]
+    with open('/sys/devices/system/node/node{}/cpulist'.format(node)) as f:
+      cpus = set()
+      for part in f.read().strip().split(','):
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    cpus &= before
+    if not cpus:
+      return node, None, before
+    os.sched_setaffinity(0, cpus)
+    return node, len(cpus), before
+  except (OSError, ValueError, AttributeError):
+    return None, None, before
+
+
+def measured_write_ceiling(buf, device, launches=20):
+  """What this chip sustains for a pure stream of stores over `buf` (the observation buffer of
+  the rollout just timed: exactly the bytes a launch writes), GB/s - the denominator SURVEY
+  section 8(d) asks for beside the 8 TB/s vendor peak.  Two probes, HIP events on the current
+  stream round `launches` back-to-back launches each: the library's own streaming-store kernel
+  (campx_write_probe_launch: the render kernel's store form and block order, nothing to compute)
+  and torch's `fill_`; the ceiling is the better of the two."""
+  import ctypes
+  import torch
+  from campx_amd import _hip
+  flat = buf.view(-1).view(torch.uint8)
+  n = flat.numel() // 16 * 16
+  stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+  def probe():
+    _hip.check(_hip.lib.campx_write_probe_launch(ctypes.c_void_p(flat.data_ptr()), n, 0x01010101, stream),
+               'campx_write_probe_launch')
+
+  def fill():
+    flat.fill_(1)
+
+  rates = {}
+  for name, fn in (('probe', probe), ('fill', fill)):
+    for _ in range(5):
+      fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+      fn()
+    e1.record()
+    e1.synchronize()
+    rates[name] = n / (e0.elapsed_time(e1) / launches / 1e3) / 1e9
+  return rates
+
+
+def short_row(value, ms_per_step, roof, cpu):
+  """One configuration as a string short enough to survive the driver's record whole (its parser
+  keeps scalar keys only and cuts strings at 120 characters): everything a reader needs to
+  recompute the roofline fraction - value, ms per step, kernel ms, bytes per env-step (x batch x
+  frames of the key's name = bytes per launch), fraction of peak / of the measured ceiling,
+  counter traffic over algorithmic bytes, CPU baseline / cores."""
+  traffic = roof.get('traffic')
+  return 'v={:.4g} ms={:.4f} kms={:.4f} Bps={} frac={:.4f} ofmeas={} traf={} cpu={}'.format(
+      value, ms_per_step, roof['kernel_ms'], roof['bytes_per_env_step'], roof['frac'],
+      'n/a' if roof.get('frac_of_measured') is None else '{:.3f}'.format(roof['frac_of_measured']),
+      'n/a' if not traffic else '{:.3f}'.format(traffic / roof['bytes_per_launch']),
+      'n/a' if not cpu else '{:.3g}/{}c'.format(cpu['value'], cpu['cores']))
 
 
 # ------------------------------------------------------------ CPU baselines
@@ -275,7 +370,7 @@ def kernel_names(fused, split, B=None, T=None):
 
 
 def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_every,
-                    standin=None, pipelined=False, with_log=False, gather_at=2.0 / 3.0):
+                    standin=None, deferred=False, with_log=False, gather_at=2.0 / 3.0):
   """Warm up, then time exactly `steps` rollout launches.  Returns a dict.
 
   Wall clock: perf_counter around the timed region, bracketed by synchronize +
@@ -300,17 +395,12 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   gen = torch.Generator(device='cpu').manual_seed(0xC0FFEE + rank)
   streams = [torch.randint(0, 5, (T, B), generator=gen, dtype=torch.int8)
              .to(device) for _ in range(2)]
-  # Output buffers are allocated once; a step is then op dispatches only.  Pipelined
-  # rollouts (the update pass of launch i+1 overlaps the observation stream of launch
-  # i) alternate two sets of scalars / trace over one observation buffer.
+  # Output buffers are allocated once; a step is then op dispatches only.  Deferred
+  # rollouts (the update pass of launch i+1 shares a launch with the observation stream of
+  # launch i) alternate two sets of scalars / trace over one observation buffer.
   bufs = [fused.rollout_buffers(T)]
-  deferred = pipelined == 'deferred' and bufs[0].get('trace') is not None and hasattr(fused, 'rollout_deferred')
-  share_obs = os.environ.get('CAMPX_BENCH_OWN_OBS') != '1'    # (A/B: an observation buffer per set)
-  if deferred and not share_obs:
-    bufs.append(fused.rollout_buffers(T))
-  else:
-    bufs.append(fused.rollout_buffers(T, share=bufs[0]) if pipelined else bufs[0])
-  pipelined = 'deferred' if deferred else (pipelined is True and bufs[0].get('trace') is not None)
+  deferred = bool(deferred) and bufs[0].get('trace') is not None and hasattr(fused, 'rollout_deferred')
+  bufs.append(fused.rollout_buffers(T, share=bufs[0]) if deferred else bufs[0])
   log = None
   if dist is not None or with_log:
     # Episode returns are logged per rank and all-gathered every `gather_every`
@@ -335,11 +425,12 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
       # buffer sets strictly alternate, whatever `i` the caller's loops restart from)
       k = n_calls[0] & 1
       n_calls[0] += 1
-      fused.rollout_deferred(streams[k], bufs[k], reset_first=True)
+      # (the action streams are resident and complete: the promise that lets multi-mover games
+      # past the shared launch's bounds run their update pass ahead, on the side stream)
+      fused.rollout_deferred(streams[k], bufs[k], reset_first=True, actions_ready=True)
       out = bufs[k]
     else:
-      out = fused.rollout(streams[i & 1], out=bufs[i & 1], reset_first=True,
-                          pipelined=pipelined)
+      out = fused.rollout(streams[i & 1], out=bufs[i & 1], reset_first=True)
     if log is not None:
       log.episode_done()
     return out
@@ -447,7 +538,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     elapsed = float(t.item())
 
   result = dict(fused=fused, elapsed=elapsed, own_elapsed=own_elapsed, log=log, out=out,
-                pipelined=pipelined, settle=settle, window_us=window_us, gathers=gathers,
+                pipelined='deferred' if deferred else False, settle=settle, window_us=window_us, gathers=gathers,
                 gather_every=gather_every if log is not None else None,
                 mean_return=float(out['reward'].sum(0).mean())
                 if out['reward'] is not None else None)
@@ -469,10 +560,14 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     per = [s.elapsed_time(e) for s, e in zip(starts, stops)]
     result['per_launch_ms'] = {'median': float(np.median(per)), 'min': float(min(per)),
                                'max': float(max(per)), 'mean': float(np.mean(per))}
+    # ... and, with the chip as warm as it was for the timed launches, what it sustains for a
+    # pure stream of stores over the same observation buffer
+    obs = out['obs']
+    result['ceiling'] = measured_write_ceiling(obs, device) if obs.dim() == 5 else None
   return result
 
 
-def roofline(game_name, B, T, fused, kernel_ms, per_launch):
+def roofline(game_name, B, T, fused, kernel_ms, per_launch, ceiling=None):
   from campx_amd import fused as fused_mod
   bytes_per_launch = BYTES_PER_ENV_STEP[game_name] * B * T
   achieved = bytes_per_launch / (kernel_ms / 1e3) / 1e9
@@ -484,14 +579,20 @@ def roofline(game_name, B, T, fused, kernel_ms, per_launch):
       'peak': HBM_PEAK_GBS,
       'unit': 'GB/s',
       'frac': achieved / HBM_PEAK_GBS,
+      # SURVEY 8(d) "Bound": the box's measured streaming-write bandwidth over the launch's own
+      # observation buffer, timed in this run right after the launches (measured_write_ceiling)
+      'measured_write_ceiling_gbs': None if not ceiling else max(ceiling.values()),
+      'ceiling_probe_gbs': None if not ceiling else ceiling['probe'],
+      'ceiling_fill_gbs': None if not ceiling else ceiling['fill'],
+      'frac_of_measured': None if not ceiling else achieved / max(ceiling.values()),
       'traffic': traffic,
+      'traffic_over_algorithmic': None if not traffic else traffic / bytes_per_launch,
       'traffic_note': 'HBM bytes per launch (WRITE_SIZE + FETCH_SIZE, separate '
                       'rocprofv3 --pmc passes, profiles/' + os.path.basename(TRAFFIC_FILE) + ')',
       'kernel': kernel_names(fused, split, B, T),
       'kernel_note': 'kernel_ms = HIP-event time on the launch stream around the timed '
                      'launches / steps: every kernel of a rollout launch plus the gaps '
-                     'between launches (pipelined: the update pass of launch i+1 runs on '
-                     'a side stream under the render of launch i, which waits for it)',
+                     'between launches',
       'kernel_ms': kernel_ms,
       'per_launch_ms': per_launch,
       'bytes_per_env_step': BYTES_PER_ENV_STEP[game_name],
@@ -552,10 +653,14 @@ def run_rank(args):
   sys.stdout.flush()
   real_stdout = os.fdopen(os.dup(1), 'w')
   os.dup2(2, 1)
-  import torch
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  # (before torch is imported and long before the first GPU call: the launch loop's thread and
+  # every thread started from here on stay on the socket the rank's GPU hangs off)
+  numa_node, cpus_pinned, affinity_before = (None, None, None) if args.no_pin else \
+      pin_to_gpu_numa_node(local_rank)
+  import torch
   standin = None
   if args.standin:
     import importlib
@@ -569,14 +674,6 @@ def run_rank(args):
                        .format(rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-  if args.reserve_cus and standin is None:
-    import ctypes
-    from campx_amd import _hip
-    raw = ctypes.c_void_p()
-    n_cus = torch.cuda.get_device_properties(device).multi_processor_count - args.reserve_cus
-    _hip.check(_hip.lib.campx_stream_create_cu_subset(n_cus, ctypes.byref(raw)),
-               'campx_stream_create_cu_subset')
-    torch.cuda.set_stream(torch.cuda.ExternalStream(raw.value, device=device))
   # Every run - one rank too - goes through the process group and the episode-return log,
   # so that the N = 1 line times the same protocol as the ranks of an N > 1 run (the driver
   # computes scaling efficiency from those lines).
@@ -605,7 +702,7 @@ def run_rank(args):
   B = args.batch or default_batch
   T = args.frames
   m = measure_rollout(args.game, B, T, args.steps, args.warmup, device, rank, dist,
-                      args.gather_every, standin, 'deferred' if args.deferred else args.pipeline,
+                      args.gather_every, standin, args.deferred,
                       with_log=True, gather_at=args.gather_at)
   fused, elapsed = m['fused'], m['elapsed']
 
@@ -615,20 +712,32 @@ def run_rank(args):
     if block is not None:
       mine = m['log'].last_local_block()
       gathered_ok = bool(block.shape[0] == world and torch.equal(block[rank], mine))
-  # per-rank figures for whoever reads the line: a straggler, or a rank whose part of the
-  # gathered log is wrong, shows here and not only in the max / the all()
-  per_rank_ms = [m['own_elapsed'] / args.steps * 1e3]
-  per_rank_ok = [gathered_ok]
+  # Per-rank figures for whoever reads the line - the first N > 1 run on hardware will be read
+  # blind: a straggler, a rank whose launches were slow (its kernel_ms) as against one whose
+  # WINDOW was slow (ms_per_step well above kernel_ms: host, gather, fence), a gather that was
+  # still running when the launches ended (exposed_us), a rank whose part of the gathered log is
+  # wrong.  All of it as scalars in `config` (the driver's record keeps scalars).
+  own_kernel_ms = m.get('kernel_ms', m['own_elapsed'] / args.steps * 1e3)
+  launches_end_us = m['window_us']['loop'] + m['window_us']['launches']
+  call_us = max([g['call_us'] for g in m['gathers']] or [0.0]) if m['gathers'] else 0.0
+  exposed_us = 0.0
+  for g in m['gathers'] or []:
+    if not g['done_when_launches_ended']:
+      seen = g['seen_done_us'] if g['seen_done_us'] is not None else m['window_us']['total']
+      exposed_us = max(exposed_us, seen - launches_end_us)
+  per_rank = [[m['own_elapsed'] / args.steps * 1e3, own_kernel_ms, call_us, exposed_us,
+               -1.0 if gathered_ok is None else float(gathered_ok),
+               -1.0 if numa_node is None else float(numa_node)]]
   if dist is not None:
-    mine = torch.tensor([m['own_elapsed'] / args.steps * 1e3,
-                         -1.0 if gathered_ok is None else float(gathered_ok)],
-                        dtype=torch.float64, device=device)
-    everyone = torch.zeros((world, 2), dtype=torch.float64, device=device)
+    mine = torch.tensor(per_rank[0], dtype=torch.float64, device=device)
+    everyone = torch.zeros((world, mine.numel()), dtype=torch.float64, device=device)
     dist.all_gather_into_tensor(everyone.view(-1), mine)
-    everyone = everyone.cpu()
-    per_rank_ms = [float(x) for x in everyone[:, 0]]
-    per_rank_ok = [None if x < 0 else bool(x) for x in everyone[:, 1]]
-    gathered_ok = None if any(x is None for x in per_rank_ok) else all(per_rank_ok)
+    per_rank = [[float(x) for x in row] for row in everyone.cpu()]
+  per_rank_ms = [row[0] for row in per_rank]
+  per_rank_kernel_ms = [row[1] for row in per_rank]
+  per_rank_ok = [None if row[4] < 0 else bool(row[4]) for row in per_rank]
+  gathered_ok = None if any(x is None for x in per_rank_ok) else all(per_rank_ok)
+  worst = max(range(len(per_rank)), key=lambda r: per_rank_ms[r])
 
   if rank == 0 and args.episode_csv and m['log'] is not None:
     block = m['log'].wait()
@@ -672,25 +781,53 @@ def run_rank(args):
             'rccl_world': world if (dist is not None and standin is None) else None,
             'gather_every': m['gather_every'],
             'settle_launches': m['settle'],
-            # rank 0's timed window: host clock (the loop that issues the launches, the wait for the
-            # last launch to finish, for the log's last gather, the synchronise that closes the window) and, on the device
-            # clock from the window's opening event, when the launches were done; per gather:
-            # `ready_us` (device clock: its block complete), `issued_us` / `call_us` / `seen_done_us`
-            # (host clock from the window's start: the collective issued, the call's own cost,
-            # first seen complete - asked once per launch, once when the last launch has finished,
-            # once at the end), `done_when_launches_ended`
-            'window_us': m['window_us'],
-            'gathers': m['gathers'],
+            # every launch issued before the timed window opened (`warmup` is the argument;
+            # the settle launches make sure the chip and these buffers have seen 50 ms of work)
+            'untimed_launches_before_window': args.warmup + m['settle'],
+            # rank 0's timed window on the host's clock: the loop that issues the launches, the
+            # wait for the last launch to finish, for the log's last gather, the synchronise that
+            # closes the window; `window_launches_done_us`: the launches on the DEVICE's clock
+            'window_loop_us': m['window_us']['loop'],
+            'window_launches_us': m['window_us']['launches'],
+            'window_log_wait_us': m['window_us']['log_wait'],
+            'window_synchronize_us': m['window_us']['synchronize'],
+            'window_total_us': m['window_us']['total'],
+            'window_launches_done_us': m['window_us'].get('launches_done'),
+            # the all-gathers of the timed window, over all ranks: how many (rank 0), the dearest
+            # call on the host, the longest any of them was still running after a rank's last
+            # launch had finished (0: every gather was hidden under launches)
+            'gather_count': len(m['gathers'] or []),
+            'gather_call_us_max': max(row[2] for row in per_rank),
+            'gather_exposed_us_max': max(row[3] for row in per_rank),
+            # per rank (lists for a human; the scalars below are what the driver's record keeps)
             'per_rank_ms_per_step': per_rank_ms,
+            'per_rank_kernel_ms': per_rank_kernel_ms,
+            'per_rank_numa_node': [None if row[5] < 0 else int(row[5]) for row in per_rank],
+            'worst_rank': worst,
+            'worst_rank_ms_per_step': per_rank_ms[worst],
+            'worst_rank_kernel_ms': per_rank_kernel_ms[worst],
+            'best_rank_kernel_ms': min(per_rank_kernel_ms),
+            # how much of the slowest rank's window the fastest rank's kernels account for: what
+            # scaling efficiency would be if only the kernels counted (1.0 = nothing but kernels)
+            'efficiency_vs_own_kernel': min(per_rank_kernel_ms) / max(per_rank_ms),
+            'numa_node': numa_node,
+            'cpus_pinned': cpus_pinned,
             'gathered_log_matches_local': gathered_ok,
             'per_rank_gathered_log_matches_local': per_rank_ok,
             'mean_episode_return': m['mean_return'],
         },
     }
+    details = {'window_us': m['window_us'], 'gathers': m['gathers']}
+    if standin is None:
+      from campx_amd import _hip
+      line['config']['library_settings'] = _hip.config_string()
     if standin is None:
       line['roofline'] = roofline(args.game, B, T, fused, m['kernel_ms'],
-                                  m['per_launch_ms'])
+                                  m['per_launch_ms'], m.get('ceiling'))
+      line['config']['launch_ms_median'] = m['per_launch_ms']['median']
     solo = world == 1 and standin is None and not args.force_dist
+    if affinity_before is not None:
+      os.sched_setaffinity(0, affinity_before)      # the CPU baselines below use every core
     if solo and not args.no_cpu_baseline:
       line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds,
                                           batch=4096 if args.game.startswith(('maze', 'sokoban16', 'hello')) else 65536)
@@ -704,8 +841,41 @@ def run_rank(args):
     if solo and not args.no_extras and headline:
       del m
       torch.cuda.empty_cache()
+      also = []
+      # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
+      # second one's 4.4 M-state table is enumerated on the device during its_showtime())
+      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16', 'hello_world'):
+        oname, ob = WORKLOADS[other]
+        steps = args.steps
+        om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
+                             deferred=args.deferred)
+        row = {
+            'workload': '{}, batch={}, random actions, {} frames per launch'.format(
+                oname, ob, T),
+            'value': ob * T * steps / om['elapsed'], 'unit': 'env-steps/s',
+            'steps': steps, 'ms_per_step': om['elapsed'] / steps * 1e3,
+            'settle_launches': om['settle'],
+            'roofline': roofline(other, ob, T, om['fused'], om['kernel_ms'],
+                                 om['per_launch_ms'], om.get('ceiling')),
+            'cpu_baseline': None if args.no_cpu_baseline else
+                            cpu_baseline(other, T, args.cpu_seconds / 2,
+                                         batch=4096 if other.startswith(('maze', 'sokoban16', 'hello')) else ob)}
+        for note in ('traffic_note', 'kernel_note'):      # (said once, in the headline's roofline)
+          row['roofline'].pop(note, None)
+        if row['cpu_baseline']:
+          details.setdefault('cpu_samples', {})[other] = row['cpu_baseline'].pop('sample')
+        # the same row as ONE short string among the headline's scalars: the driver's record
+        # keeps those and drops this list (BENCH_r05: sokoban's number was not in it at all)
+        line['config']['{}_{}'.format(other, ob)] = short_row(
+            row['value'], row['ms_per_step'], row['roofline'], row['cpu_baseline'])
+        also.append(row)
+        del om
+        torch.cuda.empty_cache()
+      line['also'] = also
       line['play_mode'] = play_mode(device)
-      if not args.deferred and not args.pipeline:
+      line['config']['play_us_per_call'] = line['play_mode']['validate_off']['us_per_call']
+      line['config']['play_graph32_us_per_call'] = line['play_mode']['hip_graph_32_frames']['us_per_call']
+      if not args.deferred:
         # Rollouts pipelined across calls (FusedGame.rollout_deferred: ONE launch = the update
         # pass of rollout i+1 + the render pass of rollout i), beside the headline's two
         # launches per rollout, at the batches where the library shares the launch.  Reported, not
@@ -714,7 +884,7 @@ def run_rank(args):
         for db in (32768, 16384, 4096):
           dsteps = args.steps * max(1, B // db)      # (the same env-steps per timed window)
           dm = measure_rollout(args.game, db, T, dsteps, args.warmup, device, 0, None, 0,
-                               pipelined='deferred')
+                               deferred=True)
           rows.append({'batch': db, 'steps': dsteps, 'value': db * T * dsteps / dm['elapsed'],
                        'unit': 'env-steps/s', 'ms_per_step': dm['elapsed'] / dsteps * 1e3,
                        'kernel_ms': dm['kernel_ms'],
@@ -722,38 +892,19 @@ def run_rank(args):
                        / HBM_PEAK_GBS})
           del dm
           torch.cuda.empty_cache()
-        line['deferred_rollouts'] = {
-            'note': 'rollout_deferred(): one launch per step = update pass of rollout i+1 + '
-                    'render pass of rollout i (pipe_table_kernel); same work per step as the '
-                    'headline, observations delivered one call late; these rows run without the '
-                    'episode-return log of the headline (with it: tools/gpu_deferred_rep.sh)',
-            'rows': rows}
-      also = []
-      # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
-      # second one's 4.4 M-state table is enumerated on the device during its_showtime())
-      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16', 'hello_world'):
-        oname, ob = WORKLOADS[other]
-        steps = args.steps
-        om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
-                             pipelined='deferred' if args.deferred else args.pipeline)
-        also.append({
-            'workload': '{}, batch={}, random actions, {} frames per launch'.format(
-                oname, ob, T),
-            'value': ob * T * steps / om['elapsed'], 'unit': 'env-steps/s',
-            'steps': steps, 'ms_per_step': om['elapsed'] / steps * 1e3,
-            'settle_launches': om['settle'],
-            'roofline': roofline(other, ob, T, om['fused'], om['kernel_ms'],
-                                 om['per_launch_ms']),
-            'cpu_baseline': None if args.no_cpu_baseline else
-                            cpu_baseline(other, T, args.cpu_seconds / 2,
-                                         batch=4096 if other.startswith(('maze', 'sokoban16', 'hello')) else ob)})
-        del om
-        torch.cuda.empty_cache()
-      line['also'] = also
+        # (rollout_deferred(): one launch per step = update pass of rollout i+1 + render pass of
+        # rollout i, pipe_table_kernel; same work per step as the headline, observations delivered
+        # one call late; these rows run without the episode-return log of the headline)
+        line['deferred_rollouts'] = {'rows': rows}
+        for r in rows:
+          line['config']['deferred_{}_frac'.format(r['batch'])] = r['frac']
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()
   if rank == 0:
+    # what does not fit one line a parser keeps whole: on stderr, one JSON line of its own
+    sys.stderr.write('BENCH_DETAILS ' + json.dumps(details) + '\n')
+    sys.stderr.flush()
     real_stdout.write(json.dumps(line) + '\n')
     real_stdout.flush()
   real_stdout.close()

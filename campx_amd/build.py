@@ -117,9 +117,78 @@ def build_torch_ops(force=False, verbose=False):
   return TORCH_OUT
 
 
+# ---- the host side under sanitizers (tests/test_c_abi_sanitized.py; CPU only)
+SAN_DIR = os.path.join(REPO, 'build', 'sanitize')
+SAN_OUT = os.path.join(SAN_DIR, 'libcampx_hip_san.so')
+SAN_FLAGS = ['--offload-host-only', '-O1', '-g', '-std=c++17', '-fPIC', '-ffp-contract=off',
+             '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
+             '-fno-omit-frame-pointer', '-shared-libsan', '-Wno-unused-function', '-Wno-pass-failed']
+
+
+def sanitizer_runtime():
+  """Path of clang's shared ASan runtime (to LD_PRELOAD into a python that loads SAN_OUT)."""
+  hipcc = find_hipcc()
+  out = subprocess.run([hipcc, '-print-file-name=libclang_rt.asan-x86_64.so'],
+                       stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+  if not os.path.isabs(out) or not os.path.exists(out):
+    raise RuntimeError('clang\'s libclang_rt.asan-x86_64.so not found (hipcc says {!r})'.format(out))
+  return out
+
+
+def build_sanitized(force=False, verbose=False):
+  """libcampx_hip.so's HOST side only (`--offload-host-only`: validators, table builders, launch
+  arithmetic; the kernels are not compiled, a launch would fail) with AddressSanitizer and
+  UndefinedBehaviorSanitizer - the product's own sources, no stand-ins.  Not shipped, not loaded
+  by the package: `build/sanitize/libcampx_hip_san.so`, for the fuzz test of the C ABI's
+  host-only entry points.  (GPU sanitizers are not available on this pool.)"""
+  if not force and not _stale(SAN_OUT, SRCS + HEADERS):
+    return SAN_OUT
+  os.makedirs(SAN_DIR, exist_ok=True)
+  hipcc = find_hipcc()
+  objs, todo = [], []
+  for unit, src in zip(UNITS, SRCS):
+    obj = os.path.join(SAN_DIR, unit + '.o')
+    objs.append(obj)
+    todo.append([hipcc] + SAN_FLAGS + ['-I', INCLUDE, '-I', CSRC, '-c', src, '-o', obj])
+
+  def run(cmd):
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+
+  with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
+    list(pool.map(run, todo))
+  # Every host object registers "its" device code at load time and names it by a symbol the
+  # device half of the compilation would have defined (__hip_fatbin_<hash>).  There is no device
+  # half here: each of those symbols becomes an EMPTY code-object bundle (the bundle's magic, zero
+  # entries) - the kernels do not exist in this library, and nothing in its test launches one.
+  wanted = set()
+  for obj in objs:
+    names = subprocess.run(['nm', '-u', obj], stdout=subprocess.PIPE, text=True, check=True).stdout
+    wanted.update(line.split()[-1] for line in names.splitlines() if '__hip_fatbin_' in line)
+  stub = os.path.join(SAN_DIR, 'no_device_code.c')
+  with open(stub, 'w') as f:
+    f.write('/* generated by campx_amd/build.py build_sanitized(): empty code-object bundles */\n')
+    for name in sorted(wanted):
+      f.write('__attribute__((section(".hip_fatbin"), aligned(4096))) const unsigned char {}[32] = '
+              '"__CLANG_OFFLOAD_BUNDLE__";\n'.format(name))
+  stub_obj = os.path.join(SAN_DIR, 'no_device_code.o')
+  run(['gcc', '-c', '-fPIC', stub, '-o', stub_obj])
+  cmd = [hipcc, '--offload-host-only', '-shared', '-fPIC', '-fsanitize=address,undefined',
+         '-shared-libsan'] + objs + [stub_obj, '-o', SAN_OUT + '.tmp']
+  if verbose:
+    print(' '.join(cmd))
+  subprocess.run(cmd, check=True)
+  os.replace(SAN_OUT + '.tmp', SAN_OUT)
+  return SAN_OUT
+
+
 def build_all(force=False, verbose=False):
   return build_hip(force, verbose), build_torch_ops(force, verbose)
 
 
 if __name__ == '__main__':
-  print(build_all(force='--force' in sys.argv, verbose=True))
+  if '--sanitize' in sys.argv:
+    print(build_sanitized(force='--force' in sys.argv, verbose=True))
+  else:
+    print(build_all(force='--force' in sys.argv, verbose=True))

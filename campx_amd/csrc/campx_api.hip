@@ -41,65 +41,77 @@ namespace campx_impl {
 
 thread_local int32_t g_last_hip_error = 0;
 
-// Tuning knobs for A/B measurements only (environment variables, read once; not
-// part of the ABI).
-bool knob_store_nt() {
-  static const bool nt = [] {
-    const char* v = getenv("CAMPX_STORE_NT");
-    return !v || v[0] != '0';   // non-temporal observation stores by default
-  }();
-  return nt;
+// ----------------------------------------------------------------------- configuration
+// Everything about the library's behaviour that is not an argument of a call, in ONE table: set
+// through campx_config_set() (tests, an embedding application) or, for a whole process, through
+// the environment variable CAMPX_CONFIG="name=value,name=value" - the only getenv of this
+// library, read once, before the first value is asked for.  campx_config_string() writes the
+// effective values.  Until round 5 there were some thirty-five environment variables, read once
+// each wherever they were used; those whose A/B measurement is settled are gone, with the code
+// paths they selected (which profile settled each: NOTES.md R6.2).
+struct KnobRow {
+  const char* name;
+  int64_t value, lo, hi;
+  const char* what;
+};
+static KnobRow g_knobs[K_COUNT] = {
+    // largest trace one update + render pair of a rollout works on; a longer rollout runs in chunks
+    // of whole frames (the render's trace reads then hit the memory-side cache: profiles/r02_sweep.txt).
+    // 0: a chunk per frame (tests/test_chunked_rollouts.py runs the chunked form at test sizes)
+    {"trace_chunk_mb", 16, 0, 1 << 20, "MiB of trace per update + render pair of a chunked rollout"},
+    {"trace_whole_mb", 28, 0, 1 << 20, "largest trace (MiB) a rollout may have and still run as one pair"},
+    // frame-major shape tier: environment-frames per chunk, in thousands (profiles/r05_shape_rocprofv3.txt)
+    {"shape_chunk_kf", 2000, 1, 1 << 30, "thousand environment-frames per chunk of a frame-major shape rollout"},
+    // 0: always the one-wave-per-environment shape kernel (the second implementation the parity tests hold
+    // the frame-major kernels against)
+    {"shape_split", 1, 0, 1, "frame-major shape kernels where the launch allows them"},
+    // number of 8-wave "big" update workgroups from which launch_update prefers them; -1: one per
+    // compute unit of the device (1: at every batch size - tests/test_update_workgroups.py)
+    {"big_wgs", -1, -1, 1 << 30, "big update workgroups from this many up (-1: one per CU)"},
+    // 0: a rollout is always two launches (update pass, render), never the tagged-trace single launch
+    // (the parity twin of tests/test_flow.py)
+    {"flow", 1, 0, 1, "one-launch rollouts (tagged trace) for table games up to 8 192 environments"},
+    // how long a render wave of a one-launch rollout waits for its trace entries before it raises
+    // CAMPX_ERR_FLOW_TIMEOUT, and a debugging delay (s_sleep units) in front of the update role's
+    // stores: tests/test_flow.py provokes the timeout with (1, 3000)
+    {"flow_max_naps", kFlowMaxNaps, 1, 1ll << 32, "naps before a one-launch rollout's render wave gives up"},
+    {"flow_debug_delay", 0, 0, 1 << 24, "debug: delay in front of the update role's tagged stores"},
+    // wide tier: largest state table (bytes) staged in LDS; 0 sends every game through L2 / HBM gathers
+    {"wide_lds_max", (int64_t)kWideLdsMax, 0, (int64_t)kWideLdsMax, "largest state table (bytes) kept in LDS by wide_update_kernel"},
+};
+
+static void knobs_from_environment() {
+  const char* v = getenv("CAMPX_CONFIG");
+  if (!v) return;
+  std::string text(v);
+  size_t at = 0;
+  while (at < text.size()) {
+    size_t end = text.find(',', at);
+    if (end == std::string::npos) end = text.size();
+    const std::string item = text.substr(at, end - at);
+    const size_t eq = item.find('=');
+    if (eq != std::string::npos) {
+      const std::string name = item.substr(0, eq);
+      bool known = false;
+      for (KnobRow& row : g_knobs)
+        if (name == row.name) {
+          const long long x = atoll(item.c_str() + eq + 1);
+          known = true;
+          if (x >= row.lo && x <= row.hi) row.value = x;
+          else fprintf(stderr, "campx: CAMPX_CONFIG: %s=%lld is outside %lld..%lld, ignored\n", row.name, x,
+                       (long long)row.lo, (long long)row.hi);
+        }
+      if (!known) fprintf(stderr, "campx: CAMPX_CONFIG: no setting is called '%s', ignored\n", name.c_str());
+    }
+    at = end + 1;
+  }
 }
-int knob_xcd() {
-  static const int m = [] {
-    const char* v = getenv("CAMPX_XCD_MODE");
-    return v ? atoi(v) : 0;
-  }();
-  return m;
-}
-bool knob_no_split() {
-  static const bool off = [] {
-    const char* v = getenv("CAMPX_NO_SPLIT");
-    return v && v[0] == '1';
-  }();
-  return off;
-}
-bool knob_no_step() {
-  static const bool off = [] {
-    const char* v = getenv("CAMPX_NO_STEP");
-    return v && v[0] == '1';
-  }();
-  return off;
-}
-// Largest trace (bytes) one update + render pair of a rollout works on (launch_split).
-int64_t knob_trace_chunk_bytes() {
-  static const int64_t n = [] {
-    const char* v = getenv("CAMPX_TRACE_CHUNK_MB");
-    return (int64_t)(v && *v ? atoll(v) : 16) << 20;
-  }();
-  return n;
-}
-// ... and the largest trace a rollout may have and still run as one pair.
-int64_t knob_trace_whole_bytes() {
-  static const int64_t n = [] {
-    const char* v = getenv("CAMPX_TRACE_WHOLE_MB");
-    return (int64_t)(v && *v ? atoll(v) : 28) << 20;
-  }();
-  return n;
-}
-int knob_pair_mode() {
-  static const int m = [] {
-    const char* v = getenv("CAMPX_PAIR_MODE");
-    return v ? atoi(v) : 3;
-  }();
-  return m;
-}
-bool knob_no_table() {
-  static const bool off = [] {
-    const char* v = getenv("CAMPX_NO_TABLE");
-    return v && v[0] == '1';
-  }();
-  return off;
+
+static std::once_flag g_knobs_read;
+
+int64_t knob(Knob k) {
+  std::call_once(g_knobs_read, knobs_from_environment);
+  return __atomic_load_n(&g_knobs[k].value, __ATOMIC_RELAXED);
 }
 
 int32_t hip_failed(hipError_t e) {
@@ -123,7 +135,7 @@ bool last_frame_only(const CampxOutputs& out) {
 
 bool split_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T) {
   const int64_t HW = (int64_t)s.rows * s.cols, LHW = HW * s.n_layers;
-  if (!out.trace || !s.render_valid || T <= 0 || knob_no_split()) return false;
+  if (!out.trace || !s.render_valid || T <= 0) return false;
   if (LHW < 16 || B * LHW >= (1ll << 32) - 65536) return false;
   if (out.board && HW < 16) return false;
   // every frame kept, back to back - or only the last one (strides 0)
@@ -155,19 +167,19 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   // The render kernel runs at the write ceiling only while the trace it reads stays cached
   // (boat race, B = 65 536: 6.96 TB/s with a 26 MB trace at T = 400, 5.35 TB/s with 65 MB at
   // T = 1 000; the same at B = 524 288, T = 100): run long launches as chunks of frames,
-  // update pass and render alternating, each chunk's trace plane at most 16 MB (CAMPX_TRACE_CHUNK_MB).
+  // update pass and render alternating, each chunk's trace plane at most 16 MB (setting trace_chunk_mb).
   // (us per launch, render kernels only, no chunks / 28 / 16 / 8 MB: T = 1 000: 2 265 / 1 820 /
   // 1 641 / 1 644; B = 524 288: 1 739 / 1 504 / 1 314 / 1 316 - gpurun_out/t16.  A 26 MB trace
-  // in one piece is still at full speed, so launches up to 28 MB (CAMPX_TRACE_WHOLE_MB) are not cut.)
+  // in one piece is still at full speed, so launches up to 28 MB (trace_whole_mb) are not cut.)
   // (per moving thing's plane of the trace: sokoban with three boxes, four planes of 13 MB,
   // renders at full speed in one piece, and 4 % slower cut in four)
   const int64_t per_frame = B;
-  int64_t chunk = knob_trace_chunk_bytes() / per_frame;
+  int64_t chunk = (knob(K_TRACE_CHUNK_MB) << 20) / per_frame;
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
   chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
-  const bool whole = (per_frame * T <= knob_trace_whole_bytes() && T <= 65535) || T <= chunk;
+  const bool whole = (per_frame * T <= (knob(K_TRACE_WHOLE_MB) << 20) && T <= 65535) || T <= chunk;
   // (two to four movers: their pair / tuple table is the caller's, CampxState.pair_table)
-  const bool multi_table = s.n_dyn >= 2 && st.pair_table && (!knob_no_table() || s.table_only);
+  const bool multi_table = s.n_dyn >= 2 && st.pair_table;
   if (whole && !last_frame_only(out) && flow_ok(s, out, B, T, use_table || multi_table, stream)) {
     // table games of small batches: one launch, the render role following the update role as
     // its entries arrive (k_update.hip, launch_flow)
@@ -217,20 +229,17 @@ int32_t launch(const CampxSpec* spec_host, const CampxSpec* spec_dev, CampxState
   hipStream_t s = static_cast<hipStream_t>(stream);
   // a host-tabulated game (table_only) has no rules: its tables are not optional
   const bool only = spec_host->table_only != 0;
-  const bool no_table = knob_no_table() && !only;
-  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 && !no_table;
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1;
   if (only && T > 0 && spec_host->n_dyn >= 2 && !st.pair_table) return CAMPX_ESPEC;
   if (out.obs_format < CAMPX_OBS_INT8 || out.obs_format > CAMPX_OBS_BF16) return CAMPX_EINVAL;
   if (!emit_first && split_ok(*spec_host, out, B, T))
     return launch_split(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table, s);
   // (16-bit observations: the render kernel above, or the one-frame kernels below)
-  if (use_table && T == 1 && !emit_first && spec_host->render_valid && !knob_no_step())
+  if (use_table && T == 1 && !emit_first && spec_host->render_valid)
     return launch_step_table(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
-  if (T == 1 && !emit_first && spec_host->n_dyn == 2 && st.pair_table && spec_host->render_valid &&
-      !no_table && !knob_no_step())
+  if (T == 1 && !emit_first && spec_host->n_dyn == 2 && st.pair_table && spec_host->render_valid)
     return launch_step_pair(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
-  if (T == 1 && !emit_first && spec_host->n_dyn >= 3 && st.pair_table && spec_host->render_valid &&
-      !no_table && !knob_no_step())
+  if (T == 1 && !emit_first && spec_host->n_dyn >= 3 && st.pair_table && spec_host->render_valid)
     return launch_step_tuple(*spec_host, spec_dev, st, actions, out, B, reset_first, s);
   if (out.obs_format != CAMPX_OBS_INT8) return CAMPX_EINVAL;
   if (use_table)
@@ -350,14 +359,18 @@ int32_t campx_spec_validate(const CampxSpec* s) {
   if (s->table_only != 0 && s->table_only != 1) return CAMPX_ESPEC;
   if (s->table_only) {
     if (s->n_rules != 0) return CAMPX_ESPEC;
-    if (s->n_dyn == 1) {   // the host-filled transition table is the game
-      if (!s->table_valid) return CAMPX_ESPEC;
-      for (int i = 0; i < HW * CAMPX_N_ACTIONS; ++i)
-        if (s->table[i].next_cell >= HW || (s->table[i].done & 0x0eu) ||
-            (s->table[i].paint & 0x7fu) >= (uint32_t)s->n_layers)
-          return CAMPX_ESPEC;
-    }
+    // (one mover: the host-filled transition table is the game)
+    if (s->n_dyn == 1 && !s->table_valid) return CAMPX_ESPEC;
   }
+  // Whoever says the table is filled - campx_spec_compile() for a rule game, the host tabulator, or
+  // a C caller with a table of its own - has its entries looked at: the table kernels index the
+  // board with `next_cell` and the scenery's layers with `paint` (until round 5 only table_only
+  // games were checked: a hand-filled table on a rule game went through to the kernels).
+  if (s->table_valid && s->n_dyn == 1)
+    for (int i = 0; i < HW * CAMPX_N_ACTIONS; ++i)
+      if (s->table[i].next_cell >= HW || (s->table[i].done & 0x0eu) ||
+          (s->table[i].paint & 0x7fu) >= (uint32_t)s->n_layers)
+        return CAMPX_ESPEC;
   if (s->perf_dyn < -1 || s->perf_dyn >= s->n_dyn) return CAMPX_ESPEC;
   if (s->perf_dyn >= 0) {
     if (s->perf_scale == 0 || s->perf_scale < -16 || s->perf_scale > 16) return CAMPX_ESPEC;
@@ -627,8 +640,7 @@ int32_t campx_update_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
   const int32_t v = campx_spec_validate(spec_host);
   if (v != CAMPX_OK) return v;
   if (!spec_host->render_valid) return CAMPX_ESPEC;
-  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
-                         (!knob_no_table() || spec_host->table_only);
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1;
   if (out.scalar_pitch && out.scalar_pitch < B) return CAMPX_EINVAL;
   return launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
                        (int64_t)T * row_pitch(out, B), static_cast<hipStream_t>(stream));
@@ -669,11 +681,10 @@ int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* 
     return CAMPX_EINVAL;
   CampxOutputs probe = prev;
   if (!split_ok(*spec_host, probe, B, T)) return CAMPX_EINVAL;
-  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
-                         (!knob_no_table() || spec_host->table_only);
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // (games of two to four movers share the launch too, over the caller's pair / tuple table)
-  const bool multi_table = spec_host->n_dyn >= 2 && st.pair_table && (!knob_no_table() || spec_host->table_only);
+  const bool multi_table = spec_host->n_dyn >= 2 && st.pair_table;
   if (pipe_ok(*spec_host, out, prev, B, T, use_table || multi_table))
     return launch_pipe(*spec_host, spec_dev, st, actions, out, prev, B, T, reset_first, s);
   const int32_t rc = launch_update(*spec_host, spec_dev, st, actions, out, B, T, reset_first, use_table,
@@ -684,8 +695,7 @@ int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* 
 
 int32_t campx_update_render_shared(const CampxSpec* spec_host, int64_t B, int32_t T) {
   if (!spec_host || B <= 0 || T <= 0 || campx_spec_validate(spec_host) != CAMPX_OK) return 0;
-  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
-                         (!knob_no_table() || spec_host->table_only);
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1;
   CampxOutputs prev{};       // int8 observations of every frame, back to back, 16-byte aligned
   prev.obs = reinterpret_cast<int8_t*>(uintptr_t{4096});
   prev.trace = reinterpret_cast<uint8_t*>(uintptr_t{4096});
@@ -693,14 +703,13 @@ int32_t campx_update_render_shared(const CampxSpec* spec_host, int64_t B, int32_
   prev.obs_format = CAMPX_OBS_INT8;
   // (two to four movers: with their pair / tuple table in CampxState.pair_table, which this
   // query cannot see - a caller without one gets two launches whatever this says)
-  const bool multi_table = spec_host->n_dyn >= 2 && (!knob_no_table() || spec_host->table_only);
+  const bool multi_table = spec_host->n_dyn >= 2;
   return pipe_ok(*spec_host, prev, prev, B, T, use_table || multi_table) ? 1 : 0;
 }
 
 int32_t campx_flow_shared(const CampxSpec* spec_host, int64_t B, int32_t T, int64_t scalar_pitch) {
   if (!spec_host || B <= 0 || T <= 0 || campx_spec_validate(spec_host) != CAMPX_OK) return 0;
-  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1 &&
-                         (!knob_no_table() || spec_host->table_only);
+  const bool use_table = spec_host->table_valid && spec_host->n_dyn == 1;
   // a call as the header describes it: every output this path looks at present and aligned
   static CampxFlowState some_state;        // (never read or written: flow_ok only asks whether there is one)
   static int32_t some_flag;
@@ -716,38 +725,45 @@ int32_t campx_flow_shared(const CampxSpec* spec_host, int64_t B, int32_t T, int6
   out.error_flag = &some_flag;
   // (two to four movers: with their pair / tuple table in CampxState.pair_table, which this query
   // cannot see - a caller without one gets two launches whatever this says)
-  const bool multi_table = spec_host->n_dyn >= 2 && (!knob_no_table() || spec_host->table_only);
+  const bool multi_table = spec_host->n_dyn >= 2;
   return flow_ok(*spec_host, out, B, T, use_table || multi_table, nullptr, /*ask_stream=*/false) ? 1 : 0;
 }
 
-int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out) {
-  if (!stream_out) return CAMPX_EINVAL;
-  int dev = 0, cus = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (e != hipSuccess) return hip_failed(e);
-  if (n_cus < 1 || n_cus > cus) return CAMPX_EINVAL;
-  // bit i of the mask = compute unit i; every (cus / n_cus)-th one, so that the subset is
-  // spread over the XCDs and shader engines whatever their numbering
-  uint32_t mask[32];
-  memset(mask, 0, sizeof(mask));
-  const int words = (cus + 31) / 32;
-  if (words > 32) return CAMPX_EINVAL;
-  for (int k = 0; k < n_cus; ++k) {
-    const int cu = (int)(((int64_t)k * cus) / n_cus);
-    mask[cu >> 5] |= 1u << (cu & 31);
-  }
-  hipStream_t s = nullptr;
-  e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-  if (e != hipSuccess) return hip_failed(e);
-  *stream_out = s;
-  return CAMPX_OK;
+int32_t campx_config_set(const char* name, int64_t value) {
+  if (!name) return CAMPX_EINVAL;
+  (void)knob(K_TRACE_CHUNK_MB);           // (the environment first: an explicit call overrides it)
+  for (KnobRow& row : g_knobs)
+    if (!strcmp(name, row.name)) {
+      if (value < row.lo || value > row.hi) return CAMPX_EINVAL;
+      __atomic_store_n(&row.value, value, __ATOMIC_RELAXED);
+      return CAMPX_OK;
+    }
+  return CAMPX_EINVAL;
 }
 
-int32_t campx_stream_destroy(void* stream) {
-  if (!stream) return CAMPX_EINVAL;
-  const hipError_t e = hipStreamDestroy(static_cast<hipStream_t>(stream));
-  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+int32_t campx_config_get(const char* name, int64_t* value) {
+  if (!name || !value) return CAMPX_EINVAL;
+  for (int k = 0; k < K_COUNT; ++k)
+    if (!strcmp(name, g_knobs[k].name)) {
+      *value = knob((Knob)k);
+      return CAMPX_OK;
+    }
+  return CAMPX_EINVAL;
+}
+
+int32_t campx_config_string(char* buf, int32_t buf_len) {
+  std::string text;
+  for (int k = 0; k < K_COUNT; ++k) {
+    if (k) text += ' ';
+    text += g_knobs[k].name;
+    text += '=';
+    text += std::to_string((long long)knob((Knob)k));
+  }
+  if (buf && buf_len > 0) {
+    strncpy(buf, text.c_str(), (size_t)buf_len - 1);
+    buf[buf_len - 1] = '\0';
+  }
+  return (int32_t)text.size() + 1;
 }
 
 const char* campx_strerror(int32_t code) {

@@ -13,7 +13,9 @@
 
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,37 +32,21 @@ constexpr int kChunk = 64;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// The streaming 16-byte store of the observation writers.  CAMPX_NT_FLAVOR picks the
-// cache policy (A/B builds): 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = sc0 sc1 nt (default:
-// system-scope write-through + non-temporal, i.e. the line is not kept anywhere on
-// its way to HBM).  Measured on the boat-race bench, ms per 100-frame launch,
-// fused / split path: plain 0.254 / 0.336, nt 0.233 / 0.220, sc1 0.259 / 0.247,
-// sc0 sc1 0.261 / 0.250, sc0 sc1 nt 0.224 / 0.196.
-#ifndef CAMPX_NT_FLAVOR
-#define CAMPX_NT_FLAVOR 4
-#endif
+// The streaming 16-byte store of the observation writers: system-scope write-through +
+// non-temporal, i.e. the line is not kept anywhere on its way to HBM.  (The other cache policies
+// were builds of round 1 - ms per 100-frame boat-race launch, fused / split path: plain 0.254 /
+// 0.336, nt 0.233 / 0.220, sc1 0.259 / 0.247, sc0 sc1 0.261 / 0.250, sc0 sc1 nt 0.224 / 0.196 - and
+// are gone.)
 __device__ __forceinline__ void store16_streaming(u32x4* p, u32x4 v) {
-#if CAMPX_NT_FLAVOR == 1
-  __builtin_nontemporal_store(v, p);
-#elif CAMPX_NT_FLAVOR == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#elif CAMPX_NT_FLAVOR == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#endif
 }
 
 // The same store with the address as (wave-uniform 64-bit base in SGPRs) + (32-bit byte
 // offset per lane): no 64-bit vector address arithmetic.  `base` must be provably uniform
 // (kernel arguments, blockIdx).
 __device__ __forceinline__ void store16_streaming_at(const void* base, uint32_t off, u32x4 v) {
-#if CAMPX_NT_FLAVOR == 4
   asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base)
                : "memory");
-#else
-  store16_streaming(reinterpret_cast<u32x4*>(const_cast<char*>(static_cast<const char*>(base)) + off), v);
-#endif
 }
 
 // The part of the GameSpec the interpreter reads every frame.  Passed BY VALUE
@@ -479,14 +465,15 @@ inline TupleParams make_tuple_params(const CampxSpec& s) {
 // campx_api.hip
 extern thread_local int32_t g_last_hip_error;
 int32_t hip_failed(hipError_t e);
-bool knob_store_nt();
-int knob_xcd();
-bool knob_no_split();
-bool knob_no_step();
-int64_t knob_trace_chunk_bytes();
-int64_t knob_trace_whole_bytes();
-int knob_pair_mode();
-bool knob_no_table();
+// The library's settings (campx_api.hip holds the table: name, default, range, what each selects;
+// campx_config_set / _get / _string in include/campx_hip.h).  Read at every use - a plain load.
+enum Knob : int {
+  K_TRACE_CHUNK_MB, K_TRACE_WHOLE_MB, K_SHAPE_CHUNK_KF, K_SHAPE_SPLIT, K_BIG_WGS, K_FLOW,
+  K_FLOW_MAX_NAPS, K_FLOW_DEBUG_DELAY, K_WIDE_LDS_MAX, K_COUNT
+};
+int64_t knob(Knob k);
+constexpr uint32_t kFlowMaxNaps = 1u << 20;   // looks at stale entries before a render wave gives up (seconds)
+constexpr size_t kWideLdsMax = 144 * 1024;    // wide tier: state tables up to this size are staged in LDS
 
 // Kernels that keep a 64-environment image in dynamic LDS need more than HIP's default
 // 64 KiB for large rows (128 cells x 16 characters: 146 KiB of the CU's 160).

@@ -290,11 +290,11 @@ int32_t launch_k(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
   // Streaming (write-through, non-temporal) stores pay when frames go to a trajectory
   // buffer that is not read back soon; a single frame buffer that every call
   // overwrites (Engine.play) is better left to the caches.
-  const bool nt = knob_store_nt() && out.obs_t_stride != 0;
+  const bool nt = out.obs_t_stride != 0;
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                  \
   CAMPX_ALLOW_LDS((rollout_kernel<K, BOARD, NT, ENVS, false>), shmem);                       \
   hipLaunchKernelGGL((rollout_kernel<K, BOARD, NT, ENVS, false>), grid, block, shmem, stream, \
-                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd(), \
+                     rb, spec_dev, st, actions, out, B, T, reset_first, emit_first, 0, \
                      (int64_t)T * row_pitch(out, B))
 #define CAMPX_LAUNCH(BOARD, NT) do { CAMPX_LAUNCH_E(BOARD, NT, 64); } while (0)
   if (board) {

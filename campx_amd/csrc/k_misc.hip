@@ -1,4 +1,4 @@
-// k_misc.hip - small stand-alone kernels: action-id check, one-hot -> ids.
+// k_misc.hip - small stand-alone kernels: action-id check, one-hot -> ids, the write-ceiling probe.
 
 #include "campx_common.hip.h"
 
@@ -38,6 +38,18 @@ __global__ void onehot_to_ids_kernel(const float* __restrict__ onehot, int8_t* _
   if (bad) atomicAdd(bad_count, bad);
 }
 
+// The denominator SURVEY section 8(d) asks for beside the vendor peak: what THIS chip sustains for
+// a pure stream of the render kernel's own stores (16 bytes per lane, `sc0 sc1 nt`, one-shot waves
+// of one aligned 2 KiB window each, XCD-contiguous block order) with nothing to compute and nothing
+// to read.  bench.py times it over exactly the bytes a rollout launch writes.
+__global__ void __launch_bounds__(128) write_probe_kernel(u32x4* __restrict__ dst, int64_t n16, uint32_t value) {
+  // (block b runs on XCD b % 8: give each XCD one contiguous eighth of the buffer, as render_kernel does)
+  const int64_t nb = gridDim.x, per = nb / 8;
+  const int64_t b = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int64_t i = b * 128 + threadIdx.x;
+  if (i < n16) store16_streaming(dst + i, u32x4{value, value, value, value});
+}
+
 }  // namespace campx_impl
 
 using namespace campx_impl;
@@ -52,6 +64,18 @@ int32_t campx_check_actions_launch(const int8_t* actions, int64_t n, int32_t* ba
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
   hipLaunchKernelGGL(check_actions_kernel, dim3(grid), dim3(256), 0,
                      static_cast<hipStream_t>(stream), actions, n, bad_count);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+}
+
+int32_t campx_write_probe_launch(void* dst, int64_t n_bytes, uint32_t value, void* stream) {
+  if (!dst || n_bytes < 0 || (reinterpret_cast<uintptr_t>(dst) & 15) || (n_bytes & 15)) return CAMPX_EINVAL;
+  if (n_bytes == 0) return CAMPX_OK;
+  const int64_t n16 = n_bytes / 16;
+  const int64_t blocks = ((n16 + 127) / 128 + 7) / 8 * 8;     // (a multiple of 8: the XCD order)
+  if (blocks > 0x7fffffffll) return CAMPX_EINVAL;
+  hipLaunchKernelGGL(write_probe_kernel, dim3((unsigned)blocks), dim3(128), 0,
+                     static_cast<hipStream_t>(stream), static_cast<u32x4*>(dst), n16, value);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? CAMPX_OK : hip_failed(e);
 }

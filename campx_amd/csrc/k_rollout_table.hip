@@ -171,7 +171,7 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   // Streaming (write-through, non-temporal) stores pay when frames go to a trajectory
   // buffer that is not read back soon; a single frame buffer that every call
   // overwrites (Engine.play) is better left to the caches.
-  const bool nt = knob_store_nt() && out.obs_t_stride != 0;
+  const bool nt = out.obs_t_stride != 0;
   const size_t shmem = table_lds_bytes(s, board, envs);
   const dim3 grid((unsigned)((B + envs - 1) / envs)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
@@ -179,7 +179,7 @@ int32_t launch_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
 #define CAMPX_LAUNCH_E(BOARD, NT, ENVS)                                                      \
   CAMPX_ALLOW_LDS((rollout_table_kernel<BOARD, NT, ENVS>), shmem);                              \
   hipLaunchKernelGGL((rollout_table_kernel<BOARD, NT, ENVS>), grid, block, shmem, stream, mp, \
-                     spec_dev, st, actions, out, B, T, reset_first, emit_first, knob_xcd())
+                     spec_dev, st, actions, out, B, T, reset_first, emit_first, 0)
 #define CAMPX_LAUNCH(BOARD, NT) do { CAMPX_LAUNCH_E(BOARD, NT, 64); } while (0)
   if (board) {
     if (nt) CAMPX_LAUNCH(true, true); else CAMPX_LAUNCH(true, false);

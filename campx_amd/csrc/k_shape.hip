@@ -949,11 +949,7 @@ static int64_t shape_offsets_bytes(const CampxShapeSpec& s, int64_t B, int32_t T
 
 // Frames per chunk of a frame-major launch of T frames of B environments (launch_shape_split).
 static int32_t shape_chunk_frames(int64_t B, int32_t T) {
-  static const int64_t chunk_env_frames = [] {
-    const char* v = getenv("CAMPX_SHAPE_CHUNK_KF");
-    return (int64_t)(v && *v ? atoll(v) : 2000) * 1000;
-  }();
-  int64_t chunk = chunk_env_frames / B;
+  int64_t chunk = knob(K_SHAPE_CHUNK_KF) * 1000 / B;
   chunk = chunk / kShapeKey * kShapeKey;
   chunk = chunk < kShapeKey ? kShapeKey : chunk;
   return (int32_t)(chunk < T ? chunk : T);
@@ -975,8 +971,7 @@ int64_t shape_scratch_bytes(const CampxShapeSpec& s, int64_t B, int32_t T) {
 // board, frames of whole 16-byte chunks below 4 GiB, the tables and the scratch given.
 bool shape_split_ok(const CampxShapeSpec& s, const void* tables, const CampxOutputs& out, int64_t B,
                     int32_t T, int32_t emit_first) {
-  static const bool off = [] { const char* v = getenv("CAMPX_SHAPE_SPLIT"); return v && v[0] == '0'; }();
-  if (off || !tables || !out.trace || out.board || emit_first || T < 1 || T > 65535) return false;
+  if (!knob(K_SHAPE_SPLIT) || !tables || !out.trace || out.board || emit_first || T < 1 || T > 65535) return false;
   if (!shape_tables_ok(s) || out.obs_format != CAMPX_OBS_INT8) return false;
   const int64_t R = (int64_t)s.rows * s.cols * s.n_layers;
   if ((B * R) % 16 || B * R >= (1ll << 32) - 65536 || (int64_t)T * B >= (1ll << 31)) return false;
@@ -1032,12 +1027,8 @@ int32_t launch_shape_split(const ShapeParams& sp, const CampxShapeSpec& s, const
   pp.B = B;
   pp.max_pairs = shape_max_pairs(s);
   // replicas of an update wave (see the kernel): 4, fewer where four copies of the trail words do
-  // not fit the 64 KiB a workgroup may ask for; CAMPX_SHAPE_REPLICAS overrides (1: round 5's first form)
-  static const int want_replicas = [] {
-    const char* v = getenv("CAMPX_SHAPE_REPLICAS");
-    const int n = v && *v ? atoi(v) : kShapeMaxReplicas;
-    return n < 1 ? 1 : (n > kShapeMaxReplicas ? kShapeMaxReplicas : n);
-  }();
+  // not fit the 64 KiB a workgroup may ask for
+  constexpr int want_replicas = kShapeMaxReplicas;
   const size_t lds_one = (size_t)8 * pp.n_trail * H * kWave;
   // (Hello World, T = 100, of peak, 1 / 2 / 4 replicas: B = 4 096 0.507 / 0.533 / 0.545, 16 384 0.745 /
   // 0.757 / 0.765, 32 768 0.801 / 0.802 / 0.808, 65 536 0.830 / 0.833 / 0.79-0.81: past 512 workgroups

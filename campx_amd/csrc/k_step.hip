@@ -674,19 +674,6 @@ __global__ __launch_bounds__(kWave) void step_tuple_kernel(
   report_bad_actions(out, bad);
 }
 
-// A/B: bytes of observation a wave of the row-group-major kernels aims at (default 3072)
-static const int g_step_span = [] {
-  const char* v = getenv("CAMPX_STEP_SPAN");
-  const int x = (v && *v) ? atoi(v) : 0;      // 0: each kernel's own default
-  return x <= 0 ? 0 : (x < 256 ? 256 : x);
-}();
-// A/B: one-mover games through step_rows_kernel (round 3: the table copied to LDS) instead of
-// step_rows_dep_kernel (a dependent trip for the table entry)
-static const bool g_step_tab1 = [] {
-  const char* v = getenv("CAMPX_STEP_LDS_TABLE");
-  return v && v[0] == '1';
-}();
-
 // Environments per wave of step_rows_kernel for this game, or 0 when its rows do not fit the
 // kernel's shape: n * R and (with a board) n * HW must be multiples of 16 bytes - 8 for the
 // 16-bit formats -, n <= 64, the observation span at most 4 KiB and the board span 1 KiB.
@@ -704,29 +691,12 @@ int rows_per_wave(const CampxSpec& s, bool board, int fmt, int max_chunks = kRow
       R < 16 || HW < 4)
     return 0;
   // about `target` bytes of observation per wave, in whole multiples of n0
-  if (target <= 0) target = g_step_span > 0 ? g_step_span : 3072;
+  if (target <= 0) target = 3072;
   if (target > max_chunks * 1024) target = max_chunks * 1024;
   int n = n0 * (target / (n0 * R) > 0 ? target / (n0 * R) : 1);
   while (n > n0 && (n > kWave || (board && n * HW > board_chunks * 1024))) n -= n0;
   return n;
 }
-
-static const bool g_no_rows_kernel = [] {
-  const char* v = getenv("CAMPX_NO_ROWS_STEP");
-  return v && v[0] == '1';
-}();
-// A/B: streaming (write-through, non-temporal) observation stores in the one-frame kernel
-static const bool g_step_nt = [] {
-  const char* v = getenv("CAMPX_STEP_NT");
-  return v && v[0] == '1';
-}();
-
-// A/B: dynamic LDS per workgroup in KiB (more than the kernel needs = fewer resident waves
-// per CU, so that the launch runs in phases and one phase's loads overlap another's stores)
-static const size_t g_step_lds_kb = [] {
-  const char* v = getenv("CAMPX_STEP_LDS_KB");
-  return (size_t)(v && *v ? atoi(v) : 0);
-}();
 
 int32_t launch_step_rows(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                          const int8_t* actions, CampxOutputs out, int64_t B, int32_t reset_first,
@@ -750,7 +720,6 @@ int32_t launch_step_rows(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
   rp.inv_hw = ((1u << 24) + (uint32_t)HW - 1u) / (uint32_t)HW;
   rp.step_r = 1024u % (uint32_t)R;
   size_t shmem = (size_t)kStepWaves * 1024 * (size_t)(rp.n_obs + rp.n_tab + (board ? 1 : 0));
-  if (g_step_lds_kb * 1024 > shmem) shmem = g_step_lds_kb * 1024;
   const int64_t waves = (B + n - 1) / n;
   // rounded up to a multiple of 8 for the XCD remap; surplus waves exit at once
   const dim3 grid((unsigned)((((waves + kStepWaves - 1) / kStepWaves) + 7) & ~(int64_t)7)),
@@ -763,7 +732,8 @@ int32_t launch_step_rows(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
   } while (0)
 #define CAMPX_ROWS(BOARD, FMT)                                           \
   do {                                                                   \
-    if (g_step_nt) CAMPX_ROWS3(BOARD, FMT, true); else CAMPX_ROWS3(BOARD, FMT, false); \
+    /* (streaming stores measured no faster for one frame: profiles/r03_play_rocprofv3.txt) */ \
+    CAMPX_ROWS3(BOARD, FMT, false);                                      \
   } while (0)
   if (board) {
     if (out.obs_format == CAMPX_OBS_F16) CAMPX_ROWS(true, 1);
@@ -785,7 +755,7 @@ int32_t launch_step_rows(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
 // three boxes 10.0 / 9.3 / 8.2, with two 8.3 / 7.7 / 7.7, boat race 6.5 / 6.4 / 6.4;
 // profiles/r04_play_rocprofv3.txt).
 int dep_rows_per_wave(const CampxSpec& s, bool board, int fmt) {
-  return rows_per_wave(s, board, fmt, kDepMaxChunks, kDepBoardChunks, g_step_span > 0 ? g_step_span : 8192);
+  return rows_per_wave(s, board, fmt, kDepMaxChunks, kDepBoardChunks, 8192);
 }
 
 int32_t launch_step_rows_dep(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
@@ -818,7 +788,6 @@ int32_t launch_step_rows_dep(const CampxSpec& s, const CampxSpec* spec_dev, Camp
   dp.perf_offset = s.perf_offset;
   dp.step_hw = 1024u % (uint32_t)HW;
   size_t shmem = 1024 * (size_t)(rp.n_obs + (board ? kDepBoardChunks : 0)) + (K > 1 ? 1024 + 128 : 0);
-  if (g_step_lds_kb * 1024 > shmem) shmem = g_step_lds_kb * 1024;
   const int64_t waves = (B + n - 1) / n;
   const dim3 grid((unsigned)((waves + 7) & ~(int64_t)7)), block(kWave);
 #define CAMPX_DEP4(KK, CH, BOARD, FMT)                                                             \
@@ -860,15 +829,11 @@ int32_t launch_step_table(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
                           hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
-  if (!g_no_rows_kernel) {
-    if (!g_step_tab1) {
-      const int nd = dep_rows_per_wave(s, board, out.obs_format);
-      if (nd > 0)
-        return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, nd, stream);
-    }
-    const int n = rows_per_wave(s, board, out.obs_format);
-    if (n > 0) return launch_step_rows(s, spec_dev, st, actions, out, B, reset_first, n, stream);
-  }
+  const int nd = dep_rows_per_wave(s, board, out.obs_format);
+  if (nd > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, nd, stream);
+  // (rows the dependent-trip kernel's shape does not take: round 3's kernel, the table in LDS)
+  const int n = rows_per_wave(s, board, out.obs_format);
+  if (n > 0) return launch_step_rows(s, spec_dev, st, actions, out, B, reset_first, n, stream);
   const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
@@ -891,10 +856,8 @@ int32_t launch_step_pair(const CampxSpec& s, const CampxSpec* spec_dev, CampxSta
                          hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
-  if (!g_no_rows_kernel) {
-    const int n = dep_rows_per_wave(s, board, out.obs_format);
-    if (n > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, n, stream);
-  }
+  const int n = dep_rows_per_wave(s, board, out.obs_format);
+  if (n > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, n, stream);
   const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const MoverParams mp = {s.rows, s.cols, s.n_layers, s.dyn_layer[0], s.dyn_z[0],
@@ -917,10 +880,8 @@ int32_t launch_step_tuple(const CampxSpec& s, const CampxSpec* spec_dev, CampxSt
                           hipStream_t stream) {
   const int HW = s.rows * s.cols, LHW = s.n_layers * HW;
   const bool board = out.board != nullptr;
-  if (!g_no_rows_kernel) {
-    const int n = dep_rows_per_wave(s, board, out.obs_format);
-    if (n > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, n, stream);
-  }
+  const int n = dep_rows_per_wave(s, board, out.obs_format);
+  if (n > 0) return launch_step_rows_dep(s, spec_dev, st, actions, out, B, reset_first, n, stream);
   const size_t shmem = (size_t)((kWave * LHW + 15) & ~15) + (board ? (size_t)((kWave * HW + 15) & ~15) : 0);
   const dim3 grid((unsigned)((B + kWave - 1) / kWave)), block(kWave);
   const TupleParams tp = make_tuple_params(s);

@@ -1098,12 +1098,9 @@ __global__ __launch_bounds__((kProd + kCons + update_loaders(kProd)) * kWave,
 constexpr int kBigEnvs = 8 * kWave;   // environments of a "big" update workgroup
 
 // Number of big workgroups from which launch_update prefers them: one per CU of the chip
-// (CAMPX_BIG_WGS overrides; a huge value turns them off).
+// (setting big_wgs overrides; a huge value turns them off).
 int64_t knob_big_workgroups() {
-  static const int64_t forced = [] {
-    const char* v = getenv("CAMPX_BIG_WGS");
-    return (v && *v) ? (int64_t)atoll(v) : (int64_t)-1;
-  }();
+  const int64_t forced = knob(K_BIG_WGS);
   if (forced >= 0) return forced;
   // the current device's CU count, asked once per device (a process may drive several)
   static std::mutex lock;
@@ -1204,11 +1201,11 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
       hipLaunchKernelGGL((update_table_kernel<kProd, kCons, CAMPX_UPD_GROUP>), grid, block, 0, stream, mp,
                          spec_dev, st, actions, out, B, T, reset_first, fc);
     }
-  } else if (s.n_dyn == 2 && st.pair_table && (!knob_no_table() || s.table_only)) {
+  } else if (s.n_dyn == 2 && st.pair_table) {
     const PairParams pp = make_pair_params(s);
     const int n_entries = s.rows * s.cols * s.rows * s.cols * CAMPX_N_ACTIONS;
     // the entries in LDS when they fit (CAMPX_PAIR_MODE=0: read them through L1/L2 anyway)
-    const bool in_lds = n_entries <= kPairLdsEntries && knob_pair_mode() != 0;
+    const bool in_lds = n_entries <= kPairLdsEntries;
     const size_t shmem = in_lds ? (((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15) : 0;
 #define CAMPX_PAIR_LAUNCH(PROD, CONS)                                                          \
   do {                                                                                         \
@@ -1231,7 +1228,7 @@ int32_t launch_update(const CampxSpec& s, const CampxSpec* spec_dev, CampxState 
     else
       CAMPX_PAIR_LAUNCH(CAMPX_PAIR_PROD, CAMPX_PAIR_CONS);
 #undef CAMPX_PAIR_LAUNCH
-  } else if (s.n_dyn >= 3 && st.pair_table && (!knob_no_table() || s.table_only)) {
+  } else if (s.n_dyn >= 3 && st.pair_table) {
     constexpr int kProd = CAMPX_TUPLE_PROD, kCons = CAMPX_TUPLE_CONS, kEnvs = kProd * kWave;
     const dim3 grid((unsigned)((B + kEnvs - 1) / kEnvs)),
         block((kProd + kCons + update_loaders(kProd)) * kWave);
@@ -1313,7 +1310,6 @@ constexpr uint32_t kPipeSpan = 1024u * kPipeWin;
 #ifndef CAMPX_PIPE_GROUP
 #define CAMPX_PIPE_GROUP 16
 #endif
-constexpr uint32_t kFlowMaxNaps = 1u << 20;     // looks at stale entries before a render wave gives up (seconds)
 // A render wave that gives up says so: CAMPX_ERR_FLOW_TIMEOUT in the caller's error word (system
 // scope: the word may be host memory), once per wave; the frames it then writes are wrong.
 __device__ __forceinline__ void flow_gave_up(int32_t* error_flag) {
@@ -1631,13 +1627,10 @@ __global__ __launch_bounds__(kPipeWaves * kWave, CAMPX_PIPE_MULTI_MINWAVES) void
 // Whether launch_pipe() can put these two passes in one launch (`prev`: the rollout to render).
 bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& prev, int64_t B,
              int32_t T, bool use_table) {
-  static const bool off = [] { const char* v = getenv("CAMPX_NO_PIPE"); return v && v[0] == '1'; }();
   const int64_t HW = (int64_t)s.rows * s.cols, R = HW * s.n_layers;
   // (`use_table`: the game's table is there - the one-mover table in the spec, or, for two to
-  // four movers, the caller's pair / tuple table; CAMPX_NO_PIPE_MULTI=1: one-mover games only)
-  static const bool no_multi = [] { const char* v = getenv("CAMPX_NO_PIPE_MULTI"); return v && v[0] == '1'; }();
-  if (off || !use_table || s.n_dyn < 1 || s.n_dyn > CAMPX_MAX_DYN || (no_multi && s.n_dyn != 1) ||
-      !prev.trace || !prev.obs || prev.board)
+  // four movers, the caller's pair / tuple table)
+  if (!use_table || s.n_dyn < 1 || s.n_dyn > CAMPX_MAX_DYN || !prev.trace || !prev.obs || prev.board)
     return false;
   if (prev.obs_format != CAMPX_OBS_INT8 || prev.obs_t_stride != B * R) return false;
   if ((B * R) % 16 != 0 || B * R >= (int64_t)1 << 31 || T > 65535) return false;
@@ -1651,14 +1644,7 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
   // first wave of resident workgroups (5 per CU, 1 280): 1 024 of them (65 536 environments)
   // is where the shared launch stops winning consistently - single launches then swing
   // between 165 and 200 us - so it is taken up to 512 (32 768 environments).
-  static const int64_t max_b = [] {
-    const char* v = getenv("CAMPX_PIPE_MAX_B");
-    return (int64_t)(v && *v ? atoll(v) : 512 * kPipeEnvs);
-  }();
-  static const int64_t max_bytes = [] {
-    const char* v = getenv("CAMPX_PIPE_MAX_BYTES");
-    return (int64_t)(v && *v ? atoll(v) : 2000000000ll);
-  }();
+  constexpr int64_t max_b = 512 * kPipeEnvs, max_bytes = 2000000000ll;
   if (B > max_b || B * R * T > max_bytes) return false;
   if (s.n_dyn >= 2) {
     // Two to four movers (pipe_multi_kernel; sokoban levels 0 / 1 / 2, T = 100, of HBM peak, two
@@ -1670,11 +1656,7 @@ bool pipe_ok(const CampxSpec& s, const CampxOutputs& out, const CampxOutputs& pr
     // From 16 384 environments up the update pass of three- / four-mover games on a high-priority
     // side stream (campx::rollout_pipelined, one op) does better - 0.70 / 0.75, 32 768: 0.85 / 0.84 -
     // so they take the shared launch up to 8 192, the two-mover game up to 16 384.
-    static const int64_t forced = [] {
-      const char* v = getenv("CAMPX_PIPE_MULTI_MAX_B");
-      return (int64_t)(v && *v ? atoll(v) : -1);
-    }();
-    const int64_t multi_max = forced >= 0 ? forced : (s.n_dyn == 2 ? 16384 : 8192);
+    const int64_t multi_max = s.n_dyn == 2 ? 16384 : 8192;
     if (B > multi_max) return false;
   }
   (void)out;
@@ -1705,20 +1687,8 @@ static uint32_t next_flow_tag(CampxFlowState& l, void* block, int64_t block_byte
   return (uint32_t)l.tag;
 }
 
-static uint32_t flow_max_naps() {
-  static const uint32_t v = [] {
-    const char* e = getenv("CAMPX_FLOW_MAX_NAPS");
-    return (uint32_t)(e && *e ? strtoul(e, nullptr, 10) : kFlowMaxNaps);
-  }();
-  return v;
-}
-static uint32_t flow_debug_delay() {
-  static const uint32_t v = [] {
-    const char* e = getenv("CAMPX_FLOW_DEBUG_DELAY");
-    return (uint32_t)(e && *e ? strtoul(e, nullptr, 10) : 0u);
-  }();
-  return v;
-}
+static uint32_t flow_max_naps() { return (uint32_t)knob(K_FLOW_MAX_NAPS); }
+static uint32_t flow_debug_delay() { return (uint32_t)knob(K_FLOW_DEBUG_DELAY); }
 
 static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpec* spec_dev, CampxState st,
                                    const int8_t* actions, CampxOutputs out, CampxOutputs prev, int64_t B,
@@ -1775,9 +1745,8 @@ static int32_t launch_pipe_or_flow(bool flow, const CampxSpec& s, const CampxSpe
     const int n_entries = HW * HW * CAMPX_N_ACTIONS;
     // (the pair table's entries staged in LDS when they fit - charged to every workgroup of the
     // launch, the render ones too, and still the faster form: sokoban B = 4 096 / 8 192 / 16 384
-    // 48 / 50 / 66 us through L1 / L2, 37 / 41 / 60 from LDS; CAMPX_PIPE_PAIR_LDS=0: never)
-    static const bool want_lds = [] { const char* v = getenv("CAMPX_PIPE_PAIR_LDS"); return !(v && v[0] == '0'); }();
-    const bool in_lds = s.n_dyn == 2 && want_lds && n_entries <= kPairLdsEntries;
+    // 48 / 50 / 66 us through L1 / L2, 37 / 41 / 60 from LDS)
+    const bool in_lds = s.n_dyn == 2 && n_entries <= kPairLdsEntries;
     const size_t shmem = in_lds ? (((size_t)n_entries * sizeof(uint32_t) + 15) & ~(size_t)15) : 0;
 #define CAMPX_PIPE_MULTI(KK, LDS)                                                                        \
   do {                                                                                                   \
@@ -1834,16 +1803,12 @@ int32_t launch_pipe(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
 // B = 1 024 20.7 / 16.9, 4 096 27.9 / 23.8, 8 192 38.2 / 35.9, 16 384 60.2 / 61.8, 32 768 101 / 113,
 // 65 536 184 / 234 - the tagged copy is read from the fabric (write-through stores drop their
 // lines from L2) by every render wave, which costs more than hiding the update pass saves once
-// the render is the longer part: on for B <= 8 192 (CAMPX_FLOW_MAX_B), CAMPX_NO_FLOW=1: never.
+// the render is the longer part: on for B <= 8 192; setting flow=0: never.
 // Not while the stream is being captured into a graph: a replay would reuse the launch's tag.
 bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, bool use_table,
              hipStream_t stream, bool ask_stream) {
-  static const bool off = [] { const char* v = getenv("CAMPX_NO_FLOW"); return v && v[0] == '1'; }();
-  static const int64_t max_b = [] {
-    const char* v = getenv("CAMPX_FLOW_MAX_B");
-    return (int64_t)(v && *v ? atoll(v) : 8192);
-  }();
-  if (off || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
+  constexpr int64_t max_b = 8192;
+  if (!knob(K_FLOW) || B > max_b || !out.overlap_ctl || !out.trace || !out.obs) return false;
   // (no caller-owned tag state, or nowhere to report a render wave that gave up: two launches)
   if (!out.flow_state || !out.error_flag) return false;
   if (s.n_dyn < 1 || out.overlap_ctl_bytes < 16 + 2 * (int64_t)s.n_dyn * T * row_pitch(out, B) ||
@@ -1856,11 +1821,7 @@ bool flow_ok(const CampxSpec& s, const CampxOutputs& out, int64_t B, int32_t T, 
   // update role (64 environments a workgroup, its chain a load from the 212 MB tuple table per
   // frame, 128 VGPRs with 12 spilled) is the longer part of a small launch and slower beside
   // render waves than alone: it takes the one launch from 4 097 environments up only.
-  static const int64_t four_min_b = [] {
-    const char* v = getenv("CAMPX_FLOW4_MIN_B");
-    return (int64_t)(v && *v ? atoll(v) : 4097);
-  }();
-  if (s.n_dyn >= 4 && B < four_min_b) return false;
+  if (s.n_dyn >= 4 && B < 4097) return false;
   CampxOutputs self = out;
   self.board = nullptr;          // (rendered by the ordinary kernel afterwards)
   if (!pipe_ok(s, out, self, B, T, use_table)) return false;

@@ -19,7 +19,6 @@ namespace campx_impl {
 
 constexpr int kWideThreads = 256;
 constexpr int kWideAhead = 8;     // frames whose actions are fetched before their chain runs
-constexpr size_t kWideLdsMax = 144 * 1024;   // tables up to this size are staged in LDS
 
 struct WideParams {
   int32_t n_states, n_dyn;
@@ -724,12 +723,8 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   {
     // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
     const int HW = s->rows * s->cols, R = HW * s->n_layers;
-    static const bool no_step = [] {
-      const char* v = getenv("CAMPX_NO_WIDE_STEP");
-      return v && v[0] == '1';
-    }();
     if (T == 1 && !reset_first && (R & 15) == 0 &&
-        (!out.board || (HW & 15) == 0) && !no_step &&
+        (!out.board || (HW & 15) == 0) &&
         (int64_t)kStepEnvMax * R < (1ll << 24)) {
       WideStepParams sp;
       memset(&sp, 0, sizeof(sp));
@@ -798,10 +793,9 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   int32_t* state = reinterpret_cast<int32_t*>(st.pos);
   const size_t want = (size_t)(w.cells_off) + (size_t)s->n_states * sizeof(u32x4) +
                       (out.perf ? (size_t)w.n_entries : 0);
-  // (CAMPX_WIDE_LDS_MAX=bytes, read at every launch: tests run small games through the
-  // global-memory path that games with thousands of states take)
-  size_t lds_max = kWideLdsMax;
-  if (const char* v = getenv("CAMPX_WIDE_LDS_MAX")) lds_max = (size_t)atoll(v) < kWideLdsMax ? (size_t)atoll(v) : kWideLdsMax;
+  // (setting wide_lds_max = bytes: tests run small games through the global-memory path that
+  // games with thousands of states take)
+  const size_t lds_max = (size_t)knob(K_WIDE_LDS_MAX);
   const bool in_lds = want <= lds_max;
   const size_t lds = in_lds ? want : 0;
   const dim3 grid((unsigned)((B + kWideThreads - 1) / kWideThreads));

@@ -52,13 +52,13 @@ from .rendering import Observation
 COMPILE_TABLE = True
 # Rollouts that keep every frame run the update pass and the render as two kernels
 # (needs a [K, T, B] uint8 trace buffer; NOTES.md "Kernels", profiles/): faster for
-# every game, tabulated update pass or interpreted.  CAMPX_SPLIT=0 keeps everything in
+# every game, tabulated update pass or interpreted.  False keeps everything in
 # the single fused kernel; parity tests run both.
-SPLIT_ROLLOUT = os.environ.get('CAMPX_SPLIT', '1') != '0'
+SPLIT_ROLLOUT = True
 FORCE_SPLIT = SPLIT_ROLLOUT   # kept for callers that toggled it: same as SPLIT_ROLLOUT now
 # Pad the rows of the per-frame streams to a multiple of 16 elements (see rollout_buffers).
-# CAMPX_ROW_PITCH=0 keeps them back to back: the A/B of tools/gpu_odd_ab.sh.
-PAD_ROWS = os.environ.get('CAMPX_ROW_PITCH', '1') != '0'
+# (False keeps them back to back: B = 65 535 then costs 47 instead of 16 us per 100 frames.)
+PAD_ROWS = True
 
 _OBS_DTYPES = (torch.int8, torch.float16, torch.bfloat16)
 
@@ -67,10 +67,6 @@ def _ptr(t):
   return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-# (A/B knob: deferred rollouts of multi-mover games past the shared launch run in order)
-_PIPELINE_DEFERRED = os.environ.get('CAMPX_NO_PIPELINE_DEFERRED', '0') != '1'
-# (A/B knob: the two-stream choreography of pipelined rollouts from Python instead of the C++ op)
-_PIPELINE_IN_CPP = os.environ.get('CAMPX_PIPELINE_PY', '0') != '1'
 
 
 class FusedGame(object):
@@ -194,31 +190,11 @@ class FusedGame(object):
     self._deferred = None      # rollout_deferred(): the dict whose observations are still owed
     self._deferred_rendered = False    # ... unless that rollout was run whole (no shared launch)
     self._shared_launch = {}   # T -> whether campx_update_render_launch shares one launch
-    # pipelined rollouts: the update pass runs on this side stream
-    self._aux = None
-    self._aux_event = None
+    # pipelined rollouts (campx::rollout_pipelined keeps the side stream): whether that stream
+    # already comes after everything this game issued on the caller's stream
     self._aux_in_sync = False
-    self.aux_cus = int(os.environ.get('CAMPX_AUX_CUS', '0'))   # pipelined update passes: CU subset
-    self._trace_readers = {}   # trace buffer address -> event after the render that read it
 
   # ------------------------------------------------------------------ helpers
-
-  def _side_stream(self):
-    """The stream of pipelined update passes: an ordinary one, or - `aux_cus = n` - one
-    confined to n compute units (campx_stream_create_cu_subset), so that the update pass
-    cannot take workgroup slots from the render kernel it runs under."""
-    if not self.aux_cus:
-      # (a HIGH-priority side stream: the short update pass is scheduled ahead of the render
-      # blocks it runs under - sokoban with three boxes, B = 16 384 / 32 768: 0.53 / 0.64 of peak
-      # at normal priority, 0.70 / 0.78 at high, 0.60 / 0.72 for launches in order;
-      # profiles/r05_multimover_pipeline_ab.txt.  CAMPX_AUX_PRIORITY=0: normal)
-      return torch.cuda.Stream(self.device, priority=int(os.environ.get('CAMPX_AUX_PRIORITY', '-1')))
-    raw = ctypes.c_void_p()
-    with torch.cuda.device(self.device):
-      _hip.check(_hip.lib.campx_stream_create_cu_subset(int(self.aux_cus), ctypes.byref(raw)),
-                 'campx_stream_create_cu_subset')
-    self._aux_raw = raw          # (lives as long as the game: destroyed with the process)
-    return torch.cuda.ExternalStream(raw.value, device=self.device)
 
   def _observation(self, obs, board):
     layers = {ch: obs[:, i] for i, ch in enumerate(self.chars)}
@@ -517,53 +493,19 @@ class FusedGame(object):
       if out['trace'] is None:
         raise ValueError('pipelined rollouts need the two-kernel path (a trace buffer: '
                          'keep_obs=True on a game whose update pass is tabulated)')
-      if not self.aux_cus and _PIPELINE_IN_CPP:
-        # one op does the two-stream choreography (csrc/campx_torch.cpp rollout_pipelined: the
-        # update pass on a high-priority side stream, the render on this stream behind it; from
-        # Python - below, kept for the CU-subset A/B - the same calls cost the host 36-46 us)
-        # (ids made from the caller's actions by kernels on THIS stream - clamp / to(int8) /
-        # onehot_to_ids - are work the side stream has to come after: resync for this call)
-        self._rollout_pipelined(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
-                                self._pair_table, ids, out['obs'], out['board'], out['reward'],
-                                out['discount'], out['done'], out['perf'], out['trace'],
-                                self._bad if validate else None,
-                                self._bad_flag if validate else None, bool(reset_first),
-                                not self._aux_in_sync or ids is not actions)
-        self._aux_in_sync = True
-        self.frame = T if reset_first else self.frame + T
-        self.check_ok()
-        if validate:
-          self._after_launch()
-        return out
-      main = torch.cuda.current_stream(self.device)
-      if self._aux is None:
-        self._aux = self._side_stream()
-        self._aux_event = torch.cuda.Event()
-      if not self._aux_in_sync or ids is not actions:
-        self._aux.wait_stream(main)      # state set up by earlier non-pipelined work; ids made on `main`
-        self._aux_in_sync = True
-        self._trace_readers.clear()      # ... which also covers every render issued so far
-      # The side stream runs ahead of the main one without bound; what it may not do is
-      # overwrite a trace buffer that a render on the main stream is still reading (with two
-      # alternating buffer sets: the render of two calls ago).
-      trace_key = out['trace'].data_ptr()
-      if len(self._trace_readers) >= 64 and trace_key not in self._trace_readers:
-        self._aux.wait_stream(main)      # (new buffers every call: let the old events go)
-        self._trace_readers.clear()
-      reader = self._trace_readers.get(trace_key)
-      if reader is not None:
-        self._aux.wait_event(reader)
-      with torch.cuda.stream(self._aux):
-        self._update(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
-                     self._pair_table, ids, out['reward'], out['discount'], out['done'],
-                     out['perf'], out['trace'], self._bad if validate else None,
-                     self._bad_flag if validate else None, bool(reset_first))
-        self._aux_event.record(self._aux)
-      main.wait_event(self._aux_event)
-      self._render(self._spec_host, self._spec_dev, out['trace'], out['obs'], out['board'])
-      if reader is None:
-        reader = self._trace_readers[trace_key] = torch.cuda.Event()
-      reader.record(main)
+      # one op does the two-stream choreography (csrc/campx_torch.cpp rollout_pipelined: the
+      # update pass on a high-priority side stream, the render on this stream behind it; from
+      # Python the same calls cost the host 36-46 us and are gone, as is the side stream confined
+      # to a subset of the compute units - measured slower, profiles/r03_cumask_ab.txt).
+      # (ids made from the caller's actions by kernels on THIS stream - clamp / to(int8) /
+      # onehot_to_ids - are work the side stream has to come after: resync for this call)
+      self._rollout_pipelined(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
+                              self._pair_table, ids, out['obs'], out['board'], out['reward'],
+                              out['discount'], out['done'], out['perf'], out['trace'],
+                              self._bad if validate else None,
+                              self._bad_flag if validate else None, bool(reset_first),
+                              not self._aux_in_sync or ids is not actions or pipelined == 'resync')
+      self._aux_in_sync = True
     else:
       self._aux_in_sync = False
       self._rollout(self._spec_host, self._spec_dev, self.pos, self.done, self.ret,
@@ -664,7 +606,7 @@ class FusedGame(object):
       # Separate observation buffers: the whole rollout now, rendered while its trace is still
       # cached.  `out` is complete a call early; what the caller sees is the same.
       self.flush()
-      if (actions_ready and out['obs'].dtype == torch.int8 and _PIPELINE_DEFERRED and
+      if (actions_ready and out['obs'].dtype == torch.int8 and
           self.batch > 8192 and (self.n_dyn >= 3 or self.batch < 32768)):
         # Games of two to four movers past the shared launch's bounds (16 384 environments with
         # two movers, 8 192 with more): the update pass on the (high-priority) side stream, under
@@ -674,7 +616,9 @@ class FusedGame(object):
         # 0.84, 65 536 0.81 -> 0.77-0.85 / 0.81 -> 0.86; the two-mover game gains nothing from 32 768
         # up (0.73 -> 0.74, 0.83 -> 0.81) and stays in order (profiles/r05_multimover_deferred_ab.txt).
         # Complete a call early, like the rollout below.
-        self.rollout(ids, out=out, reset_first=reset_first, pipelined=True)
+        # (ids this call made from the caller's actions, on the caller's stream: the side stream waits)
+        self.rollout(ids, out=out, reset_first=reset_first,
+                     pipelined='resync' if ids is not actions else True)
         self._deferred, self._deferred_rendered = out, True
         return prev
       self._aux_in_sync = False

@@ -29,8 +29,8 @@ from .rendering import Observation
 # observation arithmetically from 64-bit row words (the things' masks in every column rotation,
 # the per-environment trail words of sprites painted before the first drape) - the one-cell
 # tier's store pattern instead of "every wave streams its own row".  Boards with rows of 16 to 64
-# cells; CAMPX_SHAPE_SPLIT=0 (read by the library too): always the one-wave-per-environment kernel.
-FRAME_MAJOR = os.environ.get('CAMPX_SHAPE_SPLIT', '1') != '0'
+# cells; False (or the library setting shape_split=0): always the one-wave-per-environment kernel.
+FRAME_MAJOR = True
 
 
 class ShapeGame(object):

@@ -657,15 +657,27 @@ int32_t campx_onehot_to_ids_launch(const float* onehot, int8_t* ids, int64_t n,
                                    int32_t* bad_count, void* stream);
 
 /*
- * A stream whose kernels may only run on `n_cus` of the device's compute units, spread evenly
- * over the chip (hipExtStreamCreateWithCUMask).  For callers that overlap the short,
- * latency-bound update pass of one launch with the observation stream of the previous one
- * (campx_update_launch / campx_render_launch on two streams): confined to a few CUs the
- * update pass cannot take workgroup slots from the render's blocks.  Destroy with
- * campx_stream_destroy().  CAMPX_EINVAL unless 1 <= n_cus <= the device's CU count.
+ * Settings: everything about the library's behaviour that is not an argument of a call.  ONE table
+ * (campx_amd/csrc/campx_api.hip: name, default, range, what each selects; INTEGRATION.md lists
+ * them).  A value is set for the process by campx_config_set() - thread-safe, takes effect with
+ * the next call - or, before the library's first call, by the environment variable
+ * CAMPX_CONFIG="name=value,name=value" (the library's only getenv).  campx_config_string() writes
+ * "name=value name=value ..." of the EFFECTIVE values into `buf` (host, NUL-terminated, truncated to
+ * buf_len) and returns the length needed including the NUL; a bench or an embedding application
+ * records it beside its numbers.  campx_config_set / _get return CAMPX_EINVAL for a name that is
+ * not in the table or a value outside its range.  No reference counterpart.
  */
-int32_t campx_stream_create_cu_subset(int32_t n_cus, void** stream_out);
-int32_t campx_stream_destroy(void* stream);
+int32_t campx_config_set(const char* name, int64_t value);
+int32_t campx_config_get(const char* name, int64_t* value);
+int32_t campx_config_string(char* buf, int32_t buf_len);
+
+/* Measurement aid, not on the path (SURVEY section 8d "Bound": the measured achievable HBM write
+ * bandwidth of the box, quoted next to the vendor peak): one launch that fills `n_bytes` (a
+ * multiple of 16, `dst` 16-byte aligned, DEVICE memory) with the 32-bit `value` through the render
+ * kernel's own store form - 16 bytes per lane, `sc0 sc1 nt`, one 2 KiB window per wave,
+ * XCD-contiguous block order - and nothing else.  bench.py times it over the bytes a rollout
+ * launch writes: `roofline.measured_write_ceiling_gbs`.  No reference counterpart. */
+int32_t campx_write_probe_launch(void* dst, int64_t n_bytes, uint32_t value, void* stream);
 
 const char* campx_strerror(int32_t code);
 /* hipError_t of the most recent failed HIP call on this thread (0 if none). */

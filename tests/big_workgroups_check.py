@@ -1,4 +1,4 @@
-"""Run by tests/test_update_workgroups.py in a child process with CAMPX_BIG_WGS=1, which makes
+"""Run by tests/test_update_workgroups.py in a child process; the library setting big_wgs=1 makes
 the library pick its 512-environment update workgroups from B = 512 up (it reads the knob
 once per process): ragged batches around that size against the oracle, bit for bit."""
 import os
@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from campx_amd import gamespec           # noqa: E402
+from campx_amd import _hip, gamespec     # noqa: E402
 from oracle import cpu                    # noqa: E402
 from games_under_test import FUSED_GAMES  # noqa: E402
 
@@ -22,7 +22,7 @@ def same(a, b):
 
 
 def main():
-  assert os.environ.get('CAMPX_BIG_WGS') == '1'
+  _hip.config_set('big_wgs', 1)        # the 512-environment workgroups from one workgroup up
   rng = np.random.RandomState(7)
   for name in ('boat_race', 'wall_world', 'sokoban', 'demo3'):
     og = cpu.OracleGame.from_description(gamespec.describe(FUSED_GAMES[name]()))

@@ -25,6 +25,38 @@ def _run(extra, env_extra=None):
                         capture_output=True, text=True, timeout=600, env=env)
 
 
+def _details(run):
+  """The second record of a bench run: what does not fit a line a parser keeps whole (the timed
+  window's breakdown, every gather's times) - one JSON line on stderr, marked."""
+  rows = [l for l in run.stderr.splitlines() if l.startswith('BENCH_DETAILS ')]
+  assert len(rows) == 1, run.stderr[-2000:]
+  return json.loads(rows[0][len('BENCH_DETAILS '):])
+
+
+# the scalars that let a first, blind multi-GPU run explain itself (VERDICT r5 item 7)
+SELF_DIAGNOSIS = ('worst_rank', 'worst_rank_ms_per_step', 'worst_rank_kernel_ms', 'best_rank_kernel_ms',
+                  'efficiency_vs_own_kernel', 'gather_count', 'gather_call_us_max', 'gather_exposed_us_max',
+                  'window_loop_us', 'window_launches_us', 'window_log_wait_us', 'window_synchronize_us',
+                  'window_total_us', 'untimed_launches_before_window', 'numa_node', 'cpus_pinned')
+
+
+def _self_diagnosing(line, world):
+  cfg = line['config']
+  for key in SELF_DIAGNOSIS:
+    assert key in cfg and not isinstance(cfg[key], (list, dict)), key     # scalars: they survive a parser
+  assert 0 <= cfg['worst_rank'] < world
+  assert cfg['worst_rank_ms_per_step'] == max(cfg['per_rank_ms_per_step'])
+  assert abs(cfg['worst_rank_ms_per_step'] - line['ms_per_step']) < 1e-6 * line['ms_per_step']
+  assert len(cfg['per_rank_kernel_ms']) == world and len(cfg['per_rank_numa_node']) == world
+  assert cfg['best_rank_kernel_ms'] == min(cfg['per_rank_kernel_ms'])
+  assert 0 < cfg['efficiency_vs_own_kernel'] <= 1.0 + 1e-9
+  assert abs(cfg['efficiency_vs_own_kernel'] -
+             cfg['best_rank_kernel_ms'] / cfg['worst_rank_ms_per_step']) < 1e-9
+  assert cfg['gather_exposed_us_max'] >= 0 and cfg['gather_call_us_max'] >= 0
+  assert abs(cfg['window_total_us'] - (cfg['window_loop_us'] + cfg['window_launches_us'] +
+                                        cfg['window_log_wait_us'] + cfg['window_synchronize_us'])) < 1.0
+
+
 def test_gpus_2_spawns_two_ranks_and_prints_one_line(tmp_path):
   csv_path = str(tmp_path / 'episodes.csv')
   r = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '64',
@@ -50,6 +82,9 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line(tmp_path):
   assert line['config']['per_rank_gathered_log_matches_local'] == [True, True]
   assert line['config']['rccl_world'] is None          # gloo stand-in: no RCCL in this run
   assert line['config']['gather_every'] == 2 and line['config']['settle_launches'] == 0
+  _self_diagnosing(line, 2)
+  details = _details(r)
+  assert set(details['window_us']) >= {'loop', 'launches', 'log_wait', 'synchronize', 'total'}
 
 
 def test_force_dist_goes_through_the_launcher_with_one_rank():
@@ -84,6 +119,7 @@ def test_gpus_8_the_baseline_config_5_shape():
   assert abs(max(per_rank) - line['ms_per_step']) < 1e-6 * line['ms_per_step']
   assert line['config']['per_rank_gathered_log_matches_local'] == [True] * 8
   assert line['config']['gather_every'] == 1           # the clamp: never rarer than the run
+  _self_diagnosing(line, 8)
 
 
 def test_one_rank_times_the_same_protocol_as_the_ranks_of_a_sharded_run():
@@ -159,8 +195,8 @@ def test_eight_rccl_ranks_keep_the_one_rank_step_time(tmp_path):
   assert cfg['per_rank_gathered_log_matches_local'] == [True] * 8
   record = {'n1': {'value': base['value'], 'ms_per_step': base['ms_per_step']},
             'n8': {'value': line['value'], 'ms_per_step': line['ms_per_step'],
-                   'per_rank_ms_per_step': cfg['per_rank_ms_per_step'], 'window_us': cfg['window_us'],
-                   'gathers': cfg['gathers']},
+                   'per_rank_ms_per_step': cfg['per_rank_ms_per_step'],
+                   'per_rank_kernel_ms': cfg['per_rank_kernel_ms'], **_details(r)},
             'efficiency': line['value'] / (8 * base['value'])}
   out = os.path.join(REPO, 'gpurun_out', 'scale_8gpu_test.json')
   os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -176,7 +212,7 @@ def test_one_rccl_rank_through_the_real_launcher():
   """What a one-GPU box CAN show of that path: the launcher, an RCCL group of one, the gather -
   at the DRIVER's own command (`--steps 20 --warmup 5`).  VERDICT r4: the driver's round-4 line
   read ms_per_step = 1.219 x kernel_ms (0.8 ms after the last launch); the line now says where a
-  window's time went (`config.window_us`, `config.gathers`), RCCL's stream is high priority, and
+  window's time went (`config.window_*_us`, `config.gather_*`, the BENCH_DETAILS record on stderr), RCCL's stream is high priority, and
   60 driver-style runs read 1.008-1.026 (profiles/r05_driver_repro.txt): the bound is 1.05."""
   r = _run(['--gpus', '1', '--force-dist', '--steps', '20', '--warmup', '5', '--no-cpu-baseline',
             '--no-extras'])
@@ -185,7 +221,10 @@ def test_one_rccl_rank_through_the_real_launcher():
   cfg = line['config']
   assert cfg['rccl_world'] == 1 and cfg['gathered_log_matches_local'] is True
   # where the window's time went, and when its one gather ran: well before the launches ended
-  w, g = cfg['window_us'], cfg['gathers']
+  details = _details(r)
+  w, g = details['window_us'], details['gathers']
+  _self_diagnosing(line, 1)
+  assert cfg['gather_count'] == 1 and cfg['gather_exposed_us_max'] == 0.0
   assert set(w) >= {'loop', 'launches', 'log_wait', 'synchronize', 'total', 'launches_done'} and len(g) == 1
   assert abs(w['total'] - line['ms_per_step'] * 20 * 1e3) < 1.0
   assert 0 < g[0]['ready_us'] < w['launches_done']

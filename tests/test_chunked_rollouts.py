@@ -1,8 +1,9 @@
 """Long rollouts run as chunks of frames (update pass and render alternating) so that the
 trace the render kernel reads stays cached; the library cuts from a 28 MB trace up, 16 MB per
-chunk.  Here the same code at test sizes: CAMPX_TRACE_WHOLE_MB=0 / CAMPX_TRACE_CHUNK_MB=0 make
-every rollout longer than 16 frames run in 16-frame chunks (the library reads the knobs once
-per process, hence the child process)."""
+chunk.  Here the same code at test sizes: the settings trace_whole_mb=0 / trace_chunk_mb=0 make
+every rollout longer than 16 frames run in 16-frame chunks.  A whole test FILE is run again under
+them, so they are given the way an embedding process would give them for its lifetime: the
+library's one environment variable, CAMPX_CONFIG (include/campx_hip.h)."""
 import os
 import subprocess
 import sys
@@ -14,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_rollouts_in_16_frame_chunks_match_the_goldens_and_the_oracle():
-  env = dict(os.environ, CAMPX_TRACE_WHOLE_MB='0', CAMPX_TRACE_CHUNK_MB='0')
+  env = dict(os.environ, CAMPX_CONFIG='trace_whole_mb=0,trace_chunk_mb=0')
   run = subprocess.run(
       [sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_fused_parity.py'), '-m', 'gpu', '-q',
        '-x', '-k', 'golden_traj or random_streams or sixteen_bit_obs or reset_first or keep_obs',

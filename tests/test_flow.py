@@ -4,7 +4,7 @@ update workgroups first, render workgroups of the SAME rollout behind
 them, reading a tagged 16-bit copy of the trace as the update role writes it).  The default path
 of `rollout()` up to 8 192 environments, so every parity test of such games already runs it; here:
 that it IS the path taken (the profiler sees one kernel), the same bytes with it switched off
-(CAMPX_NO_FLOW=1, a subprocess: the knob is read once), rollouts of changing length and state
+(the library setting flow=0), rollouts of changing length and state
 carried over (the tagged copy is re-zeroed when T changes, tags wrap after 255 launches), and a
 rollout captured into a HIP graph (must NOT take it: a replay would reuse the launch's tag)."""
 
@@ -138,10 +138,11 @@ _CODE = r'''
 import sys
 sys.path.insert(0, %(repo)r)
 import numpy as np, torch
-from campx_amd import gamespec
+from campx_amd import _hip, gamespec
 from campx_amd.games import boat_race
 from oracle import cpu
 from torch.profiler import ProfilerActivity, profile
+_hip.config_set('flow', 0)          # never the one-launch rollout: update pass, then render
 B = 4096
 game = boat_race.build(batch=B, device='cuda')
 game.its_showtime()
@@ -161,8 +162,7 @@ print('ok')
 
 
 def test_switched_off_the_two_launches_give_the_same_bytes():
-  env = dict(os.environ, CAMPX_NO_FLOW='1')
-  out = subprocess.run([sys.executable, '-c', _CODE], env=env, capture_output=True, text=True,
+  out = subprocess.run([sys.executable, '-c', _CODE], capture_output=True, text=True,
                        timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
   assert out.stdout.strip().endswith('ok')
@@ -185,7 +185,10 @@ _GIVE_UP = r'''
 import sys
 sys.path.insert(0, %(repo)r)
 import torch
+from campx_amd import _hip
 from campx_amd.games import boat_race, sokoban
+_hip.config_set('flow_max_naps', %(naps)d)
+_hip.config_set('flow_debug_delay', 3000)
 B, T = 4096, 40
 game = %(build)s(batch=B, device='cuda')
 game.its_showtime()
@@ -209,17 +212,15 @@ else:
 @pytest.mark.parametrize('build', ['boat_race.build', 'sokoban.build'])
 def test_a_render_wave_that_gives_up_says_so(build):
   """a render wave whose trace entries never get this launch's tag used to
-  `break` and render stale bytes without a word.  Provoked here with the library's two test knobs -
+  `break` and render stale bytes without a word.  Provoked here with the library's two test settings (flow_max_naps, flow_debug_delay) -
   the update role held back by a sleep, render waves allowed ONE second look - the launch must
   raise CAMPX_ERR_FLOW_TIMEOUT in the error word and `rollout()` / `check_ok()` a RuntimeError."""
-  env = dict(os.environ, CAMPX_FLOW_MAX_NAPS='1', CAMPX_FLOW_DEBUG_DELAY='3000')
-  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO, build=build)], env=env,
+  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO, build=build, naps=1)],
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
   assert out.stdout.strip().endswith('raised'), out.stdout[-500:]
   # ... and with the default patience the same delay is simply waited out: right frames, no error
-  env = dict(os.environ, CAMPX_FLOW_DEBUG_DELAY='3000')
-  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO, build=build)], env=env,
+  out = subprocess.run([sys.executable, '-c', _GIVE_UP % dict(repo=REPO, build=build, naps=1 << 20)],
                        capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stderr[-3000:]
   assert out.stdout.strip().endswith('silent'), out.stdout[-500:]

@@ -170,7 +170,8 @@ _CHUNKED = r'''
 import sys
 sys.path.insert(0, %(repo)r); sys.path.insert(0, %(tests)r)
 import numpy as np, torch
-from campx_amd import gamespec
+from campx_amd import _hip, gamespec
+_hip.config_set('shape_chunk_kf', 1)        # chunks of 1 000 environment-frames
 from games_under_test import SHAPE_GAMES
 from oracle import cpu
 for name, batch in (('hello_world', 64), ('shape_zoo3', 1000), ('shape_zoo4', 64)):
@@ -193,7 +194,7 @@ print('ok')
 
 
 def test_long_launches_run_as_chunks_of_frames():
-  """A launch of more than CAMPX_SHAPE_CHUNK_KF thousand environment-frames (default 2 000) runs
+  """A launch of more than `shape_chunk_kf` thousand environment-frames (a library setting, default 2 000) runs
   as chunks - update pass and render alternating, positions / trail words / returns carried from
   chunk to chunk - so that a chunk's offset trace and keyframes stay in the memory-side cache.
   With the bound set to 1 000 environment-frames: 64 environments x 70 frames in chunks of 12, 1 000
@@ -202,9 +203,8 @@ def test_long_launches_run_as_chunks_of_frames():
   import subprocess
   import sys
   from conftest import REPO
-  env = dict(os.environ, CAMPX_SHAPE_CHUNK_KF='1')
   out = subprocess.run([sys.executable, '-c', _CHUNKED % dict(repo=REPO, tests=os.path.join(REPO, 'tests'))],
-                       env=env, capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
   assert out.stdout.strip().endswith('ok')
 

@@ -12,8 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_big_update_workgroups_at_ragged_batches():
-  env = dict(os.environ, CAMPX_BIG_WGS='1')
-  run = subprocess.run([sys.executable, os.path.join(HERE, 'big_workgroups_check.py')], env=env,
+  run = subprocess.run([sys.executable, os.path.join(HERE, 'big_workgroups_check.py')],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
   assert run.returncode == 0, run.stdout[-3000:]
   assert run.stdout.count('ok ') == 12, run.stdout[-3000:]      # 4 games x 3 batches

@@ -441,7 +441,7 @@ def test_six_things_that_show_through_the_wide_kernels():
 @pytest.mark.gpu
 def test_state_tables_too_large_for_lds_are_read_through_the_caches():
   """Games with thousands of states keep their table in global memory (wide_update_kernel<false>);
-  CAMPX_WIDE_LDS_MAX=0 sends a small game down that path: same bytes."""
+  the library setting wide_lds_max=0 sends a small game down that path: same bytes."""
   game = _big_vault(batch=5000, device='cuda')
   game.its_showtime()
   rng = np.random.RandomState(9)
@@ -449,11 +449,9 @@ def test_state_tables_too_large_for_lds_are_read_through_the_caches():
   acts[:, 0] = np.resize([1] * 5 + [3] * 5 + [1] * 3 + [2] * 5 + [1] * 5, 90)   # key, door, gem
   actions = torch.from_numpy(acts)
   ref = game.rollout(actions, reset_first=True, want_board=True)
-  os.environ['CAMPX_WIDE_LDS_MAX'] = '0'
-  try:
+  from campx_amd import _hip
+  with _hip.config(wide_lds_max=0):
     out = game.rollout(actions, reset_first=True, want_board=True)
-  finally:
-    del os.environ['CAMPX_WIDE_LDS_MAX']
   for k in ('obs', 'board', 'trace', 'done'):
     assert torch.equal(out[k], ref[k]), k
   for k in ('reward', 'discount'):

@@ -32,14 +32,16 @@ def main():
   print('# run  ms_per_step  kernel_ms  ratio   loop launches log_wait  sync | launches_done(dev)  gather: ready(dev) | issued+call..seen_done(host), done when the launches ended? (us)')
   worst = 0.0
   for i in range(n):
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
       d = json.loads(r.stdout.strip().splitlines()[-1])
     except (IndexError, ValueError):
       print('%3d  rc=%d no line' % (i, r.returncode))
       continue
-    w = d['config']['window_us']
-    g = d['config']['gathers'] or []
+    extra_rows = [l for l in r.stderr.splitlines() if l.startswith('BENCH_DETAILS ')]
+    details = json.loads(extra_rows[-1][len('BENCH_DETAILS '):]) if extra_rows else {}
+    w = details.get('window_us') or {'loop': 0.0, 'log_wait': 0.0, 'synchronize': 0.0}
+    g = details.get('gathers') or []
     ratio = d['ms_per_step'] / d['roofline']['kernel_ms']
     worst = max(worst, ratio)
     print('%3d  %.4f  %.4f  %.3f  %6.0f %6.0f %6.0f %6.0f | %6.0f  %s' % (

@@ -36,6 +36,44 @@ def per_dispatch(db, counter):
   return {k: (sorted(v)[len(v) // 2] * 1024.0, len(v)) for k, v in per.items()}
 
 
+def totals(db, counter):
+  """kernel -> (bytes over ALL its dispatches of the run, dispatches)."""
+  cur = sqlite3.connect(db).cursor()
+  rows = cur.execute('select kernel_name, count(distinct dispatch_id), sum(value) from counters_collection '
+                     'where counter_name = ? group by kernel_name', (counter,)).fetchall()
+  return {k: (v * 1024.0, n) for k, n, v in rows}
+
+
+def launches_of(log):
+  """Rollout launches of the bench run whose output is in `log`: warm-up + settle + the timed
+  steps + the untimed per-launch pass (bench.py measure_rollout)."""
+  for raw in reversed(open(log).read().splitlines()):
+    if raw.startswith('{'):
+      line = json.loads(raw)
+      return line['warmup'] + line['config']['settle_launches'] + 2 * line['steps']
+  raise ValueError('no bench line in ' + log)
+
+
+def shape_entry(d, game, batch, frames, rnd):
+  """The shape tier runs a launch as several chunks of update pass + render (+ the backdrop /
+  trail-word conversions at its ends): per LAUNCH = the kernels' bytes over the whole run / the
+  run's launches (each pass prints its own bench line: the settle count differs under counters)."""
+  out = {}
+  for name, counter, log in (('write_bytes', 'WRITE_SIZE', 'pmc_write'), ('fetch_bytes', 'FETCH_SIZE', 'pmc_fetch')):
+    per = totals(os.path.join(d, log + '_results.db'), counter)
+    n = launches_of(os.path.join(d, log + '.log'))
+    names = [k for k in per if 'shape_' in k]
+    # (FETCH_SIZE doubled for the update pass's wide action loads, as for the one-cell tier)
+    out[name] = sum(per[k][0] * (2.0 if counter == 'FETCH_SIZE' and 'shape_update' in k else 1.0)
+                    for k in names) / n
+    out['kernels'] = ' + '.join(sorted({k.replace('(anonymous namespace)::', '').replace('campx_impl::', '').split('(')[0].split('<')[0]
+                                        for k in names}))
+    out[name.replace('bytes', 'launches')] = n
+  out['traffic_bytes'] = out['write_bytes'] + out['fetch_bytes']
+  out['source'] = 'profiles/{}_{}_rocprofv3.txt'.format(rnd, game)
+  return out
+
+
 def main(specs):
   rnd = 'r04'
   if specs and specs[0] == '--round':
@@ -50,6 +88,9 @@ def main(specs):
   table['_comment'] = __doc__.split('\n\n', 2)[2].strip().replace('\n', ' ')
   for spec in specs:
     d, game, batch, frames = spec.split(':')
+    if game.startswith('hello') or game.startswith('shape'):
+      table['{}:{}:{}:split'.format(game, batch, frames)] = shape_entry(d, game, batch, frames, rnd)
+      continue
     w = per_dispatch(os.path.join(d, 'pmc_write_results.db'), 'WRITE_SIZE')
     f = per_dispatch(os.path.join(d, 'pmc_fetch_results.db'), 'FETCH_SIZE')
     names = [k for k in w if 'render_kernel' in k or 'update_' in k or 'rollout_kernel' in k]
