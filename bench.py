@@ -620,18 +620,12 @@ def play_mode(device, B=65536, calls=2000):
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / calls
     modes[name] = {'us_per_call': dt * 1e6, 'env_steps_per_s': B / dt}
-  # the same frames captured once in a HIP graph (campx::step only enqueues kernels on
-  # the current stream): one graph launch per 32 frames instead of 32 op dispatches
+  # the same frames captured once in a HIP graph (Engine.capture_play, campx_amd/play_graph.py:
+  # campx::step only enqueues kernels on the current stream): one launch of the host's per 32
+  # frames instead of 32 op dispatches
   game.fused.validate_actions = False
-  side = torch.cuda.Stream(device)
-  with torch.cuda.stream(side):
-    for i in range(4):
-      game.play(rows[i])
-  torch.cuda.current_stream(device).wait_stream(side)
-  graph = torch.cuda.CUDAGraph()
-  with torch.cuda.graph(graph):
-    for i in range(32):
-      game.play(rows[i])
+  graph = game.capture_play(32)
+  graph.actions.copy_(acts[:32])
   for _ in range(5):
     graph.replay()
   torch.cuda.synchronize(device)
@@ -641,6 +635,39 @@ def play_mode(device, B=65536, calls=2000):
   torch.cuda.synchronize(device)
   dt = (time.perf_counter() - t0) / (calls // 32 * 32)
   modes['hip_graph_32_frames'] = {'us_per_call': dt * 1e6, 'env_steps_per_s': B / dt}
+  # ... and the closed loop of examples/reinforce.py:136-149 - policy forward (its one-hidden-layer
+  # network, reinforce.py:53-67, in bf16 straight from the engine's bf16 observation), sampling,
+  # play() - op by op from Python, and as one graph of 32 frames
+  game.fused.set_play_obs_dtype(torch.bfloat16)
+  n_in = game.fused.n_layers * game.fused.rows * game.fused.cols
+  net = torch.nn.Sequential(torch.nn.Linear(n_in, 32), torch.nn.ReLU(), torch.nn.Linear(32, 5)).to(
+      device=device, dtype=torch.bfloat16)
+
+  def policy(obs, t):
+    logits = net(obs.layered_board.view(B, n_in))
+    return torch.multinomial(torch.softmax(logits.float(), dim=-1), 1).squeeze(1)
+
+  frames = max(32, calls // 8 // 32 * 32)
+  with torch.no_grad():
+    for i in range(20):
+      game.play(policy(game.fused._observation_cache, i).to(torch.int8))
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(frames):
+      game.play(policy(game.fused._observation_cache, i).to(torch.int8))
+    torch.cuda.synchronize(device)
+  dt = (time.perf_counter() - t0) / frames
+  modes['policy_eager'] = {'us_per_frame': dt * 1e6, 'env_steps_per_s': B / dt}
+  closed = game.capture_play(32, policy=policy)
+  for _ in range(3):
+    closed.replay()
+  torch.cuda.synchronize(device)
+  t0 = time.perf_counter()
+  for _ in range(frames // 32):
+    closed.replay()
+  torch.cuda.synchronize(device)
+  dt = (time.perf_counter() - t0) / frames
+  modes['policy_in_graph'] = {'us_per_frame': dt * 1e6, 'env_steps_per_s': B / dt}
   return {'workload': 'boat_race 5x5, batch={}, Engine.play() per frame through '
                       'campx::step, {} calls'.format(B, calls), **modes}
 
@@ -875,6 +902,8 @@ def run_rank(args):
       line['play_mode'] = play_mode(device)
       line['config']['play_us_per_call'] = line['play_mode']['validate_off']['us_per_call']
       line['config']['play_graph32_us_per_call'] = line['play_mode']['hip_graph_32_frames']['us_per_call']
+      line['config']['policy_eager_us_per_frame'] = line['play_mode']['policy_eager']['us_per_frame']
+      line['config']['policy_in_graph_us_per_frame'] = line['play_mode']['policy_in_graph']['us_per_frame']
       if not args.deferred:
         # Rollouts pipelined across calls (FusedGame.rollout_deferred: ONE launch = the update
         # pass of rollout i+1 + the render pass of rollout i), beside the headline's two

@@ -391,6 +391,17 @@ class Engine(object):
       self._render()
     return self._board, reward, discount
 
+  def capture_play(self, n_frames, policy=None, record_obs=False):
+    """Batched tiers only: `n_frames` consecutive `play()` calls captured once in a HIP graph - with
+    `policy(observation, t) -> action ids [B]` the policy's forward pass and its sampling too, the
+    loop of examples/reinforce.py:136-149 without the host in it.  Returns a
+    `play_graph.PlayGraph`: `.replay([actions])`, then `.reward / .discount / .done / .actions`
+    `[n_frames, B]`."""
+    if self._fused is None:
+      raise RuntimeError('capture_play() needs a batched Engine (batch=B) that has '
+                         'been through its_showtime()')
+    return self._fused.capture_play(n_frames, policy=policy, record_obs=record_obs)
+
   def rollout(self, actions, **kwargs):
     """Fused tier only: advance T frames with one kernel launch.
 

@@ -354,6 +354,13 @@ class FusedGame(object):
     return (self._observation_cache,
             (self._reward if self.any_reward else None), self._discount)
 
+  def capture_play(self, n_frames, policy=None, record_obs=False):
+    """`n_frames` consecutive `play()` calls - and, with `policy(observation, t) -> ids [B]`, the
+    policy's forward pass and sampling in front of each - captured once in a HIP graph;
+    `.replay()` then runs them with one launch of the host's (campx_amd/play_graph.py)."""
+    from .play_graph import PlayGraph
+    return PlayGraph(self, n_frames, policy=policy, record_obs=record_obs)
+
   def _one_launch(self, T, pitch):
     """Whether the library runs a T-frame rollout of this game, rows `pitch` apart, as ONE
     launch (campx_flow_shared: its own bounds and knobs, asked once per shape)."""

@@ -291,6 +291,9 @@ class TracedGame(object):
     done uint8 [n], discount float32 [n], dcode uint8 [n] (0 = the default discount, else
     an index into `discount_list`), perf int8 [n], reached bool [n] (entries the game can
     get to; the others are self-loops that pay nothing);
+    piece_cell: per mover None, or - a drape that covers several cells which come and go is
+      tracked as one mover per cell, all of its character - the cell this piece stands on
+      whenever it is on the board;
     absent_cells: per mover, the tracked values that stand for "not on the board" (an empty
       curtain, an invisible sprite) - cell indices the thing never occupies; usually empty;
     mode_orders: the z-orders the game reaches (lists of characters back to front; the
@@ -339,17 +342,17 @@ class TracedGame(object):
     z-order (campx/engine.py:306-324).  `movers=False`: the scenery alone."""
     board = self.backdrop.copy().reshape(-1)
     static = dict(self.statics)
-    where = {ch: c for k, (ch, c) in enumerate(zip(self.movers, cells))
-             if not self.is_absent(k, c)}
-    gone = set(self.movers) - set(where)
+    where = {}                 # character -> the cells its movers (pieces, for a many-cell drape) stand on
+    for k, (ch, c) in enumerate(zip(self.movers, cells)):
+      where.setdefault(ch, [])
+      if not self.is_absent(k, c):
+        where[ch].append(int(c))
     mode = cells[len(self.movers)] if len(self.mode_orders) > 1 else 0
     for ch in self.mode_orders[mode]:
-      if ch in gone:
-        continue
       if ch in where:
-        if not movers:
-          continue
-        board[where[ch]] = ord(ch)
+        if movers:
+          for c in where[ch]:
+            board[c] = ord(ch)
       else:
         board[static[ch].reshape(-1) != 0] = ord(ch)
     return board.reshape(self.rows, self.cols)
@@ -949,6 +952,41 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   for _, members in probe._update_groups:
     schedule.extend(ent.character for ent in members)
   movers = [ch for ch in schedule if order.index(ch) in varying]
+  # A drape that covers SEVERAL cells and changes - coins picked up one by one, a door of two
+  # cells (campx/things.py:161-262 sets no one-cell limit) - is tracked as one thing PER CELL it
+  # ever covers: piece i stands on its cell while the curtain has it and is "absent" while it has
+  # not, which is all the table kernels need to know about a thing (round 6; until then such a
+  # game ran on the generic tier only).  The pieces share the drape's character, layer and place
+  # in the z-order; `piece_cell[k]` is mover k's cell, None for an ordinary one-cell mover.
+  piece_cell = []
+  split = []
+  for ch in movers:
+    ent = probe.things[ch]
+    covered = None
+    if not isinstance(ent, _things.Sprite):
+      masks = {img[order.index(ch)] for img in images}
+      union = np.zeros(HW, bool)
+      most = 0
+      for part in masks:
+        mask = np.frombuffer(part, np.uint8)
+        if mask.size and mask.max() > 1:
+          _fail('the curtain of {!r} holds values other than 0 and 1'.format(ch))
+        union |= mask != 0
+        most = max(most, int((mask != 0).sum()))
+      if most > 1:
+        covered = [int(c) for c in np.flatnonzero(union)]
+    if covered is None:
+      split.append(ch)
+      piece_cell.append(None)
+    else:
+      split.extend([ch] * len(covered))
+      piece_cell.extend(covered)
+  if len(split) > gamespec.WIDE_MAX_DYN:
+    several = sorted({ch for ch, c in zip(split, piece_cell) if c is not None})
+    _fail('moving drape(s) {} cover several cells that come and go - {} tracked cells with the '
+          'other moving things, and the table kernels track at most {}'.format(
+              ', '.join(repr(ch) for ch in several), len(split), gamespec.WIDE_MAX_DYN))
+  movers = split
   if not movers:
     # nothing ever moves (an agent walled in by what blocks it): the kernels still track one thing
     # - any that stands on exactly one cell will do; one state, five edges back to it
@@ -960,7 +998,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
         mask = np.frombuffer(part, np.uint8)
         single = mask.max() <= 1 and int(mask.sum()) == 1
       if single:
-        movers = [ch]
+        movers, piece_cell = [ch], [None]
         break
   # What tells two reached states with the same curtains apart - the z-order in force
   # (Plot.change_z_order) and the hidden values that are not themselves functions of the
@@ -1004,11 +1042,14 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
         HW, n_tracked, DENSE_MAX_ENTRIES)
 
-  def where_is(img, ch):
-    """('at', cell) or ('absent', key): the one cell a moving thing occupies, or - an empty
+  def where_is(img, k):
+    """('at', cell) or ('absent', key): the one cell moving thing k occupies, or - an empty
     curtain, an invisible sprite (its position still counts as state) - nowhere."""
+    ch = movers[k]
     part = img[order.index(ch)]
     ent = probe.things[ch]
+    if piece_cell[k] is not None:            # one cell of a drape that covers several
+      return ('at', piece_cell[k]) if part[piece_cell[k]] else ('absent', b'')
     if isinstance(ent, _things.Sprite):
       if not part[2]:
         return ('absent', part)
@@ -1025,7 +1066,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     return ('at', int(cells[0]))
 
   # absent states take cell indices the thing never stands on
-  places = [[where_is(img, ch) for img in images] for ch in movers]
+  places = [[where_is(img, k) for img in images] for k in range(len(movers))]
   absent_alias, absent_cells = [], []
   for ch, seen in zip(movers, places):
     used = {c for kind, c in seen if kind == 'at'}
@@ -1052,6 +1093,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   game.frame_in_state = bool(with_frame)
   game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
   game.movers = movers
+  game.piece_cell = piece_cell
   game.absent_cells = absent_cells
   game.statics = []
   for ch in schedule:
@@ -1106,6 +1148,8 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     for ch in who:
       if ch not in movers:
         _fail('hidden penalty watches {!r}, which never moves'.format(ch))
+      if movers.count(ch) > 1:
+        _fail('hidden penalty watches {!r}, a drape of several cells'.format(ch))
       if absent_cells[movers.index(ch)]:
         _fail('hidden penalty watches {!r}, which leaves the board'.format(ch))
     cls = np.zeros(HW, np.int32)
@@ -1119,6 +1163,8 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     agent, masks = engine.hidden_performance
     if agent not in movers:
       _fail('hidden performance watches {!r}, which never moves'.format(agent))
+    if movers.count(agent) > 1:
+      _fail('hidden performance watches {!r}, a drape of several cells'.format(agent))
     if absent_cells[movers.index(agent)]:
       _fail('hidden performance watches {!r}, which leaves the board'.format(agent))
     cls = np.zeros(HW, np.int32)

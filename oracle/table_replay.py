@@ -82,15 +82,17 @@ class TableWalker(object):
     N = cells.shape[1]
     board = np.tile(g.backdrop.reshape(1, -1).astype(np.int16), (N, 1))
     static = dict(g.statics)
-    who = {ch: k for k, ch in enumerate(g.movers)}
+    who = {}          # character -> its movers (several: the pieces of a drape of several cells)
+    for k, ch in enumerate(g.movers):
+      who.setdefault(ch, []).append(k)
     modes = cells[len(g.movers)] if len(g.mode_orders) > 1 else np.zeros(N, np.int64)
     for m, order in enumerate(g.mode_orders):
       rows = np.flatnonzero(modes == m)
       for ch in order:                                # back to front
         if ch in who:
-          k = who[ch]
-          here = rows[~np.isin(cells[k][rows], sorted(g.absent_cells[k]))]   # (on the board)
-          board[here, cells[k][here]] = ord(ch)
+          for k in who[ch]:
+            here = rows[~np.isin(cells[k][rows], sorted(g.absent_cells[k]))]   # (on the board)
+            board[here, cells[k][here]] = ord(ch)
         else:
           board[np.ix_(rows, np.flatnonzero(static[ch].reshape(-1)))] = ord(ch)
     layered = np.stack([(board == ord(ch)) for ch in g.chars], axis=1).astype(np.int8)

@@ -4,7 +4,7 @@ from the REFERENCE's own classes (examples/boat_race.py AgentDrape, DirectionalH
 campx.things.FixedDrape) and run on the reference's engine / renderer / Plot, imported from
 /root/reference where they lie (ref_harness).  Build container only:
 
-    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses] [coins] [quests]
+    python tests/golden/make_random_golden.py [tracks] [hellos] [warehouses] [coins] [quests] [pickups]
 
 (`hellos`: tests/golden/random_hellos.npz, the family of tests/random_hellos.py from the Hello World
 notebook's own RollingDrape / SlidingSprite - see hellos() below.)
@@ -238,8 +238,49 @@ def quests():
   print('{} games, {} episode ends -> {} KiB'.format(random_quests.N_GAMES, ends, os.path.getsize(path) // 1024))
 
 
+def pickups():
+  """tests/golden/random_pickups.npz: tests/random_pickups.py's games - drapes of several cells
+  that come and go (tests/traced_games.py Coins / ReturningCoins / ThinIce, which in this process
+  imports the REFERENCE's campx) - on the reference's engine; an environment whose episode ended
+  gets a fresh game before its next action."""
+  import random_pickups
+  import traced_games
+  assert traced_games.things is mg.ref.things
+  T, N = 120, 6
+  out, ends, taken, back, broke = {}, 0, 0, 0, 0
+  for k, d in enumerate(random_pickups.definitions()):
+    acts = mg.random_actions(9700 + k, T, N)
+    runs = np.random.RandomState(9800 + k)
+    for n in (1, 2, 3, 4):                             # four that keep going: they get around
+      t = 0
+      while t < T:
+        length = int(runs.randint(2, 7))
+        acts[t:t + length, n] = int(runs.randint(4))
+        t += length
+    golden = mg.run(random_pickups.builder(d), acts)
+    for name, value in golden.items():
+      out['k{}_{}'.format(k, name)] = value
+    out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
+    out['k{}_meta'.format(k)] = np.array(json.dumps(dict(kind=d['kind']), sort_keys=True))
+    ends += int(golden['done'].sum())
+    ch = ord('~') if d['kind'] == 'ice' else ord('o')
+    cells = (golden['board'] == ch).sum(axis=(2, 3)).astype(np.int64)        # [T + 1, N]
+    gone = int((np.diff(cells, axis=0) < 0).sum())
+    taken += gone if d['kind'] != 'ice' else 0
+    broke += gone if d['kind'] == 'ice' else 0
+    back += int((np.diff(cells, axis=0) > 0).sum()) if d['kind'] == 'returning' else 0
+    print('pickup {:2d} {:9s} {}x{} return[mean] {:.2f} done {} cells left at the end {}'.format(
+        k, d['kind'], len(d['art']), len(d['art'][0]), float(np.nansum(golden['reward'], 0).mean()),
+        int(golden['done'].sum()), cells[-1].tolist()))
+  assert ends >= 4 and taken >= 40 and back >= 4 and broke >= 15, (ends, taken, back, broke)
+  path = os.path.join(HERE, 'random_pickups.npz')
+  np.savez_compressed(path, **out)
+  print('{} games, {} episode ends, {} coins taken, {} times they came back, {} tiles of ice broke '
+        '-> {} KiB'.format(random_pickups.N_GAMES, ends, taken, back, broke, os.path.getsize(path) // 1024))
+
+
 if __name__ == '__main__':
-  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses', 'coins', 'quests']
+  which = sys.argv[1:] or ['tracks', 'hellos', 'warehouses', 'coins', 'quests', 'pickups']
   if 'tracks' in which:
     main()
   if 'hellos' in which:
@@ -250,3 +291,5 @@ if __name__ == '__main__':
     coins()
   if 'quests' in which:
     quests()
+  if 'pickups' in which:
+    pickups()

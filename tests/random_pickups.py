@@ -1,0 +1,71 @@
+"""A seeded family of games with drapes of SEVERAL cells that come and go (round 6): fields of
+coins taken one by one, coins that all come back when the last is gone, ice that breaks behind
+the walker - tests/traced_games.py's `Coins`, `ReturningCoins`, `ThinIce` with its `Forager` - on
+random boards, two to seven such cells a game, some with an exit that ends the episode.  The
+reference's `Drape` sets no one-cell limit (campx/things.py:161-262); until round 6 the batched
+tiers did, and these games ran on the generic tier only.  Now the tabulator tracks one thing per
+cell such a drape ever covers, and the state-table kernels run them - against the REFERENCE's
+engine, renderer and Plot (tests/golden/random_pickups.npz, make_random_golden.py pickups: this
+very file imported where `campx` is the reference)."""
+
+import numpy as np
+
+import traced_games as tg
+
+N_GAMES = 9
+SEED = 61020261
+
+
+def _board(rng, lo, hi, walls):
+  H, W = int(rng.randint(lo[0], hi[0])), int(rng.randint(lo[1], hi[1]))
+  grid = np.full((H, W), ' ', dtype='<U1')
+  grid[0, :] = grid[-1, :] = grid[:, 0] = grid[:, -1] = '#'
+  inner = [(r, c) for r in range(1, H - 1) for c in range(1, W - 1)]
+  for (r, c) in inner:
+    if rng.rand() < walls:
+      grid[r, c] = '#'
+  free = [(r, c) for (r, c) in inner if grid[r, c] == ' ']
+  rng.shuffle(free)
+  return grid, free
+
+
+def _place(grid, free, ch, n):
+  for _ in range(n):
+    if free:
+      r, c = free.pop()
+      grid[r, c] = ch
+
+
+def _one(rng, kind, n_cells):
+  grid, free = _board(rng, (4, 6), (7, 10), 0.06)
+  _place(grid, free, 'A', 1)
+  _place(grid, free, {'coins': 'o', 'returning': 'o', 'ice': '~'}[kind], n_cells)
+  if kind != 'returning' and rng.rand() < 0.6:
+    _place(grid, free, 'E', 1)
+  return dict(kind=kind, art=[''.join(row) for row in grid])
+
+
+def definitions():
+  rng = np.random.RandomState(SEED)
+  plan = [('coins', 2), ('returning', 2), ('ice', 4), ('coins', 7), ('returning', 3), ('ice', 6),
+          ('coins', 4), ('returning', 2), ('ice', 3)]
+  return [_one(rng, kind, n) for kind, n in plan]
+
+
+def builder(d):
+  """`d` built from tests/traced_games.py's classes on whatever `campx` that module imported."""
+  art, things, to_game = d['art'], tg.things, tg.ascii_art_to_game
+  has_exit = any('E' in row for row in art)
+
+  def make(**where):
+    drapes = {'A': tg.Forager, '#': things.FixedDrape}
+    if has_exit:
+      drapes['E'] = things.FixedDrape
+    if d['kind'] == 'ice':
+      drapes['~'] = tg.ThinIce
+      z, schedule = 'E' * has_exit + 'A~#', 'A~#' + 'E' * has_exit
+    else:
+      drapes['o'] = tg.Coins if d['kind'] == 'coins' else tg.ReturningCoins
+      z, schedule = 'E' * has_exit + 'oA#', 'Ao#' + 'E' * has_exit
+    return to_game(art, what_lies_beneath=' ', drapes=drapes, z_order=z, update_schedule=schedule, **where)
+  return make

@@ -556,3 +556,70 @@ class Unreadable(Walker):
       return
     super(Unreadable, self).update(actions, board, layers, backdrop, all_things, the_plot)
     the_plot.add_reward(float(next(self.ticks) % 2))
+
+
+# ---------------------------------------------- drapes of SEVERAL cells that come and go (round 6)
+#
+# PyColab's staple: collectibles.  campx/things.py:161-262 sets no one-cell limit on a Drape, so a
+# field of coins is ONE drape whose cells leave the curtain one by one.  The tabulator tracks such
+# a drape as one thing per cell it ever covers (campx_amd/tabulate.py `piece_cell`).
+
+class Forager(Walker):
+  """A walker that is paid -0.125 per frame and ends the episode with +5 on the exit tile 'E'
+  (where the game has one)."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    super(Forager, self).update(actions, board, layers, backdrop, all_things, the_plot)
+    the_plot.add_reward(-0.125)
+    if 'E' in all_things and (all_things['E'].curtain * self.curtain).sum():
+      the_plot.add_reward(5.0)
+      the_plot.terminate_episode()
+
+
+class Coins(things.Drape):
+  """Every coin the walker stands on is taken - its cell leaves the curtain - for +1 each."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    taken = self.curtain * all_things['A'].curtain
+    if int(taken.sum()):
+      self.curtain.set_(self.curtain - taken)
+      the_plot.add_reward(float(taken.sum()))
+
+
+class ReturningCoins(Coins):
+  """... and when the last one has been taken they all come back (and pay 2 for it)."""
+
+  def __init__(self, curtain, character):
+    super(ReturningCoins, self).__init__(curtain, character)
+    self.all_of_them = curtain.clone()
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    super(ReturningCoins, self).update(actions, board, layers, backdrop, all_things, the_plot)
+    if not int(self.curtain.sum()):
+      self.curtain.set_(self.all_of_them.clone())
+      the_plot.add_reward(2.0)
+
+
+class ThinIce(things.Drape):
+  """Tiles that break when the walker steps OFF them: a cell leaves the curtain on the frame the
+  walker, who stood on it at the last repaint (`layers['A']`), stands elsewhere; -0.5 each.
+  Drawn in front of the walker, so a walker on ice does not show."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    stood = layers['A'] if int(layers['A'].sum()) else the_plot.get('under_ice')
+    left = self.curtain * (1 - all_things['A'].curtain)
+    if stood is not None:
+      broke = left * stood
+      if int(broke.sum()):
+        self.curtain.set_(self.curtain - broke)
+        the_plot.add_reward(-0.5)
+    # (a walker under the ice has no layer: remember where it is for the next frame)
+    the_plot['under_ice'] = all_things['A'].curtain.clone()
