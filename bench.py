@@ -454,6 +454,14 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   # read 0.790 of peak in the driver's run against 0.859 in its profile).  Untimed; the
   # count is reported as config.settle_launches; `steps` / `warmup` stay as given.
   settle = 0
+  # (the collector runs BEFORE the settle launches, and stays off until the window has closed:
+  # round 6 found the driver's 20-launch windows of the side measurements 7-9 % slower than the
+  # same launches a moment later - sokoban 0.401 against 0.368 ms, Hello World 1.79 against 1.68 -
+  # because gc.collect() sat between the last settle launch and the fence: by then a process that
+  # has built six games takes longer to collect than the queued launches take to run, the chip
+  # idled for tens of milliseconds, and the window opened on lowered clocks)
+  gc.collect()
+  gc.disable()
   if on_gpu:
     probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     probe[0].record()
@@ -470,9 +478,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
     log.align()                       # the timed window starts on a block boundary of the log
   if log is not None and on_gpu and os.environ.get('CAMPX_BENCH_NO_GATHER_TIMING') != '1':
     log.time_gathers()                # the gathers of the timed window leave their start / end events
-  gc.collect()                        # (before the fence: the chip should not idle longer than it must)
-  gc.disable()                        # no collector pause between two launches of the timed region
-  fence()
+  fence()                             # (nothing between the last settle launch and the fence but the log's bookkeeping)
   if on_gpu:
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)

@@ -313,7 +313,18 @@ class Engine(object):
         with chance.forbidden(tabulate.TabulationError):
           actions = recognise.detect_actions(self)
           if recognise.looks_like_shapes(self, actions):
-            recognised = recognise.shapes(self, actions)
+            # (a drape of several cells that changes: a rigidly translating thing of the shape
+            # tier - or, since round 6, one whose cells come and go, which the tabulator tracks
+            # cell by cell: coins, doors of two cells)
+            try:
+              recognised = recognise.shapes(self, actions)
+            except recognise.RecogniseError as not_shapes:
+              try:
+                traced = tabulate.trace(self, actions=actions)
+              except tabulate.TabulationError as refusal:
+                if getattr(refusal, 'campx_chance', False):
+                  raise
+                raise tabulate.TabulationError('{} (and {})'.format(not_shapes, refusal))
           else:
             try:
               traced = tabulate.trace(self, actions=actions)

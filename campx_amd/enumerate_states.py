@@ -157,6 +157,8 @@ def enumerate_rule_game(engine, device, max_states=None):
   game.rows, game.cols, game.chars = H, W, list(desc.chars)
   dynamic = [e for e in desc.entities if e.moves]
   game.movers = [e.char for e in dynamic]
+  game.piece_cell = [None] * len(dynamic)
+  game.in_backdrop = [False] * len(dynamic)
   game.statics = [(e.char, e.mask) for e in desc.entities if not e.moves]
   game.z_order = list(desc.z_order)
   game.mode_orders = [list(desc.z_order)]

@@ -294,6 +294,9 @@ class TracedGame(object):
     piece_cell: per mover None, or - a drape that covers several cells which come and go is
       tracked as one mover per cell, all of its character - the cell this piece stands on
       whenever it is on the board;
+    in_backdrop: per mover, True for a piece of a Backdrop that changes (one per (cell,
+      character) it shows other than at the start; they come after every other mover and are
+      painted on the backdrop itself, behind every thing);
     absent_cells: per mover, the tracked values that stand for "not on the board" (an empty
       curtain, an invisible sprite) - cell indices the thing never occupies; usually empty;
     mode_orders: the z-orders the game reaches (lists of characters back to front; the
@@ -343,7 +346,12 @@ class TracedGame(object):
     board = self.backdrop.copy().reshape(-1)
     static = dict(self.statics)
     where = {}                 # character -> the cells its movers (pieces, for a many-cell drape) stand on
+    in_backdrop = getattr(self, 'in_backdrop', None) or [False] * len(self.movers)
     for k, (ch, c) in enumerate(zip(self.movers, cells)):
+      if in_backdrop[k]:       # what a changing Backdrop shows: on the backdrop itself, behind every thing
+        if movers and not self.is_absent(k, c):
+          board[int(c)] = ord(ch)
+        continue
       where.setdefault(ch, [])
       if not self.is_absent(k, c):
         where[ch].append(int(c))
@@ -841,8 +849,9 @@ def _trace_once(engine, actions, max_plays, with_frame):
   hidden0 = hidden_image(probe, with_frame)
   # state bookkeeping: a state is (curtains and positions, z-order, everything else a frame
   # can read)
-  index_of = {(things0, z0, hidden0): 0}
+  index_of = {(things0, z0, hidden0, backdrop0): 0}
   images = [things0]
+  backdrops = [backdrop0]    # per state: the Backdrop's curtain (a Backdrop.update() may change it)
   orders = [z0]              # per state: the z-order in force (characters back to front)
   hiddens = [hidden0]        # per state: `hidden_image()`
   engines = [probe]          # an engine standing in that state, or None (only seen ended)
@@ -884,13 +893,10 @@ def _trace_once(engine, actions, max_plays, with_frame):
     if not with_frame and FRAME_READS[0] != reads0:
       raise _FrameWasRead()
     things, backdrop, z = _image(eng)
-    if backdrop != backdrop0:
-      _fail('the Backdrop changed during play (a Backdrop.update(), or a sprite painted '
-            'before the first drape in z-order writes into it: campx/rendering.py:128,150)')
     over = bool(eng.game_over)
     discount = float(np.float32(discount))
     board = obs.board.detach().to(torch.int64).numpy().astype(np.uint8).tobytes()
-    return (things, z, hidden_image(eng, with_frame)), reward_f32(reward), discount, over, board
+    return (things, z, hidden_image(eng, with_frame), backdrop), reward_f32(reward), discount, over, board
 
   while queue:
     s = queue.popleft()
@@ -904,6 +910,7 @@ def _trace_once(engine, actions, max_plays, with_frame):
         images.append(key[0])
         orders.append(key[1])
         hiddens.append(key[2])
+        backdrops.append(key[3])
         note_hidden(key[2])
         boards.append(board)
         engines.append(None)
@@ -932,11 +939,11 @@ def _trace_once(engine, actions, max_plays, with_frame):
               'differently'.format(a))
 
   return _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, images, orders,
-                 hiddens, boards, edges, plays[0])
+                 hiddens, boards, edges, plays[0], backdrops)
 
 
 def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, images, orders, hiddens,
-            boards, edges, n_plays):
+            boards, edges, n_plays, backdrops=None):
   """From the walked state graph to a `TracedGame`: `images[s]` (per-thing byte images, things in
   ascending character order), `orders[s]` (z-order string), `hiddens[s]` (`hidden_image()`),
   `boards[s]` (the rendered board's bytes) of every reached state, state 0 the one after
@@ -981,12 +988,32 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     else:
       split.extend([ch] * len(covered))
       piece_cell.extend(covered)
+  # ... and so is a Backdrop that changes (a Backdrop.update() of its own, campx/things.py:103-148;
+  # a sprite painted into it, campx/rendering.py:128,150): every (cell, character) it ever shows
+  # other than what it showed after its_showtime() is a piece - on the board while the Backdrop
+  # shows that character there, painted right on the scenery's backdrop, behind every thing.
+  base_backdrop = np.frombuffer(backdrop0, np.int64)
+  backdrop_pieces = set()
+  for b in set(backdrops or ()):
+    now = np.frombuffer(b, np.int64)
+    for c in np.flatnonzero(now != base_backdrop):
+      backdrop_pieces.add((int(c), int(now[c])))
+  n_thing_movers = len(split)
+  for c, code in sorted(backdrop_pieces):
+    if not 0 <= code < 256 or chr(code) not in chars:
+      _fail('the Backdrop shows character code {} at cell {}, which is not in its palette'.format(code, c))
+    split.append(chr(code))
+    piece_cell.append(c)
   if len(split) > gamespec.WIDE_MAX_DYN:
-    several = sorted({ch for ch, c in zip(split, piece_cell) if c is not None})
+    several = sorted({ch for ch, c in zip(split[:n_thing_movers], piece_cell) if c is not None})
+    if backdrop_pieces:
+      several.append('the Backdrop')
     _fail('moving drape(s) {} cover several cells that come and go - {} tracked cells with the '
           'other moving things, and the table kernels track at most {}'.format(
-              ', '.join(repr(ch) for ch in several), len(split), gamespec.WIDE_MAX_DYN))
+              ', '.join(ch if ch == 'the Backdrop' else repr(ch) for ch in several), len(split),
+              gamespec.WIDE_MAX_DYN))
   movers = split
+  in_backdrop = [k >= n_thing_movers for k in range(len(movers))]
   if not movers:
     # nothing ever moves (an agent walled in by what blocks it): the kernels still track one thing
     # - any that stands on exactly one cell will do; one state, five edges back to it
@@ -998,7 +1025,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
         mask = np.frombuffer(part, np.uint8)
         single = mask.max() <= 1 and int(mask.sum()) == 1
       if single:
-        movers, piece_cell = [ch], [None]
+        movers, piece_cell, in_backdrop, n_thing_movers = [ch], [None], [False], 1
         break
   # What tells two reached states with the same curtains apart - the z-order in force
   # (Plot.change_z_order) and the hidden values that are not themselves functions of the
@@ -1041,11 +1068,17 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   elif HW ** n_tracked * N_ACTIONS > DENSE_MAX_ENTRIES:
     dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
         HW, n_tracked, DENSE_MAX_ENTRIES)
+  if any(in_backdrop) and dense_reason is None:
+    dense_reason = 'the Backdrop changes (its cells are painted behind every thing)'
 
-  def where_is(img, k):
-    """('at', cell) or ('absent', key): the one cell moving thing k occupies, or - an empty
-    curtain, an invisible sprite (its position still counts as state) - nowhere."""
+  def where_is(s, k):
+    """('at', cell) or ('absent', key): the one cell moving thing k occupies in state s, or - an
+    empty curtain, an invisible sprite (its position still counts as state) - nowhere."""
+    img = images[s]
     ch = movers[k]
+    if in_backdrop[k]:                       # one (cell, character) of a Backdrop that changes
+      shows = int(np.frombuffer(backdrops[s], np.int64)[piece_cell[k]]) == ord(ch)
+      return ('at', piece_cell[k]) if shows else ('absent', b'')
     part = img[order.index(ch)]
     ent = probe.things[ch]
     if piece_cell[k] is not None:            # one cell of a drape that covers several
@@ -1066,7 +1099,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     return ('at', int(cells[0]))
 
   # absent states take cell indices the thing never stands on
-  places = [[where_is(img, k) for img in images] for k in range(len(movers))]
+  places = [[where_is(s, k) for s in range(len(images))] for k in range(len(movers))]
   absent_alias, absent_cells = [], []
   for ch, seen in zip(movers, places):
     used = {c for kind, c in seen if kind == 'at'}
@@ -1094,10 +1127,11 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
   game.movers = movers
   game.piece_cell = piece_cell
+  game.in_backdrop = in_backdrop
   game.absent_cells = absent_cells
   game.statics = []
   for ch in schedule:
-    if ch in movers:
+    if ch in movers[:n_thing_movers]:
       continue
     ent = probe.things[ch]
     if isinstance(ent, _things.Sprite):

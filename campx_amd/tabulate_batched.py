@@ -499,6 +499,8 @@ def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, rewar
   game.frame_in_state = False
   game.backdrop = np.frombuffer(backdrop0, np.int64).astype(np.uint8).reshape(H, W)
   game.movers = movers
+  game.piece_cell = [None] * K          # (drapes of several cells go to the one-frame-per-play walker)
+  game.in_backdrop = [False] * K
   game.absent_cells = absent_cells
   game.statics = [(ch, start_np[ch].copy()) for ch in schedule if ch not in movers]
   if len(game.statics) > gamespec.MAX_STATIC:

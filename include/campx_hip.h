@@ -22,9 +22,10 @@
  *   - plain C, no exceptions: every function returns CAMPX_OK (0) or a negative
  *     CAMPX_E* code; campx_strerror() names it.
  *   - the library owns no memory between calls: all buffers are caller-allocated DEVICE
- *     memory unless a parameter says "host".  The only process-wide state is read-only
- *     after first use: measurement knobs read once from the environment (NOTES.md 3.8)
- *     and, per device, its CU count and the dynamic-LDS limit already granted to a kernel.
+ *     memory unless a parameter says "host".  The only process-wide state: the settings
+ *     (campx_config_set / _get / _string below: one table, no environment variable but
+ *     CAMPX_CONFIG) and - read-only after first use - per device, its CU count and the
+ *     dynamic-LDS limit already granted to a kernel.
  *   - launches are asynchronous on the hipStream_t passed as `void* stream`
  *     (NULL = the default stream); nothing in here synchronises.
  *   - re-entrant; calls on distinct state buffers may be issued concurrently.
@@ -277,7 +278,7 @@ typedef struct CampxOutputs {
                          20 / 27 / 38 at B = 1 024 / 4 096 / 8 192; pipe_multi_kernel<K, ., true>,
                          sokoban with one box: 23 / 30 / 44 against 28 / 35 / 46; the four-mover
                          level from 4 097 environments up).  Not while `stream` is being
-                         captured into a graph.  CAMPX_NO_FLOW=1 in the environment: never.
+                         captured into a graph.  Setting flow = 0 (campx_config_set): never.
                          Two launches that may run at the same time must not share a block.
                          campx_flow_shared() says whether a call will take this path. */
   int64_t overlap_ctl_bytes;
@@ -430,8 +431,7 @@ int32_t campx_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_de
  * chunks per frame and no flat board, up to 32 768 environments and 2 GB of observations per
  * rollout, the two passes share ONE launch (update workgroups first, the others render);
  * otherwise they are issued one after the other on `stream`.  prev.trace == NULL: the update
- * pass alone.  CAMPX_NO_PIPE=1 in the environment: always one after the other;
- * CAMPX_NO_PIPE_MULTI=1: only one-mover games share the launch.
+ * pass alone.
  */
 int32_t campx_update_render_launch(const CampxSpec* spec_host, const CampxSpec* spec_dev,
                                    CampxState state, const int8_t* actions, CampxOutputs out,
@@ -515,7 +515,7 @@ int32_t campx_shape_spec_validate(const CampxShapeSpec* spec_host);
  * of one-shot waves with memory-aligned 2 KiB windows that computes every W-cell row of the
  * observation arithmetically from 64-bit row words - which streams the observations at the
  * one-cell tier's rate.  Rows of 16 to 64 cells only; other games and calls ignore both (NULL is
- * fine) and run the one-wave-per-environment kernel.  CAMPX_SHAPE_SPLIT=0: never.
+ * fine) and run the one-wave-per-environment kernel.  Setting shape_split = 0: never.
  */
 int64_t campx_shape_tables_bytes(const CampxShapeSpec* spec_host);   /* 0: not a game for that path */
 /* Fills `tables_host` (HOST memory, `bytes` >= campx_shape_tables_bytes); the caller copies it

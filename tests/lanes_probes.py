@@ -276,7 +276,7 @@ CASES = [(Where, Still, 'lanes: '), (Counter, Still, 'one frame per play (lanes:
          (ViewWrite, Still, 'lanes: '), (PlotMem, Still, "one frame per play (lanes: the_plot['prev']"),
          (Rand, Still, 'REFUSED: draws random numbers in Rand.update (torch.rand)'), (Nonzero, Still, 'one frame per play (lanes: nonzero'),
          (Roll, Still, 'lanes: '), (Terminator, Still, 'lanes: '),
-         (Grower, Still, 'REFUSED: covers'), (Indexer, Still, 'one frame per play (lanes: __getitem__'),
+         (Grower, Still, 'REFUSED: cover several cells that come and go - 12 tracked cells'), (Indexer, Still, 'one frame per play (lanes: __getitem__'),
          (Float, Still, 'lanes: '), (ChangeZ, Still, 'one frame per play (lanes: the game changes the z-order'),
          (Pusher, Still, 'lanes: '), (BoardReader, Still, 'lanes: '), (Mover, Chaser, 'lanes: '),
          (NanReward, Still, 'lanes: '), (Discounter, Still, 'lanes: '), (IntIndex, Still, 'lanes: '),

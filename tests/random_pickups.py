@@ -1,7 +1,9 @@
 """A seeded family of games with drapes of SEVERAL cells that come and go (round 6): fields of
 coins taken one by one, coins that all come back when the last is gone, ice that breaks behind
 the walker - tests/traced_games.py's `Coins`, `ReturningCoins`, `ThinIce` with its `Forager` - on
-random boards, two to seven such cells a game, some with an exit that ends the episode.  The
+random boards, two to seven such cells a game, some with an exit that ends the episode; and
+(`lamps`) a BACKDROP that changes: `Lamps`, a `Backdrop.update()` that flips floor lamps between
+':' and '*' as the walker steps on them (campx/things.py:103-148).  The
 reference's `Drape` sets no one-cell limit (campx/things.py:161-262); until round 6 the batched
 tiers did, and these games ran on the generic tier only.  Now the tabulator tracks one thing per
 cell such a drape ever covers, and the state-table kernels run them - against the REFERENCE's
@@ -12,7 +14,7 @@ import numpy as np
 
 import traced_games as tg
 
-N_GAMES = 9
+N_GAMES = 12
 SEED = 61020261
 
 
@@ -39,7 +41,11 @@ def _place(grid, free, ch, n):
 def _one(rng, kind, n_cells):
   grid, free = _board(rng, (4, 6), (7, 10), 0.06)
   _place(grid, free, 'A', 1)
-  _place(grid, free, {'coins': 'o', 'returning': 'o', 'ice': '~'}[kind], n_cells)
+  if kind == 'lamps':
+    _place(grid, free, ':', n_cells - 1)
+    _place(grid, free, '*', 1)                   # (one is on from the start: both characters in the palette)
+  else:
+    _place(grid, free, {'coins': 'o', 'returning': 'o', 'ice': '~'}[kind], n_cells)
   if kind != 'returning' and rng.rand() < 0.6:
     _place(grid, free, 'E', 1)
   return dict(kind=kind, art=[''.join(row) for row in grid])
@@ -48,7 +54,7 @@ def _one(rng, kind, n_cells):
 def definitions():
   rng = np.random.RandomState(SEED)
   plan = [('coins', 2), ('returning', 2), ('ice', 4), ('coins', 7), ('returning', 3), ('ice', 6),
-          ('coins', 4), ('returning', 2), ('ice', 3)]
+          ('coins', 4), ('returning', 2), ('ice', 3), ('lamps', 2), ('lamps', 4), ('lamps', 3)]
   return [_one(rng, kind, n) for kind, n in plan]
 
 
@@ -61,6 +67,9 @@ def builder(d):
     drapes = {'A': tg.Forager, '#': things.FixedDrape}
     if has_exit:
       drapes['E'] = things.FixedDrape
+    if d['kind'] == 'lamps':
+      return to_game(art, what_lies_beneath=' ', drapes=drapes, backdrop=tg.Lamps,
+                     z_order='E' * has_exit + 'A#', update_schedule='A#' + 'E' * has_exit, **where)
     if d['kind'] == 'ice':
       drapes['~'] = tg.ThinIce
       z, schedule = 'E' * has_exit + 'A~#', 'A~#' + 'E' * has_exit

@@ -125,8 +125,8 @@ def test_what_a_graph_cannot_hold_is_refused():
     graph.replay(torch.zeros((3, 64), dtype=torch.int8, device='cuda'))
   # bad ids are counted by the kernels inside the graph and reported like anywhere else
   bad = torch.full((4, 64), 9, dtype=torch.int64, device='cuda')
-  graph.replay(bad)
-  with pytest.raises(ValueError, match='outside 0..4'):
+  with pytest.raises(ValueError, match='outside 0..4'):     # (at the replay already, if the flag is up by then)
+    graph.replay(bad)
     game.fused.check_actions()
   with_policy = game.capture_play(2, policy=lambda obs, t: torch.zeros(64, dtype=torch.int8, device='cuda'))
   with pytest.raises(ValueError, match='policy'):

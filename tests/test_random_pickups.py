@@ -6,7 +6,10 @@ make_random_golden.py pickups).  The reference's Drape has no one-cell limit
 (campx/things.py:161-262); VERDICT r5 named such drapes as the first thing the batched tiers
 refuse that PyColab games do.  The tabulator now tracks one thing per cell the drape ever covers
 (`TracedGame.piece_cell`), two to seven of them here, with and without an episode end, with a
-hidden Plot entry on top (the ice).
+hidden Plot entry on top (the ice).  And the second thing the verdict named: a `Backdrop.update()`
+that changes the scenery (`Lamps`, campx/things.py:103-148) - every (cell, character) the
+backdrop ever shows beyond its first picture is a piece painted behind every thing
+(`TracedGame.in_backdrop`); three games of it.
 
 Per game: (a) the generator still makes the fixture's game; (b) this repo's generic tier gives
 the reference engine's frames; (c) so does the table tabulated from the classes, walked on the
@@ -43,7 +46,7 @@ def _same(a, b):
 
 
 def test_the_generator_still_makes_the_games_of_the_fixture():
-  assert len(DEFS) == random_pickups.N_GAMES == 9
+  assert len(DEFS) == random_pickups.N_GAMES == 12
   for k, d in enumerate(DEFS):
     gold = _gold(k)
     assert [''.join(chr(c) for c in row) for row in gold['art']] == d['art'], k
@@ -54,13 +57,23 @@ def test_a_drape_of_several_cells_becomes_one_tracked_thing_per_cell():
   pieces = []
   for k, d in enumerate(DEFS):
     traced = tabulate.trace(random_pickups.builder(d)(), cache=False)
+    W = len(d['art'][0])
+    where = lambda ch: [r * W + c for r, row in enumerate(d['art']) for c, x in enumerate(row) if x == ch]
+    assert traced.piece_cell[0] is None and traced.in_backdrop[0] is False
+    if d['kind'] == 'lamps':
+      # a Backdrop that changes: one piece per (cell, character) it shows beyond its first picture -
+      # a lamp that starts off can come on ('*' there), the one that starts on can go off (':')
+      want = sorted([(c, '*') for c in where(':')] + [(c, ':') for c in where('*')])
+      assert list(zip(traced.piece_cell[1:], traced.movers[1:])) == want, (k, traced.movers)
+      assert traced.in_backdrop[1:] == [True] * len(want) and traced.dense_reason.startswith(
+          ('the Backdrop changes', '{} moving things'.format(len(want) + 1)))
+      pieces.append((len(want), False))
+      continue
     ch = '~' if d['kind'] == 'ice' else 'o'
-    n = sum(row.count(ch) for row in d['art'])
+    n = len(where(ch))
     assert traced.movers == ['A'] + [ch] * n, (k, traced.movers)
-    assert traced.piece_cell[0] is None
-    art_cells = [r * len(d['art'][0]) + c for r, row in enumerate(d['art']) for c, x in enumerate(row) if x == ch]
-    assert traced.piece_cell[1:] == art_cells, k
-    dense = n <= 3 and d['kind'] != 'ice' and (len(d['art']) * len(d['art'][0])) ** (n + 1) * 5 <= tabulate.DENSE_MAX_ENTRIES
+    assert traced.piece_cell[1:] == where(ch) and not any(traced.in_backdrop), k
+    dense = n <= 3 and d['kind'] != 'ice' and (len(d['art']) * W) ** (n + 1) * 5 <= tabulate.DENSE_MAX_ENTRIES
     assert (traced.dense_reason is None) == dense, (k, traced.dense_reason)
     pieces.append((n, dense))
   assert max(pieces)[0] == 7 and min(pieces)[0] == 2 and sum(d for _, d in pieces) >= 3      # both tiers

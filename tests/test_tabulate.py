@@ -290,12 +290,22 @@ def test_reference_engine_goldens_on_the_generic_tier_and_through_the_table(name
 
 @pytest.mark.parametrize('cls,why', [
     (traced_games.Stepper, r"the_plot\['n'\] \(\d+ different values"),
-    (traced_games.Grower, 'covers 2 cells'),
     (traced_games.Discounter, 'more than 15 distinct discounts'),
 ])
 def test_games_the_table_model_is_not_exact_for_are_refused(cls, why):
   with pytest.raises(tabulate.TabulationError, match=why):
     tabulate.trace(traced_games.refused(cls))
+
+
+def test_a_drape_that_grows_is_tracked_cell_by_cell_until_that_is_too_many():
+  """Until round 6 a moving drape on two cells was refused ("covers 2 cells"); now every cell it
+  ever covers is a tracked thing of its own - the four cells of this one's row - and the refusal
+  comes when they are more than the kernels track (tests/lanes_probes.py's trail: twelve)."""
+  traced = tabulate.trace(traced_games.refused(traced_games.Grower), cache=False)
+  assert traced.movers == ['A'] * 4 and traced.piece_cell == [0, 1, 2, 3] and traced.n_states == 4
+  import lanes_probes
+  with pytest.raises(tabulate.TabulationError, match=r"'A' cover several cells that come and go - 12 tracked cells"):
+    tabulate.trace(lanes_probes.game(lanes_probes.Grower)(), cache=False)
 
 
 def test_a_z_order_change_that_reorders_the_scenery_is_refused():

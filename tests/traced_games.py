@@ -623,3 +623,35 @@ class ThinIce(things.Drape):
         the_plot.add_reward(-0.5)
     # (a walker under the ice has no layer: remember where it is for the next frame)
     the_plot['under_ice'] = all_things['A'].curtain.clone()
+
+
+# ---------------------------------------------- a Backdrop that changes (round 6)
+#
+# campx/things.py:103-148: `Backdrop.update(actions, board, layers, things, the_plot)` runs first
+# in every frame (campx/engine.py:190) and may repaint the scenery.  The tabulator tracks every
+# (cell, character) such a backdrop ever shows beyond its first picture as a piece painted behind
+# every thing (campx_amd/tabulate.py `in_backdrop`).
+
+class Lamps(things.Backdrop):
+  """Floor lamps: a cell showing ':' (off) or '*' (on) flips each time the walker has just
+  stepped onto it - seen at the START of the next frame, where `things['A']` still stands where
+  the last frame put it.  A lit room pays: +0.25 per lamp that is on, every frame."""
+
+  def update(self, actions, board, layers, things_, the_plot):
+    if actions is None:
+      return
+    here = things_['A'].curtain
+    before = the_plot.get('lamp_walker')
+    the_plot['lamp_walker'] = here.clone()
+    off, on = self.curtain == ord(':'), self.curtain == ord('*')
+    lit = int(on.sum())
+    if before is not None and not bool((before == here).all()):
+      (r,), (c,) = np.nonzero(here.numpy())
+      if bool(off[r, c]):
+        self.curtain[r, c] = ord('*')
+        lit += 1
+      elif bool(on[r, c]):
+        self.curtain[r, c] = ord(':')
+        lit -= 1
+    if lit:
+      the_plot.add_reward(0.25 * lit)
