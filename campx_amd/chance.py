@@ -22,7 +22,8 @@ between a source of chance and a table:
 2. The states of the three process-wide generators (`random`, `numpy.random`, torch's CPU
    generator) are compared before and after: a draw through a reference taken BEFORE the walk
    (`from random import random` binds the generator's C method, which no stand-in can replace)
-   moves the state and refuses the game.
+   moves the state and refuses the game.  (A generator that somebody else - another thread -
+   drew from through a stand-in meanwhile is left out of the comparison: its state proves nothing.)
 3. `named_sources()` - used by `tabulate.reached_behind_the_engine()` - finds, statically, in the
    code of the game's classes: generator objects (`random.Random`, `numpy.random.Generator` /
    `RandomState`, `torch.Generator`) and bound methods of them, and the clock / entropy functions
@@ -93,6 +94,8 @@ class _Guard(object):
   def __init__(self, error):
     self.error = error
     self.drawn = []          # (what was asked for, '<Class>.<method>')
+    self.others = set()      # process-wide generators SOMEBODY ELSE drew from meanwhile (another
+                             # thread, this package's own checks): their state proves nothing
     self.saved = []          # (owner, name, had_own_attribute, original)
 
   def message(self):
@@ -117,6 +120,7 @@ class _Guard(object):
         return original(*args, **kwargs)         # default_rng(7): a function of its seed
       who = _who_on_stack(sys._getframe(1))
       if who is None:
+        guard.others.add(label.split('.')[0])
         return original(*args, **kwargs)
       guard.drawn.append((label, who))
       raise guard.refusal()
@@ -214,7 +218,8 @@ def forbidden(error):
       raise guard.refusal() from raised
     if raised is None or isinstance(raised, Exception):
       after = _generator_states()
-      moved = [name for name, a, b in zip(('random', 'numpy.random', 'torch'), before, after) if a != b]
+      moved = [name for name, a, b in zip(('random', 'numpy.random', 'torch'), before, after)
+               if a != b and name.split('.')[0] not in guard.others]
       if moved:
         raise guard.refusal(
             'the game drew from the process-wide generator of {} while its classes were run for '
