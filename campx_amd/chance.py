@@ -11,7 +11,9 @@ between a source of chance and a table:
 
 1. `forbidden()` - a context the front ends run their walks in - puts stand-ins in place of the
    process's entry points to chance: the module-level functions of `random` and `numpy.random`,
-   `numpy.random.default_rng()` / `random.SystemRandom` without a seed, torch's sampling
+   `numpy.random.default_rng()` / `random.SystemRandom` without a seed, the generator classes
+   themselves made without a seed (`random.Random()`, `numpy.random.RandomState()`, `PCG64()` ...:
+   subclasses that look at their arguments), `torch.Generator.seed()`, torch's sampling
    functions and in-place samplers (`torch.rand`, `Tensor.uniform_` ... without an explicit
    `generator=`), `os.urandom`, `secrets`, `uuid.uuid1/4` and the clocks of `time`.  A stand-in
    asks who is calling: with a Sprite / Drape / Backdrop method anywhere on the stack it records the
@@ -64,6 +66,13 @@ _CLOCKS = ('time', 'time_ns', 'perf_counter', 'perf_counter_ns', 'monotonic', 'm
            'process_time', 'process_time_ns', 'thread_time', 'thread_time_ns', 'clock_gettime',
            'clock_gettime_ns')
 _SECRETS = ('token_bytes', 'token_hex', 'token_urlsafe', 'randbelow', 'randbits', 'choice')
+# generator classes that seed themselves from the operating system when made without a seed
+_SELF_SEEDING = ((random, 'Random'), (np.random, 'RandomState'), (np.random, 'SeedSequence'),
+                 (np.random, 'PCG64'), (np.random, 'PCG64DXSM'), (np.random, 'MT19937'),
+                 (np.random, 'Philox'), (np.random, 'SFC64'))
+# (the real classes, for isinstance: inside `forbidden()` the module attributes are stand-ins)
+_GENERATOR_TYPES = (random.Random, np.random.RandomState, np.random.Generator, np.random.BitGenerator,
+                    torch.Generator)
 
 
 def _who_on_stack(start):
@@ -129,6 +138,31 @@ class _Guard(object):
     chance_standin.campx_standin = True
     return chance_standin
 
+  def class_standin(self, label, original):
+    """A subclass of a generator class that refuses to be made WITHOUT a seed by a game's class
+    (`random.Random()`, `numpy.random.RandomState()`, `PCG64()`: seeded from the operating system's
+    entropy, straight from C - no function a stand-in could replace); with a seed it is the
+    original, and `isinstance` keeps working either way."""
+    guard = self
+
+    def __init__(me, *args, **kwargs):
+      unseeded = (not args or args[0] is None) and not any(v is not None for v in kwargs.values())
+      if unseeded:
+        who = _who_on_stack(sys._getframe(1))
+        if who is not None:
+          guard.drawn.append((label, who))
+          raise guard.refusal()
+      original.__init__(me, *args, **kwargs)
+    return type(original.__name__, (original,), {'__init__': __init__, '__module__': original.__module__,
+                                                 '__qualname__': original.__qualname__,
+                                                 'campx_standin': True, '__wrapped__': original})
+
+  def put_class(self, owner, name, label):
+    original = getattr(owner, name, None)
+    if isinstance(original, type):
+      self.saved.append((owner, name, True, original))
+      setattr(owner, name, self.class_standin(label, original))
+
   def put(self, owner, name, label, **how):
     original = getattr(owner, name, None)
     if original is None or not callable(original):
@@ -150,6 +184,24 @@ class _Guard(object):
       if legacy is not None and getattr(fn, '__self__', None) is legacy and name not in _NUMPY_KEEP:
         self.put(np.random, name, 'numpy.random.' + name)
     self.put(np.random, 'default_rng', 'numpy.random.default_rng() without a seed', unseeded_only=True)
+    for owner, name in _SELF_SEEDING:
+      self.put_class(owner, name, '{}.{}() without a seed'.format(
+          'random' if owner is random else 'numpy.random', name))
+    # (torch.Generator() starts from a fixed default seed; its seed() asks the operating system)
+    original_generator = torch.Generator
+    guard = self
+
+    class Generator(original_generator):
+      campx_standin, __wrapped__ = True, original_generator
+
+      def seed(me):
+        who = _who_on_stack(sys._getframe(1))
+        if who is not None:
+          guard.drawn.append(('torch.Generator.seed', who))
+          raise guard.refusal()
+        return original_generator.seed(me)
+    self.saved.append((torch, 'Generator', True, original_generator))
+    torch.Generator = Generator
     for name in _TORCH_FUNCTIONS:
       self.put(torch, name, 'torch.' + name, needs_no_generator=name not in ('manual_seed', 'seed'))
     for name in _TENSOR_METHODS:
@@ -234,8 +286,7 @@ def forbidden(error):
 # ------------------------------------------------------------------ static: what the code NAMES
 
 def _generator_types():
-  return (random.Random, np.random.RandomState, np.random.Generator, np.random.BitGenerator,
-          torch.Generator)
+  return _GENERATOR_TYPES
 
 
 def _clock_functions():

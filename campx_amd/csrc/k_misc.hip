@@ -46,8 +46,11 @@ __global__ void __launch_bounds__(128) write_probe_kernel(u32x4* __restrict__ ds
   // (block b runs on XCD b % 8: give each XCD one contiguous eighth of the buffer, as render_kernel does)
   const int64_t nb = gridDim.x, per = nb / 8;
   const int64_t b = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int64_t i = b * 128 + threadIdx.x;
-  if (i < n16) store16_streaming(dst + i, u32x4{value, value, value, value});
+  // a wave's window: 2 KiB = two rounds of 64 lanes x 16 bytes; a block: two waves, 4 KiB
+  const int64_t i = b * 256 + (threadIdx.x >> 6) * 128 + (threadIdx.x & 63);
+  const u32x4 v{value, value, value, value};
+  if (i < n16) store16_streaming(dst + i, v);
+  if (i + 64 < n16) store16_streaming(dst + i + 64, v);
 }
 
 }  // namespace campx_impl
@@ -72,7 +75,7 @@ int32_t campx_write_probe_launch(void* dst, int64_t n_bytes, uint32_t value, voi
   if (!dst || n_bytes < 0 || (reinterpret_cast<uintptr_t>(dst) & 15) || (n_bytes & 15)) return CAMPX_EINVAL;
   if (n_bytes == 0) return CAMPX_OK;
   const int64_t n16 = n_bytes / 16;
-  const int64_t blocks = ((n16 + 127) / 128 + 7) / 8 * 8;     // (a multiple of 8: the XCD order)
+  const int64_t blocks = ((n16 + 255) / 256 + 7) / 8 * 8;     // (4 KiB a block; a multiple of 8: the XCD order)
   if (blocks > 0x7fffffffll) return CAMPX_EINVAL;
   hipLaunchKernelGGL(write_probe_kernel, dim3((unsigned)blocks), dim3(128), 0,
                      static_cast<hipStream_t>(stream), static_cast<u32x4*>(dst), n16, value);

@@ -110,6 +110,40 @@ class UnseededGenerator(lanes_probes.Base):
     the_plot.add_reward(1.0 if np.random.default_rng().random() < P else 0.0)
 
 
+class SelfSeededStream(lanes_probes.Base):       # seeded by the operating system, straight from C
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if random.Random().random() < P else 0.0)
+
+
+class SelfSeededNumpy(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if np.random.RandomState().rand() < P else 0.0)
+
+
+class SelfSeededBits(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if np.random.Generator(np.random.PCG64()).random() < P else 0.0)
+
+
+class ReseededTorch(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    g = torch.Generator()
+    g.seed()
+    the_plot.add_reward(1.0 if float(torch.rand((), generator=g)) < P else 0.0)
+
+
 class BehindTheStandIns(lanes_probes.Base):
   """The legacy generator's own method, through the library module: no attribute of `numpy.random`
   is looked up, so no stand-in is in the way - the generator's state moving gives it away."""
@@ -160,6 +194,8 @@ class SeededEveryFrame(lanes_probes.Base):
     self.curtain.set_(self.step(actions.byte(), layers))
     g = torch.Generator().manual_seed(11)
     bonus = float(np.random.default_rng(3).integers(0, 4)) + float(torch.randint(0, 3, (), generator=g))
+    assert isinstance(random.Random(4), random.Random) and isinstance(np.random.RandomState(4), np.random.RandomState)
+    bonus += 0.0 * (random.Random(4).random() + np.random.RandomState(4).rand() + np.random.Generator(np.random.PCG64(4)).random())
     the_plot.add_reward(bonus)
 
 
@@ -173,6 +209,10 @@ DYNAMIC = [(RareRandom, r'draws random numbers in RareRandom\.update \(random\.r
            (OsEntropy, r'draws random numbers in OsEntropy\.update \(os\.urandom\)'),
            (UnseededGenerator, r'draws random numbers in UnseededGenerator\.update \(numpy\.random\.default_rng\(\) '
                                r'without a seed\)'),
+           (SelfSeededStream, r'draws random numbers in SelfSeededStream\.update \(random\.Random\(\) without a seed\)'),
+           (SelfSeededNumpy, r'draws random numbers in SelfSeededNumpy\.update \(numpy\.random\.RandomState\(\) without'),
+           (SelfSeededBits, r'draws random numbers in SelfSeededBits\.update \(numpy\.random\.PCG64\(\) without a seed\)'),
+           (ReseededTorch, r'draws random numbers in ReseededTorch\.update \(torch\.Generator\.seed\)'),
            (BehindTheStandIns, r'drew from the process-wide generator of numpy\.random')]
 STATIC = [(FromImport, r"its code names a method of a random number generator \(random\.Random\.random\) through "
                        r"the module global '_from_import_draw'"),
@@ -182,7 +222,8 @@ STATIC = [(FromImport, r"its code names a method of a random number generator \(
 
 
 def _entry_points():
-  return (random.random, random.randint, np.random.rand, np.random.default_rng, torch.rand, torch.randint,
+  return (random.random, random.randint, random.Random, np.random.RandomState, np.random.PCG64, torch.Generator,
+          np.random.rand, np.random.default_rng, torch.rand, torch.randint,
           torch.Tensor.uniform_, torch.Tensor.random_, time.time, time.perf_counter, os.urandom,
           random.SystemRandom.random, 'uniform_' in vars(torch.Tensor))
 
