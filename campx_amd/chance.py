@@ -33,9 +33,12 @@ between a source of chance and a table:
    attribute (`from time import time`).  A generator kept in an INSTANCE attribute is refused by
    the state image (`tabulate._plain`: unimageable).
 
-Not covered: `datetime.datetime.now()` (a C type: no attribute can be replaced, and no state to
-compare) - unless named statically through a from-import, where (3) sees it - and chance that
-comes from outside the interpreter (a file that changes, a socket).
+`datetime.datetime.now()` / `date.today()`: the types are C types, no attribute of theirs can be
+replaced, but the module's NAMES can - by subclasses whose `now` / `utcnow` / `today` ask who is
+calling; a class bound by `from datetime import datetime` before the walk is seen by (3), which
+refuses a class's code that names a clock class together with one of those methods.
+Not covered: chance that comes from outside the interpreter (a file that changes, a socket, the
+process id).
 
 Host logic only.  Restores every entry point on exit, also when the walk raises; re-entrant (the
 inner contexts of nested front ends are no-ops).
@@ -71,6 +74,8 @@ _SELF_SEEDING = ((random, 'Random'), (np.random, 'RandomState'), (np.random, 'Se
                  (np.random, 'PCG64'), (np.random, 'PCG64DXSM'), (np.random, 'MT19937'),
                  (np.random, 'Philox'), (np.random, 'SFC64'))
 # (the real classes, for isinstance: inside `forbidden()` the module attributes are stand-ins)
+import datetime as _datetime
+_CLOCK_TYPES = (_datetime.datetime, _datetime.date)
 _GENERATOR_TYPES = (random.Random, np.random.RandomState, np.random.Generator, np.random.BitGenerator,
                     torch.Generator)
 
@@ -119,7 +124,7 @@ class _Guard(object):
     err.campx_chance = True          # (the context below tells its own refusals from others)
     return err
 
-  def standin(self, label, original, needs_no_generator=False, unseeded_only=False):
+  def standin(self, label, original, needs_no_generator=False, unseeded_only=False, max_args=None):
     guard = self
 
     def chance_standin(*args, **kwargs):
@@ -127,6 +132,8 @@ class _Guard(object):
         return original(*args, **kwargs)         # the caller's own, explicitly seeded stream
       if unseeded_only and (args or any(v is not None for v in kwargs.values())):
         return original(*args, **kwargs)         # default_rng(7): a function of its seed
+      if max_args is not None and len(args) > max_args:
+        return original(*args, **kwargs)         # time.strftime(fmt, t): a function of t
       who = _who_on_stack(sys._getframe(1))
       if who is None:
         guard.others.add(label.split('.')[0])
@@ -208,6 +215,30 @@ class _Guard(object):
       self.put(torch.Tensor, name, 'torch.Tensor.' + name, needs_no_generator=True)
     for name in _CLOCKS:
       self.put(time, name, 'time.' + name)
+    for name in ('localtime', 'gmtime', 'ctime'):      # (with no argument: now)
+      self.put(time, name, 'time.' + name, unseeded_only=True)
+    self.put(time, 'strftime', 'time.strftime', max_args=1)
+    import datetime
+    original_datetime, original_date = datetime.datetime, datetime.date
+    guard = self
+
+    def clock_method(owner, name):
+      def method(cls, *args, **kwargs):
+        who = _who_on_stack(sys._getframe(1))
+        if who is not None:
+          guard.drawn.append(('time.' + owner.__name__ + '.' + name, who))
+          raise guard.refusal()
+        return getattr(owner, name)(*args, **kwargs)
+      return classmethod(method)
+
+    # (C types: no attribute of theirs can be replaced - but the NAME `datetime.datetime` can, by a
+    # subclass whose now() / utcnow() / today() ask who is calling; instances stay the originals')
+    for owner, names in ((original_datetime, ('now', 'utcnow', 'today')), (original_date, ('today',))):
+      body = {name: clock_method(owner, name) for name in names}
+      body.update({'campx_standin': True, '__wrapped__': owner, '__module__': owner.__module__,
+                   '__qualname__': owner.__qualname__})
+      self.saved.append((datetime, owner.__name__, True, owner))
+      setattr(datetime, owner.__name__, type(owner.__name__, (owner,), body))
     self.put(os, 'urandom', 'os.urandom')
     if hasattr(os, 'getrandom'):
       self.put(os, 'getrandom', 'os.getrandom')
@@ -290,7 +321,6 @@ def _generator_types():
 
 
 def _clock_functions():
-  import datetime
   import secrets
   import uuid
   fns = {}
@@ -304,12 +334,14 @@ def _clock_functions():
       fn = getattr(owner, name, None)
       if fn is not None:
         fns[id(getattr(fn, '__wrapped__', fn))] = 'the entropy source ' + label + name
-  return fns, (datetime.datetime, datetime.date)
+  return fns, _CLOCK_TYPES
 
 
-def named_source(x):
+def named_source(x, attribute_names=()):
   """What `x` - a value the code of a game's class names through a global, a closure variable, a
-  default argument or a class attribute - is, if it is a source of chance; else None."""
+  default argument or a class attribute - is, if it is a source of chance; else None.
+  `attribute_names`: the attribute names that code uses (a clock CLASS - `from datetime import
+  datetime` - is only a clock to code that also says `.now` / `.utcnow` / `.today`)."""
   if getattr(x, 'campx_standin', False):
     x = x.__wrapped__
   if isinstance(x, _generator_types()):
@@ -321,6 +353,8 @@ def named_source(x):
   fns, clock_types = _clock_functions()
   if id(x) in fns:
     return fns[id(x)]
+  if isinstance(x, type) and issubclass(x, clock_types) and {'now', 'utcnow', 'today'} & set(attribute_names):
+    return 'the clock class {}.{} (now() / today())'.format(x.__module__, x.__name__)
   if owner is not None and isinstance(owner, type) and issubclass(owner, clock_types) and \
       getattr(x, '__name__', '') in ('now', 'utcnow', 'today'):
     return 'the clock {}.{}'.format(owner.__name__, x.__name__)

@@ -667,7 +667,8 @@ def _live_in_function(fn, live, depth, seen):
           if found:
             return '{} through {}.{} (named by {}())'.format(found, name, attr, fn.__name__)
       continue
-    found = _live_in_value(value, live, depth + 1, seen)
+    attrs = _attribute_names(code, set()) if attrs is None else attrs
+    found = chance.named_source(value, attrs) or _live_in_value(value, live, depth + 1, seen)
     if found:
       return '{} through the module global {!r} (named by {}())'.format(found, name, fn.__name__)
   return None

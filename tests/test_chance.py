@@ -144,6 +144,44 @@ class ReseededTorch(lanes_probes.Base):
     the_plot.add_reward(1.0 if float(torch.rand((), generator=g)) < P else 0.0)
 
 
+import datetime                                   # noqa: E402
+from datetime import datetime as _bound_early     # noqa: E402
+
+
+class WallClock(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if datetime.datetime.now().second == 7 else 0.0)
+
+
+class WallClockBoundEarly(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if _bound_early.now().second == 7 else 0.0)
+
+
+class Calendar(lanes_probes.Base):
+  """NOT a clock: the class is used to build a constant date, no `now` / `today` anywhere."""
+
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(float(_bound_early(2020, 2, 29).day + time.gmtime(0).tm_year - 1970 - 29))
+
+
+class LocalTime(lanes_probes.Base):
+  def update(self, actions, board, layers, backdrop, all_things, the_plot):
+    if actions is None:
+      return
+    self.curtain.set_(self.step(actions.byte(), layers))
+    the_plot.add_reward(1.0 if time.localtime().tm_sec == 7 else 0.0)
+
+
 class BehindTheStandIns(lanes_probes.Base):
   """The legacy generator's own method, through the library module: no attribute of `numpy.random`
   is looked up, so no stand-in is in the way - the generator's state moving gives it away."""
@@ -213,16 +251,20 @@ DYNAMIC = [(RareRandom, r'draws random numbers in RareRandom\.update \(random\.r
            (SelfSeededNumpy, r'draws random numbers in SelfSeededNumpy\.update \(numpy\.random\.RandomState\(\) without'),
            (SelfSeededBits, r'draws random numbers in SelfSeededBits\.update \(numpy\.random\.PCG64\(\) without a seed\)'),
            (ReseededTorch, r'draws random numbers in ReseededTorch\.update \(torch\.Generator\.seed\)'),
+           (WallClock, r'reads the clock in WallClock\.update \(time\.datetime\.now\)'),
+           (LocalTime, r'reads the clock in LocalTime\.update \(time\.localtime\)'),
            (BehindTheStandIns, r'drew from the process-wide generator of numpy\.random')]
 STATIC = [(FromImport, r"its code names a method of a random number generator \(random\.Random\.random\) through "
                        r"the module global '_from_import_draw'"),
           (FromImportClock, r"its code names the clock time\.perf_counter through the module global"),
+          (WallClockBoundEarly, r"its code names the clock class datetime\.datetime \(now\(\) / today\(\)\) through the "
+                                r"module global '_bound_early'"),
           (OwnStream, r"its code names a random number generator \(random\.Random\) through the module global "
                       r"'_OWN_STREAM'")]
 
 
 def _entry_points():
-  return (random.random, random.randint, random.Random, np.random.RandomState, np.random.PCG64, torch.Generator,
+  return (random.random, random.randint, random.Random, datetime.datetime, datetime.date, time.localtime, np.random.RandomState, np.random.PCG64, torch.Generator,
           np.random.rand, np.random.default_rng, torch.rand, torch.randint,
           torch.Tensor.uniform_, torch.Tensor.random_, time.time, time.perf_counter, os.urandom,
           random.SystemRandom.random, 'uniform_' in vars(torch.Tensor))
@@ -255,6 +297,12 @@ def test_a_function_of_a_constant_seed_is_not_chance():
       float(torch.randint(0, 3, (), generator=torch.Generator().manual_seed(11)))
   rewards = np.asarray(table.reward, np.float32)      # (NaN: entries of states the game never reaches)
   assert set(np.unique(rewards[~np.isnan(rewards)])) == {np.float32(want)}
+
+
+def test_a_constant_date_is_not_the_clock():
+  table = tabulate.trace(lanes_probes.game(Calendar)(), cache=False)
+  rewards = np.asarray(table.reward, np.float32)
+  assert set(np.unique(rewards[~np.isnan(rewards)])) == {np.float32(0.0)} and table.n_states > 1
 
 
 def test_other_callers_are_not_in_the_way():
