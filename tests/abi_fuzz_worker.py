@@ -210,6 +210,8 @@ def fuzz_wide(lib, dtype, cases, n, rng):
   lib.campx_wide_spec_validate.argtypes = [vp]
   lib.campx_wide_tables_bytes.restype = ctypes.c_int64
   lib.campx_wide_tables_bytes.argtypes = [vp]
+  lib.campx_wide_tables_build.restype = ctypes.c_int32
+  lib.campx_wide_tables_build.argtypes = [vp, vp, vp]
   pointers = ('state_cells', 'next_state', 'reward', 'done', 'perf')
   # (the host pointers are the harness's; n_states and n_dyn size the caller's own arrays - a
   # caller that lies about them is beyond what a validator can see)
@@ -237,7 +239,44 @@ def fuzz_wide(lib, dtype, cases, n, rng):
     accepted += 1
     wide_invariants(s, arrays)
     assert need > 0
+    if i % 8 == 0:
+      # the table builder, under the sanitizers: it packs the whole blob on the host and only then
+      # copies it to the "device" - here a host buffer and no GPU, so the copy is what fails
+      # (CAMPX_ELAUNCH), after every index has been used
+      blob_out = np.empty(need, np.uint8)
+      assert lib.campx_wide_tables_build(ptr, blob_out.ctypes.data, None) in (-3, 0)
   return accepted
+
+
+# ------------------------------------------------------------------ campx_pair_table_pack
+
+def fuzz_pack(lib, cases, n, rng):
+  """The host arrays of a host-tabulated game of two to four movers (next cell | shows bit per
+  mover, reward, done | discount code, perf per (cell, ..., cell, action)) packed into the pair /
+  tuple table: a cell outside the board is refused (CAMPX_EINVAL); otherwise the packing runs to
+  its end and the copy to a device that is not there fails (CAMPX_ELAUNCH)."""
+  vp = ctypes.c_void_p
+  lib.campx_pair_table_bytes.restype = ctypes.c_int64
+  lib.campx_pair_table_bytes.argtypes = [vp]
+  lib.campx_pair_table_pack.restype = ctypes.c_int32
+  lib.campx_pair_table_pack.argtypes = [vp] * 7
+  refused = 0
+  for i in range(n):
+    case = cases[i % len(cases)]
+    spec = np.array(case['spec'], np.uint8)
+    arrays = {k: np.array(case[k], copy=True) for k in ('trace', 'reward', 'done', 'perf') if case[k] is not None}
+    name = ('trace', 'trace', 'done', 'reward')[int(rng.randint(4))]
+    _mutate(rng, arrays[name].view(np.uint8).reshape(-1), [])
+    need = lib.campx_pair_table_bytes(spec.ctypes.data)
+    assert need > 0
+    table = np.empty(need, np.uint8)
+    rc = lib.campx_pair_table_pack(spec.ctypes.data, arrays['trace'].ctypes.data, arrays['reward'].ctypes.data,
+                                   arrays['done'].ctypes.data,
+                                   arrays['perf'].ctypes.data if 'perf' in arrays else None, table.ctypes.data, None)
+    bad_cell = bool(((arrays['trace'] & 0x7f) >= case['cells']).any())
+    assert rc == -1 if bad_cell else rc in (-3, -2, 0), (rc, bad_cell)
+    refused += rc == -1
+  return refused
 
 
 def main(argv):
@@ -254,6 +293,8 @@ def main(argv):
   out['shape_accepted'], out['shape_tables_built'] = fuzz_shapes(lib, cases['shape_dtype'], cases['shapes'], n_shape, rng)
   out['wide_mutants'] = n - n_spec - n_shape
   out['wide_accepted'] = fuzz_wide(lib, cases['wide_dtype'], cases['wides'], out['wide_mutants'], rng)
+  out['pack_mutants'] = max(200, n // 100)
+  out['pack_refused'] = fuzz_pack(lib, cases['packs'], out['pack_mutants'], rng)
   # every valid case is accepted as it is
   for blob in cases['specs']:
     kept = np.array(blob, np.uint8)              # (a name: the buffer must outlive the call)

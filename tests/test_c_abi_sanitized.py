@@ -62,7 +62,16 @@ def _cases():
     spec, arrays = tabulate.to_wide_spec(tabulate.trace(WIDE_GAMES[name]()))
     wides.append((_blob(spec), {k: (None if k == 'perf' and not spec.has_perf else np.array(v))
                                 for k, v in arrays.items()}))
-  return dict(spec_dtype=np.dtype(gamespec.CampxSpec), specs=specs,
+  # host-tabulated games of two and three movers: the arrays campx_pair_table_pack() takes
+  packs = []
+  for level in (0, 1):
+    game = tabulate.trace(FUSED_GAMES['sokoban' if level == 0 else 'sokoban_l1']())
+    packs.append(dict(spec=_blob(tabulate.to_spec(game)), cells=game.rows * game.cols,
+                      trace=np.ascontiguousarray(game.trace_bytes()),
+                      reward=np.ascontiguousarray(game.reward, dtype=np.float32),
+                      done=np.ascontiguousarray(game.done_bytes(), dtype=np.uint8),
+                      perf=np.ascontiguousarray(game.perf, dtype=np.int8) if game.has_perf else None))
+  return dict(packs=packs, spec_dtype=np.dtype(gamespec.CampxSpec), specs=specs,
               shape_dtype=np.dtype(gamespec.CampxShapeSpec), shapes=shapes,
               wide_dtype=np.dtype(gamespec.CampxWideSpec), wides=wides)
 
@@ -109,6 +118,7 @@ def test_host_only_entry_points_survive_100000_mutants_under_asan_and_ubsan(tmp_
     n, ok = got[family + '_mutants'], got[family + '_accepted']
     assert 0.05 * n < ok < 0.95 * n, got
   assert got['shape_tables_built'] > 1000, got
+  assert 0 < got['pack_refused'] < got['pack_mutants'], got       # (cells off the board: refused)
 
 
 def test_the_sanitized_library_is_not_the_one_that_ships():
