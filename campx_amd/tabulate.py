@@ -37,18 +37,24 @@ nothing else).  What an order changes on the screen - which of two things on one
 already in the table entries' "is the character its cell shows" bits.  The tabulation is exact
 under conditions that are CHECKED while tabulating (TabulationError otherwise):
 
-* every moving thing occupies exactly one cell in every reached state - or NONE: a drape
+* every tracked thing occupies exactly one cell in every reached state - or NONE: a drape
   whose curtain is empty (a key that was picked up, a door that opened) and a sprite that
   is not `visible` (campx/things.py:294-296, 391-392; engine.py:314 skips it) are "absent",
-  tabulated as standing on a cell index the thing never occupies and never shown -, there
-  are at most four of them -
+  tabulated as standing on a cell index the thing never occupies and never shown.  A drape
+  that covers SEVERAL cells which come and go (coins taken one by one; campx/things.py:161-262
+  sets no one-cell limit) is tracked as one thing per cell it ever covers - on its cell while
+  the curtain has it, absent otherwise (round 6, `TracedGame.piece_cell`).  There are at most
+  four tracked things -
   the mode counts as one, and it has at most rows*cols values (beyond either: the game runs
   from its STATE table, the wide tier, which only needs the state count to fit) -,
   the board has at most 128 cells (one mover and one mode: 1 024, the wide tier,
   csrc/k_wide.hip) and 16 characters;
-* the Backdrop's curtain never changes (no sprite painted into the backdrop:
-  campx/rendering.py:128,150), and no reached z-order changes how the SCENERY paints (two
-  overlapping static drapes swapping places);
+* a Backdrop whose curtain changes (a `Backdrop.update()` of its own, campx/things.py:103-148; a
+  sprite painted into the backdrop, campx/rendering.py:128,150) is tracked the same way: one
+  piece per (cell, character) it ever shows beyond its first picture, painted on the backdrop
+  itself, behind every thing (round 6, `TracedGame.in_backdrop`; such a game runs from its state
+  table); no reached z-order changes how the SCENERY paints (two overlapping static drapes
+  swapping places);
 * every rendered board equals "backdrop, then things in the state's z-order" computed from
   the cells alone - which also yields whether a moving thing is the character its cell shows;
 * at most fifteen distinct discounts other than the default - 1.0, or 0.0 on the frame
