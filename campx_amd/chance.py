@@ -110,6 +110,10 @@ class _Guard(object):
     self.drawn = []          # (what was asked for, '<Class>.<method>')
     self.others = set()      # process-wide generators SOMEBODY ELSE drew from meanwhile (another
                              # thread, this package's own checks): their state proves nothing
+    self.thread = threading.get_ident()     # the stand-ins are the whole process's while they
+                             # last, but only THIS thread is running a game for its tables: a
+                             # stochastic game played on the generic tier by another thread is
+                             # none of the guard's business
     self.saved = []          # (owner, name, had_own_attribute, original)
 
   def message(self):
@@ -134,7 +138,7 @@ class _Guard(object):
         return original(*args, **kwargs)         # default_rng(7): a function of its seed
       if max_args is not None and len(args) > max_args:
         return original(*args, **kwargs)         # time.strftime(fmt, t): a function of t
-      who = _who_on_stack(sys._getframe(1))
+      who = _who_on_stack(sys._getframe(1)) if threading.get_ident() == guard.thread else None
       if who is None:
         guard.others.add(label.split('.')[0])
         return original(*args, **kwargs)
@@ -154,7 +158,7 @@ class _Guard(object):
 
     def __init__(me, *args, **kwargs):
       unseeded = (not args or args[0] is None) and not any(v is not None for v in kwargs.values())
-      if unseeded:
+      if unseeded and threading.get_ident() == guard.thread:
         who = _who_on_stack(sys._getframe(1))
         if who is not None:
           guard.drawn.append((label, who))
@@ -202,7 +206,7 @@ class _Guard(object):
       campx_standin, __wrapped__ = True, original_generator
 
       def seed(me):
-        who = _who_on_stack(sys._getframe(1))
+        who = _who_on_stack(sys._getframe(1)) if threading.get_ident() == guard.thread else None
         if who is not None:
           guard.drawn.append(('torch.Generator.seed', who))
           raise guard.refusal()
@@ -224,7 +228,7 @@ class _Guard(object):
 
     def clock_method(owner, name):
       def method(cls, *args, **kwargs):
-        who = _who_on_stack(sys._getframe(1))
+        who = _who_on_stack(sys._getframe(1)) if threading.get_ident() == guard.thread else None
         if who is not None:
           guard.drawn.append(('time.' + owner.__name__ + '.' + name, who))
           raise guard.refusal()

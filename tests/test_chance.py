@@ -324,6 +324,41 @@ def test_other_callers_are_not_in_the_way():
       np.random.mtrand._rand.random_sample()
 
 
+def test_a_game_of_chance_PLAYED_by_another_thread_is_none_of_the_guards_business():
+  """The stand-ins are the whole process's while a tabulation lasts; a stochastic game that another
+  thread plays on the generic tier meanwhile (batch=None: the reference's model, where chance is
+  fine) must neither be refused nor make the tabulation fail."""
+  import threading
+  played, errors, stop = [0], [], threading.Event()
+
+  def play_a_game_of_chance():
+    try:
+      game = lanes_probes.game(RareRandom)()
+      game.its_showtime()
+      onehot = tabulate.default_actions()
+      while not stop.is_set():
+        game.play(onehot[played[0] % 5])
+        played[0] += 1
+    except Exception as e:            # noqa: BLE001 - reported below
+      errors.append(e)
+
+  other = threading.Thread(target=play_a_game_of_chance)
+  other.start()
+  try:
+    while played[0] < 20 and not errors:
+      time.sleep(0.01)
+    for _ in range(3):
+      table = tabulate.trace(lanes_probes.game(lanes_probes.Where)(), cache=False)     # a deterministic game
+      assert table.n_states > 1
+    before = played[0]
+    while played[0] < before + 20 and not errors:
+      time.sleep(0.01)
+  finally:
+    stop.set()
+    other.join()
+  assert not errors, errors
+
+
 def _hello():
   sys.path.insert(0, os.path.join(REPO, 'examples'))
   import hello_world_batched as ex
