@@ -80,6 +80,8 @@ class PlayGraph(object):
     with torch.cuda.graph(self._graph):
       self._frames()
     f.frame = frame0
+    # (the graph holds ADDRESSES: the engine's frame buffers as they were when it was captured)
+    self._captured = (f._obs.data_ptr(), f._board.data_ptr())
 
   def _frames(self):
     """The n frames, issued on the current stream: called to warm up and, once, under capture."""
@@ -122,6 +124,9 @@ class PlayGraph(object):
     these; with a policy they are ignored and `self.actions` holds what the policy chose).
     Nothing is synchronised; returns self."""
     f = self.fused
+    if (f._obs.data_ptr(), f._board.data_ptr()) != self._captured:
+      raise RuntimeError('the engine\'s frame buffers are not the ones this graph was captured with '
+                         '(set_play_obs_dtype() after capture_play()?): capture again')
     if actions is not None:
       if self.policy is not None:
         raise ValueError('this graph was captured with a policy: it chooses the actions')

@@ -128,6 +128,12 @@ def test_what_a_graph_cannot_hold_is_refused():
   with pytest.raises(ValueError, match='outside 0..4'):     # (at the replay already, if the flag is up by then)
     graph.replay(bad)
     game.fused.check_actions()
+  # a graph holds addresses: another observation buffer (a change of play()'s dtype) means another graph
+  stale = game.capture_play(2)
+  game.fused.set_play_obs_dtype(torch.bfloat16)
+  with pytest.raises(RuntimeError, match='capture again'):
+    stale.replay(torch.zeros((2, 64), dtype=torch.int8, device='cuda'))
+  game.fused.set_play_obs_dtype(torch.int8)
   with_policy = game.capture_play(2, policy=lambda obs, t: torch.zeros(64, dtype=torch.int8, device='cuda'))
   with pytest.raises(ValueError, match='policy'):
     with_policy.replay(torch.zeros((2, 64), dtype=torch.int8, device='cuda'))
