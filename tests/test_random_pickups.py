@@ -38,6 +38,16 @@ def _gold(k):
     return {name[len(pre):]: f[name] for name in f.files if name.startswith(pre)}
 
 
+_TRACED = {}
+
+
+def _traced(k):
+  """Game k tabulated (once per test process: the one-frame-per-play walker takes 1-4 s a game)."""
+  if k not in _TRACED:
+    _TRACED[k] = tabulate.trace(random_pickups.builder(DEFS[k])(), cache=False)
+  return _TRACED[k]
+
+
 def _same(a, b):
   a, b = np.asarray(a), np.asarray(b)
   if a.dtype.kind == 'f' or b.dtype.kind == 'f':
@@ -56,7 +66,7 @@ def test_the_generator_still_makes_the_games_of_the_fixture():
 def test_a_drape_of_several_cells_becomes_one_tracked_thing_per_cell():
   pieces = []
   for k, d in enumerate(DEFS):
-    traced = tabulate.trace(random_pickups.builder(d)(), cache=False)
+    traced = _traced(k)
     W = len(d['art'][0])
     where = lambda ch: [r * W + c for r, row in enumerate(d['art']) for c, x in enumerate(row) if x == ch]
     assert traced.piece_cell[0] is None and traced.in_backdrop[0] is False
@@ -113,7 +123,7 @@ def test_the_table_tabulated_from_the_classes_gives_them_too(k):
   from oracle.table_replay import StateWalker, TableWalker
   gold = _gold(k)
   T, N = gold['actions'].shape
-  traced = tabulate.trace(random_pickups.builder(DEFS[k])(), cache=False)
+  traced = _traced(k)
   assert [ord(c) for c in traced.chars] == gold['chars'].tolist()
   if traced.dense_reason is not None:
     walker = StateWalker(traced, N)
@@ -159,7 +169,7 @@ def test_hip_path_gives_the_reference_engines_frames(k):
   # ... and at a size the kernels' workgroups fill: 4 096 environments against the host's walker
   from oracle.table_replay import StateWalker, TableWalker
   B = 4096
-  traced = tabulate.trace(build(), cache=False)
+  traced = _traced(k)
   acts = np.random.RandomState(40 + k).randint(0, 5, size=(60, B)).astype(np.int8)
   game = build(batch=B, device='cuda')
   game.its_showtime()
