@@ -562,6 +562,11 @@ struct RenderSource {
   const int8_t* rot_board;
   const uint8_t* top_layer;   // device: scenery layer per cell (one-byte trace only)
   bool wide;                  // 16-bit trace entries (k_wide.hip)
+  // a scenery that changes with the state (CampxWideSpec.n_variants > 1): `rot_obs` / `rot_board`
+  // hold one set of rotations per variant, these many bytes apart, and plane `n_dyn` of the trace
+  // names each (frame, environment)'s variant
+  int32_t n_variants;
+  int64_t rot_obs_stride, rot_board_stride;
 };
 int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* dst, int64_t B,
                            int32_t T, int64_t plane_rows, int64_t pitch, bool is_board, int fmt,

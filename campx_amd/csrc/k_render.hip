@@ -28,7 +28,22 @@ struct RenderParams {
   int32_t dyn_off[CAMPX_WIDE_MAX_DYN];   // byte offset of moving thing d's layer inside a row
   const int8_t* rot;          // device: the 16 rotations of the scenery row (layered or flat board)
   const uint8_t* top_layer;   // device: scenery layer per cell (one-byte trace only)
+  int64_t rot_stride;         // kVar: bytes from one variant's rotations to the next's
 };
+
+// kVar: bytes [0, n) of a 16-byte scenery chunk come from one environment's row, bytes [n, 16)
+// from the next environment's, whose scenery is another variant (1 <= n <= 15).
+__device__ __forceinline__ u32x4 merge_rows(u32x4 a, u32x4 b, int n) {
+  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int left = n - 4 * w;          // bytes of this dword that are still the first row's
+    const uint32_t mask = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+    o[w] = (aw[w] & mask) | (bw[w] & ~mask);
+  }
+  return u32x4{o[0], o[1], o[2], o[3]};
+}
 
 // The trace entry of one moving thing in one frame.  One byte in the one-cell tier (cell |
 // visible << 7; the scenery layer the thing covers is looked up per cell).  Boards above 128
@@ -91,7 +106,14 @@ constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 // row (the trace plane is [T * B] rows: row B of this frame is row 0 of the next); only at
 // the two ends of a launch is a chunk written byte by byte - the part after the first
 // frame's start, the part before the last frame's end.
-template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false, bool kWide = false>
+// kVar (wide tier, round 6): the scenery is a function of the state - a Backdrop that repaints
+// itself over many cells.  Plane `n_dyn` of the trace holds, per (frame, environment), the
+// index of the scenery variant; a chunk's scenery bytes come from that variant's rotations, and a
+// chunk that runs over the end of an environment's row takes the rest from the NEXT environment's
+// variant (the rotations continue a row cyclically with its own start, which is what the next
+// row starts with when both show the same variant - and what merge_rows() replaces when not).
+template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false, bool kWide = false,
+          bool kVar = false>
 __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     RenderParams rp, const typename TraceFormat<kWide>::Entry* __restrict__ trace,
     int8_t* __restrict__ dst, int64_t n_rows) {
@@ -169,7 +191,35 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     // then starts 8 image bytes into a scenery chunk, and `off % R` of the wrapped offset put
     // another part of the row in the frame's first 8 elements
     if ((kOdd || kFmt != 0) && off >= 0xfffffff0u) k = R - (int)(0u - off);
-    scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+    if constexpr (kVar) {
+      // which environment's row the chunk starts in, and the next one's: rows past this frame's
+      // last are the next frame's first (the trace plane is [T * B] rows), except in the
+      // launch's last frame, whose chunks past the end are never stored; a chunk that starts
+      // BEFORE the frame (wrapped offset) only ever has its bytes of row 0 stored by this block
+      const bool before = off >= 0xfffffff0u;
+      uint32_t r0 = before ? 0u : row, r1 = before ? 0u : row + 1u;
+      const uint32_t top = (uint32_t)rp.B - 1u;
+      if (last_frame) {
+        r0 = r0 < top ? r0 : top;
+        r1 = r1 < top ? r1 : top;
+      } else {
+        r0 = r0 < 2u * top + 1u ? r0 : 2u * top + 1u;
+        r1 = r1 < 2u * top + 1u ? r1 : 2u * top + 1u;
+      }
+      const typename Fmt::Entry* vars = frame_trace + (int64_t)rp.n_dyn * n_rows;
+      const uint32_t v0 = (uint32_t)Fmt::cell(vars[trace_row(r0)]);
+      const int at = (k & 15) * pitch + (k & ~15);
+      scen[j] = *reinterpret_cast<const u32x4*>(rot + (int64_t)v0 * rp.rot_stride + at);
+      const int left = R - k;                          // bytes of the chunk inside row r0
+      if (left < 16) {
+        const uint32_t v1 = (uint32_t)Fmt::cell(vars[trace_row(r1)]);
+        if (v1 != v0)
+          scen[j] = merge_rows(scen[j], *reinterpret_cast<const u32x4*>(rot + (int64_t)v1 * rp.rot_stride + at),
+                               left);
+      }
+    } else {
+      scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
+    }
   }
   // the scenery layer of two cells per lane (kBoard needs none of it)
   uint32_t top2 = 0;
@@ -307,6 +357,7 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
   rp.pitch = pitch;
   rp.cells = HW;
   rp.rot = is_board ? src.rot_board : src.rot_obs;
+  rp.rot_stride = is_board ? src.rot_board_stride : src.rot_obs_stride;
   rp.top_layer = src.top_layer;
   for (int d = 0; d < src.n_dyn; ++d) {
     rp.dyn_char[d] = src.layer_char[src.dyn_layer[d]];
@@ -349,7 +400,23 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
   do {                                                                      \
     if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
   } while (0)
-  if (src.wide) {
+  if (src.wide && src.n_variants > 1) {
+    // a scenery of several variants: the run-time-K instantiation, whatever the number of things
+#define CAMPX_RENDER_VAR(BOARD, FMT, ODD)                                                          \
+  hipLaunchKernelGGL((render_kernel<8, BOARD, true, (FMT) ? kWin16 : kWin, FMT, ODD, true, true>), \
+                     grid, dim3(kRenderWaves * kWave), 0, stream, rp,                              \
+                     static_cast<const uint16_t*>(trace), dst, n_rows)
+    if (is_board) {
+      if (odd) CAMPX_RENDER_VAR(true, 0, true); else CAMPX_RENDER_VAR(true, 0, false);
+    } else if (fmt == 1) {
+      if (odd) CAMPX_RENDER_VAR(false, 1, true); else CAMPX_RENDER_VAR(false, 1, false);
+    } else if (fmt == 2) {
+      if (odd) CAMPX_RENDER_VAR(false, 2, true); else CAMPX_RENDER_VAR(false, 2, false);
+    } else {
+      if (odd) CAMPX_RENDER_VAR(false, 0, true); else CAMPX_RENDER_VAR(false, 0, false);
+    }
+#undef CAMPX_RENDER_VAR
+  } else if (src.wide) {
 #define CAMPX_RENDER_WIDE(KK)                                             \
   do {                                                                    \
     if (is_board) {                                                       \

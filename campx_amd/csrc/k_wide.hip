@@ -325,7 +325,11 @@ __global__ void wide_reset_kernel(const u32x4* __restrict__ cells, int32_t K, in
 struct WideLayout {
   int64_t n_entries, cells_off, perf_off, rot_obs_off, rot_board_off, total;
   int pitch_obs, pitch_board;
+  int n_variants;          // sets of rotations (1: the scenery never changes)
+  int n_planes;            // planes of the trace: the things, plus the variant's when there are several
 };
+
+static int wide_variants(const CampxWideSpec& s) { return s.n_variants > 1 ? s.n_variants : 1; }
 
 WideLayout wide_layout(const CampxWideSpec& s) {
   WideLayout w;
@@ -335,9 +339,11 @@ WideLayout wide_layout(const CampxWideSpec& s) {
   w.perf_off = w.cells_off + S * (int64_t)sizeof(u32x4);
   w.rot_obs_off = (w.perf_off + w.n_entries + 15) & ~(int64_t)15;
   w.pitch_obs = (int)(((R + 15) & ~(int64_t)15) + 16);
-  w.rot_board_off = w.rot_obs_off + 16ll * w.pitch_obs;
+  w.n_variants = wide_variants(s);
+  w.n_planes = s.n_dyn + (w.n_variants > 1 ? 1 : 0);
+  w.rot_board_off = w.rot_obs_off + 16ll * w.pitch_obs * w.n_variants;
   w.pitch_board = (int)(((HW + 15) & ~(int64_t)15) + 16);
-  w.total = w.rot_board_off + 16ll * w.pitch_board;
+  w.total = w.rot_board_off + 16ll * w.pitch_board * w.n_variants;
   return w;
 }
 
@@ -356,6 +362,9 @@ RenderSource wide_render_source(const CampxWideSpec& s, const void* tables_dev) 
   src.rot_board = reinterpret_cast<const int8_t*>(blob + w.rot_board_off);
   src.top_layer = nullptr;
   src.wide = true;
+  src.n_variants = w.n_variants;
+  src.rot_obs_stride = 16ll * w.pitch_obs;
+  src.rot_board_stride = 16ll * w.pitch_board;
   return src;
 }
 
@@ -380,6 +389,9 @@ int32_t wide_validate_plain(const CampxWideSpec* s) {
   if ((s->has_perf | s->any_reward | s->any_dcode) & ~1) return CAMPX_ESPEC;
   for (int i = 0; i < HW; ++i)
     if (s->static_top_layer[i] >= s->n_layers) return CAMPX_ESPEC;
+  // a scenery of several variants takes one plane of the trace (and one slot of a state's entries)
+  if (s->n_variants < 0 || s->n_variants > CAMPX_WIDE_MAX_VARIANTS) return CAMPX_ESPEC;
+  if (s->n_variants > 1 && s->n_dyn > CAMPX_WIDE_MAX_DYN - 1) return CAMPX_ESPEC;
   return CAMPX_OK;
 }
 
@@ -626,6 +638,17 @@ int32_t campx_wide_spec_validate(const CampxWideSpec* s) {
   if (s->done)
     for (int64_t i = 0; i < (int64_t)S * CAMPX_N_ACTIONS; ++i)
       if ((s->done[i] & 0x0eu) || ((s->done[i] >> 4) && !s->any_dcode)) return CAMPX_ESPEC;
+  if (s->n_variants > 1) {
+    if (s->variant_top_layer) {
+      for (int64_t i = 0; i < (int64_t)s->n_variants * HW; ++i)
+        if (s->variant_top_layer[i] >= s->n_layers) return CAMPX_ESPEC;
+      for (int i = 0; i < HW; ++i)     // (variant 0 is the scenery of the plain fields)
+        if (s->variant_top_layer[i] != s->static_top_layer[i]) return CAMPX_ESPEC;
+    }
+    if (s->state_variant)
+      for (int64_t i = 0; i < S; ++i)
+        if (s->state_variant[i] >= s->n_variants) return CAMPX_ESPEC;
+  }
   return CAMPX_OK;
 }
 
@@ -638,6 +661,7 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
   if (!s || !tables_dev) return CAMPX_EINVAL;
   if (!s->state_cells || !s->next_state || !s->reward || !s->done) return CAMPX_EINVAL;
   if (s->has_perf && !s->perf) return CAMPX_EINVAL;
+  if (s->n_variants > 1 && (!s->variant_top_layer || !s->state_variant)) return CAMPX_EINVAL;
   const int32_t v = campx_wide_spec_validate(s);
   if (v != CAMPX_OK) return v;
   const WideLayout w = wide_layout(*s);
@@ -654,34 +678,43 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
     entries[i].y = wide_pack((uint32_t)s->next_state[i], s->done[i] & 1u, (uint32_t)(s->done[i] >> 4));
     perf[i] = s->perf ? s->perf[i] : 0;
   }
+  const int V = w.n_variants;
   for (int st = 0; st < S; ++st) {
     uint32_t e[CAMPX_WIDE_MAX_DYN] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    // (what a thing covers is the scenery of the STATE's variant)
+    const int variant = V > 1 ? s->state_variant[st] : 0;
+    const uint8_t* top = V > 1 ? s->variant_top_layer + (int64_t)variant * HW : s->static_top_layer;
     for (int d = 0; d < K; ++d) {
       const uint32_t c = s->state_cells[(int64_t)st * K + d];
       const uint32_t cell = c & 0x3ffu;
-      e[d] = cell | ((uint32_t)s->static_top_layer[cell] << 10) | ((c >> 15) ? 0u : 0x8000u);
+      e[d] = cell | ((uint32_t)top[cell] << 10) | ((c >> 15) ? 0u : 0x8000u);
     }
+    if (V > 1) e[K] = (uint32_t)variant;       // plane K of the trace: never painted (bit 15 clear)
     cells[st].x = e[0] | (e[1] << 16);
     cells[st].y = e[2] | (e[3] << 16);
     cells[st].z = e[4] | (e[5] << 16);
     cells[st].w = e[6] | (e[7] << 16);
   }
-  // the scenery's row (layers by equality, campx/rendering.py:204-215) and its rotations
+  // the scenery's row (layers by equality, campx/rendering.py:204-215) and its rotations - per variant
   int8_t* row = static_cast<int8_t*>(calloc(1, (size_t)R + HW));
   if (!row) {
     free(blob);
     return CAMPX_ENOMEM;
   }
   int8_t* brow = row + R;
-  for (int i = 0; i < HW; ++i) {
-    row[(int)s->static_top_layer[i] * HW + i] = 1;
-    brow[i] = (int8_t)s->layer_char[s->static_top_layer[i]];
-  }
-  int8_t* rot_obs = reinterpret_cast<int8_t*>(blob + w.rot_obs_off);
-  int8_t* rot_board = reinterpret_cast<int8_t*>(blob + w.rot_board_off);
-  for (int r = 0; r < 16; ++r) {
-    for (int j = 0; j < w.pitch_obs; ++j) rot_obs[(int64_t)r * w.pitch_obs + j] = row[(j + r) % R];
-    for (int j = 0; j < w.pitch_board; ++j) rot_board[(int64_t)r * w.pitch_board + j] = brow[(j + r) % HW];
+  for (int variant = 0; variant < V; ++variant) {
+    const uint8_t* top = V > 1 ? s->variant_top_layer + (int64_t)variant * HW : s->static_top_layer;
+    memset(row, 0, (size_t)R + HW);
+    for (int i = 0; i < HW; ++i) {
+      row[(int)top[i] * HW + i] = 1;
+      brow[i] = (int8_t)s->layer_char[top[i]];
+    }
+    int8_t* rot_obs = reinterpret_cast<int8_t*>(blob + w.rot_obs_off) + 16ll * w.pitch_obs * variant;
+    int8_t* rot_board = reinterpret_cast<int8_t*>(blob + w.rot_board_off) + 16ll * w.pitch_board * variant;
+    for (int r = 0; r < 16; ++r) {
+      for (int j = 0; j < w.pitch_obs; ++j) rot_obs[(int64_t)r * w.pitch_obs + j] = row[(j + r) % R];
+      for (int j = 0; j < w.pitch_board; ++j) rot_board[(int64_t)r * w.pitch_board + j] = brow[(j + r) % HW];
+    }
   }
   free(row);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -702,7 +735,7 @@ int32_t campx_wide_reset_launch(const CampxWideSpec* s, const void* tables_dev, 
   uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
   const int64_t P = row_pitch(out, B);
   hipLaunchKernelGGL(wide_reset_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, hs, cells,
-                     s->n_dyn, reinterpret_cast<int32_t*>(st.pos), st, trace, P, B);
+                     w.n_planes, reinterpret_cast<int32_t*>(st.pos), st, trace, P, B);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_failed(e);
   CampxOutputs one = out;     // one frame, written to slot 0 of each buffer
@@ -723,7 +756,8 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   {
     // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
     const int HW = s->rows * s->cols, R = HW * s->n_layers;
-    if (T == 1 && !reset_first && (R & 15) == 0 &&
+    // (a scenery of several variants: through the update + render kernels, which know about them)
+    if (T == 1 && !reset_first && (R & 15) == 0 && w.n_variants == 1 &&
         (!out.board || (HW & 15) == 0) &&
         (int64_t)kStepEnvMax * R < (1ll << 24)) {
       WideStepParams sp;
@@ -782,7 +816,7 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   WideParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.n_states = s->n_states;
-  wp.n_dyn = s->n_dyn;
+  wp.n_dyn = w.n_planes;           // (planes the update pass writes: the variant's is one of them)
   wp.discounts[0] = 1.0f;
   for (int i = 1; i < 16; ++i) wp.discounts[i] = s->discount_list[i];
   wp.has_dcodes = s->any_dcode;

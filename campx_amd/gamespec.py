@@ -512,6 +512,7 @@ WIDE_MAX_CELLS = 1024
 
 WIDE_MAX_STATES = 1 << 24
 WIDE_MAX_DYN = 8
+WIDE_MAX_VARIANTS = 64      # pictures of a scenery that changes (CampxWideSpec.n_variants)
 
 
 class CampxWideRules(ctypes.Structure):
@@ -534,7 +535,7 @@ class CampxWideSpec(ctypes.Structure):
               ('n_layers', ctypes.c_int32), ('n_dyn', ctypes.c_int32),
               ('n_states', ctypes.c_int32), ('any_reward', ctypes.c_int32),
               ('has_perf', ctypes.c_int32), ('any_dcode', ctypes.c_int32),
-              ('reserved0', ctypes.c_int32 * 2),
+              ('n_variants', ctypes.c_int32), ('reserved0', ctypes.c_int32),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * WIDE_MAX_DYN),
               ('discount_list', ctypes.c_float * 16),
@@ -542,4 +543,5 @@ class CampxWideSpec(ctypes.Structure):
               # host arrays, read at validation / table-build time only
               ('state_cells', ctypes.c_void_p), ('next_state', ctypes.c_void_p),
               ('reward', ctypes.c_void_p), ('done', ctypes.c_void_p),
-              ('perf', ctypes.c_void_p)]
+              ('perf', ctypes.c_void_p),
+              ('variant_top_layer', ctypes.c_void_p), ('state_variant', ctypes.c_void_p)]

@@ -303,6 +303,9 @@ class TracedGame(object):
     in_backdrop: per mover, True for a piece of a Backdrop that changes (one per (cell,
       character) it shows other than at the start; they come after every other mover and are
       painted on the backdrop itself, behind every thing);
+    variants, st_variant: a Backdrop whose pictures differ in more cells than there are tracked
+      things to spare: the pictures themselves (uint8 [H, W] each, the first = `backdrop`) and,
+      per state, which one it shows (one picture, all zeros, for every other game);
     absent_cells: per mover, the tracked values that stand for "not on the board" (an empty
       curtain, an invisible sprite) - cell indices the thing never occupies; usually empty;
     mode_orders: the z-orders the game reaches (lists of characters back to front; the
@@ -345,11 +348,13 @@ class TracedGame(object):
     sprite): an index it never occupies while on the board."""
     return int(cell) in self.absent_cells[k]
 
-  def model_board(self, cells, movers=True):
+  def model_board(self, cells, movers=True, variant=0):
     """The flat board (character codes) when the movers stand at `cells` (followed by the
     z-order mode, if the game has more than one): backdrop, then every thing in that
-    z-order (campx/engine.py:306-324).  `movers=False`: the scenery alone."""
-    board = self.backdrop.copy().reshape(-1)
+    z-order (campx/engine.py:306-324).  `movers=False`: the scenery alone.  `variant`: which
+    of the Backdrop's pictures (`variants`; 0 = the first, `backdrop`) lies beneath."""
+    variants = getattr(self, 'variants', None)
+    board = (variants[variant] if variants else self.backdrop).copy().reshape(-1)
     static = dict(self.statics)
     where = {}                 # character -> the cells its movers (pieces, for a many-cell drape) stand on
     in_backdrop = getattr(self, 'in_backdrop', None) or [False] * len(self.movers)
@@ -1006,6 +1011,27 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     for c in np.flatnonzero(now != base_backdrop):
       backdrop_pieces.add((int(c), int(now[c])))
   n_thing_movers = len(split)
+  # ... unless its pictures differ in more (cell, character) pairs than there are tracked things
+  # to spare - day and night over a whole floor: two pictures, dozens of cells.  Then the scenery
+  # itself comes in VARIANTS: the state names which picture the backdrop shows, the state-table
+  # tier's render kernel lays that variant's row (CampxWideSpec.n_variants), and it costs one
+  # tracked value however many cells change.
+  variants, state_variant = [backdrop0], [0] * len(images)
+  if backdrop_pieces and n_thing_movers + len(backdrop_pieces) > gamespec.WIDE_MAX_DYN:
+    index = {backdrop0: 0}
+    for s_, b in enumerate(backdrops):
+      if b not in index:
+        index[b] = len(variants)
+        variants.append(b)
+      state_variant[s_] = index[b]
+    if len(variants) <= gamespec.WIDE_MAX_VARIANTS and n_thing_movers + 1 <= gamespec.WIDE_MAX_DYN:
+      for b in variants:
+        for code in np.unique(np.frombuffer(b, np.int64)):
+          if not 0 <= int(code) < 256 or chr(int(code)) not in chars:
+            _fail('the Backdrop shows character code {}, which is not in its palette'.format(int(code)))
+      backdrop_pieces = set()              # the variants carry every cell
+    else:
+      variants, state_variant = [backdrop0], [0] * len(images)
   for c, code in sorted(backdrop_pieces):
     if not 0 <= code < 256 or chr(code) not in chars:
       _fail('the Backdrop shows character code {} at cell {}, which is not in its palette'.format(code, c))
@@ -1014,7 +1040,8 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   if len(split) > gamespec.WIDE_MAX_DYN:
     several = sorted({ch for ch, c in zip(split[:n_thing_movers], piece_cell) if c is not None})
     if backdrop_pieces:
-      several.append('the Backdrop')
+      several.append('the Backdrop (which also shows more than {} different pictures, or leaves no '
+                     'tracked value to name them)'.format(gamespec.WIDE_MAX_VARIANTS))
     _fail('moving drape(s) {} cover several cells that come and go - {} tracked cells with the '
           'other moving things, and the table kernels track at most {}'.format(
               ', '.join(ch if ch == 'the Backdrop' else repr(ch) for ch in several), len(split),
@@ -1075,7 +1102,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   elif HW ** n_tracked * N_ACTIONS > DENSE_MAX_ENTRIES:
     dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
         HW, n_tracked, DENSE_MAX_ENTRIES)
-  if any(in_backdrop) and dense_reason is None:
+  if (any(in_backdrop) or len(variants) > 1) and dense_reason is None:
     dense_reason = 'the Backdrop changes (its cells are painted behind every thing)'
 
   def where_is(s, k):
@@ -1135,6 +1162,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   game.movers = movers
   game.piece_cell = piece_cell
   game.in_backdrop = in_backdrop
+  game.variants = [np.frombuffer(b, np.int64).astype(np.uint8).reshape(H, W) for b in variants]
   game.absent_cells = absent_cells
   game.statics = []
   for ch in schedule:
@@ -1156,7 +1184,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   state_cells = [tuple(cell_of(s, k) for k in range(K)) +
                  ((state_mode[s],) if len(modes) > 1 else ())
                  for s in range(len(orders))]
-  if len(set(state_cells)) != len(state_cells):
+  if len(set(zip(state_cells, state_variant))) != len(state_cells):
     _fail('two reachable states have every moving thing on the same cells and the same mode '
           '(a thing that is "absent" in more ways than its free cells can name)')
   game.init_cells = state_cells[0]
@@ -1176,8 +1204,8 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
             'only moving things may change places')
 
   # ---- every reached board is "backdrop + things in z-order" of the cells alone
-  for cells, board in zip(state_cells, boards):
-    model = game.model_board(cells)
+  for cells, board, variant in zip(state_cells, boards, state_variant):
+    model = game.model_board(cells, variant=variant)
     if model.tobytes() != board:
       _fail('a rendered board is not "backdrop, then every thing in z-order" of the moving '
             'things\' cells')
@@ -1234,6 +1262,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     game.st_shows[:, k] = (game.st_present[:, k] &
                            (game.st_board[np.arange(S), game.st_cells[:, k]] == codes[k]))
   game.st_mode = np.array(state_mode, np.int32)
+  game.st_variant = np.array(state_variant, np.uint16)
   game.st_next = np.tile(np.arange(S, dtype=np.int32)[:, None], (1, N_ACTIONS))
   game.st_reward = np.full((S, N_ACTIONS), np.nan, np.float32)
   game.st_done = np.zeros((S, N_ACTIONS), np.uint8)
@@ -1416,6 +1445,16 @@ def to_wide_spec(game):
       reward=np.array(game.st_reward, np.float32, order='C'),
       done=np.array(game.st_done | (game.st_dcode << 4), np.uint8, order='C'),
       perf=np.array(game.st_perf, np.int8, order='C'))
+  variants = getattr(game, 'variants', None) or [game.backdrop]
+  if len(variants) > 1:
+    # the scenery's front-most layer per cell, per picture of the Backdrop; which one a state shows
+    spec.n_variants = len(variants)
+    tops = np.zeros((len(variants), HW), np.uint8)
+    for v in range(len(variants)):
+      scenery = game.model_board(game.init_cells, movers=False, variant=v).reshape(-1)
+      tops[v] = [layer_of[chr(int(c))] for c in scenery]
+    arrays['variant_top_layer'] = tops
+    arrays['state_variant'] = np.array(game.st_variant, np.uint16, order='C')
   for name, a in arrays.items():
     setattr(spec, name, a.ctypes.data)
   if not game.has_perf:

@@ -49,6 +49,8 @@ class WideGame(fused.FusedGame):
     self.rows, self.cols = engine.rows, engine.cols
     self.n_layers = len(self.chars)
     self.n_dyn = len(traced.movers)
+    # planes of the trace: the things, plus - a scenery of several variants - which one shows
+    self._n_planes = self.n_dyn + (1 if self.spec.n_variants > 1 else 0)
     self.uses_table = True
     self.any_reward = bool(self.spec.any_reward)
     self.has_perf = bool(self.spec.has_perf)
@@ -66,7 +68,7 @@ class WideGame(fused.FusedGame):
           'campx_wide_tables_build')
     # The launches read the spec's plain fields only; the blob they get carries no pointers
     # to the host arrays (which stay alive in self._arrays anyway).
-    for name in ('state_cells', 'next_state', 'reward', 'done', 'perf'):
+    for name in ('state_cells', 'next_state', 'reward', 'done', 'perf', 'variant_top_layer', 'state_variant'):
       setattr(self.spec, name, None)
     self._spec_host = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
                                        dtype=torch.uint8)
@@ -95,7 +97,7 @@ class WideGame(fused.FusedGame):
     """int16 [K, B] (one frame) or [K, T, B] trace buffer, rows padded like the other streams."""
     B = self.batch
     pitch = (B + 15) // 16 * 16 if fused.PAD_ROWS else B
-    shape = (self.n_dyn, pitch) if T is None else (self.n_dyn, T, pitch)
+    shape = (self._n_planes, pitch) if T is None else (self._n_planes, T, pitch)
     return torch.empty(shape, dtype=torch.int16, device=self.device)[..., :B]
 
   # --------------------------------------------------------------------- API

@@ -547,6 +547,7 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
 #define CAMPX_WIDE_MAX_CELLS 1024        /* rows * cols; rows, cols <= 127 */
 #define CAMPX_WIDE_MAX_STATES (1 << 24)
 #define CAMPX_WIDE_MAX_DYN 8             /* things that move / come and go */
+#define CAMPX_WIDE_MAX_VARIANTS 64       /* pictures of a scenery that changes */
 
 typedef struct CampxWideSpec {
   uint32_t magic, version;
@@ -558,7 +559,17 @@ typedef struct CampxWideSpec {
   int32_t has_perf;                /* `perf` below means something */
   int32_t any_dcode;               /* 1: some entry of `done` carries a discount code (0: the
                                       update kernel need not look the discount up) */
-  int32_t reserved0[2];
+  int32_t n_variants;              /* V: pictures of the SCENERY the game shows (0 or 1: one; up to
+                                      CAMPX_WIDE_MAX_VARIANTS).  A Backdrop.update() that repaints
+                                      the backdrop (campx/things.py:103-148) over many cells - day
+                                      and night over a whole floor - makes the scenery a function of
+                                      the state: the render kernel then lays, per environment and
+                                      frame, the pre-rotated row of the state's variant, which the
+                                      update pass hands it as one more (never painted) plane of the
+                                      trace.  With V > 1: n_dyn <= CAMPX_WIDE_MAX_DYN - 1, the trace
+                                      holds n_dyn + 1 planes, and `variant_top_layer` /
+                                      `state_variant` below are given. */
+  int32_t reserved0;
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_WIDE_MAX_DYN];   /* layer thing d paints */
   float discount_list[16];                 /* as CampxSpec.discount_list */
@@ -573,6 +584,9 @@ typedef struct CampxWideSpec {
   const uint8_t* done;             /* [S][5]: as CampxTransition.done (bit 0 terminated, bits
                                       4-7 discount code) */
   const int8_t* perf;              /* [S][5] hidden performance (the value), or NULL */
+  const uint8_t* variant_top_layer; /* [V][rows*cols]: the front-most scenery layer per cell in
+                                      variant v (row 0 = static_top_layer); NULL when V <= 1 */
+  const uint16_t* state_variant;   /* [S]: the variant the scenery shows in state s; NULL when V <= 1 */
 } CampxWideSpec;
 
 int32_t campx_wide_spec_size(void);

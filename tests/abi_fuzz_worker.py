@@ -193,6 +193,11 @@ def wide_invariants(s, arrays):
   HW = rows * cols
   assert 1 <= rows <= 127 and 1 <= cols <= 127 and 16 <= HW <= s['static_top_layer'].size
   assert 1 <= L <= 16 and 1 <= K <= s['dyn_layer'].size and S >= 1
+  V = int(s['n_variants'])
+  assert 0 <= V <= 64 and (V <= 1 or K <= s['dyn_layer'].size - 1)
+  if V > 1 and 'variant_top_layer' in arrays:
+    assert (arrays['variant_top_layer'] < L).all() and (arrays['state_variant'] < V).all()
+    assert (arrays['variant_top_layer'][0][:HW] == s['static_top_layer'][:HW]).all()
   assert ((s['dyn_layer'][:K] >= 0) & (s['dyn_layer'][:K] < L)).all()
   assert (s['static_top_layer'][:HW] < L).all()
   cells = arrays['state_cells']
@@ -212,7 +217,7 @@ def fuzz_wide(lib, dtype, cases, n, rng):
   lib.campx_wide_tables_bytes.argtypes = [vp]
   lib.campx_wide_tables_build.restype = ctypes.c_int32
   lib.campx_wide_tables_build.argtypes = [vp, vp, vp]
-  pointers = ('state_cells', 'next_state', 'reward', 'done', 'perf')
+  pointers = ('state_cells', 'next_state', 'reward', 'done', 'perf', 'variant_top_layer', 'state_variant')
   # (the host pointers are the harness's; n_states and n_dyn size the caller's own arrays - a
   # caller that lies about them is beyond what a validator can see)
   frozen = [_span(dtype, name) for name in pointers + ('n_states', 'n_dyn')]
@@ -223,9 +228,13 @@ def fuzz_wide(lib, dtype, cases, n, rng):
     blob = np.array(blob0, dtype=np.uint8, copy=True)
     arrays = {k: np.array(v, copy=True) for k, v in arrays0.items() if v is not None}
     if rng.rand() < 0.5:
-      _mutate(rng, blob, hot, frozen)
+      # (a game whose scenery has variants: their number and the board's size also size the
+      # caller's [V][rows * cols] array)
+      sizes = [_span(dtype, name) for name in ('n_variants', 'rows', 'cols')] if 'variant_top_layer' in arrays else []
+      _mutate(rng, blob, hot, frozen + sizes)
     else:                                        # ... or the tables the pointers point at
-      name = ('state_cells', 'next_state', 'done')[int(rng.randint(3))]
+      names = ['state_cells', 'next_state', 'done'] + [n_ for n_ in ('variant_top_layer', 'state_variant') if n_ in arrays]
+      name = names[int(rng.randint(len(names)))]
       _mutate(rng, arrays[name].view(np.uint8).reshape(-1), [])
     s = blob.view(dtype)[0]
     for name in pointers:
@@ -244,7 +253,11 @@ def fuzz_wide(lib, dtype, cases, n, rng):
       # copies it to the "device" - here a host buffer and no GPU, so the copy is what fails
       # (CAMPX_ELAUNCH), after every index has been used
       blob_out = np.empty(need, np.uint8)
-      assert lib.campx_wide_tables_build(ptr, blob_out.ctypes.data, None) in (-3, 0)
+      rc = lib.campx_wide_tables_build(ptr, blob_out.ctypes.data, None)
+      missing = (int(s['n_variants']) > 1 and 'variant_top_layer' not in arrays) or \
+          (int(s['has_perf']) and 'perf' not in arrays)
+      # (a scenery of several variants / a hidden performance, and no array given: refused)
+      assert (rc == -1) if missing else (rc in (-3, 0)), (rc, missing)
   return accepted
 
 

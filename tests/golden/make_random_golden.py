@@ -241,14 +241,14 @@ def quests():
 def pickups():
   """tests/golden/random_pickups.npz: tests/random_pickups.py's games - drapes of several cells
   that come and go and a Backdrop that changes (tests/traced_games.py Coins / ReturningCoins /
-  ThinIce / Lamps, which in this process
+  ThinIce / Lamps / Tide / Seasons, which in this process
   imports the REFERENCE's campx) - on the reference's engine; an environment whose episode ended
   gets a fresh game before its next action."""
   import random_pickups
   import traced_games
   assert traced_games.things is mg.ref.things
   T, N = 120, 6
-  out, ends, taken, back, broke, flips = {}, 0, 0, 0, 0, 0
+  out, ends, taken, back, broke, flips, turns = {}, 0, 0, 0, 0, 0, 0
   for k, d in enumerate(random_pickups.definitions()):
     acts = mg.random_actions(9700 + k, T, N)
     runs = np.random.RandomState(9800 + k)
@@ -264,10 +264,12 @@ def pickups():
     out['k{}_art'.format(k)] = np.array([[ord(c) for c in row] for row in d['art']], np.uint8)
     out['k{}_meta'.format(k)] = np.array(json.dumps(dict(kind=d['kind']), sort_keys=True))
     ends += int(golden['done'].sum())
-    ch = {'ice': ord('~'), 'lamps': ord('*')}.get(d['kind'], ord('o'))
+    ch = {'ice': ord('~'), 'lamps': ord('*'), 'tide': ord('.'), 'seasons': ord('.')}.get(d['kind'], ord('o'))
     cells = (golden['board'] == ch).sum(axis=(2, 3)).astype(np.int64)        # [T + 1, N]
     if d['kind'] == 'lamps':
       flips += int((np.diff(cells, axis=0) != 0).sum())
+    if d['kind'] in ('tide', 'seasons'):               # (a whole floor turns; an episode's end turns it back)
+      turns += int((np.abs(np.diff(cells, axis=0)) > 3).sum())
     gone = int((np.diff(cells, axis=0) < 0).sum())
     taken += gone if d['kind'] in ('coins', 'returning') else 0
     broke += gone if d['kind'] == 'ice' else 0
@@ -275,12 +277,13 @@ def pickups():
     print('pickup {:2d} {:9s} {}x{} return[mean] {:.2f} done {} cells left at the end {}'.format(
         k, d['kind'], len(d['art']), len(d['art'][0]), float(np.nansum(golden['reward'], 0).mean()),
         int(golden['done'].sum()), cells[-1].tolist()))
-  assert ends >= 4 and taken >= 40 and back >= 4 and broke >= 15 and flips >= 20, (ends, taken, back, broke, flips)
+  assert ends >= 4 and taken >= 40 and back >= 4 and broke >= 15 and flips >= 20 and turns >= 15, (
+      ends, taken, back, broke, flips, turns)
   path = os.path.join(HERE, 'random_pickups.npz')
   np.savez_compressed(path, **out)
   print('{} games, {} episode ends, {} coins taken, {} times they came back, {} tiles of ice broke, '
-        '{} lamps flipped -> {} KiB'.format(random_pickups.N_GAMES, ends, taken, back, broke, flips,
-                                             os.path.getsize(path) // 1024))
+        '{} lamps flipped, {} times a whole floor turned -> {} KiB'.format(
+            random_pickups.N_GAMES, ends, taken, back, broke, flips, turns, os.path.getsize(path) // 1024))
 
 
 if __name__ == '__main__':

@@ -3,7 +3,9 @@ coins taken one by one, coins that all come back when the last is gone, ice that
 the walker - tests/traced_games.py's `Coins`, `ReturningCoins`, `ThinIce` with its `Forager` - on
 random boards, two to seven such cells a game, some with an exit that ends the episode; and
 (`lamps`) a BACKDROP that changes: `Lamps`, a `Backdrop.update()` that flips floor lamps between
-':' and '*' as the walker steps on them (campx/things.py:103-148).  The
+':' and '*' as the walker steps on them (campx/things.py:103-148); and (`tide`, `seasons`) one that
+changes ALL OVER - `Tide` / `Seasons`: a switch turns the whole floor, two or three pictures of
+dozens of cells, which the tabulator tracks as VARIANTS of the scenery.  The
 reference's `Drape` sets no one-cell limit (campx/things.py:161-262); until round 6 the batched
 tiers did, and these games ran on the generic tier only.  Now the tabulator tracks one thing per
 cell such a drape ever covers, and the state-table kernels run them - against the REFERENCE's
@@ -14,7 +16,7 @@ import numpy as np
 
 import traced_games as tg
 
-N_GAMES = 12
+N_GAMES = 15
 SEED = 61020261
 
 
@@ -44,6 +46,10 @@ def _one(rng, kind, n_cells):
   if kind == 'lamps':
     _place(grid, free, ':', n_cells - 1)
     _place(grid, free, '*', 1)                   # (one is on from the start: both characters in the palette)
+  elif kind in ('tide', 'seasons'):
+    _place(grid, free, 's', n_cells)             # switches; and one floor cell of every other picture's
+    for ch in ('.' if kind == 'tide' else '.:'):  # character, so that the palette has them all
+      _place(grid, free, ch, 1)
   else:
     _place(grid, free, {'coins': 'o', 'returning': 'o', 'ice': '~'}[kind], n_cells)
   if kind != 'returning' and rng.rand() < 0.6:
@@ -54,7 +60,8 @@ def _one(rng, kind, n_cells):
 def definitions():
   rng = np.random.RandomState(SEED)
   plan = [('coins', 2), ('returning', 2), ('ice', 4), ('coins', 7), ('returning', 3), ('ice', 6),
-          ('coins', 4), ('returning', 2), ('ice', 3), ('lamps', 2), ('lamps', 4), ('lamps', 3)]
+          ('coins', 4), ('returning', 2), ('ice', 3), ('lamps', 2), ('lamps', 4), ('lamps', 3),
+          ('tide', 2), ('seasons', 1), ('tide', 3)]
   return [_one(rng, kind, n) for kind, n in plan]
 
 
@@ -67,6 +74,11 @@ def builder(d):
     drapes = {'A': tg.Forager, '#': things.FixedDrape}
     if has_exit:
       drapes['E'] = things.FixedDrape
+    if d['kind'] in ('tide', 'seasons'):
+      drapes['s'] = things.FixedDrape
+      return to_game(art, what_lies_beneath=' ', drapes=drapes,
+                     backdrop=tg.Tide if d['kind'] == 'tide' else tg.Seasons,
+                     z_order='s' + 'E' * has_exit + 'A#', update_schedule='A#s' + 'E' * has_exit, **where)
     if d['kind'] == 'lamps':
       return to_game(art, what_lies_beneath=' ', drapes=drapes, backdrop=tg.Lamps,
                      z_order='E' * has_exit + 'A#', update_schedule='A#' + 'E' * has_exit, **where)

@@ -80,7 +80,7 @@ class TracedOracle(object):
 # back (three tracked things: the cell-indexed tables), thin ice with a hidden Plot entry, floor lamps
 import random_pickups  # noqa: E402
 from campx_amd import tabulate  # noqa: E402
-for _k in (1, 3, 5, 10):
+for _k in (1, 3, 5, 10, 13, 14):      # (13, 14: a scenery of three / two VARIANTS - a whole floor that turns)
   _d = random_pickups.definitions()[_k]
   GAMES['pickup%d_%s' % (_k, _d['kind'])] = (random_pickups.builder(_d), {}, 5, 'traced')
 

@@ -58,8 +58,10 @@ def _cases():
   specs.append(_blob(rule))
   shapes = [_blob(gamespec.lower_shapes(gamespec.describe(SHAPE_GAMES[name]()))) for name in sorted(SHAPE_GAMES)]
   wides = []
-  for name in sorted(WIDE_GAMES):
-    spec, arrays = tabulate.to_wide_spec(tabulate.trace(WIDE_GAMES[name]()))
+  import random_pickups
+  tide = random_pickups.builder(random_pickups.definitions()[13])     # a scenery of three variants
+  for build_ in [WIDE_GAMES[name] for name in sorted(WIDE_GAMES)] + [tide]:
+    spec, arrays = tabulate.to_wide_spec(tabulate.trace(build_()))
     wides.append((_blob(spec), {k: (None if k == 'perf' and not spec.has_perf else np.array(v))
                                 for k, v in arrays.items()}))
   # host-tabulated games of two and three movers: the arrays campx_pair_table_pack() takes

@@ -9,7 +9,10 @@ refuse that PyColab games do.  The tabulator now tracks one thing per cell the d
 hidden Plot entry on top (the ice).  And the second thing the verdict named: a `Backdrop.update()`
 that changes the scenery (`Lamps`, campx/things.py:103-148) - every (cell, character) the
 backdrop ever shows beyond its first picture is a piece painted behind every thing
-(`TracedGame.in_backdrop`); three games of it.
+(`TracedGame.in_backdrop`), three games of it - and when its pictures differ in more cells than
+there are tracked things to spare (a switch turns the WHOLE floor: `Tide`, `Seasons`), the pictures
+become variants of the scenery that the state names (`TracedGame.variants`,
+`CampxWideSpec.n_variants`: the render kernel lays each environment's own variant); three games.
 
 Per game: (a) the generator still makes the fixture's game; (b) this repo's generic tier gives
 the reference engine's frames; (c) so does the table tabulated from the classes, walked on the
@@ -56,7 +59,7 @@ def _same(a, b):
 
 
 def test_the_generator_still_makes_the_games_of_the_fixture():
-  assert len(DEFS) == random_pickups.N_GAMES == 12
+  assert len(DEFS) == random_pickups.N_GAMES == 15
   for k, d in enumerate(DEFS):
     gold = _gold(k)
     assert [''.join(chr(c) for c in row) for row in gold['art']] == d['art'], k
@@ -70,6 +73,23 @@ def test_a_drape_of_several_cells_becomes_one_tracked_thing_per_cell():
     W = len(d['art'][0])
     where = lambda ch: [r * W + c for r, row in enumerate(d['art']) for c, x in enumerate(row) if x == ch]
     assert traced.piece_cell[0] is None and traced.in_backdrop[0] is False
+    if d['kind'] in ('tide', 'seasons'):
+      # a Backdrop that changes all over: its pictures are VARIANTS of the scenery, named by the state -
+      # one tracked value, however many cells differ (here every floor cell: 9 to 25 of them)
+      assert traced.movers == ['A'] and traced.in_backdrop == [False], (k, traced.movers)
+      assert len(traced.variants) == (2 if d['kind'] == 'tide' else 3)
+      assert set(traced.st_variant.tolist()) == set(range(len(traced.variants)))
+      differing = int((traced.variants[0] != traced.variants[1]).sum())
+      assert differing > 8 and traced.dense_reason.startswith('the Backdrop changes')
+      spec, arrays = tabulate.to_wide_spec(traced)
+      assert spec.n_variants == len(traced.variants) and arrays['variant_top_layer'].shape[0] == spec.n_variants
+      from campx_amd import _hip
+      import ctypes
+      assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
+      arrays['state_variant'][3] = spec.n_variants          # a variant that is not there
+      assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
+      pieces.append((differing, False))
+      continue
     if d['kind'] == 'lamps':
       # a Backdrop that changes: one piece per (cell, character) it shows beyond its first picture -
       # a lamp that starts off can come on ('*' there), the one that starts on can go off (':')
@@ -86,7 +106,7 @@ def test_a_drape_of_several_cells_becomes_one_tracked_thing_per_cell():
     dense = n <= 3 and d['kind'] != 'ice' and (len(d['art']) * W) ** (n + 1) * 5 <= tabulate.DENSE_MAX_ENTRIES
     assert (traced.dense_reason is None) == dense, (k, traced.dense_reason)
     pieces.append((n, dense))
-  assert max(pieces)[0] == 7 and min(pieces)[0] == 2 and sum(d for _, d in pieces) >= 3      # both tiers
+  assert min(pieces)[0] == 2 and sum(d for _, d in pieces) >= 3      # both tiers
   # ... and past what the kernels track the game is refused, by name
   import traced_games as tg
   art = ['##########', '#Aooooooo#', '#o       #', '##########']

@@ -655,3 +655,29 @@ class Lamps(things.Backdrop):
         lit -= 1
     if lit:
       the_plot.add_reward(0.25 * lit)
+
+
+class Tide(things.Backdrop):
+  """A backdrop that changes ALL OVER: each time the walker has just stepped onto a switch tile
+  ('s', a FixedDrape) the whole floor turns - every ' ' becomes the next character of `cycle` and so
+  on round (two characters: day and night; three: seasons).  Dozens of cells, two or three
+  pictures.  Every frame on a floor that is not the first picture pays 0.5."""
+
+  cycle = ' .'
+
+  def update(self, actions, board, layers, things_, the_plot):
+    if actions is None:
+      return
+    here = things_['A'].curtain
+    before = the_plot.get('tide_walker')
+    the_plot['tide_walker'] = here.clone()
+    if before is not None and not bool((before == here).all()) and int((here * things_['s'].curtain).sum()):
+      old = self.curtain.clone()
+      for i, ch in enumerate(self.cycle):
+        self.curtain[old == ord(ch)] = ord(self.cycle[(i + 1) % len(self.cycle)])
+    if int((self.curtain == ord(self.cycle[0])).sum()) < int((self.curtain == ord(self.cycle[1])).sum()):
+      the_plot.add_reward(0.5)
+
+
+class Seasons(Tide):
+  cycle = ' .:'
