@@ -174,6 +174,8 @@ def enumerate_rule_game(engine, device, max_states=None):
   bits = shows_of.cpu().numpy()
   game.st_shows = np.stack([(bits >> k) & 1 for k in range(K)], axis=1).astype(np.uint8)
   game.st_mode = np.zeros(S, np.int32)
+  game.st_variant = np.zeros(S, np.uint16)
+  game.variants = [game.backdrop]
   game.st_next = nxt_index.cpu().numpy()
   game.st_reward = reward.cpu().numpy()
   game.st_done = done.cpu().numpy()

@@ -501,6 +501,7 @@ def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, rewar
   game.movers = movers
   game.piece_cell = [None] * K          # (drapes of several cells go to the one-frame-per-play walker)
   game.in_backdrop = [False] * K
+  game.variants = [game.backdrop]       # (a Backdrop with an update() of its own goes to the other walker too)
   game.absent_cells = absent_cells
   game.statics = [(ch, start_np[ch].copy()) for ch in schedule if ch not in movers]
   if len(game.statics) > gamespec.MAX_STATIC:
@@ -567,6 +568,7 @@ def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, rewar
   game.st_board = boards
   game.st_shows = (present & (boards[rows[:, None], st_cells] == codes[None, :])).astype(np.uint8)
   game.st_mode = np.zeros(S, np.int32)
+  game.st_variant = np.zeros(S, np.uint16)
   game.st_next = nxt_safe.astype(np.int32)
   game.st_reached = np.broadcast_to(walked[:, None], (S, N_ACTIONS)).copy()
   game.st_reward = np.where(game.st_reached, reward, np.float32(np.nan)).astype(np.float32)
