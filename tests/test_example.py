@@ -89,3 +89,38 @@ def test_deferred_rollouts_example_runs():
   got = ex.run(batch=1024, frames=40, episodes=5)
   assert got['seen'] == [40 * 1024 * 25] * 5
   assert -3.0 * 40 <= got['mean_return'] <= 2.0 * 40
+
+
+def test_coins_example_runs_on_the_generic_tier_and_tabulates():
+  """examples/coins_batched.py: ordinary CampX classes - a drape of three coins, a Backdrop that
+  repaints the whole floor - on one environment without a GPU, and through the tabulator: the coins
+  one tracked thing per cell, the floors two variants of the scenery."""
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import torch
+  import coins_batched as ex
+  from campx_amd import tabulate
+  game = ex.make_game()
+  obs, reward, _ = game.its_showtime()
+  assert reward is None
+  row = lambda r: ''.join(chr(int(c)) for c in obs.board[r])
+  assert row(1) == '#A  o   .#' and row(3) == '#o  s # o#'
+  total = 0.0
+  for a in [1, 1, 1, 3, 3, 0, 0]:          # to the coin, down onto the switch, away: the floor has turned
+    obs, reward, _ = game.play(torch.eye(5)[a])
+    total += float(reward)
+  assert row(1) == '#.......' + ' #' and row(3)[4] == 's' and row(3)[2] == 'A'
+  assert total == 7 * -0.125 + 1.0 + 2 * 0.25          # a coin, two frames of night
+  traced = tabulate.trace(ex.make_game())
+  assert traced.movers == ['A', 'o', 'o', 'o'] and traced.piece_cell[1:] == [14, 31, 38]
+  assert len(traced.variants) == 2 and int((traced.variants[0] != traced.variants[1]).sum()) > 20
+
+
+@pytest.mark.gpu
+def test_coins_example_runs_batched():
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  import coins_batched as ex
+  from campx_amd import wide
+  got = ex.run(batch=2048, frames=60, launches=2)
+  f = got['game'].fused
+  assert isinstance(f, wide.WideGame) and got['variants'] == 2 and got['movers'] == ['A', 'o', 'o', 'o']
+  assert f.spec.n_variants == 2 and got['rate'] > 1e6 and got['out']['obs'].shape == (60, 2048, 7, 6, 10)
