@@ -489,9 +489,19 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   if on_gpu:
     ev1.record()
   t_loop = time.perf_counter()
-  t_launches = t_loop
+  t_launches = t_open = t_loop
   if on_gpu:
-    ev1.synchronize()                 # the last launch has finished: was every gather done by then?
+    # The last launch has finished: was every gather done by then?  The host SPINS on the two
+    # events (hipEventQuery) instead of sleeping in a synchronise: one driver-style run in twenty of
+    # round 6 read 13.0 ms here for launches the device's clock put at 3.68 ms (`ms_per_step` 3.7 x
+    # `kernel_ms`; round 4's driver line, 1.219 x, was of this kind) - either the sleeping thread
+    # was woken late, which a spin does not suffer, or the device STARTED late, which the time the
+    # opening event is seen to have passed (`window_open_seen_us`, normally within the loop) tells.
+    while not ev0.query():
+      pass
+    t_open = time.perf_counter()
+    while not ev1.query():
+      pass
     t_launches = time.perf_counter()
   if log is not None:
     log.poll()
@@ -518,7 +528,7 @@ def measure_rollout(game_name, B, T, steps, warmup, device, rank, dist, gather_e
   # (relative to the event that opens the window on the launch stream)
   if log is not None:
     log.poll()                        # (whatever was not seen complete before: stamped now, at the end)
-  window_us = {'loop': (t_loop - t0) * 1e6, 'launches': (t_launches - t_loop) * 1e6,
+  window_us = {'loop': (t_loop - t0) * 1e6, 'open_seen': (t_open - t0) * 1e6, 'launches': (t_launches - t_loop) * 1e6,
                'log_wait': (t_wait - t_launches) * 1e6, 'synchronize': (t_sync - t_wait) * 1e6,
                'total': elapsed * 1e6}
   gathers = None
@@ -821,6 +831,10 @@ def run_rank(args):
             # wait for the last launch to finish, for the log's last gather, the synchronise that
             # closes the window; `window_launches_done_us`: the launches on the DEVICE's clock
             'window_loop_us': m['window_us']['loop'],
+            # (host time at which the event that OPENS the window on the launch stream was seen to
+            # have passed, looked for once the loop is done: about `window_loop_us` unless the
+            # device started the window's first launch late)
+            'window_open_seen_us': m['window_us']['open_seen'],
             'window_launches_us': m['window_us']['launches'],
             'window_log_wait_us': m['window_us']['log_wait'],
             'window_synchronize_us': m['window_us']['synchronize'],
