@@ -34,16 +34,26 @@ struct RenderParams {
 
 // kVar: bytes [0, n) of a 16-byte scenery chunk come from one environment's row, bytes [n, 16)
 // from the next environment's, whose scenery is another variant (1 <= n <= 15).
+__device__ __forceinline__ u32x4 variant_chunk(const int8_t* here, int64_t stride, int v) {
+  return *reinterpret_cast<const u32x4*>(here + (int64_t)v * stride);
+}
+__device__ __forceinline__ u32x4 pick_variant(u32x4 c0, u32x4 c1, u32x4 c2, u32x4 c3, uint32_t v) {
+  u32x4 x = c0;
+  x = v == 1u ? c1 : x;
+  x = v == 2u ? c2 : x;
+  x = v == 3u ? c3 : x;
+  return x;
+}
+__device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b, int left) {
+  // `left`: bytes of this dword that are still the first row's (<= 0: none, >= 4: all)
+  const uint32_t mask = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+  return (a & mask) | (b & ~mask);
+}
+// (component by component: arrays indexed in a loop went to scratch memory - 80 bytes a lane,
+// and the kernel to 1.3 TB/s)
 __device__ __forceinline__ u32x4 merge_rows(u32x4 a, u32x4 b, int n) {
-  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
-  uint32_t o[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int left = n - 4 * w;          // bytes of this dword that are still the first row's
-    const uint32_t mask = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
-    o[w] = (aw[w] & mask) | (bw[w] & ~mask);
-  }
-  return u32x4{o[0], o[1], o[2], o[3]};
+  return u32x4{merge_word(a.x, b.x, n), merge_word(a.y, b.y, n - 4), merge_word(a.z, b.z, n - 8),
+               merge_word(a.w, b.w, n - 12)};
 }
 
 // The trace entry of one moving thing in one frame.  One byte in the one-cell tier (cell |
@@ -216,24 +226,24 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       // night, seasons), and picked when the entries arrive; a variant past the fourth costs the
       // second trip.
       const uint32_t e0 = vars[trace_row(r0)], e1 = vars[trace_row(r1)];
-      u32x4 cand[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int v = c < rp.n_variants ? c : rp.n_variants - 1;
-        cand[c] = *reinterpret_cast<const u32x4*>(rot + (int64_t)v * rp.rot_stride + at);
-      }
-      auto pick = [&](uint32_t v) {
-        u32x4 x = cand[0];
-        x = v == 1u ? cand[1] : x;
-        x = v == 2u ? cand[2] : x;
-        x = v == 3u ? cand[3] : x;
-        if (v >= 4u) x = *reinterpret_cast<const u32x4*>(rot + (int64_t)v * rp.rot_stride + at);
-        return x;
-      };
+      // (plain functions of values, no closures over the vectors: a first form with lambdas put
+      // 80 bytes a lane into scratch memory, and the kernel at 1.3 TB/s)
+      const int last_v = rp.n_variants - 1;
+      const int8_t* here = rot + at;
+      const u32x4 c0 = variant_chunk(here, rp.rot_stride, 0),
+                  c1 = variant_chunk(here, rp.rot_stride, 1 < last_v ? 1 : last_v),
+                  c2 = variant_chunk(here, rp.rot_stride, 2 < last_v ? 2 : last_v),
+                  c3 = variant_chunk(here, rp.rot_stride, 3 < last_v ? 3 : last_v);
       const uint32_t v0 = (uint32_t)Fmt::cell(e0), v1 = (uint32_t)Fmt::cell(e1);
-      scen[j] = pick(v0);
+      u32x4 mine = pick_variant(c0, c1, c2, c3, v0);
+      if (v0 >= 4u) mine = variant_chunk(here, rp.rot_stride, (int)v0);
       const int left = R - k;                          // bytes of the chunk inside row r0
-      if (left < 16 && v1 != v0) scen[j] = merge_rows(scen[j], pick(v1), left);
+      if (left < 16 && v1 != v0) {
+        u32x4 next = pick_variant(c0, c1, c2, c3, v1);
+        if (v1 >= 4u) next = variant_chunk(here, rp.rot_stride, (int)v1);
+        mine = merge_rows(mine, next, left);
+      }
+      scen[j] = mine;
     } else {
       scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
     }
