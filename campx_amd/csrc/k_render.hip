@@ -37,13 +37,6 @@ struct RenderParams {
 __device__ __forceinline__ u32x4 variant_chunk(const int8_t* here, int64_t stride, int v) {
   return *reinterpret_cast<const u32x4*>(here + (int64_t)v * stride);
 }
-__device__ __forceinline__ u32x4 pick_variant(u32x4 c0, u32x4 c1, u32x4 c2, u32x4 c3, uint32_t v) {
-  u32x4 x = c0;
-  x = v == 1u ? c1 : x;
-  x = v == 2u ? c2 : x;
-  x = v == 3u ? c3 : x;
-  return x;
-}
 __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b, int left) {
   // `left`: bytes of this dword that are still the first row's (<= 0: none, >= 4: all)
   const uint32_t mask = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
@@ -220,27 +213,23 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       const typename Fmt::Entry* vars = frame_trace + (int64_t)rp.n_dyn * n_rows;
       const int at = (k & 15) * pitch + (k & ~15);
       // Which variant is one trip to the trace; the scenery bytes are another, and a one-shot wave
-      // has nothing to do in between: a first version that chained the two ran 30 % below the
-      // plain kernel (4.9 against 7.0 TB/s).  So the chunk is fetched from the first FOUR variants
-      // at once, with the variant entries (most sceneries have two or three pictures: day and
-      // night, seasons), and picked when the entries arrive; a variant past the fourth costs the
-      // second trip.
+      // has nothing to do in between: chained, the kernel runs 30 % below the plain one (4.9
+      // against 7.0 TB/s).  Fetching the chunk from the first FOUR variants at once, beside the
+      // variant entries, was worse (3.9-4.3: four times the loads of a kernel that stores as fast
+      // as L1 delivers); from the first TWO - day and night, the commonest scenery that changes -
+      // costs one extra load, and a variant past the second the second trip.  (n_variants >= 2.)
       const uint32_t e0 = vars[trace_row(r0)], e1 = vars[trace_row(r1)];
       // (plain functions of values, no closures over the vectors: a first form with lambdas put
       // 80 bytes a lane into scratch memory, and the kernel at 1.3 TB/s)
-      const int last_v = rp.n_variants - 1;
       const int8_t* here = rot + at;
-      const u32x4 c0 = variant_chunk(here, rp.rot_stride, 0),
-                  c1 = variant_chunk(here, rp.rot_stride, 1 < last_v ? 1 : last_v),
-                  c2 = variant_chunk(here, rp.rot_stride, 2 < last_v ? 2 : last_v),
-                  c3 = variant_chunk(here, rp.rot_stride, 3 < last_v ? 3 : last_v);
+      const u32x4 c0 = variant_chunk(here, rp.rot_stride, 0), c1 = variant_chunk(here, rp.rot_stride, 1);
       const uint32_t v0 = (uint32_t)Fmt::cell(e0), v1 = (uint32_t)Fmt::cell(e1);
-      u32x4 mine = pick_variant(c0, c1, c2, c3, v0);
-      if (v0 >= 4u) mine = variant_chunk(here, rp.rot_stride, (int)v0);
+      u32x4 mine = v0 == 1u ? c1 : c0;
+      if (v0 >= 2u) mine = variant_chunk(here, rp.rot_stride, (int)v0);
       const int left = R - k;                          // bytes of the chunk inside row r0
       if (left < 16 && v1 != v0) {
-        u32x4 next = pick_variant(c0, c1, c2, c3, v1);
-        if (v1 >= 4u) next = variant_chunk(here, rp.rot_stride, (int)v1);
+        u32x4 next = v1 == 1u ? c1 : c0;
+        if (v1 >= 2u) next = variant_chunk(here, rp.rot_stride, (int)v1);
         mine = merge_rows(mine, next, left);
       }
       scen[j] = mine;
