@@ -48,8 +48,19 @@ def main():
     drapes = {'A': tg.Forager, '#': tg.things.FixedDrape, 's': tg.things.FixedDrape, 'E': tg.things.FixedDrape}
     return tg.ascii_art_to_game(art, what_lies_beneath=' ', drapes=drapes, z_order='sEA#',
                                 update_schedule='A#sE', **where)
-  for name, build in (('plain backdrop', plain), ('tide: 2 variants', tide)):
-    ms, tbs, tier, planes = timed(build(batch=B, device='cuda'), B)
+  class Forced(object):          # the plain game through the STATE-table tier too: the same kernels but for kVar
+    def __init__(self, engine):
+      from campx_amd import tabulate, wide
+      traced = tabulate.trace(plain())
+      self.fused = wide.WideGame(engine, B, 'cuda', traced)
+
+    def its_showtime(self):
+      self.fused.showtime()
+
+  for name, game in (('plain backdrop', plain(batch=B, device='cuda')),
+                     ('plain, state table', Forced(plain())),
+                     ('tide: 2 variants', tide(batch=B, device='cuda'))):
+    ms, tbs, tier, planes = timed(game, B)
     print('%-18s B=%d  %.4f ms per 100-frame rollout  %.2f TB/s of observations  (%s, %s trace planes)' % (
         name, B, ms, tbs, tier, planes))
 
