@@ -124,6 +124,9 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
   using Fmt = TraceFormat<kWide>;
   __shared__ __attribute__((aligned(16))) int8_t lds[kRenderWaves * kWin * 1024];
   __shared__ uint16_t scen_off_all[kRenderWaves][kWide ? 2 : CAMPX_MAX_CELLS];
+  // kVar: the variant of every row the wave's windows overlap (+ the one after): rows of at least
+  // 16 bytes, so at most kWin * 64 + 2 of them
+  __shared__ uint16_t row_variant_all[kRenderWaves][kVar ? kWin * 64 + 4 : 2];
   // readfirstlane: the wave index is uniform, and saying so keeps everything derived
   // from it (window offsets, the divisions, base addresses) on the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -181,6 +184,20 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     ent[it] = (it == 0 || slots > kWave) ? frame_trace[(int64_t)d * n_rows + trace_row(row)] : 0u;
   }
 
+  if constexpr (kVar) {
+    // (one load per ROW instead of two per chunk and lane: the 2-byte gathers were what made a
+    // first form of this path 28 % slower than the plain kernel - it stores as fast as the
+    // texture path delivers, and every extra wave-wide load is felt)
+    uint16_t* row_variant = row_variant_all[wave];
+    const typename Fmt::Entry* vars = frame_trace + (int64_t)rp.n_dyn * n_rows;
+    const uint32_t top = (uint32_t)rp.B - 1u, limit = last_frame ? top : 2u * top + 1u;
+    for (uint32_t i = (uint32_t)lane; i <= last_row - first_row + 1u; i += kWave) {
+      uint32_t r = first_row + i;
+      r = r < limit ? r : limit;       // rows past this frame's last: the next frame's first, or none to store
+      row_variant[i] = (uint16_t)Fmt::cell(vars[trace_row(r)]);
+    }
+  }
+
   // ---- scenery: issue all loads, then park them in LDS
   u32x4 scen[kWin];
 #pragma unroll
@@ -201,16 +218,11 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       // launch's last frame, whose chunks past the end are never stored; a chunk that starts
       // BEFORE the frame (wrapped offset) only ever has its bytes of row 0 stored by this block
       const bool before = off >= 0xfffffff0u;
-      uint32_t r0 = before ? 0u : row, r1 = before ? 0u : row + 1u;
-      const uint32_t top = (uint32_t)rp.B - 1u;
-      if (last_frame) {
-        r0 = r0 < top ? r0 : top;
-        r1 = r1 < top ? r1 : top;
-      } else {
-        r0 = r0 < 2u * top + 1u ? r0 : 2u * top + 1u;
-        r1 = r1 < 2u * top + 1u ? r1 : 2u * top + 1u;
-      }
-      const typename Fmt::Entry* vars = frame_trace + (int64_t)rp.n_dyn * n_rows;
+      // (index into the wave's staged variants: rows from first_row on, clamped to what was staged)
+      const uint32_t n_staged = last_row - first_row + 2u;
+      uint32_t i0 = before ? 0u : row - first_row, i1 = before ? 0u : row + 1u - first_row;
+      i0 = i0 < n_staged ? i0 : n_staged - 1u;
+      i1 = i1 < n_staged ? i1 : n_staged - 1u;
       const int at = (k & 15) * pitch + (k & ~15);
       // Which variant is one trip to the trace; the scenery bytes are another, and a one-shot wave
       // has nothing to do in between: chained, the kernel runs 30 % below the plain one (4.9
@@ -218,12 +230,11 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       // variant entries, was worse (3.9-4.3: four times the loads of a kernel that stores as fast
       // as L1 delivers); from the first TWO - day and night, the commonest scenery that changes -
       // costs one extra load, and a variant past the second the second trip.  (n_variants >= 2.)
-      const uint32_t e0 = vars[trace_row(r0)], e1 = vars[trace_row(r1)];
       // (plain functions of values, no closures over the vectors: a first form with lambdas put
       // 80 bytes a lane into scratch memory, and the kernel at 1.3 TB/s)
       const int8_t* here = rot + at;
       const u32x4 c0 = variant_chunk(here, rp.rot_stride, 0), c1 = variant_chunk(here, rp.rot_stride, 1);
-      const uint32_t v0 = (uint32_t)Fmt::cell(e0), v1 = (uint32_t)Fmt::cell(e1);
+      const uint32_t v0 = row_variant_all[wave][i0], v1 = row_variant_all[wave][i1];
       u32x4 mine = v0 == 1u ? c1 : c0;
       if (v0 >= 2u) mine = variant_chunk(here, rp.rot_stride, (int)v0);
       const int left = R - k;                          // bytes of the chunk inside row r0
