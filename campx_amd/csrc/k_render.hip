@@ -429,21 +429,34 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
     if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
   } while (0)
   if (src.wide && src.n_variants > 1) {
-    // a scenery of several variants: the run-time-K instantiation, whatever the number of things
-#define CAMPX_RENDER_VAR(BOARD, FMT, ODD)                                                          \
-  hipLaunchKernelGGL((render_kernel<8, BOARD, true, (FMT) ? kWin16 : kWin, FMT, ODD, true, true>), \
-                     grid, dim3(kRenderWaves * kWave), 0, stream, rp,                              \
+    // a scenery of several variants (the run-time-K instantiation measured 28 % below the plain
+    // kernel for a one-thing game - its patch loop divides by a count it only knows at run time -
+    // so here too the count is a template argument up to four things)
+#define CAMPX_RENDER_VAR5(KK, BOARD, FMT, ODD)                                                      \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, true, (FMT) ? kWin16 : kWin, FMT, ODD, true, true>), \
+                     grid, dim3(kRenderWaves * kWave), 0, stream, rp,                               \
                      static_cast<const uint16_t*>(trace), dst, n_rows)
-    if (is_board) {
-      if (odd) CAMPX_RENDER_VAR(true, 0, true); else CAMPX_RENDER_VAR(true, 0, false);
-    } else if (fmt == 1) {
-      if (odd) CAMPX_RENDER_VAR(false, 1, true); else CAMPX_RENDER_VAR(false, 1, false);
-    } else if (fmt == 2) {
-      if (odd) CAMPX_RENDER_VAR(false, 2, true); else CAMPX_RENDER_VAR(false, 2, false);
-    } else {
-      if (odd) CAMPX_RENDER_VAR(false, 0, true); else CAMPX_RENDER_VAR(false, 0, false);
+#define CAMPX_RENDER_VAR(KK)                                                                  \
+  do {                                                                                        \
+    if (is_board) {                                                                           \
+      if (odd) CAMPX_RENDER_VAR5(KK, true, 0, true); else CAMPX_RENDER_VAR5(KK, true, 0, false);   \
+    } else if (fmt == 1) {                                                                    \
+      if (odd) CAMPX_RENDER_VAR5(KK, false, 1, true); else CAMPX_RENDER_VAR5(KK, false, 1, false); \
+    } else if (fmt == 2) {                                                                    \
+      if (odd) CAMPX_RENDER_VAR5(KK, false, 2, true); else CAMPX_RENDER_VAR5(KK, false, 2, false); \
+    } else {                                                                                  \
+      if (odd) CAMPX_RENDER_VAR5(KK, false, 0, true); else CAMPX_RENDER_VAR5(KK, false, 0, false); \
+    }                                                                                         \
+  } while (0)
+    switch (src.n_dyn) {
+      case 1: CAMPX_RENDER_VAR(1); break;
+      case 2: CAMPX_RENDER_VAR(2); break;
+      case 3: CAMPX_RENDER_VAR(3); break;
+      case 4: CAMPX_RENDER_VAR(4); break;
+      default: CAMPX_RENDER_VAR(8); break;
     }
 #undef CAMPX_RENDER_VAR
+#undef CAMPX_RENDER_VAR5
   } else if (src.wide) {
 #define CAMPX_RENDER_WIDE(KK)                                             \
   do {                                                                    \
