@@ -224,14 +224,16 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       i0 = i0 < n_staged ? i0 : n_staged - 1u;
       i1 = i1 < n_staged ? i1 : n_staged - 1u;
       const int at = (k & 15) * pitch + (k & ~15);
-      // Which variant is one trip to the trace; the scenery bytes are another, and a one-shot wave
-      // has nothing to do in between: chained, the kernel runs 30 % below the plain one (4.9
-      // against 7.0 TB/s).  Fetching the chunk from the first FOUR variants at once, beside the
-      // variant entries, was worse (3.9-4.3: four times the loads of a kernel that stores as fast
-      // as L1 delivers); from the first TWO - day and night, the commonest scenery that changes -
-      // costs one extra load, and a variant past the second the second trip.  (n_variants >= 2.)
-      // (plain functions of values, no closures over the vectors: a first form with lambdas put
-      // 80 bytes a lane into scratch memory, and the kernel at 1.3 TB/s)
+      // What was measured on the way (tools/bench_variants.py: a 6x8 board whose whole floor turns,
+      // two pictures, B = 262 144 / 65 536; the same game with a plain Backdrop through these kernels:
+      // 6.6 / 6.5 TB/s): the variant entry loaded per chunk and the scenery chunk behind it, 4.9 /
+      // 5.0; the chunk fetched from the first FOUR variants beside the entry, 3.9 / 4.3 (four times
+      // the loads of a kernel that stores as fast as the texture path delivers); from the first TWO,
+      // 4.7 / 4.8; the entries staged once per row in LDS (above), the same; the thing count a
+      // template argument instead of the run-time-K instantiation, 5.0 / 5.4 - what ships.  Two
+      // candidates: day and night, the commonest scenery that changes, never pays a dependent
+      // load; a variant past the second does.  (Plain functions of values throughout: a form with
+      // closures over the vectors put 80 bytes a lane into scratch memory - 1.3 TB/s.)
       const int8_t* here = rot + at;
       const u32x4 c0 = variant_chunk(here, rp.rot_stride, 0), c1 = variant_chunk(here, rp.rot_stride, 1);
       const uint32_t v0 = row_variant_all[wave][i0], v1 = row_variant_all[wave][i1];
