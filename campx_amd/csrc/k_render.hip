@@ -226,25 +226,20 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       const int at = (k & 15) * pitch + (k & ~15);
       // What was measured on the way (tools/bench_variants.py: a 6x8 board whose whole floor turns,
       // two pictures, B = 262 144 / 65 536; the same game with a plain Backdrop through these kernels:
-      // 6.6 / 6.5 TB/s): the variant entry loaded per chunk and the scenery chunk behind it, 4.9 /
-      // 5.0; the chunk fetched from the first FOUR variants beside the entry, 3.9 / 4.3 (four times
-      // the loads of a kernel that stores as fast as the texture path delivers); from the first TWO,
-      // 4.7 / 4.8; the entries staged once per row in LDS (above), the same; the thing count a
-      // template argument instead of the run-time-K instantiation, 5.0 / 5.4 - what ships.  Two
-      // candidates: day and night, the commonest scenery that changes, never pays a dependent
-      // load; a variant past the second does.  (Plain functions of values throughout: a form with
-      // closures over the vectors put 80 bytes a lane into scratch memory - 1.3 TB/s.)
+      // 6.6 / 6.5 TB/s; profiles/r06_variants.txt): the variant entry loaded per chunk and the
+      // scenery chunk behind it, 4.9 / 5.0; the chunk fetched from the first FOUR variants beside
+      // the entry, 3.9 / 4.3 (four times the loads of a kernel that stores as fast as the texture
+      // path delivers); from the first TWO, 4.7 / 4.8; the entries staged once per row in LDS
+      // (above), the same; the thing count a template argument instead of the run-time-K
+      // instantiation, 5.0 / 5.4; and with all that ONE load again, of the variant the staged entry
+      // names, 5.4 / 5.7 - what ships: the second trip costs less than a second candidate's bytes.
+      // (Plain functions of values throughout: a form with closures over the vectors put 80 bytes
+      // a lane into scratch memory - 1.3 TB/s.)
       const int8_t* here = rot + at;
-      const u32x4 c0 = variant_chunk(here, rp.rot_stride, 0), c1 = variant_chunk(here, rp.rot_stride, 1);
       const uint32_t v0 = row_variant_all[wave][i0], v1 = row_variant_all[wave][i1];
-      u32x4 mine = v0 == 1u ? c1 : c0;
-      if (v0 >= 2u) mine = variant_chunk(here, rp.rot_stride, (int)v0);
+      u32x4 mine = variant_chunk(here, rp.rot_stride, (int)v0);
       const int left = R - k;                          // bytes of the chunk inside row r0
-      if (left < 16 && v1 != v0) {
-        u32x4 next = v1 == 1u ? c1 : c0;
-        if (v1 >= 2u) next = variant_chunk(here, rp.rot_stride, (int)v1);
-        mine = merge_rows(mine, next, left);
-      }
+      if (left < 16 && v1 != v0) mine = merge_rows(mine, variant_chunk(here, rp.rot_stride, (int)v1), left);
       scen[j] = mine;
     } else {
       scen[j] = *reinterpret_cast<const u32x4*>(rot + (k & 15) * pitch + (k & ~15));
