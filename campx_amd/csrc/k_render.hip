@@ -30,6 +30,7 @@ struct RenderParams {
   const uint8_t* top_layer;   // device: scenery layer per cell (one-byte trace only)
   int64_t rot_stride;         // kVar: bytes from one variant's rotations to the next's
   int32_t n_variants;         // kVar: how many there are
+  uint32_t inv_p;             // run-time thing count (five to eight things): ceil(2^32 / patches per row)
 };
 
 // kVar: bytes [0, n) of a 16-byte scenery chunk come from one environment's row, bytes [n, 16)
@@ -155,6 +156,13 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
   // count from its arguments: its surplus planes of the trace do not exist
   constexpr bool kRuntimeK = K > CAMPX_MAX_DYN;
   const int P = kRuntimeK ? (kBoard ? rp.n_dyn : 2 * rp.n_dyn) : (kBoard ? K : 2 * K);
+  // slot -> (row, patch): a division by P.  By a count only known at run time it is a few dozen
+  // instructions three times over (the run-time-K instantiation measured 8 % below the templated
+  // ones): one multiply by ceil(2^32 / P), exact while slot * P < 2^32
+  auto row_of_slot = [&](int sidx) -> int {
+    if constexpr (kRuntimeK) return (int)__umulhi((uint32_t)sidx, rp.inv_p);
+    else return sidx / P;
+  };
   const typename Fmt::Entry* frame_trace = trace + (int64_t)blockIdx.y * rp.pitch;
   // (kOdd: a chunk that straddles two frames asks for "row B" = row 0 of the next frame)
   auto trace_row = [&](uint32_t row) -> int64_t {
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
 #pragma unroll
   for (int it = 0; it < kMaxIter; ++it) {
     const int sidx = lane + it * kWave;
-    const int r = sidx / P, p = sidx - r * P;
+    const int r = row_of_slot(sidx), p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
     uint32_t row = first_row + (uint32_t)r;
     row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     return v;
   };
   auto apply = [&](int sidx, uint32_t e) {
-    const int r = sidx / P, p = sidx - r * P;
+    const int r = row_of_slot(sidx), p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
     const int cell = Fmt::cell(e);
     int byte;   // offset inside the row
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
 #pragma unroll
   for (int it = 0; it < kMaxIter; ++it) apply(lane + it * kWave, ent[it]);
   for (int sidx = lane + kMaxIter * kWave; sidx < slots; sidx += kWave) {   // tiny rows only
-    const int r = sidx / P, p = sidx - r * P;
+    const int r = row_of_slot(sidx), p = sidx - r * P;
     const int d = kBoard ? p : (p >> 1);
     apply(sidx, frame_trace[(int64_t)d * n_rows + trace_row(first_row + (uint32_t)r)]);
   }
@@ -383,6 +391,10 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
   rp.rot = is_board ? src.rot_board : src.rot_obs;
   rp.rot_stride = is_board ? src.rot_board_stride : src.rot_obs_stride;
   rp.n_variants = src.n_variants > 1 ? src.n_variants : 1;
+  {
+    const uint32_t patches = (uint32_t)(is_board ? src.n_dyn : 2 * src.n_dyn);
+    rp.inv_p = (uint32_t)(((1ull << 32) + patches - 1) / (patches ? patches : 1));
+  }
   rp.top_layer = src.top_layer;
   for (int d = 0; d < src.n_dyn; ++d) {
     rp.dyn_char[d] = src.layer_char[src.dyn_layer[d]];
