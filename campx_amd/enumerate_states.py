@@ -176,6 +176,7 @@ def enumerate_rule_game(engine, device, max_states=None):
   game.st_mode = np.zeros(S, np.int32)
   game.st_variant = np.zeros(S, np.uint16)
   game.variants = [game.backdrop]
+  game.variant_masks = [{}]
   game.st_next = nxt_index.cpu().numpy()
   game.st_reward = reward.cpu().numpy()
   game.st_done = done.cpu().numpy()

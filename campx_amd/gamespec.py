@@ -512,7 +512,7 @@ WIDE_MAX_CELLS = 1024
 
 WIDE_MAX_STATES = 1 << 24
 WIDE_MAX_DYN = 8
-WIDE_MAX_VARIANTS = 64      # pictures of a scenery that changes (CampxWideSpec.n_variants)
+WIDE_MAX_VARIANTS = 256     # pictures of a scenery that changes (CampxWideSpec.n_variants)
 
 
 class CampxWideRules(ctypes.Structure):

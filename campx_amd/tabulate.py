@@ -303,9 +303,10 @@ class TracedGame(object):
     in_backdrop: per mover, True for a piece of a Backdrop that changes (one per (cell,
       character) it shows other than at the start; they come after every other mover and are
       painted on the backdrop itself, behind every thing);
-    variants, st_variant: a Backdrop whose pictures differ in more cells than there are tracked
-      things to spare: the pictures themselves (uint8 [H, W] each, the first = `backdrop`) and,
-      per state, which one it shows (one picture, all zeros, for every other game);
+    variants, variant_masks, st_variant: the scenery in VARIANTS - the Backdrop's pictures (uint8
+      [H, W] each, the first = `backdrop`), beside each the curtains of the several-cell drapes
+      that are part of the scenery's pictures ({character: uint8 [H, W]}), and per state which
+      picture shows (one picture, all zeros, for a game whose scenery never changes);
     absent_cells: per mover, the tracked values that stand for "not on the board" (an empty
       curtain, an invisible sprite) - cell indices the thing never occupies; usually empty;
     mode_orders: the z-orders the game reaches (lists of characters back to front; the
@@ -356,6 +357,9 @@ class TracedGame(object):
     variants = getattr(self, 'variants', None)
     board = (variants[variant] if variants else self.backdrop).copy().reshape(-1)
     static = dict(self.statics)
+    masks = getattr(self, 'variant_masks', None)
+    if masks:
+      static.update(masks[variant])        # the several-cell drapes as this picture has them
     where = {}                 # character -> the cells its movers (pieces, for a many-cell drape) stand on
     in_backdrop = getattr(self, 'in_backdrop', None) or [False] * len(self.movers)
     for k, (ch, c) in enumerate(zip(self.movers, cells)):
@@ -1011,41 +1015,55 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     for c in np.flatnonzero(now != base_backdrop):
       backdrop_pieces.add((int(c), int(now[c])))
   n_thing_movers = len(split)
-  # ... unless its pictures differ in more (cell, character) pairs than there are tracked things
-  # to spare - day and night over a whole floor: two pictures, dozens of cells.  Then the scenery
-  # itself comes in VARIANTS: the state names which picture the backdrop shows, the state-table
-  # tier's render kernel lays that variant's row (CampxWideSpec.n_variants), and it costs one
-  # tracked value however many cells change.
-  variants, state_variant = [backdrop0], [0] * len(images)
-  if backdrop_pieces and n_thing_movers + len(backdrop_pieces) > gamespec.WIDE_MAX_DYN:
-    index = {backdrop0: 0}
-    for s_, b in enumerate(backdrops):
-      if b not in index:
-        index[b] = len(variants)
-        variants.append(b)
-      state_variant[s_] = index[b]
-    if len(variants) <= gamespec.WIDE_MAX_VARIANTS and n_thing_movers + 1 <= gamespec.WIDE_MAX_DYN:
-      for b in variants:
-        for code in np.unique(np.frombuffer(b, np.int64)):
+  # PIECES or VARIANTS.  Pieces cost a tracked thing per cell and the render kernel a patch per piece
+  # (seven coins and a walker on a 4x9 board: 2.6 TB/s); a game whose pieces are few enough for the
+  # cell-indexed tables - at most three tracked things, no piece in the Backdrop - keeps them.  For
+  # every other game the SCENERY itself comes in variants: a picture = the Backdrop's curtain and
+  # the curtains of the several-cell drapes, the state names which picture shows, the state-table
+  # tier's render kernel lays that variant's row (CampxWideSpec.n_variants: one tracked value however
+  # many cells change - day and night over a whole floor, a field of coins: 5.4-5.7 TB/s) - as long
+  # as the pictures are at most WIDE_MAX_VARIANTS and something else is left to track.  Failing
+  # that, pieces again, up to the eight things the kernels track.
+  several = [ch for ch in dict.fromkeys(ch for ch, c in zip(split, piece_cell) if c is not None)]
+  singles = [ch for ch, c in zip(split, piece_cell) if c is None]
+  variants, variant_masks, state_variant = [backdrop0], [{}], [0] * len(images)
+  few = not backdrop_pieces and len(split) <= 3
+  if (several or backdrop_pieces) and not few and singles and len(singles) + 1 <= gamespec.WIDE_MAX_DYN:
+    index, pictures = {}, []
+    for s_, img in enumerate(images):
+      picture = (backdrops[s_] if backdrops else backdrop0,) + tuple(img[order.index(ch)] for ch in several)
+      if picture not in index:
+        index[picture] = len(pictures)
+        pictures.append(picture)
+      state_variant[s_] = index[picture]
+    if len(pictures) <= gamespec.WIDE_MAX_VARIANTS:
+      # (the first picture is state 0's: `backdrop` and the curtains after its_showtime())
+      for picture in pictures:
+        for code in np.unique(np.frombuffer(picture[0], np.int64)):
           if not 0 <= int(code) < 256 or chr(int(code)) not in chars:
             _fail('the Backdrop shows character code {}, which is not in its palette'.format(int(code)))
+      variants = [picture[0] for picture in pictures]
+      variant_masks = [{ch: np.frombuffer(part, np.uint8).reshape(H, W).copy()
+                        for ch, part in zip(several, picture[1:])} for picture in pictures]
       backdrop_pieces = set()              # the variants carry every cell
+      split, piece_cell = singles, [None] * len(singles)
+      n_thing_movers = len(split)
     else:
-      variants, state_variant = [backdrop0], [0] * len(images)
+      state_variant = [0] * len(images)
+  folded = set(several) if len(variants) > 1 else set()
   for c, code in sorted(backdrop_pieces):
     if not 0 <= code < 256 or chr(code) not in chars:
       _fail('the Backdrop shows character code {} at cell {}, which is not in its palette'.format(code, c))
     split.append(chr(code))
     piece_cell.append(c)
   if len(split) > gamespec.WIDE_MAX_DYN:
-    several = sorted({ch for ch, c in zip(split[:n_thing_movers], piece_cell) if c is not None})
+    named = sorted({ch for ch, c in zip(split[:n_thing_movers], piece_cell) if c is not None})
     if backdrop_pieces:
-      several.append('the Backdrop (which also shows more than {} different pictures, or leaves no '
-                     'tracked value to name them)'.format(gamespec.WIDE_MAX_VARIANTS))
-    _fail('moving drape(s) {} cover several cells that come and go - {} tracked cells with the '
-          'other moving things, and the table kernels track at most {}'.format(
-              ', '.join(ch if ch == 'the Backdrop' else repr(ch) for ch in several), len(split),
-              gamespec.WIDE_MAX_DYN))
+      named.append('the Backdrop')
+    _fail('moving drape(s) {} cover several cells that come and go - {} tracked cells with the other '
+          'moving things (the table kernels track at most {}), and more than {} different pictures of '
+          'the scenery'.format(', '.join(ch if ch == 'the Backdrop' else repr(ch) for ch in named),
+                               len(split), gamespec.WIDE_MAX_DYN, gamespec.WIDE_MAX_VARIANTS))
   movers = split
   in_backdrop = [k >= n_thing_movers for k in range(len(movers))]
   if not movers:
@@ -1103,7 +1121,8 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
         HW, n_tracked, DENSE_MAX_ENTRIES)
   if (any(in_backdrop) or len(variants) > 1) and dense_reason is None:
-    dense_reason = 'the Backdrop changes (its cells are painted behind every thing)'
+    dense_reason = ('the scenery changes (a Backdrop that repaints itself, drapes of several cells that come '
+                    'and go): its pictures are variants the state names, or pieces painted behind every thing')
 
   def where_is(s, k):
     """('at', cell) or ('absent', key): the one cell moving thing k occupies in state s, or - an
@@ -1163,10 +1182,11 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   game.piece_cell = piece_cell
   game.in_backdrop = in_backdrop
   game.variants = [np.frombuffer(b, np.int64).astype(np.uint8).reshape(H, W) for b in variants]
+  game.variant_masks = variant_masks
   game.absent_cells = absent_cells
   game.statics = []
   for ch in schedule:
-    if ch in movers[:n_thing_movers]:
+    if ch in movers[:n_thing_movers] or ch in folded:
       continue
     ent = probe.things[ch]
     if isinstance(ent, _things.Sprite):

@@ -547,7 +547,7 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
 #define CAMPX_WIDE_MAX_CELLS 1024        /* rows * cols; rows, cols <= 127 */
 #define CAMPX_WIDE_MAX_STATES (1 << 24)
 #define CAMPX_WIDE_MAX_DYN 8             /* things that move / come and go */
-#define CAMPX_WIDE_MAX_VARIANTS 64       /* pictures of a scenery that changes */
+#define CAMPX_WIDE_MAX_VARIANTS 256      /* pictures of a scenery that changes */
 
 typedef struct CampxWideSpec {
   uint32_t magic, version;

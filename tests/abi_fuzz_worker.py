@@ -194,7 +194,7 @@ def wide_invariants(s, arrays):
   assert 1 <= rows <= 127 and 1 <= cols <= 127 and 16 <= HW <= s['static_top_layer'].size
   assert 1 <= L <= 16 and 1 <= K <= s['dyn_layer'].size and S >= 1
   V = int(s['n_variants'])
-  assert 0 <= V <= 64 and (V <= 1 or K <= s['dyn_layer'].size - 1)
+  assert 0 <= V <= 256 and (V <= 1 or K <= s["dyn_layer"].size - 1)
   if V > 1 and 'variant_top_layer' in arrays:
     assert (arrays['variant_top_layer'] < L).all() and (arrays['state_variant'] < V).all()
     assert (arrays['variant_top_layer'][0][:HW] == s['static_top_layer'][:HW]).all()

@@ -66,48 +66,58 @@ def test_the_generator_still_makes_the_games_of_the_fixture():
     assert json.loads(str(gold['meta'])) == dict(kind=d['kind']), k
 
 
-def test_a_drape_of_several_cells_becomes_one_tracked_thing_per_cell():
-  pieces = []
+def test_several_cell_drapes_and_changing_backdrops_become_pieces_or_variants():
+  """Few pieces - at most three tracked things, none in the Backdrop - stay pieces, on the cell-indexed
+  tables; everything else becomes VARIANTS of the scenery (the Backdrop's picture and the several-cell
+  drapes' curtains together), one tracked value beside the walker."""
+  kinds = {}
   for k, d in enumerate(DEFS):
     traced = _traced(k)
     W = len(d['art'][0])
     where = lambda ch: [r * W + c for r, row in enumerate(d['art']) for c, x in enumerate(row) if x == ch]
-    assert traced.piece_cell[0] is None and traced.in_backdrop[0] is False
-    if d['kind'] in ('tide', 'seasons'):
-      # a Backdrop that changes all over: its pictures are VARIANTS of the scenery, named by the state -
-      # one tracked value, however many cells differ (here every floor cell: 9 to 25 of them)
-      assert traced.movers == ['A'] and traced.in_backdrop == [False], (k, traced.movers)
-      assert len(traced.variants) == (2 if d['kind'] == 'tide' else 3)
-      assert set(traced.st_variant.tolist()) == set(range(len(traced.variants)))
-      differing = int((traced.variants[0] != traced.variants[1]).sum())
-      assert differing > 8 and traced.dense_reason.startswith('the Backdrop changes')
-      spec, arrays = tabulate.to_wide_spec(traced)
-      assert spec.n_variants == len(traced.variants) and arrays['variant_top_layer'].shape[0] == spec.n_variants
-      from campx_amd import _hip
-      import ctypes
-      assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
-      arrays['state_variant'][3] = spec.n_variants          # a variant that is not there
-      assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
-      pieces.append((differing, False))
+    ch = {'ice': '~', 'coins': 'o', 'returning': 'o'}.get(d['kind'])
+    n = len(where(ch)) if ch else 0
+    if ch and n <= 2 and d['kind'] != 'ice':
+      # pieces: one tracked thing per cell the drape ever covers, all of its character
+      assert traced.movers == ['A'] + [ch] * n and traced.piece_cell == [None] + where(ch), (k, traced.movers)
+      assert len(traced.variants) == 1 and traced.dense_reason is None and not any(traced.in_backdrop)
+      kinds['pieces'] = kinds.get('pieces', 0) + 1
       continue
-    if d['kind'] == 'lamps':
-      # a Backdrop that changes: one piece per (cell, character) it shows beyond its first picture -
-      # a lamp that starts off can come on ('*' there), the one that starts on can go off (':')
-      want = sorted([(c, '*') for c in where(':')] + [(c, ':') for c in where('*')])
-      assert list(zip(traced.piece_cell[1:], traced.movers[1:])) == want, (k, traced.movers)
-      assert traced.in_backdrop[1:] == [True] * len(want) and traced.dense_reason.startswith(
-          ('the Backdrop changes', '{} moving things'.format(len(want) + 1)))
-      pieces.append((len(want), False))
-      continue
-    ch = '~' if d['kind'] == 'ice' else 'o'
-    n = len(where(ch))
-    assert traced.movers == ['A'] + [ch] * n, (k, traced.movers)
-    assert traced.piece_cell[1:] == where(ch) and not any(traced.in_backdrop), k
-    dense = n <= 3 and d['kind'] != 'ice' and (len(d['art']) * W) ** (n + 1) * 5 <= tabulate.DENSE_MAX_ENTRIES
-    assert (traced.dense_reason is None) == dense, (k, traced.dense_reason)
-    pieces.append((n, dense))
-  assert min(pieces)[0] == 2 and sum(d for _, d in pieces) >= 3      # both tiers
-  # ... and past what the kernels track the game is refused, by name
+    assert traced.movers == ['A'] and traced.piece_cell == [None], (k, traced.movers)
+    V = len(traced.variants)
+    assert 2 <= V <= 256 and set(traced.st_variant.tolist()) == set(range(V))
+    assert traced.dense_reason.startswith('the scenery changes')
+    if ch:                       # the drape's curtains are part of the pictures; the Backdrop stays
+      assert all(sorted(m) == [ch] for m in traced.variant_masks)
+      assert all((v == traced.variants[0]).all() for v in traced.variants)
+      assert traced.variant_masks[0][ch].reshape(-1).nonzero()[0].tolist() == where(ch)
+      assert V <= 2 ** n and not any(name == ch for name, _ in traced.statics)
+    else:                        # the Backdrop's own pictures
+      assert all(m == {} for m in traced.variant_masks)
+      assert V == {'tide': 2, 'seasons': 3}.get(d['kind'], V)
+      if d['kind'] == 'lamps':
+        assert V == 2 ** len(where(':') + where('*'))
+    kinds[d['kind']] = kinds.get(d['kind'], 0) + 1
+    spec, arrays = tabulate.to_wide_spec(traced)
+    assert spec.n_variants == V and arrays['variant_top_layer'].shape == (V, len(d['art']) * W)
+    from campx_amd import _hip
+    import ctypes
+    assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
+    arrays['state_variant'][min(3, traced.n_states - 1)] = V          # a variant that is not there
+    assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
+  assert kinds == {'pieces': 3, 'ice': 3, 'coins': 2, 'returning': 1, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
+
+
+def test_past_the_variants_the_pieces_and_past_the_pieces_a_refusal(monkeypatch):
+  """More pictures than the kernels hold sets of rows for (here: the bound lowered to one): pieces
+  again - a tracked thing per cell, the Backdrop's painted behind every thing - up to eight."""
+  from campx_amd import gamespec
+  monkeypatch.setattr(gamespec, 'WIDE_MAX_VARIANTS', 1)
+  lamps = tabulate.trace(random_pickups.builder(DEFS[10])(), cache=False)       # four lamps in the Backdrop
+  assert lamps.movers[0] == 'A' and lamps.in_backdrop == [False] + [True] * 4 and len(lamps.variants) == 1
+  assert sorted(zip(lamps.piece_cell[1:], lamps.movers[1:])) == list(zip(lamps.piece_cell[1:], lamps.movers[1:]))
+  coins = tabulate.trace(random_pickups.builder(DEFS[3])(), cache=False)        # seven coins
+  assert coins.movers == ['A'] + ['o'] * 7 and len(coins.variants) == 1
   import traced_games as tg
   art = ['##########', '#Aooooooo#', '#o       #', '##########']
   game = tg.ascii_art_to_game(art, what_lies_beneath=' ', drapes={'A': tg.Forager, 'o': tg.Coins, '#': tg.things.FixedDrape},
