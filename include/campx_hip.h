@@ -561,8 +561,9 @@ typedef struct CampxWideSpec {
                                       update kernel need not look the discount up) */
   int32_t n_variants;              /* V: pictures of the SCENERY the game shows (0 or 1: one; up to
                                       CAMPX_WIDE_MAX_VARIANTS).  A Backdrop.update() that repaints
-                                      the backdrop (campx/things.py:103-148) over many cells - day
-                                      and night over a whole floor - makes the scenery a function of
+                                      the backdrop (campx/things.py:103-148) - day and night over a
+                                      whole floor - or a Drape of several cells that come and go
+                                      (coins taken one by one) makes the scenery a function of
                                       the state: the render kernel then lays, per environment and
                                       frame, the pre-rotated row of the state's variant, which the
                                       update pass hands it as one more (never painted) plane of the
