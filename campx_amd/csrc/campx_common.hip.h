@@ -567,6 +567,13 @@ struct RenderSource {
   // names each (frame, environment)'s variant
   int32_t n_variants;
   int64_t rot_obs_stride, rot_board_stride;
+  // pieces of the scenery that come and go (CampxWideSpec.n_pieces > 0): plane `n_dyn` of the trace
+  // holds each (frame, environment)'s 16-bit mask of the pieces that show; device tables of
+  // CAMPX_WIDE_MAX_PIECES words: layered rows  (offset of the byte a piece sets) | (offset of the
+  // scenery byte it clears) << 16;  flat board  cell | character << 16
+  int32_t n_pieces;
+  const uint32_t* pieces_obs;
+  const uint32_t* pieces_board;
 };
 int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* dst, int64_t B,
                            int32_t T, int64_t plane_rows, int64_t pitch, bool is_board, int fmt,

@@ -642,8 +642,9 @@ void wide_rollout(const Tensor& spec_host, const Tensor& tables, Tensor& state, 
   TORCH_CHECK(state.device().is_cuda() && state.dim() == 1,
               "campx::wide_rollout: state must be on a HIP device (no CPU implementation)");
   const c10::Device dev = state.device();
-  // (planes of the trace: the things, plus the scenery's variant when it has several)
-  const int64_t B = state.size(0), K = hs->n_dyn + (hs->n_variants > 1 ? 1 : 0), L = hs->n_layers, H = hs->rows,
+  // (planes of the trace: the things, plus the scenery's variant when it has several - or the mask
+  // of its pieces that show)
+  const int64_t B = state.size(0), K = hs->n_dyn + ((hs->n_variants > 1 || hs->n_pieces > 0) ? 1 : 0), L = hs->n_layers, H = hs->rows,
                 W = hs->cols;
   want(state, "state", at::kInt, dev, {B});
   want(done, "done", at::kByte, dev, {B});

@@ -31,6 +31,8 @@ struct RenderParams {
   int64_t rot_stride;         // kVar: bytes from one variant's rotations to the next's
   int32_t n_variants;         // kVar: how many there are
   uint32_t inv_p;             // run-time thing count (five to eight things): ceil(2^32 / patches per row)
+  const uint32_t* pieces;     // kMask: device, per piece (byte it sets | byte it clears << 16), or (cell | character << 16)
+  int32_t piece_shift;        // kMask: log2 of the pieces per row, rounded up to a power of two
 };
 
 // kVar: bytes [0, n) of a 16-byte scenery chunk come from one environment's row, bytes [n, 16)
@@ -117,12 +119,20 @@ constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 // chunk that runs over the end of an environment's row takes the rest from the NEXT environment's
 // variant (the rotations continue a row cyclically with its own start, which is what the next
 // row starts with when both show the same variant - and what merge_rows() replaces when not).
+// kMask (wide tier, round 6): pieces of the scenery that come and go - the cells of a drape whose
+// curtain loses them one by one, the cells a Backdrop repaints.  Plane `n_dyn` of the trace holds,
+// per (frame, environment), the 16-bit mask of the pieces that show; the wave patches them onto
+// the plain scenery like the things (a byte set in the piece's layer, the scenery's byte under it
+// cleared) from ONE trace entry per row however many pieces there are - eight things tracked
+// one by one load sixteen slots a row (2.6 TB/s on a 4x9 board), a scenery in variants waits for
+// the entry before it can fetch its row (4.4-5.7): here nothing waits for anything but the trace.
 template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false, bool kWide = false,
-          bool kVar = false>
+          int kScen = 0>
 __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     RenderParams rp, const typename TraceFormat<kWide>::Entry* __restrict__ trace,
     int8_t* __restrict__ dst, int64_t n_rows) {
   using Fmt = TraceFormat<kWide>;
+  constexpr bool kVar = kScen == 1, kMask = kScen == 2;
   __shared__ __attribute__((aligned(16))) int8_t lds[kRenderWaves * kWin * 1024];
   __shared__ uint16_t scen_off_all[kRenderWaves][kWide ? 2 : CAMPX_MAX_CELLS];
   // kVar: the variant of every row the wave's windows overlap (+ the one after): rows of at least
@@ -192,6 +202,25 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     uint32_t row = first_row + (uint32_t)r;
     row = row <= last_row ? row : last_row;            // clamp: slot unused, entry ignored
     ent[it] = (it == 0 || slots > it * kWave) ? frame_trace[(int64_t)d * n_rows + trace_row(row)] : 0u;
+  }
+
+  // kMask: slot = (row, piece), sixteen (or fewer: a power of two) to a row, so a lane's piece is
+  // the same in every round of slots; its table entry and the rows' masks travel with the things'
+  // entries (the mask of one row is one address for all its slots: the loads coalesce)
+  constexpr int kMaskIter = 2;
+  uint32_t piece = 0, shown[kMaskIter] = {0u, 0u};
+  int mask_slots = 0;
+  if constexpr (kMask) {
+    const typename Fmt::Entry* masks = frame_trace + (int64_t)rp.n_dyn * n_rows;
+    const int sh = rp.piece_shift;
+    mask_slots = (int)(last_row - first_row + 1u) << sh;
+    piece = rp.pieces[lane & ((1 << sh) - 1)];
+#pragma unroll
+    for (int it = 0; it < kMaskIter; ++it) {
+      uint32_t row = first_row + (uint32_t)((lane + it * kWave) >> sh);
+      row = row <= last_row ? row : last_row;
+      shown[it] = (it == 0 || mask_slots > it * kWave) ? (uint32_t)masks[trace_row(row)] : 0u;
+    }
   }
 
   if constexpr (kVar) {
@@ -308,6 +337,28 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
     const int d = kBoard ? p : (p >> 1);
     apply(sidx, frame_trace[(int64_t)d * n_rows + trace_row(first_row + (uint32_t)r)]);
   }
+  if constexpr (kMask) {
+    // (a piece that shows and a thing that shows never share a cell: the order does not matter)
+    const int sh = rp.piece_shift;
+    const uint32_t bit = 1u << (lane & ((1 << sh) - 1));
+    auto lay = [&](int slot, uint32_t mask) {
+      if (slot < mask_slots && (mask & bit)) {
+        const uint32_t row0 = (first_row + (uint32_t)(slot >> sh)) * (uint32_t)R - woff0;
+        const uint32_t a = row0 + (piece & 0xffffu), b = row0 + (piece >> 16);
+        if (kBoard) {
+          if (a < span) win0[a] = (int8_t)(piece >> 16);
+        } else {
+          if (a < span) win0[a] = 1;
+          if (b < span) win0[b] = 0;
+        }
+      }
+    };
+#pragma unroll
+    for (int it = 0; it < kMaskIter; ++it) lay(lane + it * kWave, shown[it]);
+    const typename Fmt::Entry* masks = frame_trace + (int64_t)rp.n_dyn * n_rows;
+    for (int slot = lane + kMaskIter * kWave; slot < mask_slots; slot += kWave)
+      lay(slot, (uint32_t)masks[trace_row(first_row + (uint32_t)(slot >> sh))]);
+  }
 
   // ---- out: aligned, contiguous KiB stores
   if (kFmt == 0) {
@@ -398,6 +449,10 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
     rp.inv_p = (uint32_t)(((1ull << 32) + patches - 1) / (patches ? patches : 1));
   }
   rp.top_layer = src.top_layer;
+  if (src.n_pieces > 0) {
+    rp.pieces = is_board ? src.pieces_board : src.pieces_obs;
+    while ((1 << rp.piece_shift) < src.n_pieces) ++rp.piece_shift;
+  }
   for (int d = 0; d < src.n_dyn; ++d) {
     rp.dyn_char[d] = src.layer_char[src.dyn_layer[d]];
     rp.dyn_off[d] = src.dyn_layer[d] * HW;
@@ -439,25 +494,29 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
   do {                                                                      \
     if (is_board) CAMPX_RENDER2(KK, true); else CAMPX_RENDER2(KK, false);   \
   } while (0)
-  if (src.wide && src.n_variants > 1) {
-    // a scenery of several variants (the run-time-K instantiation measured 28 % below the plain
-    // kernel for a one-thing game - its patch loop divides by a count it only knows at run time -
-    // so here too the count is a template argument up to four things)
-#define CAMPX_RENDER_VAR5(KK, BOARD, FMT, ODD)                                                      \
-  hipLaunchKernelGGL((render_kernel<KK, BOARD, true, (FMT) ? kWin16 : kWin, FMT, ODD, true, true>), \
+  if (src.wide && (src.n_variants > 1 || src.n_pieces > 0)) {
+    // a scenery of several variants, or of pieces that come and go (the run-time-K instantiation
+    // measured 28 % below the plain kernel for a one-thing game - its patch loop divides by a count
+    // it only knows at run time - so here too the count is a template argument up to four things)
+#define CAMPX_RENDER_VAR5(KK, BOARD, FMT, ODD, SCEN)                                                \
+  hipLaunchKernelGGL((render_kernel<KK, BOARD, true, (FMT) ? kWin16 : kWin, FMT, ODD, true, SCEN>), \
                      grid, dim3(kRenderWaves * kWave), 0, stream, rp,                               \
                      static_cast<const uint16_t*>(trace), dst, n_rows)
+#define CAMPX_RENDER_VAR4(KK, BOARD, FMT, SCEN)                                               \
+  do {                                                                                        \
+    if (odd) CAMPX_RENDER_VAR5(KK, BOARD, FMT, true, SCEN);                                   \
+    else CAMPX_RENDER_VAR5(KK, BOARD, FMT, false, SCEN);                                      \
+  } while (0)
+#define CAMPX_RENDER_VAR3(KK, SCEN)                                                           \
+  do {                                                                                        \
+    if (is_board) CAMPX_RENDER_VAR4(KK, true, 0, SCEN);                                       \
+    else if (fmt == 1) CAMPX_RENDER_VAR4(KK, false, 1, SCEN);                                 \
+    else if (fmt == 2) CAMPX_RENDER_VAR4(KK, false, 2, SCEN);                                 \
+    else CAMPX_RENDER_VAR4(KK, false, 0, SCEN);                                               \
+  } while (0)
 #define CAMPX_RENDER_VAR(KK)                                                                  \
   do {                                                                                        \
-    if (is_board) {                                                                           \
-      if (odd) CAMPX_RENDER_VAR5(KK, true, 0, true); else CAMPX_RENDER_VAR5(KK, true, 0, false);   \
-    } else if (fmt == 1) {                                                                    \
-      if (odd) CAMPX_RENDER_VAR5(KK, false, 1, true); else CAMPX_RENDER_VAR5(KK, false, 1, false); \
-    } else if (fmt == 2) {                                                                    \
-      if (odd) CAMPX_RENDER_VAR5(KK, false, 2, true); else CAMPX_RENDER_VAR5(KK, false, 2, false); \
-    } else {                                                                                  \
-      if (odd) CAMPX_RENDER_VAR5(KK, false, 0, true); else CAMPX_RENDER_VAR5(KK, false, 0, false); \
-    }                                                                                         \
+    if (src.n_pieces > 0) CAMPX_RENDER_VAR3(KK, 2); else CAMPX_RENDER_VAR3(KK, 1);            \
   } while (0)
     switch (src.n_dyn) {
       case 1: CAMPX_RENDER_VAR(1); break;
@@ -467,6 +526,8 @@ int32_t launch_render_from(const RenderSource& src, const void* trace, int8_t* d
       default: CAMPX_RENDER_VAR(8); break;
     }
 #undef CAMPX_RENDER_VAR
+#undef CAMPX_RENDER_VAR3
+#undef CAMPX_RENDER_VAR4
 #undef CAMPX_RENDER_VAR5
   } else if (src.wide) {
 #define CAMPX_RENDER_WIDE(KK)                                             \

@@ -321,12 +321,13 @@ __global__ void wide_reset_kernel(const u32x4* __restrict__ cells, int32_t K, in
 }
 
 // ---- the table blob: [entries uint2 x 5S, padded to 16][cells 8 x uint16 x S][perf int8 x 5S, padded to 16]
-// [rot_obs][rot_board]
+// [rot_obs][rot_board][pieces: 16 words for the layered rows, 16 for the flat board]
 struct WideLayout {
-  int64_t n_entries, cells_off, perf_off, rot_obs_off, rot_board_off, total;
+  int64_t n_entries, cells_off, perf_off, rot_obs_off, rot_board_off, pieces_off, total;
   int pitch_obs, pitch_board;
   int n_variants;          // sets of rotations (1: the scenery never changes)
-  int n_planes;            // planes of the trace: the things, plus the variant's when there are several
+  int n_planes;            // planes of the trace: the things, plus the variant's when there are several,
+                           // or the mask of the pieces that show
 };
 
 static int wide_variants(const CampxWideSpec& s) { return s.n_variants > 1 ? s.n_variants : 1; }
@@ -340,10 +341,11 @@ WideLayout wide_layout(const CampxWideSpec& s) {
   w.rot_obs_off = (w.perf_off + w.n_entries + 15) & ~(int64_t)15;
   w.pitch_obs = (int)(((R + 15) & ~(int64_t)15) + 16);
   w.n_variants = wide_variants(s);
-  w.n_planes = s.n_dyn + (w.n_variants > 1 ? 1 : 0);
+  w.n_planes = s.n_dyn + ((w.n_variants > 1 || s.n_pieces > 0) ? 1 : 0);
   w.rot_board_off = w.rot_obs_off + 16ll * w.pitch_obs * w.n_variants;
   w.pitch_board = (int)(((HW + 15) & ~(int64_t)15) + 16);
-  w.total = w.rot_board_off + 16ll * w.pitch_board * w.n_variants;
+  w.pieces_off = w.rot_board_off + 16ll * w.pitch_board * w.n_variants;
+  w.total = w.pieces_off + (s.n_pieces > 0 ? 2 * CAMPX_WIDE_MAX_PIECES * (int64_t)sizeof(uint32_t) : 0);
   return w;
 }
 
@@ -365,6 +367,11 @@ RenderSource wide_render_source(const CampxWideSpec& s, const void* tables_dev) 
   src.n_variants = w.n_variants;
   src.rot_obs_stride = 16ll * w.pitch_obs;
   src.rot_board_stride = 16ll * w.pitch_board;
+  src.n_pieces = s.n_pieces;
+  if (s.n_pieces > 0) {
+    src.pieces_obs = reinterpret_cast<const uint32_t*>(blob + w.pieces_off);
+    src.pieces_board = src.pieces_obs + CAMPX_WIDE_MAX_PIECES;
+  }
   return src;
 }
 
@@ -392,6 +399,14 @@ int32_t wide_validate_plain(const CampxWideSpec* s) {
   // a scenery of several variants takes one plane of the trace (and one slot of a state's entries)
   if (s->n_variants < 0 || s->n_variants > CAMPX_WIDE_MAX_VARIANTS) return CAMPX_ESPEC;
   if (s->n_variants > 1 && s->n_dyn > CAMPX_WIDE_MAX_DYN - 1) return CAMPX_ESPEC;
+  // ... and so does the mask of the pieces that show; one or the other
+  if (s->n_pieces < 0 || s->n_pieces > CAMPX_WIDE_MAX_PIECES) return CAMPX_ESPEC;
+  if (s->n_pieces > 0 && (s->n_variants > 1 || s->n_dyn > CAMPX_WIDE_MAX_DYN - 1)) return CAMPX_ESPEC;
+  for (int p = 0; p < s->n_pieces; ++p) {
+    if (s->piece_cell[p] >= HW || s->piece_layer[p] >= s->n_layers) return CAMPX_ESPEC;
+    // (a piece that paints the scenery's own layer there would set and clear the same byte)
+    if (s->piece_layer[p] == s->static_top_layer[s->piece_cell[p]]) return CAMPX_ESPEC;
+  }
   return CAMPX_OK;
 }
 
@@ -649,6 +664,9 @@ int32_t campx_wide_spec_validate(const CampxWideSpec* s) {
       for (int64_t i = 0; i < S; ++i)
         if (s->state_variant[i] >= s->n_variants) return CAMPX_ESPEC;
   }
+  if (s->n_pieces > 0 && s->state_pieces)
+    for (int64_t i = 0; i < S; ++i)
+      if (s->state_pieces[i] >> s->n_pieces) return CAMPX_ESPEC;
   return CAMPX_OK;
 }
 
@@ -662,6 +680,7 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
   if (!s->state_cells || !s->next_state || !s->reward || !s->done) return CAMPX_EINVAL;
   if (s->has_perf && !s->perf) return CAMPX_EINVAL;
   if (s->n_variants > 1 && (!s->variant_top_layer || !s->state_variant)) return CAMPX_EINVAL;
+  if (s->n_pieces > 0 && !s->state_pieces) return CAMPX_EINVAL;
   const int32_t v = campx_wide_spec_validate(s);
   if (v != CAMPX_OK) return v;
   const WideLayout w = wide_layout(*s);
@@ -690,6 +709,7 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
       e[d] = cell | ((uint32_t)top[cell] << 10) | ((c >> 15) ? 0u : 0x8000u);
     }
     if (V > 1) e[K] = (uint32_t)variant;       // plane K of the trace: never painted (bit 15 clear)
+    if (s->n_pieces > 0) e[K] = s->state_pieces[st];   // (or the pieces that show: all sixteen bits)
     cells[st].x = e[0] | (e[1] << 16);
     cells[st].y = e[2] | (e[3] << 16);
     cells[st].z = e[4] | (e[5] << 16);
@@ -717,6 +737,17 @@ int32_t campx_wide_tables_build(const CampxWideSpec* s, void* tables_dev, void* 
     }
   }
   free(row);
+  if (s->n_pieces > 0) {
+    uint32_t* pieces_obs = reinterpret_cast<uint32_t*>(blob + w.pieces_off);
+    uint32_t* pieces_board = pieces_obs + CAMPX_WIDE_MAX_PIECES;
+    for (int p = 0; p < s->n_pieces; ++p) {
+      const uint32_t cell = s->piece_cell[p];
+      const uint32_t sets = (uint32_t)s->piece_layer[p] * (uint32_t)HW + cell;          // < 16 * 1024
+      const uint32_t clears = (uint32_t)s->static_top_layer[cell] * (uint32_t)HW + cell;
+      pieces_obs[p] = sets | (clears << 16);
+      pieces_board[p] = cell | ((uint32_t)s->layer_char[s->piece_layer[p]] << 16);
+    }
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipError_t e = hipMemcpyAsync(tables_dev, blob, (size_t)w.total, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -757,7 +788,7 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
     // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
     const int HW = s->rows * s->cols, R = HW * s->n_layers;
     // (a scenery of several variants: through the update + render kernels, which know about them)
-    if (T == 1 && !reset_first && (R & 15) == 0 && w.n_variants == 1 &&
+    if (T == 1 && !reset_first && (R & 15) == 0 && w.n_variants == 1 && s->n_pieces == 0 &&
         (!out.board || (HW & 15) == 0) &&
         (int64_t)kStepEnvMax * R < (1ll << 24)) {
       WideStepParams sp;

@@ -177,6 +177,7 @@ def enumerate_rule_game(engine, device, max_states=None):
   game.st_variant = np.zeros(S, np.uint16)
   game.variants = [game.backdrop]
   game.variant_masks = [{}]
+  game.pieces_as_mask = False
   game.st_next = nxt_index.cpu().numpy()
   game.st_reward = reward.cpu().numpy()
   game.st_done = done.cpu().numpy()

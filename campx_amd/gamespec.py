@@ -513,6 +513,7 @@ WIDE_MAX_CELLS = 1024
 WIDE_MAX_STATES = 1 << 24
 WIDE_MAX_DYN = 8
 WIDE_MAX_VARIANTS = 256     # pictures of a scenery that changes (CampxWideSpec.n_variants)
+WIDE_MAX_PIECES = 16        # cells of the scenery that come and go one by one (CampxWideSpec.n_pieces)
 
 
 class CampxWideRules(ctypes.Structure):
@@ -535,13 +536,16 @@ class CampxWideSpec(ctypes.Structure):
               ('n_layers', ctypes.c_int32), ('n_dyn', ctypes.c_int32),
               ('n_states', ctypes.c_int32), ('any_reward', ctypes.c_int32),
               ('has_perf', ctypes.c_int32), ('any_dcode', ctypes.c_int32),
-              ('n_variants', ctypes.c_int32), ('reserved0', ctypes.c_int32),
+              ('n_variants', ctypes.c_int32), ('n_pieces', ctypes.c_int32),
               ('layer_char', ctypes.c_uint8 * MAX_LAYERS),
               ('dyn_layer', ctypes.c_int32 * WIDE_MAX_DYN),
               ('discount_list', ctypes.c_float * 16),
               ('static_top_layer', ctypes.c_uint8 * WIDE_MAX_CELLS),
+              ('piece_cell', ctypes.c_uint16 * WIDE_MAX_PIECES),
+              ('piece_layer', ctypes.c_uint8 * WIDE_MAX_PIECES),
               # host arrays, read at validation / table-build time only
               ('state_cells', ctypes.c_void_p), ('next_state', ctypes.c_void_p),
               ('reward', ctypes.c_void_p), ('done', ctypes.c_void_p),
               ('perf', ctypes.c_void_p),
-              ('variant_top_layer', ctypes.c_void_p), ('state_variant', ctypes.c_void_p)]
+              ('variant_top_layer', ctypes.c_void_p), ('state_variant', ctypes.c_void_p),
+              ('state_pieces', ctypes.c_void_p)]

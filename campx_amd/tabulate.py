@@ -303,6 +303,9 @@ class TracedGame(object):
     in_backdrop: per mover, True for a piece of a Backdrop that changes (one per (cell,
       character) it shows other than at the start; they come after every other mover and are
       painted on the backdrop itself, behind every thing);
+    pieces_as_mask: the pieces are handed to the state-table tier as one 16-bit mask per state
+      (`CampxWideSpec.n_pieces`: bit p = piece p shows) instead of a tracked thing each - up to
+      sixteen of them beside up to seven ordinary movers; nothing else about the game changes;
     variants, variant_masks, st_variant: the scenery in VARIANTS - the Backdrop's pictures (uint8
       [H, W] each, the first = `backdrop`), beside each the curtains of the several-cell drapes
       that are part of the scenery's pictures ({character: uint8 [H, W]}), and per state which
@@ -781,7 +784,8 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
   if cache and engine.backdrop is not None:
     key = fingerprint(engine, default_actions() if actions is None else list(actions))
     if key is not None:
-      key = (key, max_plays)
+      # (... and the bounds that decide how pieces of the scenery are handed to the kernels)
+      key = (key, max_plays, gamespec.WIDE_MAX_PIECES, gamespec.WIDE_MAX_VARIANTS)
       if key in _CACHE:
         _CACHE.move_to_end(key)
         return _CACHE[key]
@@ -1015,20 +1019,25 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     for c in np.flatnonzero(now != base_backdrop):
       backdrop_pieces.add((int(c), int(now[c])))
   n_thing_movers = len(split)
-  # PIECES or VARIANTS.  Pieces cost a tracked thing per cell and the render kernel a patch per piece
-  # (seven coins and a walker on a 4x9 board: 2.6 TB/s); a game whose pieces are few enough for the
-  # cell-indexed tables - at most three tracked things, no piece in the Backdrop - keeps them.  For
-  # every other game the SCENERY itself comes in variants: a picture = the Backdrop's curtain and
-  # the curtains of the several-cell drapes, the state names which picture shows, the state-table
-  # tier's render kernel lays that variant's row (CampxWideSpec.n_variants: one tracked value however
-  # many cells change - day and night over a whole floor, a field of coins: 5.4-5.7 TB/s) - as long
-  # as the pictures are at most WIDE_MAX_VARIANTS and something else is left to track.  Failing
-  # that, pieces again, up to the eight things the kernels track.
+  # PIECES or VARIANTS.  A piece tracked as a thing costs the render kernel a trace entry and a patch
+  # slot per piece and row (seven coins and a walker on a 4x9 board: 2.6 TB/s).  A game whose pieces
+  # are few enough for the cell-indexed tables - at most three tracked things, no piece in the
+  # Backdrop - keeps them as things.  Up to sixteen pieces beside at least one ordinary mover are
+  # handed to the state-table tier as a MASK (CampxWideSpec.n_pieces: which of them show is one
+  # 16-bit value per state, `pieces_as_mask` below - everything else about the game stays as the
+  # pieces describe it).  More cells than that - day and night over a whole floor - and the SCENERY
+  # itself comes in variants: a picture = the Backdrop's curtain and the curtains of the
+  # several-cell drapes, the state names which picture shows, the render kernel lays that variant's
+  # row (CampxWideSpec.n_variants; 4.4-5.7 TB/s) - as long as the pictures are at most
+  # WIDE_MAX_VARIANTS.  Failing that, pieces as things again, up to the eight the kernels track.
   several = [ch for ch in dict.fromkeys(ch for ch, c in zip(split, piece_cell) if c is not None)]
   singles = [ch for ch, c in zip(split, piece_cell) if c is None]
   variants, variant_masks, state_variant = [backdrop0], [{}], [0] * len(images)
   few = not backdrop_pieces and len(split) <= 3
-  if (several or backdrop_pieces) and not few and singles and len(singles) + 1 <= gamespec.WIDE_MAX_DYN:
+  n_pieces = len(split) - len(singles) + len(backdrop_pieces)
+  room = bool(singles) and len(singles) + 1 <= gamespec.WIDE_MAX_DYN
+  pieces_as_mask = bool(n_pieces) and not few and room and n_pieces <= gamespec.WIDE_MAX_PIECES
+  if (several or backdrop_pieces) and not few and room and not pieces_as_mask:
     index, pictures = {}, []
     for s_, img in enumerate(images):
       picture = (backdrops[s_] if backdrops else backdrop0,) + tuple(img[order.index(ch)] for ch in several)
@@ -1056,7 +1065,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
       _fail('the Backdrop shows character code {} at cell {}, which is not in its palette'.format(code, c))
     split.append(chr(code))
     piece_cell.append(c)
-  if len(split) > gamespec.WIDE_MAX_DYN:
+  if len(split) > gamespec.WIDE_MAX_DYN and not pieces_as_mask:
     named = sorted({ch for ch, c in zip(split[:n_thing_movers], piece_cell) if c is not None})
     if backdrop_pieces:
       named.append('the Backdrop')
@@ -1101,7 +1110,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
       modes.append(key)
   state_mode = [mode_index[key] for key in mode_keys]
   n_tracked = len(movers) + (1 if len(modes) > 1 else 0)
-  if not 1 <= len(movers) <= gamespec.WIDE_MAX_DYN:
+  if not 1 <= len(movers) <= gamespec.WIDE_MAX_DYN and not pieces_as_mask:
     _fail('needs between 1 and {} moving things, found {} ({})'.format(
         gamespec.WIDE_MAX_DYN, len(movers), ''.join(movers) or 'nothing moves'))
   K = len(movers)
@@ -1120,9 +1129,9 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   elif HW ** n_tracked * N_ACTIONS > DENSE_MAX_ENTRIES:
     dense_reason = 'a table over {} cells ^ {} things has more than {} entries'.format(
         HW, n_tracked, DENSE_MAX_ENTRIES)
-  if (any(in_backdrop) or len(variants) > 1) and dense_reason is None:
+  if (any(in_backdrop) or len(variants) > 1 or pieces_as_mask) and dense_reason is None:
     dense_reason = ('the scenery changes (a Backdrop that repaints itself, drapes of several cells that come '
-                    'and go): its pictures are variants the state names, or pieces painted behind every thing')
+                    'and go): pieces the state names a mask of, or pictures it names the variant of')
 
   def where_is(s, k):
     """('at', cell) or ('absent', key): the one cell moving thing k occupies in state s, or - an
@@ -1183,6 +1192,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   game.in_backdrop = in_backdrop
   game.variants = [np.frombuffer(b, np.int64).astype(np.uint8).reshape(H, W) for b in variants]
   game.variant_masks = variant_masks
+  game.pieces_as_mask = pieces_as_mask
   game.absent_cells = absent_cells
   game.statics = []
   for ch in schedule:
@@ -1436,7 +1446,12 @@ def to_wide_spec(game):
   the user's own code rendered."""
   H, W = game.rows, game.cols
   HW = H * W
-  K, S = len(game.movers), game.n_states
+  S = game.n_states
+  # pieces handed over as a mask are not among the kernels' things
+  as_mask = bool(getattr(game, 'pieces_as_mask', False))
+  things = [k for k in range(len(game.movers)) if not (as_mask and game.piece_cell[k] is not None)]
+  pieces = [k for k in range(len(game.movers)) if k not in things and game.st_shows[:, k].any()]
+  K = len(things)
   if HW < 16:
     _fail('the state-table tier needs a board of at least 16 cells')
   if S > gamespec.WIDE_MAX_STATES:
@@ -1450,17 +1465,18 @@ def to_wide_spec(game):
   spec.any_dcode = int((game.st_dcode != 0).any())
   for i, ch in enumerate(game.chars):
     spec.layer_char[i] = ord(ch)
-  for d, ch in enumerate(game.movers):
-    spec.dyn_layer[d] = layer_of[ch]
+  for d, k in enumerate(things):
+    spec.dyn_layer[d] = layer_of[game.movers[k]]
   for code, value in enumerate(game.discount_list):
     if code:
       spec.discount_list[code] = float(value)
   top = game.model_board(game.init_cells, movers=False).reshape(-1)
   for i in range(HW):
     spec.static_top_layer[i] = layer_of[chr(int(top[i]))]
-  cells = np.where(game.st_present, game.st_cells, 0).astype(np.uint16)
+  cells = np.where(game.st_present, game.st_cells, 0).astype(np.uint16)[:, things]
+  hidden = (game.st_shows[:, things] == 0).astype(np.uint16)
   arrays = dict(        # (copies: a TracedGame may be shared through the tabulation cache)
-      state_cells=np.array(cells | ((game.st_shows == 0).astype(np.uint16) << 15), np.uint16, order='C'),
+      state_cells=np.array(cells | (hidden << 15), np.uint16, order='C'),
       next_state=np.array(game.st_next, np.int32, order='C'),
       reward=np.array(game.st_reward, np.float32, order='C'),
       done=np.array(game.st_done | (game.st_dcode << 4), np.uint8, order='C'),
@@ -1475,6 +1491,17 @@ def to_wide_spec(game):
       tops[v] = [layer_of[chr(int(c))] for c in scenery]
     arrays['variant_top_layer'] = tops
     arrays['state_variant'] = np.array(game.st_variant, np.uint16, order='C')
+  if pieces:
+    # which pieces SHOW in a state (on their cell, nothing in front): one bit each
+    spec.n_pieces = len(pieces)
+    shown = np.zeros(S, np.uint16)
+    for p, k in enumerate(pieces):
+      cell = int(game.piece_cell[k])
+      spec.piece_cell[p], spec.piece_layer[p] = cell, layer_of[game.movers[k]]
+      if spec.piece_layer[p] == spec.static_top_layer[cell]:
+        _fail('piece {!r} at cell {} is the character the scenery shows there anyway'.format(game.movers[k], cell))
+      shown |= (game.st_shows[:, k] != 0).astype(np.uint16) << p
+    arrays['state_pieces'] = np.array(shown, np.uint16, order='C')
   for name, a in arrays.items():
     setattr(spec, name, a.ctypes.data)
   if not game.has_perf:

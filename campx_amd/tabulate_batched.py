@@ -503,6 +503,7 @@ def _finish_arrays(engine, probe, chars, movers_sorted, start, cells, nxt, rewar
   game.in_backdrop = [False] * K
   game.variants = [game.backdrop]       # (a Backdrop with an update() of its own goes to the other walker too)
   game.variant_masks = [{}]
+  game.pieces_as_mask = False
   game.absent_cells = absent_cells
   game.statics = [(ch, start_np[ch].copy()) for ch in schedule if ch not in movers]
   if len(game.statics) > gamespec.MAX_STATIC:

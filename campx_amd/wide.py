@@ -48,9 +48,10 @@ class WideGame(fused.FusedGame):
                'campx_wide_spec_validate')
     self.rows, self.cols = engine.rows, engine.cols
     self.n_layers = len(self.chars)
-    self.n_dyn = len(traced.movers)
-    # planes of the trace: the things, plus - a scenery of several variants - which one shows
-    self._n_planes = self.n_dyn + (1 if self.spec.n_variants > 1 else 0)
+    self.n_dyn = int(self.spec.n_dyn)      # (pieces of the scenery are not among the things)
+    # planes of the trace: the things, plus - a scenery of several variants - which one shows,
+    # or - a scenery of pieces that come and go - the mask of those that do
+    self._n_planes = self.n_dyn + (1 if self.spec.n_variants > 1 or self.spec.n_pieces > 0 else 0)
     self.uses_table = True
     self.any_reward = bool(self.spec.any_reward)
     self.has_perf = bool(self.spec.has_perf)
@@ -68,7 +69,8 @@ class WideGame(fused.FusedGame):
           'campx_wide_tables_build')
     # The launches read the spec's plain fields only; the blob they get carries no pointers
     # to the host arrays (which stay alive in self._arrays anyway).
-    for name in ('state_cells', 'next_state', 'reward', 'done', 'perf', 'variant_top_layer', 'state_variant'):
+    for name in ('state_cells', 'next_state', 'reward', 'done', 'perf', 'variant_top_layer', 'state_variant',
+                 'state_pieces'):
       setattr(self.spec, name, None)
     self._spec_host = torch.frombuffer(bytearray(gamespec.spec_bytes(self.spec)),
                                        dtype=torch.uint8)

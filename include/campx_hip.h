@@ -548,6 +548,7 @@ int32_t campx_shape_rollout_launch(const CampxShapeSpec* spec_host, const CampxS
 #define CAMPX_WIDE_MAX_STATES (1 << 24)
 #define CAMPX_WIDE_MAX_DYN 8             /* things that move / come and go */
 #define CAMPX_WIDE_MAX_VARIANTS 256      /* pictures of a scenery that changes */
+#define CAMPX_WIDE_MAX_PIECES 16         /* cells of the scenery that come and go one by one */
 
 typedef struct CampxWideSpec {
   uint32_t magic, version;
@@ -570,11 +571,25 @@ typedef struct CampxWideSpec {
                                       trace.  With V > 1: n_dyn <= CAMPX_WIDE_MAX_DYN - 1, the trace
                                       holds n_dyn + 1 planes, and `variant_top_layer` /
                                       `state_variant` below are given. */
-  int32_t reserved0;
+  int32_t n_pieces;                /* P: PIECES of the scenery, 0 .. CAMPX_WIDE_MAX_PIECES - fixed
+                                      cells that show a character of their own in some states and
+                                      the plain scenery in the others: the cells of a Drape whose
+                                      curtain loses them one by one (coins that are taken, ice that
+                                      breaks; campx/things.py:161-262 sets no one-cell limit), the
+                                      cells a Backdrop.update() repaints (lamps).  Which of them
+                                      show is a 16-bit MASK per state (`state_pieces`), handed to
+                                      the render kernel as one more (never painted) plane of the
+                                      trace; it patches them onto the scenery's row like the
+                                      things, from ONE trace entry per environment however many
+                                      there are.  With P > 0: n_dyn <= CAMPX_WIDE_MAX_DYN - 1,
+                                      n_variants <= 1, the trace holds n_dyn + 1 planes. */
   uint8_t layer_char[CAMPX_MAX_LAYERS];
   int32_t dyn_layer[CAMPX_WIDE_MAX_DYN];   /* layer thing d paints */
   float discount_list[16];                 /* as CampxSpec.discount_list */
   uint8_t static_top_layer[CAMPX_WIDE_MAX_CELLS];  /* front-most scenery layer per cell */
+  uint16_t piece_cell[CAMPX_WIDE_MAX_PIECES];      /* the cell of piece p (row * cols + col) */
+  uint8_t piece_layer[CAMPX_WIDE_MAX_PIECES];      /* the layer it paints when it shows (it hides
+                                                      static_top_layer there, like a thing) */
   /* HOST arrays, read by campx_wide_spec_validate(full) / campx_wide_tables_build() only -
    * the launch calls never touch them, they may be gone by then: */
   const uint16_t* state_cells;     /* [S][K]: bits 0-9 the cell thing d is on in state s; bit 15
@@ -588,6 +603,8 @@ typedef struct CampxWideSpec {
   const uint8_t* variant_top_layer; /* [V][rows*cols]: the front-most scenery layer per cell in
                                       variant v (row 0 = static_top_layer); NULL when V <= 1 */
   const uint16_t* state_variant;   /* [S]: the variant the scenery shows in state s; NULL when V <= 1 */
+  const uint16_t* state_pieces;    /* [S]: bit p set = piece p SHOWS in state s (not taken, and nothing
+                                      in front of it); NULL when P = 0 */
 } CampxWideSpec;
 
 int32_t campx_wide_spec_size(void);

@@ -198,6 +198,12 @@ def wide_invariants(s, arrays):
   if V > 1 and 'variant_top_layer' in arrays:
     assert (arrays['variant_top_layer'] < L).all() and (arrays['state_variant'] < V).all()
     assert (arrays['variant_top_layer'][0][:HW] == s['static_top_layer'][:HW]).all()
+  P = int(s['n_pieces'])
+  assert 0 <= P <= s['piece_cell'].size and (P == 0 or (V <= 1 and K <= s['dyn_layer'].size - 1))
+  assert (s['piece_cell'][:P] < HW).all() and (s['piece_layer'][:P] < L).all()
+  assert (s['piece_layer'][:P] != s['static_top_layer'][s['piece_cell'][:P]]).all()
+  if P and 'state_pieces' in arrays:
+    assert not (arrays['state_pieces'] >> P).any()
   assert ((s['dyn_layer'][:K] >= 0) & (s['dyn_layer'][:K] < L)).all()
   assert (s['static_top_layer'][:HW] < L).all()
   cells = arrays['state_cells']
@@ -217,7 +223,8 @@ def fuzz_wide(lib, dtype, cases, n, rng):
   lib.campx_wide_tables_bytes.argtypes = [vp]
   lib.campx_wide_tables_build.restype = ctypes.c_int32
   lib.campx_wide_tables_build.argtypes = [vp, vp, vp]
-  pointers = ('state_cells', 'next_state', 'reward', 'done', 'perf', 'variant_top_layer', 'state_variant')
+  pointers = ('state_cells', 'next_state', 'reward', 'done', 'perf', 'variant_top_layer', 'state_variant',
+              'state_pieces')
   # (the host pointers are the harness's; n_states and n_dyn size the caller's own arrays - a
   # caller that lies about them is beyond what a validator can see)
   frozen = [_span(dtype, name) for name in pointers + ('n_states', 'n_dyn')]
@@ -233,7 +240,8 @@ def fuzz_wide(lib, dtype, cases, n, rng):
       sizes = [_span(dtype, name) for name in ('n_variants', 'rows', 'cols')] if 'variant_top_layer' in arrays else []
       _mutate(rng, blob, hot, frozen + sizes)
     else:                                        # ... or the tables the pointers point at
-      names = ['state_cells', 'next_state', 'done'] + [n_ for n_ in ('variant_top_layer', 'state_variant') if n_ in arrays]
+      names = ['state_cells', 'next_state', 'done'] + [n_ for n_ in ('variant_top_layer', 'state_variant', 'state_pieces')
+                                                        if n_ in arrays]
       name = names[int(rng.randint(len(names)))]
       _mutate(rng, arrays[name].view(np.uint8).reshape(-1), [])
     s = blob.view(dtype)[0]
@@ -255,8 +263,9 @@ def fuzz_wide(lib, dtype, cases, n, rng):
       blob_out = np.empty(need, np.uint8)
       rc = lib.campx_wide_tables_build(ptr, blob_out.ctypes.data, None)
       missing = (int(s['n_variants']) > 1 and 'variant_top_layer' not in arrays) or \
-          (int(s['has_perf']) and 'perf' not in arrays)
-      # (a scenery of several variants / a hidden performance, and no array given: refused)
+          (int(s['has_perf']) and 'perf' not in arrays) or \
+          (int(s['n_pieces']) > 0 and 'state_pieces' not in arrays)
+      # (a scenery of several variants or of pieces / a hidden performance, and no array given: refused)
       assert (rc == -1) if missing else (rc in (-3, 0)), (rc, missing)
   return accepted
 

@@ -59,8 +59,9 @@ def _cases():
   shapes = [_blob(gamespec.lower_shapes(gamespec.describe(SHAPE_GAMES[name]()))) for name in sorted(SHAPE_GAMES)]
   wides = []
   import random_pickups
-  tide = random_pickups.builder(random_pickups.definitions()[13])     # a scenery of three variants
-  for build_ in [WIDE_GAMES[name] for name in sorted(WIDE_GAMES)] + [tide]:
+  seasons = random_pickups.builder(random_pickups.definitions()[13])  # a scenery of three variants
+  coins = random_pickups.builder(random_pickups.definitions()[3])     # ... and one of seven pieces
+  for build_ in [WIDE_GAMES[name] for name in sorted(WIDE_GAMES)] + [seasons, coins]:
     spec, arrays = tabulate.to_wide_spec(tabulate.trace(build_()))
     wides.append((_blob(spec), {k: (None if k == 'perf' and not spec.has_perf else np.array(v))
                                 for k, v in arrays.items()}))

@@ -1,18 +1,22 @@
-"""A seeded family of 9 games whose drapes cover SEVERAL cells that come and go
-(tests/random_pickups.py: coins taken one by one, coins that come back, ice that breaks behind the
-walker - tests/traced_games.py's Coins / ReturningCoins / ThinIce) against what the REFERENCE's
-engine, renderer and Plot did with the very same classes (tests/golden/random_pickups.npz,
-make_random_golden.py pickups).  The reference's Drape has no one-cell limit
-(campx/things.py:161-262); VERDICT r5 named such drapes as the first thing the batched tiers
-refuse that PyColab games do.  The tabulator now tracks one thing per cell the drape ever covers
-(`TracedGame.piece_cell`), two to seven of them here, with and without an episode end, with a
-hidden Plot entry on top (the ice).  And the second thing the verdict named: a `Backdrop.update()`
-that changes the scenery (`Lamps`, campx/things.py:103-148) - every (cell, character) the
-backdrop ever shows beyond its first picture is a piece painted behind every thing
-(`TracedGame.in_backdrop`), three games of it - and when its pictures differ in more cells than
-there are tracked things to spare (a switch turns the WHOLE floor: `Tide`, `Seasons`), the pictures
-become variants of the scenery that the state names (`TracedGame.variants`,
-`CampxWideSpec.n_variants`: the render kernel lays each environment's own variant); three games.
+"""A seeded family of 15 games whose SCENERY changes (tests/random_pickups.py) against what the
+REFERENCE's engine, renderer and Plot did with the very same classes
+(tests/golden/random_pickups.npz, make_random_golden.py pickups): drapes that cover SEVERAL cells
+which come and go - coins taken one by one, coins that come back, ice that breaks behind the walker
+(tests/traced_games.py's Coins / ReturningCoins / ThinIce; the reference's Drape has no one-cell
+limit, campx/things.py:161-262) - and a `Backdrop.update()` that repaints the scenery (`Lamps`,
+`Tide`, `Seasons`; campx/things.py:103-148): the two things VERDICT r5 named as what the batched
+tiers refuse that PyColab games do.
+
+The tabulator describes such cells as PIECES (`TracedGame.piece_cell` / `in_backdrop`: one per cell
+a drape ever covers, one per (cell, character) a Backdrop shows beyond its first picture) and hands
+them to the kernels in one of three ways, all three held against the reference's frames here:
+  * three tracked things or fewer, none in the Backdrop: pieces as THINGS of the one-cell tier;
+  * up to sixteen pieces beside an ordinary mover: a MASK of the pieces that show, one 16-bit value
+    per state (`CampxWideSpec.n_pieces`; the render kernel patches them from one trace entry a row);
+  * more cells than that - a switch turns the WHOLE floor: `Tide`, `Seasons` - as VARIANTS of the
+    scenery the state names (`TracedGame.variants`, `CampxWideSpec.n_variants`).
+`ROUTES` below runs some games down the road they would not take by themselves (the bounds
+lowered), so that every road sees drapes and Backdrops both.
 
 Per game: (a) the generator still makes the fixture's game; (b) this repo's generic tier gives
 the reference engine's frames; (c) so does the table tabulated from the classes, walked on the
@@ -42,13 +46,28 @@ def _gold(k):
 
 
 _TRACED = {}
+# (game, road): every game down its own road, some down the others
+ROUTES = ([(k, 'own') for k in range(len(DEFS))] + [(k, 'variants') for k in (3, 5, 10)] +
+          [(k, 'things') for k in (3, 4, 9, 10)])
+ROUTE_IDS = ['{}-{}'.format(IDS[k], road) for k, road in ROUTES]
 
 
-def _traced(k):
-  """Game k tabulated (once per test process: the one-frame-per-play walker takes 1-4 s a game)."""
-  if k not in _TRACED:
-    _TRACED[k] = tabulate.trace(random_pickups.builder(DEFS[k])(), cache=False)
-  return _TRACED[k]
+def _road(monkeypatch, road):
+  """The bounds that decide how pieces reach the kernels, lowered: 'variants' = no mask;
+  'things' = no mask and one picture only (round 6's first form: a tracked thing per piece)."""
+  from campx_amd import gamespec
+  if road in ('variants', 'things'):
+    monkeypatch.setattr(gamespec, 'WIDE_MAX_PIECES', 0)
+  if road == 'things':
+    monkeypatch.setattr(gamespec, 'WIDE_MAX_VARIANTS', 1)
+
+
+def _traced(k, road='own'):
+  """Game k tabulated (once per test process: the one-frame-per-play walker takes 1-4 s a game);
+  call under `_road()` for a road that is not the game's own."""
+  if (k, road) not in _TRACED:
+    _TRACED[k, road] = tabulate.trace(random_pickups.builder(DEFS[k])(), cache=False)
+  return _TRACED[k, road]
 
 
 def _same(a, b):
@@ -66,58 +85,84 @@ def test_the_generator_still_makes_the_games_of_the_fixture():
     assert json.loads(str(gold['meta'])) == dict(kind=d['kind']), k
 
 
-def test_several_cell_drapes_and_changing_backdrops_become_pieces_or_variants():
-  """Few pieces - at most three tracked things, none in the Backdrop - stay pieces, on the cell-indexed
-  tables; everything else becomes VARIANTS of the scenery (the Backdrop's picture and the several-cell
-  drapes' curtains together), one tracked value beside the walker."""
+def test_how_the_pieces_of_each_game_reach_the_kernels():
+  import ctypes
+  from campx_amd import _hip
   kinds = {}
   for k, d in enumerate(DEFS):
     traced = _traced(k)
     W = len(d['art'][0])
     where = lambda ch: [r * W + c for r, row in enumerate(d['art']) for c, x in enumerate(row) if x == ch]
     ch = {'ice': '~', 'coins': 'o', 'returning': 'o'}.get(d['kind'])
-    n = len(where(ch)) if ch else 0
-    if ch and n <= 2 and d['kind'] != 'ice':
-      # pieces: one tracked thing per cell the drape ever covers, all of its character
+    if ch:
+      # one piece per cell the drape ever covers, all of its character
+      n = len(where(ch))
       assert traced.movers == ['A'] + [ch] * n and traced.piece_cell == [None] + where(ch), (k, traced.movers)
-      assert len(traced.variants) == 1 and traced.dense_reason is None and not any(traced.in_backdrop)
-      kinds['pieces'] = kinds.get('pieces', 0) + 1
-      continue
-    assert traced.movers == ['A'] and traced.piece_cell == [None], (k, traced.movers)
-    V = len(traced.variants)
-    assert 2 <= V <= 256 and set(traced.st_variant.tolist()) == set(range(V))
-    assert traced.dense_reason.startswith('the scenery changes')
-    if ch:                       # the drape's curtains are part of the pictures; the Backdrop stays
-      assert all(sorted(m) == [ch] for m in traced.variant_masks)
-      assert all((v == traced.variants[0]).all() for v in traced.variants)
-      assert traced.variant_masks[0][ch].reshape(-1).nonzero()[0].tolist() == where(ch)
-      assert V <= 2 ** n and not any(name == ch for name, _ in traced.statics)
-    else:                        # the Backdrop's own pictures
+      assert len(traced.variants) == 1 and not any(traced.in_backdrop)
+      if n <= 2:                 # three tracked things: the cell-indexed tables
+        assert traced.dense_reason is None and not traced.pieces_as_mask
+        kinds['things'] = kinds.get('things', 0) + 1
+        continue
+    elif d['kind'] == 'lamps':
+      # one piece per (cell, character) the Backdrop shows beyond its first picture
+      lamps = where(':') + where('*')
+      assert traced.movers[0] == 'A' and traced.in_backdrop == [False] + [True] * len(lamps)
+      assert sorted(traced.piece_cell[1:]) == sorted(lamps) and len(traced.variants) == 1
+    else:                        # the whole floor turns: the Backdrop's own pictures
+      assert traced.movers == ['A'] and traced.piece_cell == [None] and not traced.pieces_as_mask
+      V = len(traced.variants)
+      assert V == {'tide': 2, 'seasons': 3}[d['kind']] and set(traced.st_variant.tolist()) == set(range(V))
       assert all(m == {} for m in traced.variant_masks)
-      assert V == {'tide': 2, 'seasons': 3}.get(d['kind'], V)
-      if d['kind'] == 'lamps':
-        assert V == 2 ** len(where(':') + where('*'))
-    kinds[d['kind']] = kinds.get(d['kind'], 0) + 1
+      spec, arrays = tabulate.to_wide_spec(traced)
+      assert (spec.n_dyn, spec.n_pieces, spec.n_variants) == (1, 0, V)
+      assert arrays['variant_top_layer'].shape == (V, len(d['art']) * W)
+      assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
+      arrays['state_variant'][min(3, traced.n_states - 1)] = V          # a variant that is not there
+      assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
+      kinds[d['kind']] = kinds.get(d['kind'], 0) + 1
+      continue
+    # a mask: the walker is the kernels' one thing, the pieces are bits
+    assert traced.pieces_as_mask and traced.dense_reason
     spec, arrays = tabulate.to_wide_spec(traced)
-    assert spec.n_variants == V and arrays['variant_top_layer'].shape == (V, len(d['art']) * W)
-    from campx_amd import _hip
-    import ctypes
+    P = len(traced.movers) - 1
+    assert (spec.n_dyn, spec.n_pieces, spec.n_variants) == (1, P, 0) and arrays['state_cells'].shape[1] == 1
+    assert list(spec.piece_cell[:P]) == traced.piece_cell[1:]
+    assert [traced.chars[i] for i in spec.piece_layer[:P]] == traced.movers[1:]
+    shown = arrays['state_pieces']
+    assert shown.dtype == np.uint16 and int(shown.max()) < (1 << P)
+    for p in range(P):
+      assert np.array_equal((shown >> p) & 1, traced.st_shows[:, 1 + p])
+    assert len(set(shown.tolist())) > P                                   # (many pictures, one plane)
     assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
-    arrays['state_variant'][min(3, traced.n_states - 1)] = V          # a variant that is not there
+    shown[min(3, traced.n_states - 1)] = 1 << P                         # a piece that is not there
     assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
-  assert kinds == {'pieces': 3, 'ice': 3, 'coins': 2, 'returning': 1, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
+    shown[min(3, traced.n_states - 1)] = 0
+    spec.piece_cell[0] = len(d['art']) * W                                # off the board
+    assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
+    kinds[d['kind']] = kinds.get(d['kind'], 0) + 1
+  assert kinds == {'things': 3, 'ice': 3, 'coins': 2, 'returning': 1, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
 
 
-def test_past_the_variants_the_pieces_and_past_the_pieces_a_refusal(monkeypatch):
-  """More pictures than the kernels hold sets of rows for (here: the bound lowered to one): pieces
-  again - a tracked thing per cell, the Backdrop's painted behind every thing - up to eight."""
-  from campx_amd import gamespec
-  monkeypatch.setattr(gamespec, 'WIDE_MAX_VARIANTS', 1)
-  lamps = tabulate.trace(random_pickups.builder(DEFS[10])(), cache=False)       # four lamps in the Backdrop
+def test_past_the_mask_the_variants_then_things_then_a_refusal(monkeypatch):
+  """More pieces than the mask has bits (here: the bound lowered to none): the scenery's pictures
+  as variants, the several-cell drapes' curtains part of them; more pictures than the kernels hold
+  sets of rows for (the bound lowered to one): a tracked thing per piece, up to eight."""
+  _road(monkeypatch, 'variants')
+  coins = _traced(3, 'variants')                                             # seven coins: 51 pictures
+  assert coins.movers == ['A'] and coins.piece_cell == [None] and not coins.pieces_as_mask
+  V = len(coins.variants)
+  assert 7 < V <= 2 ** 7 and set(coins.st_variant.tolist()) == set(range(V))
+  assert all(sorted(m) == ['o'] for m in coins.variant_masks)
+  assert all((v == coins.variants[0]).all() for v in coins.variants)         # (the Backdrop stays)
+  assert not any(name == 'o' for name, _ in coins.statics)
+  lamps = _traced(10, 'variants')                                            # four lamps: 16 pictures
+  assert lamps.movers == ['A'] and len(lamps.variants) == 16 and all(m == {} for m in lamps.variant_masks)
+  _road(monkeypatch, 'things')
+  lamps = _traced(10, 'things')
   assert lamps.movers[0] == 'A' and lamps.in_backdrop == [False] + [True] * 4 and len(lamps.variants) == 1
-  assert sorted(zip(lamps.piece_cell[1:], lamps.movers[1:])) == list(zip(lamps.piece_cell[1:], lamps.movers[1:]))
-  coins = tabulate.trace(random_pickups.builder(DEFS[3])(), cache=False)        # seven coins
-  assert coins.movers == ['A'] + ['o'] * 7 and len(coins.variants) == 1
+  assert not lamps.pieces_as_mask and tabulate.to_wide_spec(lamps)[0].n_dyn == 5
+  coins = _traced(3, 'things')
+  assert coins.movers == ['A'] + ['o'] * 7 and len(coins.variants) == 1 and not coins.pieces_as_mask
   import traced_games as tg
   art = ['##########', '#Aooooooo#', '#o       #', '##########']
   game = tg.ascii_art_to_game(art, what_lies_beneath=' ', drapes={'A': tg.Forager, 'o': tg.Coins, '#': tg.things.FixedDrape},
@@ -148,12 +193,13 @@ def test_generic_tier_gives_the_reference_engines_frames(k):
       assert int(game.game_over) == gold['done'][t, n]
 
 
-@pytest.mark.parametrize('k', range(len(DEFS)), ids=IDS)
-def test_the_table_tabulated_from_the_classes_gives_them_too(k):
+@pytest.mark.parametrize('k,road', ROUTES, ids=ROUTE_IDS)
+def test_the_table_tabulated_from_the_classes_gives_them_too(k, road, monkeypatch):
   from oracle.table_replay import StateWalker, TableWalker
   gold = _gold(k)
   T, N = gold['actions'].shape
-  traced = _traced(k)
+  _road(monkeypatch, road)
+  traced = _traced(k, road)
   assert [ord(c) for c in traced.chars] == gold['chars'].tolist()
   if traced.dense_reason is not None:
     walker = StateWalker(traced, N)
@@ -172,10 +218,11 @@ def test_the_table_tabulated_from_the_classes_gives_them_too(k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('k', range(len(DEFS)), ids=IDS)
-def test_hip_path_gives_the_reference_engines_frames(k):
+@pytest.mark.parametrize('k,road', ROUTES, ids=ROUTE_IDS)
+def test_hip_path_gives_the_reference_engines_frames(k, road, monkeypatch):
   gold = _gold(k)
   T, N = gold['actions'].shape
+  _road(monkeypatch, road)
   build = random_pickups.builder(DEFS[k])
   game = build(batch=N, device='cuda')
   first, _, _ = game.its_showtime()
@@ -199,10 +246,12 @@ def test_hip_path_gives_the_reference_engines_frames(k):
   # ... and at a size the kernels' workgroups fill: 4 096 environments against the host's walker
   from oracle.table_replay import StateWalker, TableWalker
   B = 4096
-  traced = _traced(k)
+  traced = _traced(k, road)
+  for_road = {'own': None, 'variants': lambda f: f.spec.n_variants > 1, 'things': lambda f: f.spec.n_dyn > 1}[road]
   acts = np.random.RandomState(40 + k).randint(0, 5, size=(60, B)).astype(np.int8)
   game = build(batch=B, device='cuda')
   game.its_showtime()
+  assert for_road is None or for_road(game.fused), road
   out = game.rollout(torch.from_numpy(acts), want_board=True)
   if traced.dense_reason is not None:
     walker = StateWalker(traced, B)

@@ -299,7 +299,7 @@ def test_a_warehouse_of_half_a_million_states_tabulates_in_seconds_and_predicts_
   game = tabulate.trace(lanes_games.warehouse(), cache=False)
   took = time.perf_counter() - t0
   assert game.n_states == 592588 and game.movers == ['X', 'Y', 'P'] and game.dense_reason
-  assert took < 30.0, took
+  assert took < 90.0, took       # (15-20 s on eight idle cores; the bound leaves room for a loaded machine)
   assert game.n_plays < 600                       # frames of Python, each over a whole level
   # the table against the user's classes on the generic tier: three random walks
   acts = tabulate.default_actions()
