@@ -16,7 +16,7 @@ import numpy as np
 
 import traced_games as tg
 
-N_GAMES = 15
+N_GAMES = 16
 SEED = 61020261
 
 
@@ -62,7 +62,11 @@ def definitions():
   plan = [('coins', 2), ('returning', 2), ('ice', 4), ('coins', 7), ('returning', 3), ('ice', 6),
           ('coins', 4), ('returning', 2), ('ice', 3), ('lamps', 2), ('lamps', 4), ('lamps', 3),
           ('tide', 2), ('seasons', 1), ('tide', 3)]
-  return [_one(rng, kind, n) for kind, n in plan]
+  games = [_one(rng, kind, n) for kind, n in plan]
+  # ... and one by hand: NINE tiles of ice in two rows - more pieces than a byte has bits (the
+  # state-table tier hands pieces to the render kernel as a 16-bit mask), 1 097 reachable states
+  games.append(dict(kind='ice', art=['#######', '#A~~~~#', '#~~~~~#', '#######']))
+  return games
 
 
 def builder(d):

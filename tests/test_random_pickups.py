@@ -1,4 +1,4 @@
-"""A seeded family of 15 games whose SCENERY changes (tests/random_pickups.py) against what the
+"""A seeded family of 16 games whose SCENERY changes (tests/random_pickups.py) against what the
 REFERENCE's engine, renderer and Plot did with the very same classes
 (tests/golden/random_pickups.npz, make_random_golden.py pickups): drapes that cover SEVERAL cells
 which come and go - coins taken one by one, coins that come back, ice that breaks behind the walker
@@ -133,6 +133,8 @@ def test_how_the_pieces_of_each_game_reach_the_kernels():
     for p in range(P):
       assert np.array_equal((shown >> p) & 1, traced.st_shows[:, 1 + p])
     assert len(set(shown.tolist())) > P                                   # (many pictures, one plane)
+    if k == 15:                  # nine tiles of ice: the mask's second byte
+      assert P == 9 and int(shown.max()) == 0x1ff and traced.n_states == 1097
     assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == 0
     shown[min(3, traced.n_states - 1)] = 1 << P                         # a piece that is not there
     assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
@@ -140,7 +142,7 @@ def test_how_the_pieces_of_each_game_reach_the_kernels():
     spec.piece_cell[0] = len(d['art']) * W                                # off the board
     assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
     kinds[d['kind']] = kinds.get(d['kind'], 0) + 1
-  assert kinds == {'things': 3, 'ice': 3, 'coins': 2, 'returning': 1, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
+  assert kinds == {'things': 3, 'ice': 4, 'coins': 2, 'returning': 1, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
 
 
 def test_past_the_mask_the_variants_then_things_then_a_refusal(monkeypatch):
