@@ -78,7 +78,7 @@ def _same(a, b):
 
 
 def test_the_generator_still_makes_the_games_of_the_fixture():
-  assert len(DEFS) == random_pickups.N_GAMES == 15
+  assert len(DEFS) == random_pickups.N_GAMES == 16
   for k, d in enumerate(DEFS):
     gold = _gold(k)
     assert [''.join(chr(c) for c in row) for row in gold['art']] == d['art'], k
