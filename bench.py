@@ -54,7 +54,10 @@ BYTES_PER_ENV_STEP = {'boat_race': 184, 'wall_world': 509, 'sokoban': 194,
                       # 16x16 sokoban, two boxes: 6 characters, three movers (S = 6)
                       'sokoban16': 6 * 256 + 4 + 1 + 12 + 1,
                       # Hello World 13x36 (shape tier): 7 characters, five things' offsets (S = 10)
-                      'hello_world': 7 * 468 + 4 + 1 + 20 + 1}
+                      'hello_world': 7 * 468 + 4 + 1 + 20 + 1,
+                      # a user-written coin field 6x10 (state-table tier): 5 characters, the walker's
+                      # plane of the trace and the mask of the coins that show (S = 2)
+                      'coin_field': 5 * 60 + 4 + 1 + 4 + 1}
 WORKLOADS = {
     'boat_race': ('boat_race 5x5', 65536),
     'wall_world': ('Demo-2 wall world 10x10, 4 drapes', 262144),
@@ -70,12 +73,24 @@ WORKLOADS = {
     'sokoban16': ('sokoban 16x16 with two boxes (build-authored level 3, wide tier)', 65536),
     # not a BASELINE config: the reference's Hello World notebook (rigid multi-cell things, trails)
     'hello_world': ('Hello World 13x36, 7 characters, trails (shape tier)', 32768),
+    # not a BASELINE config: plain Python update() classes (examples/coins_batched.py without its
+    # switch), tabulated on the host during its_showtime(); a drape of three coins that are taken
+    # one by one = pieces of the scenery in a 16-bit mask per state (round 6)
+    'coin_field': ('coin field 6x10, user-written plain Python classes, three coins in one drape '
+                   '(state-table tier, pieces in a mask)', 262144),
 }
+NO_C_ORACLE = ('coin_field',)      # plain Python classes: no rule description for oracle/campx_oracle.c
 
 
 def build_game(game_name, **where):
   """The library game behind a --game name (set up, not started)."""
   from campx_amd import games
+  if game_name == 'coin_field':
+    examples = os.path.join(REPO, 'examples')
+    if examples not in sys.path:
+      sys.path.insert(0, examples)
+    import coins_batched
+    return coins_batched.make_game(floor=False, **where)
   if game_name.startswith('sokoban_l'):
     return games.sokoban.build(level=int(game_name[-1]), **where)
   if game_name == 'sokoban16':
@@ -875,7 +890,7 @@ def run_rank(args):
     solo = world == 1 and standin is None and not args.force_dist
     if affinity_before is not None:
       os.sched_setaffinity(0, affinity_before)      # the CPU baselines below use every core
-    if solo and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline and args.game not in NO_C_ORACLE:
       line['cpu_baseline'] = cpu_baseline(args.game, T, args.cpu_seconds,
                                           batch=4096 if args.game.startswith(('maze', 'sokoban16', 'hello')) else 65536)
       line['cpu_baseline']['generic_b1'] = generic_b1()
@@ -891,7 +906,7 @@ def run_rank(args):
       also = []
       # (maze16, sokoban16: not BASELINE configs - the wide tier, boards above 128 cells; the
       # second one's 4.4 M-state table is enumerated on the device during its_showtime())
-      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16', 'hello_world'):
+      for other in ('wall_world', 'sokoban', 'maze16', 'sokoban16', 'hello_world', 'coin_field'):
         oname, ob = WORKLOADS[other]
         steps = args.steps
         om = measure_rollout(other, ob, T, steps, args.warmup, device, 0, None, 0,
@@ -904,7 +919,7 @@ def run_rank(args):
             'settle_launches': om['settle'],
             'roofline': roofline(other, ob, T, om['fused'], om['kernel_ms'],
                                  om['per_launch_ms'], om.get('ceiling')),
-            'cpu_baseline': None if args.no_cpu_baseline else
+            'cpu_baseline': None if args.no_cpu_baseline or other in NO_C_ORACLE else
                             cpu_baseline(other, T, args.cpu_seconds / 2,
                                          batch=4096 if other.startswith(('maze', 'sokoban16', 'hello')) else ob)}
         for note in ('traffic_note', 'kernel_note'):      # (said once, in the headline's roofline)

@@ -11,10 +11,12 @@ PyColab games are written: plain Python `update()` methods, nothing from the rul
 
 The reference's Drape sets no one-cell limit and its Backdrop may repaint itself
 (campx/things.py:161-262, 103-148).  A batched Engine tabulates the classes on the host by running
-them over every reachable state: the coins become one tracked thing per cell, the two floors two
-VARIANTS of the scenery that the state names, and the state-table kernels run the game - each
-environment's own floor laid by the render kernel.  The classes also run,
-unchanged, on the single-environment generic tier.
+them over every reachable state: the walker is the one thing the kernels track cell by cell; the
+floor and the coins that are left are thirteen pictures of the scenery - VARIANTS that the state
+names, each environment's own laid by the render kernel.  Without the switch
+(`make_game(floor=False)`: a plain Backdrop) the three coins are PIECES of the scenery: which of them
+show is a 16-bit mask per state that the render kernel patches onto the one scenery row.  The
+classes also run, unchanged, on the single-environment generic tier.
 
     python examples/coins_batched.py --batch 65536 --frames 100
 
@@ -88,7 +90,12 @@ class Floor(things.Backdrop):
       the_plot.add_reward(0.25)
 
 
-def make_game(**where):
+def make_game(floor=True, **where):
+  if not floor:        # the coin field alone: no switch, a Backdrop that stays
+    art = [row.replace('s', ' ').replace('.', ' ') for row in ART]
+    return ascii_art_to_game(art, what_lies_beneath=' ',
+                             drapes={'A': Walker, 'o': Coins, '#': things.FixedDrape, 'E': things.FixedDrape},
+                             z_order='oEA#', update_schedule='Ao#E', **where)
   return ascii_art_to_game(ART, what_lies_beneath=' ', backdrop=Floor,
                            drapes={'A': Walker, 'o': Coins, '#': things.FixedDrape, 's': things.FixedDrape,
                                    'E': things.FixedDrape},

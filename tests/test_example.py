@@ -93,8 +93,9 @@ def test_deferred_rollouts_example_runs():
 
 def test_coins_example_runs_on_the_generic_tier_and_tabulates():
   """examples/coins_batched.py: ordinary CampX classes - a drape of three coins, a Backdrop that
-  repaints the whole floor - on one environment without a GPU, and through the tabulator: the coins
-  one tracked thing per cell, the floors two variants of the scenery."""
+  repaints the whole floor - on one environment without a GPU, and through the tabulator: the floors
+  and the coins that are left are variants of the scenery; without the switch the coins are pieces in
+  a mask."""
   sys.path.insert(0, os.path.join(REPO, 'examples'))
   import torch
   import coins_batched as ex
@@ -116,6 +117,13 @@ def test_coins_example_runs_on_the_generic_tier_and_tabulates():
   assert all(sorted(m) == ['o'] for m in traced.variant_masks)
   assert traced.variant_masks[0]['o'].reshape(-1).nonzero()[0].tolist() == [14, 31, 38]
   assert len({v.tobytes() for v in traced.variants}) == 2               # day and night
+  # the coin field alone (what bench.py's `coin_field` row runs): three pieces beside the walker
+  field = tabulate.trace(ex.make_game(floor=False))
+  assert field.movers == ['A', 'o', 'o', 'o'] and field.piece_cell == [None, 14, 31, 38] and field.pieces_as_mask
+  spec, arrays = tabulate.to_wide_spec(field)
+  assert (spec.n_dyn, spec.n_pieces, spec.n_variants, spec.n_layers) == (1, 3, 0, 5)
+  # (every subset of the coins is reached but one: the way to the third leads over one of the others)
+  assert sorted(set(arrays['state_pieces'].tolist())) == [0, 1, 2, 4, 5, 6, 7]
 
 
 @pytest.mark.gpu
@@ -127,3 +135,11 @@ def test_coins_example_runs_batched():
   f = got['game'].fused
   assert isinstance(f, wide.WideGame) and 2 < got['variants'] <= 16 and got['movers'] == ['A']
   assert f.spec.n_variants == got['variants'] and got['rate'] > 1e6 and got['out']['obs'].shape == (60, 2048, 7, 6, 10)
+  # ... and bench.py's `coin_field` row builds the game it says it does
+  sys.path.insert(0, REPO)
+  import bench
+  game = bench.build_game('coin_field', batch=512, device='cuda')
+  game.its_showtime()
+  assert isinstance(game.fused, wide.WideGame) and (game.fused.spec.n_dyn, game.fused.spec.n_pieces) == (1, 3)
+  row = game.fused.n_layers * game.fused.rows * game.fused.cols
+  assert bench.BYTES_PER_ENV_STEP['coin_field'] == row + 4 + 1 + 2 * game.fused._n_planes + 1
