@@ -42,18 +42,20 @@ under conditions that are CHECKED while tabulating (TabulationError otherwise):
   is not `visible` (campx/things.py:294-296, 391-392; engine.py:314 skips it) are "absent",
   tabulated as standing on a cell index the thing never occupies and never shown.  A drape
   that covers SEVERAL cells which come and go (coins taken one by one; campx/things.py:161-262
-  sets no one-cell limit) is tracked as one thing per cell it ever covers - on its cell while
-  the curtain has it, absent otherwise (round 6, `TracedGame.piece_cell`).  There are at most
+  sets no one-cell limit) is described as one PIECE per cell it ever covers - on its cell while
+  the curtain has it, absent otherwise (round 6, `TracedGame.piece_cell`; `_finish` decides how
+  pieces reach the kernels: as tracked things, as a 16-bit mask per state, or folded into
+  variants of the scenery).  There are at most
   four tracked things -
   the mode counts as one, and it has at most rows*cols values (beyond either: the game runs
   from its STATE table, the wide tier, which only needs the state count to fit) -,
   the board has at most 128 cells (one mover and one mode: 1 024, the wide tier,
   csrc/k_wide.hip) and 16 characters;
 * a Backdrop whose curtain changes (a `Backdrop.update()` of its own, campx/things.py:103-148; a
-  sprite painted into the backdrop, campx/rendering.py:128,150) is tracked the same way: one
+  sprite painted into the backdrop, campx/rendering.py:128,150) is described the same way: one
   piece per (cell, character) it ever shows beyond its first picture, painted on the backdrop
   itself, behind every thing (round 6, `TracedGame.in_backdrop`; such a game runs from its state
-  table); no reached z-order changes how the SCENERY paints (two overlapping static drapes
+  table) - or, more than sixteen of them, its pictures become the scenery's variants; no reached z-order changes how the SCENERY paints (two overlapping static drapes
   swapping places);
 * every rendered board equals "backdrop, then things in the state's z-order" computed from
   the cells alone - which also yields whether a moving thing is the character its cell shows;

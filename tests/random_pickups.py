@@ -7,8 +7,9 @@ random boards, two to seven such cells a game, some with an exit that ends the e
 changes ALL OVER - `Tide` / `Seasons`: a switch turns the whole floor, two or three pictures of
 dozens of cells, which the tabulator tracks as VARIANTS of the scenery.  The
 reference's `Drape` sets no one-cell limit (campx/things.py:161-262); until round 6 the batched
-tiers did, and these games ran on the generic tier only.  Now the tabulator tracks one thing per
-cell such a drape ever covers, and the state-table kernels run them - against the REFERENCE's
+tiers did, and these games ran on the generic tier only.  Now the tabulator describes such cells
+as pieces of the scenery (tests/test_random_pickups.py says how they reach the kernels), and the
+state-table kernels run them - against the REFERENCE's
 engine, renderer and Plot (tests/golden/random_pickups.npz, make_random_golden.py pickups: this
 very file imported where `campx` is the reference)."""
 
