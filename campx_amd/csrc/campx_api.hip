@@ -58,7 +58,7 @@ static KnobRow g_knobs[K_COUNT] = {
     // largest trace one update + render pair of a rollout works on; a longer rollout runs in chunks
     // of whole frames (the render's trace reads then hit the memory-side cache: profiles/r02_sweep.txt).
     // 0: a chunk per frame (tests/test_chunked_rollouts.py runs the chunked form at test sizes)
-    {"trace_chunk_mb", 16, 0, 1 << 20, "MiB of trace per update + render pair of a chunked rollout"},
+    {"trace_chunk_mb", 16, 0, 1 << 20, "MiB of trace per update + render pair of a chunked rollout (state-table tier: x 4, all planes)"},
     {"trace_whole_mb", 28, 0, 1 << 20, "largest trace (MiB) a rollout may have and still run as one pair"},
     // frame-major shape tier: environment-frames per chunk, in thousands (profiles/r05_shape_rocprofv3.txt)
     {"shape_chunk_kf", 2000, 1, 1 << 30, "thousand environment-frames per chunk of a frame-major shape rollout"},

@@ -124,8 +124,9 @@ constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 // per (frame, environment), the 16-bit mask of the pieces that show; the wave patches them onto
 // the plain scenery like the things (a byte set in the piece's layer, the scenery's byte under it
 // cleared) from ONE trace entry per row however many pieces there are - eight things tracked
-// one by one load sixteen slots a row (2.6 TB/s on a 4x9 board), a scenery in variants waits for
-// the entry before it can fetch its row (4.4-5.7): here nothing waits for anything but the trace.
+// one by one load sixteen slots a row (3.5 TB/s on a 4x9 board against 6.25 this way), a scenery
+// in variants waits for the entry before it can fetch its row (5.2): here nothing waits for
+// anything but the trace.
 template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false, bool kWide = false,
           int kScen = 0>
 __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
@@ -272,6 +273,9 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
       // (above), the same; the thing count a template argument instead of the run-time-K
       // instantiation, 5.0 / 5.4; and with all that ONE load again, of the variant the staged entry
       // names, 5.4 / 5.7 - what ships: the second trip costs less than a second candidate's bytes.
+      // (All of these with a trace of two 52 MB planes read back from HBM: since the state-table
+      // tier cuts such launches into chunks whose trace stays cached - campx_wide_rollout_launch -
+      // the shipped form reads 6.42 against the plain kernel's 6.65.)
       // (Plain functions of values throughout: a form with closures over the vectors put 80 bytes
       // a lane into scratch memory - 1.3 TB/s.)
       const int8_t* here = rot + at;

@@ -24,6 +24,8 @@ struct WideParams {
   int32_t n_states, n_dyn;
   int32_t has_dcodes;          // some entry of the table carries a discount code
   float discounts[16];
+  int64_t plane;               // entries from one thing's plane of the trace to the next's (the
+                               // whole rollout's frames x row pitch, also when a launch runs a chunk of them)
 };
 
 // Table-blob entry of (state, action): x = reward; y = [0:23] the state after the frame,
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_update_kernel(
   }
   uint32_t from = over ? 0u : now;
   uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
-  const int64_t P = row_pitch(out, B), plane = (int64_t)T * P;
+  const int64_t P = row_pitch(out, B), plane = wp.plane;
   int bad = 0;
   int64_t at = env;                                // element (frame, env) of the [T, P] streams
   // The actions of a chunk of frames are loaded ONE CHUNK AHEAD, before the previous chunk's
@@ -847,10 +849,12 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   WideParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.n_states = s->n_states;
-  wp.n_dyn = w.n_planes;           // (planes the update pass writes: the variant's is one of them)
+  wp.n_dyn = w.n_planes;           // (planes the update pass writes: the variant's / the pieces' is one of them)
   wp.discounts[0] = 1.0f;
   for (int i = 1; i < 16; ++i) wp.discounts[i] = s->discount_list[i];
   wp.has_dcodes = s->any_dcode;
+  const int64_t pitch = row_pitch(out, B);
+  wp.plane = (int64_t)T * pitch;
   const char* blob = static_cast<const char*>(tables_dev);
   const uint2* entries = reinterpret_cast<const uint2*>(blob);
   const u32x4* cells = reinterpret_cast<const u32x4*>(blob + w.cells_off);
@@ -864,21 +868,53 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   const bool in_lds = want <= lds_max;
   const size_t lds = in_lds ? want : 0;
   const dim3 grid((unsigned)((B + kWideThreads - 1) / kWideThreads));
+  // The render kernel runs at the write ceiling only while the trace it reads stays cached
+  // (launch_split() in campx_api.hip has the one-cell tier's numbers).  Here an entry is two
+  // bytes and a game has up to nine planes.  The coin field of examples/coins_batched.py, B = 262 144,
+  // T = 100, TB/s of observations in one piece / in chunks whose trace - all planes - is at most
+  // 16 / 32 / 64 MB (tools/bench_pieces.py, profiles/r06_variants.txt): the walker's plane and the
+  // pieces' mask, 105 MB: 6.20 / 6.49 / 6.63 / 6.71; the same with a scenery in seven variants:
+  // 5.01 / 5.57 / 5.65 / 5.69; four planes of things, 210 MB: 4.09 / 6.36 / 6.37 / 6.53; one plane of
+  // 52 MB in one piece loses nothing (6.64 against the one-cell tier's 6.75).  So: a launch whose
+  // trace is more than 4 x trace_chunk_mb (64 MB) runs as chunks of frames of at most that much,
+  // update pass and render alternating.
+  const int64_t per_frame = pitch * (int64_t)sizeof(uint16_t) * w.n_planes;
+  int64_t chunk = (4 * (knob(K_TRACE_CHUNK_MB) << 20)) / per_frame;
+  chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
+  const bool whole = T <= chunk || wide_last_only(out);
+  const int64_t elem = out.obs_format == CAMPX_OBS_INT8 ? 1 : 2;
+  const uint16_t* trace0 = reinterpret_cast<const uint16_t*>(out.trace);
+  for (int64_t t0 = 0; t0 < T; t0 += whole ? T : chunk) {
+    const int32_t n = whole ? T : (int32_t)(T - t0 < chunk ? T - t0 : chunk);
+    CampxOutputs part = out;
+    if (!whole) {
+      part.obs = out.obs + t0 * out.obs_t_stride * elem;
+      if (out.board) part.board = out.board + t0 * out.board_t_stride;
+      if (out.reward) part.reward = out.reward + t0 * pitch;
+      if (out.discount) part.discount = out.discount + t0 * pitch;
+      if (out.done) part.done = out.done + t0 * pitch;
+      if (out.perf) part.perf = out.perf + t0 * pitch;
+      part.trace = reinterpret_cast<uint8_t*>(const_cast<uint16_t*>(trace0 + t0 * pitch));
+    }
+    const int8_t* acts = actions + t0 * B;
+    const int32_t first = t0 == 0 ? reset_first : 0;
 #define CAMPX_WIDE_LAUNCH(LDS, PERF)                                                              \
   do {                                                                                            \
     CAMPX_ALLOW_LDS((wide_update_kernel<LDS, PERF>), lds);                                        \
     hipLaunchKernelGGL((wide_update_kernel<LDS, PERF>), grid, dim3(kWideThreads), lds, hs, wp,    \
-                       entries, cells, perf, state, st, actions, out, B, T, reset_first);         \
+                       entries, cells, perf, state, st, acts, part, B, n, first);                 \
   } while (0)
-  if (in_lds && out.perf) CAMPX_WIDE_LAUNCH(true, true);
-  else if (in_lds) CAMPX_WIDE_LAUNCH(true, false);
-  else if (out.perf) CAMPX_WIDE_LAUNCH(false, true);
-  else CAMPX_WIDE_LAUNCH(false, false);
+    if (in_lds && out.perf) CAMPX_WIDE_LAUNCH(true, true);
+    else if (in_lds) CAMPX_WIDE_LAUNCH(true, false);
+    else if (out.perf) CAMPX_WIDE_LAUNCH(false, true);
+    else CAMPX_WIDE_LAUNCH(false, false);
 #undef CAMPX_WIDE_LAUNCH
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_failed(e);
-  return wide_renders(*s, tables_dev, reinterpret_cast<const uint16_t*>(out.trace), out, B, T,
-                      (int64_t)T * row_pitch(out, B), hs);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_failed(e);
+    const int32_t rc = wide_renders(*s, tables_dev, trace0 + t0 * pitch, part, B, n, wp.plane, hs);
+    if (rc != CAMPX_OK) return rc;
+  }
+  return CAMPX_OK;
 }
 
 int32_t campx_wide_rules_size(void) { return (int32_t)sizeof(CampxWideRules); }

@@ -1022,7 +1022,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
       backdrop_pieces.add((int(c), int(now[c])))
   n_thing_movers = len(split)
   # PIECES or VARIANTS.  A piece tracked as a thing costs the render kernel a trace entry and a patch
-  # slot per piece and row (seven coins and a walker on a 4x9 board: 2.6 TB/s).  A game whose pieces
+  # slot per piece and row (seven coins and a walker on a 4x9 board: 3.5 TB/s).  A game whose pieces
   # are few enough for the cell-indexed tables - at most three tracked things, no piece in the
   # Backdrop - keeps them as things.  Up to sixteen pieces beside at least one ordinary mover are
   # handed to the state-table tier as a MASK (CampxWideSpec.n_pieces: which of them show is one
@@ -1030,7 +1030,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   # pieces describe it).  More cells than that - day and night over a whole floor - and the SCENERY
   # itself comes in variants: a picture = the Backdrop's curtain and the curtains of the
   # several-cell drapes, the state names which picture shows, the render kernel lays that variant's
-  # row (CampxWideSpec.n_variants; 4.4-5.7 TB/s) - as long as the pictures are at most
+  # row (CampxWideSpec.n_variants; 5.2-6.4 TB/s) - as long as the pictures are at most
   # WIDE_MAX_VARIANTS.  Failing that, pieces as things again, up to the eight the kernels track.
   several = [ch for ch in dict.fromkeys(ch for ch, c in zip(split, piece_cell) if c is not None)]
   singles = [ch for ch, c in zip(split, piece_cell) if c is None]
