@@ -208,8 +208,8 @@ __global__ __launch_bounds__(kRenderWaves * kWave) void render_kernel(
   // kMask: slot = (row, piece), sixteen (or fewer: a power of two) to a row, so a lane's piece is
   // the same in every round of slots; its table entry and the rows' masks travel with the things'
   // entries (the mask of one row is one address for all its slots: the loads coalesce)
-  constexpr int kMaskIter = 2;
-  uint32_t piece = 0, shown[kMaskIter] = {0u, 0u};
+  constexpr int kMaskIter = 4;     // (nine pieces on 140-byte rows: sixteen slots x fifteen rows)
+  uint32_t piece = 0, shown[kMaskIter] = {0u, 0u, 0u, 0u};
   int mask_slots = 0;
   if constexpr (kMask) {
     const typename Fmt::Entry* masks = frame_trace + (int64_t)rp.n_dyn * n_rows;
