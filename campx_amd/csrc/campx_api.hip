@@ -172,12 +172,17 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   // 1 641 / 1 644; B = 524 288: 1 739 / 1 504 / 1 314 / 1 316 - gpurun_out/t16.  A 26 MB trace
   // in one piece is still at full speed, so launches up to 28 MB (trace_whole_mb) are not cut.)
   // (per moving thing's plane of the trace: sokoban with three boxes, four planes of 13 MB,
-  // renders at full speed in one piece, and 4 % slower cut in four)
+  // renders at full speed in one piece, and 4 % slower cut in four.  But not four planes of 26 MB:
+  // round 6 found the state-table tier's launches losing up to a third of their rate once ALL the
+  // planes together pass 64 MB (k_wide.hip), and here too - B = 262 144, T = 100: sokoban with two /
+  // three boxes in one piece 0.763 / 0.683 of peak, in 16 MB chunks 0.859 / 0.842 - so a launch also
+  // goes in one piece only while its planes together stay within 4 x trace_chunk_mb.)
   const int64_t per_frame = B;
   int64_t chunk = (knob(K_TRACE_CHUNK_MB) << 20) / per_frame;
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
   chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
-  const bool whole = (per_frame * T <= (knob(K_TRACE_WHOLE_MB) << 20) && T <= 65535) || T <= chunk;
+  const bool whole = (per_frame * T <= (knob(K_TRACE_WHOLE_MB) << 20) &&
+                      per_frame * T * s.n_dyn <= 4 * (knob(K_TRACE_CHUNK_MB) << 20) && T <= 65535) || T <= chunk;
   // (two to four movers: their pair / tuple table is the caller's, CampxState.pair_table)
   const bool multi_table = s.n_dyn >= 2 && st.pair_table;
   if (whole && !last_frame_only(out) && flow_ok(s, out, B, T, use_table || multi_table, stream)) {
