@@ -330,7 +330,8 @@ def test_recognising_hello_world_takes_seconds():
   ex, game = _hello()
   t0 = time.perf_counter()
   desc = recognise.shapes(game)
-  assert time.perf_counter() - t0 < 10.0
+  from conftest import took_about
+  took_about(time.perf_counter() - t0, 10.0, 'recognising Hello World')
   assert _spec_bytes(gamespec.lower_shapes(desc)) == _golden('hello_world_spec')['spec'].tobytes()
 
 

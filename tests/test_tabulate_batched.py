@@ -299,8 +299,12 @@ def test_a_warehouse_of_half_a_million_states_tabulates_in_seconds_and_predicts_
   game = tabulate.trace(lanes_games.warehouse(), cache=False)
   took = time.perf_counter() - t0
   assert game.n_states == 592588 and game.movers == ['X', 'Y', 'P'] and game.dense_reason
-  assert took < 90.0, took       # (15-20 s on eight idle cores; the bound leaves room for a loaded machine)
-  assert game.n_plays < 600                       # frames of Python, each over a whole level
+  # (15-20 s on eight idle cores.  What is asserted is the structure that makes it so - a few hundred
+  # frames of Python, each over a whole level of the state graph -, not the wall clock of whatever else
+  # the machine is doing: four pytest workers x eight torch threads once read 894 s here)
+  assert game.n_plays < 600
+  from conftest import took_about
+  took_about(took, 90.0, 'tabulating the 592 588-state warehouse')
   # the table against the user's classes on the generic tier: three random walks
   acts = tabulate.default_actions()
   rng = np.random.RandomState(5)
@@ -427,7 +431,8 @@ def test_a_sprite_agent_written_with_python_ints_and_branches_is_tabulated_on_la
   t0 = time.perf_counter()
   table = tabulate.trace(lanes_probes.porter(big)(), cache=False)
   assert tabulate.LAST_WALK[0].startswith('lanes: ') and table.n_states > 3000
-  assert time.perf_counter() - t0 < 60
+  from conftest import took_about
+  took_about(time.perf_counter() - t0, 60.0, 'tabulating the big porter board on lanes')
   _predicts_live_play(table, lanes_probes.porter(big), frames=300, seed=9)
 
 
