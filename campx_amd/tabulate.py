@@ -1072,9 +1072,11 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
     if backdrop_pieces:
       named.append('the Backdrop')
     _fail('moving drape(s) {} cover several cells that come and go - {} tracked cells with the other '
-          'moving things (the table kernels track at most {}), and more than {} different pictures of '
+          'moving things (the table kernels track at most {} things, or {} such cells as a mask '
+          'beside at least one ordinary mover), and more than {} different pictures of '
           'the scenery'.format(', '.join(ch if ch == 'the Backdrop' else repr(ch) for ch in named),
-                               len(split), gamespec.WIDE_MAX_DYN, gamespec.WIDE_MAX_VARIANTS))
+                               len(split), gamespec.WIDE_MAX_DYN, gamespec.WIDE_MAX_PIECES,
+                               gamespec.WIDE_MAX_VARIANTS))
   movers = split
   in_backdrop = [k >= n_thing_movers for k in range(len(movers))]
   if not movers:
