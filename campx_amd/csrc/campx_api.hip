@@ -58,7 +58,7 @@ static KnobRow g_knobs[K_COUNT] = {
     // largest trace one update + render pair of a rollout works on; a longer rollout runs in chunks
     // of whole frames (the render's trace reads then hit the memory-side cache: profiles/r02_sweep.txt).
     // 0: a chunk per frame (tests/test_chunked_rollouts.py runs the chunked form at test sizes)
-    {"trace_chunk_mb", 16, 0, 1 << 20, "MiB of trace per update + render pair of a chunked rollout (state-table tier: x 4, all planes)"},
+    {"trace_chunk_mb", 16, 0, 1 << 20, "MiB of trace per plane and update + render pair of a chunked rollout (all planes: x 2)"},
     {"trace_whole_mb", 28, 0, 1 << 20, "largest trace (MiB) a rollout may have and still run as one pair"},
     // frame-major shape tier: environment-frames per chunk, in thousands (profiles/r05_shape_rocprofv3.txt)
     {"shape_chunk_kf", 2000, 1, 1 << 30, "thousand environment-frames per chunk of a frame-major shape rollout"},
@@ -176,9 +176,13 @@ int32_t launch_split(const CampxSpec& s, const CampxSpec* spec_dev, CampxState s
   // round 6 found the state-table tier's launches losing up to a third of their rate once ALL the
   // planes together pass 64 MB (k_wide.hip), and here too - B = 262 144, T = 100: sokoban with two /
   // three boxes in one piece 0.763 / 0.683 of peak, in 16 MB chunks 0.859 / 0.842 - so a launch also
-  // goes in one piece only while its planes together stay within 4 x trace_chunk_mb.)
+  // goes in one piece only while its planes together stay within 4 x trace_chunk_mb.  And a chunk's
+  // planes together within 2 x trace_chunk_mb: B = 524 288 with chunks of 16 / 8 MB per plane:
+  // two boxes 0.689 / 0.822, three 0.629 / 0.802 - one box, two planes, 0.817 / 0.788;
+  // profiles/r06_sweep.txt.)
   const int64_t per_frame = B;
-  int64_t chunk = (knob(K_TRACE_CHUNK_MB) << 20) / per_frame;
+  const int64_t planes = s.n_dyn > 2 ? s.n_dyn : 2;
+  int64_t chunk = (2 * (knob(K_TRACE_CHUNK_MB) << 20)) / (per_frame * planes);
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
   chunk = chunk > 65520 ? 65520 : chunk;   // a render launch has one grid row per frame
   const bool whole = (per_frame * T <= (knob(K_TRACE_WHOLE_MB) << 20) &&

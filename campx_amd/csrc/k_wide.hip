@@ -875,13 +875,16 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   // 16 / 32 / 64 MB (tools/bench_pieces.py, profiles/r06_variants.txt): the walker's plane and the
   // pieces' mask, 105 MB: 6.20 / 6.49 / 6.63 / 6.71; the same with a scenery in seven variants:
   // 5.01 / 5.57 / 5.65 / 5.69; four planes of things, 210 MB: 4.09 / 6.36 / 6.37 / 6.53; one plane of
-  // 52 MB in one piece loses nothing (6.64 against the one-cell tier's 6.75).  So: a launch whose
-  // trace is more than 4 x trace_chunk_mb (64 MB) runs as chunks of frames of at most that much,
-  // update pass and render alternating.
+  // 52 MB in one piece loses nothing (6.64 against the one-cell tier's 6.75).  64 MB chunks are the
+  // best there and the worst elsewhere (fraction of peak with chunks of 64 / 32 / 16 MB,
+  // profiles/r06_sweep.txt: the coin field at B = 524 288 0.674 / 0.862 / 0.859, at B = 65 536 with
+  // T = 1 000 0.797 / 0.847 / 0.821, maze 16x16 at B = 524 288 0.774 / 0.884 / 0.876; at B = 262 144
+  // 0.871 / 0.860 / 0.842).  So: a launch whose trace is more than 4 x trace_chunk_mb (64 MB) runs
+  // as chunks of frames of at most 2 x trace_chunk_mb (32 MB), update pass and render alternating.
   const int64_t per_frame = pitch * (int64_t)sizeof(uint16_t) * w.n_planes;
-  int64_t chunk = (4 * (knob(K_TRACE_CHUNK_MB) << 20)) / per_frame;
+  int64_t chunk = (2 * (knob(K_TRACE_CHUNK_MB) << 20)) / per_frame;
   chunk = chunk < 16 ? 16 : chunk & ~(int64_t)15;
-  const bool whole = T <= chunk || wide_last_only(out);
+  const bool whole = per_frame * T <= 4 * (knob(K_TRACE_CHUNK_MB) << 20) || T <= chunk || wide_last_only(out);
   const int64_t elem = out.obs_format == CAMPX_OBS_INT8 ? 1 : 2;
   const uint16_t* trace0 = reinterpret_cast<const uint16_t*>(out.trace);
   for (int64_t t0 = 0; t0 < T; t0 += whole ? T : chunk) {
