@@ -124,7 +124,7 @@ constexpr int kRenderWaves = CAMPX_RENDER_WAVES;
 // per (frame, environment), the 16-bit mask of the pieces that show; the wave patches them onto
 // the plain scenery like the things (a byte set in the piece's layer, the scenery's byte under it
 // cleared) from ONE trace entry per row however many pieces there are - eight things tracked
-// one by one load sixteen slots a row (3.5 TB/s on a 4x9 board against 6.25 this way), a scenery
+// one by one load sixteen slots a row (3.7 TB/s on a 4x9 board against 6.1 this way), a scenery
 // in variants waits for the entry before it can fetch its row (5.2): here nothing waits for
 // anything but the trace.
 template <int K, bool kBoard, bool kNT, int kWin, int kFmt, bool kOdd = false, bool kWide = false,
