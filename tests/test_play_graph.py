@@ -17,6 +17,7 @@ import torch
 
 from campx_amd.games import boat_race, sokoban
 from conftest import REPO
+import random_pickups
 from games_under_test import SHAPE_GAMES, WIDE_GAMES
 
 pytestmark = pytest.mark.gpu
@@ -42,7 +43,11 @@ def _same(x, y):
     ('boat_race', boat_race.build, {}, 4097),
     ('sokoban_l1', sokoban.build, {'level': 1}, 2048),
     ('maze_16x16', WIDE_GAMES['maze_16x16'], {}, 1000),
-    ('hello_world', SHAPE_GAMES['hello_world'], {}, 333)])
+    ('hello_world', SHAPE_GAMES['hello_world'], {}, 333),
+    # a scenery that changes (tests/random_pickups.py): seven coins as pieces in a mask, a floor in
+    # three variants - their play() is the update + render pair, two kernel nodes a frame
+    ('pickup3_coins', random_pickups.builder(random_pickups.definitions()[3]), {}, 777),
+    ('pickup13_seasons', random_pickups.builder(random_pickups.definitions()[13]), {}, 1025)])
 def test_open_loop_graph_equals_frame_by_frame_play(name, build, kw, B):
   n = 12
   a, b = _pair(build, B, **kw)
