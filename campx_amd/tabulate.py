@@ -787,7 +787,7 @@ def trace(engine, actions=None, max_plays=MAX_PLAYS, cache=True):
     key = fingerprint(engine, default_actions() if actions is None else list(actions))
     if key is not None:
       # (... and the bounds that decide how pieces of the scenery are handed to the kernels)
-      key = (key, max_plays, gamespec.WIDE_MAX_PIECES, gamespec.WIDE_MAX_VARIANTS)
+      key = (key, max_plays, gamespec.WIDE_MAX_PIECES, gamespec.WIDE_MAX_VARIANTS, gamespec.PIECES_AS_THINGS_MAX)
       if key in _CACHE:
         _CACHE.move_to_end(key)
         return _CACHE[key]
@@ -1035,7 +1035,7 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
   several = [ch for ch in dict.fromkeys(ch for ch, c in zip(split, piece_cell) if c is not None)]
   singles = [ch for ch, c in zip(split, piece_cell) if c is None]
   variants, variant_masks, state_variant = [backdrop0], [{}], [0] * len(images)
-  few = not backdrop_pieces and len(split) <= 3
+  few = not backdrop_pieces and len(split) <= gamespec.PIECES_AS_THINGS_MAX
   n_pieces = len(split) - len(singles) + len(backdrop_pieces)
   room = bool(singles) and len(singles) + 1 <= gamespec.WIDE_MAX_DYN
   pieces_as_mask = bool(n_pieces) and not few and room and n_pieces <= gamespec.WIDE_MAX_PIECES

@@ -16,6 +16,8 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 road = sys.argv[3] if len(sys.argv) > 3 else 'own'
 from campx_amd import gamespec  # noqa: E402
+if road == 'mask':          # (also where three tracked things would stay on the one-cell tier)
+  gamespec.PIECES_AS_THINGS_MAX = 0
 if road in ('variants', 'things'):
   gamespec.WIDE_MAX_PIECES = 0
 if road == 'things':
