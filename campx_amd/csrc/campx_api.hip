@@ -78,6 +78,9 @@ static KnobRow g_knobs[K_COUNT] = {
     {"flow_debug_delay", 0, 0, 1 << 24, "debug: delay in front of the update role's tagged stores"},
     // wide tier: largest state table (bytes) staged in LDS; 0 sends every game through L2 / HBM gathers
     {"wide_lds_max", (int64_t)kWideLdsMax, 0, (int64_t)kWideLdsMax, "largest state table (bytes) kept in LDS by wide_update_kernel"},
+    // 0: Engine.play() of a state-table game is always the update + render pair, never wide_step_kernel
+    // (the parity twin of tests/test_wide_parity.py)
+    {"wide_step", 1, 0, 1, "one-kernel Engine.play() for state-table games"},
 };
 
 static void knobs_from_environment() {

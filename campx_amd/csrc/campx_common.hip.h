@@ -469,7 +469,7 @@ int32_t hip_failed(hipError_t e);
 // campx_config_set / _get / _string in include/campx_hip.h).  Read at every use - a plain load.
 enum Knob : int {
   K_TRACE_CHUNK_MB, K_TRACE_WHOLE_MB, K_SHAPE_CHUNK_KF, K_SHAPE_SPLIT, K_BIG_WGS, K_FLOW,
-  K_FLOW_MAX_NAPS, K_FLOW_DEBUG_DELAY, K_WIDE_LDS_MAX, K_COUNT
+  K_FLOW_MAX_NAPS, K_FLOW_DEBUG_DELAY, K_WIDE_LDS_MAX, K_WIDE_STEP, K_COUNT
 };
 int64_t knob(Knob k);
 constexpr uint32_t kFlowMaxNaps = 1u << 20;   // looks at stale entries before a render wave gives up (seconds)

@@ -790,7 +790,12 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
     // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
     const int HW = s->rows * s->cols, R = HW * s->n_layers;
     // (a scenery of several variants: through the update + render kernels, which know about them)
+    // (rows that are not whole chunks, pieces: a form of this kernel that poked them into the
+    // registers too - two environments' patches per chunk, sixteen unrolled pieces - was built at
+    // the end of round 6 and measured SLOWER than the pair: the coin field 24-29 us per play() at
+    // B = 65 536 against 13, 11.5-14 at 4 096 against 13 - 4.5 times the instructions; not kept)
     if (T == 1 && !reset_first && (R & 15) == 0 && w.n_variants == 1 && s->n_pieces == 0 &&
+        knob(K_WIDE_STEP) &&
         (!out.board || (HW & 15) == 0) &&
         (int64_t)kStepEnvMax * R < (1ll << 24)) {
       WideStepParams sp;

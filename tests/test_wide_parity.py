@@ -460,6 +460,50 @@ def test_state_tables_too_large_for_lds_are_read_through_the_caches():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('which', ['maze 15x17 (rows of 1 530 bytes)', 'coin field (rows of 300 bytes, pieces)',
+                                   'maze 16x16 (whole chunks)', 'seven coins on 4x9 (rows of 180 bytes)'])
+@pytest.mark.parametrize('B', [1, 7, 1000, 4099])
+def test_play_in_one_kernel_equals_the_update_and_render_pair(which, B):
+  """Engine.play() of a state-table game whose rows are whole 16-byte chunks is ONE kernel
+  (wide_step_kernel: the 16x16 maze here); the setting wide_step=0 sends the same calls through the
+  update + render pair, which every other game takes anyway (rows of 1 530, 300, 180 bytes; a scenery
+  of pieces): same bytes, frame by frame, int8 and 16-bit observations, boards, scalars, carried
+  state - whichever road a game takes, with the setting or without."""
+  import sys
+  from campx_amd import _hip
+  from campx_amd.games import maze
+  from conftest import REPO
+  sys.path.insert(0, os.path.join(REPO, 'examples'))
+  if which.startswith('maze 15x17'):
+    build = lambda: maze.build(15, 17, batch=B, device='cuda')
+  elif which.startswith('maze 16x16'):
+    build = lambda: maze.build(16, 16, batch=B, device='cuda')
+  elif which.startswith('coin field'):
+    import coins_batched
+    build = lambda: coins_batched.make_game(floor=False, batch=B, device='cuda')
+  else:
+    import random_pickups
+    build = lambda: random_pickups.builder(random_pickups.definitions()[3])(batch=B, device='cuda')
+  one, two = build(), build()
+  one.its_showtime()
+  two.its_showtime()
+  gen = torch.Generator(device='cuda').manual_seed(11)
+  for t in range(40):
+    if t == 20:                   # ... and as 16-bit observations from here on
+      one.fused.set_play_obs_dtype(torch.bfloat16)
+      two.fused.set_play_obs_dtype(torch.bfloat16)
+    ids = torch.randint(0, 5, (B,), generator=gen, device='cuda', dtype=torch.int8)
+    oa, ra, da = one.play(ids)
+    with _hip.config(wide_step=0):
+      ob, rb, db = two.play(ids)
+    assert torch.equal(oa.layered_board, ob.layered_board), (which, B, t)
+    assert torch.equal(oa.board, ob.board), (which, B, t)
+    assert _same(ra.cpu().numpy(), rb.cpu().numpy()) and _same(da.cpu().numpy(), db.cpu().numpy()), (which, B, t)
+    for name in ('state', 'done', 'ret', '_step_trace'):
+      assert torch.equal(getattr(one.fused, name), getattr(two.fused, name)), (which, B, t, name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('rows,cols,B', [(16, 16, 8192), (15, 17, 2001), (32, 32, 1024)])
 def test_mazes_against_the_c_oracle(rows, cols, B):
   """oracle/campx_oracle.c - the literal restatement of the reference engine (full curtains,
