@@ -303,6 +303,152 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
   if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true);
 }
 
+// Engine.play() in one launch for the games wide_step_kernel cannot take: rows that are not whole
+// 16-byte chunks (a 6x10 coin field: 300 bytes) and a scenery of pieces (round 6).  The same
+// ownership - a wave, n consecutive environments, n chosen so that its span of the frame STARTS
+// on a 16-byte boundary - but the span is built in LDS the way render_kernel builds its windows:
+// the scenery's chunks from the rotations (which continue a row with its own start - the next
+// environment's row, the scenery being the same), then every environment's lane writes the bytes
+// its things and pieces set and clear, then aligned 16-byte stores; the last bytes of a span that
+// is not whole chunks (the frame's end) leave one by one.  (A first form that poked the patches
+// into the chunks' registers - two environments per chunk, sixteen unrolled pieces - ran 24-29 us per
+// call for the coin field at B = 65 536 where the update + render pair takes 13.)
+constexpr int kStepLdsSpan = 4096;   // bytes of a wave's span at most
+
+struct WideStepLdsParams {
+  int32_t n_pieces, n_planes;                    // pieces of the scenery; planes of the trace
+  int32_t pitch_obs, pitch_board;                // bytes from one rotation of the scenery row to the next
+  uint32_t piece_obs[CAMPX_WIDE_MAX_PIECES];     // byte a piece sets | byte of the scenery it clears << 16
+  uint32_t piece_board[CAMPX_WIDE_MAX_PIECES];   // cell | character << 16
+};
+
+template <bool kBoard, bool kPerf, int kFmt>
+__global__ __launch_bounds__(kWideThreads) void wide_step_lds_kernel(
+    WideStepParams sp, WideStepLdsParams lp, const uint2* __restrict__ entries,
+    const u32x4* __restrict__ cells, const int8_t* __restrict__ perf_tab,
+    const int8_t* __restrict__ rot_obs, const int8_t* __restrict__ rot_board,
+    int32_t* __restrict__ state, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out,
+    int64_t B) {
+  __shared__ __attribute__((aligned(16))) int8_t win_all[kWideThreads / kWave][kStepLdsSpan + 16];
+  const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = sp.n_env, K = sp.n_dyn;
+  const int64_t env0 = ((int64_t)blockIdx.x * (kWideThreads / kWave) + wave) * n;
+  if (env0 >= B) return;                          // (wave-uniform; no workgroup barrier below)
+  const int n_here = (B - env0 < n) ? (int)(B - env0) : n;
+  // ---- update pass: lane i < n_here owns environment env0 + i (as in wide_step_kernel)
+  int bad = 0;
+  u32x4 mine = {0u, 0u, 0u, 0u};                  // where this lane's environment's things show
+  if (lane < n_here) {
+    const int64_t env = env0 + lane;
+    uint32_t now = (uint32_t)state[env];
+    now = now < (uint32_t)sp.n_states ? now : 0u;
+    const int over = st.done[env];
+    const uint32_t a = (uint8_t)actions[env];
+    bad = a > 4u;
+    const uint32_t idx = (over ? 0u : now) * CAMPX_N_ACTIONS + (a > 4u ? 4u : a);
+    const uint2 e = entries[idx];
+    now = e.y & 0xffffffu;
+    const uint32_t done = (e.y >> 24) & 1u, dcode = (e.y >> 25) & 15u;
+    mine = cells[now];
+    state[env] = (int32_t)now;
+    st.done[env] = (uint8_t)done;
+    if (st.ret) st.ret[env] = (over ? 0.0f : st.ret[env]) + real_reward(__uint_as_float(e.x));
+    if (out.reward) out.reward[env] = __uint_as_float(e.x);
+    if (out.discount)
+      out.discount[env] = __uint_as_float(dcode ? __float_as_uint(sp.discounts[dcode])
+                                                : (done ? 0u : 0x3f800000u));
+    if (out.done) out.done[env] = (uint8_t)done;
+    if (kPerf && out.perf) out.perf[env] = perf_tab[idx];
+    uint16_t* trace = reinterpret_cast<uint16_t*>(out.trace);
+    const int64_t P = row_pitch(out, B);
+    const uint32_t w[4] = {mine.x, mine.y, mine.z, mine.w};
+#pragma unroll
+    for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d)
+      if (d < lp.n_planes) trace[(int64_t)d * P + env] = (uint16_t)(w[d >> 1] >> (16 * (d & 1)));
+  }
+  report_bad_actions(out, bad);
+
+  // ---- render: the wave's span of the frame, built in LDS
+  int8_t* const win = win_all[wave];
+  auto rows = [&](int8_t* dst, const int8_t* rot, int R, bool board, int rot_pitch) {
+    const int span = n_here * R;                  // bytes; starts on a 16-byte boundary of `dst`
+    for (int byte = lane * 16; byte < span; byte += kWave * 16) {
+      const int e = board ? byte / R : (int)(((uint64_t)(uint32_t)byte * sp.inv_r) >> 32);
+      const int off = byte - e * R;
+      *reinterpret_cast<u32x4*>(win + byte) =
+          *reinterpret_cast<const u32x4*>(rot + (off & 15) * rot_pitch + (off & ~15));
+    }
+    // (the wave's own LDS operations complete in order: the chunks above are in place)
+    if (lane < n_here) {
+      int8_t* const row = win + lane * R;
+      const uint32_t w[4] = {mine.x, mine.y, mine.z, mine.w};
+#pragma unroll
+      for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d) {
+        if (d < K) {
+          const uint32_t t = (w[d >> 1] >> (16 * (d & 1))) & 0xffffu;
+          if (t >> 15) {
+            const int cell = (int)(t & 0x3ffu);
+            if (board) {
+              row[cell] = (int8_t)sp.dyn_char[d];
+            } else {
+              row[(int)((t >> 10) & 15u) * sp.cells + cell] = 0;
+              row[sp.dyn_off[d] + cell] = 1;
+            }
+          }
+        }
+      }
+      if (lp.n_pieces > 0) {
+        uint32_t mask = 0u;                       // slot n_dyn of the entries: the pieces that show
+#pragma unroll
+        for (int d = 1; d < CAMPX_WIDE_MAX_DYN; ++d)
+          mask = d == K ? (w[d >> 1] >> (16 * (d & 1))) & 0xffffu : mask;
+#pragma unroll
+        for (int p = 0; p < CAMPX_WIDE_MAX_PIECES; ++p) {
+          if (p < lp.n_pieces && ((mask >> p) & 1u)) {
+            if (board) {
+              row[lp.piece_board[p] & 0xffffu] = (int8_t)(lp.piece_board[p] >> 16);
+            } else {
+              row[lp.piece_obs[p] >> 16] = 0;
+              row[lp.piece_obs[p] & 0xffffu] = 1;
+            }
+          }
+        }
+      }
+    }
+    for (int byte = lane * 16; byte < span; byte += kWave * 16) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(win + byte);
+      const int left = span - byte;               // (only the frame's last span can end short)
+      if (kFmt == 0 || board) {
+        if (left >= 16) {
+          store16_streaming(reinterpret_cast<u32x4*>(dst + byte), v);
+        } else {
+          for (int i = 0; i < left; ++i) dst[byte + i] = win[byte + i];
+        }
+      } else {
+        constexpr uint32_t kOne = (kFmt == 1) ? 0x3C00u : 0x3F80u;
+        const uint32_t b[4] = {v.x, v.y, v.z, v.w};
+        u32x4 h[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          h[i].x = ((b[2 * i] & 0xffu) | ((b[2 * i] << 8) & 0x00ff0000u)) * kOne;
+          h[i].y = (((b[2 * i] >> 16) & 0xffu) | ((b[2 * i] >> 8) & 0x00ff0000u)) * kOne;
+          h[i].z = ((b[2 * i + 1] & 0xffu) | ((b[2 * i + 1] << 8) & 0x00ff0000u)) * kOne;
+          h[i].w = (((b[2 * i + 1] >> 16) & 0xffu) | ((b[2 * i + 1] >> 8) & 0x00ff0000u)) * kOne;
+        }
+        if (left >= 16) {
+          store16_streaming(reinterpret_cast<u32x4*>(dst + 2 * (int64_t)byte), h[0]);
+          store16_streaming(reinterpret_cast<u32x4*>(dst + 2 * (int64_t)byte + 16), h[1]);
+        } else {
+          uint16_t* to = reinterpret_cast<uint16_t*>(dst) + byte;
+          for (int i = 0; i < left; ++i) to[i] = (uint16_t)((uint32_t)(uint8_t)win[byte + i] * kOne);
+        }
+      }
+    }
+  };
+  rows(out.obs + env0 * sp.R * (kFmt ? 2 : 1), rot_obs, sp.R, false, lp.pitch_obs);
+  if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true, lp.pitch_board);
+}
+
 // its_showtime(): state 0 and the trace rows of the first observation.
 __global__ void wide_reset_kernel(const u32x4* __restrict__ cells, int32_t K, int32_t* __restrict__ state,
                                   CampxState st, uint16_t* __restrict__ trace, int64_t P, int64_t B) {
@@ -790,10 +936,6 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
     // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
     const int HW = s->rows * s->cols, R = HW * s->n_layers;
     // (a scenery of several variants: through the update + render kernels, which know about them)
-    // (rows that are not whole chunks, pieces: a form of this kernel that poked them into the
-    // registers too - two environments' patches per chunk, sixteen unrolled pieces - was built at
-    // the end of round 6 and measured SLOWER than the pair: the coin field 24-29 us per play() at
-    // B = 65 536 against 13, 11.5-14 at 4 096 against 13 - 4.5 times the instructions; not kept)
     if (T == 1 && !reset_first && (R & 15) == 0 && w.n_variants == 1 && s->n_pieces == 0 &&
         knob(K_WIDE_STEP) &&
         (!out.board || (HW & 15) == 0) &&
@@ -849,6 +991,76 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
 #undef CAMPX_WIDE_STEP2
       const hipError_t e = hipGetLastError();
       return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+    }
+    // ... and the rest - rows that are not whole chunks, a scenery of pieces - when a wave's span can
+    // start on a 16-byte boundary and fits its LDS window (wide_step_lds_kernel), for frames up to
+    // 24 MB: us per play(), one kernel / the pair (tools/bench_wide_play.py, round 6): the coin
+    // field (300-byte rows, three pieces) B = 1 000 6.6 / 12.9, 4 096 6.7 / 13.0, 16 384 7.3 / 13.1,
+    // 65 536 (19.7 MB) 12.1 / 13.3, 131 072 (39 MB) 20.4 / 15.8, 262 144 36.3 / 22.7; seven coins on
+    // 4x9 B = 65 536 7.5 / 13.0, 262 144 (47 MB) 18.4 / 20.4
+    if (T == 1 && !reset_first && w.n_variants == 1 && knob(K_WIDE_STEP) && B * R <= (24ll << 20) &&
+        (!out.board || (reinterpret_cast<uintptr_t>(out.board) & 15) == 0)) {
+      // environments per aligned span: of the layered rows and - when the flat board is asked for - of
+      // the board's (rows * cols divides R)
+      const int unit = out.board ? HW : R;
+      int step = 1;
+      while (step < 16 && (unit * step) % 16 != 0) step <<= 1;
+      int n_env = (kStepLdsSpan / R) / step * step;                // as many as the window holds
+      n_env = n_env < step ? step : (n_env > kStepEnvMax ? kStepEnvMax : n_env);
+      if ((int64_t)n_env * R <= kStepLdsSpan) {
+        WideStepParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.n_states = s->n_states;
+        sp.n_dyn = s->n_dyn;
+        sp.cells = HW;
+        sp.R = R;
+        sp.n_env = n_env;
+        sp.inv_r = (uint32_t)(((1ull << 32) + R - 1) / R);
+        for (int d = 0; d < s->n_dyn; ++d) {
+          sp.dyn_off[d] = s->dyn_layer[d] * HW;
+          sp.dyn_char[d] = s->layer_char[s->dyn_layer[d]];
+        }
+        sp.discounts[0] = 1.0f;
+        for (int i = 1; i < 16; ++i) sp.discounts[i] = s->discount_list[i];
+        WideStepLdsParams lp;
+        memset(&lp, 0, sizeof(lp));
+        lp.n_pieces = s->n_pieces;
+        lp.n_planes = w.n_planes;
+        lp.pitch_obs = w.pitch_obs;
+        lp.pitch_board = w.pitch_board;
+        for (int p = 0; p < s->n_pieces; ++p) {
+          const uint32_t cell = s->piece_cell[p];
+          lp.piece_obs[p] = ((uint32_t)s->piece_layer[p] * (uint32_t)HW + cell) |
+                            (((uint32_t)s->static_top_layer[cell] * (uint32_t)HW + cell) << 16);
+          lp.piece_board[p] = cell | ((uint32_t)s->layer_char[s->piece_layer[p]] << 16);
+        }
+        const char* blob = static_cast<const char*>(tables_dev);
+        const uint2* entries = reinterpret_cast<const uint2*>(blob);
+        const u32x4* cells = reinterpret_cast<const u32x4*>(blob + w.cells_off);
+        const int8_t* perf = reinterpret_cast<const int8_t*>(blob + w.perf_off);
+        const int8_t* rot_obs = reinterpret_cast<const int8_t*>(blob + w.rot_obs_off);
+        const int8_t* rot_board = reinterpret_cast<const int8_t*>(blob + w.rot_board_off);
+        const int64_t n_waves = (B + n_env - 1) / n_env;
+        const dim3 grid((unsigned)((n_waves + kWideThreads / kWave - 1) / (kWideThreads / kWave)));
+        int32_t* state = reinterpret_cast<int32_t*>(st.pos);
+#define CAMPX_WIDE_STEP2(BOARD, PERF, FMT)                                                           \
+  hipLaunchKernelGGL((wide_step_lds_kernel<BOARD, PERF, FMT>), grid, dim3(kWideThreads), 0, hs, sp,  \
+                     lp, entries, cells, perf, rot_obs, rot_board, state, st, actions, out, B)
+#define CAMPX_WIDE_STEP(BOARD, PERF)                                      \
+  do {                                                                    \
+    if (out.obs_format == CAMPX_OBS_F16) CAMPX_WIDE_STEP2(BOARD, PERF, 1);      \
+    else if (out.obs_format == CAMPX_OBS_BF16) CAMPX_WIDE_STEP2(BOARD, PERF, 2); \
+    else CAMPX_WIDE_STEP2(BOARD, PERF, 0);                                \
+  } while (0)
+        if (out.board && out.perf) CAMPX_WIDE_STEP(true, true);
+        else if (out.board) CAMPX_WIDE_STEP(true, false);
+        else if (out.perf) CAMPX_WIDE_STEP(false, true);
+        else CAMPX_WIDE_STEP(false, false);
+#undef CAMPX_WIDE_STEP
+#undef CAMPX_WIDE_STEP2
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? CAMPX_OK : hip_failed(e);
+      }
     }
   }
   WideParams wp;

@@ -515,10 +515,10 @@ WIDE_MAX_DYN = 8
 WIDE_MAX_VARIANTS = 256     # pictures of a scenery that changes (CampxWideSpec.n_variants)
 WIDE_MAX_PIECES = 16        # cells of the scenery that come and go one by one (CampxWideSpec.n_pieces)
 # tracked things up to which pieces stay things of the one-cell tier (tabulate._finish).  A trade:
-# as a mask on the state-table tier such a game's ROLLOUTS are 9-13 % faster (a walker and two coins
-# on 4x9, B = 262 144: 5.81 -> 6.33 TB/s; tools/bench_pickups.py 0 262144 mask), but the one-cell tier
-# has the one-launch rollouts of small batches and a one-kernel play() for rows of any length
-# (the state-table tier's needs rows of whole 16-byte chunks: 6 against 10 us per frame).
+# as a mask on the state-table tier such a game's ROLLOUTS are 9-13 % faster at large batches (a
+# walker and two coins on 4x9, B = 262 144: 5.81 -> 6.33 TB/s; tools/bench_pickups.py 0 262144 mask),
+# but the one-cell tier has the one-launch rollouts of small batches (up to 8 192 environments) and
+# deferred rollouts; play() is one kernel on either.
 PIECES_AS_THINGS_MAX = 3
 
 

@@ -464,11 +464,12 @@ def test_state_tables_too_large_for_lds_are_read_through_the_caches():
                                    'maze 16x16 (whole chunks)', 'seven coins on 4x9 (rows of 180 bytes)'])
 @pytest.mark.parametrize('B', [1, 7, 1000, 4099])
 def test_play_in_one_kernel_equals_the_update_and_render_pair(which, B):
-  """Engine.play() of a state-table game whose rows are whole 16-byte chunks is ONE kernel
-  (wide_step_kernel: the 16x16 maze here); the setting wide_step=0 sends the same calls through the
-  update + render pair, which every other game takes anyway (rows of 1 530, 300, 180 bytes; a scenery
-  of pieces): same bytes, frame by frame, int8 and 16-bit observations, boards, scalars, carried
-  state - whichever road a game takes, with the setting or without."""
+  """Engine.play() of a state-table game is ONE kernel: wide_step_kernel when its rows are whole
+  16-byte chunks (the 16x16 maze), and since round 6 wide_step_lds_kernel for the others - rows of
+  300 and 180 bytes, a scenery of pieces - while a wave's span fits its LDS window (the 15x17 maze's
+  rows of 1 530 bytes do not: the pair).  The setting wide_step=0 sends the same calls through the
+  update + render pair: same bytes, frame by frame, int8 and 16-bit observations, boards, scalars,
+  carried state."""
   import sys
   from campx_amd import _hip
   from campx_amd.games import maze

@@ -17,7 +17,7 @@ from campx_amd.games import maze  # noqa: E402
 def main():
   sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
   import coins_batched
-  for rows, B in ((16, 65536), (16, 4096), (32, 16384), (32, 1024), (0, 65536), (0, 4096)):
+  for rows, B in ((16, 65536), (16, 4096), (32, 16384), (32, 1024), (0, 65536), (0, 16384), (0, 4096), (0, 1000)):
     if rows == 0:
       game = coins_batched.make_game(floor=False, batch=B, device='cuda')
     else:
