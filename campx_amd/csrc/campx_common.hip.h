@@ -554,6 +554,24 @@ int32_t launch_flow(const CampxSpec& s, const CampxSpec* spec_dev, CampxState st
 
 // k_render.hip: the observation stream of the two-kernel path
 // Where a render launch finds a game's tables (k_render.hip).
+// (render_kernel<kVar>, wide_step kernels)
+// kVar: bytes [0, n) of a 16-byte scenery chunk come from one environment's row, bytes [n, 16)
+// from the next environment's, whose scenery is another variant (1 <= n <= 15).
+__device__ __forceinline__ u32x4 variant_chunk(const int8_t* here, int64_t stride, int v) {
+  return *reinterpret_cast<const u32x4*>(here + (int64_t)v * stride);
+}
+__device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b, int left) {
+  // `left`: bytes of this dword that are still the first row's (<= 0: none, >= 4: all)
+  const uint32_t mask = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
+  return (a & mask) | (b & ~mask);
+}
+// (component by component: arrays indexed in a loop went to scratch memory - 80 bytes a lane,
+// and the kernel to 1.3 TB/s)
+__device__ __forceinline__ u32x4 merge_rows(u32x4 a, u32x4 b, int n) {
+  return u32x4{merge_word(a.x, b.x, n), merge_word(a.y, b.y, n - 4), merge_word(a.z, b.z, n - 8),
+               merge_word(a.w, b.w, n - 12)};
+}
+
 struct RenderSource {
   int32_t rows, cols, n_layers, n_dyn;
   int32_t dyn_layer[CAMPX_WIDE_MAX_DYN];

@@ -35,23 +35,6 @@ struct RenderParams {
   int32_t piece_shift;        // kMask: log2 of the pieces per row, rounded up to a power of two
 };
 
-// kVar: bytes [0, n) of a 16-byte scenery chunk come from one environment's row, bytes [n, 16)
-// from the next environment's, whose scenery is another variant (1 <= n <= 15).
-__device__ __forceinline__ u32x4 variant_chunk(const int8_t* here, int64_t stride, int v) {
-  return *reinterpret_cast<const u32x4*>(here + (int64_t)v * stride);
-}
-__device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b, int left) {
-  // `left`: bytes of this dword that are still the first row's (<= 0: none, >= 4: all)
-  const uint32_t mask = left >= 4 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << (8 * left)) - 1u));
-  return (a & mask) | (b & ~mask);
-}
-// (component by component: arrays indexed in a loop went to scratch memory - 80 bytes a lane,
-// and the kernel to 1.3 TB/s)
-__device__ __forceinline__ u32x4 merge_rows(u32x4 a, u32x4 b, int n) {
-  return u32x4{merge_word(a.x, b.x, n), merge_word(a.y, b.y, n - 4), merge_word(a.z, b.z, n - 8),
-               merge_word(a.w, b.w, n - 12)};
-}
-
 // The trace entry of one moving thing in one frame.  One byte in the one-cell tier (cell |
 // visible << 7; the scenery layer the thing covers is looked up per cell).  Boards above 128
 // cells (the wide tier, k_wide.hip) write 16 bits: cell | covered layer << 10 | visible << 15,

@@ -188,7 +188,20 @@ struct WideStepParams {
   int32_t dyn_off[CAMPX_WIDE_MAX_DYN];           // byte offset of thing d's layer inside a row
   int32_t dyn_char[CAMPX_WIDE_MAX_DYN];
   float discounts[16];
+  // a scenery in variants (slot n_dyn of a state's entries names the variant): one set of rotations
+  // per variant, these many bytes apart; planes of the trace (the things', and the variant's / the mask's)
+  int32_t n_variants, n_planes;
+  int64_t rot_obs_stride, rot_board_stride;
 };
+
+// slot K (1 .. 7) of a state's eight 16-bit entries
+__device__ __forceinline__ uint32_t wide_slot(const u32x4& c, int K) {
+  const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+  uint32_t v = 0u;
+#pragma unroll
+  for (int d = 1; d < CAMPX_WIDE_MAX_DYN; ++d) v = d == K ? (w[d >> 1] >> (16 * (d & 1))) & 0xffffu : v;
+  return v;
+}
 
 constexpr int kStepEnvMax = 16;    // environments per wave at most
 
@@ -251,20 +264,23 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
     const uint32_t w[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
     for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d)
-      if (d < K) trace[(int64_t)d * P + env] = (uint16_t)(w[d >> 1] >> (16 * (d & 1)));
+      if (d < sp.n_planes) trace[(int64_t)d * P + env] = (uint16_t)(w[d >> 1] >> (16 * (d & 1)));
   }
   report_bad_actions(out, bad);
   // (the wave's own LDS writes are visible to its own later reads: one wave, in order)
 
   // ---- render: the wave's span of the frame, 16 bytes per lane per round
-  auto rows = [&](int8_t* dst, const int8_t* rot, int R, bool board) {
+  auto rows = [&](int8_t* dst, const int8_t* rot, int R, bool board, int64_t stride) {
     const int span = n_here * R;                  // bytes, a multiple of 16
     for (int byte = lane * 16; byte < span; byte += kWave * 16) {
       const int el = (int)(((uint64_t)(uint32_t)byte * sp.inv_r) >> 32);   // byte / R (R = sp.R)
       const int e_local = board ? byte / R : el;
       const int off = byte - e_local * R;
-      u32x4 v = *reinterpret_cast<const u32x4*>(rot + off);
       const u32x4 c = shown[wave][e_local];
+      // (a scenery in variants: the environment's own set of rotations; rows are whole chunks, so a
+      // chunk never runs into the next environment's)
+      const int64_t from = sp.n_variants > 1 ? (int64_t)wide_slot(c, K) * stride : 0;
+      u32x4 v = *reinterpret_cast<const u32x4*>(rot + from + off);
       const uint32_t w[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
       for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d) {
@@ -299,8 +315,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_kernel(
       }
     }
   };
-  rows(out.obs + env0 * sp.R * (kFmt ? 2 : 1), rot_obs, sp.R, false);
-  if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true);
+  rows(out.obs + env0 * sp.R * (kFmt ? 2 : 1), rot_obs, sp.R, false, sp.rot_obs_stride);
+  if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true, sp.rot_board_stride);
 }
 
 // Engine.play() in one launch for the games wide_step_kernel cannot take: rows that are not whole
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_lds_kernel(
     int32_t* __restrict__ state, CampxState st, const int8_t* __restrict__ actions, CampxOutputs out,
     int64_t B) {
   __shared__ __attribute__((aligned(16))) int8_t win_all[kWideThreads / kWave][kStepLdsSpan + 16];
+  __shared__ uint16_t variant_all[kWideThreads / kWave][kStepEnvMax + 1];   // (a scenery in variants)
   const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = sp.n_env, K = sp.n_dyn;
   const int64_t env0 = ((int64_t)blockIdx.x * (kWideThreads / kWave) + wave) * n;
@@ -365,18 +382,30 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_lds_kernel(
 #pragma unroll
     for (int d = 0; d < CAMPX_WIDE_MAX_DYN; ++d)
       if (d < lp.n_planes) trace[(int64_t)d * P + env] = (uint16_t)(w[d >> 1] >> (16 * (d & 1)));
+    if (sp.n_variants > 1) variant_all[wave][lane] = (uint16_t)wide_slot(mine, K);
   }
   report_bad_actions(out, bad);
 
   // ---- render: the wave's span of the frame, built in LDS
   int8_t* const win = win_all[wave];
-  auto rows = [&](int8_t* dst, const int8_t* rot, int R, bool board, int rot_pitch) {
+  auto rows = [&](int8_t* dst, const int8_t* rot, int R, bool board, int rot_pitch, int64_t stride) {
     const int span = n_here * R;                  // bytes; starts on a 16-byte boundary of `dst`
     for (int byte = lane * 16; byte < span; byte += kWave * 16) {
       const int e = board ? byte / R : (int)(((uint64_t)(uint32_t)byte * sp.inv_r) >> 32);
       const int off = byte - e * R;
-      *reinterpret_cast<u32x4*>(win + byte) =
-          *reinterpret_cast<const u32x4*>(rot + (off & 15) * rot_pitch + (off & ~15));
+      const int8_t* here = rot + (off & 15) * rot_pitch + (off & ~15);
+      u32x4 v;
+      if (sp.n_variants > 1) {
+        // the environment's own variant; a chunk that runs over the end of its row takes the rest from
+        // the NEXT environment's (as render_kernel<kVar> does: the same offset in that variant's rotations)
+        const int v0 = variant_all[wave][e], v1 = variant_all[wave][e + 1 < n_here ? e + 1 : e];
+        v = variant_chunk(here, stride, v0);
+        const int left = R - off;
+        if (left < 16 && v1 != v0) v = merge_rows(v, variant_chunk(here, stride, v1), left);
+      } else {
+        v = *reinterpret_cast<const u32x4*>(here);
+      }
+      *reinterpret_cast<u32x4*>(win + byte) = v;
     }
     // (the wave's own LDS operations complete in order: the chunks above are in place)
     if (lane < n_here) {
@@ -398,10 +427,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_lds_kernel(
         }
       }
       if (lp.n_pieces > 0) {
-        uint32_t mask = 0u;                       // slot n_dyn of the entries: the pieces that show
-#pragma unroll
-        for (int d = 1; d < CAMPX_WIDE_MAX_DYN; ++d)
-          mask = d == K ? (w[d >> 1] >> (16 * (d & 1))) & 0xffffu : mask;
+        const uint32_t mask = wide_slot(mine, K);   // slot n_dyn of the entries: the pieces that show
 #pragma unroll
         for (int p = 0; p < CAMPX_WIDE_MAX_PIECES; ++p) {
           if (p < lp.n_pieces && ((mask >> p) & 1u)) {
@@ -445,8 +471,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_step_lds_kernel(
       }
     }
   };
-  rows(out.obs + env0 * sp.R * (kFmt ? 2 : 1), rot_obs, sp.R, false, lp.pitch_obs);
-  if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true, lp.pitch_board);
+  rows(out.obs + env0 * sp.R * (kFmt ? 2 : 1), rot_obs, sp.R, false, lp.pitch_obs, sp.rot_obs_stride);
+  if (kBoard) rows(out.board + env0 * sp.cells, rot_board, sp.cells, true, lp.pitch_board, sp.rot_board_stride);
 }
 
 // its_showtime(): state 0 and the trace rows of the first observation.
@@ -935,9 +961,7 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
   {
     // Engine.play(): one launch when the rows are whole 16-byte chunks (see wide_step_kernel)
     const int HW = s->rows * s->cols, R = HW * s->n_layers;
-    // (a scenery of several variants: through the update + render kernels, which know about them)
-    if (T == 1 && !reset_first && (R & 15) == 0 && w.n_variants == 1 && s->n_pieces == 0 &&
-        knob(K_WIDE_STEP) &&
+    if (T == 1 && !reset_first && (R & 15) == 0 && s->n_pieces == 0 && knob(K_WIDE_STEP) &&
         (!out.board || (HW & 15) == 0) &&
         (int64_t)kStepEnvMax * R < (1ll << 24)) {
       WideStepParams sp;
@@ -959,6 +983,10 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
       }
       sp.n_env = n_env;
       sp.inv_r = (uint32_t)(((1ull << 32) + R - 1) / R);
+      sp.n_variants = w.n_variants;
+      sp.n_planes = w.n_planes;
+      sp.rot_obs_stride = 16ll * w.pitch_obs;
+      sp.rot_board_stride = 16ll * w.pitch_board;
       for (int d = 0; d < s->n_dyn; ++d) {
         sp.dyn_off[d] = s->dyn_layer[d] * HW;
         sp.dyn_char[d] = s->layer_char[s->dyn_layer[d]];
@@ -998,7 +1026,7 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
     // field (300-byte rows, three pieces) B = 1 000 6.6 / 12.9, 4 096 6.7 / 13.0, 16 384 7.3 / 13.1,
     // 65 536 (19.7 MB) 12.1 / 13.3, 131 072 (39 MB) 20.4 / 15.8, 262 144 36.3 / 22.7; seven coins on
     // 4x9 B = 65 536 7.5 / 13.0, 262 144 (47 MB) 18.4 / 20.4
-    if (T == 1 && !reset_first && w.n_variants == 1 && knob(K_WIDE_STEP) && B * R <= (24ll << 20) &&
+    if (T == 1 && !reset_first && knob(K_WIDE_STEP) && B * R <= (24ll << 20) &&
         (!out.board || (reinterpret_cast<uintptr_t>(out.board) & 15) == 0)) {
       // environments per aligned span: of the layered rows and - when the flat board is asked for - of
       // the board's (rows * cols divides R)
@@ -1016,6 +1044,10 @@ int32_t campx_wide_rollout_launch(const CampxWideSpec* s, const void* tables_dev
         sp.R = R;
         sp.n_env = n_env;
         sp.inv_r = (uint32_t)(((1ull << 32) + R - 1) / R);
+        sp.n_variants = w.n_variants;
+        sp.n_planes = w.n_planes;
+        sp.rot_obs_stride = 16ll * w.pitch_obs;
+        sp.rot_board_stride = 16ll * w.pitch_board;
         for (int d = 0; d < s->n_dyn; ++d) {
           sp.dyn_off[d] = s->dyn_layer[d] * HW;
           sp.dyn_char[d] = s->layer_char[s->dyn_layer[d]];

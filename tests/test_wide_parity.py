@@ -461,13 +461,15 @@ def test_state_tables_too_large_for_lds_are_read_through_the_caches():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('which', ['maze 15x17 (rows of 1 530 bytes)', 'coin field (rows of 300 bytes, pieces)',
-                                   'maze 16x16 (whole chunks)', 'seven coins on 4x9 (rows of 180 bytes)'])
+                                   'maze 16x16 (whole chunks)', 'seven coins on 4x9 (rows of 180 bytes)',
+                                   'coins and a floor that turns (rows of 420 bytes, 13 variants)',
+                                   'tide (rows of 288 bytes: whole chunks, two variants)'])
 @pytest.mark.parametrize('B', [1, 7, 1000, 4099])
 def test_play_in_one_kernel_equals_the_update_and_render_pair(which, B):
   """Engine.play() of a state-table game is ONE kernel: wide_step_kernel when its rows are whole
   16-byte chunks (the 16x16 maze), and since round 6 wide_step_lds_kernel for the others - rows of
-  300 and 180 bytes, a scenery of pieces - while a wave's span fits its LDS window (the 15x17 maze's
-  rows of 1 530 bytes do not: the pair).  The setting wide_step=0 sends the same calls through the
+  300, 180 and 420 bytes, a scenery of pieces or in variants - while a wave's span fits its LDS window
+  (the 15x17 maze's rows of 1 530 bytes do not: the pair).  The setting wide_step=0 sends the same calls through the
   update + render pair: same bytes, frame by frame, int8 and 16-bit observations, boards, scalars,
   carried state."""
   import sys
@@ -482,6 +484,12 @@ def test_play_in_one_kernel_equals_the_update_and_render_pair(which, B):
   elif which.startswith('coin field'):
     import coins_batched
     build = lambda: coins_batched.make_game(floor=False, batch=B, device='cuda')
+  elif which.startswith('coins and a floor'):
+    import coins_batched
+    build = lambda: coins_batched.make_game(batch=B, device='cuda')
+  elif which.startswith('tide'):
+    import random_pickups
+    build = lambda: random_pickups.builder(random_pickups.definitions()[14])(batch=B, device='cuda')
   else:
     import random_pickups
     build = lambda: random_pickups.builder(random_pickups.definitions()[3])(batch=B, device='cuda')

@@ -17,8 +17,11 @@ from campx_amd.games import maze  # noqa: E402
 def main():
   sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
   import coins_batched
-  for rows, B in ((16, 65536), (16, 4096), (32, 16384), (32, 1024), (0, 65536), (0, 16384), (0, 4096), (0, 1000)):
-    if rows == 0:
+  for rows, B in ((16, 65536), (16, 4096), (32, 16384), (32, 1024), (0, 65536), (0, 16384), (0, 4096), (0, 1000),
+                  (-1, 32768), (-1, 4096)):
+    if rows == -1:       # ... with its switch: a floor that turns, 13 variants of the scenery, rows of 420 bytes
+      game = coins_batched.make_game(batch=B, device='cuda')
+    elif rows == 0:
       game = coins_batched.make_game(floor=False, batch=B, device='cuda')
     else:
       game = maze.build(rows, rows, batch=B, device='cuda')
@@ -42,7 +45,7 @@ def main():
     frame = B * game.fused.n_layers * game.fused.rows * game.fused.cols
     print('{0} B={1}: {2:.2f} us per play() = {3:.3e} env-steps/s, {4:.2f} TB/s of '
           'observations ({5:.1f} MB per frame)'.format(
-              'maze {0}x{0}'.format(rows) if rows else 'coin field 6x10', B, dt * 1e6, B / dt,
+              'maze {0}x{0}'.format(rows) if rows > 0 else ('coin field 6x10' if rows == 0 else 'coins + floor in 13 variants'), B, dt * 1e6, B / dt,
               frame / dt / 1e12, frame / 1e6) + '; as update + render pair {:.2f} us'.format(times[1] * 1e6))
 
 
