@@ -514,12 +514,13 @@ WIDE_MAX_STATES = 1 << 24
 WIDE_MAX_DYN = 8
 WIDE_MAX_VARIANTS = 256     # pictures of a scenery that changes (CampxWideSpec.n_variants)
 WIDE_MAX_PIECES = 16        # cells of the scenery that come and go one by one (CampxWideSpec.n_pieces)
-# tracked things up to which pieces stay things of the one-cell tier (tabulate._finish).  A trade:
-# as a mask on the state-table tier such a game's ROLLOUTS are 9-13 % faster at large batches (a
-# walker and two coins on 4x9, B = 262 144: 5.81 -> 6.33 TB/s; tools/bench_pickups.py 0 262144 mask),
-# but the one-cell tier has the one-launch rollouts of small batches (up to 8 192 environments) and
-# deferred rollouts; play() is one kernel on either.
-PIECES_AS_THINGS_MAX = 3
+# tracked things up to which pieces would stay things of the one-cell tier (tabulate._finish): none.
+# A walker and two coins on 4x9 as three things of the cell-indexed tables against the walker and a
+# mask of two pieces on the state-table tier, us per 100-frame rollout (tools/bench_pickups.py 0 <B>
+# own|mask with this bound at 3): B = 1 024 43 / 22, 4 096 50 / 30, 8 192 49 / 41, 16 384 88 / 63,
+# 262 144 813 / 745 - the mask wins at every size, and play() is one kernel on either tier.  (3 keeps
+# such games on the one-cell tier, which alone has deferred rollouts; tests run that road too.)
+PIECES_AS_THINGS_MAX = 0
 
 
 class CampxWideRules(ctypes.Structure):

@@ -1022,9 +1022,10 @@ def _finish(engine, probe, H, W, chars, with_frame, things0, backdrop0, z0, imag
       backdrop_pieces.add((int(c), int(now[c])))
   n_thing_movers = len(split)
   # PIECES or VARIANTS.  A piece tracked as a thing costs the render kernel a trace entry and a patch
-  # slot per piece and row (seven coins and a walker on a 4x9 board: 3.5 TB/s).  A game whose pieces
-  # are few enough for the cell-indexed tables - at most three tracked things, no piece in the
-  # Backdrop - keeps them as things.  Up to sixteen pieces beside at least one ordinary mover are
+  # slot per piece and row (seven coins and a walker on a 4x9 board: 3.5 TB/s).  (A game whose pieces
+  # are few enough for the cell-indexed tables - gamespec.PIECES_AS_THINGS_MAX tracked things, no piece
+  # in the Backdrop - would keep them as things: measured slower at every batch size, so the bound
+  # is 0.)  Up to sixteen pieces beside at least one ordinary mover are
   # handed to the state-table tier as a MASK (CampxWideSpec.n_pieces: which of them show is one
   # 16-bit value per state, `pieces_as_mask` below - everything else about the game stays as the
   # pieces describe it).  More cells than that - day and night over a whole floor - and the SCENERY

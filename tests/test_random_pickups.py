@@ -10,7 +10,6 @@ tiers refuse that PyColab games do.
 The tabulator describes such cells as PIECES (`TracedGame.piece_cell` / `in_backdrop`: one per cell
 a drape ever covers, one per (cell, character) a Backdrop shows beyond its first picture) and hands
 them to the kernels in one of three ways, all three held against the reference's frames here:
-  * three tracked things or fewer, none in the Backdrop: pieces as THINGS of the one-cell tier;
   * up to sixteen pieces beside an ordinary mover: a MASK of the pieces that show, one 16-bit value
     per state (`CampxWideSpec.n_pieces`; the render kernel patches them from one trace entry a row);
   * more cells than that - a switch turns the WHOLE floor: `Tide`, `Seasons` - as VARIANTS of the
@@ -48,14 +47,17 @@ def _gold(k):
 _TRACED = {}
 # (game, road): every game down its own road, some down the others
 ROUTES = ([(k, 'own') for k in range(len(DEFS))] + [(k, 'variants') for k in (3, 5, 10)] +
-          [(k, 'things') for k in (3, 4, 9, 10)])
+          [(k, 'things') for k in (3, 4, 9, 10)] + [(k, 'dense') for k in (0, 1, 7)])
 ROUTE_IDS = ['{}-{}'.format(IDS[k], road) for k, road in ROUTES]
 
 
 def _road(monkeypatch, road):
   """The bounds that decide how pieces reach the kernels, lowered: 'variants' = no mask;
-  'things' = no mask and one picture only (round 6's first form: a tracked thing per piece)."""
+  'things' = no mask and one picture only (round 6's first form: a tracked thing per piece);
+  'dense' = a walker and two coins stay three things of the cell-indexed tables."""
   from campx_amd import gamespec
+  if road == 'dense':            # three tracked things: pieces as things of the one-cell tier's tables
+    monkeypatch.setattr(gamespec, 'PIECES_AS_THINGS_MAX', 3)
   if road in ('variants', 'things'):
     monkeypatch.setattr(gamespec, 'WIDE_MAX_PIECES', 0)
   if road == 'things':
@@ -99,10 +101,6 @@ def test_how_the_pieces_of_each_game_reach_the_kernels():
       n = len(where(ch))
       assert traced.movers == ['A'] + [ch] * n and traced.piece_cell == [None] + where(ch), (k, traced.movers)
       assert len(traced.variants) == 1 and not any(traced.in_backdrop)
-      if n <= 2:                 # three tracked things: the cell-indexed tables
-        assert traced.dense_reason is None and not traced.pieces_as_mask
-        kinds['things'] = kinds.get('things', 0) + 1
-        continue
     elif d['kind'] == 'lamps':
       # one piece per (cell, character) the Backdrop shows beyond its first picture
       lamps = where(':') + where('*')
@@ -142,13 +140,16 @@ def test_how_the_pieces_of_each_game_reach_the_kernels():
     spec.piece_cell[0] = len(d['art']) * W                                # off the board
     assert _hip.lib.campx_wide_spec_validate(ctypes.byref(spec)) == -2
     kinds[d['kind']] = kinds.get(d['kind'], 0) + 1
-  assert kinds == {'things': 3, 'ice': 4, 'coins': 2, 'returning': 1, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
+  assert kinds == {'ice': 4, 'coins': 3, 'returning': 3, 'lamps': 3, 'tide': 2, 'seasons': 1}, kinds
 
 
 def test_past_the_mask_the_variants_then_things_then_a_refusal(monkeypatch):
   """More pieces than the mask has bits (here: the bound lowered to none): the scenery's pictures
   as variants, the several-cell drapes' curtains part of them; more pictures than the kernels hold
   sets of rows for (the bound lowered to one): a tracked thing per piece, up to eight."""
+  _road(monkeypatch, 'dense')      # a walker and two coins: three things of the cell-indexed tables
+  few = _traced(0, 'dense')
+  assert few.movers == ['A', 'o', 'o'] and few.dense_reason is None and not few.pieces_as_mask
   _road(monkeypatch, 'variants')
   coins = _traced(3, 'variants')                                             # seven coins: 51 pictures
   assert coins.movers == ['A'] and coins.piece_cell == [None] and not coins.pieces_as_mask
@@ -249,7 +250,8 @@ def test_hip_path_gives_the_reference_engines_frames(k, road, monkeypatch):
   from oracle.table_replay import StateWalker, TableWalker
   B = 4096
   traced = _traced(k, road)
-  for_road = {'own': None, 'variants': lambda f: f.spec.n_variants > 1, 'things': lambda f: f.spec.n_dyn > 1}[road]
+  for_road = {'own': None, 'variants': lambda f: f.spec.n_variants > 1, 'things': lambda f: f.spec.n_dyn > 1,
+              'dense': lambda f: not hasattr(f, 'spec') or not hasattr(f.spec, 'n_pieces')}[road]
   acts = np.random.RandomState(40 + k).randint(0, 5, size=(60, B)).astype(np.int8)
   game = build(batch=B, device='cuda')
   game.its_showtime()
